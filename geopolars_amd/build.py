@@ -1,0 +1,98 @@
+"""Build libgeopolars_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m geopolars_amd.build [--force] [--verbose]
+
+Objects go to geopolars_amd/csrc/build/, the shared library to geopolars_amd/libgeopolars_hip.so
+(git-ignored, but it travels with the tree to the GPU box).  -ffp-contract=off is part of the
+numerical contract: kernels must round exactly like the CPU semantics they restate
+(see csrc/gpk_device.h); the only fused operations are explicit fma() calls.
+"""
+from __future__ import annotations
+
+import argparse
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, "libgeopolars_hip.so")
+ARCH = "gfx950"
+
+SOURCES = [
+    "gpk_runtime.hip",
+    "gpk_unary.hip",
+    "gpk_join.hip",
+    "gpk_rowwise.hip",
+    "gpk_hull.hip",
+    "gpk_wkb.cpp",
+]
+
+FLAGS = [
+    f"--offload-arch={ARCH}",
+    "-O3",
+    "-std=c++17",
+    "-fPIC",
+    "-ffp-contract=off",
+    "-fno-fast-math",
+    "-Wall",
+    "-Wno-unused-function",
+    "-Wno-unused-result",
+]
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libgeopolars_hip.so cannot be built (there is no CPU fallback)")
+
+
+def _deps_mtime() -> float:
+    m = 0.0
+    for root in (CSRC, os.path.join(HERE, "..", "include")):
+        for fn in os.listdir(root):
+            if fn.endswith((".h", ".hip", ".cpp")):
+                m = max(m, os.path.getmtime(os.path.join(root, fn)))
+    return m
+
+
+def _compile(src: str, verbose: bool) -> str:
+    obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+    lang = ["-x", "hip"] if src.endswith(".hip") else []
+    cmd = [_hipcc(), *FLAGS, *lang, "-c", os.path.join(CSRC, src), "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+    if verbose and r.stderr.strip():
+        print(r.stderr, file=sys.stderr)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _deps_mtime():
+        return LIB
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(lambda s: _compile(s, verbose), srcs))
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--verbose", action="store_true")
+    a = ap.parse_args()
+    print(build(force=a.force, verbose=a.verbose))

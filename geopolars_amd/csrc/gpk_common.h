@@ -1,0 +1,109 @@
+// gpk_common.h — host-side plumbing shared by every translation unit of libgeopolars_hip.so:
+// error reporting across the C ABI, the device-resident GeoArrow view, the per-thread scratch
+// workspace and the launch wrapper that feeds gpk_profile_*.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/geopolars_hip.h"
+
+namespace gpk {
+
+// ---- errors ------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int32_t fail(int32_t code, const char* fmt, ...);
+
+#define GPK_HIP(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess)                                                                    \
+            return ::gpk::fail(_e == hipErrorOutOfMemory ? GPK_ERR_OOM : GPK_ERR_DEVICE,         \
+                               "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,  \
+                               __LINE__);                                                        \
+    } while (0)
+
+#define GPK_TRY(expr)                   \
+    do {                                \
+        int32_t _rc = (expr);           \
+        if (_rc != GPK_OK) return _rc;  \
+    } while (0)
+
+// ---- device-resident GeoArrow view ---------------------------------------------------------
+// What every kernel receives by value.  Polygonal arrays are normalised to three levels
+// (geom -> part -> ring -> coord); a POLYGON array gets an identity geom->part mapping, signalled by
+// part_off == nullptr (geom g owns exactly part g, whose rings are geom_off[g]..geom_off[g+1]).
+struct DevGeo {
+    int32_t type;
+    int64_t n_geoms, n_parts, n_rings, n_coords;
+    const double2* xy;        // interleaved coordinates, one 16-byte load per vertex
+    const int32_t* geom_off;  // level-1 offsets (nullptr for POINT)
+    const int32_t* part_off;  // MULTIPOLYGON only
+    const int32_t* ring_off;  // POLYGON / MULTILINESTRING / MULTIPOLYGON
+    const uint8_t* validity;  // Arrow bitmap or nullptr
+};
+
+}  // namespace gpk
+
+struct gpk_geoarray {
+    gpk::DevGeo d;
+    int device;
+    void* owned[5];  // hipMalloc'ed copies (xy, geom_off, part_off, ring_off, validity) or nullptr
+    int64_t nbytes;
+};
+
+namespace gpk {
+
+// ---- per-thread grow-only scratch ------------------------------------------------------------
+// Steady-state calls do no hipMalloc/hipFree.  One arena per calling thread keeps the ABI
+// re-entrant; a thread that issues calls on several streams must order them itself.
+class Workspace {
+  public:
+    // carve `bytes` (256-byte aligned) out of the arena; grows (and invalidates earlier carves) only
+    // between begin() calls.
+    int32_t begin(size_t total_bytes);
+    void* take(size_t bytes);
+    ~Workspace();
+
+  private:
+    char* base_ = nullptr;
+    size_t cap_ = 0, used_ = 0;
+    int device_ = -1;
+};
+Workspace& workspace();
+
+inline size_t align256(size_t n) { return (n + 255) & ~size_t(255); }
+
+// ---- profiling -----------------------------------------------------------------------------
+bool profiling_enabled();
+void profile_begin(const char* name, hipStream_t s, void** token);
+void profile_end(void* token, hipStream_t s);
+
+// Launch wrapper: every kernel of the library goes through this so bench.py can read per-kernel
+// HIP-event durations on the launching stream (gpk_profile_query).
+#define GPK_LAUNCH(name, kernel, grid, block, shmem, stream, ...)                        \
+    do {                                                                                 \
+        void* _tok = nullptr;                                                            \
+        if (::gpk::profiling_enabled()) ::gpk::profile_begin(name, stream, &_tok);       \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);             \
+        if (_tok) ::gpk::profile_end(_tok, stream);                                      \
+        hipError_t _le = hipGetLastError();                                              \
+        if (_le != hipSuccess)                                                           \
+            return ::gpk::fail(GPK_ERR_DEVICE, "launch of %s failed: %s", name,          \
+                               hipGetErrorString(_le));                                  \
+    } while (0)
+
+int32_t require_device();  // GPK_ERR_DEVICE unless the current device is a gfx950
+int cu_count();
+
+// copy helpers honouring the ABI's memory-space tags
+int32_t copy_out(void* dst, int32_t dst_space, const void* src_dev, size_t bytes, hipStream_t s);
+
+__host__ __device__ inline bool is_polygonal(int32_t t) { return t == GPK_GEOM_POLYGON || t == GPK_GEOM_MULTIPOLYGON; }
+
+}  // namespace gpk

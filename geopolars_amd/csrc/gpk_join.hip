@@ -1,0 +1,379 @@
+// gpk_join.hip — spatial index build + the join refine of geopolars/src/spatial_index.rs:37-143.
+//
+//   gpk_index_build   == SpatialIndex::try_from(&Series)            spatial_index.rs:320-334
+//   gpk_spatial_join  == intersection_candidates_with_other_tree     spatial_index.rs:74-76
+//                        + the exact refine loop                     spatial_index.rs:83-143
+//
+// Point x polygonal rows (the 10M x 1k headline) run as
+//   pip_count  : one lane per point; grid cell -> candidate polygons -> closed bbox test -> exact
+//                winding walk (gpk_device.h).  Emits the per-point hit count, the first hit id and one
+//                64-bit total per work-group.
+//   scan       : single-block exclusive scan of the work-group totals.
+//   pip_write  : block-local scan of the counts + work-group base -> (l, r) pairs in sorted order;
+//                only rows with more than one hit re-run the predicate.
+#include "gpk_device.h"
+#include "gpk_index.h"
+#include "gpk_scan.h"
+
+namespace gpk {
+
+// ================================= index build ==================================================
+__global__ __launch_bounds__(1024) void extent_kernel(const double4* __restrict__ bbox, int64_t n,
+                                                      int gx, int gy, GridParams* __restrict__ out) {
+    __shared__ double red[4][16];
+    double mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const double4 b = bbox[i];
+        if (b.x == b.x) {  // NaN marks an empty geometry
+            mnx = fmin(mnx, b.x);
+            mny = fmin(mny, b.y);
+            mxx = fmax(mxx, b.z);
+            mxy = fmax(mxy, b.w);
+        }
+    }
+    mnx = dev::wave_min(mnx);
+    mny = dev::wave_min(mny);
+    mxx = dev::wave_max(mxx);
+    mxy = dev::wave_max(mxy);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[0][wave] = mnx;
+        red[1][wave] = mny;
+        red[2][wave] = mxx;
+        red[3][wave] = mxy;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) {
+            mnx = fmin(mnx, red[0][w]);
+            mny = fmin(mny, red[1][w]);
+            mxx = fmax(mxx, red[2][w]);
+            mxy = fmax(mxy, red[3][w]);
+        }
+        GridParams g;
+        const bool any = mnx <= mxx;
+        g.x0 = any ? mnx : 0.0;
+        g.y0 = any ? mny : 0.0;
+        const double w = any ? mxx - mnx : 0.0, h = any ? mxy - mny : 0.0;
+        g.inv_w = w > 0.0 ? (double)gx / w : 0.0;
+        g.inv_h = h > 0.0 ? (double)gy / h : 0.0;
+        g.gx = gx;
+        g.gy = gy;
+        *out = g;
+    }
+}
+
+template <bool FILL>
+__global__ void grid_register_kernel(const double4* __restrict__ bbox, int64_t n,
+                                     const GridParams* __restrict__ gp, int32_t* __restrict__ cell_cnt,
+                                     int32_t* __restrict__ items) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const double4 b = bbox[j];
+    if (!(b.x == b.x)) return;
+    const GridParams g = *gp;
+    const int cx0 = dev::cell_of(b.x, g.x0, g.inv_w, g.gx), cx1 = dev::cell_of(b.z, g.x0, g.inv_w, g.gx);
+    const int cy0 = dev::cell_of(b.y, g.y0, g.inv_h, g.gy), cy1 = dev::cell_of(b.w, g.y0, g.inv_h, g.gy);
+    for (int cy = cy0; cy <= cy1; ++cy)
+        for (int cx = cx0; cx <= cx1; ++cx) {
+            const int c = cy * g.gx + cx;
+            const int slot = atomicAdd(&cell_cnt[c], 1);
+            if (FILL) items[slot] = (int32_t)j;
+        }
+}
+
+// ascending ids within each cell -> deterministic candidate order, hence sorted (l, r) output
+__global__ void cell_sort_kernel(const int32_t* __restrict__ cell_off, int64_t n_cells, int32_t* __restrict__ items) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cells) return;
+    const int b = cell_off[c], e = cell_off[c + 1];
+    for (int i = b + 1; i < e; ++i) {
+        const int32_t key = items[i];
+        int k = i - 1;
+        while (k >= b && items[k] > key) {
+            items[k + 1] = items[k];
+            --k;
+        }
+        items[k + 1] = key;
+    }
+}
+
+// ================================= point-in-polygon join =========================================
+constexpr int PIP_BLOCK = 256;
+
+// Visits every right-side row whose closed bbox contains the point, in ascending id order.
+template <typename F>
+__device__ __forceinline__ void for_each_candidate(const IndexView& ix, const GridParams& g, double px,
+                                                   double py, F&& f) {
+    if (!(px == px) || !(py == py)) return;  // empty point
+    const int cx = dev::cell_of(px, g.x0, g.inv_w, g.gx), cy = dev::cell_of(py, g.y0, g.inv_h, g.gy);
+    const int c = cy * g.gx + cx;
+    const int b = ix.cell_off[c], e = ix.cell_off[c + 1];
+    for (int k = b; k < e; ++k) {
+        const int j = ix.items[k];
+        const double4 bb = ix.bbox[j];
+        if (px >= bb.x && px <= bb.z && py >= bb.y && py <= bb.w) f(j);
+    }
+}
+
+__global__ __launch_bounds__(PIP_BLOCK) void pip_count_kernel(DevGeo pts, DevGeo polys, IndexView ix,
+                                                               uint32_t* __restrict__ counts,
+                                                               uint32_t* __restrict__ first_hit,
+                                                               unsigned long long* __restrict__ block_tot) {
+    __shared__ unsigned long long lds[PIP_BLOCK / 64 + 1];
+    const int64_t i = (int64_t)blockIdx.x * PIP_BLOCK + threadIdx.x;
+    uint32_t cnt = 0, first = 0xFFFFFFFFu;
+    if (i < pts.n_geoms && dev::valid_row(pts.validity, i)) {
+        const double2 p = pts.xy[i];
+        const GridParams g = *ix.grid;
+        for_each_candidate(ix, g, p.x, p.y, [&](int j) {
+            if (dev::valid_row(polys.validity, j) && dev::polygonal_hits_point<false>(polys, j, p.x, p.y)) {
+                if (cnt == 0) first = (uint32_t)j;
+                ++cnt;
+            }
+        });
+    }
+    if (i < pts.n_geoms) {
+        counts[i] = cnt;
+        first_hit[i] = first;
+    }
+    unsigned long long tot;
+    (void)dev::block_exclusive_scan<unsigned long long, PIP_BLOCK>((unsigned long long)cnt, lds, &tot);
+    if (threadIdx.x == 0) block_tot[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(PIP_BLOCK) void pip_write_kernel(DevGeo pts, DevGeo polys, IndexView ix,
+                                                               const uint32_t* __restrict__ counts,
+                                                               const uint32_t* __restrict__ first_hit,
+                                                               const unsigned long long* __restrict__ block_off,
+                                                               uint32_t left_base, uint2* __restrict__ pairs,
+                                                               int64_t capacity) {
+    __shared__ unsigned long long lds[PIP_BLOCK / 64 + 1];
+    const int64_t i = (int64_t)blockIdx.x * PIP_BLOCK + threadIdx.x;
+    const uint32_t cnt = i < pts.n_geoms ? counts[i] : 0u;
+    unsigned long long tot;
+    const unsigned long long ex = dev::block_exclusive_scan<unsigned long long, PIP_BLOCK>((unsigned long long)cnt, lds, &tot);
+    if (cnt == 0) return;
+    int64_t o = (int64_t)(block_off[blockIdx.x] + ex);
+    const uint32_t l = left_base + (uint32_t)i;
+    if (cnt == 1) {
+        if (o < capacity) pairs[o] = make_uint2(l, first_hit[i]);
+        return;
+    }
+    const double2 p = pts.xy[i];
+    const GridParams g = *ix.grid;
+    for_each_candidate(ix, g, p.x, p.y, [&](int j) {
+        if (dev::valid_row(polys.validity, j) && dev::polygonal_hits_point<false>(polys, j, p.x, p.y)) {
+            if (o < capacity) pairs[o] = make_uint2(l, (uint32_t)j);
+            ++o;
+        }
+    });
+}
+
+// ================================= host drivers ================================================
+static inline dim3 grid_for(int64_t n, int block) {
+    int64_t b = (n + block - 1) / block;
+    return dim3((unsigned)(b > 0 ? b : 1));
+}
+
+}  // namespace gpk
+
+using namespace gpk;
+
+extern "C" {
+
+int32_t gpk_index_free(gpk_index* idx) {
+    if (!idx) return GPK_OK;
+    for (int i = 0; i < 4; ++i)
+        if (idx->owned[i]) (void)hipFree(idx->owned[i]);
+    delete idx;
+    return GPK_OK;
+}
+
+int32_t gpk_index_nbytes(const gpk_index* idx, int64_t* out_bytes) {
+    if (!idx || !out_bytes) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out_bytes = idx->nbytes;
+    return GPK_OK;
+}
+
+int32_t gpk_index_build(const gpk_geoarray* a, void* stream, gpk_index** out) {
+    if (!a || !out) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = nullptr;
+    GPK_TRY(require_device());
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = a->d.n_geoms;
+
+    gpk_index* ix = new gpk_index;
+    memset(ix, 0, sizeof *ix);
+    ix->device = a->device;
+    ix->n_geoms = n;
+    ix->geom_type = a->d.type;
+
+    // grid resolution: ~2 cells per geometry along each axis of a square layout
+    int gdim = (int)ceil(2.0 * sqrt((double)(n > 0 ? n : 1)));
+    if (gdim < 1) gdim = 1;
+    if (gdim > 2048) gdim = 2048;
+    const int64_t n_cells = (int64_t)gdim * gdim;
+
+    auto cleanup = [&](int32_t rc) {
+        gpk_index_free(ix);
+        return rc;
+    };
+#define IX_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return cleanup(fail(_e == hipErrorOutOfMemory ? GPK_ERR_OOM : GPK_ERR_DEVICE,         \
+                                "%s failed: %s", #expr, hipGetErrorString(_e)));                  \
+    } while (0)
+#define IX_TRY(expr)                             \
+    do {                                         \
+        int32_t _rc = (expr);                    \
+        if (_rc != GPK_OK) return cleanup(_rc);  \
+    } while (0)
+
+    double4* bbox = nullptr;
+    GridParams* grid = nullptr;
+    int32_t* cell_off = nullptr;
+    IX_HIP(hipMalloc((void**)&bbox, sizeof(double4) * (size_t)(n > 0 ? n : 1)));
+    ix->owned[0] = bbox;
+    IX_HIP(hipMalloc((void**)&grid, sizeof(GridParams)));
+    ix->owned[1] = grid;
+    IX_HIP(hipMalloc((void**)&cell_off, sizeof(int32_t) * (size_t)(n_cells + 1)));
+    ix->owned[2] = cell_off;
+
+    // 1. bounding boxes (NodeEnvelope, spatial_index.rs:212-312)
+    IX_TRY(gpk_bounds(a, (double*)bbox, GPK_MEM_DEVICE, stream));
+
+    // 2. extent + grid parameters, all on device
+    GPK_LAUNCH("gpk_index_extent", extent_kernel, dim3(1), dim3(1024), 0, s, bbox, n, gdim, gdim, grid);
+
+    // 3. count, scan, fill, sort
+    const int64_t n_blocks = (n_cells + 255) / 256;
+    IX_TRY(workspace().begin(align256(sizeof(int32_t) * (size_t)(n_cells + 1)) * 2 +
+                             align256(sizeof(unsigned long long) * (size_t)(n_blocks + 1)) + 1024));
+    int32_t* cell_cnt = (int32_t*)workspace().take(sizeof(int32_t) * (size_t)(n_cells + 1));
+    int32_t* cursor = (int32_t*)workspace().take(sizeof(int32_t) * (size_t)(n_cells + 1));
+    unsigned long long* btot = (unsigned long long*)workspace().take(sizeof(unsigned long long) * (size_t)(n_blocks + 1));
+    IX_HIP(hipMemsetAsync(cell_cnt, 0, sizeof(int32_t) * (size_t)(n_cells + 1), s));
+    if (n > 0)
+        GPK_LAUNCH("gpk_index_count", grid_register_kernel<false>, grid_for(n, 256), dim3(256), 0, s, bbox, n, grid, cell_cnt, (int32_t*)nullptr);
+    IX_TRY(exclusive_scan_i32(cell_cnt, n_cells, cell_off, cursor, btot, s));
+    unsigned long long total = 0;
+    IX_HIP(hipMemcpyAsync(&total, btot + n_blocks, sizeof total, hipMemcpyDeviceToHost, s));
+    IX_HIP(hipStreamSynchronize(s));
+    if (total > (unsigned long long)INT32_MAX)
+        return cleanup(fail(GPK_ERR_INVALID_OFFSETS, "spatial index directory overflows i32 (%llu entries)", total));
+    int32_t* items = nullptr;
+    IX_HIP(hipMalloc((void**)&items, sizeof(int32_t) * (size_t)(total > 0 ? total : 1)));
+    ix->owned[3] = items;
+    if (n > 0) {
+        GPK_LAUNCH("gpk_index_fill", grid_register_kernel<true>, grid_for(n, 256), dim3(256), 0, s, bbox, n, grid, cursor, items);
+        GPK_LAUNCH("gpk_index_sort", cell_sort_kernel, grid_for(n_cells, 256), dim3(256), 0, s, cell_off, n_cells, items);
+    }
+    IX_HIP(hipStreamSynchronize(s));  // the workspace may be recycled by the next call on another stream
+#undef IX_HIP
+#undef IX_TRY
+
+    ix->v.bbox = bbox;
+    ix->v.grid = grid;
+    ix->v.cell_off = cell_off;
+    ix->v.items = items;
+    ix->v.gx = gdim;
+    ix->v.gy = gdim;
+    ix->nbytes = (int64_t)(sizeof(double4) * (size_t)n + sizeof(GridParams) + sizeof(int32_t) * (size_t)(n_cells + 1) +
+                           sizeof(int32_t) * (size_t)total);
+    *out = ix;
+    return GPK_OK;
+}
+
+int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right, const gpk_index* right_index,
+                         int32_t predicate, uint32_t left_row_base, uint32_t* out_counts, uint32_t* out_pairs,
+                         int64_t pair_capacity, int64_t* n_pairs, int32_t out_space, void* stream) {
+    if (!left || !right || !n_pairs) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (predicate != GPK_PRED_INTERSECTS && predicate != GPK_PRED_CONTAINS && predicate != GPK_PRED_WITHIN)
+        return fail(GPK_ERR_INVALID_ARGUMENT, "unknown predicate %d", predicate);
+    if (pair_capacity < 0 || (pair_capacity > 0 && !out_pairs))
+        return fail(GPK_ERR_INVALID_ARGUMENT, "pair_capacity without out_pairs");
+    GPK_TRY(require_device());
+    hipStream_t s = (hipStream_t)stream;
+    *n_pairs = 0;
+
+    // dispatch table of spatial_index.rs:89-137
+    const bool pip = left->d.type == GPK_GEOM_POINT && is_polygonal(right->d.type);
+    if (!pip)
+        return fail(GPK_ERR_MISMATCHED_GEOMETRY,
+                    "spatial_join: left type %d x right type %d is not supported by this build",
+                    left->d.type, right->d.type);
+
+    gpk_index* tmp_index = nullptr;
+    if (!right_index) {  // built on the fly, like spatial_index.rs:60-71
+        GPK_TRY(gpk_index_build(right, stream, &tmp_index));
+        right_index = tmp_index;
+    } else if (right_index->n_geoms != right->d.n_geoms) {
+        return fail(GPK_ERR_INVALID_ARGUMENT, "right_index was built over a different array");
+    }
+    auto done = [&](int32_t rc) {
+        if (tmp_index) gpk_index_free(tmp_index);
+        return rc;
+    };
+
+    const int64_t n = left->d.n_geoms;
+    if (n == 0) return done(GPK_OK);
+    const int64_t n_blocks = (n + PIP_BLOCK - 1) / PIP_BLOCK;
+    const bool host_out = out_space != GPK_MEM_DEVICE;
+    const bool want_pairs = pair_capacity > 0;
+    const size_t counts_bytes = sizeof(uint32_t) * (size_t)n;
+    const size_t pairs_bytes = sizeof(uint32_t) * 2 * (size_t)pair_capacity;
+    size_t need = align256(counts_bytes) /*first_hit*/ + align256(sizeof(unsigned long long) * (size_t)(n_blocks + 1)) + 1024;
+    const bool stage_counts = host_out || !out_counts;
+    if (stage_counts) need += align256(counts_bytes);
+    if (host_out && want_pairs) need += align256(pairs_bytes);
+    int32_t rc = workspace().begin(need);
+    if (rc != GPK_OK) return done(rc);
+    uint32_t* first_hit = (uint32_t*)workspace().take(counts_bytes);
+    unsigned long long* btot = (unsigned long long*)workspace().take(sizeof(unsigned long long) * (size_t)(n_blocks + 1));
+    uint32_t* counts_dev = stage_counts ? (uint32_t*)workspace().take(counts_bytes) : out_counts;
+    uint32_t* pairs_dev = want_pairs ? (host_out ? (uint32_t*)workspace().take(pairs_bytes) : out_pairs) : nullptr;
+
+#define J_LAUNCH(...)                          \
+    do {                                       \
+        auto _f = [&]() -> int32_t {           \
+            GPK_LAUNCH(__VA_ARGS__);           \
+            return GPK_OK;                     \
+        };                                     \
+        int32_t _rc = _f();                    \
+        if (_rc != GPK_OK) return done(_rc);   \
+    } while (0)
+
+    J_LAUNCH("gpk_pip_count", pip_count_kernel, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
+             right_index->v, counts_dev, first_hit, btot);
+    J_LAUNCH("gpk_scan_totals", scan_block_totals_kernel, dim3(1), dim3(1024), 0, s, btot, n_blocks, btot + n_blocks);
+    if (want_pairs)
+        J_LAUNCH("gpk_pip_write", pip_write_kernel, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
+                 right_index->v, counts_dev, first_hit, btot, left_row_base, (uint2*)pairs_dev, pair_capacity);
+#undef J_LAUNCH
+
+    unsigned long long total = 0;
+    hipError_t e = hipMemcpyAsync(&total, btot + n_blocks, sizeof total, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return done(fail(GPK_ERR_DEVICE, "spatial_join: %s", hipGetErrorString(e)));
+    *n_pairs = (int64_t)total;
+    if (host_out) {
+        if (out_counts) {
+            rc = copy_out(out_counts, out_space, counts_dev, counts_bytes, s);
+            if (rc != GPK_OK) return done(rc);
+        }
+        if (want_pairs) {
+            const int64_t w = (int64_t)total < pair_capacity ? (int64_t)total : pair_capacity;
+            rc = copy_out(out_pairs, out_space, pairs_dev, sizeof(uint32_t) * 2 * (size_t)w, s);
+            if (rc != GPK_OK) return done(rc);
+        }
+    }
+    if (want_pairs && (int64_t)total > pair_capacity)
+        return done(fail(GPK_ERR_CAPACITY, "spatial_join: %lld pairs but capacity %lld", (long long)total,
+                         (long long)pair_capacity));
+    return done(GPK_OK);
+}
+
+}  // extern "C"

@@ -1,0 +1,527 @@
+// gpk_rowwise.hip — 1-to-1 row-wise binary operators.
+//   distance               geoseries.rs:141-146,248-251 (intended impl ops::distance::euclidean_distance,
+//                          geoseries.rs:250) — geo 0.27 euclidean_distance.rs + geo-types private_utils.rs
+//   contains / within /    north-star additions to the trait; semantics = geo's Contains / Intersects
+//   intersects             as dispatched in spatial_index.rs:89-137
+//
+// Mapping: G lanes (power of two, picked from the mean vertex count of the non-point side) share one
+// row.  Lane k takes segments k, k+G, ... of each ring, so a wave reads 64 consecutive vertices per
+// load instruction (coalesced 16-byte loads) no matter how ragged the rows are; the per-row minimum,
+// winding number and any-hit flags are folded with xor-shuffles inside the group.  That is the
+// "bin on vertex count so lanes in a wave see similar work" rule of the north star applied per call.
+#include <cfloat>
+
+#include "gpk_device.h"
+
+namespace gpk {
+
+// ---- per-segment pieces (IEEE, contraction off: same branch structure as the CPU semantics) -------
+__device__ __forceinline__ double line_segment_distance(double px, double py, double sx, double sy, double ex,
+                                                        double ey) {
+    if (sx == ex && sy == ey) return hypot(sx - px, sy - py);
+    const double dx = ex - sx, dy = ey - sy;
+    const double d2 = dx * dx + dy * dy;
+    const double r = ((px - sx) * dx + (py - sy) * dy) / d2;
+    if (r <= 0.0) return hypot(sx - px, sy - py);
+    if (r >= 1.0) return hypot(ex - px, ey - py);
+    const double q = ((sy - py) * dx - (sx - px) * dy) / d2;
+    return fabs(q) * hypot(dx, dy);
+}
+// geo-types private_utils::line_string_contains_point, one segment (tolerance f64::EPSILON)
+__device__ __forceinline__ bool segment_contains_eps(double px, double py, double sx, double sy, double ex,
+                                                     double ey) {
+    const double dx = ex - sx, dy = ey - sy;
+    if (dx == 0.0 && dy == 0.0) return px == sx && py == sy;
+    if (dy == 0.0) {
+        const double t = (px - sx) / dx;
+        return py == sy && 0.0 <= t && t <= 1.0;
+    }
+    if (dx == 0.0) {
+        const double t = (py - sy) / dy;
+        return px == sx && 0.0 <= t && t <= 1.0;
+    }
+    const double tx = (px - sx) / dx, ty = (py - sy) / dy;
+    return fabs(tx - ty) <= DBL_EPSILON && 0.0 <= tx && tx <= 1.0;
+}
+
+template <int G>
+__device__ __forceinline__ double gmin(double v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) {
+        const double w = __shfl_xor(v, o, 64);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+template <int G>
+__device__ __forceinline__ int gsum(int v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int G>
+__device__ __forceinline__ int gor(int v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v |= __shfl_xor(v, o, 64);
+    return v;
+}
+
+// One coordinate sequence against one point, G lanes cooperating.
+struct SeqAcc {
+    double dmin;    // min line_segment_distance
+    int wn;         // winding number (rings)
+    int on_ring;    // coordinate_position boundary hit
+    int eps_hit;    // line_string_contains_point (vertex equality or eps-collinear)
+};
+template <int G, bool WANT_DIST, bool WANT_POS>
+__device__ __forceinline__ SeqAcc scan_sequence(const double2* __restrict__ xy, int c0, int c1, double px, double py,
+                                                int lane) {
+    SeqAcc a{DBL_MAX, 0, 0, 0};
+    const int n = c1 - c0;
+    if (n == 1) {
+        const double2 p = xy[c0];
+        const int eq = p.x == px && p.y == py;
+        a.on_ring = eq;
+        a.eps_hit = eq;
+    }
+    for (int i = c0 + lane; i + 1 < c1; i += G) {
+        const double2 s = xy[i], e = xy[i + 1];
+        if (WANT_POS) {
+            int wn = 0;
+            a.on_ring |= (int)dev::ring_edge(s.x, s.y, e.x, e.y, px, py, wn);
+            a.wn += wn;
+        }
+        if (WANT_DIST) {
+            const double d = line_segment_distance(px, py, s.x, s.y, e.x, e.y);
+            a.dmin = d < a.dmin ? d : a.dmin;
+            a.eps_hit |= (int)((s.x == px && s.y == py) || (e.x == px && e.y == py) ||
+                               segment_contains_eps(px, py, s.x, s.y, e.x, e.y));
+        }
+    }
+    if (WANT_DIST) {
+        a.dmin = gmin<G>(a.dmin);
+        a.eps_hit = gor<G>(a.eps_hit);
+    }
+    if (WANT_POS) {
+        a.wn = gsum<G>(a.wn);
+        a.on_ring = gor<G>(a.on_ring);
+    }
+    return a;
+}
+__device__ __forceinline__ int pos_of(const SeqAcc& a, int n) {
+    if (n == 0) return dev::POS_OUTSIDE;
+    if (a.on_ring) return dev::POS_BOUNDARY;
+    return a.wn == 0 ? dev::POS_OUTSIDE : dev::POS_INSIDE;
+}
+
+// point_line_string_euclidean_distance
+template <int G>
+__device__ __forceinline__ double point_linestring_distance(const double2* xy, int c0, int c1, double px, double py,
+                                                            int lane) {
+    if (c1 == c0) return 0.0;
+    const SeqAcc a = scan_sequence<G, true, false>(xy, c0, c1, px, py, lane);
+    return a.eps_hit ? 0.0 : a.dmin;
+}
+
+// EuclideanDistance<Point, Polygon>: 0 if the polygon intersects the point (or its exterior is empty);
+// else min over holes (as linestrings) and exterior segments.  Also returns the polygon position.
+template <int G, bool WANT_DIST>
+__device__ __forceinline__ double point_polygon(const DevGeo& b, int r0, int r1, double px, double py, int lane,
+                                                int* pos_out) {
+    *pos_out = dev::POS_OUTSIDE;
+    if (r1 <= r0) return 0.0;
+    const int e0 = b.ring_off[r0], e1 = b.ring_off[r0 + 1];
+    if (e1 == e0) return 0.0;
+    const SeqAcc ext = scan_sequence<G, WANT_DIST, true>(b.xy, e0, e1, px, py, lane);
+    int pos = pos_of(ext, e1 - e0);
+    double dh = DBL_MAX;
+    bool resolved = pos != dev::POS_INSIDE;  // Outside / Boundary: holes do not change the position
+    for (int r = r0 + 1; r < r1; ++r) {
+        const int h0 = b.ring_off[r], h1 = b.ring_off[r + 1];
+        if (!WANT_DIST && resolved) break;
+        const SeqAcc h = scan_sequence<G, WANT_DIST, true>(b.xy, h0, h1, px, py, lane);
+        if (!resolved) {
+            const int ph = pos_of(h, h1 - h0);
+            if (ph == dev::POS_BOUNDARY) {
+                pos = dev::POS_BOUNDARY;
+                resolved = true;
+            } else if (ph == dev::POS_INSIDE) {
+                pos = dev::POS_OUTSIDE;
+                resolved = true;
+            }
+        }
+        if (WANT_DIST) {
+            const double d = (h1 == h0 || h.eps_hit) ? 0.0 : h.dmin;
+            dh = d < dh ? d : dh;
+        }
+    }
+    *pos_out = pos;
+    if (!WANT_DIST) return 0.0;
+    if (pos != dev::POS_OUTSIDE) return 0.0;
+    return dh < ext.dmin ? dh : ext.dmin;
+}
+
+// distance from one point to row j of b
+template <int G>
+__device__ __forceinline__ double point_geom_distance(const DevGeo& b, int64_t j, double px, double py, int lane) {
+    switch (b.type) {
+    case GPK_GEOM_POINT: {
+        const double2 q = b.xy[j];
+        return hypot(px - q.x, py - q.y);
+    }
+    case GPK_GEOM_MULTIPOINT: {
+        double m = DBL_MAX;
+        for (int i = b.geom_off[j] + lane; i < b.geom_off[j + 1]; i += G) {
+            const double2 q = b.xy[i];
+            const double d = hypot(px - q.x, py - q.y);
+            m = d < m ? d : m;
+        }
+        return gmin<G>(m);
+    }
+    case GPK_GEOM_LINESTRING:
+        return point_linestring_distance<G>(b.xy, b.geom_off[j], b.geom_off[j + 1], px, py, lane);
+    case GPK_GEOM_MULTILINESTRING: {
+        double m = DBL_MAX;
+        for (int l = b.geom_off[j]; l < b.geom_off[j + 1]; ++l) {
+            const double d = point_linestring_distance<G>(b.xy, b.ring_off[l], b.ring_off[l + 1], px, py, lane);
+            m = d < m ? d : m;
+        }
+        return m;
+    }
+    default: {
+        int p0, p1;
+        dev::geom_parts(b, j, p0, p1);
+        double m = DBL_MAX;
+        for (int p = p0; p < p1; ++p) {
+            int r0, r1, pos;
+            dev::part_rings(b, p, r0, r1);
+            const double d = point_polygon<G, true>(b, r0, r1, px, py, lane, &pos);
+            m = d < m ? d : m;
+        }
+        return m;
+    }
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void distance_kernel(DevGeo pts, DevGeo other, const uint32_t* __restrict__ rows,
+                                                       double* __restrict__ out) {
+    const int lane = threadIdx.x & (G - 1);
+    const int64_t groups = (int64_t)gridDim.x * (256 / G);
+    for (int64_t i = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G; i < pts.n_geoms; i += groups) {
+        const int64_t j = rows ? (int64_t)rows[i] : i;
+        const double2 p = pts.xy[i];
+        double d;
+        if (!dev::valid_row(pts.validity, i) || !dev::valid_row(other.validity, j) || isnan(p.x) || isnan(p.y))
+            d = NAN;
+        else
+            d = point_geom_distance<G>(other, j, p.x, p.y, lane);
+        if (lane == 0) out[i] = d;
+    }
+}
+
+// ---- row-wise predicates: point x polygonal (cooperative), everything else one lane per row -------------
+template <int G>
+__global__ __launch_bounds__(256) void point_poly_predicate_kernel(DevGeo pts, DevGeo polys,
+                                                                    const uint32_t* __restrict__ rows,
+                                                                    bool rows_index_polys, bool boundary_counts,
+                                                                    uint8_t* __restrict__ out, int64_t n_out) {
+    const int lane = threadIdx.x & (G - 1);
+    const int64_t groups = (int64_t)gridDim.x * (256 / G);
+    for (int64_t i = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G; i < n_out; i += groups) {
+        // row i of the left operand pairs with row rows[i] (or i) of the right operand
+        const int64_t ip = rows_index_polys ? i : (rows ? (int64_t)rows[i] : i);
+        const int64_t jp = rows_index_polys ? (rows ? (int64_t)rows[i] : i) : i;
+        const double2 p = pts.xy[ip];
+        bool hit = false;
+        if (dev::valid_row(pts.validity, ip) && dev::valid_row(polys.validity, jp) && !isnan(p.x) && !isnan(p.y)) {
+            int p0, p1;
+            dev::geom_parts(polys, jp, p0, p1);
+            for (int q = p0; q < p1 && !hit; ++q) {
+                int r0, r1, pos;
+                dev::part_rings(polys, q, r0, r1);
+                (void)point_polygon<G, false>(polys, r0, r1, p.x, p.y, lane, &pos);
+                hit = boundary_counts ? pos != dev::POS_OUTSIDE : pos == dev::POS_INSIDE;
+            }
+        }
+        if (lane == 0) out[i] = hit;
+    }
+}
+
+// Intersects<Line> for Line (geo 0.27 intersects/line.rs)
+__device__ __forceinline__ bool point_in_rect(double px, double py, double ax, double ay, double bx, double by) {
+    return dev::value_in_between(px, ax, bx) && dev::value_in_between(py, ay, by);
+}
+__device__ inline bool line_intersects_line(double2 a0, double2 a1, double2 b0, double2 b1) {
+    if (a0.x == a1.x && a0.y == a1.y)
+        return dev::orient2d(b0.x, b0.y, b1.x, b1.y, a0.x, a0.y) == 0 && point_in_rect(a0.x, a0.y, b0.x, b0.y, b1.x, b1.y);
+    const int c11 = dev::orient2d(a0.x, a0.y, a1.x, a1.y, b0.x, b0.y);
+    const int c12 = dev::orient2d(a0.x, a0.y, a1.x, a1.y, b1.x, b1.y);
+    if (c11 != c12) {
+        const int c21 = dev::orient2d(b0.x, b0.y, b1.x, b1.y, a0.x, a0.y);
+        const int c22 = dev::orient2d(b0.x, b0.y, b1.x, b1.y, a1.x, a1.y);
+        return c21 != c22;
+    }
+    if (c11 == 0)
+        return point_in_rect(b0.x, b0.y, a0.x, a0.y, a1.x, a1.y) || point_in_rect(b1.x, b1.y, a0.x, a0.y, a1.x, a1.y) ||
+               point_in_rect(a1.x, a1.y, b0.x, b0.y, b1.x, b1.y) || point_in_rect(a0.x, a0.y, b0.x, b0.y, b1.x, b1.y);
+    return false;
+}
+
+__device__ inline bool exterior_bbox(const DevGeo& a, int r0, int r1, double4* bb) {
+    if (r1 <= r0) return false;
+    const int c0 = a.ring_off[r0], c1 = a.ring_off[r0 + 1];
+    if (c1 == c0) return false;
+    double mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+    for (int i = c0; i < c1; ++i) {
+        const double2 p = a.xy[i];
+        mnx = p.x < mnx ? p.x : mnx;
+        mny = p.y < mny ? p.y : mny;
+        mxx = p.x > mxx ? p.x : mxx;
+        mxy = p.y > mxy ? p.y : mxy;
+    }
+    *bb = make_double4(mnx, mny, mxx, mxy);
+    return true;
+}
+
+// bbox over ALL rings of a polygon: used only to prune segment pairs (invalid input may have holes
+// poking out of the exterior, and pruning must never change the answer)
+__device__ inline double4 all_rings_bbox(const DevGeo& a, int r0, int r1) {
+    double mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+    for (int i = a.ring_off[r0]; i < a.ring_off[r1]; ++i) {
+        const double2 p = a.xy[i];
+        mnx = p.x < mnx ? p.x : mnx;
+        mny = p.y < mny ? p.y : mny;
+        mxx = p.x > mxx ? p.x : mxx;
+        mxy = p.y > mxy ? p.y : mxy;
+    }
+    return make_double4(mnx, mny, mxx, mxy);
+}
+
+// Intersects<Polygon> for Polygon (geo 0.27 intersects/polygon.rs), one lane.  Equivalent boolean:
+// bboxes not disjoint AND (some ring segment pair intersects OR a vertex of B is not Outside A OR a
+// vertex of A's exterior is not Outside B).
+__device__ inline bool polygon_intersects_polygon(const DevGeo& a, int ar0, int ar1, const DevGeo& b, int br0, int br1) {
+    double4 ba, bb;
+    if (!exterior_bbox(a, ar0, ar1, &ba) || !exterior_bbox(b, br0, br1, &bb)) return false;
+    if (ba.z < bb.x || ba.w < bb.y || bb.z < ba.x || bb.w < ba.y) return false;
+    const double4 fa = all_rings_bbox(a, ar0, ar1);
+    for (int rb = br0; rb < br1; ++rb) {
+        const int b0 = b.ring_off[rb], b1 = b.ring_off[rb + 1];
+        for (int j = b0; j + 1 < b1; ++j) {
+            const double2 q0 = b.xy[j], q1 = b.xy[j + 1];
+            // cheap reject of this segment against A's bbox keeps the O(n*m) loop short in practice
+            const double qlx = fmin(q0.x, q1.x), qhx = fmax(q0.x, q1.x), qly = fmin(q0.y, q1.y), qhy = fmax(q0.y, q1.y);
+            if (qhx < fa.x || qlx > fa.z || qhy < fa.y || qly > fa.w) continue;
+            for (int ra = ar0; ra < ar1; ++ra) {
+                const int a0 = a.ring_off[ra], a1 = a.ring_off[ra + 1];
+                for (int i = a0; i + 1 < a1; ++i) {
+                    const double2 p0 = a.xy[i], p1 = a.xy[i + 1];
+                    if (fmax(p0.x, p1.x) < qlx || fmin(p0.x, p1.x) > qhx || fmax(p0.y, p1.y) < qly || fmin(p0.y, p1.y) > qhy)
+                        continue;  // disjoint segment boxes cannot intersect (closed test)
+                    if (line_intersects_line(p0, p1, q0, q1)) return true;
+                }
+            }
+        }
+    }
+    // no boundary crossing: containment of one in the other (every vertex is tested, as upstream does)
+    for (int rb = br0; rb < br1; ++rb) {
+        const int b0 = b.ring_off[rb], b1 = b.ring_off[rb + 1];
+        for (int j = b0; j < b1; ++j) {
+            const double2 q = b.xy[j];
+            if (dev::polygon_pos(a, ar0, ar1, q.x, q.y) != dev::POS_OUTSIDE) return true;
+        }
+    }
+    {
+        const int a0 = a.ring_off[ar0], a1 = a.ring_off[ar0 + 1];
+        for (int i = a0; i < a1; ++i) {
+            const double2 p = a.xy[i];
+            if (dev::polygon_pos(b, br0, br1, p.x, p.y) != dev::POS_OUTSIDE) return true;
+        }
+    }
+    return false;
+}
+
+__device__ inline bool polygonal_intersects_polygonal(const DevGeo& a, int64_t ia, const DevGeo& b, int64_t ib) {
+    int a0, a1, b0, b1;
+    dev::geom_parts(a, ia, a0, a1);
+    dev::geom_parts(b, ib, b0, b1);
+    for (int p = a0; p < a1; ++p) {
+        int ar0, ar1;
+        dev::part_rings(a, p, ar0, ar1);
+        for (int q = b0; q < b1; ++q) {
+            int br0, br1;
+            dev::part_rings(b, q, br0, br1);
+            if (polygon_intersects_polygon(a, ar0, ar1, b, br0, br1)) return true;
+        }
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(256) void poly_poly_intersects_kernel(DevGeo a, DevGeo b, const uint32_t* __restrict__ rows,
+                                                                    uint8_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_geoms) return;
+    const int64_t j = rows ? (int64_t)rows[i] : i;
+    bool hit = false;
+    if (dev::valid_row(a.validity, i) && dev::valid_row(b.validity, j)) hit = polygonal_intersects_polygonal(a, i, b, j);
+    out[i] = hit;
+}
+
+__global__ void point_point_equal_kernel(DevGeo a, DevGeo b, const uint32_t* __restrict__ rows, uint8_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_geoms) return;
+    const int64_t j = rows ? (int64_t)rows[i] : i;
+    const double2 p = a.xy[i], q = b.xy[j];
+    out[i] = dev::valid_row(a.validity, i) && dev::valid_row(b.validity, j) && p.x == q.x && p.y == q.y;
+}
+
+__global__ void fill_u8_kernel(uint8_t* out, int64_t n, uint8_t v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = v;
+}
+
+// ---- host side -----------------------------------------------------------------------------------
+static int pick_group_rows(const DevGeo& g) {
+    const double mean = g.n_geoms > 0 ? (double)g.n_coords / (double)g.n_geoms : 1.0;
+    int G = 1;
+    while (G < 64 && G * 2 <= mean) G <<= 1;  // largest power of two <= mean vertex count
+    return G;
+}
+static dim3 coop_grid(int64_t n_rows, int G) {
+    const int64_t per_block = 256 / G;
+    int64_t blocks = (n_rows + per_block - 1) / per_block;
+    const int64_t cap = (int64_t)cu_count() * 32;
+    if (blocks > cap) blocks = cap;
+    return dim3((unsigned)(blocks > 0 ? blocks : 1));
+}
+
+}  // namespace gpk
+
+using namespace gpk;
+
+extern "C" {
+
+int32_t gpk_distance_rowwise(const gpk_geoarray* a, const gpk_geoarray* b, const uint32_t* b_rows, double* out,
+                             int32_t out_space, void* stream) {
+    if (!a || !b || !out) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
+    GPK_TRY(require_device());
+    hipStream_t s = (hipStream_t)stream;
+    const gpk_geoarray *pts = a, *other = b;
+    if (a->d.type != GPK_GEOM_POINT) {
+        if (b->d.type != GPK_GEOM_POINT)
+            return fail(GPK_ERR_MISMATCHED_GEOMETRY, "distance: one side must be a POINT array (found types %d, %d)",
+                        a->d.type, b->d.type);
+        if (b_rows) return fail(GPK_ERR_INVALID_ARGUMENT, "distance: b_rows requires the POINT array on the left");
+        pts = b;
+        other = a;
+    }
+    if (!b_rows && a->d.n_geoms != b->d.n_geoms)
+        return fail(GPK_ERR_INVALID_ARGUMENT, "distance: row counts differ (%lld vs %lld)", (long long)a->d.n_geoms,
+                    (long long)b->d.n_geoms);
+    const int64_t n = pts->d.n_geoms;
+    if (n == 0) return GPK_OK;
+    const size_t ob = sizeof(double) * (size_t)n;
+    const bool host_out = out_space != GPK_MEM_DEVICE;
+    const uint32_t* rows_dev = b_rows;
+    double* out_dev = out;
+    if (host_out) {
+        GPK_TRY(workspace().begin(align256(ob) + (b_rows ? align256(sizeof(uint32_t) * (size_t)n) : 0) + 512));
+        out_dev = (double*)workspace().take(ob);
+        if (b_rows) {
+            uint32_t* r = (uint32_t*)workspace().take(sizeof(uint32_t) * (size_t)n);
+            GPK_HIP(hipMemcpyAsync(r, b_rows, sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, s));
+            rows_dev = r;
+        }
+    }
+    const int G = other->d.type == GPK_GEOM_POINT ? 1 : pick_group_rows(other->d);
+    const dim3 grid = coop_grid(n, G), block(256);
+    switch (G) {
+    case 1: GPK_LAUNCH("gpk_distance", distance_kernel<1>, grid, block, 0, s, pts->d, other->d, rows_dev, out_dev); break;
+    case 2: GPK_LAUNCH("gpk_distance", distance_kernel<2>, grid, block, 0, s, pts->d, other->d, rows_dev, out_dev); break;
+    case 4: GPK_LAUNCH("gpk_distance", distance_kernel<4>, grid, block, 0, s, pts->d, other->d, rows_dev, out_dev); break;
+    case 8: GPK_LAUNCH("gpk_distance", distance_kernel<8>, grid, block, 0, s, pts->d, other->d, rows_dev, out_dev); break;
+    case 16: GPK_LAUNCH("gpk_distance", distance_kernel<16>, grid, block, 0, s, pts->d, other->d, rows_dev, out_dev); break;
+    case 32: GPK_LAUNCH("gpk_distance", distance_kernel<32>, grid, block, 0, s, pts->d, other->d, rows_dev, out_dev); break;
+    default: GPK_LAUNCH("gpk_distance", distance_kernel<64>, grid, block, 0, s, pts->d, other->d, rows_dev, out_dev); break;
+    }
+    return copy_out(out, out_space, out_dev, ob, s);
+}
+
+int32_t gpk_predicate_rowwise(const gpk_geoarray* a, const gpk_geoarray* b, const uint32_t* b_rows, int32_t predicate,
+                              uint8_t* out, int32_t out_space, void* stream) {
+    if (!a || !b || !out) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (predicate != GPK_PRED_INTERSECTS && predicate != GPK_PRED_CONTAINS && predicate != GPK_PRED_WITHIN)
+        return fail(GPK_ERR_INVALID_ARGUMENT, "unknown predicate %d", predicate);
+    GPK_TRY(require_device());
+    hipStream_t s = (hipStream_t)stream;
+    if (!b_rows && a->d.n_geoms != b->d.n_geoms)
+        return fail(GPK_ERR_INVALID_ARGUMENT, "predicate: row counts differ (%lld vs %lld)", (long long)a->d.n_geoms,
+                    (long long)b->d.n_geoms);
+    const int64_t n = a->d.n_geoms;
+    if (n == 0) return GPK_OK;
+    const bool host_out = out_space != GPK_MEM_DEVICE;
+    const uint32_t* rows_dev = b_rows;
+    uint8_t* out_dev = out;
+    if (host_out) {
+        GPK_TRY(workspace().begin(align256((size_t)n) + (b_rows ? align256(sizeof(uint32_t) * (size_t)n) : 0) + 512));
+        out_dev = (uint8_t*)workspace().take((size_t)n);
+        if (b_rows) {
+            uint32_t* r = (uint32_t*)workspace().take(sizeof(uint32_t) * (size_t)n);
+            GPK_HIP(hipMemcpyAsync(r, b_rows, sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, s));
+            rows_dev = r;
+        }
+    }
+    const int ta = a->d.type, tb = b->d.type;
+    const dim3 block(256);
+    const dim3 flat((unsigned)((n + 255) / 256));
+
+    // contains(a, b): a polygonal, b point -> Inside.  within(a, b) == contains(b, a): a point, b polygonal.
+    // intersects: either order, boundary counts.
+    const bool a_poly_b_pt = is_polygonal(ta) && tb == GPK_GEOM_POINT;
+    const bool a_pt_b_poly = ta == GPK_GEOM_POINT && is_polygonal(tb);
+    bool run_pp = false, boundary = false, rows_index_polys = false;
+    const gpk_geoarray *pts = nullptr, *polys = nullptr;
+    if (predicate == GPK_PRED_INTERSECTS && (a_poly_b_pt || a_pt_b_poly)) {
+        run_pp = true;
+        boundary = true;
+    } else if (predicate == GPK_PRED_CONTAINS && a_poly_b_pt) {
+        run_pp = true;
+    } else if (predicate == GPK_PRED_WITHIN && a_pt_b_poly) {
+        run_pp = true;
+    }
+    if (run_pp) {
+        pts = a_pt_b_poly ? a : b;
+        polys = a_pt_b_poly ? b : a;
+        rows_index_polys = a_pt_b_poly;  // b_rows indexes b; b is the polygon side when a is the point side
+        const int G = pick_group_rows(polys->d);
+        const dim3 grid = coop_grid(n, G);
+#define PP(GG)                                                                                                       \
+    GPK_LAUNCH("gpk_point_poly_predicate", point_poly_predicate_kernel<GG>, grid, block, 0, s, pts->d, polys->d,    \
+               rows_dev, rows_index_polys, boundary, out_dev, n)
+        switch (G) {
+        case 1: PP(1); break;
+        case 2: PP(2); break;
+        case 4: PP(4); break;
+        case 8: PP(8); break;
+        case 16: PP(16); break;
+        case 32: PP(32); break;
+        default: PP(64); break;
+        }
+#undef PP
+    } else if (predicate == GPK_PRED_INTERSECTS && is_polygonal(ta) && is_polygonal(tb)) {
+        GPK_LAUNCH("gpk_poly_poly_intersects", poly_poly_intersects_kernel, flat, block, 0, s, a->d, b->d, rows_dev, out_dev);
+    } else if (ta == GPK_GEOM_POINT && tb == GPK_GEOM_POINT) {
+        GPK_LAUNCH("gpk_point_point_equal", point_point_equal_kernel, flat, block, 0, s, a->d, b->d, rows_dev, out_dev);
+    } else if ((predicate == GPK_PRED_CONTAINS && is_polygonal(ta) && is_polygonal(tb)) ||
+               (predicate == GPK_PRED_WITHIN && is_polygonal(ta) && is_polygonal(tb))) {
+        return fail(GPK_ERR_MISMATCHED_GEOMETRY,
+                    "contains/within(polygon, polygon) is a DE-9IM relate upstream and is not implemented");
+    } else {
+        // combinations the reference's dispatch table maps to `false` (spatial_index.rs:136)
+        GPK_LAUNCH("gpk_fill_u8", fill_u8_kernel, flat, block, 0, s, out_dev, n, (uint8_t)0);
+    }
+    return copy_out(out, out_space, out_dev, (size_t)n, s);
+}
+
+}  // extern "C"

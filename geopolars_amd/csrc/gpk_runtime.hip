@@ -1,0 +1,336 @@
+// gpk_runtime.hip — library plumbing behind the C ABI: thread-local error text, the per-thread
+// scratch arena, HIP-event profiling of every launch, device checks and the "copy once to HBM"
+// upload (include/geopolars_hip.h: gpk_geoarray_upload replaces the per-op row decode of
+// geopolars/geopolars-geo/src/util.rs:27-37).
+#include <mutex>
+#include <vector>
+
+#include "gpk_common.h"
+
+namespace gpk {
+
+static thread_local char g_err[512] = {0};
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+int32_t fail(int32_t code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// ---- workspace ---------------------------------------------------------------------------------
+int32_t Workspace::begin(size_t total) {
+    int dev = 0;
+    GPK_HIP(hipGetDevice(&dev));
+    total = align256(total) + 256;
+    if (dev != device_ || total > cap_) {
+        if (base_) {
+            GPK_HIP(hipDeviceSynchronize());  // earlier launches may still read the old arena
+            (void)hipFree(base_);
+            base_ = nullptr;
+            cap_ = 0;
+        }
+        size_t want = total + total / 4;
+        hipError_t e = hipMalloc((void**)&base_, want);
+        if (e != hipSuccess) {
+            want = total;
+            e = hipMalloc((void**)&base_, want);
+        }
+        if (e != hipSuccess) {
+            base_ = nullptr;
+            return fail(GPK_ERR_OOM, "workspace hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        }
+        cap_ = want;
+        device_ = dev;
+    }
+    used_ = 0;
+    return GPK_OK;
+}
+void* Workspace::take(size_t bytes) {
+    bytes = align256(bytes);
+    if (used_ + bytes > cap_) return nullptr;
+    void* p = base_ + used_;
+    used_ += bytes;
+    return p;
+}
+Workspace::~Workspace() {
+    // process teardown: the HIP runtime may already be gone; leak rather than crash.
+}
+Workspace& workspace() {
+    static thread_local Workspace ws;
+    return ws;
+}
+
+// ---- profiling -----------------------------------------------------------------------------
+struct ProfRec {
+    std::string name;
+    hipEvent_t a, b;
+};
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfRec*> g_prof;
+
+bool profiling_enabled() { return g_prof_on; }
+void profile_begin(const char* name, hipStream_t s, void** token) {
+    ProfRec* r = new ProfRec;
+    r->name = name;
+    if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess) {
+        delete r;
+        *token = nullptr;
+        return;
+    }
+    (void)hipEventRecord(r->a, s);
+    *token = r;
+}
+void profile_end(void* token, hipStream_t s) {
+    ProfRec* r = (ProfRec*)token;
+    (void)hipEventRecord(r->b, s);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back(r);
+}
+
+// ---- device --------------------------------------------------------------------------------
+static thread_local int g_checked_dev = -1;
+static thread_local int g_cus = 0;
+
+int32_t require_device() {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess)
+        return fail(GPK_ERR_DEVICE, "no HIP device: %s (libgeopolars_hip has no CPU fallback)",
+                    hipGetErrorString(e));
+    if (dev == g_checked_dev) return GPK_OK;
+    hipDeviceProp_t p;
+    GPK_HIP(hipGetDeviceProperties(&p, dev));
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0)
+        return fail(GPK_ERR_DEVICE, "device %d is %s; this library is built for gfx950 only", dev,
+                    p.gcnArchName);
+    g_checked_dev = dev;
+    g_cus = p.multiProcessorCount;
+    return GPK_OK;
+}
+int cu_count() { return g_cus > 0 ? g_cus : 256; }
+
+int32_t copy_out(void* dst, int32_t dst_space, const void* src_dev, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return GPK_OK;
+    if (dst_space == GPK_MEM_DEVICE) {
+        if (dst != src_dev) GPK_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToDevice, s));
+        return GPK_OK;
+    }
+    GPK_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, s));
+    GPK_HIP(hipStreamSynchronize(s));
+    return GPK_OK;
+}
+
+}  // namespace gpk
+
+using namespace gpk;
+
+extern "C" {
+
+const char* gpk_version(void) { return "geopolars_hip 0.1.0 (gfx950)"; }
+
+int32_t gpk_last_error(char* buf, size_t cap) {
+    if (!buf || cap == 0) return GPK_ERR_INVALID_ARGUMENT;
+    strncpy(buf, g_err, cap - 1);
+    buf[cap - 1] = 0;
+    return GPK_OK;
+}
+
+int32_t gpk_device_count(int32_t* out_n) {
+    if (!out_n) return fail(GPK_ERR_INVALID_ARGUMENT, "out_n is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *out_n = 0;
+        return fail(GPK_ERR_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *out_n = n;
+    return GPK_OK;
+}
+
+int32_t gpk_device_info(char* name_buf, size_t cap, int32_t* out_cus) {
+    GPK_TRY(require_device());
+    int dev = 0;
+    GPK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    GPK_HIP(hipGetDeviceProperties(&p, dev));
+    if (name_buf && cap) snprintf(name_buf, cap, "%s (%s)", p.name, p.gcnArchName);
+    if (out_cus) *out_cus = p.multiProcessorCount;
+    return GPK_OK;
+}
+
+// ---- upload ----------------------------------------------------------------------------------
+static int32_t validate_desc(const gpk_geoarrow_desc* d) {
+    if (!d) return fail(GPK_ERR_INVALID_ARGUMENT, "desc is NULL");
+    if (d->n_geoms < 0 || d->n_coords < 0)
+        return fail(GPK_ERR_INVALID_ARGUMENT, "negative length");
+    if (d->n_coords > INT32_MAX || d->n_geoms > INT32_MAX)
+        return fail(GPK_ERR_INVALID_OFFSETS, "arrays beyond i32 offsets are not supported (split the chunk)");
+    if (d->n_coords > 0 && !d->xy) return fail(GPK_ERR_INVALID_ARGUMENT, "xy is NULL");
+    switch (d->geom_type) {
+    case GPK_GEOM_POINT:
+        if (d->n_coords != d->n_geoms)
+            return fail(GPK_ERR_INVALID_OFFSETS, "POINT array: n_coords != n_geoms");
+        break;
+    case GPK_GEOM_LINESTRING:
+    case GPK_GEOM_MULTIPOINT:
+        if (!d->geom_offsets) return fail(GPK_ERR_INVALID_OFFSETS, "geom_offsets is NULL");
+        break;
+    case GPK_GEOM_POLYGON:
+    case GPK_GEOM_MULTILINESTRING:
+        if (!d->geom_offsets || !d->ring_offsets)
+            return fail(GPK_ERR_INVALID_OFFSETS, "geom_offsets / ring_offsets is NULL");
+        break;
+    case GPK_GEOM_MULTIPOLYGON:
+        if (!d->geom_offsets || !d->ring_offsets || !d->part_offsets)
+            return fail(GPK_ERR_INVALID_OFFSETS, "geom/part/ring offsets must all be given");
+        break;
+    default:
+        return fail(GPK_ERR_MISMATCHED_GEOMETRY, "unsupported geometry type id %d", d->geom_type);
+    }
+    return GPK_OK;
+}
+
+// host-side monotonicity / range check of one offsets level (only for host descriptors; device
+// descriptors are trusted, as a borrowed Arrow buffer would be)
+static int32_t check_offsets(const int32_t* off, int64_t n, int64_t child_len, const char* what) {
+    if (n == 0) return GPK_OK;
+    if (off[0] != 0) return fail(GPK_ERR_INVALID_OFFSETS, "%s[0] != 0", what);
+    for (int64_t i = 0; i < n; ++i)
+        if (off[i + 1] < off[i]) return fail(GPK_ERR_INVALID_OFFSETS, "%s not monotone at %lld", what, (long long)i);
+    if (off[n] != child_len)
+        return fail(GPK_ERR_INVALID_OFFSETS, "%s[last] = %d but child length is %lld", what, off[n],
+                    (long long)child_len);
+    return GPK_OK;
+}
+
+int32_t gpk_geoarray_upload(const gpk_geoarrow_desc* d, void* stream, gpk_geoarray** out) {
+    if (!out) return fail(GPK_ERR_INVALID_ARGUMENT, "out is NULL");
+    *out = nullptr;
+    GPK_TRY(validate_desc(d));
+    GPK_TRY(require_device());
+    hipStream_t s = (hipStream_t)stream;
+
+    const int t = d->geom_type;
+    const bool has_ring = t == GPK_GEOM_POLYGON || t == GPK_GEOM_MULTILINESTRING || t == GPK_GEOM_MULTIPOLYGON;
+    const bool has_part = t == GPK_GEOM_MULTIPOLYGON;
+    const int64_t n_rings = has_ring ? d->n_rings : 0;
+    const int64_t n_parts = has_part ? d->n_parts : 0;
+
+    if (d->mem_space == GPK_MEM_HOST) {
+        if (t == GPK_GEOM_LINESTRING || t == GPK_GEOM_MULTIPOINT)
+            GPK_TRY(check_offsets(d->geom_offsets, d->n_geoms, d->n_coords, "geom_offsets"));
+        if (t == GPK_GEOM_POLYGON || t == GPK_GEOM_MULTILINESTRING) {
+            GPK_TRY(check_offsets(d->geom_offsets, d->n_geoms, n_rings, "geom_offsets"));
+            GPK_TRY(check_offsets(d->ring_offsets, n_rings, d->n_coords, "ring_offsets"));
+        }
+        if (t == GPK_GEOM_MULTIPOLYGON) {
+            GPK_TRY(check_offsets(d->geom_offsets, d->n_geoms, n_parts, "geom_offsets"));
+            GPK_TRY(check_offsets(d->part_offsets, n_parts, n_rings, "part_offsets"));
+            GPK_TRY(check_offsets(d->ring_offsets, n_rings, d->n_coords, "ring_offsets"));
+        }
+    }
+
+    gpk_geoarray* a = new gpk_geoarray;
+    memset(a, 0, sizeof *a);
+    GPK_HIP(hipGetDevice(&a->device));
+    a->d.type = t;
+    a->d.n_geoms = d->n_geoms;
+    a->d.n_parts = has_part ? n_parts : (is_polygonal(t) ? d->n_geoms : 0);
+    a->d.n_rings = n_rings;
+    a->d.n_coords = d->n_coords;
+
+    struct Buf {
+        const void* src;
+        size_t bytes;
+        const void** dst;
+    } bufs[5] = {
+        {d->xy, sizeof(double) * 2 * (size_t)d->n_coords, (const void**)&a->d.xy},
+        {t != GPK_GEOM_POINT ? d->geom_offsets : nullptr, sizeof(int32_t) * (size_t)(d->n_geoms + 1),
+         (const void**)&a->d.geom_off},
+        {has_part ? d->part_offsets : nullptr, sizeof(int32_t) * (size_t)(n_parts + 1),
+         (const void**)&a->d.part_off},
+        {has_ring ? d->ring_offsets : nullptr, sizeof(int32_t) * (size_t)(n_rings + 1),
+         (const void**)&a->d.ring_off},
+        {d->validity, (size_t)((d->n_geoms + 7) / 8), (const void**)&a->d.validity},
+    };
+    for (int i = 0; i < 5; ++i) {
+        *bufs[i].dst = nullptr;
+        if (!bufs[i].src || bufs[i].bytes == 0) continue;
+        a->nbytes += (int64_t)bufs[i].bytes;
+        if (d->mem_space == GPK_MEM_DEVICE) {
+            *bufs[i].dst = bufs[i].src;  // borrowed: the caller keeps it alive, as with Arrow buffers
+            continue;
+        }
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, bufs[i].bytes);
+        if (e == hipSuccess) e = hipMemcpyAsync(p, bufs[i].src, bufs[i].bytes, hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) {
+            if (p) (void)hipFree(p);
+            gpk_geoarray_free(a);
+            return fail(e == hipErrorOutOfMemory ? GPK_ERR_OOM : GPK_ERR_DEVICE, "upload: %s",
+                        hipGetErrorString(e));
+        }
+        a->owned[i] = p;
+        *bufs[i].dst = p;
+    }
+    if (d->mem_space == GPK_MEM_HOST) GPK_HIP(hipStreamSynchronize(s));  // host buffers are only borrowed for the call
+    *out = a;
+    return GPK_OK;
+}
+
+int32_t gpk_geoarray_free(gpk_geoarray* a) {
+    if (!a) return GPK_OK;
+    for (int i = 0; i < 5; ++i)
+        if (a->owned[i]) (void)hipFree(a->owned[i]);
+    delete a;
+    return GPK_OK;
+}
+
+int32_t gpk_geoarray_nbytes(const gpk_geoarray* a, int64_t* out_bytes) {
+    if (!a || !out_bytes) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out_bytes = a->nbytes;
+    return GPK_OK;
+}
+
+// ---- profiling ABI ---------------------------------------------------------------------------
+int32_t gpk_profile_enable(int32_t on) {
+    g_prof_on = on != 0;
+    return GPK_OK;
+}
+int32_t gpk_profile_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (ProfRec* r : g_prof) {
+        (void)hipEventDestroy(r->a);
+        (void)hipEventDestroy(r->b);
+        delete r;
+    }
+    g_prof.clear();
+    return GPK_OK;
+}
+int32_t gpk_profile_query(const char* substr, double* out_ms, int64_t* out_launches) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    double ms = 0.0;
+    int64_t n = 0;
+    for (ProfRec* r : g_prof) {
+        if (substr && *substr && r->name.find(substr) == std::string::npos) continue;
+        if (hipEventSynchronize(r->b) != hipSuccess) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r->a, r->b) != hipSuccess) continue;
+        ms += t;
+        ++n;
+    }
+    if (out_ms) *out_ms = ms;
+    if (out_launches) *out_launches = n;
+    return GPK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,572 @@
+// gpk_unary.hip — streaming (HBM-bound) unary operators of the GeoSeries surface:
+//   area / signed_area   geoseries.rs:14-16,188-190   (geo 0.27 area.rs semantics)
+//   centroid             geoseries.rs:18-21,192-194   (geo 0.27 centroid.rs semantics)
+//   bounds / envelope    geoseries.rs:28-33,200-202   (geo 0.27 bounding_rect.rs semantics)
+//   euclidean_length     geoseries.rs:35-41
+//   affine_transform     geoseries.rs:11-12,184-186   (AffineTransform::apply, no FMA)
+//
+// Layout: every reduction is two stages.  Stage 1 streams the coordinate buffer once (16 B per
+// vertex, double2 loads) with G lanes cooperating on one coordinate sequence (ring / linestring),
+// G a power of two picked from the mean sequence length so that the 64 lanes of a wave cover 64/G
+// neighbouring sequences = one contiguous stretch of the buffer.  Per-sequence partials land in a
+// small stats array (8 B x K per sequence).  Stage 2 is one thread per geometry folding its rings
+// with the polygon / multipolygon rules.  Reduction order is fixed (xor-tree), so results are
+// bit-reproducible run to run.
+#include "gpk_device.h"
+
+namespace gpk {
+
+enum : int {
+    ST_AREA2 = 0,  // twice the signed ring area (shifted by the first coordinate)
+    ST_ACX = 1,    // sum (ex+sx)*cross  (shifted)
+    ST_ACY = 2,
+    ST_LEN = 3,  // sum of segment lengths
+    ST_LMX = 4,  // sum of midpoint * length
+    ST_LMY = 5,
+    ST_MINX = 6,
+    ST_MINY = 7,
+    ST_MAXX = 8,
+    ST_MAXY = 9,
+    ST_SUMX = 10,  // plain coordinate sums (MULTIPOINT centroid)
+    ST_SUMY = 11,
+    ST_COUNT = 12
+};
+constexpr unsigned M_AREA = 1u << 0, M_CENT = 1u << 1, M_LEN = 1u << 2, M_BBOX = 1u << 3, M_SUM = 1u << 4;
+
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int G>
+__device__ __forceinline__ double group_min(double v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) {
+        const double w = __shfl_xor(v, o, 64);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+template <int G>
+__device__ __forceinline__ double group_max(double v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) {
+        const double w = __shfl_xor(v, o, 64);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
+// Stage 1: per-sequence partials.  stats is [ST_COUNT][n_seq] (SoA so stage 2 reads are coalesced).
+template <int G, unsigned MASK>
+__global__ __launch_bounds__(256) void seq_stats_kernel(const double2* __restrict__ xy,
+                                                        const int32_t* __restrict__ seq_off,
+                                                        int64_t n_seq, double* __restrict__ stats) {
+    const int lane = threadIdx.x & (G - 1);
+    const int64_t groups_per_grid = (int64_t)gridDim.x * (blockDim.x / G);
+    for (int64_t s = (int64_t)blockIdx.x * (blockDim.x / G) + threadIdx.x / G; s < n_seq;
+         s += groups_per_grid) {
+        const int c0 = seq_off[s], c1 = seq_off[s + 1];
+        const int n = c1 - c0;
+        double a2 = 0, acx = 0, acy = 0, len = 0, lmx = 0, lmy = 0, sx_ = 0, sy_ = 0;
+        double mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+        double2 first = make_double2(0, 0), last = make_double2(0, 0);
+        if (n > 0) {
+            first = xy[c0];
+            last = xy[c1 - 1];
+        }
+        // twice_signed_ring_area: < 3 coords or open -> 0 (area.rs); centroid's add_ring uses the same
+        const bool closed_ring = n >= 3 && first.x == last.x && first.y == last.y;
+        for (int i = c0 + lane; i < c1; i += G) {
+            const double2 p = xy[i];
+            if (MASK & M_BBOX) {
+                mnx = p.x < mnx ? p.x : mnx;
+                mny = p.y < mny ? p.y : mny;
+                mxx = p.x > mxx ? p.x : mxx;
+                mxy = p.y > mxy ? p.y : mxy;
+            }
+            if (MASK & M_SUM) {
+                sx_ += p.x;
+                sy_ += p.y;
+            }
+            if ((MASK & (M_AREA | M_CENT | M_LEN)) && i + 1 < c1) {
+                const double2 q = xy[i + 1];
+                if ((MASK & (M_AREA | M_CENT)) && closed_ring) {
+                    const double sx = p.x - first.x, sy = p.y - first.y;
+                    const double ex = q.x - first.x, ey = q.y - first.y;
+                    const double cr = sx * ey - sy * ex;
+                    a2 += cr;
+                    if (MASK & M_CENT) {
+                        acx += (ex + sx) * cr;
+                        acy += (ey + sy) * cr;
+                    }
+                }
+                if (MASK & (M_LEN | M_CENT)) {
+                    const double l = hypot(q.x - p.x, q.y - p.y);
+                    len += l;
+                    if (MASK & M_CENT) {
+                        lmx += (p.x + q.x) / 2.0 * l;
+                        lmy += (p.y + q.y) / 2.0 * l;
+                    }
+                }
+            }
+        }
+        if (MASK & (M_AREA | M_CENT)) a2 = group_sum<G>(a2);
+        if (MASK & M_CENT) {
+            acx = group_sum<G>(acx);
+            acy = group_sum<G>(acy);
+            lmx = group_sum<G>(lmx);
+            lmy = group_sum<G>(lmy);
+        }
+        if (MASK & (M_LEN | M_CENT)) len = group_sum<G>(len);
+        if (MASK & M_BBOX) {
+            mnx = group_min<G>(mnx);
+            mny = group_min<G>(mny);
+            mxx = group_max<G>(mxx);
+            mxy = group_max<G>(mxy);
+        }
+        if (MASK & M_SUM) {
+            sx_ = group_sum<G>(sx_);
+            sy_ = group_sum<G>(sy_);
+        }
+        if (lane == 0) {
+            if (MASK & (M_AREA | M_CENT)) stats[ST_AREA2 * n_seq + s] = a2;
+            if (MASK & M_CENT) {
+                stats[ST_ACX * n_seq + s] = acx;
+                stats[ST_ACY * n_seq + s] = acy;
+                stats[ST_LMX * n_seq + s] = lmx;
+                stats[ST_LMY * n_seq + s] = lmy;
+            }
+            if (MASK & (M_LEN | M_CENT)) stats[ST_LEN * n_seq + s] = len;
+            if (MASK & M_BBOX) {
+                stats[ST_MINX * n_seq + s] = mnx;
+                stats[ST_MINY * n_seq + s] = mny;
+                stats[ST_MAXX * n_seq + s] = mxx;
+                stats[ST_MAXY * n_seq + s] = mxy;
+            }
+            if (MASK & M_SUM) {
+                stats[ST_SUMX * n_seq + s] = sx_;
+                stats[ST_SUMY * n_seq + s] = sy_;
+            }
+        }
+    }
+}
+
+// ---- stage 2: one thread per geometry ----------------------------------------------------------
+__device__ __forceinline__ void geom_seq_range(const DevGeo& a, int64_t g, int& s0, int& s1) {
+    // range of level-2 sequences (rings / member linestrings) of geometry g, for non-polygonal types
+    if (a.type == GPK_GEOM_MULTILINESTRING) {
+        s0 = a.geom_off[g];
+        s1 = a.geom_off[g + 1];
+    } else {  // LINESTRING / MULTIPOINT: the geometry is its own sequence
+        s0 = (int)g;
+        s1 = (int)g + 1;
+    }
+}
+
+template <bool SIGNED>
+__global__ void area_combine_kernel(DevGeo a, const double* __restrict__ stats, int64_t n_seq,
+                                    double* __restrict__ out) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.n_geoms) return;
+    if (!dev::valid_row(a.validity, g)) {
+        out[g] = NAN;
+        return;
+    }
+    double v = 0.0;
+    if (is_polygonal(a.type)) {
+        int p0, p1;
+        dev::geom_parts(a, g, p0, p1);
+        for (int p = p0; p < p1; ++p) {
+            int r0, r1;
+            dev::part_rings(a, p, r0, r1);
+            if (r1 <= r0) continue;
+            double area = stats[ST_AREA2 * n_seq + r0] / 2.0;
+            const bool neg = area < 0.0;
+            area = fabs(area);
+            for (int r = r0 + 1; r < r1; ++r) area -= fabs(stats[ST_AREA2 * n_seq + r] / 2.0);
+            const double sa = neg ? -area : area;
+            v += SIGNED ? sa : fabs(sa);
+        }
+    }
+    out[g] = v;
+}
+
+__global__ void length_combine_kernel(DevGeo a, const double* __restrict__ stats, int64_t n_seq,
+                                      double* __restrict__ out) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.n_geoms) return;
+    if (!dev::valid_row(a.validity, g)) {
+        out[g] = NAN;
+        return;
+    }
+    double v = 0.0;
+    if (is_polygonal(a.type)) {  // exterior rings only
+        int p0, p1;
+        dev::geom_parts(a, g, p0, p1);
+        for (int p = p0; p < p1; ++p) {
+            int r0, r1;
+            dev::part_rings(a, p, r0, r1);
+            if (r1 > r0) v += stats[ST_LEN * n_seq + r0];
+        }
+    } else if (a.type == GPK_GEOM_LINESTRING || a.type == GPK_GEOM_MULTILINESTRING) {
+        int s0, s1;
+        geom_seq_range(a, g, s0, s1);
+        for (int s = s0; s < s1; ++s) v += stats[ST_LEN * n_seq + s];
+    }
+    out[g] = v;
+}
+
+__global__ void bounds_combine_kernel(DevGeo a, const double* __restrict__ stats, int64_t n_seq,
+                                      double* __restrict__ out4) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.n_geoms) return;
+    double mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+    bool have = false;
+    if (dev::valid_row(a.validity, g)) {
+        if (is_polygonal(a.type)) {  // Polygon::bounding_rect scans the exterior only
+            int p0, p1;
+            dev::geom_parts(a, g, p0, p1);
+            for (int p = p0; p < p1; ++p) {
+                int r0, r1;
+                dev::part_rings(a, p, r0, r1);
+                if (r1 <= r0 || a.ring_off[r0 + 1] == a.ring_off[r0]) continue;
+                have = true;
+                mnx = fmin(mnx, stats[ST_MINX * n_seq + r0]);
+                mny = fmin(mny, stats[ST_MINY * n_seq + r0]);
+                mxx = fmax(mxx, stats[ST_MAXX * n_seq + r0]);
+                mxy = fmax(mxy, stats[ST_MAXY * n_seq + r0]);
+            }
+        } else {
+            int s0, s1;
+            geom_seq_range(a, g, s0, s1);
+            const int32_t* so = a.type == GPK_GEOM_MULTILINESTRING ? a.ring_off : a.geom_off;
+            for (int s = s0; s < s1; ++s) {
+                if (so[s + 1] == so[s]) continue;
+                have = true;
+                mnx = fmin(mnx, stats[ST_MINX * n_seq + s]);
+                mny = fmin(mny, stats[ST_MINY * n_seq + s]);
+                mxx = fmax(mxx, stats[ST_MAXX * n_seq + s]);
+                mxy = fmax(mxy, stats[ST_MAXY * n_seq + s]);
+            }
+        }
+    }
+    double4 r;
+    if (have)
+        r = make_double4(mnx, mny, mxx, mxy);
+    else
+        r = make_double4(NAN, NAN, NAN, NAN);
+    reinterpret_cast<double4*>(out4)[g] = r;
+}
+
+// geo 0.27 centroid.rs WeightedCentroid: highest dimension wins.
+struct WC {
+    int dim;
+    double w, ax, ay;
+};
+__device__ __forceinline__ void wc_add(WC& c, int dim, double cx, double cy, double w) {
+    if (dim > c.dim) {
+        c.dim = dim;
+        c.w = w;
+        c.ax = cx * w;
+        c.ay = cy * w;
+    } else if (dim == c.dim) {
+        c.w += w;
+        c.ax += cx * w;
+        c.ay += cy * w;
+    }
+}
+__device__ __forceinline__ void wc_add_raw(WC& c, int dim, double ax, double ay, double w) {
+    if (dim > c.dim) {
+        c.dim = dim;
+        c.w = w;
+        c.ax = ax;
+        c.ay = ay;
+    } else if (dim == c.dim) {
+        c.w += w;
+        c.ax += ax;
+        c.ay += ay;
+    }
+}
+// add_line_string from the per-sequence length partials
+__device__ __forceinline__ void wc_add_linestring(WC& c, const double* stats, int64_t n_seq, int s,
+                                                  const double2* xy, int c0, int n) {
+    if (n == 0) return;
+    const double len = stats[ST_LEN * n_seq + s];
+    if (len > 0.0) {
+        wc_add_raw(c, 1, stats[ST_LMX * n_seq + s], stats[ST_LMY * n_seq + s], len);
+    } else {
+        // every segment is zero-length: add_coord(start) per segment (or the single coord)
+        const double2 p = xy[c0];
+        const double k = n == 1 ? 1.0 : (double)(n - 1);
+        wc_add_raw(c, 0, p.x * k, p.y * k, k);
+    }
+}
+__device__ __forceinline__ void wc_add_ring(WC& c, const double* stats, int64_t n_seq, int r,
+                                            const double2* xy, int c0, int n) {
+    const double area = stats[ST_AREA2 * n_seq + r] / 2.0;
+    if (area == 0.0) {
+        wc_add_linestring(c, stats, n_seq, r, xy, c0, n);
+        return;
+    }
+    const double2 sh = xy[c0];
+    const double cx = stats[ST_ACX * n_seq + r] / (6.0 * area) + sh.x;
+    const double cy = stats[ST_ACY * n_seq + r] / (6.0 * area) + sh.y;
+    wc_add(c, 2, cx, cy, fabs(area));
+}
+
+__global__ void centroid_combine_kernel(DevGeo a, const double* __restrict__ stats, int64_t n_seq,
+                                        double* __restrict__ out_xy, uint8_t* __restrict__ out_valid) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.n_geoms) return;
+    WC c{-1, 0, 0, 0};
+    if (dev::valid_row(a.validity, g)) {
+        if (is_polygonal(a.type)) {
+            int p0, p1;
+            dev::geom_parts(a, g, p0, p1);
+            for (int p = p0; p < p1; ++p) {
+                int r0, r1;
+                dev::part_rings(a, p, r0, r1);
+                if (r1 <= r0) continue;
+                WC ext{-1, 0, 0, 0}, in{-1, 0, 0, 0};
+                const int e0 = a.ring_off[r0], en = a.ring_off[r0 + 1] - e0;
+                wc_add_ring(ext, stats, n_seq, r0, a.xy, e0, en);
+                for (int r = r0 + 1; r < r1; ++r)
+                    wc_add_ring(in, stats, n_seq, r, a.xy, a.ring_off[r], a.ring_off[r + 1] - a.ring_off[r]);
+                if (ext.dim < 0) continue;
+                if (in.dim >= 0 && in.dim == ext.dim) {
+                    ext.w -= in.w;
+                    ext.ax -= in.ax;
+                    ext.ay -= in.ay;
+                    if (ext.w == 0.0) {
+                        wc_add_linestring(c, stats, n_seq, r0, a.xy, e0, en);
+                        continue;
+                    }
+                }
+                wc_add_raw(c, ext.dim, ext.ax, ext.ay, ext.w);
+            }
+        } else if (a.type == GPK_GEOM_MULTIPOINT) {
+            const int c0 = a.geom_off[g], n = a.geom_off[g + 1] - c0;
+            if (n > 0) wc_add_raw(c, 0, stats[ST_SUMX * n_seq + g], stats[ST_SUMY * n_seq + g], (double)n);
+        } else {
+            int s0, s1;
+            geom_seq_range(a, g, s0, s1);
+            const int32_t* so = a.type == GPK_GEOM_MULTILINESTRING ? a.ring_off : a.geom_off;
+            for (int s = s0; s < s1; ++s) wc_add_linestring(c, stats, n_seq, s, a.xy, so[s], so[s + 1] - so[s]);
+        }
+    }
+    double2 r;
+    if (c.dim < 0)
+        r = make_double2(NAN, NAN);
+    else
+        r = make_double2(c.ax / c.w, c.ay / c.w);
+    reinterpret_cast<double2*>(out_xy)[g] = r;
+    if (out_valid) out_valid[g] = c.dim >= 0;
+}
+
+// ---- POINT arrays -------------------------------------------------------------------------------
+__global__ void point_unary_kernel(DevGeo a, int op, double* __restrict__ out, uint8_t* __restrict__ out_valid) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.n_geoms) return;
+    const double2 p = a.xy[g];
+    const bool ok = dev::valid_row(a.validity, g);
+    const bool empty = !ok || isnan(p.x) || isnan(p.y);
+    if (op == 0) {  // area / length
+        out[g] = ok ? 0.0 : NAN;
+    } else if (op == 1) {  // centroid
+        reinterpret_cast<double2*>(out)[g] = empty ? make_double2(NAN, NAN) : p;
+        if (out_valid) out_valid[g] = !empty;
+    } else {  // bounds
+        reinterpret_cast<double4*>(out)[g] =
+            empty ? make_double4(NAN, NAN, NAN, NAN) : make_double4(p.x, p.y, p.x, p.y);
+    }
+}
+
+// ---- affine: pure elementwise stream, 16 B in + 16 B out per coordinate ------------------------------
+__global__ __launch_bounds__(256) void affine_kernel(const double2* __restrict__ xy, int64_t n,
+                                                     double m0, double m1, double m2, double m3,
+                                                     double m4, double m5, double2* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double2 p = xy[i];
+        double2 q;
+        q.x = (m0 * p.x + m1 * p.y) + m2;  // contraction is off: matches AffineTransform::apply bit for bit
+        q.y = (m3 * p.x + m4 * p.y) + m5;
+        out[i] = q;
+    }
+}
+
+// ---- host drivers ------------------------------------------------------------------------------
+static int pick_group(int64_t n_coords, int64_t n_seq) {
+    const double mean = n_seq > 0 ? (double)n_coords / (double)n_seq : 1.0;
+    int g = 4;
+    while (g < 64 && g < mean) g <<= 1;
+    return g;
+}
+
+static void seq_view(const DevGeo& a, const int32_t** seq_off, int64_t* n_seq) {
+    if (a.type == GPK_GEOM_LINESTRING || a.type == GPK_GEOM_MULTIPOINT) {
+        *seq_off = a.geom_off;
+        *n_seq = a.n_geoms;
+    } else {
+        *seq_off = a.ring_off;
+        *n_seq = a.n_rings;
+    }
+}
+
+template <unsigned MASK>
+static int32_t launch_seq_stats(const DevGeo& a, double* stats, hipStream_t s, const char* name) {
+    const int32_t* seq_off;
+    int64_t n_seq;
+    seq_view(a, &seq_off, &n_seq);
+    if (n_seq == 0) return GPK_OK;
+    const int G = pick_group(a.n_coords, n_seq);
+    const int64_t groups_per_block = 256 / G;
+    int64_t blocks = (n_seq + groups_per_block - 1) / groups_per_block;
+    const int64_t cap = (int64_t)cu_count() * 16;
+    if (blocks > cap) blocks = cap;
+    dim3 grid((unsigned)blocks), block(256);
+    switch (G) {
+    case 4: GPK_LAUNCH(name, (seq_stats_kernel<4, MASK>), grid, block, 0, s, a.xy, seq_off, n_seq, stats); break;
+    case 8: GPK_LAUNCH(name, (seq_stats_kernel<8, MASK>), grid, block, 0, s, a.xy, seq_off, n_seq, stats); break;
+    case 16: GPK_LAUNCH(name, (seq_stats_kernel<16, MASK>), grid, block, 0, s, a.xy, seq_off, n_seq, stats); break;
+    case 32: GPK_LAUNCH(name, (seq_stats_kernel<32, MASK>), grid, block, 0, s, a.xy, seq_off, n_seq, stats); break;
+    default: GPK_LAUNCH(name, (seq_stats_kernel<64, MASK>), grid, block, 0, s, a.xy, seq_off, n_seq, stats); break;
+    }
+    return GPK_OK;
+}
+
+static inline dim3 grid_for(int64_t n, int block = 256) {
+    int64_t b = (n + block - 1) / block;
+    return dim3((unsigned)(b > 0 ? b : 1));
+}
+
+// common prologue: stats + output staging in the workspace
+struct UnaryCtx {
+    double* stats = nullptr;
+    void* out_dev = nullptr;
+    void* out2_dev = nullptr;
+    int64_t n_seq = 0;
+};
+static int32_t unary_begin(const gpk_geoarray* a, size_t out_bytes, size_t out2_bytes, void* out,
+                           void* out2, int32_t out_space, UnaryCtx* c) {
+    if (!a || !out) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
+    GPK_TRY(require_device());
+    const int32_t* so;
+    seq_view(a->d, &so, &c->n_seq);
+    if (a->d.type == GPK_GEOM_POINT) c->n_seq = 0;
+    const size_t stats_bytes = sizeof(double) * ST_COUNT * (size_t)c->n_seq;
+    const bool stage = out_space != GPK_MEM_DEVICE;
+    GPK_TRY(workspace().begin(align256(stats_bytes) + (stage ? align256(out_bytes) + align256(out2_bytes) : 0) + 1024));
+    c->stats = (double*)workspace().take(stats_bytes ? stats_bytes : 8);
+    c->out_dev = stage ? workspace().take(out_bytes ? out_bytes : 8) : out;
+    c->out2_dev = out2 ? (stage ? workspace().take(out2_bytes ? out2_bytes : 8) : out2) : nullptr;
+    return GPK_OK;
+}
+
+}  // namespace gpk
+
+using namespace gpk;
+
+extern "C" {
+
+static int32_t area_impl(const gpk_geoarray* a, double* out, int32_t out_space, void* stream, bool is_signed) {
+    UnaryCtx c;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t ob = a ? sizeof(double) * (size_t)a->d.n_geoms : 0;
+    GPK_TRY(unary_begin(a, ob, 0, out, nullptr, out_space, &c));
+    const int64_t n = a->d.n_geoms;
+    if (n == 0) return GPK_OK;
+    if (a->d.type == GPK_GEOM_POINT) {
+        GPK_LAUNCH("gpk_point_unary", point_unary_kernel, grid_for(n), dim3(256), 0, s, a->d, 0, (double*)c.out_dev, (uint8_t*)nullptr);
+    } else {
+        if (is_polygonal(a->d.type)) GPK_TRY(launch_seq_stats<M_AREA>(a->d, c.stats, s, "gpk_ring_area"));
+        if (is_signed)
+            GPK_LAUNCH("gpk_area_combine", area_combine_kernel<true>, grid_for(n), dim3(256), 0, s, a->d, c.stats, c.n_seq, (double*)c.out_dev);
+        else
+            GPK_LAUNCH("gpk_area_combine", area_combine_kernel<false>, grid_for(n), dim3(256), 0, s, a->d, c.stats, c.n_seq, (double*)c.out_dev);
+    }
+    return copy_out(out, out_space, c.out_dev, ob, s);
+}
+
+int32_t gpk_area(const gpk_geoarray* a, double* out, int32_t out_space, void* stream) {
+    return area_impl(a, out, out_space, stream, false);
+}
+int32_t gpk_signed_area(const gpk_geoarray* a, double* out, int32_t out_space, void* stream) {
+    return area_impl(a, out, out_space, stream, true);
+}
+
+int32_t gpk_euclidean_length(const gpk_geoarray* a, double* out, int32_t out_space, void* stream) {
+    UnaryCtx c;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t ob = a ? sizeof(double) * (size_t)a->d.n_geoms : 0;
+    GPK_TRY(unary_begin(a, ob, 0, out, nullptr, out_space, &c));
+    const int64_t n = a->d.n_geoms;
+    if (n == 0) return GPK_OK;
+    if (a->d.type == GPK_GEOM_POINT) {
+        GPK_LAUNCH("gpk_point_unary", point_unary_kernel, grid_for(n), dim3(256), 0, s, a->d, 0, (double*)c.out_dev, (uint8_t*)nullptr);
+    } else {
+        if (a->d.type != GPK_GEOM_MULTIPOINT) GPK_TRY(launch_seq_stats<M_LEN>(a->d, c.stats, s, "gpk_seq_length"));
+        GPK_LAUNCH("gpk_length_combine", length_combine_kernel, grid_for(n), dim3(256), 0, s, a->d, c.stats, c.n_seq, (double*)c.out_dev);
+    }
+    return copy_out(out, out_space, c.out_dev, ob, s);
+}
+
+int32_t gpk_bounds(const gpk_geoarray* a, double* out4, int32_t out_space, void* stream) {
+    UnaryCtx c;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t ob = a ? sizeof(double) * 4 * (size_t)a->d.n_geoms : 0;
+    GPK_TRY(unary_begin(a, ob, 0, out4, nullptr, out_space, &c));
+    const int64_t n = a->d.n_geoms;
+    if (n == 0) return GPK_OK;
+    if (a->d.type == GPK_GEOM_POINT) {
+        GPK_LAUNCH("gpk_point_unary", point_unary_kernel, grid_for(n), dim3(256), 0, s, a->d, 2, (double*)c.out_dev, (uint8_t*)nullptr);
+    } else {
+        GPK_TRY(launch_seq_stats<M_BBOX>(a->d, c.stats, s, "gpk_seq_bbox"));
+        GPK_LAUNCH("gpk_bounds_combine", bounds_combine_kernel, grid_for(n), dim3(256), 0, s, a->d, c.stats, c.n_seq, (double*)c.out_dev);
+    }
+    return copy_out(out4, out_space, c.out_dev, ob, s);
+}
+
+int32_t gpk_centroid(const gpk_geoarray* a, double* out_xy, uint8_t* out_valid, int32_t out_space, void* stream) {
+    UnaryCtx c;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t ob = a ? sizeof(double) * 2 * (size_t)a->d.n_geoms : 0;
+    const size_t vb = a ? (size_t)a->d.n_geoms : 0;
+    GPK_TRY(unary_begin(a, ob, vb, out_xy, out_valid, out_space, &c));
+    const int64_t n = a->d.n_geoms;
+    if (n == 0) return GPK_OK;
+    if (a->d.type == GPK_GEOM_POINT) {
+        GPK_LAUNCH("gpk_point_unary", point_unary_kernel, grid_for(n), dim3(256), 0, s, a->d, 1, (double*)c.out_dev, (uint8_t*)c.out2_dev);
+    } else {
+        if (a->d.type == GPK_GEOM_MULTIPOINT)
+            GPK_TRY(launch_seq_stats<M_SUM>(a->d, c.stats, s, "gpk_seq_sum"));
+        else
+            GPK_TRY(launch_seq_stats<M_CENT>(a->d, c.stats, s, "gpk_ring_centroid"));
+        GPK_LAUNCH("gpk_centroid_combine", centroid_combine_kernel, grid_for(n), dim3(256), 0, s, a->d, c.stats, c.n_seq, (double*)c.out_dev, (uint8_t*)c.out2_dev);
+    }
+    if (out_valid) GPK_TRY(copy_out(out_valid, out_space, c.out2_dev, vb, s));
+    return copy_out(out_xy, out_space, c.out_dev, ob, s);
+}
+
+int32_t gpk_affine_transform(const gpk_geoarray* a, const double m[6], double* out_xy, int32_t out_space, void* stream) {
+    if (!a || !m || !out_xy) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
+    GPK_TRY(require_device());
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = a->d.n_coords;
+    if (n == 0) return GPK_OK;
+    const size_t ob = sizeof(double) * 2 * (size_t)n;
+    void* out_dev = out_xy;
+    if (out_space != GPK_MEM_DEVICE) {
+        GPK_TRY(workspace().begin(ob + 512));
+        out_dev = workspace().take(ob);
+    }
+    int64_t blocks = (n + 255) / 256;
+    const int64_t cap = (int64_t)cu_count() * 8;
+    if (blocks > cap) blocks = cap;
+    GPK_LAUNCH("gpk_affine", affine_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a->d.xy, n, m[0], m[1], m[2], m[3], m[4], m[5], (double2*)out_dev);
+    return copy_out(out_xy, out_space, out_dev, ob, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,309 @@
+"""`GeoSeries` — the host-side mirror of the reference's operator surface.
+
+Same method names, argument meaning and error behaviour as `trait GeoSeries`
+(geopolars/geopolars-geo/src/geoseries.rs:10-181) and its Python accessor `GeoRustSeries`
+(py-geopolars/python/geopolars/internals/georust/geoseries.py:17-320), plus the north-star
+predicates (`contains` / `within` / `intersects` / `bounds`) that exist in the reference only as
+dead code (geopolars/src/spatial_index.rs:89-137).  polars is not available here, so a series is a
+single-chunk GeoArrow array (`GeoArrowArray`) instead of a `polars.Series` — exactly what
+ffi.rs:56 rechunks to before crossing into Rust.
+
+Every operator goes through the C ABI into HIP kernels; nothing here computes geometry on the CPU.
+Cheap structural accessors (`geom_type`, `is_empty`, `x`, `y`, `exterior`, `envelope` ring assembly)
+only slice offset buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Sequence, Union
+
+import numpy as np
+
+from . import _abi
+from ._abi import (
+    GEOM_LINESTRING,
+    GEOM_MULTILINESTRING,
+    GEOM_MULTIPOINT,
+    GEOM_MULTIPOLYGON,
+    GEOM_POINT,
+    GEOM_POLYGON,
+    MEM_HOST,
+    PREDICATES,
+)
+from .geoarrow import DeviceGeoArray, GeoArrowArray
+
+TransformOrigin = Union[str, tuple]
+
+
+class GeoSeries:
+    def __init__(self, array: GeoArrowArray, name: str = "geometry"):
+        self.array = array
+        self.name = name  # output column name is always "geometry" (util.rs:22,43,52)
+        self._dev: Optional[DeviceGeoArray] = None
+
+    # ---- construction --------------------------------------------------------------------------
+    @staticmethod
+    def from_wkb(column) -> "GeoSeries":
+        return GeoSeries(GeoArrowArray.from_arrow_wkb(column))
+
+    @staticmethod
+    def from_points(xy) -> "GeoSeries":
+        return GeoSeries(GeoArrowArray.from_points(xy))
+
+    def __len__(self) -> int:
+        return len(self.array)
+
+    def device(self) -> DeviceGeoArray:
+        """Upload on first use ("copied once to HBM"); later operators reuse the resident copy."""
+        if self._dev is None:
+            self._dev = DeviceGeoArray.upload(self.array)
+        return self._dev
+
+    # ---- structural accessors (offset arithmetic only) -------------------------------------------
+    def geom_type(self) -> np.ndarray:
+        """geoseries.rs:60-73: -1 missing, 0 Point, 1 LineString, 3 Polygon, 4.., 6 MultiPolygon."""
+        out = np.full(len(self), self.array.geom_type, dtype=np.int8)
+        out[~self.array.is_valid()] = -1
+        return out
+
+    def is_empty(self) -> np.ndarray:
+        a = self.array
+        if a.geom_type == GEOM_POINT:
+            return np.isnan(a.xy).any(axis=1)
+        return np.diff(a.geom_offsets) == 0
+
+    def x(self) -> np.ndarray:
+        self._require(GEOM_POINT, "x")
+        return self.array.xy[:, 0].copy()
+
+    def y(self) -> np.ndarray:
+        self._require(GEOM_POINT, "y")
+        return self.array.xy[:, 1].copy()
+
+    def exterior(self) -> "GeoSeries":
+        """Outer ring of each polygon as a LineString series (geoseries.rs:43-47)."""
+        self._require(GEOM_POLYGON, "exterior")
+        a = self.array
+        first = a.geom_offsets[:-1]
+        has = np.diff(a.geom_offsets) > 0
+        starts = np.where(has, a.ring_offsets[np.minimum(first, a.n_rings - 1 if a.n_rings else 0)], 0)
+        ends = np.where(has, a.ring_offsets[np.minimum(first + 1, a.n_rings)], 0)
+        lens = ends - starts
+        off = np.zeros(len(self) + 1, dtype=np.int32)
+        off[1:] = np.cumsum(lens)
+        idx = np.concatenate([np.arange(s, e) for s, e in zip(starts, ends)]) if len(self) else np.zeros(0, int)
+        return GeoSeries(GeoArrowArray(GEOM_LINESTRING, a.xy[idx.astype(np.int64)], geom_offsets=off))
+
+    def _require(self, t: int, op: str) -> None:
+        if self.array.geom_type != t:
+            raise _abi.MismatchedGeometry(
+                _abi.GPK_ERR_MISMATCHED_GEOMETRY,
+                f"{op}: expected {_abi_name(t)} (found {_abi_name(self.array.geom_type)})",
+            )
+
+    # ---- unary operators (HIP) -----------------------------------------------------------------
+    def area(self) -> np.ndarray:
+        out = np.empty(len(self), dtype=np.float64)
+        _abi.check(_abi.lib().gpk_area(self.device().handle, out.ctypes.data, MEM_HOST, None))
+        return out
+
+    def signed_area(self) -> np.ndarray:
+        out = np.empty(len(self), dtype=np.float64)
+        _abi.check(_abi.lib().gpk_signed_area(self.device().handle, out.ctypes.data, MEM_HOST, None))
+        return out
+
+    def euclidean_length(self) -> np.ndarray:
+        out = np.empty(len(self), dtype=np.float64)
+        _abi.check(_abi.lib().gpk_euclidean_length(self.device().handle, out.ctypes.data, MEM_HOST, None))
+        return out
+
+    def bounds(self) -> np.ndarray:
+        """(n, 4) minx, miny, maxx, maxy — the north-star `bounds`; NaN for empty geometries."""
+        out = np.empty((len(self), 4), dtype=np.float64)
+        _abi.check(_abi.lib().gpk_bounds(self.device().handle, out.ctypes.data, MEM_HOST, None))
+        return out
+
+    def envelope(self) -> "GeoSeries":
+        """geoseries.rs:28-33: the bounding rectangle as a geometry.  Points stay points; everything
+        else becomes the closed 5-coordinate rectangle polygon (minx miny, maxx miny, maxx maxy,
+        minx maxy, minx miny) that geo's `Rect::to_polygon` produces."""
+        if self.array.geom_type == GEOM_POINT:
+            return GeoSeries(self.array)
+        b = self.bounds()
+        n = len(self)
+        ok = ~np.isnan(b[:, 0])
+        xy = np.empty((n, 5, 2), dtype=np.float64)
+        xy[:, 0] = b[:, [0, 1]]
+        xy[:, 1] = b[:, [2, 1]]
+        xy[:, 2] = b[:, [2, 3]]
+        xy[:, 3] = b[:, [0, 3]]
+        xy[:, 4] = b[:, [0, 1]]
+        xy = xy[ok].reshape(-1, 2)
+        ring_off = np.arange(0, 5 * int(ok.sum()) + 1, 5, dtype=np.int32)
+        geom_off = np.zeros(n + 1, dtype=np.int32)
+        geom_off[1:] = np.cumsum(ok)
+        return GeoSeries(GeoArrowArray(GEOM_POLYGON, xy, geom_offsets=geom_off, ring_offsets=ring_off))
+
+    def centroid(self) -> "GeoSeries":
+        xy = np.empty((len(self), 2), dtype=np.float64)
+        valid = np.empty(len(self), dtype=np.uint8)
+        _abi.check(_abi.lib().gpk_centroid(self.device().handle, xy.ctypes.data, valid.ctypes.data, MEM_HOST, None))
+        return GeoSeries(GeoArrowArray.from_points(xy))
+
+    def convex_hull(self) -> "GeoSeries":
+        a = self.array
+        xy = np.empty((a.n_coords + len(self), 2), dtype=np.float64)
+        ring_off = np.empty(len(self) + 1, dtype=np.int32)
+        _abi.check(_abi.lib().gpk_convex_hull(self.device().handle, xy.ctypes.data, ring_off.ctypes.data, MEM_HOST, None))
+        xy = xy[: ring_off[-1]]
+        return GeoSeries(
+            GeoArrowArray(GEOM_POLYGON, xy, geom_offsets=np.arange(len(self) + 1, dtype=np.int32), ring_offsets=ring_off)
+        )
+
+    def affine_transform(self, matrix: Sequence[float]) -> "GeoSeries":
+        """matrix = [a, b, xoff, d, e, yoff] — the order `AffineTransform::from([f64; 6])` takes and
+        py-geopolars/src/geo.rs:10-16 forwards (NOT the [a,b,d,e,xoff,yoff] of the Python docstring,
+        georust/geoseries.py:33)."""
+        m = (C.c_double * 6)(*[float(v) for v in matrix])
+        a = self.array
+        out = np.empty_like(a.xy)
+        _abi.check(_abi.lib().gpk_affine_transform(self.device().handle, m, out.ctypes.data, MEM_HOST, None))
+        return GeoSeries(
+            GeoArrowArray(a.geom_type, out, a.geom_offsets, a.part_offsets, a.ring_offsets, a.validity, n_geoms=a.n_geoms)
+        )
+
+    def translate(self, x: float = 0.0, y: float = 0.0) -> "GeoSeries":
+        return self.affine_transform([1.0, 0.0, x, 0.0, 1.0, y])
+
+    def _origin(self, origin: TransformOrigin) -> np.ndarray:
+        """TransformOrigin (py-geopolars/src/utils.rs:5-27): 'centroid' | 'center' (of the bbox) |
+        (x, y).  Per-geometry origins -> one matrix per row."""
+        if isinstance(origin, str):
+            o = origin.lower()
+            if o == "centroid":
+                return self.centroid().array.xy
+            if o == "center":
+                b = self.bounds()
+                return np.stack([(b[:, 0] + b[:, 2]) / 2.0, (b[:, 1] + b[:, 3]) / 2.0], axis=1)
+            raise ValueError("Invalid argument")  # PyGeopolarsError::Other("Invalid argument"), utils.rs:21
+        x, y = origin
+        return np.tile(np.array([[float(x), float(y)]]), (len(self), 1))
+
+    def _per_row_affine(self, mats: np.ndarray) -> "GeoSeries":
+        # rows share a matrix only when the origin is a fixed point; otherwise group by row.
+        if len(mats) == 0:
+            return self
+        if np.all(mats == mats[0]):
+            return self.affine_transform(mats[0])
+        parts = []
+        for i in range(len(self)):
+            parts.append(_take_rows(self.array, i).affine_row(mats[i]))
+        return GeoSeries(_concat_like(self.array, parts))
+
+    def rotate(self, angle: float, origin: TransformOrigin = "center") -> "GeoSeries":
+        """angle in degrees, counter-clockwise, about `origin` (geoseries.rs:85-93)."""
+        t = math.radians(angle)
+        c, s = math.cos(t), math.sin(t)
+        o = self._origin(origin)
+        mats = np.stack(
+            [np.full(len(o), c), np.full(len(o), -s), o[:, 0] - c * o[:, 0] + s * o[:, 1], np.full(len(o), s), np.full(len(o), c), o[:, 1] - s * o[:, 0] - c * o[:, 1]],
+            axis=1,
+        )
+        return self._per_row_affine(mats)
+
+    def scale(self, xfact: float = 1.0, yfact: float = 1.0, origin: TransformOrigin = "center") -> "GeoSeries":
+        o = self._origin(origin)
+        z = np.zeros(len(o))
+        mats = np.stack([z + xfact, z, o[:, 0] * (1 - xfact), z, z + yfact, o[:, 1] * (1 - yfact)], axis=1)
+        return self._per_row_affine(mats)
+
+    def skew(self, xs: float = 0.0, ys: float = 0.0, origin: TransformOrigin = "center") -> "GeoSeries":
+        """geoseries.rs:118-139: [[1, tan(xs), xoff], [tan(ys), 1, yoff]], xoff = -origin.y*tan(xs),
+        yoff = -origin.x*tan(ys); angles in degrees."""
+        tx, ty = math.tan(math.radians(xs)), math.tan(math.radians(ys))
+        o = self._origin(origin)
+        z = np.zeros(len(o))
+        mats = np.stack([z + 1.0, z + tx, -o[:, 1] * tx, z + ty, z + 1.0, -o[:, 0] * ty], axis=1)
+        return self._per_row_affine(mats)
+
+    # ---- binary row-wise operators (HIP) ---------------------------------------------------------
+    def distance(self, other: "GeoSeries", other_rows: Optional[np.ndarray] = None) -> np.ndarray:
+        """geoseries.rs:141-146: 1-to-1 row-wise Euclidean distance.  `other_rows` pairs row i with
+        other[other_rows[i]] (the take() a dataframe caller would have materialised)."""
+        n = len(self) if self.array.geom_type == GEOM_POINT or other_rows is not None else len(other)
+        out = np.empty(n, dtype=np.float64)
+        rows = None
+        if other_rows is not None:
+            rows = np.ascontiguousarray(other_rows, dtype=np.uint32)
+        _abi.check(
+            _abi.lib().gpk_distance_rowwise(
+                self.device().handle, other.device().handle, None if rows is None else rows.ctypes.data, out.ctypes.data, MEM_HOST, None
+            )
+        )
+        return out
+
+    def _predicate(self, other: "GeoSeries", name: str, other_rows=None) -> np.ndarray:
+        out = np.empty(len(self), dtype=np.uint8)
+        rows = None if other_rows is None else np.ascontiguousarray(other_rows, dtype=np.uint32)
+        _abi.check(
+            _abi.lib().gpk_predicate_rowwise(
+                self.device().handle, other.device().handle, None if rows is None else rows.ctypes.data, PREDICATES[name], out.ctypes.data, MEM_HOST, None
+            )
+        )
+        return out.astype(bool)
+
+    def contains(self, other: "GeoSeries", other_rows=None) -> np.ndarray:
+        return self._predicate(other, "contains", other_rows)
+
+    def within(self, other: "GeoSeries", other_rows=None) -> np.ndarray:
+        return self._predicate(other, "within", other_rows)
+
+    def intersects(self, other: "GeoSeries", other_rows=None) -> np.ndarray:
+        return self._predicate(other, "intersects", other_rows)
+
+
+def _abi_name(t: int) -> str:
+    from .geoarrow import GEOM_NAMES
+
+    return GEOM_NAMES.get(t, f"type {t}")
+
+
+class _RowView:
+    def __init__(self, arr: GeoArrowArray):
+        self.arr = arr
+
+    def affine_row(self, m) -> GeoArrowArray:
+        return GeoSeries(self.arr).affine_transform(m).array
+
+
+def _take_rows(a: GeoArrowArray, i: int) -> _RowView:
+    """Single-row slice (used only by per-row origins of rotate/scale/skew)."""
+    if a.geom_type == GEOM_POINT:
+        return _RowView(GeoArrowArray.from_points(a.xy[i : i + 1]))
+    g0, g1 = int(a.geom_offsets[i]), int(a.geom_offsets[i + 1])
+    if a.geom_type in (GEOM_LINESTRING, GEOM_MULTIPOINT):
+        return _RowView(GeoArrowArray(a.geom_type, a.xy[g0:g1], geom_offsets=np.array([0, g1 - g0], np.int32)))
+    if a.geom_type in (GEOM_POLYGON, GEOM_MULTILINESTRING):
+        ro = a.ring_offsets[g0 : g1 + 1]
+        return _RowView(
+            GeoArrowArray(a.geom_type, a.xy[ro[0] : ro[-1]], geom_offsets=np.array([0, g1 - g0], np.int32), ring_offsets=ro - ro[0])
+        )
+    po = a.part_offsets[g0 : g1 + 1]
+    ro = a.ring_offsets[po[0] : po[-1] + 1]
+    return _RowView(
+        GeoArrowArray(
+            a.geom_type,
+            a.xy[ro[0] : ro[-1]],
+            geom_offsets=np.array([0, g1 - g0], np.int32),
+            part_offsets=po - po[0],
+            ring_offsets=ro - ro[0],
+        )
+    )
+
+
+def _concat_like(proto: GeoArrowArray, parts: Sequence[GeoArrowArray]) -> GeoArrowArray:
+    xy = np.concatenate([p.xy for p in parts]) if parts else np.zeros((0, 2))
+    return GeoArrowArray(
+        proto.geom_type, xy, proto.geom_offsets, proto.part_offsets, proto.ring_offsets, proto.validity, n_geoms=proto.n_geoms
+    )

@@ -1,0 +1,185 @@
+/*
+ * geopolars_hip.h — flat C ABI of libgeopolars_hip.so, the MI355X (gfx950) geometry-kernel
+ * backend that sits under GeoPolars' `GeoSeries` operator surface.
+ *
+ * Every entry point replaces one `todo!()` body (or one dead-code call site) in the reference:
+ *   trait GeoSeries / impl GeoSeries for Series   geopolars/geopolars-geo/src/geoseries.rs:10-181,183-279
+ *   spatial_join + SpatialIndex                    geopolars/src/spatial_index.rs:37-204,314-350
+ *   row codec (WKB <-> geometry)                   geopolars/geopolars-geo/src/util.rs:11-37
+ * The only FFI convention the reference has is the Arrow C Data Interface
+ * (py-geopolars/src/ffi.rs:12-52): single-chunk arrays, inputs BORROWED for the call, outputs owned
+ * by the producer until released.  This ABI keeps that ownership model but speaks raw GeoArrow
+ * buffers (coords FixedSizeList<f64,2> interleaved + i32 List offsets) so a Rust shim can pass
+ * `array.values().as_ptr()` straight through (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - All functions return int32_t status (GPK_OK == 0).  Nothing throws or aborts across the ABI;
+ *     `gpk_last_error` returns a thread-local message.  Status codes map onto
+ *     `GeopolarsError` (geopolars/geopolars-geo/src/error.rs:9-28) in the shim.
+ *   - Pointers carry a memory space tag (GPK_MEM_HOST / GPK_MEM_DEVICE).  Host buffers are copied to
+ *     HBM once by `gpk_geoarray_upload`; device buffers are borrowed (zero copy) — that is how a
+ *     caller that already holds data in HBM (another kernel, a torch tensor's data_ptr) plugs in.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the library's own per-thread stream).  Calls
+ *     with host outputs block until the result is host-visible; calls with device outputs are
+ *     stream-ordered and do not synchronise.
+ *   - Geometry handles are immutable after upload and may be shared between threads
+ *     (mirrors `Arc<SpatialIndex>`, spatial_index.rs:20-21).
+ *   - Null rows: validity bitmaps are Arrow LSB-first; null in -> null out (never a panic, unlike
+ *     util.rs:32).
+ *   - There is NO CPU fallback in this library.  Without a gfx950 device every compute entry point
+ *     returns GPK_ERR_DEVICE.
+ */
+#ifndef GEOPOLARS_HIP_H
+#define GEOPOLARS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------------------------- */
+#define GPK_OK                        0
+#define GPK_ERR_MISMATCHED_GEOMETRY   1 /* -> GeopolarsError::MismatchedGeometry (error.rs:12-16) */
+#define GPK_ERR_INVALID_OFFSETS       2 /* -> PolarsError::ComputeError */
+#define GPK_ERR_NULL_UNSUPPORTED      3
+#define GPK_ERR_DEVICE                4 /* HIP error / no device / extension not usable */
+#define GPK_ERR_OOM                   5
+#define GPK_ERR_INVALID_ARGUMENT      6
+#define GPK_ERR_CAPACITY              7 /* caller-provided pair buffer too small; n_pairs is set */
+
+/* ---- geometry type ids: identical to GeoSeries::geom_type (geoseries.rs:60-73) --------------- */
+#define GPK_GEOM_POINT             0
+#define GPK_GEOM_LINESTRING        1
+#define GPK_GEOM_POLYGON           3
+#define GPK_GEOM_MULTIPOINT        4
+#define GPK_GEOM_MULTILINESTRING   5
+#define GPK_GEOM_MULTIPOLYGON      6
+
+#define GPK_MEM_HOST    0
+#define GPK_MEM_DEVICE  1
+
+/* ---- predicates: `Predicate` of spatial_index.rs:13,28 -------------------------------------- */
+#define GPK_PRED_INTERSECTS  0 /* default, spatial_index.rs:28 */
+#define GPK_PRED_CONTAINS    1
+#define GPK_PRED_WITHIN      2 /* within(a,b) == contains(b,a) */
+
+/*
+ * One single-chunk GeoArrow array.  Nesting by type:
+ *   POINT                         coords
+ *   LINESTRING / MULTIPOINT       geom_offsets[n+1] -> coords
+ *   POLYGON / MULTILINESTRING     geom_offsets[n+1] -> rings ; ring_offsets[n_rings+1] -> coords
+ *   MULTIPOLYGON                  geom_offsets[n+1] -> parts ; part_offsets[n_parts+1] -> rings ;
+ *                                 ring_offsets[n_rings+1] -> coords
+ * coords are interleaved xy (FixedSizeList<f64,2>); rings are stored closed (first == last).
+ * Unused offset pointers are NULL.  All buffers of one descriptor live in `mem_space`.
+ */
+typedef struct gpk_geoarrow_desc {
+    int32_t        geom_type;     /* GPK_GEOM_* */
+    int32_t        mem_space;     /* GPK_MEM_HOST or GPK_MEM_DEVICE */
+    int64_t        n_geoms;
+    int64_t        n_coords;
+    const double*  xy;            /* 2*n_coords doubles */
+    const int32_t* geom_offsets;  /* n_geoms+1 or NULL (POINT) */
+    const int32_t* part_offsets;  /* n_parts+1, MULTIPOLYGON only */
+    const int32_t* ring_offsets;  /* n_rings+1, POLYGON / MULTILINESTRING / MULTIPOLYGON */
+    int64_t        n_parts;       /* MULTIPOLYGON only */
+    int64_t        n_rings;       /* POLYGON / MULTILINESTRING / MULTIPOLYGON */
+    const uint8_t* validity;      /* Arrow bitmap, NULL = all valid */
+} gpk_geoarrow_desc;
+
+typedef struct gpk_geoarray gpk_geoarray; /* device-resident SoA copy (or borrowed view) */
+typedef struct gpk_index    gpk_index;    /* device-resident spatial index over one geoarray */
+
+/* ---- library ------------------------------------------------------------------------------ */
+const char* gpk_version(void);
+int32_t gpk_last_error(char* buf, size_t cap);
+int32_t gpk_device_count(int32_t* out_n);
+/* name + CU count of the current HIP device; fails with GPK_ERR_DEVICE when it is not gfx950 */
+int32_t gpk_device_info(char* name_buf, size_t cap, int32_t* out_cus);
+
+/* ---- "copied once to HBM as SoA" ---------------------------------------------------------- */
+/* replaces the per-op row decode of util.rs:27-37 (iter_geom) */
+int32_t gpk_geoarray_upload(const gpk_geoarrow_desc* desc, void* stream, gpk_geoarray** out);
+int32_t gpk_geoarray_free(gpk_geoarray* a);
+/* HBM bytes held by the handle (owned + borrowed), for roofline accounting */
+int32_t gpk_geoarray_nbytes(const gpk_geoarray* a, int64_t* out_bytes);
+
+/* WKB BinaryArray<i32> (util.rs:27-37 input format) -> GeoArrow buffers, host side.
+ * Pass 1 (out == NULL): validates and fills `counts` = {geom_type, n_geoms, n_parts, n_rings, n_coords}.
+ * Pass 2: fills caller-allocated buffers of exactly those sizes.  Mixed Polygon/MultiPolygon input is
+ * promoted to MULTIPOLYGON, mixed LineString/MultiLineString to MULTILINESTRING. */
+int32_t gpk_wkb_decode(const uint8_t* wkb_values, const int32_t* wkb_offsets, int64_t n_rows,
+                       const uint8_t* validity, int64_t counts[5], double* xy,
+                       int32_t* geom_offsets, int32_t* part_offsets, int32_t* ring_offsets);
+
+/* ---- unary operators: GeoSeries::{area, centroid, envelope/bounds, affine_transform, ...} --- */
+/* out arrays live in `out_space`; sizes are in elements.                                      */
+/* area: geoseries.rs:14-16,188-190.  out[n_geoms] */
+int32_t gpk_area(const gpk_geoarray* a, double* out, int32_t out_space, void* stream);
+/* signed area (exterior orientation sign), same layout */
+int32_t gpk_signed_area(const gpk_geoarray* a, double* out, int32_t out_space, void* stream);
+/* centroid: geoseries.rs:18-21,192-194.  out_xy[2*n_geoms]; out_valid[n_geoms] bytes (0 = empty geometry -> null) */
+int32_t gpk_centroid(const gpk_geoarray* a, double* out_xy, uint8_t* out_valid, int32_t out_space,
+                     void* stream);
+/* bounds (north-star) / envelope (geoseries.rs:28-33,200-202): out[4*n_geoms] = minx,miny,maxx,maxy;
+ * empty geometry -> NaN x4 */
+int32_t gpk_bounds(const gpk_geoarray* a, double* out4, int32_t out_space, void* stream);
+/* euclidean_length: geoseries.rs:35-41.  out[n_geoms] */
+int32_t gpk_euclidean_length(const gpk_geoarray* a, double* out, int32_t out_space, void* stream);
+/* affine_transform: geoseries.rs:11-12,184-186.  m = [a, b, xoff, d, e, yoff] (upstream
+ * `AffineTransform::from([f64;6])` order, which py-geopolars/src/geo.rs:10-16 passes through; the
+ * Python docstring georust/geoseries.py:33 says [a,b,d,e,xoff,yoff] — that docstring is wrong).
+ * out_xy[2*n_coords]; offsets are unchanged and shared with the input. */
+int32_t gpk_affine_transform(const gpk_geoarray* a, const double m[6], double* out_xy,
+                             int32_t out_space, void* stream);
+/* convex_hull: geoseries.rs:23-26,196-198.  Output = POLYGON array, one closed CCW ring per geometry.
+ * out_ring_offsets[n_geoms+1]; out_xy capacity must be >= 2*(n_coords + n_geoms) doubles. */
+int32_t gpk_convex_hull(const gpk_geoarray* a, double* out_xy, int32_t* out_ring_offsets,
+                        int32_t out_space, void* stream);
+
+/* ---- row-wise binary operators ------------------------------------------------------------ */
+/* distance: geoseries.rs:141-146,248-251 ("1-to-1 row-wise").  `b_rows` (optional, same space as
+ * out) maps row i of `a` to row b_rows[i] of `b` — the take() a caller would otherwise materialise;
+ * NULL = identity (then n_geoms must match).  out[n_geoms(a)].  Supported: POINT x {POINT,
+ * LINESTRING, POLYGON, MULTIPOLYGON, MULTILINESTRING, MULTIPOINT} and the mirrored pairs. */
+int32_t gpk_distance_rowwise(const gpk_geoarray* a, const gpk_geoarray* b, const uint32_t* b_rows,
+                             double* out, int32_t out_space, void* stream);
+/* contains / within / intersects row-wise (north-star additions to the trait; semantics from the
+ * dispatch table spatial_index.rs:89-137).  out[n] bytes 0/1. */
+int32_t gpk_predicate_rowwise(const gpk_geoarray* a, const gpk_geoarray* b, const uint32_t* b_rows,
+                              int32_t predicate, uint8_t* out, int32_t out_space, void* stream);
+
+/* ---- spatial index + join: spatial_index.rs:37-204,314-350 -------------------------------- */
+/* SpatialIndex::try_from(&Series) (spatial_index.rs:320-334): bbox per geometry + a uniform-grid
+ * directory over the bboxes (the GPU replacement for rstar's R-tree) + per-polygon edge slabs. */
+int32_t gpk_index_build(const gpk_geoarray* a, void* stream, gpk_index** out);
+int32_t gpk_index_free(gpk_index* idx);
+int32_t gpk_index_nbytes(const gpk_index* idx, int64_t* out_bytes);
+
+/*
+ * spatial_join refine (spatial_index.rs:74-143): all (l, r) with predicate(left[l], right[r]) true,
+ * emitted SORTED by (l, r) (rstar's traversal order is unspecified; the shim may compare sets).
+ *   out_counts[n_left]   u32 hits per left row (may be NULL)
+ *   out_pairs[2*cap]     u32 (l, r) interleaved (may be NULL when cap == 0: count-only mode)
+ *   *n_pairs             total hits (always set; GPK_ERR_CAPACITY if > cap and pairs requested)
+ * `right_index` may be NULL (built on the fly like spatial_index.rs:60-71).
+ * `left_row_base` is added to every emitted l (row-sharded multi-GPU runs).
+ */
+int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right,
+                         const gpk_index* right_index, int32_t predicate, uint32_t left_row_base,
+                         uint32_t* out_counts, uint32_t* out_pairs, int64_t pair_capacity,
+                         int64_t* n_pairs, int32_t out_space, void* stream);
+
+/* ---- profiling hooks (bench.py's roofline leg) -------------------------------------------- */
+/* When enabled every kernel launch is bracketed by hipEvents on its stream. */
+int32_t gpk_profile_enable(int32_t on);
+int32_t gpk_profile_reset(void);
+/* accumulated milliseconds + launch count of kernels whose name contains `substr` */
+int32_t gpk_profile_query(const char* substr, double* out_ms, int64_t* out_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEOPOLARS_HIP_H */

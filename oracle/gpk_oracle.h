@@ -1,0 +1,79 @@
+/*
+ * gpk_oracle.h — CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C restatement of the algorithms GeoPolars' operator surface would call in its un-vendored
+ * dependencies (geo 0.27.0, geo-types 0.7.12, robust 1.1.0 — Cargo.lock:986-1004,2251), written
+ * from their published behaviour.  The reference tree itself holds no
+ * implementation of this path (every body in geopolars/geopolars-geo/src/geoseries.rs:184-278 is
+ * `todo!()`), and no Rust toolchain exists here, so there is no `oracle/_ref` build.
+ *
+ * PARITY PINNING: pinned only by the reference's in-tree known-answer vectors
+ * (geopolars/src/spatial_index.rs:361-484: KA-1 boundary-not-contained, KA-2 closed bbox, KA-3) and
+ * by exact rational arithmetic (tests/test_oracle_exact.py).  For area / centroid / distance /
+ * convex_hull / intersects the reference pins nothing: "parity unpinned" for those ops.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * Nothing under geopolars_amd/ imports, links or calls it.
+ */
+#ifndef GPK_ORACLE_H
+#define GPK_ORACLE_H
+
+#include <stdint.h>
+#include "../include/geopolars_hip.h" /* gpk_geoarrow_desc + GPK_* constants only */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* CoordPos of geo::coordinate_position */
+#define GPKO_OUTSIDE  0
+#define GPKO_BOUNDARY 1
+#define GPKO_INSIDE   2
+
+/* exact sign of orient2d(a, b, c): +1 CCW, -1 CW, 0 collinear (robust::orient2d semantics) */
+int32_t gpko_orient2d(double ax, double ay, double bx, double by, double cx, double cy);
+/* how many calls since load took the exact (expansion) path — test instrumentation */
+int64_t gpko_orient2d_exact_calls(void);
+
+/* coord_pos_relative_to_ring on a closed ring of n interleaved coords */
+int32_t gpko_coord_pos_ring(double cx, double cy, const double* xy, int64_t n);
+/* CoordPos of geometry g (POLYGON / MULTIPOLYGON array) for one coordinate */
+int32_t gpko_coord_pos_geom(const gpk_geoarrow_desc* a, int64_t g, double cx, double cy);
+
+int32_t gpko_line_intersects_line(const double a0[2], const double a1[2], const double b0[2],
+                                  const double b1[2]);
+
+/* predicate(a[ia], b[ib]) following the dispatch of spatial_index.rs:89-137 */
+int32_t gpko_predicate_pair(const gpk_geoarrow_desc* a, int64_t ia, const gpk_geoarrow_desc* b,
+                            int64_t ib, int32_t predicate);
+
+/* unary, whole array */
+int32_t gpko_area(const gpk_geoarrow_desc* a, double* out, int32_t is_signed);
+int32_t gpko_centroid(const gpk_geoarrow_desc* a, double* out_xy, uint8_t* out_valid);
+int32_t gpko_bounds(const gpk_geoarrow_desc* a, double* out4);
+int32_t gpko_euclidean_length(const gpk_geoarrow_desc* a, double* out);
+int32_t gpko_affine_transform(const gpk_geoarrow_desc* a, const double m[6], double* out_xy);
+int32_t gpko_convex_hull(const gpk_geoarrow_desc* a, double* out_xy, int32_t* out_ring_offsets);
+
+/* row-wise binary */
+int32_t gpko_distance_rowwise(const gpk_geoarrow_desc* a, const gpk_geoarrow_desc* b,
+                              const uint32_t* b_rows, double* out, int32_t n_threads);
+int32_t gpko_predicate_rowwise(const gpk_geoarrow_desc* a, const gpk_geoarrow_desc* b,
+                               const uint32_t* b_rows, int32_t predicate, uint8_t* out,
+                               int32_t n_threads);
+
+/*
+ * spatial join refine, sorted (l, r) pairs.  mode 0 = brute force (bbox reject for every pair),
+ * mode 1 = bbox grid directory standing in for the rstar R-tree of spatial_index.rs:74-76 (same
+ * candidates, since both enumerate exactly the bbox-overlapping pairs).  n_threads <= 0 -> all cores.
+ * out_pairs may be NULL (count only).  Returns the OpenMP thread count actually used in *used_threads.
+ */
+int32_t gpko_spatial_join(const gpk_geoarrow_desc* left, const gpk_geoarrow_desc* right,
+                          int32_t predicate, int32_t mode, int32_t n_threads, uint32_t* out_counts,
+                          uint32_t* out_pairs, int64_t pair_capacity, int64_t* n_pairs,
+                          int32_t* used_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,97 @@
+"""GPU parity: point-in-polygon spatial join through the C ABI vs the CPU
+oracle, bit-exact on counts and sorted (l, r) pairs."""
+import numpy as np
+import pytest
+
+from geopolars_amd import synth
+from geopolars_amd.geoarrow import GeoArrowArray
+from geopolars_amd.geoseries import GeoSeries
+from geopolars_amd.spatial_index import SpatialIndex, join_pairs
+
+pytestmark = pytest.mark.gpu
+
+KA1_POINTS = [(0.0, 10.0), (1.0, 1.0), (10.0, 1.0), (1.0, -1.0), (0.0, -10.0), (-1.0, -1.0), (-10.0, 0.0), (-1.0, 1.0), (0.0, 10.0)]
+KA1_SQUARE = [[[(0.0, 0.0), (20.0, 0.0), (20.0, 20.0), (0.0, 20.0)]]]
+
+
+def test_ka1_boundary_is_not_contained(gpk):
+    """spatial_join_test, spatial_index.rs:432-484: inner join has exactly 2 rows -> hits {1, 2};
+    both (0, 10) points lie on the edge x = 0 and must be rejected."""
+    pts = GeoSeries(GeoArrowArray.from_points(KA1_POINTS))
+    poly = GeoSeries(GeoArrowArray.from_polygons(KA1_SQUARE))
+    pairs, counts = join_pairs(pts, poly, "intersects")
+    assert pairs.tolist() == [[1, 0], [2, 0]]
+    assert counts.tolist() == [0, 1, 1, 0, 0, 0, 0, 0, 0]
+
+
+@pytest.mark.parametrize("n_points,n_polys,n_verts", [(1, 1, 3), (257, 7, 5), (50_000, 1000, 64), (200_000, 300, 17)])
+def test_c2_parity(gpk, oracle, n_points, n_polys, n_verts):
+    polys = synth.star_polygons(n_polys, n_verts)
+    pts = synth.uniform_points(n_points)
+    exp_pairs, exp_counts, _ = oracle.spatial_join(pts, polys, "intersects", mode=0)
+    got_pairs, got_counts = join_pairs(GeoSeries(pts), GeoSeries(polys), "intersects")
+    assert np.array_equal(got_counts, exp_counts)
+    assert np.array_equal(got_pairs, exp_pairs)
+
+
+def test_adversarial_points(gpk, oracle):
+    """vertices, edge midpoints, points level with vertices, bbox corners: every degenerate arm of
+    coord_pos_relative_to_ring, including the exact-arithmetic fallback."""
+    polys = synth.star_polygons(64, 64)
+    pts = synth.adversarial_points(polys)
+    exp_pairs, exp_counts, _ = oracle.spatial_join(pts, polys, "contains", mode=0)
+    got_pairs, got_counts = join_pairs(GeoSeries(pts), GeoSeries(polys), "contains")
+    assert np.array_equal(got_counts, exp_counts)
+    assert np.array_equal(got_pairs, exp_pairs)
+
+
+def test_axis_aligned_and_collinear(gpk, oracle):
+    """integer lattice points against rectangles / an L-shape with horizontal and vertical edges and
+    a hole: on-edge, on-vertex, collinear-with-horizontal-edge cases are all exact."""
+    polys = GeoArrowArray.from_polygons(
+        [
+            [[(0, 0), (4, 0), (4, 4), (0, 4)], [(1, 1), (1, 3), (3, 3), (3, 1)]],
+            [[(5, 0), (9, 0), (9, 2), (7, 2), (7, 4), (5, 4)]],
+            [[(2, 2), (6, 2), (6, 6), (2, 6)]],  # overlaps the other two: multi-hit rows
+        ]
+    )
+    gx, gy = np.meshgrid(np.arange(-1, 11, 0.5), np.arange(-1, 8, 0.5))
+    pts = GeoArrowArray.from_points(np.stack([gx.ravel(), gy.ravel()], axis=1))
+    exp_pairs, exp_counts, _ = oracle.spatial_join(pts, polys, "intersects", mode=0)
+    got_pairs, got_counts = join_pairs(GeoSeries(pts), GeoSeries(polys), "intersects")
+    assert exp_counts.max() >= 2
+    assert np.array_equal(got_counts, exp_counts)
+    assert np.array_equal(got_pairs, exp_pairs)
+
+
+def test_multipolygons_with_holes(gpk, oracle):
+    mp = synth.powerlaw_multipolygons(500)
+    pts = synth.uniform_points(100_000)
+    exp_pairs, exp_counts, _ = oracle.spatial_join(pts, mp, "within", mode=1)
+    got_pairs, got_counts = join_pairs(GeoSeries(pts), GeoSeries(mp), "within")
+    assert len(exp_pairs) > 0
+    assert np.array_equal(got_counts, exp_counts)
+    assert np.array_equal(got_pairs, exp_pairs)
+
+
+def test_prebuilt_index_and_row_base(gpk, oracle):
+    """spatial_join_test_with_precomputed_indexes (spatial_index.rs:558-624) + the row base used by
+    row-sharded runs."""
+    polys = GeoSeries(synth.star_polygons(100, 16))
+    pts = synth.uniform_points(10_000)
+    idx = SpatialIndex(polys)
+    a, ca = join_pairs(GeoSeries(pts), polys, "intersects", r_index=idx)
+    b, cb = join_pairs(GeoSeries(pts), polys, "intersects")
+    assert np.array_equal(a, b) and np.array_equal(ca, cb)
+    c, _ = join_pairs(GeoSeries(pts), polys, "intersects", r_index=idx, left_row_base=1000)
+    assert np.array_equal(c[:, 0], a[:, 0] + 1000) and np.array_equal(c[:, 1], a[:, 1])
+
+
+def test_empty_and_nan_inputs(gpk):
+    polys = GeoSeries(synth.star_polygons(10, 8))
+    empty = GeoSeries(GeoArrowArray.from_points(np.zeros((0, 2))))
+    pairs, counts = join_pairs(empty, polys)
+    assert pairs.shape == (0, 2) and counts.shape == (0,)
+    nanpts = GeoSeries(GeoArrowArray.from_points([[np.nan, np.nan], [np.nan, 1.0]]))
+    pairs, counts = join_pairs(nanpts, polys)
+    assert pairs.shape == (0, 2) and counts.tolist() == [0, 0]

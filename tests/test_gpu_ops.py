@@ -1,0 +1,177 @@
+"""GPU parity for the streaming / row-wise operators through the C ABI vs the
+CPU oracle.  Tolerances: f64 results within 1e-9 relative (north star); affine and bounds are
+bit-exact (no reduction-order freedom); booleans bit-exact."""
+import numpy as np
+import pytest
+
+from geopolars_amd import synth
+from geopolars_amd.geoarrow import GeoArrowArray
+from geopolars_amd.geoseries import GeoSeries
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+
+
+def _close(got, exp, rtol=RTOL):
+    got, exp = np.asarray(got), np.asarray(exp)
+    assert got.shape == exp.shape
+    nan_g, nan_e = np.isnan(got), np.isnan(exp)
+    assert np.array_equal(nan_g, nan_e)
+    g, e = got[~nan_g], exp[~nan_e]
+    scale = np.maximum(np.abs(e), 1e-300)
+    bad = np.abs(g - e) > rtol * scale
+    assert not bad.any(), f"max rel err {np.max(np.abs(g - e) / scale):.3e}"
+
+
+def _arrays():
+    return {
+        "stars": synth.star_polygons(300, 64),
+        "tri": synth.star_polygons(1000, 3),
+        "clustered": synth.clustered_polygons(2000),
+        "multipoly": synth.powerlaw_multipolygons(1500),
+        "lines": synth.random_linestrings(800),
+        "points": synth.uniform_points(5000),
+        "holes": GeoArrowArray.from_polygons(
+            [
+                [[(0, 0), (10, 0), (10, 10), (0, 10)], [(2, 2), (2, 8), (8, 8), (8, 2)]],
+                [[(0, 0), (0, 5), (5, 5), (5, 0)]],  # clockwise exterior
+                [[(1, 1), (2, 2), (3, 3), (1, 1)]],  # zero-area ring -> linestring centroid
+                [[(4, 4), (4, 4), (4, 4), (4, 4)]],  # all-identical ring -> point centroid
+                [],  # empty polygon
+            ]
+        ),
+    }
+
+
+@pytest.mark.parametrize("name", list(_arrays()))
+def test_area_length_bounds_centroid(gpk, oracle, name):
+    a = _arrays()[name]
+    s = GeoSeries(a)
+    _close(s.area(), oracle.area(a))
+    _close(s.signed_area(), oracle.area(a, signed=True))
+    _close(s.euclidean_length(), oracle.euclidean_length(a))
+    got_b, exp_b = s.bounds(), oracle.bounds(a)
+    assert np.array_equal(got_b, exp_b, equal_nan=True)  # min/max: bit exact
+    exp_c, exp_v = oracle.centroid(a)
+    _close(s.centroid().array.xy, exp_c)
+
+
+@pytest.mark.parametrize("name", ["stars", "multipoly", "lines", "points"])
+def test_affine_bit_exact(gpk, oracle, name):
+    a = _arrays()[name]
+    m = [0.8660254037844387, -0.5, 12.25, 0.5, 0.8660254037844387, -3.125]
+    got = GeoSeries(a).affine_transform(m).array.xy
+    assert np.array_equal(got, oracle.affine_transform(a, m))
+    t = GeoSeries(a).translate(10.0, 10.0).array.xy  # benches/affine.rs:25
+    assert np.array_equal(t, oracle.affine_transform(a, [1, 0, 10.0, 0, 1, 10.0]))
+
+
+def _canon(ring):
+    ring = ring[:-1] if len(ring) > 1 and np.array_equal(ring[0], ring[-1]) else ring
+    if len(ring) == 0:
+        return ring
+    k = np.lexsort((ring[:, 1], ring[:, 0]))[0]
+    return np.roll(ring, -k, axis=0)
+
+
+@pytest.mark.parametrize("name", ["stars", "multipoly", "lines", "holes"])
+def test_convex_hull(gpk, oracle, name):
+    a = _arrays()[name]
+    exp_xy, exp_off = oracle.convex_hull(a)
+    h = GeoSeries(a).convex_hull().array
+    assert np.array_equal(h.ring_offsets, exp_off)
+    for g in range(len(a)):
+        got = _canon(h.xy[h.ring_offsets[g] : h.ring_offsets[g + 1]])
+        exp = _canon(exp_xy[exp_off[g] : exp_off[g + 1]])
+        assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("other", ["lines", "stars", "multipoly", "holes", "points"])
+def test_distance_rowwise(gpk, oracle, other):
+    b = _arrays()[other]
+    pts = synth.uniform_points(20_000)
+    rows = (np.arange(len(pts)) % len(b)).astype(np.uint32)
+    exp = oracle.distance_rowwise(pts, b, rows)
+    got = GeoSeries(pts).distance(GeoSeries(b), rows)
+    _close(got, exp)
+    shuffled = np.random.default_rng(5).permutation(rows)
+    _close(GeoSeries(pts).distance(GeoSeries(b), shuffled), oracle.distance_rowwise(pts, b, shuffled))
+
+
+def test_distance_points_on_lines(gpk, oracle):
+    """vertices and (numerically) on-segment points: the f64::EPSILON short-circuit of
+    line_string_contains_point must fire identically."""
+    ls = synth.random_linestrings(200)
+    off = ls.geom_offsets
+    rows, pts = [], []
+    for i in range(len(ls)):
+        v = ls.xy[off[i] : off[i + 1]]
+        pts += [v[0], v[-1], (v[0] + v[1]) / 2.0, v[1] + (v[2] - v[1]) * 0.25]
+        rows += [i] * 4
+    p = GeoArrowArray.from_points(np.array(pts))
+    rows = np.array(rows, dtype=np.uint32)
+    exp = oracle.distance_rowwise(p, ls, rows)
+    got = GeoSeries(p).distance(GeoSeries(ls), rows)
+    assert np.array_equal(got == 0.0, exp == 0.0)
+    _close(got, exp)
+
+
+def test_distance_swapped_and_identity(gpk, oracle):
+    ls = synth.random_linestrings(3000)
+    pts = synth.uniform_points(3000)
+    exp = oracle.distance_rowwise(pts, ls)
+    _close(GeoSeries(pts).distance(GeoSeries(ls)), exp)
+    _close(GeoSeries(ls).distance(GeoSeries(pts)), exp)
+
+
+@pytest.mark.parametrize("pred", ["contains", "within", "intersects"])
+def test_predicates_rowwise_point_polygon(gpk, oracle, pred):
+    polys = _arrays()["holes"]
+    gx, gy = np.meshgrid(np.arange(-1, 12, 0.5), np.arange(-1, 12, 0.5))
+    pts = GeoArrowArray.from_points(np.stack([gx.ravel(), gy.ravel()], axis=1))
+    rows = (np.arange(len(pts)) % len(polys)).astype(np.uint32)
+    if pred == "contains":  # contains(polygon_row, point): polygons on the left need equal lengths
+        polys_rep = synth.star_polygons(len(pts), 9)
+        exp = oracle.predicate_rowwise(polys_rep, pts, pred)
+        got = GeoSeries(polys_rep).contains(GeoSeries(pts))
+    else:
+        exp = oracle.predicate_rowwise(pts, polys, pred, rows)
+        got = getattr(GeoSeries(pts), pred)(GeoSeries(polys), rows)
+    assert np.array_equal(got, exp)
+
+
+def test_predicate_within_large(gpk, oracle):
+    mp = synth.powerlaw_multipolygons(3000)
+    c, _ = oracle.centroid(mp)
+    # half the points sit at a member centroid's neighbourhood, half are random
+    pts = synth.uniform_points(len(mp)).xy
+    pts[::2] = c[::2]
+    p = GeoArrowArray.from_points(pts)
+    for pred in ("within", "intersects"):
+        exp = oracle.predicate_rowwise(p, mp, pred)
+        got = getattr(GeoSeries(p), pred)(GeoSeries(mp))
+        assert exp.any()
+        assert np.array_equal(got, exp)
+
+
+def test_intersects_polygon_polygon(gpk, oracle):
+    a = synth.clustered_polygons(4000, seed=11, mean_neighbours=40.0)
+    b = synth.clustered_polygons(4000, seed=12, mean_neighbours=40.0)
+    rows = np.random.default_rng(3).integers(0, len(b), len(a)).astype(np.uint32)
+    # re-pair every other row with a bbox-overlapping partner so that both outcomes are well covered
+    ba, bb = oracle.bounds(a), oracle.bounds(b)
+    order = np.argsort(bb[:, 0])
+    pos = np.searchsorted(bb[order, 0], ba[:, 0])
+    near = order[np.clip(pos, 0, len(b) - 1)]
+    rows[::2] = near[::2]
+    exp = oracle.predicate_rowwise(a, b, "intersects", rows)
+    assert 0.02 < exp.mean() < 0.98
+    got = GeoSeries(a).intersects(GeoSeries(b), rows)
+    assert np.array_equal(got, exp)
+    same = GeoSeries(a).intersects(GeoSeries(a))
+    assert same.all()
+    nested = GeoArrowArray.from_polygons([[[(0, 0), (10, 0), (10, 10), (0, 10)]], [[(0, 0), (10, 0), (10, 10), (0, 10)]], [[(0, 0), (1, 0), (1, 1), (0, 1)]]])
+    inner = GeoArrowArray.from_polygons([[[(4, 4), (5, 4), (5, 5), (4, 5)]], [[(10, 10), (11, 10), (11, 11), (10, 11)]], [[(2, 2), (3, 2), (3, 3), (2, 3)]]])
+    assert GeoSeries(nested).intersects(GeoSeries(inner)).tolist() == [True, True, False]
+    assert oracle.predicate_rowwise(nested, inner, "intersects").tolist() == [True, True, False]
