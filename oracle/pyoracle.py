@@ -158,16 +158,20 @@ def predicate_rowwise(a: GeoArrowArray, b: GeoArrowArray, predicate: str, b_rows
     return out.astype(bool)
 
 
-def spatial_join(left: GeoArrowArray, right: GeoArrowArray, predicate: str = "intersects", mode: int = 1, n_threads: int = 0):
-    """-> (pairs (H,2) uint32 sorted by (l, r), counts (n_left,) uint32, threads used)."""
+def spatial_join(left: GeoArrowArray, right: GeoArrowArray, predicate: str = "intersects", mode: int = 1, n_threads: int = 0, capacity: int = -1):
+    """-> (pairs (H,2) uint32 sorted by (l, r), counts (n_left,) uint32, threads used).
+    With `capacity` >= 0 the join runs ONCE into a buffer of that many pairs (timing runs); otherwise a
+    count-only call sizes the buffer first."""
     L = lib()
     dl, dr = left.desc(), right.desc()
     counts = np.empty(len(left), dtype=np.uint32)
     n_pairs = C.c_int64(0)
     used = C.c_int32(0)
-    rc = L.gpko_spatial_join(C.byref(dl), C.byref(dr), PREDICATES[predicate], mode, n_threads, counts.ctypes.data, None, 0, C.byref(n_pairs), C.byref(used))
-    _ok(rc, "spatial_join(count)")
-    pairs = np.empty((int(n_pairs.value), 2), dtype=np.uint32)
+    if capacity < 0:
+        rc = L.gpko_spatial_join(C.byref(dl), C.byref(dr), PREDICATES[predicate], mode, n_threads, counts.ctypes.data, None, 0, C.byref(n_pairs), C.byref(used))
+        _ok(rc, "spatial_join(count)")
+        capacity = int(n_pairs.value)
+    pairs = np.empty((capacity, 2), dtype=np.uint32)
     rc = L.gpko_spatial_join(C.byref(dl), C.byref(dr), PREDICATES[predicate], mode, n_threads, counts.ctypes.data, pairs.ctypes.data, len(pairs), C.byref(n_pairs), C.byref(used))
     _ok(rc, "spatial_join")
-    return pairs, counts, int(used.value)
+    return pairs[: int(n_pairs.value)], counts, int(used.value)
