@@ -1,0 +1,96 @@
+"""world_size-2 gloo tests of the N>1 path: row sharding, the right-side all-gatherv
+with offset rebasing, the broadcast of a replicated right side, and shard/concat equivalence of the
+join on the CPU oracle (K = 2, 4, 8 shards == unsharded)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from geopolars_amd import synth
+from geopolars_amd.dist import shard_rows, slice_rows
+from geopolars_amd.geoarrow import GeoArrowArray
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _same(a: GeoArrowArray, b: GeoArrowArray) -> bool:
+    if a.geom_type != b.geom_type or not np.array_equal(a.xy, b.xy):
+        return False
+    for k in ("geom_offsets", "part_offsets", "ring_offsets"):
+        x, y = getattr(a, k), getattr(b, k)
+        if (x is None) != (y is None) or (x is not None and not np.array_equal(x, y)):
+            return False
+    return True
+
+
+def _worker(rank: int, world: int, port: int, kind: str, q):
+    import torch.distributed as dist
+
+    from geopolars_amd.dist import all_gatherv_geoarray, broadcast_geoarray
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        full = {"multipoly": lambda: synth.powerlaw_multipolygons(301), "poly": lambda: synth.star_polygons(57, 9), "lines": lambda: synth.random_linestrings(40), "points": lambda: synth.uniform_points(33)}[kind]()
+        w = np.diff(full.geom_offsets) if full.geom_offsets is not None else None
+        lo, hi = shard_rows(len(full), world, rank, weights=w)
+        local = slice_rows(full, lo, hi)
+        got = all_gatherv_geoarray(local)
+        ok = _same(got, full)
+        rep = broadcast_geoarray(full if rank == 0 else None, 0)
+        ok = ok and _same(rep, full)
+        q.put((rank, ok, lo, hi))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["multipoly", "poly", "lines", "points"])
+def test_all_gatherv_and_broadcast_world2(kind):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, kind, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in res), res
+    spans = sorted((lo, hi) for _, _, lo, hi in res)
+    assert spans[0][0] == 0 and spans[0][1] == spans[1][0]
+
+
+def test_shard_rows_balances_weight():
+    w = np.array([1] * 90 + [1000] * 10)
+    cuts = [shard_rows(100, 4, r, w) for r in range(4)]
+    assert cuts[0][0] == 0 and cuts[-1][1] == 100
+    assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+    loads = [w[lo:hi].sum() for lo, hi in cuts]
+    assert max(loads) <= 2 * (w.sum() / 4) + 1000
+    assert [shard_rows(10, 3, r) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
+
+
+@pytest.mark.parametrize("k", [2, 4, 8])
+def test_row_sharded_join_equals_unsharded(oracle, k):
+    """outputs of row shards are disjoint: concat(shard results with left_row_base) == unsharded."""
+    polys = synth.star_polygons(120, 16)
+    pts = synth.uniform_points(20_000)
+    full_pairs, full_counts, _ = oracle.spatial_join(pts, polys, "intersects", mode=1)
+    parts, counts = [], []
+    for r in range(k):
+        lo, hi = shard_rows(len(pts), k, r)
+        p, c, _ = oracle.spatial_join(slice_rows(pts, lo, hi), polys, "intersects", mode=1)
+        p = p.copy()
+        p[:, 0] += lo
+        parts.append(p)
+        counts.append(c)
+    assert np.array_equal(np.concatenate(parts), full_pairs)
+    assert np.array_equal(np.concatenate(counts), full_counts)

@@ -1,0 +1,233 @@
+"""Pins the CPU oracle (test infrastructure) before anything is compared against it:
+  * exact rational arithmetic (fractions.Fraction) for the orientation kernel, including the
+    inputs that force the expansion-arithmetic path;
+  * the reference's in-tree known-answer vectors (geopolars/src/spatial_index.rs:361-484):
+      KA-1 spatial_join_test        -> boundary is NOT contained, exactly 2 hits {1, 2}
+      KA-2 spatial_index_points     -> bbox tests are closed intervals
+      KA-3 spatial_index_polygons   -> envelope values
+  * an independent pure-Python restatement of coord_pos_relative_to_ring on rational inputs.
+"""
+from fractions import Fraction
+
+import numpy as np
+import pytest
+from hypothesis import given, settings
+from hypothesis import strategies as st
+
+from geopolars_amd.geoarrow import GeoArrowArray
+
+F = Fraction
+
+
+def exact_orient(a, b, c) -> int:
+    det = (F(a[0]) - F(c[0])) * (F(b[1]) - F(c[1])) - (F(a[1]) - F(c[1])) * (F(b[0]) - F(c[0]))
+    return (det > 0) - (det < 0)
+
+
+def test_orient2d_simple(oracle):
+    assert oracle.orient2d((0, 0), (1, 0), (0, 1)) == 1
+    assert oracle.orient2d((0, 0), (0, 1), (1, 0)) == -1
+    assert oracle.orient2d((0, 0), (1, 1), (2, 2)) == 0
+
+
+def test_orient2d_adversarial_matches_rationals(oracle):
+    """Shewchuk's classic near-degenerate grid: points within a few ulps of a line."""
+    before = oracle.lib().gpko_orient2d_exact_calls()
+    rng = np.random.default_rng(7)
+    checked = 0
+    for _ in range(300):
+        b = (12.0 + rng.uniform(-1, 1), 12.0 + rng.uniform(-1, 1))
+        c = (24.0 + rng.uniform(-1, 1), 24.0 + rng.uniform(-1, 1))
+        t = rng.uniform(0, 1)
+        base = (b[0] + t * (c[0] - b[0]), b[1] + t * (c[1] - b[1]))
+        for i in range(-3, 4):
+            for j in range(-3, 4):
+                a = (float(np.nextafter(base[0], np.inf) if i > 0 else base[0]) + i * np.spacing(base[0]),
+                     base[1] + j * np.spacing(base[1]))
+                assert oracle.orient2d(a, b, c) == exact_orient(a, b, c)
+                checked += 1
+    assert checked > 10_000
+    assert oracle.lib().gpko_orient2d_exact_calls() > before, "the exact path was never exercised"
+
+
+@settings(max_examples=300, deadline=None)
+@given(
+    st.lists(
+        # error-free products hold "barring over/underflow" (Shewchuk; robust 1.1 has the same domain):
+        # keep magnitudes where no product of two coordinates leaves the normal range
+        st.floats(min_value=-1e6, max_value=1e6, allow_nan=False, width=64).filter(lambda x: x == 0.0 or abs(x) > 1e-100),
+        min_size=6,
+        max_size=6,
+    )
+)
+def test_orient2d_random_matches_rationals(oracle, v):
+    a, b, c = (v[0], v[1]), (v[2], v[3]), (v[4], v[5])
+    assert oracle.orient2d(a, b, c) == exact_orient(a, b, c)
+
+
+@settings(max_examples=200, deadline=None)
+@given(st.integers(-50, 50), st.integers(-50, 50), st.integers(1, 40), st.integers(-30, 30), st.integers(0, 60))
+def test_orient2d_exactly_collinear_scaled(oracle, x0, y0, dx, dy, k):
+    """exactly collinear triples with awkward scalings (thirds, sevenths are not representable, so build
+    them from integers scaled by powers of two)."""
+    s = 2.0 ** -20
+    a = (x0 * s, y0 * s)
+    b = ((x0 + dx) * s, (y0 + dy) * s)
+    c = ((x0 + k * dx) * s, (y0 + k * dy) * s)
+    assert oracle.orient2d(a, b, c) == 0
+    assert exact_orient(a, b, c) == 0
+
+
+# ---- independent restatement of coord_pos_relative_to_ring on exact rationals -----------------------------
+def py_ring_pos(c, ring) -> int:
+    if len(ring) == 0:
+        return 0
+    if len(ring) == 1:
+        return 1 if tuple(c) == tuple(ring[0]) else 0
+    wn = 0
+    for (sx, sy), (ex, ey) in zip(ring[:-1], ring[1:]):
+        if sy <= c[1]:
+            if ey >= c[1]:
+                o = exact_orient((sx, sy), (ex, ey), c)
+                if o > 0 and ey != c[1]:
+                    wn += 1
+                elif o == 0 and min(sx, ex) <= c[0] <= max(sx, ex):
+                    return 1
+        elif ey <= c[1]:
+            o = exact_orient((sx, sy), (ex, ey), c)
+            if o < 0:
+                wn -= 1
+            elif o == 0 and min(sx, ex) <= c[0] <= max(sx, ex):
+                return 1
+    return 2 if wn != 0 else 0
+
+
+RINGS = {
+    "square": [(0, 0), (20, 0), (20, 20), (0, 20), (0, 0)],
+    "square_cw": [(0, 0), (0, 20), (20, 20), (20, 0), (0, 0)],
+    "L": [(0, 0), (8, 0), (8, 2), (2, 2), (2, 8), (0, 8), (0, 0)],
+    "spike": [(0, 0), (4, 0), (4, 4), (2, 4), (2, 6), (2, 4), (0, 4), (0, 0)],
+    "tri": [(0, 0), (7, 3), (3, 9), (0, 0)],
+}
+
+
+@pytest.mark.parametrize("name", list(RINGS))
+def test_coord_pos_ring_lattice(oracle, name):
+    ring = [(float(x), float(y)) for x, y in RINGS[name]]
+    arr = np.array(ring)
+    for x in np.arange(-1, 22, 0.5):
+        for y in np.arange(-1, 22, 0.5):
+            assert oracle.coord_pos_ring((x, y), arr) == py_ring_pos((x, y), ring), (name, x, y)
+
+
+def test_coord_pos_ring_degenerate(oracle):
+    assert oracle.coord_pos_ring((0, 0), np.zeros((0, 2))) == 0
+    assert oracle.coord_pos_ring((1, 2), np.array([[1.0, 2.0]])) == 1
+    assert oracle.coord_pos_ring((1, 3), np.array([[1.0, 2.0]])) == 0
+
+
+# ---- reference known-answer vectors ------------------------------------------------------------
+KA_POINTS = [(0.0, 10.0), (1.0, 1.0), (10.0, 1.0), (1.0, -1.0), (0.0, -10.0), (-1.0, -1.0), (-10.0, 0.0), (-1.0, 1.0), (0.0, 10.0)]
+
+
+def test_ka1_spatial_join_boundary_not_contained(oracle):
+    """spatial_index.rs:432-484: inner join shape (2, 4), left join 9 rows."""
+    pts = GeoArrowArray.from_points(KA_POINTS)
+    poly = GeoArrowArray.from_polygons([[[(0.0, 0.0), (20.0, 0.0), (20.0, 20.0), (0.0, 20.0)]]])
+    for mode in (0, 1):
+        for pred in ("intersects", "contains", "within"):  # Point x Polygon ignores the predicate (spatial_index.rs:91-96)
+            pairs, counts, _ = oracle.spatial_join(pts, poly, pred, mode=mode)
+            assert pairs.tolist() == [[1, 0], [2, 0]]
+            assert counts.tolist() == [0, 1, 1, 0, 0, 0, 0, 0, 0]
+    # the two (0, 10) points are ON the edge x = 0
+    assert oracle.coord_pos_geom(poly, 0, (0.0, 10.0)) == 1
+
+
+def test_ka2_bbox_is_closed_interval(oracle):
+    """spatial_index.rs:361-395 uses points 2 = (10, 0); locate_in_envelope([0,0]-[20,20]) returns
+    {0, 1, 2, 8}: points ON the box edge are inside the closed envelope."""
+    pts = list(KA_POINTS)
+    pts[2] = (10.0, 0.0)
+    b = oracle.bounds(GeoArrowArray.from_points(pts))
+    inside = [i for i, (x0, y0, x1, y1) in enumerate(b) if x0 >= 0 and y0 >= 0 and x1 <= 20 and y1 <= 20]
+    assert inside == [0, 1, 2, 8]
+
+
+def test_ka3_polygon_envelopes(oracle):
+    """spatial_index.rs:397-430: only polygon 0 lies inside [0,0]-[20,20]."""
+    polys = GeoArrowArray.from_polygons(
+        [[[(0.0, 0.0), (10.0, 0.0), (10.0, 10.0), (0.0, 10.0)]], [[(0.0, 0.0), (-10.0, 0.0), (-10.0, -10.0), (0.0, -10.0)]]]
+    )
+    b = oracle.bounds(polys)
+    assert b.tolist() == [[0.0, 0.0, 10.0, 10.0], [-10.0, -10.0, 0.0, 0.0]]
+    inside = [i for i, (x0, y0, x1, y1) in enumerate(b) if x0 >= 0 and y0 >= 0 and x1 <= 20 and y1 <= 20]
+    assert inside == [0]
+
+
+# ---- semantic properties (SURVEY.md §8c "extra pins") -----------------------------------------------
+def test_join_grid_equals_bruteforce(oracle):
+    from geopolars_amd import synth
+
+    polys = synth.star_polygons(200, 24)
+    pts = synth.uniform_points(30_000)
+    a = oracle.spatial_join(pts, polys, "intersects", mode=0)
+    b = oracle.spatial_join(pts, polys, "intersects", mode=1)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_translation_invariance_and_within_is_contains_swapped(oracle):
+    from geopolars_amd import synth
+
+    polys = synth.star_polygons(64, 12)
+    pts = synth.uniform_points(4096)
+    rows = (np.arange(len(pts)) % len(polys)).astype(np.uint32)
+    w = oracle.predicate_rowwise(pts, polys, "within", rows)
+    # exact translation by a power of two keeps every coordinate difference bit-identical
+    sh = 1024.0
+    polys2 = GeoArrowArray(polys.geom_type, polys.xy + sh, polys.geom_offsets, ring_offsets=polys.ring_offsets)
+    pts2 = GeoArrowArray.from_points(pts.xy + sh)
+    assert np.array_equal(oracle.predicate_rowwise(pts2, polys2, "within", rows), w)
+    i = oracle.predicate_rowwise(pts, polys, "intersects", rows)
+    assert not (w & ~i).any()  # within implies intersects
+
+
+def test_area_and_centroid_known_values(oracle):
+    a = GeoArrowArray.from_polygons(
+        [
+            [[(0, 0), (10, 0), (10, 10), (0, 10)], [(2, 2), (2, 8), (8, 8), (8, 2)]],
+            [[(0, 0), (0, 5), (5, 5), (5, 0)]],
+            [[(0, 0), (4, 0), (0, 3)]],
+        ]
+    )
+    assert oracle.area(a).tolist() == [64.0, 25.0, 6.0]
+    assert oracle.area(a, signed=True).tolist() == [64.0, -25.0, 6.0]
+    c, v = oracle.centroid(a)
+    assert np.allclose(c, [[5.0, 5.0], [2.5, 2.5], [4.0 / 3.0, 1.0]], rtol=1e-15)
+    assert oracle.euclidean_length(a).tolist() == [40.0, 20.0, 12.0]
+
+
+def test_line_intersects_line_cases(oracle):
+    L = oracle.line_intersects_line
+    assert L((0, 0), (2, 2), (0, 2), (2, 0))  # proper crossing
+    assert L((0, 0), (2, 0), (2, 0), (3, 5))  # touching endpoints
+    assert L((0, 0), (4, 0), (2, 0), (6, 0))  # collinear overlap
+    assert not L((0, 0), (1, 0), (2, 0), (3, 0))  # collinear disjoint
+    assert not L((0, 0), (1, 1), (2, 0), (3, 1))  # parallel
+    assert L((1, 1), (1, 1), (0, 0), (2, 2))  # degenerate point on the other segment
+    assert not L((1, 2), (1, 2), (0, 0), (2, 2))
+
+
+def test_distance_known_values(oracle):
+    ls = GeoArrowArray.from_linestrings([[(0, 0), (10, 0)], [(0, 0), (10, 0)], [(0, 0), (10, 0)], [(0, 0), (10, 0)]])
+    pts = GeoArrowArray.from_points([(5, 3), (-3, 4), (13, -4), (7, 0)])
+    assert oracle.distance_rowwise(pts, ls).tolist() == [3.0, 5.0, 5.0, 0.0]
+    poly = GeoArrowArray.from_polygons([[[(0, 0), (10, 0), (10, 10), (0, 10)], [(4, 4), (4, 6), (6, 6), (6, 4)]]] * 3)
+    p2 = GeoArrowArray.from_points([(5, 5), (2, 2), (13, 14)])
+    assert oracle.distance_rowwise(p2, poly).tolist() == [1.0, 0.0, 5.0]
+
+
+def test_convex_hull_square_with_interior_and_collinear(oracle):
+    a = GeoArrowArray.from_linestrings([[(0, 0), (2, 0), (4, 0), (4, 4), (2, 2), (0, 4), (2, 4), (1, 1)]])
+    xy, off = oracle.convex_hull(a)
+    assert off.tolist() == [0, 5]
+    assert xy.tolist() == [[0, 0], [4, 0], [4, 4], [0, 4], [0, 0]]  # CCW, closed, collinear dropped
