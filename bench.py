@@ -124,7 +124,7 @@ def main() -> None:
         lib.gpk_profile_query(name.encode(), C.byref(ms), C.byref(cnt))
         return (ms.value / max(cnt.value, 1), int(cnt.value))
 
-    k_count, n_count = kernel_ms("gpk_pip_count")
+    k_count, n_count = kernel_ms("gpk_pip_tile")
     k_write, _ = kernel_ms("gpk_pip_write")
     k_scan, _ = kernel_ms("gpk_scan_totals")
     lib.gpk_profile_reset()
@@ -137,7 +137,7 @@ def main() -> None:
     evals = float(world) * n * m * args.steps
     ms_per_step = elapsed / args.steps * 1e3
     v_total = polys_host.n_coords
-    # algorithmic bytes of the dominant launch (gpk_pip_count): points in, polygon coords + offsets in,
+    # algorithmic bytes of the dominant launch (gpk_pip_tile): points in, polygon coords + offsets in,
     # hit counts out — each distinct byte once (the 8H pair bytes belong to gpk_pip_write)
     bytes_count = 16 * n + 16 * v_total + 2 * 4 * (m + 1) + 4 * n
     bytes_join = bytes_count + 8 * h
@@ -168,11 +168,11 @@ def main() -> None:
             "cus": cus,
             "join_bytes_per_step": bytes_join,
             "join_GBps_end_to_end": bytes_join / (ms_per_step * 1e-3) / 1e9,
-            "kernel_ms": {"gpk_pip_count": k_count, "gpk_scan_totals": k_scan, "gpk_pip_write": k_write},
+            "kernel_ms": {"gpk_pip_tile": k_count, "gpk_scan_totals": k_scan, "gpk_pip_write": k_write},
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "gpk_pip_count",
+            "kernel": "gpk_pip_tile",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",

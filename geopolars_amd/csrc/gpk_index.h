@@ -26,6 +26,32 @@ struct IndexView {  // passed to kernels by value
     int32_t gx, gy;
 };
 
+// ---- point-in-polygon accelerator (polygonal arrays only) -----------------------------------------
+// A fine R x R raster over the (padded) extent plus per-ring edge slabs on the raster rows.
+//   cell word  : tag(2) | payload(30).  tag 0 = no polygon can contain a point of this cell;
+//                tag 1 = exactly one entry, inline; tag 2 = payload is an offset into `list`
+//                (list[off] = n, then n entries).
+//   entry      : part << 1 | boundary.  boundary = 0 means EVERY representable point that maps to this
+//                cell is strictly inside that part (holes included) — decided once, exactly, at build
+//                time; boundary = 1 means some edge of the part may touch the cell: run the exact test.
+//   slabs      : for ring r and raster row j in [row0[r], row0[r] + nrows) the list of edges whose closed
+//                y-range meets the row (under the same monotone row function the points use), stored as
+//                contiguous double4 (sx, sy, ex, ey) records -> 8 lanes read one slab with 2 cache lines.
+// Exactness does not depend on the raster: it only routes points; every boundary decision is made by
+// the exact winding walk over the slab's edges, which are a superset of the edges that can count.
+struct PipView {
+    int32_t R;  // 0 = accelerator not built (degenerate extent): kernels use the generic walk
+    double rx0, ry0, fw, fh, inv_fw, inv_fh;
+    const uint32_t* cell;
+    const uint32_t* list;
+    const uint32_t* part_geom;       // nullptr for POLYGON arrays (part == geometry)
+    const int32_t* ring_row0;
+    const int32_t* ring_slab_base;   // n_rings + 1
+    const int32_t* slab_off;         // n_slabs + 1
+    const double4* slab_edges;
+};
+constexpr uint32_t CELL_TAG_EMPTY = 0u, CELL_TAG_SINGLE = 1u, CELL_TAG_LIST = 2u;
+
 namespace dev {
 // Monotone non-decreasing in v (subtract, multiply by a non-negative constant, floor, clamp), so
 // minx <= px <= maxx implies cell(minx) <= cell(px) <= cell(maxx): no candidate can be missed.
@@ -41,9 +67,18 @@ __device__ __forceinline__ int cell_of(double v, double v0, double inv, int g) {
 
 struct gpk_index {
     gpk::IndexView v;
+    gpk::PipView pip;
+    gpk::GridParams host_grid;
     int device;
     int64_t n_geoms;
     int32_t geom_type;
-    void* owned[4];  // bbox, grid, cell_off, items
+    void* owned[12];  // bbox, grid, cell_off, items, then the PipView tables
     int64_t nbytes;
 };
+
+namespace gpk {
+// gpk_pipindex.hip: builds ix->pip for a polygonal array (no-op otherwise).  ix->v must be complete.
+int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s);
+// gpk_unary.hip: closed bbox of every coordinate sequence (ring) as AoS double4; NaN for empty ones
+int32_t ring_bboxes(const gpk_geoarray* a, double4* out_dev, hipStream_t s);
+}  // namespace gpk

@@ -13,6 +13,7 @@
 //                only rows with more than one hit re-run the predicate.
 #include "gpk_device.h"
 #include "gpk_index.h"
+#include "gpk_pip.h"
 #include "gpk_scan.h"
 
 namespace gpk {
@@ -99,7 +100,12 @@ __global__ void cell_sort_kernel(const int32_t* __restrict__ cell_off, int64_t n
 }
 
 // ================================= point-in-polygon join =========================================
-constexpr int PIP_BLOCK = 256;
+constexpr int PIP_BLOCK = 256;              // threads per work-group
+constexpr int PIP_PPT = 4;                  // points per thread, strided by PIP_BLOCK (coalesced 16-byte loads)
+constexpr int PIP_TILE = PIP_BLOCK * PIP_PPT;  // points per work-group
+constexpr int PIP_GS = 8;                   // lanes cooperating on one queued (point, part) pair
+constexpr int PIP_QCAP = PIP_TILE;          // LDS queue capacity (overflow is resolved inline, still exact)
+constexpr uint32_t NO_HIT = 0xFFFFFFFFu;
 
 // Visits every right-side row whose closed bbox contains the point, in ascending id order.
 template <typename F>
@@ -116,30 +122,162 @@ __device__ __forceinline__ void for_each_candidate(const IndexView& ix, const Gr
     }
 }
 
-__global__ __launch_bounds__(PIP_BLOCK) void pip_count_kernel(DevGeo pts, DevGeo polys, IndexView ix,
-                                                               uint32_t* __restrict__ counts,
-                                                               uint32_t* __restrict__ first_hit,
-                                                               unsigned long long* __restrict__ block_tot) {
+// Generic (always exact, never fast) evaluation of one point: directory candidates -> full ring walks.
+// It is the reference every accelerated route falls back to: rows with several hits, queue overflow,
+// right sides without a raster.
+__device__ inline void generic_point(const DevGeo& polys, const IndexView& ix, double px, double py, uint32_t& cnt,
+                                     uint32_t& first) {
+    cnt = 0;
+    first = NO_HIT;
+    const GridParams g = *ix.grid;
+    for_each_candidate(ix, g, px, py, [&](int j) {
+        if (dev::valid_row(polys.validity, j) && dev::polygonal_hits_point<false>(polys, j, px, py)) {
+            if (cnt == 0) first = (uint32_t)j;
+            ++cnt;
+        }
+    });
+}
+
+struct QEntry {
+    double px, py;
+    uint32_t part, li;
+};
+
+// pip_tile: one work-group classifies PIP_TILE points.
+//   phase 1 (lane = point): ONE 4-byte gather from the raster answers most points outright (no polygon
+//            here / strictly inside part p); points whose cell an edge may cross are pushed to an LDS queue
+//            with a wave-aggregated slot grab (ballot + one LDS atomic per wave).
+//   phase 2 (PIP_GS lanes = one queued pair): the group reads the part's slab for the point's raster row as
+//            consecutive 32-byte edge records and runs the exact winding walk, folding the winding number and
+//            the on-boundary flag with xor-shuffles.  Compacting the undecided points this way keeps the lanes
+//            dense in the only expensive part of the kernel.
+//   finalize: rows with exactly one part hit map part -> geometry; rows with several hits (overlapping
+//            polygons / multipolygon parts) are recomputed by the generic walk so that counts are per geometry.
+template <bool RASTER>
+__global__ __launch_bounds__(PIP_BLOCK) void pip_tile_kernel(DevGeo pts, DevGeo polys, IndexView ix, PipView pv,
+                                                              uint32_t* __restrict__ counts,
+                                                              uint32_t* __restrict__ first_hit,
+                                                              unsigned long long* __restrict__ block_tot) {
+    __shared__ QEntry q[RASTER ? PIP_QCAP : 1];
+    __shared__ uint32_t s_cnt[PIP_TILE], s_hit[PIP_TILE];
+    __shared__ uint32_t q_n;
     __shared__ unsigned long long lds[PIP_BLOCK / 64 + 1];
-    const int64_t i = (int64_t)blockIdx.x * PIP_BLOCK + threadIdx.x;
-    uint32_t cnt = 0, first = 0xFFFFFFFFu;
-    if (i < pts.n_geoms && dev::valid_row(pts.validity, i)) {
-        const double2 p = pts.xy[i];
-        const GridParams g = *ix.grid;
-        for_each_candidate(ix, g, p.x, p.y, [&](int j) {
-            if (dev::valid_row(polys.validity, j) && dev::polygonal_hits_point<false>(polys, j, p.x, p.y)) {
-                if (cnt == 0) first = (uint32_t)j;
-                ++cnt;
+    const int tid = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * PIP_TILE;
+    const int64_t n = pts.n_geoms;
+
+    if (RASTER) {
+#pragma unroll
+        for (int k = 0; k < PIP_PPT; ++k) s_cnt[k * PIP_BLOCK + tid] = 0;
+        if (tid == 0) q_n = 0;
+        __syncthreads();
+
+        const int lane64 = tid & 63;
+#pragma unroll
+        for (int k = 0; k < PIP_PPT; ++k) {
+            const int li = k * PIP_BLOCK + tid;
+            const int64_t i = base + li;
+            uint32_t word = 0;
+            double2 p = make_double2(0.0, 0.0);
+            if (i < n && dev::valid_row(pts.validity, i)) {
+                p = pts.xy[i];
+                const int fx = pip::col_of(pv, p.x), fy = pip::row_of(pv, p.y);
+                word = pv.cell[(int64_t)fy * pv.R + fx];
             }
-        });
+            const uint32_t tag = word >> 30;
+            const uint32_t payload = word & 0x3FFFFFFFu;
+            bool push = false;
+            if (tag == CELL_TAG_SINGLE) {
+                if (payload & 1u) {
+                    push = true;
+                } else {
+                    s_cnt[li] = 1;  // only this lane touches s_cnt[li] before the barrier
+                    s_hit[li] = payload >> 1;
+                }
+            }
+            // wave-aggregated queue push
+            const unsigned long long mask = __ballot(push);
+            if (mask) {
+                uint32_t wbase = 0;
+                const int leader = __ffsll((long long)mask) - 1;
+                if (lane64 == leader) wbase = atomicAdd(&q_n, (uint32_t)__popcll(mask));
+                wbase = __shfl(wbase, leader, 64);
+                if (push) {
+                    const uint32_t slot = wbase + (uint32_t)__popcll(mask & ((1ull << lane64) - 1ull));
+                    if (slot < (uint32_t)PIP_QCAP) {
+                        q[slot] = QEntry{p.x, p.y, payload >> 1, (uint32_t)li};
+                    } else if (pip::part_pos_single(pv, polys, (int)(payload >> 1), p.x, p.y) == dev::POS_INSIDE) {
+                        s_cnt[li] += 1;
+                        s_hit[li] = payload >> 1;
+                    }
+                }
+            }
+            if (tag == CELL_TAG_LIST) {  // several parts meet this cell (shared borders, overlaps)
+                const uint32_t m = pv.list[payload];
+                for (uint32_t t = 0; t < m; ++t) {
+                    const uint32_t e = pv.list[payload + 1 + t];
+                    if (e & 1u) {
+                        const uint32_t slot = atomicAdd(&q_n, 1u);
+                        if (slot < (uint32_t)PIP_QCAP) {
+                            q[slot] = QEntry{p.x, p.y, e >> 1, (uint32_t)li};
+                            continue;
+                        }
+                        if (pip::part_pos_single(pv, polys, (int)(e >> 1), p.x, p.y) != dev::POS_INSIDE) continue;
+                    }
+                    s_cnt[li] += 1;
+                    s_hit[li] = e >> 1;
+                }
+            }
+        }
+        __syncthreads();
+
+        const uint32_t nq = q_n < (uint32_t)PIP_QCAP ? q_n : (uint32_t)PIP_QCAP;
+        const int glane = tid & (PIP_GS - 1);
+        for (uint32_t e = tid / PIP_GS; e < nq; e += PIP_BLOCK / PIP_GS) {
+            const QEntry en = q[e];
+            const int pos = pip::part_pos_group<PIP_GS>(pv, polys, (int)en.part, en.px, en.py, glane);
+            if (glane == 0 && pos == dev::POS_INSIDE) {
+                atomicAdd(&s_cnt[en.li], 1u);
+                s_hit[en.li] = en.part;  // with several hits the row is recomputed below, so any writer may win
+            }
+        }
+        __syncthreads();
     }
-    if (i < pts.n_geoms) {
+
+    unsigned long long local = 0;
+#pragma unroll
+    for (int k = 0; k < PIP_PPT; ++k) {
+        const int li = k * PIP_BLOCK + tid;
+        const int64_t i = base + li;
+        if (i >= n) continue;
+        uint32_t cnt = 0, first = NO_HIT;
+        bool generic = !RASTER;
+        if (RASTER) {
+            cnt = s_cnt[li];
+            if (cnt == 1) {
+                first = pv.part_geom ? pv.part_geom[s_hit[li]] : s_hit[li];
+                if (!dev::valid_row(polys.validity, first)) {
+                    cnt = 0;
+                    first = NO_HIT;
+                }
+            } else if (cnt > 1) {
+                generic = true;
+            }
+        }
+        if (generic) {
+            cnt = 0;
+            if (dev::valid_row(pts.validity, i)) {
+                const double2 p = pts.xy[i];
+                generic_point(polys, ix, p.x, p.y, cnt, first);
+            }
+        }
         counts[i] = cnt;
         first_hit[i] = first;
+        local += cnt;
     }
     unsigned long long tot;
-    (void)dev::block_exclusive_scan<unsigned long long, PIP_BLOCK>((unsigned long long)cnt, lds, &tot);
-    if (threadIdx.x == 0) block_tot[blockIdx.x] = tot;
+    (void)dev::block_exclusive_scan<unsigned long long, PIP_BLOCK>(local, lds, &tot);
+    if (tid == 0) block_tot[blockIdx.x] = tot;
 }
 
 __global__ __launch_bounds__(PIP_BLOCK) void pip_write_kernel(DevGeo pts, DevGeo polys, IndexView ix,
@@ -149,25 +287,31 @@ __global__ __launch_bounds__(PIP_BLOCK) void pip_write_kernel(DevGeo pts, DevGeo
                                                                uint32_t left_base, uint2* __restrict__ pairs,
                                                                int64_t capacity) {
     __shared__ unsigned long long lds[PIP_BLOCK / 64 + 1];
-    const int64_t i = (int64_t)blockIdx.x * PIP_BLOCK + threadIdx.x;
-    const uint32_t cnt = i < pts.n_geoms ? counts[i] : 0u;
-    unsigned long long tot;
-    const unsigned long long ex = dev::block_exclusive_scan<unsigned long long, PIP_BLOCK>((unsigned long long)cnt, lds, &tot);
-    if (cnt == 0) return;
-    int64_t o = (int64_t)(block_off[blockIdx.x] + ex);
-    const uint32_t l = left_base + (uint32_t)i;
-    if (cnt == 1) {
-        if (o < capacity) pairs[o] = make_uint2(l, first_hit[i]);
-        return;
-    }
-    const double2 p = pts.xy[i];
-    const GridParams g = *ix.grid;
-    for_each_candidate(ix, g, p.x, p.y, [&](int j) {
-        if (dev::valid_row(polys.validity, j) && dev::polygonal_hits_point<false>(polys, j, p.x, p.y)) {
-            if (o < capacity) pairs[o] = make_uint2(l, (uint32_t)j);
-            ++o;
+    const int64_t base = (int64_t)blockIdx.x * PIP_TILE;
+    unsigned long long running = block_off[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < PIP_PPT; ++k) {
+        const int64_t i = base + k * PIP_BLOCK + threadIdx.x;
+        const uint32_t cnt = i < pts.n_geoms ? counts[i] : 0u;
+        unsigned long long tot;
+        const unsigned long long ex = dev::block_exclusive_scan<unsigned long long, PIP_BLOCK>((unsigned long long)cnt, lds, &tot);
+        int64_t o = (int64_t)(running + ex);
+        running += tot;
+        if (cnt == 0) continue;
+        const uint32_t l = left_base + (uint32_t)i;
+        if (cnt == 1) {
+            if (o < capacity) pairs[o] = make_uint2(l, first_hit[i]);
+            continue;
         }
-    });
+        const double2 p = pts.xy[i];
+        const GridParams g = *ix.grid;
+        for_each_candidate(ix, g, p.x, p.y, [&](int j) {
+            if (dev::valid_row(polys.validity, j) && dev::polygonal_hits_point<false>(polys, j, p.x, p.y)) {
+                if (o < capacity) pairs[o] = make_uint2(l, (uint32_t)j);
+                ++o;
+            }
+        });
+    }
 }
 
 // ================================= host drivers ================================================
@@ -184,7 +328,7 @@ extern "C" {
 
 int32_t gpk_index_free(gpk_index* idx) {
     if (!idx) return GPK_OK;
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 12; ++i)
         if (idx->owned[i]) (void)hipFree(idx->owned[i]);
     delete idx;
     return GPK_OK;
@@ -261,6 +405,7 @@ int32_t gpk_index_build(const gpk_geoarray* a, void* stream, gpk_index** out) {
     IX_TRY(exclusive_scan_i32(cell_cnt, n_cells, cell_off, cursor, btot, s));
     unsigned long long total = 0;
     IX_HIP(hipMemcpyAsync(&total, btot + n_blocks, sizeof total, hipMemcpyDeviceToHost, s));
+    IX_HIP(hipMemcpyAsync(&ix->host_grid, grid, sizeof(GridParams), hipMemcpyDeviceToHost, s));
     IX_HIP(hipStreamSynchronize(s));
     if (total > (unsigned long long)INT32_MAX)
         return cleanup(fail(GPK_ERR_INVALID_OFFSETS, "spatial index directory overflows i32 (%llu entries)", total));
@@ -283,6 +428,13 @@ int32_t gpk_index_build(const gpk_geoarray* a, void* stream, gpk_index** out) {
     ix->v.gy = gdim;
     ix->nbytes = (int64_t)(sizeof(double4) * (size_t)n + sizeof(GridParams) + sizeof(int32_t) * (size_t)(n_cells + 1) +
                            sizeof(int32_t) * (size_t)total);
+    {
+        const int32_t rc = build_pip_index(a, ix, s);  // raster + slabs for polygonal arrays
+        if (rc != GPK_OK) {
+            gpk_index_free(ix);
+            return rc;
+        }
+    }
     *out = ix;
     return GPK_OK;
 }
@@ -320,7 +472,7 @@ int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right, co
 
     const int64_t n = left->d.n_geoms;
     if (n == 0) return done(GPK_OK);
-    const int64_t n_blocks = (n + PIP_BLOCK - 1) / PIP_BLOCK;
+    const int64_t n_blocks = (n + PIP_TILE - 1) / PIP_TILE;
     const bool host_out = out_space != GPK_MEM_DEVICE;
     const bool want_pairs = pair_capacity > 0;
     const size_t counts_bytes = sizeof(uint32_t) * (size_t)n;
@@ -346,8 +498,12 @@ int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right, co
         if (_rc != GPK_OK) return done(_rc);   \
     } while (0)
 
-    J_LAUNCH("gpk_pip_count", pip_count_kernel, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
-             right_index->v, counts_dev, first_hit, btot);
+    if (right_index->pip.R > 0)
+        J_LAUNCH("gpk_pip_tile", pip_tile_kernel<true>, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
+                 right_index->v, right_index->pip, counts_dev, first_hit, btot);
+    else
+        J_LAUNCH("gpk_pip_tile_generic", pip_tile_kernel<false>, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
+                 right_index->v, right_index->pip, counts_dev, first_hit, btot);
     J_LAUNCH("gpk_scan_totals", scan_block_totals_kernel, dim3(1), dim3(1024), 0, s, btot, n_blocks, btot + n_blocks);
     if (want_pairs)
         J_LAUNCH("gpk_pip_write", pip_write_kernel, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,

@@ -1,0 +1,95 @@
+// gpk_pip.h — exact point-vs-part tests driven by the slab tables of PipView (gpk_index.h).
+//
+// A slab holds every edge of one ring whose closed y-range meets one raster row; the point's row is
+// computed with the same monotone function, so the slab is a superset of the edges that
+// coord_pos_relative_to_ring (geo 0.27) can count or report as boundary for that point.  Walking the
+// slab with dev::ring_edge therefore returns exactly the ring position of the full ring walk.
+#pragma once
+
+#include "gpk_device.h"
+#include "gpk_index.h"
+
+namespace gpk {
+namespace pip {
+
+__device__ __forceinline__ int row_of(const PipView& pv, double py) { return dev::cell_of(py, pv.ry0, pv.inv_fh, pv.R); }
+__device__ __forceinline__ int col_of(const PipView& pv, double px) { return dev::cell_of(px, pv.rx0, pv.inv_fw, pv.R); }
+
+__device__ __forceinline__ bool slab_range(const PipView& pv, int r, int row, int& e0, int& e1) {
+    const int base = pv.ring_slab_base[r], ns = pv.ring_slab_base[r + 1] - base;
+    const int j = row - pv.ring_row0[r];
+    if (j < 0 || j >= ns) return false;  // p.y outside the ring's y-range: Outside, cannot be on it
+    e0 = pv.slab_off[base + j];
+    e1 = pv.slab_off[base + j + 1];
+    return true;
+}
+
+// ---- one lane --------------------------------------------------------------------------------
+__device__ inline int ring_pos_single(const PipView& pv, int r, double px, double py, int row) {
+    int e0, e1;
+    if (!slab_range(pv, r, row, e0, e1)) return dev::POS_OUTSIDE;
+    int wn = 0;
+    bool on = false;
+    for (int k = e0; k < e1; ++k) {
+        const double4 ed = pv.slab_edges[k];
+        on |= dev::ring_edge(ed.x, ed.y, ed.z, ed.w, px, py, wn);
+    }
+    if (on) return dev::POS_BOUNDARY;
+    return wn == 0 ? dev::POS_OUTSIDE : dev::POS_INSIDE;
+}
+
+// Polygon::coordinate_position for one part (exterior, then holes)
+__device__ inline int part_pos_single(const PipView& pv, const DevGeo& a, int part, double px, double py) {
+    int r0, r1;
+    dev::part_rings(a, part, r0, r1);
+    if (r1 <= r0) return dev::POS_OUTSIDE;
+    const int row = row_of(pv, py);
+    const int pe = ring_pos_single(pv, r0, px, py, row);
+    if (pe != dev::POS_INSIDE) return pe;
+    for (int r = r0 + 1; r < r1; ++r) {
+        const int ph = ring_pos_single(pv, r, px, py, row);
+        if (ph == dev::POS_BOUNDARY) return dev::POS_BOUNDARY;
+        if (ph == dev::POS_INSIDE) return dev::POS_OUTSIDE;
+    }
+    return dev::POS_INSIDE;
+}
+
+// ---- GS lanes cooperating on one (point, part) pair --------------------------------------------------
+// All GS lanes of the group must call with identical (r / part, point); lane k reads edges k, k+GS, ...
+// so one group reads a slab as GS consecutive 32-byte records (two cache lines for GS = 8).
+template <int GS>
+__device__ __forceinline__ int ring_pos_group(const PipView& pv, int r, double px, double py, int row, int lane) {
+    int e0, e1;
+    if (!slab_range(pv, r, row, e0, e1)) return dev::POS_OUTSIDE;
+    int wn = 0, on = 0;
+    for (int k = e0 + lane; k < e1; k += GS) {
+        const double4 ed = pv.slab_edges[k];
+        on |= (int)dev::ring_edge(ed.x, ed.y, ed.z, ed.w, px, py, wn);
+    }
+#pragma unroll
+    for (int o = GS / 2; o > 0; o >>= 1) {
+        wn += __shfl_xor(wn, o, 64);
+        on |= __shfl_xor(on, o, 64);
+    }
+    if (on) return dev::POS_BOUNDARY;
+    return wn == 0 ? dev::POS_OUTSIDE : dev::POS_INSIDE;
+}
+
+template <int GS>
+__device__ __forceinline__ int part_pos_group(const PipView& pv, const DevGeo& a, int part, double px, double py, int lane) {
+    int r0, r1;
+    dev::part_rings(a, part, r0, r1);
+    if (r1 <= r0) return dev::POS_OUTSIDE;
+    const int row = row_of(pv, py);
+    const int pe = ring_pos_group<GS>(pv, r0, px, py, row, lane);
+    if (pe != dev::POS_INSIDE) return pe;
+    for (int r = r0 + 1; r < r1; ++r) {
+        const int ph = ring_pos_group<GS>(pv, r, px, py, row, lane);
+        if (ph == dev::POS_BOUNDARY) return dev::POS_BOUNDARY;
+        if (ph == dev::POS_INSIDE) return dev::POS_OUTSIDE;
+    }
+    return dev::POS_INSIDE;
+}
+
+}  // namespace pip
+}  // namespace gpk

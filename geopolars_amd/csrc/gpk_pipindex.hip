@@ -1,0 +1,456 @@
+// gpk_pipindex.hip — builds the point-in-polygon accelerator of a polygonal right side (PipView,
+// gpk_index.h): per-ring edge slabs on the raster rows, then the fine raster whose cells say
+// "nothing here" / "strictly inside part p" / "an edge of part p may pass: test exactly".
+//
+// It belongs to SpatialIndex::try_from(&Series) (geopolars/src/spatial_index.rs:320-334): it is
+// built once per right side and shared, like `Arc<SpatialIndex>` (spatial_index.rs:20-21).
+//
+// Why the raster labels are exact (not approximate):
+//   * rows/columns are assigned to points and to edge endpoints by the SAME monotone function
+//     (dev::cell_of), so an edge whose closed y-range contains p.y is registered in p's row slab;
+//   * a cell is marked "boundary" for part q whenever an edge of q is not strictly on one side of the
+//     cell's rectangle padded by 2^-16 of a cell (exact orientation tests on the four corners); the
+//     padding dwarfs the rounding of the cell function (guarded: the accelerator is not built when
+//     coordinates are so large relative to the extent that it would not);
+//   * an unmarked cell is connected and meets no edge of q, so the exact position of its centre with
+//     respect to q (holes included) is the position of every point that maps to the cell;
+//   * border cells (where out-of-extent points are clamped) never get an "inside" label.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "gpk_device.h"
+#include "gpk_index.h"
+#include "gpk_pip.h"
+#include "gpk_scan.h"
+
+namespace gpk {
+
+struct FineGrid {
+    int R;
+    double rx0, ry0, fw, fh, inv_fw, inv_fh, pad_x, pad_y;
+};
+__device__ __forceinline__ int fcol(const FineGrid& f, double x) { return dev::cell_of(x, f.rx0, f.inv_fw, f.R); }
+__device__ __forceinline__ int frow(const FineGrid& f, double y) { return dev::cell_of(y, f.ry0, f.inv_fh, f.R); }
+
+__global__ void part_geom_kernel(DevGeo a, uint32_t* __restrict__ part_geom) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.n_geoms) return;
+    for (int p = a.geom_off[g]; p < a.geom_off[g + 1]; ++p) part_geom[p] = (uint32_t)g;
+}
+__global__ void ring_part_kernel(DevGeo a, int64_t n_parts, int32_t* __restrict__ ring_part) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_parts) return;
+    int r0, r1;
+    dev::part_rings(a, (int)p, r0, r1);
+    for (int r = r0; r < r1; ++r) ring_part[r] = (int32_t)p;
+}
+
+__global__ void ring_rows_kernel(const double4* __restrict__ ring_bbox, int64_t n_rings, FineGrid f,
+                                 int32_t* __restrict__ row0, int32_t* __restrict__ nrows) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rings) return;
+    const double4 b = ring_bbox[r];
+    if (!(b.x == b.x) || !(b.y == b.y) || !(b.w == b.w)) {  // empty ring (or NaN coordinates): no slabs
+        row0[r] = 0;
+        nrows[r] = 0;
+        return;
+    }
+    const int j0 = frow(f, b.y), j1 = frow(f, b.w);
+    row0[r] = j0;
+    nrows[r] = j1 - j0 + 1;
+}
+
+// ring that owns coordinate i: largest r with ring_off[r] <= i
+__device__ __forceinline__ int ring_of_coord(const int32_t* __restrict__ ring_off, int n_rings, int i) {
+    int lo = 0, hi = n_rings;  // invariant: ring_off[lo] <= i < ring_off[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (ring_off[mid] <= i)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+// edge starting at coordinate i (a single-coordinate ring contributes one degenerate edge so that the
+// "ring of one coordinate" arm of coord_pos_relative_to_ring is reproduced by the edge walk)
+__device__ __forceinline__ bool edge_at(const DevGeo& a, int i, int& r, double2& s, double2& e) {
+    r = ring_of_coord(a.ring_off, (int)a.n_rings, i);
+    const int c0 = a.ring_off[r], c1 = a.ring_off[r + 1];
+    if (i >= c1) return false;  // coordinate belongs to an empty-ring gap (cannot happen with valid offsets)
+    s = a.xy[i];
+    if (i + 1 < c1) {
+        e = a.xy[i + 1];
+        return true;
+    }
+    if (c1 - c0 == 1) {
+        e = s;
+        return true;
+    }
+    return false;
+}
+
+template <bool FILL>
+__global__ void slab_register_kernel(DevGeo a, FineGrid f, const int32_t* __restrict__ row0,
+                                     const int32_t* __restrict__ slab_base, int32_t* __restrict__ cnt_or_cursor,
+                                     double4* __restrict__ edges) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_coords) return;
+    int r;
+    double2 s, e;
+    if (!edge_at(a, (int)i, r, s, e)) return;
+    if (slab_base[r + 1] == slab_base[r]) return;
+    const double ylo = s.y < e.y ? s.y : e.y, yhi = s.y > e.y ? s.y : e.y;
+    if (!(ylo == ylo) || !(yhi == yhi)) return;
+    const int j0 = frow(f, ylo), j1 = frow(f, yhi);
+    for (int j = j0; j <= j1; ++j) {
+        const int sl = slab_base[r] + (j - row0[r]);
+        const int slot = atomicAdd(&cnt_or_cursor[sl], 1);
+        if (FILL) edges[slot] = make_double4(s.x, s.y, e.x, e.y);
+    }
+}
+
+// cells an edge may touch (see the header comment); f(i, j) is called for each
+template <typename F>
+__device__ __forceinline__ void for_each_touched_cell(const FineGrid& g, double2 s, double2 e, F&& f) {
+    const double xlo = s.x < e.x ? s.x : e.x, xhi = s.x > e.x ? s.x : e.x;
+    const double ylo = s.y < e.y ? s.y : e.y, yhi = s.y > e.y ? s.y : e.y;
+    if (!(xlo == xlo) || !(xhi == xhi) || !(ylo == ylo) || !(yhi == yhi)) return;
+    // widen by the padding so that a vertex sitting within `pad` of a cell border also claims the neighbour
+    const int i0 = fcol(g, xlo - g.pad_x), i1 = fcol(g, xhi + g.pad_x);
+    const int j0 = frow(g, ylo - g.pad_y), j1 = frow(g, yhi + g.pad_y);
+    if (i0 == i1 && j0 == j1) {
+        f(i0, j0);
+        return;
+    }
+    for (int j = j0; j <= j1; ++j)
+        for (int i = i0; i <= i1; ++i) {
+            if (i == 0 || j == 0 || i == g.R - 1 || j == g.R - 1) {  // clamped cells are unbounded: always claim
+                f(i, j);
+                continue;
+            }
+            const double xl = g.rx0 + (double)i * g.fw - g.pad_x, xh = g.rx0 + (double)(i + 1) * g.fw + g.pad_x;
+            const double yl = g.ry0 + (double)j * g.fh - g.pad_y, yh = g.ry0 + (double)(j + 1) * g.fh + g.pad_y;
+            const int o1 = dev::orient2d(s.x, s.y, e.x, e.y, xl, yl);
+            const int o2 = dev::orient2d(s.x, s.y, e.x, e.y, xh, yl);
+            const int o3 = dev::orient2d(s.x, s.y, e.x, e.y, xh, yh);
+            const int o4 = dev::orient2d(s.x, s.y, e.x, e.y, xl, yh);
+            const bool all_pos = o1 > 0 && o2 > 0 && o3 > 0 && o4 > 0;
+            const bool all_neg = o1 < 0 && o2 < 0 && o3 < 0 && o4 < 0;
+            if (!(all_pos || all_neg)) f(i, j);
+        }
+}
+
+template <bool FILL>
+__global__ void mark_kernel(DevGeo a, FineGrid g, const int32_t* __restrict__ ring_part,
+                            unsigned long long* __restrict__ counter, unsigned long long* __restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_coords) return;
+    int r;
+    double2 s, e;
+    if (!edge_at(a, (int)i, r, s, e)) return;
+    const unsigned long long part = (unsigned long long)ring_part[r];
+    unsigned long long n = 0;
+    for_each_touched_cell(g, s, e, [&](int ci, int cj) {
+        if (FILL) {
+            const unsigned long long slot = atomicAdd(counter, 1ull);
+            keys[slot] = ((unsigned long long)(cj * g.R + ci) << 32) | part;
+        } else {
+            ++n;
+        }
+    });
+    if (!FILL && n) atomicAdd(counter, n);
+}
+
+__global__ void unique_flags_kernel(const unsigned long long* __restrict__ sorted, int64_t n, int32_t* __restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    flag[i] = (i == 0 || sorted[i] != sorted[i - 1]) ? 1 : 0;
+}
+__global__ void unique_compact_kernel(const unsigned long long* __restrict__ sorted, int64_t n, const int32_t* __restrict__ pos,
+                                      unsigned long long* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (i == 0 || sorted[i] != sorted[i - 1]) out[pos[i]] = sorted[i];
+}
+
+__device__ __forceinline__ int64_t lower_bound_u64(const unsigned long long* __restrict__ v, int64_t n, unsigned long long key) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (v[mid] < key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// One thread per raster cell: merge (a) the parts whose edges may touch the cell and (b) the parts that
+// strictly contain the cell's centre, in ascending part order.
+template <bool FILL>
+__global__ void cell_build_kernel(DevGeo a, IndexView ix, PipView pv, FineGrid g,
+                                  const unsigned long long* __restrict__ marks, int64_t n_marks,
+                                  int32_t* __restrict__ need, const int32_t* __restrict__ list_off,
+                                  uint32_t* __restrict__ cell, uint32_t* __restrict__ list) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= (int64_t)g.R * g.R) return;
+    const int ci = (int)(c % g.R), cj = (int)(c / g.R);
+    const double cx = g.rx0 + ((double)ci + 0.5) * g.fw, cy = g.ry0 + ((double)cj + 0.5) * g.fh;
+    const bool border = ci == 0 || cj == 0 || ci == g.R - 1 || cj == g.R - 1;
+    const bool centre_ok = !border && fcol(g, cx) == ci && frow(g, cy) == cj;
+    int64_t m = lower_bound_u64(marks, n_marks, (unsigned long long)c << 32);
+    const int64_t m_end = lower_bound_u64(marks, n_marks, (unsigned long long)(c + 1) << 32);
+
+    int n = 0;
+    uint32_t first_entry = 0;
+    uint32_t* out = nullptr;
+    if (FILL && need[c] > 0) {
+        out = list + list_off[c];
+        out[0] = (uint32_t)(need[c] - 1);
+        ++out;
+    }
+    auto emit = [&](uint32_t part, uint32_t boundary) {
+        const uint32_t e = (part << 1) | boundary;
+        if (n == 0) first_entry = e;
+        if (out) out[n] = e;
+        ++n;
+    };
+    auto flush_marks_below = [&](unsigned long long part_limit) {  // emit marks with part < part_limit
+        while (m < m_end && (marks[m] & 0xFFFFFFFFull) < part_limit) {
+            emit((uint32_t)(marks[m] & 0xFFFFFFFFull), 1u);
+            ++m;
+        }
+    };
+
+    // candidates whose bbox contains the centre, through the coarse directory (ascending geometry id)
+    const GridParams cg = *ix.grid;
+    const int gx = dev::cell_of(cx, cg.x0, cg.inv_w, cg.gx), gy = dev::cell_of(cy, cg.y0, cg.inv_h, cg.gy);
+    const int gc = gy * cg.gx + gx;
+    for (int k = ix.cell_off[gc]; k < ix.cell_off[gc + 1]; ++k) {
+        const int j = ix.items[k];
+        const double4 bb = ix.bbox[j];
+        if (!(cx >= bb.x && cx <= bb.z && cy >= bb.y && cy <= bb.w)) continue;
+        if (!dev::valid_row(a.validity, j)) continue;
+        int p0, p1;
+        dev::geom_parts(a, j, p0, p1);
+        for (int p = p0; p < p1; ++p) {
+            flush_marks_below((unsigned long long)p);
+            if (m < m_end && (marks[m] & 0xFFFFFFFFull) == (unsigned long long)p) {
+                emit((uint32_t)p, 1u);
+                ++m;
+                continue;
+            }
+            const int pos = pip::part_pos_single(pv, a, p, cx, cy);
+            if (pos == dev::POS_OUTSIDE) continue;
+            // Inside an unmarked, well-formed interior cell: the whole cell is inside.  Anything else
+            // (border cell, centre not representable in the cell, centre on a boundary) stays exact.
+            emit((uint32_t)p, (centre_ok && pos == dev::POS_INSIDE) ? 0u : 1u);
+        }
+    }
+    flush_marks_below(~0ull);
+
+    if (!FILL) {
+        need[c] = n >= 2 ? n + 1 : 0;
+        return;
+    }
+    uint32_t word = 0;
+    if (n == 1)
+        word = (CELL_TAG_SINGLE << 30) | first_entry;
+    else if (n >= 2)
+        word = (CELL_TAG_LIST << 30) | (uint32_t)list_off[c];
+    cell[c] = word;
+}
+
+}  // namespace gpk
+
+using namespace gpk;
+
+namespace {
+struct Temps {  // hipMalloc'ed scratch of the build, released on every exit path
+    void* p[16] = {nullptr};
+    int n = 0;
+    template <typename T>
+    int32_t alloc(T** out, size_t count) {
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, sizeof(T) * (count ? count : 1));
+        if (e != hipSuccess) return fail(GPK_ERR_OOM, "index build: hipMalloc(%zu) failed: %s", sizeof(T) * count, hipGetErrorString(e));
+        p[n++] = q;
+        *out = (T*)q;
+        return GPK_OK;
+    }
+    ~Temps() {
+        for (int i = 0; i < n; ++i) (void)hipFree(p[i]);
+    }
+};
+inline dim3 blocks_for(int64_t n) { return dim3((unsigned)((n + 255) / 256 > 0 ? (n + 255) / 256 : 1)); }
+}  // namespace
+
+namespace gpk {
+
+int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
+    memset(&ix->pip, 0, sizeof ix->pip);
+    const DevGeo& d = a->d;
+    if (!is_polygonal(d.type) || d.n_geoms == 0 || d.n_coords == 0 || d.n_rings == 0) return GPK_OK;
+    const GridParams hg = ix->host_grid;
+    const double w = hg.inv_w > 0.0 ? (double)hg.gx / hg.inv_w : 0.0, h = hg.inv_h > 0.0 ? (double)hg.gy / hg.inv_h : 0.0;
+    if (!(w > 0.0) || !(h > 0.0) || !std::isfinite(w) || !std::isfinite(h)) return GPK_OK;  // degenerate extent
+
+    int R = 64;
+    while (R < 2048 && (double)R < 4.0 * sqrt((double)d.n_coords)) R <<= 1;
+    FineGrid g;
+    g.R = R;
+    g.fw = w / (double)(R - 3);
+    g.fh = h / (double)(R - 3);
+    g.rx0 = hg.x0 - 1.5 * g.fw;
+    g.ry0 = hg.y0 - 1.5 * g.fh;
+    g.inv_fw = 1.0 / g.fw;
+    g.inv_fh = 1.0 / g.fh;
+    g.pad_x = g.fw * (1.0 / 65536.0);
+    g.pad_y = g.fh * (1.0 / 65536.0);
+    // the padding must dwarf the rounding of (v - v0) * inv: 64 ulps of the largest coordinate magnitude
+    const double max_abs = fmax(fmax(fabs(hg.x0), fabs(hg.x0 + w)), fmax(fabs(hg.y0), fabs(hg.y0 + h)));
+    const double ulp64 = max_abs * 1.4210854715202004e-14;  // 64 * 2^-52
+    if (!(g.pad_x > ulp64) || !(g.pad_y > ulp64)) return GPK_OK;
+
+    const int64_t n_rings = d.n_rings, n_parts = d.n_parts, n_cells = (int64_t)R * R;
+    Temps t;
+    int slot = 4;  // ix->owned[0..3] belong to the coarse directory
+    auto keep = [&](void* p) { ix->owned[slot++] = p; };
+
+    // ---- part / ring maps ----------------------------------------------------------------------
+    uint32_t* part_geom = nullptr;
+    if (d.type == GPK_GEOM_MULTIPOLYGON) {
+        GPK_HIP(hipMalloc((void**)&part_geom, sizeof(uint32_t) * (size_t)(n_parts ? n_parts : 1)));
+        keep(part_geom);
+        GPK_LAUNCH("gpk_pipidx_part_geom", part_geom_kernel, blocks_for(d.n_geoms), dim3(256), 0, s, d, part_geom);
+    }
+    int32_t* ring_part;
+    GPK_TRY(t.alloc(&ring_part, (size_t)n_rings));
+    GPK_LAUNCH("gpk_pipidx_ring_part", ring_part_kernel, blocks_for(n_parts), dim3(256), 0, s, d, n_parts, ring_part);
+
+    // ---- slabs ---------------------------------------------------------------------------------
+    double4* ring_bbox;
+    GPK_TRY(t.alloc(&ring_bbox, (size_t)n_rings));
+    GPK_TRY(ring_bboxes(a, ring_bbox, s));
+    int32_t *row0 = nullptr, *nrows, *slab_base = nullptr;
+    GPK_HIP(hipMalloc((void**)&row0, sizeof(int32_t) * (size_t)n_rings));
+    keep(row0);
+    GPK_HIP(hipMalloc((void**)&slab_base, sizeof(int32_t) * (size_t)(n_rings + 1)));
+    keep(slab_base);
+    GPK_TRY(t.alloc(&nrows, (size_t)n_rings));
+    unsigned long long* btot;
+    const int64_t max_scan = n_cells > d.n_coords ? n_cells : d.n_coords;
+    GPK_TRY(t.alloc(&btot, (size_t)((max_scan + 255) / 256 + 4)));
+    GPK_LAUNCH("gpk_pipidx_ring_rows", ring_rows_kernel, blocks_for(n_rings), dim3(256), 0, s, ring_bbox, n_rings, g, row0, nrows);
+    GPK_TRY(exclusive_scan_i32(nrows, n_rings, slab_base, nullptr, btot, s));
+    int32_t n_slabs = 0;
+    GPK_HIP(hipMemcpyAsync(&n_slabs, slab_base + n_rings, sizeof n_slabs, hipMemcpyDeviceToHost, s));
+    GPK_HIP(hipStreamSynchronize(s));
+    int32_t *slab_cnt, *slab_off = nullptr, *cursor;
+    GPK_TRY(t.alloc(&slab_cnt, (size_t)n_slabs + 1));
+    GPK_TRY(t.alloc(&cursor, (size_t)n_slabs + 1));
+    GPK_HIP(hipMalloc((void**)&slab_off, sizeof(int32_t) * (size_t)(n_slabs + 1)));
+    keep(slab_off);
+    GPK_HIP(hipMemsetAsync(slab_cnt, 0, sizeof(int32_t) * (size_t)(n_slabs + 1), s));
+    GPK_HIP(hipMemsetAsync(slab_off, 0, sizeof(int32_t) * (size_t)(n_slabs + 1), s));
+    GPK_LAUNCH("gpk_pipidx_slab_count", slab_register_kernel<false>, blocks_for(d.n_coords), dim3(256), 0, s, d, g, row0, slab_base,
+               slab_cnt, (double4*)nullptr);
+    int32_t n_edges = 0;
+    if (n_slabs > 0) {
+        GPK_TRY(exclusive_scan_i32(slab_cnt, n_slabs, slab_off, cursor, btot, s));
+        GPK_HIP(hipMemcpyAsync(&n_edges, slab_off + n_slabs, sizeof n_edges, hipMemcpyDeviceToHost, s));
+        GPK_HIP(hipStreamSynchronize(s));
+    }
+    double4* edges = nullptr;
+    GPK_HIP(hipMalloc((void**)&edges, sizeof(double4) * (size_t)(n_edges ? n_edges : 1)));
+    keep(edges);
+    GPK_LAUNCH("gpk_pipidx_slab_fill", slab_register_kernel<true>, blocks_for(d.n_coords), dim3(256), 0, s, d, g, row0, slab_base,
+               cursor, edges);
+
+    PipView pv;
+    memset(&pv, 0, sizeof pv);
+    pv.R = R;
+    pv.rx0 = g.rx0;
+    pv.ry0 = g.ry0;
+    pv.fw = g.fw;
+    pv.fh = g.fh;
+    pv.inv_fw = g.inv_fw;
+    pv.inv_fh = g.inv_fh;
+    pv.part_geom = part_geom;
+    pv.ring_row0 = row0;
+    pv.ring_slab_base = slab_base;
+    pv.slab_off = slab_off;
+    pv.slab_edges = edges;
+
+    // ---- boundary marks: (cell, part) keys, sorted + unique ---------------------------------------
+    unsigned long long* counter;
+    GPK_TRY(t.alloc(&counter, 2));
+    GPK_HIP(hipMemsetAsync(counter, 0, 2 * sizeof(unsigned long long), s));
+    GPK_LAUNCH("gpk_pipidx_mark_count", mark_kernel<false>, blocks_for(d.n_coords), dim3(256), 0, s, d, g, ring_part, counter,
+               (unsigned long long*)nullptr);
+    unsigned long long n_marks_raw = 0;
+    GPK_HIP(hipMemcpyAsync(&n_marks_raw, counter, sizeof n_marks_raw, hipMemcpyDeviceToHost, s));
+    GPK_HIP(hipStreamSynchronize(s));
+    if (n_marks_raw > (1ull << 31))
+        return GPK_OK;  // pathological (huge edges over a fine raster): leave the accelerator off
+    unsigned long long *keys, *sorted, *marks;
+    GPK_TRY(t.alloc(&keys, (size_t)n_marks_raw));
+    GPK_TRY(t.alloc(&sorted, (size_t)n_marks_raw));
+    GPK_TRY(t.alloc(&marks, (size_t)n_marks_raw));
+    int64_t n_marks = 0;
+    if (n_marks_raw > 0) {
+        GPK_LAUNCH("gpk_pipidx_mark_fill", mark_kernel<true>, blocks_for(d.n_coords), dim3(256), 0, s, d, g, ring_part, counter + 1, keys);
+        size_t tmp_bytes = 0;
+        GPK_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, keys, sorted, (size_t)n_marks_raw, 0, 64, s));
+        char* tmp;
+        GPK_TRY(t.alloc(&tmp, tmp_bytes));
+        GPK_HIP(rocprim::radix_sort_keys(tmp, tmp_bytes, keys, sorted, (size_t)n_marks_raw, 0, 64, s));
+        int32_t *flag, *pos;
+        GPK_TRY(t.alloc(&flag, (size_t)n_marks_raw + 1));
+        GPK_TRY(t.alloc(&pos, (size_t)n_marks_raw + 1));
+        unsigned long long* btot2;
+        GPK_TRY(t.alloc(&btot2, (size_t)((n_marks_raw + 255) / 256 + 4)));
+        GPK_LAUNCH("gpk_pipidx_unique_flags", unique_flags_kernel, blocks_for((int64_t)n_marks_raw), dim3(256), 0, s, sorted,
+                   (int64_t)n_marks_raw, flag);
+        GPK_TRY(exclusive_scan_i32(flag, (int64_t)n_marks_raw, pos, nullptr, btot2, s));
+        GPK_LAUNCH("gpk_pipidx_unique_compact", unique_compact_kernel, blocks_for((int64_t)n_marks_raw), dim3(256), 0, s, sorted,
+                   (int64_t)n_marks_raw, pos, marks);
+        int32_t nu = 0;
+        GPK_HIP(hipMemcpyAsync(&nu, pos + n_marks_raw, sizeof nu, hipMemcpyDeviceToHost, s));
+        GPK_HIP(hipStreamSynchronize(s));
+        n_marks = nu;
+    }
+
+    // ---- cells ----------------------------------------------------------------------------------
+    uint32_t* cell = nullptr;
+    GPK_HIP(hipMalloc((void**)&cell, sizeof(uint32_t) * (size_t)n_cells));
+    keep(cell);
+    int32_t *need, *list_off;
+    GPK_TRY(t.alloc(&need, (size_t)n_cells + 1));
+    GPK_TRY(t.alloc(&list_off, (size_t)n_cells + 1));
+    GPK_LAUNCH("gpk_pipidx_cell_count", cell_build_kernel<false>, blocks_for(n_cells), dim3(256), 0, s, d, ix->v, pv, g, marks, n_marks,
+               need, (const int32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    GPK_TRY(exclusive_scan_i32(need, n_cells, list_off, nullptr, btot, s));
+    int32_t list_len = 0;
+    GPK_HIP(hipMemcpyAsync(&list_len, list_off + n_cells, sizeof list_len, hipMemcpyDeviceToHost, s));
+    GPK_HIP(hipStreamSynchronize(s));
+    if ((unsigned)list_len >= (1u << 30)) return GPK_OK;
+    uint32_t* list = nullptr;
+    GPK_HIP(hipMalloc((void**)&list, sizeof(uint32_t) * (size_t)(list_len ? list_len : 1)));
+    keep(list);
+    GPK_LAUNCH("gpk_pipidx_cell_fill", cell_build_kernel<true>, blocks_for(n_cells), dim3(256), 0, s, d, ix->v, pv, g, marks, n_marks,
+               need, list_off, cell, list);
+    GPK_HIP(hipStreamSynchronize(s));
+
+    pv.cell = cell;
+    pv.list = list;
+    ix->pip = pv;
+    ix->nbytes += (int64_t)(sizeof(uint32_t) * (size_t)n_cells + sizeof(uint32_t) * (size_t)list_len + sizeof(double4) * (size_t)n_edges +
+                            sizeof(int32_t) * (size_t)(n_slabs + 1) + sizeof(int32_t) * (size_t)(2 * n_rings + 1) +
+                            (part_geom ? sizeof(uint32_t) * (size_t)n_parts : 0));
+    return GPK_OK;
+}
+
+}  // namespace gpk

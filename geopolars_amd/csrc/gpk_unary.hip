@@ -13,6 +13,7 @@
 // with the polygon / multipolygon rules.  Reduction order is fixed (xor-tree), so results are
 // bit-reproducible run to run.
 #include "gpk_device.h"
+#include "gpk_index.h"
 
 namespace gpk {
 
@@ -462,6 +463,29 @@ static int32_t unary_begin(const gpk_geoarray* a, size_t out_bytes, size_t out2_
     c->stats = (double*)workspace().take(stats_bytes ? stats_bytes : 8);
     c->out_dev = stage ? workspace().take(out_bytes ? out_bytes : 8) : out;
     c->out2_dev = out2 ? (stage ? workspace().take(out2_bytes ? out2_bytes : 8) : out2) : nullptr;
+    return GPK_OK;
+}
+
+__global__ void stats_to_bbox_kernel(const double* __restrict__ stats, const int32_t* __restrict__ seq_off, int64_t n_seq,
+                                     double4* __restrict__ out) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seq) return;
+    if (seq_off[s + 1] == seq_off[s])
+        out[s] = make_double4(NAN, NAN, NAN, NAN);
+    else
+        out[s] = make_double4(stats[ST_MINX * n_seq + s], stats[ST_MINY * n_seq + s], stats[ST_MAXX * n_seq + s],
+                              stats[ST_MAXY * n_seq + s]);
+}
+
+int32_t ring_bboxes(const gpk_geoarray* a, double4* out_dev, hipStream_t s) {
+    const int32_t* seq_off;
+    int64_t n_seq;
+    seq_view(a->d, &seq_off, &n_seq);
+    if (n_seq == 0) return GPK_OK;
+    GPK_TRY(workspace().begin(sizeof(double) * ST_COUNT * (size_t)n_seq + 1024));
+    double* stats = (double*)workspace().take(sizeof(double) * ST_COUNT * (size_t)n_seq);
+    GPK_TRY(launch_seq_stats<M_BBOX>(a->d, stats, s, "gpk_seq_bbox"));
+    GPK_LAUNCH("gpk_stats_to_bbox", stats_to_bbox_kernel, grid_for(n_seq), dim3(256), 0, s, stats, seq_off, n_seq, out_dev);
     return GPK_OK;
 }
 
