@@ -12,7 +12,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgeopolars_hip.so")
+LIB_PATH = os.environ.get("GPK_LIB_PATH") or os.path.join(HERE, "libgeopolars_hip.so")  # override: A/B builds
 
 # ---- constants (mirror of the header) ----------------------------------------------------------
 GPK_OK = 0

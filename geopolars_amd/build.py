@@ -75,6 +75,29 @@ def _compile(src: str, verbose: bool) -> str:
     return obj
 
 
+def build_variant(name: str, defines: list[str]) -> str:
+    """A/B builds for kernel tuning: same sources with extra -D flags -> geopolars_amd/variants/<name>.so
+    (select at run time with GPK_LIB_PATH)."""
+    vdir = os.path.join(HERE, "variants")
+    odir = os.path.join(OBJ, name)
+    os.makedirs(vdir, exist_ok=True)
+    os.makedirs(odir, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(odir, os.path.splitext(src)[0] + ".o")
+        lang = ["-x", "hip"] if src.endswith(".hip") else []
+        cmd = [_hipcc(), *FLAGS, *[f"-D{d}" for d in defines], *lang, "-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
+        objs.append(obj)
+    out = os.path.join(vdir, f"{name}.so")
+    r = subprocess.run([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out, *objs], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr)
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]

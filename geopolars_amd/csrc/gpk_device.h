@@ -95,37 +95,31 @@ __device__ __forceinline__ bool value_in_between(double v, double a, double b) {
 }
 
 // One edge of coord_pos_relative_to_ring (geo 0.27 coordinate_position.rs): updates the winding
-// number, returns true when the coordinate lies ON the edge.  The orientation determinant is only
-// evaluated when c.x lies within the edge's closed x-range: outside it the sign is known (strictly
-// left of both endpoints => left of the edge; strictly right => right of it) and the collinear /
-// on-boundary arm cannot fire, so the result is identical to evaluating orient2d unconditionally.
+// number, returns true when the coordinate lies ON the edge.
+//
+// Upstream evaluates orient2d for every edge whose y-range straddles c.y.  Here the determinant is only
+// evaluated when c.x also lies within the edge's closed x-range: outside it the sign is known (strictly
+// left of both endpoints => left of the directed edge; strictly right => right of it) and the
+// collinear / on-boundary arm cannot fire, so the result is identical.  The upward and downward arms share
+// ONE orientation evaluation (they are mutually exclusive), which matters on a 64-wide wave where every
+// divergent arm is paid by all lanes.
 __device__ __forceinline__ bool ring_edge(double sx, double sy, double ex, double ey, double cx,
                                           double cy, int& wn) {
-    if (sy <= cy) {
-        if (ey >= cy) {
-            const double lo = fmin(sx, ex), hi = fmax(sx, ex);
-            if (cx < lo) {
-                wn += (ey != cy);
-            } else if (cx <= hi) {
-                const int o = orient2d(sx, sy, ex, ey, cx, cy);
-                if (o > 0 && ey != cy)
-                    wn += 1;
-                else if (o == 0)
-                    return true;  // collinear and within the closed x-range
-            }
-        }
-    } else if (ey <= cy) {
-        const double lo = fmin(sx, ex), hi = fmax(sx, ex);
-        if (cx < lo) {
-            wn -= 1;
-        } else if (cx <= hi) {
-            const int o = orient2d(sx, sy, ex, ey, cx, cy);
-            if (o < 0)
-                wn -= 1;
-            else if (o == 0)
-                return true;
-        }
+    const bool up = sy <= cy && ey >= cy;   // upward (or horizontal at c.y): includes start, excludes end
+    const bool down = sy > cy && ey <= cy;  // downward: excludes start, includes end
+    if (!(up || down)) return false;
+    const double lo = fmin(sx, ex), hi = fmax(sx, ex);
+    if (cx < lo) {  // strictly left of the whole edge: it is crossed unless it ends level with c (upward arm)
+        wn += up ? (ey != cy ? 1 : 0) : -1;
+        return false;
     }
+    if (!(cx <= hi)) return false;  // strictly right (or NaN): never counted, cannot be on it
+    const int o = orient2d(sx, sy, ex, ey, cx, cy);
+    if (o == 0) return true;  // collinear and within the closed x-range: on the boundary
+    if (up)
+        wn += (o > 0 && ey != cy) ? 1 : 0;
+    else
+        wn -= (o < 0) ? 1 : 0;
     return false;
 }
 

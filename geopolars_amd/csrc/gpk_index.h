@@ -39,12 +39,16 @@ struct IndexView {  // passed to kernels by value
 //                contiguous double4 (sx, sy, ex, ey) records -> 8 lanes read one slab with 2 cache lines.
 // Exactness does not depend on the raster: it only routes points; every boundary decision is made by
 // the exact winding walk over the slab's edges, which are a superset of the edges that can count.
+struct PartInfo {  // one 16-byte load tells a lane where the exterior ring's slabs of a part live
+    int32_t slab_base, row0, nrows, n_rings;
+};
 struct PipView {
     int32_t R;  // 0 = accelerator not built (degenerate extent): kernels use the generic walk
     double rx0, ry0, fw, fh, inv_fw, inv_fh;
     const uint32_t* cell;
     const uint32_t* list;
     const uint32_t* part_geom;       // nullptr for POLYGON arrays (part == geometry)
+    const PartInfo* part_info;       // n_parts
     const int32_t* ring_row0;
     const int32_t* ring_slab_base;   // n_rings + 1
     const int32_t* slab_off;         // n_slabs + 1

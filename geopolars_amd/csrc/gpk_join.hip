@@ -5,12 +5,13 @@
 //                        + the exact refine loop                     spatial_index.rs:83-143
 //
 // Point x polygonal rows (the 10M x 1k headline) run as
-//   pip_count  : one lane per point; grid cell -> candidate polygons -> closed bbox test -> exact
-//                winding walk (gpk_device.h).  Emits the per-point hit count, the first hit id and one
-//                64-bit total per work-group.
-//   scan       : single-block exclusive scan of the work-group totals.
-//   pip_write  : block-local scan of the counts + work-group base -> (l, r) pairs in sorted order;
-//                only rows with more than one hit re-run the predicate.
+//   pip_tile   : a work-group classifies a tile of points (raster routing + LDS-compacted exact phase over
+//                edge slabs, see the kernel); emits the optional per-point hit count, a 4-byte result
+//                code per point and one 64-bit total per work-group.
+//   scan       : single-block exclusive scan of the work-group totals (LDS staged).
+//   pip_write  : codes + work-group base -> (l, r) pairs in sorted order.
+// (A single-pass variant with decoupled look-back was measured and was slower on MI355X: the in-order
+// commit makes finished work-groups hold their LDS/wave slots while they wait — see DESIGN.md.)
 #include "gpk_device.h"
 #include "gpk_index.h"
 #include "gpk_pip.h"
@@ -100,12 +101,20 @@ __global__ void cell_sort_kernel(const int32_t* __restrict__ cell_off, int64_t n
 }
 
 // ================================= point-in-polygon join =========================================
-constexpr int PIP_BLOCK = 256;              // threads per work-group
-constexpr int PIP_PPT = 4;                  // points per thread, strided by PIP_BLOCK (coalesced 16-byte loads)
+#ifndef GPK_PIP_PPT
+#define GPK_PIP_PPT 2
+#endif
+#ifndef GPK_PIP_GS
+#define GPK_PIP_GS 8
+#endif
+constexpr int PIP_BLOCK = 256;                 // threads per work-group
+constexpr int PIP_PPT = GPK_PIP_PPT;           // points per thread, strided by PIP_BLOCK (coalesced 16-byte loads)
 constexpr int PIP_TILE = PIP_BLOCK * PIP_PPT;  // points per work-group
-constexpr int PIP_GS = 8;                   // lanes cooperating on one queued (point, part) pair
-constexpr int PIP_QCAP = PIP_TILE;          // LDS queue capacity (overflow is resolved inline, still exact)
-constexpr uint32_t NO_HIT = 0xFFFFFFFFu;
+constexpr int PIP_GS = GPK_PIP_GS;             // lanes cooperating on one queued (point, part) pair
+constexpr int PIP_QCAP = PIP_TILE;             // LDS queue capacity (overflow is resolved inline, still exact)
+// per-point result code handed from pip_tile to pip_write: a geometry id (exactly one hit), CODE_NONE, or
+// CODE_MULTI (several hits: the writer re-enumerates them with the generic walk)
+constexpr uint32_t CODE_NONE = 0xFFFFFFFFu, CODE_MULTI = 0xFFFFFFFEu;
 
 // Visits every right-side row whose closed bbox contains the point, in ascending id order.
 template <typename F>
@@ -128,7 +137,7 @@ __device__ __forceinline__ void for_each_candidate(const IndexView& ix, const Gr
 __device__ inline void generic_point(const DevGeo& polys, const IndexView& ix, double px, double py, uint32_t& cnt,
                                      uint32_t& first) {
     cnt = 0;
-    first = NO_HIT;
+    first = CODE_NONE;
     const GridParams g = *ix.grid;
     for_each_candidate(ix, g, px, py, [&](int j) {
         if (dev::valid_row(polys.validity, j) && dev::polygonal_hits_point<false>(polys, j, px, py)) {
@@ -138,25 +147,29 @@ __device__ inline void generic_point(const DevGeo& polys, const IndexView& ix, d
     });
 }
 
-struct QEntry {
+struct QEntry {  // 32 bytes: one queued (point, part) pair with its exterior slab already located
     double px, py;
-    uint32_t part, li;
+    uint32_t part, e0, cnt;
+    uint32_t li_flags;  // local point index | (part has holes) << 31
 };
 
 // pip_tile: one work-group classifies PIP_TILE points.
 //   phase 1 (lane = point): ONE 4-byte gather from the raster answers most points outright (no polygon
-//            here / strictly inside part p); points whose cell an edge may cross are pushed to an LDS queue
-//            with a wave-aggregated slot grab (ballot + one LDS atomic per wave).
-//   phase 2 (PIP_GS lanes = one queued pair): the group reads the part's slab for the point's raster row as
-//            consecutive 32-byte edge records and runs the exact winding walk, folding the winding number and
-//            the on-boundary flag with xor-shuffles.  Compacting the undecided points this way keeps the lanes
+//            here / strictly inside part p).  A point whose cell an edge may cross chases two more small
+//            gathers (PartInfo, slab offsets) — all lanes of all resident waves do this concurrently, so the
+//            latency of the dependent loads is hidden here — and is pushed to an LDS queue with a
+//            wave-aggregated slot grab (ballot + one LDS atomic per wave).  Loads are issued in stages
+//            (all points, then all cells, then all PartInfos, ...) to keep PIP_PPT requests per lane in flight.
+//   phase 2 (PIP_GS lanes = one queued pair): the group reads the slab as consecutive 32-byte edge records
+//            (one dependent load level) and runs the exact winding walk, folding the winding number and the
+//            on-boundary flag with xor-shuffles.  Compacting the undecided points this way keeps the lanes
 //            dense in the only expensive part of the kernel.
 //   finalize: rows with exactly one part hit map part -> geometry; rows with several hits (overlapping
 //            polygons / multipolygon parts) are recomputed by the generic walk so that counts are per geometry.
 template <bool RASTER>
 __global__ __launch_bounds__(PIP_BLOCK) void pip_tile_kernel(DevGeo pts, DevGeo polys, IndexView ix, PipView pv,
                                                               uint32_t* __restrict__ counts,
-                                                              uint32_t* __restrict__ first_hit,
+                                                              uint32_t* __restrict__ code,
                                                               unsigned long long* __restrict__ block_tot) {
     __shared__ QEntry q[RASTER ? PIP_QCAP : 1];
     __shared__ uint32_t s_cnt[PIP_TILE], s_hit[PIP_TILE];
@@ -173,29 +186,60 @@ __global__ __launch_bounds__(PIP_BLOCK) void pip_tile_kernel(DevGeo pts, DevGeo 
         __syncthreads();
 
         const int lane64 = tid & 63;
+        double2 p[PIP_PPT];
+        uint32_t word[PIP_PPT];
+        int fy[PIP_PPT];
+        bool want[PIP_PPT];
+        PartInfo pi[PIP_PPT];
+        int e0[PIP_PPT], e1[PIP_PPT];
+        // stage A: points (coalesced 16-byte loads)
 #pragma unroll
         for (int k = 0; k < PIP_PPT; ++k) {
-            const int li = k * PIP_BLOCK + tid;
-            const int64_t i = base + li;
-            uint32_t word = 0;
-            double2 p = make_double2(0.0, 0.0);
-            if (i < n && dev::valid_row(pts.validity, i)) {
-                p = pts.xy[i];
-                const int fx = pip::col_of(pv, p.x), fy = pip::row_of(pv, p.y);
-                word = pv.cell[(int64_t)fy * pv.R + fx];
-            }
-            const uint32_t tag = word >> 30;
-            const uint32_t payload = word & 0x3FFFFFFFu;
-            bool push = false;
+            const int64_t i = base + k * PIP_BLOCK + tid;
+            const bool ok = i < n && dev::valid_row(pts.validity, i);
+            p[k] = ok ? pts.xy[i] : make_double2(NAN, NAN);
+        }
+        // stage B: raster words (one 4-byte gather per point)
+#pragma unroll
+        for (int k = 0; k < PIP_PPT; ++k) {
+            const int fx = pip::col_of(pv, p[k].x);
+            fy[k] = pip::row_of(pv, p[k].y);
+            word[k] = (p[k].x == p[k].x && p[k].y == p[k].y) ? pv.cell[(int64_t)fy[k] * pv.R + fx] : 0u;
+        }
+        // stage C: single-entry cells: decided, or PartInfo gather
+#pragma unroll
+        for (int k = 0; k < PIP_PPT; ++k) {
+            const uint32_t tag = word[k] >> 30, payload = word[k] & 0x3FFFFFFFu;
+            want[k] = false;
             if (tag == CELL_TAG_SINGLE) {
                 if (payload & 1u) {
-                    push = true;
+                    want[k] = true;
+                    pi[k] = pv.part_info[payload >> 1];
                 } else {
+                    const int li = k * PIP_BLOCK + tid;
                     s_cnt[li] = 1;  // only this lane touches s_cnt[li] before the barrier
                     s_hit[li] = payload >> 1;
                 }
             }
-            // wave-aggregated queue push
+        }
+        // stage D: slab offsets
+#pragma unroll
+        for (int k = 0; k < PIP_PPT; ++k) {
+            if (want[k]) {
+                const int j = fy[k] - pi[k].row0;
+                if (j < 0 || j >= pi[k].nrows) {
+                    want[k] = false;  // p.y outside the exterior's y-range: Outside
+                } else {
+                    e0[k] = pv.slab_off[pi[k].slab_base + j];
+                    e1[k] = pv.slab_off[pi[k].slab_base + j + 1];
+                }
+            }
+        }
+        // stage E: wave-aggregated queue push
+#pragma unroll
+        for (int k = 0; k < PIP_PPT; ++k) {
+            const int li = k * PIP_BLOCK + tid;
+            const bool push = want[k] && e1[k] > e0[k];
             const unsigned long long mask = __ballot(push);
             if (mask) {
                 uint32_t wbase = 0;
@@ -203,30 +247,44 @@ __global__ __launch_bounds__(PIP_BLOCK) void pip_tile_kernel(DevGeo pts, DevGeo 
                 if (lane64 == leader) wbase = atomicAdd(&q_n, (uint32_t)__popcll(mask));
                 wbase = __shfl(wbase, leader, 64);
                 if (push) {
+                    const uint32_t part = (word[k] & 0x3FFFFFFFu) >> 1;
                     const uint32_t slot = wbase + (uint32_t)__popcll(mask & ((1ull << lane64) - 1ull));
                     if (slot < (uint32_t)PIP_QCAP) {
-                        q[slot] = QEntry{p.x, p.y, payload >> 1, (uint32_t)li};
-                    } else if (pip::part_pos_single(pv, polys, (int)(payload >> 1), p.x, p.y) == dev::POS_INSIDE) {
+                        q[slot] = QEntry{p[k].x, p[k].y, part, (uint32_t)e0[k], (uint32_t)(e1[k] - e0[k]),
+                                         (uint32_t)li | (pi[k].n_rings > 1 ? 0x80000000u : 0u)};
+                    } else if (pip::part_pos_single(pv, polys, (int)part, p[k].x, p[k].y) == dev::POS_INSIDE) {
                         s_cnt[li] += 1;
-                        s_hit[li] = payload >> 1;
+                        s_hit[li] = part;
                     }
                 }
             }
-            if (tag == CELL_TAG_LIST) {  // several parts meet this cell (shared borders, overlaps)
-                const uint32_t m = pv.list[payload];
-                for (uint32_t t = 0; t < m; ++t) {
-                    const uint32_t e = pv.list[payload + 1 + t];
-                    if (e & 1u) {
-                        const uint32_t slot = atomicAdd(&q_n, 1u);
-                        if (slot < (uint32_t)PIP_QCAP) {
-                            q[slot] = QEntry{p.x, p.y, e >> 1, (uint32_t)li};
-                            continue;
-                        }
-                        if (pip::part_pos_single(pv, polys, (int)(e >> 1), p.x, p.y) != dev::POS_INSIDE) continue;
+        }
+        // cells where several parts meet (shared borders, overlaps): per-lane walk of the entry list
+#pragma unroll
+        for (int k = 0; k < PIP_PPT; ++k) {
+            if ((word[k] >> 30) != CELL_TAG_LIST) continue;
+            const int li = k * PIP_BLOCK + tid;
+            const uint32_t off = word[k] & 0x3FFFFFFFu;
+            const uint32_t m = pv.list[off];
+            for (uint32_t t = 0; t < m; ++t) {
+                const uint32_t e = pv.list[off + 1 + t];
+                const uint32_t part = e >> 1;
+                if (e & 1u) {
+                    const PartInfo pq = pv.part_info[part];
+                    const int j = fy[k] - pq.row0;
+                    if (j < 0 || j >= pq.nrows) continue;
+                    const int a0 = pv.slab_off[pq.slab_base + j], a1 = pv.slab_off[pq.slab_base + j + 1];
+                    if (a1 <= a0) continue;
+                    const uint32_t slot = atomicAdd(&q_n, 1u);
+                    if (slot < (uint32_t)PIP_QCAP) {
+                        q[slot] = QEntry{p[k].x, p[k].y, part, (uint32_t)a0, (uint32_t)(a1 - a0),
+                                         (uint32_t)li | (pq.n_rings > 1 ? 0x80000000u : 0u)};
+                        continue;
                     }
-                    s_cnt[li] += 1;
-                    s_hit[li] = e >> 1;
+                    if (pip::part_pos_single(pv, polys, (int)part, p[k].x, p[k].y) != dev::POS_INSIDE) continue;
                 }
+                s_cnt[li] += 1;
+                s_hit[li] = part;
             }
         }
         __syncthreads();
@@ -235,10 +293,12 @@ __global__ __launch_bounds__(PIP_BLOCK) void pip_tile_kernel(DevGeo pts, DevGeo 
         const int glane = tid & (PIP_GS - 1);
         for (uint32_t e = tid / PIP_GS; e < nq; e += PIP_BLOCK / PIP_GS) {
             const QEntry en = q[e];
-            const int pos = pip::part_pos_group<PIP_GS>(pv, polys, (int)en.part, en.px, en.py, glane);
+            const int pos = pip::part_pos_group_from_edges<PIP_GS>(pv, polys, (int)en.part, (en.li_flags >> 31) ? 2 : 1, (int)en.e0,
+                                                                   (int)en.cnt, en.px, en.py, glane);
             if (glane == 0 && pos == dev::POS_INSIDE) {
-                atomicAdd(&s_cnt[en.li], 1u);
-                s_hit[en.li] = en.part;  // with several hits the row is recomputed below, so any writer may win
+                const uint32_t li = en.li_flags & 0x7FFFFFFFu;
+                atomicAdd(&s_cnt[li], 1u);
+                s_hit[li] = en.part;  // with several hits the row is recomputed below, so any writer may win
             }
         }
         __syncthreads();
@@ -250,7 +310,7 @@ __global__ __launch_bounds__(PIP_BLOCK) void pip_tile_kernel(DevGeo pts, DevGeo 
         const int li = k * PIP_BLOCK + tid;
         const int64_t i = base + li;
         if (i >= n) continue;
-        uint32_t cnt = 0, first = NO_HIT;
+        uint32_t cnt = 0, first = CODE_NONE;
         bool generic = !RASTER;
         if (RASTER) {
             cnt = s_cnt[li];
@@ -258,7 +318,7 @@ __global__ __launch_bounds__(PIP_BLOCK) void pip_tile_kernel(DevGeo pts, DevGeo 
                 first = pv.part_geom ? pv.part_geom[s_hit[li]] : s_hit[li];
                 if (!dev::valid_row(polys.validity, first)) {
                     cnt = 0;
-                    first = NO_HIT;
+                    first = CODE_NONE;
                 }
             } else if (cnt > 1) {
                 generic = true;
@@ -267,12 +327,12 @@ __global__ __launch_bounds__(PIP_BLOCK) void pip_tile_kernel(DevGeo pts, DevGeo 
         if (generic) {
             cnt = 0;
             if (dev::valid_row(pts.validity, i)) {
-                const double2 p = pts.xy[i];
-                generic_point(polys, ix, p.x, p.y, cnt, first);
+                const double2 pp = pts.xy[i];
+                generic_point(polys, ix, pp.x, pp.y, cnt, first);
             }
         }
-        counts[i] = cnt;
-        first_hit[i] = first;
+        if (counts) counts[i] = cnt;
+        code[i] = cnt == 0 ? CODE_NONE : (cnt == 1 ? first : CODE_MULTI);
         local += cnt;
     }
     unsigned long long tot;
@@ -280,9 +340,10 @@ __global__ __launch_bounds__(PIP_BLOCK) void pip_tile_kernel(DevGeo pts, DevGeo 
     if (tid == 0) block_tot[blockIdx.x] = tot;
 }
 
+// pip_write: turns the per-point codes into the sorted (l, r) pair list.  Reads 4 bytes per point, writes 8
+// bytes per hit; only CODE_MULTI rows touch geometry again.
 __global__ __launch_bounds__(PIP_BLOCK) void pip_write_kernel(DevGeo pts, DevGeo polys, IndexView ix,
-                                                               const uint32_t* __restrict__ counts,
-                                                               const uint32_t* __restrict__ first_hit,
+                                                               const uint32_t* __restrict__ code,
                                                                const unsigned long long* __restrict__ block_off,
                                                                uint32_t left_base, uint2* __restrict__ pairs,
                                                                int64_t capacity) {
@@ -292,18 +353,23 @@ __global__ __launch_bounds__(PIP_BLOCK) void pip_write_kernel(DevGeo pts, DevGeo
 #pragma unroll
     for (int k = 0; k < PIP_PPT; ++k) {
         const int64_t i = base + k * PIP_BLOCK + threadIdx.x;
-        const uint32_t cnt = i < pts.n_geoms ? counts[i] : 0u;
+        const uint32_t c = i < pts.n_geoms ? code[i] : CODE_NONE;
+        uint32_t cnt = c == CODE_NONE ? 0u : 1u, first = c;
+        double2 p = make_double2(0.0, 0.0);
+        if (c == CODE_MULTI) {
+            p = pts.xy[i];
+            generic_point(polys, ix, p.x, p.y, cnt, first);
+        }
         unsigned long long tot;
         const unsigned long long ex = dev::block_exclusive_scan<unsigned long long, PIP_BLOCK>((unsigned long long)cnt, lds, &tot);
         int64_t o = (int64_t)(running + ex);
         running += tot;
         if (cnt == 0) continue;
         const uint32_t l = left_base + (uint32_t)i;
-        if (cnt == 1) {
-            if (o < capacity) pairs[o] = make_uint2(l, first_hit[i]);
+        if (c != CODE_MULTI) {
+            if (o < capacity) pairs[o] = make_uint2(l, c);
             continue;
         }
-        const double2 p = pts.xy[i];
         const GridParams g = *ix.grid;
         for_each_candidate(ix, g, p.x, p.y, [&](int j) {
             if (dev::valid_row(polys.validity, j) && dev::polygonal_hits_point<false>(polys, j, p.x, p.y)) {
@@ -477,16 +543,18 @@ int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right, co
     const bool want_pairs = pair_capacity > 0;
     const size_t counts_bytes = sizeof(uint32_t) * (size_t)n;
     const size_t pairs_bytes = sizeof(uint32_t) * 2 * (size_t)pair_capacity;
-    size_t need = align256(counts_bytes) /*first_hit*/ + align256(sizeof(unsigned long long) * (size_t)(n_blocks + 1)) + 1024;
-    const bool stage_counts = host_out || !out_counts;
-    if (stage_counts) need += align256(counts_bytes);
+    size_t need = align256(counts_bytes) /*code*/ + align256(sizeof(unsigned long long) * (size_t)(n_blocks + 1)) + 1024;
+    if (host_out && out_counts) need += align256(counts_bytes);
     if (host_out && want_pairs) need += align256(pairs_bytes);
     int32_t rc = workspace().begin(need);
     if (rc != GPK_OK) return done(rc);
-    uint32_t* first_hit = (uint32_t*)workspace().take(counts_bytes);
+    uint32_t* code = (uint32_t*)workspace().take(counts_bytes);
     unsigned long long* btot = (unsigned long long*)workspace().take(sizeof(unsigned long long) * (size_t)(n_blocks + 1));
-    uint32_t* counts_dev = stage_counts ? (uint32_t*)workspace().take(counts_bytes) : out_counts;
+    uint32_t* counts_dev = out_counts ? (host_out ? (uint32_t*)workspace().take(counts_bytes) : out_counts) : nullptr;
     uint32_t* pairs_dev = want_pairs ? (host_out ? (uint32_t*)workspace().take(pairs_bytes) : out_pairs) : nullptr;
+
+    static thread_local unsigned long long* pinned_total = nullptr;  // device-mapped host word: no D2H copy per call
+    if (!pinned_total && hipHostMalloc((void**)&pinned_total, 64, hipHostMallocMapped) != hipSuccess) pinned_total = nullptr;
 
 #define J_LAUNCH(...)                          \
     do {                                       \
@@ -500,20 +568,22 @@ int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right, co
 
     if (right_index->pip.R > 0)
         J_LAUNCH("gpk_pip_tile", pip_tile_kernel<true>, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
-                 right_index->v, right_index->pip, counts_dev, first_hit, btot);
+                 right_index->v, right_index->pip, counts_dev, code, btot);
     else
         J_LAUNCH("gpk_pip_tile_generic", pip_tile_kernel<false>, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
-                 right_index->v, right_index->pip, counts_dev, first_hit, btot);
-    J_LAUNCH("gpk_scan_totals", scan_block_totals_kernel, dim3(1), dim3(1024), 0, s, btot, n_blocks, btot + n_blocks);
+                 right_index->v, right_index->pip, counts_dev, code, btot);
+    J_LAUNCH("gpk_scan_totals", scan_block_totals_kernel, dim3(1), dim3(1024), 0, s, btot, n_blocks, btot + n_blocks, pinned_total);
     if (want_pairs)
         J_LAUNCH("gpk_pip_write", pip_write_kernel, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
-                 right_index->v, counts_dev, first_hit, btot, left_row_base, (uint2*)pairs_dev, pair_capacity);
+                 right_index->v, code, btot, left_row_base, (uint2*)pairs_dev, pair_capacity);
 #undef J_LAUNCH
 
     unsigned long long total = 0;
-    hipError_t e = hipMemcpyAsync(&total, btot + n_blocks, sizeof total, hipMemcpyDeviceToHost, s);
+    hipError_t e = hipSuccess;
+    if (!pinned_total) e = hipMemcpyAsync(&total, btot + n_blocks, sizeof total, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return done(fail(GPK_ERR_DEVICE, "spatial_join: %s", hipGetErrorString(e)));
+    if (pinned_total) total = *(volatile unsigned long long*)pinned_total;
     *n_pairs = (int64_t)total;
     if (host_out) {
         if (out_counts) {

@@ -75,6 +75,34 @@ __device__ __forceinline__ int ring_pos_group(const PipView& pv, int r, double p
     return wn == 0 ? dev::POS_OUTSIDE : dev::POS_INSIDE;
 }
 
+// exterior slab already resolved to the edge range [e0, e0 + cnt): walk it, then the holes if needed
+template <int GS>
+__device__ __forceinline__ int part_pos_group_from_edges(const PipView& pv, const DevGeo& a, int part, int n_rings, int e0, int cnt,
+                                                         double px, double py, int lane) {
+    int wn = 0, on = 0;
+    for (int k = lane; k < cnt; k += GS) {
+        const double4 ed = pv.slab_edges[e0 + k];
+        on |= (int)dev::ring_edge(ed.x, ed.y, ed.z, ed.w, px, py, wn);
+    }
+#pragma unroll
+    for (int o = GS / 2; o > 0; o >>= 1) {
+        wn += __shfl_xor(wn, o, 64);
+        on |= __shfl_xor(on, o, 64);
+    }
+    if (on) return dev::POS_BOUNDARY;
+    if (wn == 0) return dev::POS_OUTSIDE;
+    if (n_rings <= 1) return dev::POS_INSIDE;
+    int r0, r1;
+    dev::part_rings(a, part, r0, r1);
+    const int row = row_of(pv, py);
+    for (int r = r0 + 1; r < r1; ++r) {
+        const int ph = ring_pos_group<GS>(pv, r, px, py, row, lane);
+        if (ph == dev::POS_BOUNDARY) return dev::POS_BOUNDARY;
+        if (ph == dev::POS_INSIDE) return dev::POS_OUTSIDE;
+    }
+    return dev::POS_INSIDE;
+}
+
 template <int GS>
 __device__ __forceinline__ int part_pos_group(const PipView& pv, const DevGeo& a, int part, double px, double py, int lane) {
     int r0, r1;

@@ -46,6 +46,21 @@ __global__ void ring_part_kernel(DevGeo a, int64_t n_parts, int32_t* __restrict_
     for (int r = r0; r < r1; ++r) ring_part[r] = (int32_t)p;
 }
 
+__global__ void part_info_kernel(DevGeo a, int64_t n_parts, const int32_t* __restrict__ row0, const int32_t* __restrict__ slab_base,
+                                 PartInfo* __restrict__ info) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_parts) return;
+    int r0, r1;
+    dev::part_rings(a, (int)p, r0, r1);
+    PartInfo pi{0, 0, 0, r1 - r0};
+    if (r1 > r0) {
+        pi.slab_base = slab_base[r0];
+        pi.row0 = row0[r0];
+        pi.nrows = slab_base[r0 + 1] - slab_base[r0];
+    }
+    info[p] = pi;
+}
+
 __global__ void ring_rows_kernel(const double4* __restrict__ ring_bbox, int64_t n_rings, FineGrid f,
                                  int32_t* __restrict__ row0, int32_t* __restrict__ nrows) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -369,6 +384,11 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
     GPK_LAUNCH("gpk_pipidx_slab_fill", slab_register_kernel<true>, blocks_for(d.n_coords), dim3(256), 0, s, d, g, row0, slab_base,
                cursor, edges);
 
+    PartInfo* part_info = nullptr;
+    GPK_HIP(hipMalloc((void**)&part_info, sizeof(PartInfo) * (size_t)(n_parts ? n_parts : 1)));
+    keep(part_info);
+    GPK_LAUNCH("gpk_pipidx_part_info", part_info_kernel, blocks_for(n_parts), dim3(256), 0, s, d, n_parts, row0, slab_base, part_info);
+
     PipView pv;
     memset(&pv, 0, sizeof pv);
     pv.R = R;
@@ -379,6 +399,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
     pv.inv_fw = g.inv_fw;
     pv.inv_fh = g.inv_fh;
     pv.part_geom = part_geom;
+    pv.part_info = part_info;
     pv.ring_row0 = row0;
     pv.ring_slab_base = slab_base;
     pv.slab_off = slab_off;
@@ -449,7 +470,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
     ix->pip = pv;
     ix->nbytes += (int64_t)(sizeof(uint32_t) * (size_t)n_cells + sizeof(uint32_t) * (size_t)list_len + sizeof(double4) * (size_t)n_edges +
                             sizeof(int32_t) * (size_t)(n_slabs + 1) + sizeof(int32_t) * (size_t)(2 * n_rings + 1) +
-                            (part_geom ? sizeof(uint32_t) * (size_t)n_parts : 0));
+                            (part_geom ? sizeof(uint32_t) * (size_t)n_parts : 0) + sizeof(PartInfo) * (size_t)n_parts);
     return GPK_OK;
 }
 

@@ -52,25 +52,56 @@ __device__ __forceinline__ T block_exclusive_scan(T v, T* lds, T* total) {
 
 }  // namespace dev
 
-// Single-block exclusive scan of n 64-bit totals, in place; writes the grand total to *grand.
-// n is small (one entry per work-group of a preceding kernel).
+// Single-block exclusive scan of n 64-bit totals, in place; writes the grand total to *grand (and to
+// *grand_host when given: a pinned, device-mapped word the host reads after the stream sync, which
+// saves a D2H copy per call).  n is small (one entry per work-group of a preceding kernel).  Chunks of
+// 8192 values are staged in LDS with coalesced loads; every thread then scans 8 consecutive LDS values,
+// one block scan stitches the threads, and the chunk is written back coalesced.
 static __global__ __launch_bounds__(1024) void scan_block_totals_kernel(unsigned long long* __restrict__ v,
-                                                                  int64_t n,
-                                                                  unsigned long long* __restrict__ grand) {
+                                                                         int64_t n,
+                                                                         unsigned long long* __restrict__ grand,
+                                                                         unsigned long long* __restrict__ grand_host = nullptr) {
+    constexpr int PER = 8, CHUNK = 1024 * PER;
+    __shared__ unsigned long long buf[CHUNK + CHUNK / 32];  // padded against bank conflicts of the stride-8 walk
     __shared__ unsigned long long lds[17];
     unsigned long long carry = 0;
-    for (int64_t base = 0; base < n; base += 1024) {
-        const int64_t i = base + threadIdx.x;
-        const unsigned long long x = i < n ? v[i] : 0ull;
+    for (int64_t base = 0; base < n; base += CHUNK) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int j = k * 1024 + threadIdx.x;
+            buf[j + (j >> 5)] = base + j < n ? v[base + j] : 0ull;
+        }
+        __syncthreads();
+        unsigned long long x[PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int j = threadIdx.x * PER + k;
+            x[k] = buf[j + (j >> 5)];
+            sum += x[k];
+        }
         unsigned long long tot;
-        const unsigned long long ex = dev::block_exclusive_scan<unsigned long long, 1024>(x, lds, &tot);
-        if (i < n) v[i] = carry + ex;
+        unsigned long long run = carry + dev::block_exclusive_scan<unsigned long long, 1024>(sum, lds, &tot);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int j = threadIdx.x * PER + k;
+            buf[j + (j >> 5)] = run;
+            run += x[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int j = k * 1024 + threadIdx.x;
+            if (base + j < n) v[base + j] = buf[j + (j >> 5)];
+        }
         carry += tot;
+        __syncthreads();
     }
-    if (threadIdx.x == 0) *grand = carry;
+    if (threadIdx.x == 0) {
+        *grand = carry;
+        if (grand_host) *grand_host = carry;
+    }
 }
 
-// exclusive scan of int32 counts, 256 per block
 static __global__ __launch_bounds__(256) void scan_i32_partial_kernel(const int32_t* __restrict__ in, int64_t n,
                                                                unsigned long long* __restrict__ block_tot) {
     __shared__ unsigned long long lds[5];
@@ -105,7 +136,8 @@ static inline int32_t exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* 
     const int64_t nb = (n + 255) / 256;
     if (n <= 0) return GPK_OK;
     GPK_LAUNCH("gpk_scan_partial", scan_i32_partial_kernel, dim3((unsigned)nb), dim3(256), 0, s, in, n, block_tot);
-    GPK_LAUNCH("gpk_scan_totals", scan_block_totals_kernel, dim3(1), dim3(1024), 0, s, block_tot, nb, block_tot + nb);
+    GPK_LAUNCH("gpk_scan_totals", scan_block_totals_kernel, dim3(1), dim3(1024), 0, s, block_tot, nb, block_tot + nb,
+               (unsigned long long*)nullptr);
     GPK_LAUNCH("gpk_scan_final", scan_i32_final_kernel, dim3((unsigned)nb), dim3(256), 0, s, in, n, block_tot, out, out2);
     return GPK_OK;
 }
