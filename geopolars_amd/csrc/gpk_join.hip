@@ -15,6 +15,7 @@
 #include "gpk_device.h"
 #include "gpk_index.h"
 #include "gpk_pip.h"
+#include "gpk_polypoly.h"
 #include "gpk_scan.h"
 
 namespace gpk {
@@ -380,10 +381,135 @@ __global__ __launch_bounds__(PIP_BLOCK) void pip_write_kernel(DevGeo pts, DevGeo
     }
 }
 
+// ================================= polygonal x polygonal join ======================================
+// Candidate generation of spatial_index.rs:74-76 for bbox-shaped left rows: every directory cell the left
+// bbox touches is visited; a pair seen in several cells is processed only in the cell that holds the lower
+// left corner of the two boxes' intersection (computed with the same monotone cell function, so that cell
+// is in both registration ranges).  The exact refine is Intersects<Polygon> (gpk_polypoly.h).
+template <typename F>
+__device__ __forceinline__ void for_each_bbox_candidate(const IndexView& ix, const GridParams& g, const double4 lb, F&& f) {
+    if (!(lb.x == lb.x)) return;  // empty left geometry
+    const int cx0 = dev::cell_of(lb.x, g.x0, g.inv_w, g.gx), cx1 = dev::cell_of(lb.z, g.x0, g.inv_w, g.gx);
+    const int cy0 = dev::cell_of(lb.y, g.y0, g.inv_h, g.gy), cy1 = dev::cell_of(lb.w, g.y0, g.inv_h, g.gy);
+    for (int cy = cy0; cy <= cy1; ++cy)
+        for (int cx = cx0; cx <= cx1; ++cx) {
+            const int c = cy * g.gx + cx;
+            for (int k = ix.cell_off[c]; k < ix.cell_off[c + 1]; ++k) {
+                const int j = ix.items[k];
+                const double4 rb = ix.bbox[j];
+                if (lb.z < rb.x || lb.w < rb.y || rb.z < lb.x || rb.w < lb.y) continue;  // closed-interval overlap test
+                const double rx = lb.x > rb.x ? lb.x : rb.x, ry = lb.y > rb.y ? lb.y : rb.y;
+                if (dev::cell_of(rx, g.x0, g.inv_w, g.gx) != cx || dev::cell_of(ry, g.y0, g.inv_h, g.gy) != cy) continue;
+                f(j);
+            }
+        }
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void bbox_join_kernel(DevGeo left, DevGeo right, IndexView ix, const double4* __restrict__ lbbox,
+                                                         int32_t* __restrict__ counts, const int32_t* __restrict__ offsets,
+                                                         uint32_t left_base, uint2* __restrict__ pairs, int64_t capacity) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= left.n_geoms) return;
+    int cnt = 0;
+    const int64_t o0 = WRITE ? (int64_t)offsets[i] : 0;
+    if (dev::valid_row(left.validity, i)) {
+        const GridParams g = *ix.grid;
+        for_each_bbox_candidate(ix, g, lbbox[i], [&](int j) {
+            if (!dev::valid_row(right.validity, j)) return;
+            if (!polygonal_intersects_polygonal(left, i, right, j)) return;
+            if (WRITE && o0 + cnt < capacity) pairs[o0 + cnt] = make_uint2(left_base + (uint32_t)i, (uint32_t)j);
+            ++cnt;
+        });
+    }
+    if (!WRITE) {
+        counts[i] = cnt;
+        return;
+    }
+    // candidates arrive in cell order: sort this row's hits by right id (rows are short)
+    const int64_t m = o0 + cnt <= capacity ? cnt : (capacity > o0 ? capacity - o0 : 0);
+    for (int64_t a = 1; a < m; ++a) {
+        const uint2 key = pairs[o0 + a];
+        int64_t b = a - 1;
+        while (b >= 0 && pairs[o0 + b].y > key.y) {
+            pairs[o0 + b + 1] = pairs[o0 + b];
+            --b;
+        }
+        pairs[o0 + b + 1] = key;
+    }
+}
+
+__global__ void i32_to_u32_copy_kernel(const int32_t* __restrict__ in, uint32_t* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint32_t)in[i];
+}
+
 // ================================= host drivers ================================================
 static inline dim3 grid_for(int64_t n, int block) {
     int64_t b = (n + block - 1) / block;
     return dim3((unsigned)(b > 0 ? b : 1));
+}
+
+// polygonal x polygonal: count -> scan -> write (each row's hits sorted by right id)
+static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, const gpk_index* right_index, uint32_t left_row_base,
+                         uint32_t* out_counts, uint32_t* out_pairs, int64_t pair_capacity, int64_t* n_pairs, int32_t out_space,
+                         hipStream_t s) {
+    const int64_t n = left->d.n_geoms;
+    const bool host_out = out_space != GPK_MEM_DEVICE;
+    const bool want_pairs = pair_capacity > 0;
+    // left bboxes first (gpk_bounds uses the workspace itself), into an allocation of their own
+    double4* lbbox = nullptr;
+    GPK_HIP(hipMalloc((void**)&lbbox, sizeof(double4) * (size_t)n));
+    auto done = [&](int32_t rc) {
+        (void)hipFree(lbbox);
+        return rc;
+    };
+    int32_t rc = gpk_bounds(left, (double*)lbbox, GPK_MEM_DEVICE, (void*)s);
+    if (rc != GPK_OK) return done(rc);
+    const int64_t nb = (n + 255) / 256;
+    const size_t pairs_bytes = sizeof(uint32_t) * 2 * (size_t)pair_capacity;
+    size_t need = 2 * align256(sizeof(int32_t) * (size_t)(n + 1)) + align256(sizeof(unsigned long long) * (size_t)(nb + 2)) + 1024;
+    if (host_out && out_counts) need += align256(sizeof(uint32_t) * (size_t)n);
+    if (host_out && want_pairs) need += align256(pairs_bytes);
+    rc = workspace().begin(need);
+    if (rc != GPK_OK) return done(rc);
+    int32_t* counts = (int32_t*)workspace().take(sizeof(int32_t) * (size_t)(n + 1));
+    int32_t* offsets = (int32_t*)workspace().take(sizeof(int32_t) * (size_t)(n + 1));
+    unsigned long long* btot = (unsigned long long*)workspace().take(sizeof(unsigned long long) * (size_t)(nb + 2));
+    uint32_t* counts_out = out_counts ? (host_out ? (uint32_t*)workspace().take(sizeof(uint32_t) * (size_t)n) : out_counts) : nullptr;
+    uint32_t* pairs_dev = want_pairs ? (host_out ? (uint32_t*)workspace().take(pairs_bytes) : out_pairs) : nullptr;
+    auto run = [&]() -> int32_t {
+        GPK_LAUNCH("gpk_bbox_join_count", bbox_join_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, left->d, right->d, right_index->v,
+                   lbbox, counts, (const int32_t*)nullptr, left_row_base, (uint2*)nullptr, (int64_t)0);
+        GPK_TRY(exclusive_scan_i32(counts, n, offsets, nullptr, btot, s));
+        if (counts_out)
+            GPK_LAUNCH("gpk_counts_copy", i32_to_u32_copy_kernel, dim3((unsigned)nb), dim3(256), 0, s, counts, counts_out, n);
+        if (want_pairs)
+            GPK_LAUNCH("gpk_bbox_join_write", bbox_join_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, left->d, right->d,
+                       right_index->v, lbbox, counts, offsets, left_row_base, (uint2*)pairs_dev, pair_capacity);
+        return GPK_OK;
+    };
+    rc = run();
+    if (rc != GPK_OK) return done(rc);
+    int32_t total = 0;
+    hipError_t e = hipMemcpyAsync(&total, offsets + n, sizeof total, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return done(fail(GPK_ERR_DEVICE, "spatial_join: %s", hipGetErrorString(e)));
+    *n_pairs = (int64_t)total;
+    if (host_out) {
+        if (out_counts) {
+            rc = copy_out(out_counts, out_space, counts_out, sizeof(uint32_t) * (size_t)n, s);
+            if (rc != GPK_OK) return done(rc);
+        }
+        if (want_pairs) {
+            const int64_t w = (int64_t)total < pair_capacity ? (int64_t)total : pair_capacity;
+            rc = copy_out(out_pairs, out_space, pairs_dev, sizeof(uint32_t) * 2 * (size_t)w, s);
+            if (rc != GPK_OK) return done(rc);
+        }
+    }
+    if (want_pairs && (int64_t)total > pair_capacity)
+        return done(fail(GPK_ERR_CAPACITY, "spatial_join: %lld pairs but capacity %lld", (long long)total, (long long)pair_capacity));
+    return done(GPK_OK);
 }
 
 }  // namespace gpk
@@ -519,7 +645,11 @@ int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right, co
 
     // dispatch table of spatial_index.rs:89-137
     const bool pip = left->d.type == GPK_GEOM_POINT && is_polygonal(right->d.type);
-    if (!pip)
+    const bool polypoly = is_polygonal(left->d.type) && is_polygonal(right->d.type);
+    if (polypoly && predicate != GPK_PRED_INTERSECTS)
+        return fail(GPK_ERR_MISMATCHED_GEOMETRY,
+                    "spatial_join: contains/within(polygon, polygon) is a DE-9IM relate upstream and is not implemented");
+    if (!pip && !polypoly)
         return fail(GPK_ERR_MISMATCHED_GEOMETRY,
                     "spatial_join: left type %d x right type %d is not supported by this build",
                     left->d.type, right->d.type);
@@ -538,6 +668,7 @@ int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right, co
 
     const int64_t n = left->d.n_geoms;
     if (n == 0) return done(GPK_OK);
+    if (polypoly) return done(bbox_join(left, right, right_index, left_row_base, out_counts, out_pairs, pair_capacity, n_pairs, out_space, s));
     const int64_t n_blocks = (n + PIP_TILE - 1) / PIP_TILE;
     const bool host_out = out_space != GPK_MEM_DEVICE;
     const bool want_pairs = pair_capacity > 0;

@@ -95,3 +95,33 @@ def test_empty_and_nan_inputs(gpk):
     nanpts = GeoSeries(GeoArrowArray.from_points([[np.nan, np.nan], [np.nan, 1.0]]))
     pairs, counts = join_pairs(nanpts, polys)
     assert pairs.shape == (0, 2) and counts.tolist() == [0, 0]
+
+
+@pytest.mark.parametrize("n,neigh", [(500, 4.0), (6000, 12.0)])
+def test_c4_polygon_polygon_intersects_join(gpk, oracle, n, neigh):
+    """configs[3] at test scale: polygon x polygon intersects join (spatial_index.rs:102-104), sorted pairs."""
+    a = synth.clustered_polygons(n, seed=21, mean_neighbours=neigh)
+    b = synth.clustered_polygons(n + 37, seed=22, mean_neighbours=neigh)
+    exp_pairs, exp_counts, _ = oracle.spatial_join(a, b, "intersects", mode=0)
+    got_pairs, got_counts = join_pairs(GeoSeries(a), GeoSeries(b), "intersects")
+    assert len(exp_pairs) > n // 4
+    assert np.array_equal(got_counts, exp_counts)
+    assert np.array_equal(got_pairs, exp_pairs)
+
+
+def test_multipolygon_polygon_intersects_join(gpk, oracle):
+    a = synth.powerlaw_multipolygons(800, seed=31)
+    b = synth.clustered_polygons(900, seed=32, mean_neighbours=20.0)
+    for l, r in ((a, b), (b, a)):  # spatial_index.rs:107-123
+        exp_pairs, exp_counts, _ = oracle.spatial_join(l, r, "intersects", mode=1)
+        got_pairs, got_counts = join_pairs(GeoSeries(l), GeoSeries(r), "intersects")
+        assert len(exp_pairs) > 0
+        assert np.array_equal(got_counts, exp_counts) and np.array_equal(got_pairs, exp_pairs)
+
+
+def test_polygon_contains_polygon_is_reported_unsupported(gpk):
+    from geopolars_amd import _abi
+
+    a = GeoSeries(synth.clustered_polygons(10, seed=1))
+    with pytest.raises(_abi.MismatchedGeometry):
+        join_pairs(a, a, "contains")
