@@ -142,6 +142,18 @@ def main() -> None:
     bytes_count = 16 * n + 16 * v_total + 2 * 4 * (m + 1) + 4 * n
     bytes_join = bytes_count + 8 * h
     achieved = bytes_count / (k_count * 1e-3) / 1e9 if k_count > 0 else 0.0
+    traffic = None  # HBM-side bytes per launch of the dominant kernel, from committed PMC passes (profiles/)
+    try:
+        import glob
+
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+        if cands and n == 10_000_000 and m == 1000:
+            with open(cands[-1]) as f:
+                t = json.load(f)
+            if t.get("kernel") == "gpk_pip_tile":
+                traffic = t["traffic_bytes_per_launch"]
+    except Exception:
+        traffic = None
     out = {
         "metric": "predicate evals/sec (10M pts x 1k polys point-in-polygon)",
         "value": evals / elapsed,
@@ -177,7 +189,7 @@ def main() -> None:
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
             "launch_ms": k_count,
             "launches": n_count,
             "algorithmic_bytes": bytes_count,
