@@ -30,7 +30,9 @@ struct IndexView {  // passed to kernels by value
 // A fine R x R raster over the (padded) extent plus per-ring edge slabs on the raster rows.
 //   cell word  : tag(2) | payload(30).  tag 0 = no polygon can contain a point of this cell;
 //                tag 1 = exactly one entry, inline; tag 2 = payload is an offset into `list`
-//                (list[off] = n, then n entries).
+//                (list[off] = n, then n entries); tag 3 = exactly one part's edges cross the cell and
+//                payload indexes a 16-byte SubCell record: the cell split 4 x 4 with the same exact
+//                labelling, plus the slab location, so most of its points finish with one more gather.
 //   entry      : part << 1 | boundary.  boundary = 0 means EVERY representable point that maps to this
 //                cell is strictly inside that part (holes included) — decided once, exactly, at build
 //                time; boundary = 1 means some edge of the part may touch the cell: run the exact test.
@@ -42,11 +44,18 @@ struct IndexView {  // passed to kernels by value
 struct PartInfo {  // one 16-byte load tells a lane where the exterior ring's slabs of a part live
     int32_t slab_base, row0, nrows, n_rings;
 };
+struct SubCell {  // level-2 record of a raster cell crossed by edges of exactly ONE part (16 bytes, one gather)
+    uint32_t part;
+    uint32_t e0;         // first edge of the part's exterior slab for this cell's row
+    uint32_t cnt_flags;  // edge count | (part has holes) << 31
+    uint32_t labels;     // 4 x 4 sub-cells, 2 bits each (x fastest): 0 outside, 1 strictly inside, 2 test exactly
+};
 struct PipView {
     int32_t R;  // 0 = accelerator not built (degenerate extent): kernels use the generic walk
     double rx0, ry0, fw, fh, inv_fw, inv_fh;
     const uint32_t* cell;
     const uint32_t* list;
+    const SubCell* sub;              // level-2 records (cell tag 3)
     const uint32_t* part_geom;       // nullptr for POLYGON arrays (part == geometry)
     const PartInfo* part_info;       // n_parts
     const int32_t* ring_row0;
@@ -54,7 +63,7 @@ struct PipView {
     const int32_t* slab_off;         // n_slabs + 1
     const double4* slab_edges;
 };
-constexpr uint32_t CELL_TAG_EMPTY = 0u, CELL_TAG_SINGLE = 1u, CELL_TAG_LIST = 2u;
+constexpr uint32_t CELL_TAG_EMPTY = 0u, CELL_TAG_SINGLE = 1u, CELL_TAG_LIST = 2u, CELL_TAG_SUB = 3u;
 
 namespace dev {
 // Monotone non-decreasing in v (subtract, multiply by a non-negative constant, floor, clamp), so
@@ -76,7 +85,7 @@ struct gpk_index {
     int device;
     int64_t n_geoms;
     int32_t geom_type;
-    void* owned[12];  // bbox, grid, cell_off, items, then the PipView tables
+    void* owned[16];  // bbox, grid, cell_off, items, then the PipView tables
     int64_t nbytes;
 };
 

@@ -200,19 +200,27 @@ __global__ __launch_bounds__(PIP_BLOCK) void pip_tile_kernel(DevGeo pts, DevGeo 
             const bool ok = i < n && dev::valid_row(pts.validity, i);
             p[k] = ok ? pts.xy[i] : make_double2(NAN, NAN);
         }
-        // stage B: raster words (one 4-byte gather per point)
+        // stage B: raster words (one 4-byte gather per point).  Columns/rows are computed at 4x the raster
+        // resolution (an exact power-of-two rescale of the same monotone function), so `>> 2` is the level-1
+        // cell and `& 3` the level-2 sub-cell.
+        int sx[PIP_PPT];
 #pragma unroll
         for (int k = 0; k < PIP_PPT; ++k) {
-            const int fx = pip::col_of(pv, p[k].x);
-            fy[k] = pip::row_of(pv, p[k].y);
-            word[k] = (p[k].x == p[k].x && p[k].y == p[k].y) ? pv.cell[(int64_t)fy[k] * pv.R + fx] : 0u;
+            sx[k] = dev::cell_of(p[k].x, pv.rx0, pv.inv_fw * 4.0, pv.R * 4);
+            fy[k] = dev::cell_of(p[k].y, pv.ry0, pv.inv_fh * 4.0, pv.R * 4);
+            word[k] = (p[k].x == p[k].x && p[k].y == p[k].y) ? pv.cell[(int64_t)(fy[k] >> 2) * pv.R + (sx[k] >> 2)] : 0u;
         }
-        // stage C: single-entry cells: decided, or PartInfo gather
+        // stage C: decided cells; level-2 record gather (16 B) or PartInfo gather for inline boundary entries
+        SubCell sc[PIP_PPT];
+        bool has_sub[PIP_PPT];
 #pragma unroll
         for (int k = 0; k < PIP_PPT; ++k) {
             const uint32_t tag = word[k] >> 30, payload = word[k] & 0x3FFFFFFFu;
             want[k] = false;
-            if (tag == CELL_TAG_SINGLE) {
+            has_sub[k] = tag == CELL_TAG_SUB;
+            if (has_sub[k]) {
+                sc[k] = pv.sub[payload];
+            } else if (tag == CELL_TAG_SINGLE) {
                 if (payload & 1u) {
                     want[k] = true;
                     pi[k] = pv.part_info[payload >> 1];
@@ -223,16 +231,34 @@ __global__ __launch_bounds__(PIP_BLOCK) void pip_tile_kernel(DevGeo pts, DevGeo 
                 }
             }
         }
-        // stage D: slab offsets
+        // stage D: level-2 label, or slab offsets for inline boundary entries
+        uint32_t qpart[PIP_PPT], qflag[PIP_PPT];
 #pragma unroll
         for (int k = 0; k < PIP_PPT; ++k) {
-            if (want[k]) {
-                const int j = fy[k] - pi[k].row0;
+            qpart[k] = (word[k] & 0x3FFFFFFFu) >> 1;
+            qflag[k] = 0;
+            e0[k] = e1[k] = 0;
+            if (has_sub[k]) {
+                const uint32_t lab = (sc[k].labels >> (2 * ((fy[k] & 3) * 4 + (sx[k] & 3)))) & 3u;
+                qpart[k] = sc[k].part;
+                if (lab == 1u) {
+                    const int li = k * PIP_BLOCK + tid;
+                    s_cnt[li] = 1;
+                    s_hit[li] = sc[k].part;
+                } else if (lab == 2u) {
+                    want[k] = true;
+                    e0[k] = (int)sc[k].e0;
+                    e1[k] = (int)(sc[k].e0 + (sc[k].cnt_flags & 0x7FFFFFFFu));
+                    qflag[k] = sc[k].cnt_flags & 0x80000000u;
+                }
+            } else if (want[k]) {
+                const int j = (fy[k] >> 2) - pi[k].row0;
                 if (j < 0 || j >= pi[k].nrows) {
                     want[k] = false;  // p.y outside the exterior's y-range: Outside
                 } else {
                     e0[k] = pv.slab_off[pi[k].slab_base + j];
                     e1[k] = pv.slab_off[pi[k].slab_base + j + 1];
+                    qflag[k] = pi[k].n_rings > 1 ? 0x80000000u : 0u;
                 }
             }
         }
@@ -248,11 +274,10 @@ __global__ __launch_bounds__(PIP_BLOCK) void pip_tile_kernel(DevGeo pts, DevGeo 
                 if (lane64 == leader) wbase = atomicAdd(&q_n, (uint32_t)__popcll(mask));
                 wbase = __shfl(wbase, leader, 64);
                 if (push) {
-                    const uint32_t part = (word[k] & 0x3FFFFFFFu) >> 1;
+                    const uint32_t part = qpart[k];
                     const uint32_t slot = wbase + (uint32_t)__popcll(mask & ((1ull << lane64) - 1ull));
                     if (slot < (uint32_t)PIP_QCAP) {
-                        q[slot] = QEntry{p[k].x, p[k].y, part, (uint32_t)e0[k], (uint32_t)(e1[k] - e0[k]),
-                                         (uint32_t)li | (pi[k].n_rings > 1 ? 0x80000000u : 0u)};
+                        q[slot] = QEntry{p[k].x, p[k].y, part, (uint32_t)e0[k], (uint32_t)(e1[k] - e0[k]), (uint32_t)li | qflag[k]};
                     } else if (pip::part_pos_single(pv, polys, (int)part, p[k].x, p[k].y) == dev::POS_INSIDE) {
                         s_cnt[li] += 1;
                         s_hit[li] = part;
@@ -272,7 +297,7 @@ __global__ __launch_bounds__(PIP_BLOCK) void pip_tile_kernel(DevGeo pts, DevGeo 
                 const uint32_t part = e >> 1;
                 if (e & 1u) {
                     const PartInfo pq = pv.part_info[part];
-                    const int j = fy[k] - pq.row0;
+                    const int j = (fy[k] >> 2) - pq.row0;
                     if (j < 0 || j >= pq.nrows) continue;
                     const int a0 = pv.slab_off[pq.slab_base + j], a1 = pv.slab_off[pq.slab_base + j + 1];
                     if (a1 <= a0) continue;
@@ -520,7 +545,7 @@ extern "C" {
 
 int32_t gpk_index_free(gpk_index* idx) {
     if (!idx) return GPK_OK;
-    for (int i = 0; i < 12; ++i)
+    for (int i = 0; i < 16; ++i)
         if (idx->owned[i]) (void)hipFree(idx->owned[i]);
     delete idx;
     return GPK_OK;

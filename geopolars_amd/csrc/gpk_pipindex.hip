@@ -278,13 +278,90 @@ __global__ void cell_build_kernel(DevGeo a, IndexView ix, PipView pv, FineGrid g
     cell[c] = word;
 }
 
+// ---- level 2: cells crossed by exactly one part -----------------------------------------------------
+__global__ void sub_flag_kernel(const uint32_t* __restrict__ cell, int64_t n_cells, int32_t* __restrict__ flag) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cells) return;
+    const uint32_t w = cell[c];
+    flag[c] = ((w >> 30) == CELL_TAG_SINGLE && (w & 1u)) ? 1 : 0;
+}
+
+// 16 lanes per flagged cell: lane k labels sub-cell (k & 3, k >> 2).  A sub-cell is "test exactly" when any
+// edge of ANY ring of the part (taken from the rings' slabs of this raster row) is not strictly on one side
+// of the sub-cell's padded rectangle; otherwise it inherits the exact position of its centre.
+__global__ void sub_build_kernel(DevGeo a, PipView pv, FineGrid g, const int32_t* __restrict__ flag,
+                                 const int32_t* __restrict__ pos, int64_t n_cells, uint32_t* __restrict__ cell,
+                                 SubCell* __restrict__ sub) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t c = t >> 4;
+    const int k = (int)(t & 15);
+    if (c >= n_cells || !flag[c]) return;
+    const uint32_t w = cell[c];
+    // (all 16 lanes of a cell read the word before lane 0 rewrites it: the rewrite happens in sub_commit_kernel)
+    const int part = (int)((w & 0x3FFFFFFFu) >> 1);
+    const int ci = (int)(c % g.R), cj = (int)(c / g.R);
+    const int si = 4 * ci + (k & 3), sj = 4 * cj + (k >> 2);
+    const double fw2 = g.fw * 0.25, fh2 = g.fh * 0.25, px2 = g.pad_x * 0.25, py2 = g.pad_y * 0.25;
+    const double xl = g.rx0 + (double)si * fw2 - px2, xh = g.rx0 + (double)(si + 1) * fw2 + px2;
+    const double yl = g.ry0 + (double)sj * fh2 - py2, yh = g.ry0 + (double)(sj + 1) * fh2 + py2;
+    int r0, r1;
+    dev::part_rings(a, part, r0, r1);
+    bool touched = false;
+    for (int r = r0; r < r1 && !touched; ++r) {
+        int e0, e1;
+        if (!pip::slab_range(pv, r, cj, e0, e1)) continue;
+        for (int e = e0; e < e1 && !touched; ++e) {
+            const double4 ed = pv.slab_edges[e];
+            // cheap reject: edge bbox vs padded rectangle (closed)
+            if (fmax(ed.x, ed.z) < xl || fmin(ed.x, ed.z) > xh || fmax(ed.y, ed.w) < yl || fmin(ed.y, ed.w) > yh) continue;
+            const int o1 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yl);
+            const int o2 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yl);
+            const int o3 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yh);
+            const int o4 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yh);
+            const bool all_pos = o1 > 0 && o2 > 0 && o3 > 0 && o4 > 0;
+            const bool all_neg = o1 < 0 && o2 < 0 && o3 < 0 && o4 < 0;
+            touched = !(all_pos || all_neg);
+        }
+    }
+    uint32_t label = 2u;
+    if (!touched) {
+        const double cx = g.rx0 + ((double)si + 0.5) * fw2, cy = g.ry0 + ((double)sj + 0.5) * fh2;
+        // the centre must map to this very sub-cell under the point-side function (4x the level-1 scale)
+        const bool ok = dev::cell_of(cx, g.rx0, g.inv_fw * 4.0, g.R * 4) == si && dev::cell_of(cy, g.ry0, g.inv_fh * 4.0, g.R * 4) == sj;
+        if (ok) {
+            const int p = pip::part_pos_single(pv, a, part, cx, cy);
+            label = p == dev::POS_INSIDE ? 1u : (p == dev::POS_OUTSIDE ? 0u : 2u);
+        }
+    }
+    SubCell* rec = sub + pos[c];
+    if (k == 0) {
+        const PartInfo pi = pv.part_info[part];
+        const int j = cj - pi.row0;
+        uint32_t e0 = 0, cnt = 0;
+        if (j >= 0 && j < pi.nrows) {
+            e0 = (uint32_t)pv.slab_off[pi.slab_base + j];
+            cnt = (uint32_t)pv.slab_off[pi.slab_base + j + 1] - e0;
+        }
+        rec->part = (uint32_t)part;
+        rec->e0 = e0;
+        rec->cnt_flags = cnt | (pi.n_rings > 1 ? 0x80000000u : 0u);
+    }
+    atomicOr(&rec->labels, label << (2 * k));
+}
+__global__ void sub_commit_kernel(const int32_t* __restrict__ flag, const int32_t* __restrict__ pos, int64_t n_cells,
+                                  uint32_t* __restrict__ cell) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cells || !flag[c]) return;
+    cell[c] = (CELL_TAG_SUB << 30) | (uint32_t)pos[c];
+}
+
 }  // namespace gpk
 
 using namespace gpk;
 
 namespace {
 struct Temps {  // hipMalloc'ed scratch of the build, released on every exit path
-    void* p[16] = {nullptr};
+    void* p[32] = {nullptr};
     int n = 0;
     template <typename T>
     int32_t alloc(T** out, size_t count) {
@@ -332,7 +409,9 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
     const int64_t n_rings = d.n_rings, n_parts = d.n_parts, n_cells = (int64_t)R * R;
     Temps t;
     int slot = 4;  // ix->owned[0..3] belong to the coarse directory
-    auto keep = [&](void* p) { ix->owned[slot++] = p; };
+    auto keep = [&](void* p) {
+        if (slot < 16) ix->owned[slot++] = p;
+    };
 
     // ---- part / ring maps ----------------------------------------------------------------------
     uint32_t* part_geom = nullptr;
@@ -464,9 +543,32 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
     GPK_LAUNCH("gpk_pipidx_cell_fill", cell_build_kernel<true>, blocks_for(n_cells), dim3(256), 0, s, d, ix->v, pv, g, marks, n_marks,
                need, list_off, cell, list);
     GPK_HIP(hipStreamSynchronize(s));
-
     pv.cell = cell;
     pv.list = list;
+
+    // ---- level 2 ------------------------------------------------------------------------------------
+    int32_t n_sub = 0;
+    SubCell* sub = nullptr;
+    if (g.pad_x * 0.25 > ulp64 && g.pad_y * 0.25 > ulp64 && R * 4 <= 32768) {
+        int32_t *sflag, *spos;
+        GPK_TRY(t.alloc(&sflag, (size_t)n_cells + 1));
+        GPK_TRY(t.alloc(&spos, (size_t)n_cells + 1));
+        GPK_LAUNCH("gpk_pipidx_sub_flag", sub_flag_kernel, blocks_for(n_cells), dim3(256), 0, s, cell, n_cells, sflag);
+        GPK_TRY(exclusive_scan_i32(sflag, n_cells, spos, nullptr, btot, s));
+        GPK_HIP(hipMemcpyAsync(&n_sub, spos + n_cells, sizeof n_sub, hipMemcpyDeviceToHost, s));
+        GPK_HIP(hipStreamSynchronize(s));
+        if (n_sub > 0) {
+            GPK_HIP(hipMalloc((void**)&sub, sizeof(SubCell) * (size_t)n_sub));
+            keep(sub);
+            GPK_HIP(hipMemsetAsync(sub, 0, sizeof(SubCell) * (size_t)n_sub, s));
+            GPK_LAUNCH("gpk_pipidx_sub_build", sub_build_kernel, blocks_for(n_cells * 16), dim3(256), 0, s, d, pv, g, sflag, spos, n_cells,
+                       cell, sub);
+            GPK_LAUNCH("gpk_pipidx_sub_commit", sub_commit_kernel, blocks_for(n_cells), dim3(256), 0, s, sflag, spos, n_cells, cell);
+            GPK_HIP(hipStreamSynchronize(s));
+        }
+    }
+    pv.sub = sub;
+    ix->nbytes += (int64_t)(sizeof(SubCell) * (size_t)n_sub);
     ix->pip = pv;
     ix->nbytes += (int64_t)(sizeof(uint32_t) * (size_t)n_cells + sizeof(uint32_t) * (size_t)list_len + sizeof(double4) * (size_t)n_edges +
                             sizeof(int32_t) * (size_t)(n_slabs + 1) + sizeof(int32_t) * (size_t)(2 * n_rings + 1) +
