@@ -126,7 +126,6 @@ def main() -> None:
 
     k_count, n_count = kernel_ms("gpk_pip_tile")
     k_write, _ = kernel_ms("gpk_pip_write")
-    k_scan, _ = kernel_ms("gpk_scan_totals")
     lib.gpk_profile_reset()
 
     if rank != 0:
@@ -180,7 +179,7 @@ def main() -> None:
             "cus": cus,
             "join_bytes_per_step": bytes_join,
             "join_GBps_end_to_end": bytes_join / (ms_per_step * 1e-3) / 1e9,
-            "kernel_ms": {"gpk_pip_tile": k_count, "gpk_scan_totals": k_scan, "gpk_pip_write": k_write},
+            "kernel_ms": {"gpk_pip_tile": k_count, "gpk_pip_write": k_write},
         },
         "roofline": {
             "bound": "hbm",

@@ -8,8 +8,8 @@
 //   pip_tile   : a work-group classifies a tile of points (raster routing + LDS-compacted exact phase over
 //                edge slabs, see the kernel); emits the optional per-point hit count, a 4-byte result
 //                code per point and one 64-bit total per work-group.
-//   scan       : single-block exclusive scan of the work-group totals (LDS staged).
-//   pip_write  : codes + work-group base -> (l, r) pairs in sorted order.
+//   pip_write  : codes -> (l, r) pairs in sorted order; its global offsets come from a two-level sum of the
+//                work-group totals (no scan kernel).
 // (A single-pass variant with decoupled look-back was measured and was slower on MI355X: the in-order
 // commit makes finished work-groups hold their LDS/wave slots while they wait — see DESIGN.md.)
 #include "gpk_device.h"
@@ -113,6 +113,9 @@ constexpr int PIP_PPT = GPK_PIP_PPT;           // points per thread, strided by 
 constexpr int PIP_TILE = PIP_BLOCK * PIP_PPT;  // points per work-group
 constexpr int PIP_GS = GPK_PIP_GS;             // lanes cooperating on one queued (point, part) pair
 constexpr int PIP_QCAP = PIP_TILE;             // LDS queue capacity (overflow is resolved inline, still exact)
+constexpr int PIP_SUPER_SHIFT = 6;             // 64 tiles per super-tile (two-level prefix of the tile totals)
+constexpr int PIP_WPT = 8;                     // writer: consecutive points per thread
+constexpr int PIP_WTILE = PIP_BLOCK * PIP_WPT;  // writer: points per work-group (a multiple of PIP_TILE)
 // per-point result code handed from pip_tile to pip_write: a geometry id (exactly one hit), CODE_NONE, or
 // CODE_MULTI (several hits: the writer re-enumerates them with the generic walk)
 constexpr uint32_t CODE_NONE = 0xFFFFFFFFu, CODE_MULTI = 0xFFFFFFFEu;
@@ -171,7 +174,8 @@ template <bool RASTER>
 __global__ __launch_bounds__(PIP_BLOCK) void pip_tile_kernel(DevGeo pts, DevGeo polys, IndexView ix, PipView pv,
                                                               uint32_t* __restrict__ counts,
                                                               uint32_t* __restrict__ code,
-                                                              unsigned long long* __restrict__ block_tot) {
+                                                              unsigned long long* __restrict__ block_tot,
+                                                              unsigned long long* __restrict__ super_tot) {
     __shared__ QEntry q[RASTER ? PIP_QCAP : 1];
     __shared__ uint32_t s_cnt[PIP_TILE], s_hit[PIP_TILE];
     __shared__ uint32_t q_n;
@@ -363,39 +367,76 @@ __global__ __launch_bounds__(PIP_BLOCK) void pip_tile_kernel(DevGeo pts, DevGeo 
     }
     unsigned long long tot;
     (void)dev::block_exclusive_scan<unsigned long long, PIP_BLOCK>(local, lds, &tot);
-    if (tid == 0) block_tot[blockIdx.x] = tot;
+    if (tid == 0) {
+        block_tot[blockIdx.x] = tot;
+        if (tot) atomicAdd(&super_tot[blockIdx.x >> PIP_SUPER_SHIFT], tot);  // integer adds: order-independent
+    }
 }
 
 // pip_write: turns the per-point codes into the sorted (l, r) pair list.  Reads 4 bytes per point, writes 8
-// bytes per hit; only CODE_MULTI rows touch geometry again.
+// bytes per hit; only CODE_MULTI rows touch geometry again.  There is no separate scan kernel: a work-group
+// gets its global offset from the two-level totals (<= 64 tile totals + the super-tile totals before them,
+// summed by one wave), each thread owns PIP_WPT consecutive points, one block scan orders the threads.
 __global__ __launch_bounds__(PIP_BLOCK) void pip_write_kernel(DevGeo pts, DevGeo polys, IndexView ix,
                                                                const uint32_t* __restrict__ code,
-                                                               const unsigned long long* __restrict__ block_off,
-                                                               uint32_t left_base, uint2* __restrict__ pairs,
-                                                               int64_t capacity) {
+                                                               const unsigned long long* __restrict__ block_tot,
+                                                               const unsigned long long* __restrict__ super_tot,
+                                                               int64_t n_tiles, uint32_t left_base,
+                                                               uint2* __restrict__ pairs, int64_t capacity,
+                                                               unsigned long long* __restrict__ grand,
+                                                               unsigned long long* __restrict__ grand_host) {
     __shared__ unsigned long long lds[PIP_BLOCK / 64 + 1];
-    const int64_t base = (int64_t)blockIdx.x * PIP_TILE;
-    unsigned long long running = block_off[blockIdx.x];
+    __shared__ unsigned long long s_base;
+    const int tid = threadIdx.x;
+    const int64_t first_tile = (int64_t)blockIdx.x * (PIP_WTILE / PIP_TILE);
+    if (tid < 64) {
+        const int64_t sb = first_tile >> PIP_SUPER_SHIFT;
+        unsigned long long acc = 0;
+        for (int64_t i = tid; i < sb; i += 64) acc += super_tot[i];
+        for (int64_t i = (sb << PIP_SUPER_SHIFT) + tid; i < first_tile; i += 64) acc += block_tot[i];
 #pragma unroll
-    for (int k = 0; k < PIP_PPT; ++k) {
-        const int64_t i = base + k * PIP_BLOCK + threadIdx.x;
-        const uint32_t c = i < pts.n_geoms ? code[i] : CODE_NONE;
-        uint32_t cnt = c == CODE_NONE ? 0u : 1u, first = c;
-        double2 p = make_double2(0.0, 0.0);
-        if (c == CODE_MULTI) {
-            p = pts.xy[i];
-            generic_point(polys, ix, p.x, p.y, cnt, first);
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (tid == 0) s_base = acc;
+    }
+    const int64_t i0 = (int64_t)blockIdx.x * PIP_WTILE + (int64_t)tid * PIP_WPT;
+    uint32_t c[PIP_WPT];
+    if (i0 + PIP_WPT <= pts.n_geoms) {
+        const uint4 a = *reinterpret_cast<const uint4*>(code + i0), b = *reinterpret_cast<const uint4*>(code + i0 + 4);
+        c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < PIP_WPT; ++k) c[k] = i0 + k < pts.n_geoms ? code[i0 + k] : CODE_NONE;
+    }
+    uint32_t cnt[PIP_WPT], mine = 0;
+#pragma unroll
+    for (int k = 0; k < PIP_WPT; ++k) {
+        cnt[k] = c[k] == CODE_NONE ? 0u : 1u;
+        if (c[k] == CODE_MULTI) {
+            uint32_t first;
+            const double2 p = pts.xy[i0 + k];
+            generic_point(polys, ix, p.x, p.y, cnt[k], first);
         }
-        unsigned long long tot;
-        const unsigned long long ex = dev::block_exclusive_scan<unsigned long long, PIP_BLOCK>((unsigned long long)cnt, lds, &tot);
-        int64_t o = (int64_t)(running + ex);
-        running += tot;
-        if (cnt == 0) continue;
-        const uint32_t l = left_base + (uint32_t)i;
-        if (c != CODE_MULTI) {
-            if (o < capacity) pairs[o] = make_uint2(l, c);
+        mine += cnt[k];
+    }
+    unsigned long long tot;
+    const unsigned long long ex = dev::block_exclusive_scan<unsigned long long, PIP_BLOCK>((unsigned long long)mine, lds, &tot);
+    // (block_exclusive_scan's barriers also publish s_base)
+    int64_t o = (int64_t)(s_base + ex);
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+        *grand = s_base + tot;
+        if (grand_host) *grand_host = s_base + tot;
+    }
+    if (!pairs) return;
+#pragma unroll
+    for (int k = 0; k < PIP_WPT; ++k) {
+        if (cnt[k] == 0) continue;
+        const uint32_t l = left_base + (uint32_t)(i0 + k);
+        if (c[k] != CODE_MULTI) {
+            if (o < capacity) pairs[o] = make_uint2(l, c[k]);
+            ++o;
             continue;
         }
+        const double2 p = pts.xy[i0 + k];
         const GridParams g = *ix.grid;
         for_each_candidate(ix, g, p.x, p.y, [&](int j) {
             if (dev::valid_row(polys.validity, j) && dev::polygonal_hits_point<false>(polys, j, p.x, p.y)) {
@@ -699,13 +740,17 @@ int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right, co
     const bool want_pairs = pair_capacity > 0;
     const size_t counts_bytes = sizeof(uint32_t) * (size_t)n;
     const size_t pairs_bytes = sizeof(uint32_t) * 2 * (size_t)pair_capacity;
-    size_t need = align256(counts_bytes) /*code*/ + align256(sizeof(unsigned long long) * (size_t)(n_blocks + 1)) + 1024;
+    const int64_t n_super = (n_blocks >> PIP_SUPER_SHIFT) + 1;
+    const int64_t n_wblocks = (n + PIP_WTILE - 1) / PIP_WTILE;
+    size_t need = align256(counts_bytes + 64) /*code*/ + align256(sizeof(unsigned long long) * (size_t)(n_blocks + n_super + 2)) + 1024;
     if (host_out && out_counts) need += align256(counts_bytes);
     if (host_out && want_pairs) need += align256(pairs_bytes);
     int32_t rc = workspace().begin(need);
     if (rc != GPK_OK) return done(rc);
-    uint32_t* code = (uint32_t*)workspace().take(counts_bytes);
-    unsigned long long* btot = (unsigned long long*)workspace().take(sizeof(unsigned long long) * (size_t)(n_blocks + 1));
+    uint32_t* code = (uint32_t*)workspace().take(counts_bytes + 64);
+    unsigned long long* btot = (unsigned long long*)workspace().take(sizeof(unsigned long long) * (size_t)(n_blocks + n_super + 2));
+    unsigned long long* stot = btot + n_blocks;     // n_super super-tile totals
+    unsigned long long* grand = stot + n_super;     // total hits
     uint32_t* counts_dev = out_counts ? (host_out ? (uint32_t*)workspace().take(counts_bytes) : out_counts) : nullptr;
     uint32_t* pairs_dev = want_pairs ? (host_out ? (uint32_t*)workspace().take(pairs_bytes) : out_pairs) : nullptr;
 
@@ -722,21 +767,24 @@ int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right, co
         if (_rc != GPK_OK) return done(_rc);   \
     } while (0)
 
+    {
+        const hipError_t me = hipMemsetAsync(stot, 0, sizeof(unsigned long long) * (size_t)(n_super + 1), s);
+        if (me != hipSuccess) return done(fail(GPK_ERR_DEVICE, "spatial_join: %s", hipGetErrorString(me)));
+    }
     if (right_index->pip.R > 0)
         J_LAUNCH("gpk_pip_tile", pip_tile_kernel<true>, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
-                 right_index->v, right_index->pip, counts_dev, code, btot);
+                 right_index->v, right_index->pip, counts_dev, code, btot, stot);
     else
         J_LAUNCH("gpk_pip_tile_generic", pip_tile_kernel<false>, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
-                 right_index->v, right_index->pip, counts_dev, code, btot);
-    J_LAUNCH("gpk_scan_totals", scan_block_totals_kernel, dim3(1), dim3(1024), 0, s, btot, n_blocks, btot + n_blocks, pinned_total);
-    if (want_pairs)
-        J_LAUNCH("gpk_pip_write", pip_write_kernel, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
-                 right_index->v, code, btot, left_row_base, (uint2*)pairs_dev, pair_capacity);
+                 right_index->v, right_index->pip, counts_dev, code, btot, stot);
+    // the writer also produces the grand total; in count-only mode it runs without a pair buffer
+    J_LAUNCH("gpk_pip_write", pip_write_kernel, dim3((unsigned)n_wblocks), dim3(PIP_BLOCK), 0, s, left->d, right->d, right_index->v,
+             code, btot, stot, n_blocks, left_row_base, (uint2*)pairs_dev, pair_capacity, grand, pinned_total);
 #undef J_LAUNCH
 
     unsigned long long total = 0;
     hipError_t e = hipSuccess;
-    if (!pinned_total) e = hipMemcpyAsync(&total, btot + n_blocks, sizeof total, hipMemcpyDeviceToHost, s);
+    if (!pinned_total) e = hipMemcpyAsync(&total, grand, sizeof total, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return done(fail(GPK_ERR_DEVICE, "spatial_join: %s", hipGetErrorString(e)));
     if (pinned_total) total = *(volatile unsigned long long*)pinned_total;
