@@ -19,6 +19,15 @@ constexpr int POS_OUTSIDE = 0;
 constexpr int POS_BOUNDARY = 1;
 constexpr int POS_INSIDE = 2;
 
+// Streaming accesses (read-once inputs, write-once outputs) carry the non-temporal hint so that they do not
+// evict the small gather tables (raster, slabs, directory) from the XCD's 4 MB L2.
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 load_stream(const double2* p) {
+    const v2f64 v = __builtin_nontemporal_load(reinterpret_cast<const v2f64*>(p));
+    return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ void store_stream(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+
 __device__ __forceinline__ bool valid_row(const uint8_t* validity, int64_t i) {
     return !validity || ((validity[i >> 3] >> (i & 7)) & 1);
 }

@@ -31,24 +31,27 @@ struct IndexView {  // passed to kernels by value
 //   cell word  : tag(2) | payload(30).  tag 0 = no polygon can contain a point of this cell;
 //                tag 1 = exactly one entry, inline; tag 2 = payload is an offset into `list`
 //                (list[off] = n, then n entries); tag 3 = exactly one part's edges cross the cell and
-//                payload indexes a 16-byte SubCell record: the cell split 4 x 4 with the same exact
+//                payload indexes a 32-byte SubCell record: the cell split 8 x 8 with the same exact
 //                labelling, plus the slab location, so most of its points finish with one more gather.
+//                (Level 1 is kept coarse — 1 MB at R = 512 — so that its gathers stay L2 hits; the
+//                effective resolution is 8R.)
 //   entry      : part << 1 | boundary.  boundary = 0 means EVERY representable point that maps to this
 //                cell is strictly inside that part (holes included) — decided once, exactly, at build
 //                time; boundary = 1 means some edge of the part may touch the cell: run the exact test.
-//   slabs      : for ring r and raster row j in [row0[r], row0[r] + nrows) the list of edges whose closed
-//                y-range meets the row (under the same monotone row function the points use), stored as
+//   slabs      : for ring r and slab row j (PIP_SLAB_MUL slab rows per raster row) in [row0[r], row0[r] + nrows)
+//                the list of edges whose closed y-range meets the row (under the same monotone row function the points use), stored as
 //                contiguous double4 (sx, sy, ex, ey) records -> 8 lanes read one slab with 2 cache lines.
 // Exactness does not depend on the raster: it only routes points; every boundary decision is made by
 // the exact winding walk over the slab's edges, which are a superset of the edges that can count.
 struct PartInfo {  // one 16-byte load tells a lane where the exterior ring's slabs of a part live
     int32_t slab_base, row0, nrows, n_rings;
 };
-struct SubCell {  // level-2 record of a raster cell crossed by edges of exactly ONE part (16 bytes, one gather)
-    uint32_t part;
-    uint32_t e0;         // first edge of the part's exterior slab for this cell's row
-    uint32_t cnt_flags;  // edge count | (part has holes) << 31
-    uint32_t labels;     // 4 x 4 sub-cells, 2 bits each (x fastest): 0 outside, 1 strictly inside, 2 test exactly
+constexpr int PIP_SUB = 8;       // level-2 sub-cells per raster cell side
+constexpr int PIP_SLAB_MUL = 2;  // slab rows per raster row (slabs stay ~7 edges while the level-1 table stays small)
+struct SubCell {  // level-2 record of a raster cell crossed by edges of exactly ONE part: 32 bytes, one cache line touch
+    uint32_t part_flags;  // part | (part has holes) << 31
+    uint32_t e0, e1, e2;  // exterior-ring slab of the cell's lower slab row = [e0, e1), upper = [e1, e2)
+    uint32_t labels[4];   // 8 x 8 sub-cells, 2 bits each (x fastest): 0 outside, 1 strictly inside, 2 test exactly
 };
 struct PipView {
     int32_t R;  // 0 = accelerator not built (degenerate extent): kernels use the generic walk

@@ -105,6 +105,9 @@ __global__ void cell_sort_kernel(const int32_t* __restrict__ cell_off, int64_t n
 #ifndef GPK_PIP_PPT
 #define GPK_PIP_PPT 2
 #endif
+#ifndef GPK_ABLATE
+#define GPK_ABLATE 0
+#endif
 #ifndef GPK_PIP_GS
 #define GPK_PIP_GS 8
 #endif
@@ -202,19 +205,22 @@ __global__ __launch_bounds__(PIP_BLOCK) void pip_tile_kernel(DevGeo pts, DevGeo 
         for (int k = 0; k < PIP_PPT; ++k) {
             const int64_t i = base + k * PIP_BLOCK + tid;
             const bool ok = i < n && dev::valid_row(pts.validity, i);
-            p[k] = ok ? pts.xy[i] : make_double2(NAN, NAN);
+            p[k] = ok ? dev::load_stream(pts.xy + i) : make_double2(NAN, NAN);
         }
-        // stage B: raster words (one 4-byte gather per point).  Columns/rows are computed at 4x the raster
-        // resolution (an exact power-of-two rescale of the same monotone function), so `>> 2` is the level-1
-        // cell and `& 3` the level-2 sub-cell.
+        // stage B: raster words (one 4-byte gather per point).  Columns/rows are computed at PIP_SUB x the
+        // raster resolution (an exact power-of-two rescale of the same monotone function): `/ PIP_SUB` is the
+        // level-1 cell, `% PIP_SUB` the level-2 sub-cell, and sy / (PIP_SUB / PIP_SLAB_MUL) the slab row.
+        constexpr int S = PIP_SUB, SLAB_DIV = PIP_SUB / PIP_SLAB_MUL;
         int sx[PIP_PPT];
 #pragma unroll
         for (int k = 0; k < PIP_PPT; ++k) {
-            sx[k] = dev::cell_of(p[k].x, pv.rx0, pv.inv_fw * 4.0, pv.R * 4);
-            fy[k] = dev::cell_of(p[k].y, pv.ry0, pv.inv_fh * 4.0, pv.R * 4);
-            word[k] = (p[k].x == p[k].x && p[k].y == p[k].y) ? pv.cell[(int64_t)(fy[k] >> 2) * pv.R + (sx[k] >> 2)] : 0u;
+            sx[k] = dev::cell_of(p[k].x, pv.rx0, pv.inv_fw * S, pv.R * S);
+            fy[k] = dev::cell_of(p[k].y, pv.ry0, pv.inv_fh * S, pv.R * S);
+            word[k] = (p[k].x == p[k].x && p[k].y == p[k].y) ? pv.cell[(int64_t)(fy[k] / S) * pv.R + (sx[k] / S)] : 0u;
+            if (GPK_ABLATE == 2) word[k] = 0u;  // tuning builds only
+            if (GPK_ABLATE == 3) word[k] = (word[k] >> 30) == CELL_TAG_SINGLE && !(word[k] & 1u) ? word[k] : 0u;
         }
-        // stage C: decided cells; level-2 record gather (16 B) or PartInfo gather for inline boundary entries
+        // stage C: decided cells; level-2 record gather (32 B) or PartInfo gather for inline boundary entries
         SubCell sc[PIP_PPT];
         bool has_sub[PIP_PPT];
 #pragma unroll
@@ -243,20 +249,24 @@ __global__ __launch_bounds__(PIP_BLOCK) void pip_tile_kernel(DevGeo pts, DevGeo 
             qflag[k] = 0;
             e0[k] = e1[k] = 0;
             if (has_sub[k]) {
-                const uint32_t lab = (sc[k].labels >> (2 * ((fy[k] & 3) * 4 + (sx[k] & 3)))) & 3u;
-                qpart[k] = sc[k].part;
+                const int idx = (fy[k] % S) * S + (sx[k] % S);
+                const int wsel = idx >> 4;  // select by compares: a runtime-indexed register array would go to scratch
+                const uint32_t lw = wsel == 0 ? sc[k].labels[0] : (wsel == 1 ? sc[k].labels[1] : (wsel == 2 ? sc[k].labels[2] : sc[k].labels[3]));
+                const uint32_t lab = (lw >> (2 * (idx & 15))) & 3u;
+                qpart[k] = sc[k].part_flags & 0x7FFFFFFFu;
                 if (lab == 1u) {
                     const int li = k * PIP_BLOCK + tid;
                     s_cnt[li] = 1;
-                    s_hit[li] = sc[k].part;
+                    s_hit[li] = qpart[k];
                 } else if (lab == 2u) {
                     want[k] = true;
-                    e0[k] = (int)sc[k].e0;
-                    e1[k] = (int)(sc[k].e0 + (sc[k].cnt_flags & 0x7FFFFFFFu));
-                    qflag[k] = sc[k].cnt_flags & 0x80000000u;
+                    const bool upper = ((fy[k] / SLAB_DIV) & 1) != 0;
+                    e0[k] = (int)(upper ? sc[k].e1 : sc[k].e0);
+                    e1[k] = (int)(upper ? sc[k].e2 : sc[k].e1);
+                    qflag[k] = sc[k].part_flags & 0x80000000u;
                 }
             } else if (want[k]) {
-                const int j = (fy[k] >> 2) - pi[k].row0;
+                const int j = (fy[k] / SLAB_DIV) - pi[k].row0;
                 if (j < 0 || j >= pi[k].nrows) {
                     want[k] = false;  // p.y outside the exterior's y-range: Outside
                 } else {
@@ -301,7 +311,7 @@ __global__ __launch_bounds__(PIP_BLOCK) void pip_tile_kernel(DevGeo pts, DevGeo 
                 const uint32_t part = e >> 1;
                 if (e & 1u) {
                     const PartInfo pq = pv.part_info[part];
-                    const int j = (fy[k] >> 2) - pq.row0;
+                    const int j = (fy[k] / SLAB_DIV) - pq.row0;
                     if (j < 0 || j >= pq.nrows) continue;
                     const int a0 = pv.slab_off[pq.slab_base + j], a1 = pv.slab_off[pq.slab_base + j + 1];
                     if (a1 <= a0) continue;
@@ -319,7 +329,7 @@ __global__ __launch_bounds__(PIP_BLOCK) void pip_tile_kernel(DevGeo pts, DevGeo 
         }
         __syncthreads();
 
-        const uint32_t nq = q_n < (uint32_t)PIP_QCAP ? q_n : (uint32_t)PIP_QCAP;
+        const uint32_t nq = GPK_ABLATE == 1 ? 0u : (q_n < (uint32_t)PIP_QCAP ? q_n : (uint32_t)PIP_QCAP);
         const int glane = tid & (PIP_GS - 1);
         for (uint32_t e = tid / PIP_GS; e < nq; e += PIP_BLOCK / PIP_GS) {
             const QEntry en = q[e];
@@ -361,8 +371,8 @@ __global__ __launch_bounds__(PIP_BLOCK) void pip_tile_kernel(DevGeo pts, DevGeo 
                 generic_point(polys, ix, pp.x, pp.y, cnt, first);
             }
         }
-        if (counts) counts[i] = cnt;
-        code[i] = cnt == 0 ? CODE_NONE : (cnt == 1 ? first : CODE_MULTI);
+        if (counts) dev::store_stream(counts + i, cnt);
+        dev::store_stream(code + i, cnt == 0 ? CODE_NONE : (cnt == 1 ? first : CODE_MULTI));
         local += cnt;
     }
     unsigned long long tot;

@@ -12,7 +12,10 @@
 namespace gpk {
 namespace pip {
 
-__device__ __forceinline__ int row_of(const PipView& pv, double py) { return dev::cell_of(py, pv.ry0, pv.inv_fh, pv.R); }
+// slab row of a y coordinate (an exact power-of-two refinement of the raster row function)
+__device__ __forceinline__ int row_of(const PipView& pv, double py) {
+    return dev::cell_of(py, pv.ry0, pv.inv_fh * PIP_SLAB_MUL, pv.R * PIP_SLAB_MUL);
+}
 __device__ __forceinline__ int col_of(const PipView& pv, double px) { return dev::cell_of(px, pv.rx0, pv.inv_fw, pv.R); }
 
 __device__ __forceinline__ bool slab_range(const PipView& pv, int r, int row, int& e0, int& e1) {

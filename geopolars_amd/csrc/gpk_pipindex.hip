@@ -286,48 +286,49 @@ __global__ void sub_flag_kernel(const uint32_t* __restrict__ cell, int64_t n_cel
     flag[c] = ((w >> 30) == CELL_TAG_SINGLE && (w & 1u)) ? 1 : 0;
 }
 
-// 16 lanes per flagged cell: lane k labels sub-cell (k & 3, k >> 2).  A sub-cell is "test exactly" when any
-// edge of ANY ring of the part (taken from the rings' slabs of this raster row) is not strictly on one side
-// of the sub-cell's padded rectangle; otherwise it inherits the exact position of its centre.
+// PIP_SUB^2 lanes per flagged cell: lane k labels sub-cell (k % PIP_SUB, k / PIP_SUB).  A sub-cell is "test
+// exactly" when any edge of ANY ring of the part (taken from the rings' slabs of this raster row) is not strictly
+// on one side of the sub-cell's padded rectangle; otherwise it inherits the exact position of its centre.
 __global__ void sub_build_kernel(DevGeo a, PipView pv, FineGrid g, const int32_t* __restrict__ flag,
-                                 const int32_t* __restrict__ pos, int64_t n_cells, uint32_t* __restrict__ cell,
+                                 const int32_t* __restrict__ pos, int64_t n_cells, const uint32_t* __restrict__ cell,
                                  SubCell* __restrict__ sub) {
+    constexpr int S = PIP_SUB, SS = PIP_SUB * PIP_SUB;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t c = t >> 4;
-    const int k = (int)(t & 15);
+    const int64_t c = t / SS;
+    const int k = (int)(t % SS);
     if (c >= n_cells || !flag[c]) return;
-    const uint32_t w = cell[c];
-    // (all 16 lanes of a cell read the word before lane 0 rewrites it: the rewrite happens in sub_commit_kernel)
+    const uint32_t w = cell[c];  // still the level-1 word: sub_commit_kernel rewrites it afterwards
     const int part = (int)((w & 0x3FFFFFFFu) >> 1);
     const int ci = (int)(c % g.R), cj = (int)(c / g.R);
-    const int si = 4 * ci + (k & 3), sj = 4 * cj + (k >> 2);
-    const double fw2 = g.fw * 0.25, fh2 = g.fh * 0.25, px2 = g.pad_x * 0.25, py2 = g.pad_y * 0.25;
+    const int si = S * ci + (k % S), sj = S * cj + (k / S);
+    const double fw2 = g.fw / S, fh2 = g.fh / S, px2 = g.pad_x / S, py2 = g.pad_y / S;
     const double xl = g.rx0 + (double)si * fw2 - px2, xh = g.rx0 + (double)(si + 1) * fw2 + px2;
     const double yl = g.ry0 + (double)sj * fh2 - py2, yh = g.ry0 + (double)(sj + 1) * fh2 + py2;
     int r0, r1;
     dev::part_rings(a, part, r0, r1);
     bool touched = false;
-    for (int r = r0; r < r1 && !touched; ++r) {
-        int e0, e1;
-        if (!pip::slab_range(pv, r, cj, e0, e1)) continue;
-        for (int e = e0; e < e1 && !touched; ++e) {
-            const double4 ed = pv.slab_edges[e];
-            // cheap reject: edge bbox vs padded rectangle (closed)
-            if (fmax(ed.x, ed.z) < xl || fmin(ed.x, ed.z) > xh || fmax(ed.y, ed.w) < yl || fmin(ed.y, ed.w) > yh) continue;
-            const int o1 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yl);
-            const int o2 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yl);
-            const int o3 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yh);
-            const int o4 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yh);
-            const bool all_pos = o1 > 0 && o2 > 0 && o3 > 0 && o4 > 0;
-            const bool all_neg = o1 < 0 && o2 < 0 && o3 < 0 && o4 < 0;
-            touched = !(all_pos || all_neg);
+    for (int r = r0; r < r1 && !touched; ++r)
+        for (int h = 0; h < PIP_SLAB_MUL && !touched; ++h) {
+            int e0, e1;
+            if (!pip::slab_range(pv, r, PIP_SLAB_MUL * cj + h, e0, e1)) continue;
+            for (int e = e0; e < e1 && !touched; ++e) {
+                const double4 ed = pv.slab_edges[e];
+                // cheap reject: edge bbox vs padded rectangle (closed)
+                if (fmax(ed.x, ed.z) < xl || fmin(ed.x, ed.z) > xh || fmax(ed.y, ed.w) < yl || fmin(ed.y, ed.w) > yh) continue;
+                const int o1 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yl);
+                const int o2 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yl);
+                const int o3 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yh);
+                const int o4 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yh);
+                const bool all_pos = o1 > 0 && o2 > 0 && o3 > 0 && o4 > 0;
+                const bool all_neg = o1 < 0 && o2 < 0 && o3 < 0 && o4 < 0;
+                touched = !(all_pos || all_neg);
+            }
         }
-    }
     uint32_t label = 2u;
     if (!touched) {
         const double cx = g.rx0 + ((double)si + 0.5) * fw2, cy = g.ry0 + ((double)sj + 0.5) * fh2;
-        // the centre must map to this very sub-cell under the point-side function (4x the level-1 scale)
-        const bool ok = dev::cell_of(cx, g.rx0, g.inv_fw * 4.0, g.R * 4) == si && dev::cell_of(cy, g.ry0, g.inv_fh * 4.0, g.R * 4) == sj;
+        // the centre must map to this very sub-cell under the point-side function (S x the level-1 scale)
+        const bool ok = dev::cell_of(cx, g.rx0, g.inv_fw * S, g.R * S) == si && dev::cell_of(cy, g.ry0, g.inv_fh * S, g.R * S) == sj;
         if (ok) {
             const int p = pip::part_pos_single(pv, a, part, cx, cy);
             label = p == dev::POS_INSIDE ? 1u : (p == dev::POS_OUTSIDE ? 0u : 2u);
@@ -336,17 +337,25 @@ __global__ void sub_build_kernel(DevGeo a, PipView pv, FineGrid g, const int32_t
     SubCell* rec = sub + pos[c];
     if (k == 0) {
         const PartInfo pi = pv.part_info[part];
-        const int j = cj - pi.row0;
-        uint32_t e0 = 0, cnt = 0;
-        if (j >= 0 && j < pi.nrows) {
-            e0 = (uint32_t)pv.slab_off[pi.slab_base + j];
-            cnt = (uint32_t)pv.slab_off[pi.slab_base + j + 1] - e0;
+        // exterior slabs of the cell's PIP_SLAB_MUL (= 2) slab rows are adjacent in slab_off: [e0,e1) and [e1,e2)
+        const int j0 = PIP_SLAB_MUL * cj - pi.row0, j1 = j0 + 1;
+        const bool lo_ok = j0 >= 0 && j0 < pi.nrows, hi_ok = j1 >= 0 && j1 < pi.nrows;
+        uint32_t e0 = 0, e1 = 0, e2 = 0;
+        if (lo_ok) {
+            e0 = (uint32_t)pv.slab_off[pi.slab_base + j0];
+            e1 = (uint32_t)pv.slab_off[pi.slab_base + j0 + 1];
+            e2 = e1;
         }
-        rec->part = (uint32_t)part;
+        if (hi_ok) {
+            if (!lo_ok) e0 = e1 = (uint32_t)pv.slab_off[pi.slab_base + j1];
+            e2 = (uint32_t)pv.slab_off[pi.slab_base + j1 + 1];
+        }
+        rec->part_flags = (uint32_t)part | (pi.n_rings > 1 ? 0x80000000u : 0u);
         rec->e0 = e0;
-        rec->cnt_flags = cnt | (pi.n_rings > 1 ? 0x80000000u : 0u);
+        rec->e1 = e1;
+        rec->e2 = e2;
     }
-    atomicOr(&rec->labels, label << (2 * k));
+    atomicOr(&rec->labels[k >> 4], label << (2 * (k & 15)));
 }
 __global__ void sub_commit_kernel(const int32_t* __restrict__ flag, const int32_t* __restrict__ pos, int64_t n_cells,
                                   uint32_t* __restrict__ cell) {
@@ -390,7 +399,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
     if (!(w > 0.0) || !(h > 0.0) || !std::isfinite(w) || !std::isfinite(h)) return GPK_OK;  // degenerate extent
 
     int R = 64;
-    while (R < 2048 && (double)R < 4.0 * sqrt((double)d.n_coords)) R <<= 1;
+    while (R < 2048 && (double)R < 2.0 * sqrt((double)d.n_coords)) R <<= 1;
     FineGrid g;
     g.R = R;
     g.fw = w / (double)(R - 3);
@@ -437,7 +446,13 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
     unsigned long long* btot;
     const int64_t max_scan = n_cells > d.n_coords ? n_cells : d.n_coords;
     GPK_TRY(t.alloc(&btot, (size_t)((max_scan + 255) / 256 + 4)));
-    GPK_LAUNCH("gpk_pipidx_ring_rows", ring_rows_kernel, blocks_for(n_rings), dim3(256), 0, s, ring_bbox, n_rings, g, row0, nrows);
+    FineGrid gs = g;  // slab rows: PIP_SLAB_MUL per raster row (exact power-of-two refinement of the same function)
+    gs.R = g.R * PIP_SLAB_MUL;
+    gs.fw = g.fw / PIP_SLAB_MUL;
+    gs.fh = g.fh / PIP_SLAB_MUL;
+    gs.inv_fw = g.inv_fw * PIP_SLAB_MUL;
+    gs.inv_fh = g.inv_fh * PIP_SLAB_MUL;
+    GPK_LAUNCH("gpk_pipidx_ring_rows", ring_rows_kernel, blocks_for(n_rings), dim3(256), 0, s, ring_bbox, n_rings, gs, row0, nrows);
     GPK_TRY(exclusive_scan_i32(nrows, n_rings, slab_base, nullptr, btot, s));
     int32_t n_slabs = 0;
     GPK_HIP(hipMemcpyAsync(&n_slabs, slab_base + n_rings, sizeof n_slabs, hipMemcpyDeviceToHost, s));
@@ -449,7 +464,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
     keep(slab_off);
     GPK_HIP(hipMemsetAsync(slab_cnt, 0, sizeof(int32_t) * (size_t)(n_slabs + 1), s));
     GPK_HIP(hipMemsetAsync(slab_off, 0, sizeof(int32_t) * (size_t)(n_slabs + 1), s));
-    GPK_LAUNCH("gpk_pipidx_slab_count", slab_register_kernel<false>, blocks_for(d.n_coords), dim3(256), 0, s, d, g, row0, slab_base,
+    GPK_LAUNCH("gpk_pipidx_slab_count", slab_register_kernel<false>, blocks_for(d.n_coords), dim3(256), 0, s, d, gs, row0, slab_base,
                slab_cnt, (double4*)nullptr);
     int32_t n_edges = 0;
     if (n_slabs > 0) {
@@ -460,7 +475,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
     double4* edges = nullptr;
     GPK_HIP(hipMalloc((void**)&edges, sizeof(double4) * (size_t)(n_edges ? n_edges : 1)));
     keep(edges);
-    GPK_LAUNCH("gpk_pipidx_slab_fill", slab_register_kernel<true>, blocks_for(d.n_coords), dim3(256), 0, s, d, g, row0, slab_base,
+    GPK_LAUNCH("gpk_pipidx_slab_fill", slab_register_kernel<true>, blocks_for(d.n_coords), dim3(256), 0, s, d, gs, row0, slab_base,
                cursor, edges);
 
     PartInfo* part_info = nullptr;
@@ -549,7 +564,8 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
     // ---- level 2 ------------------------------------------------------------------------------------
     int32_t n_sub = 0;
     SubCell* sub = nullptr;
-    if (g.pad_x * 0.25 > ulp64 && g.pad_y * 0.25 > ulp64 && R * 4 <= 32768) {
+    static_assert(PIP_SLAB_MUL == 2, "SubCell stores exactly two adjacent slab ranges");
+    if (g.pad_x / PIP_SUB > ulp64 && g.pad_y / PIP_SUB > ulp64 && R * PIP_SUB <= 32768) {
         int32_t *sflag, *spos;
         GPK_TRY(t.alloc(&sflag, (size_t)n_cells + 1));
         GPK_TRY(t.alloc(&spos, (size_t)n_cells + 1));
@@ -561,8 +577,8 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
             GPK_HIP(hipMalloc((void**)&sub, sizeof(SubCell) * (size_t)n_sub));
             keep(sub);
             GPK_HIP(hipMemsetAsync(sub, 0, sizeof(SubCell) * (size_t)n_sub, s));
-            GPK_LAUNCH("gpk_pipidx_sub_build", sub_build_kernel, blocks_for(n_cells * 16), dim3(256), 0, s, d, pv, g, sflag, spos, n_cells,
-                       cell, sub);
+            GPK_LAUNCH("gpk_pipidx_sub_build", sub_build_kernel, blocks_for(n_cells * PIP_SUB * PIP_SUB), dim3(256), 0, s, d, pv, g, sflag, spos,
+                       n_cells, (const uint32_t*)cell, sub);
             GPK_LAUNCH("gpk_pipidx_sub_commit", sub_commit_kernel, blocks_for(n_cells), dim3(256), 0, s, sflag, spos, n_cells, cell);
             GPK_HIP(hipStreamSynchronize(s));
         }
