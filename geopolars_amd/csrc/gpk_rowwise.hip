@@ -16,31 +16,57 @@
 
 namespace gpk {
 
-// ---- per-segment pieces (IEEE, contraction off: same branch structure as the CPU semantics) -------
-__device__ __forceinline__ double line_segment_distance(double px, double py, double sx, double sy, double ex,
-                                                        double ey) {
-    if (sx == ex && sy == ey) return hypot(sx - px, sy - py);
-    const double dx = ex - sx, dy = ey - sy;
+// ---- per-segment pieces -----------------------------------------------------------------------------
+// geo-types private_utils::line_segment_distance, evaluated as a SQUARED distance kept as a fraction
+// num / den, so that the per-segment work has no division and no hypot (both cost tens of f64
+// instructions on the vector unit and made this kernel VALU-bound):
+//     degenerate segment or r <= 0     -> |p - s|^2 / 1
+//     r >= 1                           -> |p - e|^2 / 1
+//     otherwise                        -> cross^2 / |e - s|^2          (upstream: |cross / d2| * hypot(dx, dy))
+// r = dot / d2 is compared with 0 and 1 through dot <= 0 and dot >= d2 (same sign; at r ~ 1 the two
+// formulas agree to O((1-r)^2)).  Fractions are compared by cross-multiplication; one divide + sqrt per
+// row at the end.  Results agree with the upstream expression to a few ulps, inside the 1e-9 contract.
+struct Frac {
+    double num, den;
+};
+__device__ __forceinline__ bool frac_less(const Frac& a, const Frac& b) { return a.num * b.den < b.num * a.den; }
+__device__ __forceinline__ double frac_sqrt(const Frac& f) { return f.num == INFINITY ? DBL_MAX : sqrt(f.num / f.den); }
+
+__device__ __forceinline__ Frac segment_dist2(double px, double py, double sx, double sy, double ex, double ey, double& cross_out,
+                                              double& dxdy_out) {
+    const double dx = ex - sx, dy = ey - sy, qx = px - sx, qy = py - sy;
     const double d2 = dx * dx + dy * dy;
-    const double r = ((px - sx) * dx + (py - sy) * dy) / d2;
-    if (r <= 0.0) return hypot(sx - px, sy - py);
-    if (r >= 1.0) return hypot(ex - px, ey - py);
-    const double q = ((sy - py) * dx - (sx - px) * dy) / d2;
-    return fabs(q) * hypot(dx, dy);
+    const double dot = qx * dx + qy * dy;
+    const double cross = qx * dy - qy * dx;  // == -((sy - py) * dx - (sx - px) * dy)
+    cross_out = cross;
+    dxdy_out = dx * dy;
+    if (d2 == 0.0 || dot <= 0.0) return Frac{qx * qx + qy * qy, 1.0};
+    if (dot >= d2) {
+        const double rx = px - ex, ry = py - ey;
+        return Frac{rx * rx + ry * ry, 1.0};
+    }
+    return Frac{cross * cross, d2};
 }
-// geo-types private_utils::line_string_contains_point, one segment (tolerance f64::EPSILON)
-__device__ __forceinline__ bool segment_contains_eps(double px, double py, double sx, double sy, double ex,
-                                                     double ey) {
+
+// geo-types private_utils::line_string_contains_point, one segment (tolerance f64::EPSILON on |tx - ty|).
+// tx - ty == cross / (dx * dy) up to ~3 ulps of O(1) quantities, so the two divisions are only needed when
+// |cross| <= 8 eps |dx dy|; everywhere else the upstream predicate is certainly false.  Inside that band the
+// upstream expression is evaluated verbatim, so the zero / non-zero outcome of `distance` is exact.
+__device__ __forceinline__ bool segment_contains_eps(double px, double py, double sx, double sy, double ex, double ey, double cross,
+                                                     double dxdy) {
     const double dx = ex - sx, dy = ey - sy;
     if (dx == 0.0 && dy == 0.0) return px == sx && py == sy;
     if (dy == 0.0) {
+        if (py != sy) return false;
         const double t = (px - sx) / dx;
-        return py == sy && 0.0 <= t && t <= 1.0;
+        return 0.0 <= t && t <= 1.0;
     }
     if (dx == 0.0) {
+        if (px != sx) return false;
         const double t = (py - sy) / dy;
-        return px == sx && 0.0 <= t && t <= 1.0;
+        return 0.0 <= t && t <= 1.0;
     }
+    if (fabs(cross) > 1.7763568394002505e-15 * fabs(dxdy)) return false;  // 8 * 2^-52
     const double tx = (px - sx) / dx, ty = (py - sy) / dy;
     return fabs(tx - ty) <= DBL_EPSILON && 0.0 <= tx && tx <= 1.0;
 }
@@ -51,6 +77,15 @@ __device__ __forceinline__ double gmin(double v) {
     for (int o = G / 2; o > 0; o >>= 1) {
         const double w = __shfl_xor(v, o, 64);
         v = w < v ? w : v;
+    }
+    return v;
+}
+template <int G>
+__device__ __forceinline__ Frac gmin_frac(Frac v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) {
+        const Frac w{__shfl_xor(v.num, o, 64), __shfl_xor(v.den, o, 64)};
+        if (frac_less(w, v)) v = w;
     }
     return v;
 }
@@ -69,7 +104,7 @@ __device__ __forceinline__ int gor(int v) {
 
 // One coordinate sequence against one point, G lanes cooperating.
 struct SeqAcc {
-    double dmin;    // min line_segment_distance
+    Frac dmin;      // min line_segment_distance, squared, as a fraction
     int wn;         // winding number (rings)
     int on_ring;    // coordinate_position boundary hit
     int eps_hit;    // line_string_contains_point (vertex equality or eps-collinear)
@@ -77,7 +112,7 @@ struct SeqAcc {
 template <int G, bool WANT_DIST, bool WANT_POS>
 __device__ __forceinline__ SeqAcc scan_sequence(const double2* __restrict__ xy, int c0, int c1, double px, double py,
                                                 int lane) {
-    SeqAcc a{DBL_MAX, 0, 0, 0};
+    SeqAcc a{Frac{INFINITY, 1.0}, 0, 0, 0};
     const int n = c1 - c0;
     if (n == 1) {
         const double2 p = xy[c0];
@@ -93,14 +128,15 @@ __device__ __forceinline__ SeqAcc scan_sequence(const double2* __restrict__ xy, 
             a.wn += wn;
         }
         if (WANT_DIST) {
-            const double d = line_segment_distance(px, py, s.x, s.y, e.x, e.y);
-            a.dmin = d < a.dmin ? d : a.dmin;
+            double cross, dxdy;
+            const Frac d = segment_dist2(px, py, s.x, s.y, e.x, e.y, cross, dxdy);
+            if (frac_less(d, a.dmin)) a.dmin = d;
             a.eps_hit |= (int)((s.x == px && s.y == py) || (e.x == px && e.y == py) ||
-                               segment_contains_eps(px, py, s.x, s.y, e.x, e.y));
+                               segment_contains_eps(px, py, s.x, s.y, e.x, e.y, cross, dxdy));
         }
     }
     if (WANT_DIST) {
-        a.dmin = gmin<G>(a.dmin);
+        a.dmin = gmin_frac<G>(a.dmin);
         a.eps_hit = gor<G>(a.eps_hit);
     }
     if (WANT_POS) {
@@ -121,7 +157,7 @@ __device__ __forceinline__ double point_linestring_distance(const double2* xy, i
                                                             int lane) {
     if (c1 == c0) return 0.0;
     const SeqAcc a = scan_sequence<G, true, false>(xy, c0, c1, px, py, lane);
-    return a.eps_hit ? 0.0 : a.dmin;
+    return a.eps_hit ? 0.0 : frac_sqrt(a.dmin);
 }
 
 // EuclideanDistance<Point, Polygon>: 0 if the polygon intersects the point (or its exterior is empty);
@@ -152,14 +188,15 @@ __device__ __forceinline__ double point_polygon(const DevGeo& b, int r0, int r1,
             }
         }
         if (WANT_DIST) {
-            const double d = (h1 == h0 || h.eps_hit) ? 0.0 : h.dmin;
+            const double d = (h1 == h0 || h.eps_hit) ? 0.0 : frac_sqrt(h.dmin);
             dh = d < dh ? d : dh;
         }
     }
     *pos_out = pos;
     if (!WANT_DIST) return 0.0;
     if (pos != dev::POS_OUTSIDE) return 0.0;
-    return dh < ext.dmin ? dh : ext.dmin;
+    const double de = frac_sqrt(ext.dmin);
+    return dh < de ? dh : de;
 }
 
 // distance from one point to row j of b
@@ -276,7 +313,7 @@ __global__ void fill_u8_kernel(uint8_t* out, int64_t n, uint8_t v) {
 static int pick_group_rows(const DevGeo& g) {
     const double mean = g.n_geoms > 0 ? (double)g.n_coords / (double)g.n_geoms : 1.0;
     int G = 1;
-    while (G < 64 && G * 2 <= mean) G <<= 1;  // largest power of two <= mean vertex count
+    while (G < 64 && G * 2 * 8 <= mean) G <<= 1;  // ~8 segments per lane: short reductions, >= 64 B contiguous per group
     return G;
 }
 static dim3 coop_grid(int64_t n_rows, int G) {

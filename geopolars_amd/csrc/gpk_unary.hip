@@ -33,6 +33,9 @@ enum : int {
     ST_COUNT = 12
 };
 constexpr unsigned M_AREA = 1u << 0, M_CENT = 1u << 1, M_LEN = 1u << 2, M_BBOX = 1u << 3, M_SUM = 1u << 4;
+// M_CENT = area-weighted accumulators only; M_LENC = length-weighted ones (a hypot per edge); M_DEGEN restricts a
+// pass to sequences whose ring area came out zero (the only rings whose centroid needs the length partials)
+constexpr unsigned M_LENC = 1u << 5, M_DEGEN = 1u << 6;
 
 template <int G>
 __device__ __forceinline__ double group_sum(double v) {
@@ -60,6 +63,126 @@ __device__ __forceinline__ double group_max(double v) {
 }
 
 // Stage 1: per-sequence partials.  stats is [ST_COUNT][n_seq] (SoA so stage 2 reads are coalesced).
+constexpr int SEQ_LONG = 512;  // sequences longer than this are reduced by a whole work-group (seq_stats_long_kernel)
+
+// per-edge / per-vertex accumulation shared by the group kernel and the long-sequence kernel
+struct SeqPartial {
+    double a2 = 0, acx = 0, acy = 0, len = 0, lmx = 0, lmy = 0, sx = 0, sy = 0;
+    double mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+};
+template <unsigned MASK>
+__device__ __forceinline__ void seq_accumulate(SeqPartial& a, const double2* __restrict__ xy, int i, int c1, double2 first,
+                                               bool closed_ring) {
+    const double2 p = xy[i];
+    if (MASK & M_BBOX) {
+        a.mnx = p.x < a.mnx ? p.x : a.mnx;
+        a.mny = p.y < a.mny ? p.y : a.mny;
+        a.mxx = p.x > a.mxx ? p.x : a.mxx;
+        a.mxy = p.y > a.mxy ? p.y : a.mxy;
+    }
+    if (MASK & M_SUM) {
+        a.sx += p.x;
+        a.sy += p.y;
+    }
+    if ((MASK & (M_AREA | M_CENT | M_LEN | M_LENC)) && i + 1 < c1) {
+        const double2 q = xy[i + 1];
+        if ((MASK & (M_AREA | M_CENT)) && closed_ring) {
+            const double sx = p.x - first.x, sy = p.y - first.y;
+            const double ex = q.x - first.x, ey = q.y - first.y;
+            const double cr = sx * ey - sy * ex;
+            a.a2 += cr;
+            if (MASK & M_CENT) {
+                a.acx += (ex + sx) * cr;
+                a.acy += (ey + sy) * cr;
+            }
+        }
+        if (MASK & (M_LEN | M_LENC)) {
+            const double l = hypot(q.x - p.x, q.y - p.y);
+            a.len += l;
+            if (MASK & M_LENC) {
+                a.lmx += (p.x + q.x) / 2.0 * l;
+                a.lmy += (p.y + q.y) / 2.0 * l;
+            }
+        }
+    }
+}
+template <unsigned MASK>
+__device__ __forceinline__ void seq_store(const SeqPartial& a, double* __restrict__ stats, int64_t n_seq, int64_t s) {
+    if (MASK & (M_AREA | M_CENT)) stats[ST_AREA2 * n_seq + s] = a.a2;
+    if (MASK & M_CENT) {
+        stats[ST_ACX * n_seq + s] = a.acx;
+        stats[ST_ACY * n_seq + s] = a.acy;
+    }
+    if (MASK & M_LENC) {
+        stats[ST_LMX * n_seq + s] = a.lmx;
+        stats[ST_LMY * n_seq + s] = a.lmy;
+    }
+    if (MASK & (M_LEN | M_LENC)) stats[ST_LEN * n_seq + s] = a.len;
+    if (MASK & M_BBOX) {
+        stats[ST_MINX * n_seq + s] = a.mnx;
+        stats[ST_MINY * n_seq + s] = a.mny;
+        stats[ST_MAXX * n_seq + s] = a.mxx;
+        stats[ST_MAXY * n_seq + s] = a.mxy;
+    }
+    if (MASK & M_SUM) {
+        stats[ST_SUMX * n_seq + s] = a.sx;
+        stats[ST_SUMY * n_seq + s] = a.sy;
+    }
+}
+
+// list the sequences the group kernel skips (power-law data: a few giant rings would otherwise be walked by
+// one lane group while the rest of the chip idles); order in the list is irrelevant, every entry is reduced
+// independently and deterministically
+__global__ void find_long_kernel(const int32_t* __restrict__ seq_off, int64_t n_seq, int32_t* __restrict__ long_ws) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seq) return;
+    if (seq_off[s + 1] - seq_off[s] > SEQ_LONG) long_ws[1 + atomicAdd(&long_ws[0], 1)] = (int32_t)s;
+}
+
+template <unsigned MASK>
+__global__ __launch_bounds__(256) void seq_stats_long_kernel(const double2* __restrict__ xy, const int32_t* __restrict__ seq_off,
+                                                             int64_t n_seq, const int32_t* __restrict__ long_ws,
+                                                             double* __restrict__ stats) {
+    __shared__ double red[12][4];
+    const int n_long = long_ws[0];
+    for (int k = blockIdx.x; k < n_long; k += gridDim.x) {
+        const int64_t s = long_ws[1 + k];
+        if ((MASK & M_DEGEN) && stats[ST_AREA2 * n_seq + s] != 0.0) continue;
+        const int c0 = seq_off[s], c1 = seq_off[s + 1];
+        const double2 first = xy[c0], last = xy[c1 - 1];
+        const bool closed_ring = first.x == last.x && first.y == last.y;
+        SeqPartial a;
+        for (int i = c0 + threadIdx.x; i < c1; i += 256) seq_accumulate<MASK>(a, xy, i, c1, first, closed_ring);
+        double v[12] = {a.a2, a.acx, a.acy, a.len, a.lmx, a.lmy, a.sx, a.sy, a.mnx, a.mny, a.mxx, a.mxy};
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            if (j < 8)
+                v[j] = dev::wave_sum(v[j]);
+            else if (j < 10)
+                v[j] = dev::wave_min(v[j]);
+            else
+                v[j] = dev::wave_max(v[j]);
+        }
+        __syncthreads();  // red[] reuse across iterations
+        if ((threadIdx.x & 63) == 0)
+#pragma unroll
+            for (int j = 0; j < 12; ++j) red[j][threadIdx.x >> 6] = v[j];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            SeqPartial r;
+            double t[12];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                t[j] = red[j][0];
+                for (int w = 1; w < 4; ++w) t[j] = j < 8 ? t[j] + red[j][w] : (j < 10 ? fmin(t[j], red[j][w]) : fmax(t[j], red[j][w]));
+            }
+            r.a2 = t[0]; r.acx = t[1]; r.acy = t[2]; r.len = t[3]; r.lmx = t[4]; r.lmy = t[5]; r.sx = t[6]; r.sy = t[7];
+            r.mnx = t[8]; r.mny = t[9]; r.mxx = t[10]; r.mxy = t[11];
+            seq_store<MASK>(r, stats, n_seq, s);
+        }
+    }
+}
+
 template <int G, unsigned MASK>
 __global__ __launch_bounds__(256) void seq_stats_kernel(const double2* __restrict__ xy,
                                                         const int32_t* __restrict__ seq_off,
@@ -68,8 +191,10 @@ __global__ __launch_bounds__(256) void seq_stats_kernel(const double2* __restric
     const int64_t groups_per_grid = (int64_t)gridDim.x * (blockDim.x / G);
     for (int64_t s = (int64_t)blockIdx.x * (blockDim.x / G) + threadIdx.x / G; s < n_seq;
          s += groups_per_grid) {
+        if ((MASK & M_DEGEN) && stats[ST_AREA2 * n_seq + s] != 0.0) continue;  // group-uniform
         const int c0 = seq_off[s], c1 = seq_off[s + 1];
         const int n = c1 - c0;
+        if (n > SEQ_LONG) continue;  // reduced by seq_stats_long_kernel
         double a2 = 0, acx = 0, acy = 0, len = 0, lmx = 0, lmy = 0, sx_ = 0, sy_ = 0;
         double mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
         double2 first = make_double2(0, 0), last = make_double2(0, 0);
@@ -91,7 +216,7 @@ __global__ __launch_bounds__(256) void seq_stats_kernel(const double2* __restric
                 sx_ += p.x;
                 sy_ += p.y;
             }
-            if ((MASK & (M_AREA | M_CENT | M_LEN)) && i + 1 < c1) {
+            if ((MASK & (M_AREA | M_CENT | M_LEN | M_LENC)) && i + 1 < c1) {
                 const double2 q = xy[i + 1];
                 if ((MASK & (M_AREA | M_CENT)) && closed_ring) {
                     const double sx = p.x - first.x, sy = p.y - first.y;
@@ -103,10 +228,10 @@ __global__ __launch_bounds__(256) void seq_stats_kernel(const double2* __restric
                         acy += (ey + sy) * cr;
                     }
                 }
-                if (MASK & (M_LEN | M_CENT)) {
+                if (MASK & (M_LEN | M_LENC)) {
                     const double l = hypot(q.x - p.x, q.y - p.y);
                     len += l;
-                    if (MASK & M_CENT) {
+                    if (MASK & M_LENC) {
                         lmx += (p.x + q.x) / 2.0 * l;
                         lmy += (p.y + q.y) / 2.0 * l;
                     }
@@ -117,10 +242,12 @@ __global__ __launch_bounds__(256) void seq_stats_kernel(const double2* __restric
         if (MASK & M_CENT) {
             acx = group_sum<G>(acx);
             acy = group_sum<G>(acy);
+        }
+        if (MASK & M_LENC) {
             lmx = group_sum<G>(lmx);
             lmy = group_sum<G>(lmy);
         }
-        if (MASK & (M_LEN | M_CENT)) len = group_sum<G>(len);
+        if (MASK & (M_LEN | M_LENC)) len = group_sum<G>(len);
         if (MASK & M_BBOX) {
             mnx = group_min<G>(mnx);
             mny = group_min<G>(mny);
@@ -136,10 +263,12 @@ __global__ __launch_bounds__(256) void seq_stats_kernel(const double2* __restric
             if (MASK & M_CENT) {
                 stats[ST_ACX * n_seq + s] = acx;
                 stats[ST_ACY * n_seq + s] = acy;
+            }
+            if (MASK & M_LENC) {
                 stats[ST_LMX * n_seq + s] = lmx;
                 stats[ST_LMY * n_seq + s] = lmy;
             }
-            if (MASK & (M_LEN | M_CENT)) stats[ST_LEN * n_seq + s] = len;
+            if (MASK & (M_LEN | M_LENC)) stats[ST_LEN * n_seq + s] = len;
             if (MASK & M_BBOX) {
                 stats[ST_MINX * n_seq + s] = mnx;
                 stats[ST_MINY * n_seq + s] = mny;
@@ -304,6 +433,26 @@ __device__ __forceinline__ void wc_add_linestring(WC& c, const double* stats, in
         wc_add_raw(c, 0, p.x * k, p.y * k, k);
     }
 }
+// add_line_string walked by one thread (only for the rare polygon whose holes cancel its exterior area
+// exactly: the exterior's length partials were not computed by the degenerate-only pass)
+__device__ inline void wc_add_linestring_direct(WC& c, const double2* xy, int c0, int n) {
+    if (n == 0) return;
+    double len = 0.0, lmx = 0.0, lmy = 0.0;
+    for (int i = c0; i + 1 < c0 + n; ++i) {
+        const double2 p = xy[i], q = xy[i + 1];
+        const double l = hypot(q.x - p.x, q.y - p.y);
+        len += l;
+        lmx += (p.x + q.x) / 2.0 * l;
+        lmy += (p.y + q.y) / 2.0 * l;
+    }
+    if (len > 0.0) {
+        wc_add_raw(c, 1, lmx, lmy, len);
+    } else {
+        const double2 p = xy[c0];
+        const double k = n == 1 ? 1.0 : (double)(n - 1);
+        wc_add_raw(c, 0, p.x * k, p.y * k, k);
+    }
+}
 __device__ __forceinline__ void wc_add_ring(WC& c, const double* stats, int64_t n_seq, int r,
                                             const double2* xy, int c0, int n) {
     const double area = stats[ST_AREA2 * n_seq + r] / 2.0;
@@ -341,7 +490,7 @@ __global__ void centroid_combine_kernel(DevGeo a, const double* __restrict__ sta
                     ext.ax -= in.ax;
                     ext.ay -= in.ay;
                     if (ext.w == 0.0) {
-                        wc_add_linestring(c, stats, n_seq, r0, a.xy, e0, en);
+                        wc_add_linestring_direct(c, a.xy, e0, en);
                         continue;
                     }
                 }
@@ -399,10 +548,13 @@ __global__ __launch_bounds__(256) void affine_kernel(const double2* __restrict__
 }
 
 // ---- host drivers ------------------------------------------------------------------------------
+// Lanes per coordinate sequence: ~8 vertices per lane.  Fewer lanes per ring means fewer xor-shuffle
+// reduction steps per vertex (with G = 64 on 65-vertex rings the reductions outweighed the streaming work 3:1)
+// while a group still reads G consecutive vertices (>= 64 contiguous bytes) per load.
 static int pick_group(int64_t n_coords, int64_t n_seq) {
     const double mean = n_seq > 0 ? (double)n_coords / (double)n_seq : 1.0;
     int g = 4;
-    while (g < 64 && g < mean) g <<= 1;
+    while (g < 64 && g * 2 * 8 <= mean) g <<= 1;
     return g;
 }
 
@@ -417,11 +569,16 @@ static void seq_view(const DevGeo& a, const int32_t** seq_off, int64_t* n_seq) {
 }
 
 template <unsigned MASK>
-static int32_t launch_seq_stats(const DevGeo& a, double* stats, hipStream_t s, const char* name) {
+static int32_t launch_seq_stats(const DevGeo& a, double* stats, int32_t* long_ws, hipStream_t s, const char* name) {
     const int32_t* seq_off;
     int64_t n_seq;
     seq_view(a, &seq_off, &n_seq);
     if (n_seq == 0) return GPK_OK;
+    if (!(MASK & M_DEGEN)) {  // the degenerate-only second pass reuses the list of the first pass
+        GPK_HIP(hipMemsetAsync(long_ws, 0, sizeof(int32_t), s));
+        GPK_LAUNCH("gpk_find_long", find_long_kernel, dim3((unsigned)((n_seq + 255) / 256)), dim3(256), 0, s, seq_off, n_seq, long_ws);
+    }
+    GPK_LAUNCH("gpk_seq_long", (seq_stats_long_kernel<MASK>), dim3(1024), dim3(256), 0, s, a.xy, seq_off, n_seq, long_ws, stats);
     const int G = pick_group(a.n_coords, n_seq);
     const int64_t groups_per_block = 256 / G;
     int64_t blocks = (n_seq + groups_per_block - 1) / groups_per_block;
@@ -446,6 +603,7 @@ static inline dim3 grid_for(int64_t n, int block = 256) {
 // common prologue: stats + output staging in the workspace
 struct UnaryCtx {
     double* stats = nullptr;
+    int32_t* long_ws = nullptr;  // [0] = count, then the ids of the sequences longer than SEQ_LONG
     void* out_dev = nullptr;
     void* out2_dev = nullptr;
     int64_t n_seq = 0;
@@ -459,8 +617,10 @@ static int32_t unary_begin(const gpk_geoarray* a, size_t out_bytes, size_t out2_
     if (a->d.type == GPK_GEOM_POINT) c->n_seq = 0;
     const size_t stats_bytes = sizeof(double) * ST_COUNT * (size_t)c->n_seq;
     const bool stage = out_space != GPK_MEM_DEVICE;
-    GPK_TRY(workspace().begin(align256(stats_bytes) + (stage ? align256(out_bytes) + align256(out2_bytes) : 0) + 1024));
+    const size_t long_bytes = sizeof(int32_t) * (size_t)(c->n_seq + 1);
+    GPK_TRY(workspace().begin(align256(stats_bytes) + align256(long_bytes) + (stage ? align256(out_bytes) + align256(out2_bytes) : 0) + 1024));
     c->stats = (double*)workspace().take(stats_bytes ? stats_bytes : 8);
+    c->long_ws = (int32_t*)workspace().take(long_bytes);
     c->out_dev = stage ? workspace().take(out_bytes ? out_bytes : 8) : out;
     c->out2_dev = out2 ? (stage ? workspace().take(out2_bytes ? out2_bytes : 8) : out2) : nullptr;
     return GPK_OK;
@@ -482,9 +642,10 @@ int32_t ring_bboxes(const gpk_geoarray* a, double4* out_dev, hipStream_t s) {
     int64_t n_seq;
     seq_view(a->d, &seq_off, &n_seq);
     if (n_seq == 0) return GPK_OK;
-    GPK_TRY(workspace().begin(sizeof(double) * ST_COUNT * (size_t)n_seq + 1024));
+    GPK_TRY(workspace().begin(sizeof(double) * ST_COUNT * (size_t)n_seq + sizeof(int32_t) * (size_t)(n_seq + 1) + 1024));
     double* stats = (double*)workspace().take(sizeof(double) * ST_COUNT * (size_t)n_seq);
-    GPK_TRY(launch_seq_stats<M_BBOX>(a->d, stats, s, "gpk_seq_bbox"));
+    int32_t* long_ws = (int32_t*)workspace().take(sizeof(int32_t) * (size_t)(n_seq + 1));
+    GPK_TRY(launch_seq_stats<M_BBOX>(a->d, stats, long_ws, s, "gpk_seq_bbox"));
     GPK_LAUNCH("gpk_stats_to_bbox", stats_to_bbox_kernel, grid_for(n_seq), dim3(256), 0, s, stats, seq_off, n_seq, out_dev);
     return GPK_OK;
 }
@@ -505,7 +666,7 @@ static int32_t area_impl(const gpk_geoarray* a, double* out, int32_t out_space, 
     if (a->d.type == GPK_GEOM_POINT) {
         GPK_LAUNCH("gpk_point_unary", point_unary_kernel, grid_for(n), dim3(256), 0, s, a->d, 0, (double*)c.out_dev, (uint8_t*)nullptr);
     } else {
-        if (is_polygonal(a->d.type)) GPK_TRY(launch_seq_stats<M_AREA>(a->d, c.stats, s, "gpk_ring_area"));
+        if (is_polygonal(a->d.type)) GPK_TRY(launch_seq_stats<M_AREA>(a->d, c.stats, c.long_ws, s, "gpk_ring_area"));
         if (is_signed)
             GPK_LAUNCH("gpk_area_combine", area_combine_kernel<true>, grid_for(n), dim3(256), 0, s, a->d, c.stats, c.n_seq, (double*)c.out_dev);
         else
@@ -531,7 +692,7 @@ int32_t gpk_euclidean_length(const gpk_geoarray* a, double* out, int32_t out_spa
     if (a->d.type == GPK_GEOM_POINT) {
         GPK_LAUNCH("gpk_point_unary", point_unary_kernel, grid_for(n), dim3(256), 0, s, a->d, 0, (double*)c.out_dev, (uint8_t*)nullptr);
     } else {
-        if (a->d.type != GPK_GEOM_MULTIPOINT) GPK_TRY(launch_seq_stats<M_LEN>(a->d, c.stats, s, "gpk_seq_length"));
+        if (a->d.type != GPK_GEOM_MULTIPOINT) GPK_TRY(launch_seq_stats<M_LEN>(a->d, c.stats, c.long_ws, s, "gpk_seq_length"));
         GPK_LAUNCH("gpk_length_combine", length_combine_kernel, grid_for(n), dim3(256), 0, s, a->d, c.stats, c.n_seq, (double*)c.out_dev);
     }
     return copy_out(out, out_space, c.out_dev, ob, s);
@@ -547,7 +708,7 @@ int32_t gpk_bounds(const gpk_geoarray* a, double* out4, int32_t out_space, void*
     if (a->d.type == GPK_GEOM_POINT) {
         GPK_LAUNCH("gpk_point_unary", point_unary_kernel, grid_for(n), dim3(256), 0, s, a->d, 2, (double*)c.out_dev, (uint8_t*)nullptr);
     } else {
-        GPK_TRY(launch_seq_stats<M_BBOX>(a->d, c.stats, s, "gpk_seq_bbox"));
+        GPK_TRY(launch_seq_stats<M_BBOX>(a->d, c.stats, c.long_ws, s, "gpk_seq_bbox"));
         GPK_LAUNCH("gpk_bounds_combine", bounds_combine_kernel, grid_for(n), dim3(256), 0, s, a->d, c.stats, c.n_seq, (double*)c.out_dev);
     }
     return copy_out(out4, out_space, c.out_dev, ob, s);
@@ -565,9 +726,14 @@ int32_t gpk_centroid(const gpk_geoarray* a, double* out_xy, uint8_t* out_valid, 
         GPK_LAUNCH("gpk_point_unary", point_unary_kernel, grid_for(n), dim3(256), 0, s, a->d, 1, (double*)c.out_dev, (uint8_t*)c.out2_dev);
     } else {
         if (a->d.type == GPK_GEOM_MULTIPOINT)
-            GPK_TRY(launch_seq_stats<M_SUM>(a->d, c.stats, s, "gpk_seq_sum"));
-        else
-            GPK_TRY(launch_seq_stats<M_CENT>(a->d, c.stats, s, "gpk_ring_centroid"));
+            GPK_TRY(launch_seq_stats<M_SUM>(a->d, c.stats, c.long_ws, s, "gpk_seq_sum"));
+        else if (is_polygonal(a->d.type)) {
+            GPK_TRY(launch_seq_stats<M_CENT>(a->d, c.stats, c.long_ws, s, "gpk_ring_centroid"));
+            // zero-area rings degrade to their linestring centroid: a second pass that skips everything else
+            GPK_TRY(launch_seq_stats<M_LENC | M_DEGEN>(a->d, c.stats, c.long_ws, s, "gpk_ring_centroid_degenerate"));
+        } else {
+            GPK_TRY(launch_seq_stats<M_LENC>(a->d, c.stats, c.long_ws, s, "gpk_line_centroid"));
+        }
         GPK_LAUNCH("gpk_centroid_combine", centroid_combine_kernel, grid_for(n), dim3(256), 0, s, a->d, c.stats, c.n_seq, (double*)c.out_dev, (uint8_t*)c.out2_dev);
     }
     if (out_valid) GPK_TRY(copy_out(out_valid, out_space, c.out2_dev, vb, s));

@@ -175,3 +175,12 @@ def test_intersects_polygon_polygon(gpk, oracle):
     inner = GeoArrowArray.from_polygons([[[(4, 4), (5, 4), (5, 5), (4, 5)]], [[(10, 10), (11, 10), (11, 11), (10, 11)]], [[(2, 2), (3, 2), (3, 3), (2, 3)]]])
     assert GeoSeries(nested).intersects(GeoSeries(inner)).tolist() == [True, True, False]
     assert oracle.predicate_rowwise(nested, inner, "intersects").tolist() == [True, True, False]
+
+
+def test_centroid_polygon_fully_covered_by_hole(gpk, oracle):
+    """exterior area == hole area: the polygon degenerates to its exterior linestring (centroid.rs add_polygon)."""
+    sq = [(0, 0), (4, 0), (4, 4), (0, 4)]
+    a = GeoArrowArray.from_polygons([[sq, sq[::-1]], [sq]])
+    exp, _ = oracle.centroid(a)
+    _close(GeoSeries(a).centroid().array.xy, exp)
+    assert exp.tolist() == [[2.0, 2.0], [2.0, 2.0]]
