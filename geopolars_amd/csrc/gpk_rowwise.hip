@@ -200,9 +200,12 @@ __device__ __forceinline__ double point_polygon(const DevGeo& b, int r0, int r1,
 }
 
 // distance from one point to row j of b
-template <int G>
+// KIND selects the right-side geometry family at compile time (one instantiation per family keeps the hot
+// kernel free of the other families' code and registers); KIND < 0 = decide at run time.
+constexpr int KIND_ANY = -1;
+template <int G, int KIND = KIND_ANY>
 __device__ __forceinline__ double point_geom_distance(const DevGeo& b, int64_t j, double px, double py, int lane) {
-    switch (b.type) {
+    switch (KIND == KIND_ANY ? b.type : KIND) {
     case GPK_GEOM_POINT: {
         const double2 q = b.xy[j];
         return hypot(px - q.x, py - q.y);
@@ -241,20 +244,75 @@ __device__ __forceinline__ double point_geom_distance(const DevGeo& b, int64_t j
     }
 }
 
-template <int G>
+// coordinates a row of `b` owns (the work estimate used to bin rows)
+__device__ __forceinline__ int geom_work(const DevGeo& b, int64_t j) {
+    switch (b.type) {
+    case GPK_GEOM_POINT: return 1;
+    case GPK_GEOM_LINESTRING:
+    case GPK_GEOM_MULTIPOINT: return b.geom_off[j + 1] - b.geom_off[j];
+    case GPK_GEOM_POLYGON:
+    case GPK_GEOM_MULTILINESTRING: return b.ring_off[b.geom_off[j + 1]] - b.ring_off[b.geom_off[j]];
+    default: return b.ring_off[b.part_off[b.geom_off[j + 1]]] - b.ring_off[b.part_off[b.geom_off[j]]];
+    }
+}
+
+// Row-wise distance.  Rows are ragged (C3: 4..256 segments, log-uniform), and a wave pays for its longest
+// row, so each work-group first BINS its tile of rows by log2(vertex count) with a counting sort in LDS
+// (the north star's "binning on vertex count so lanes in a wave see similar work"), then G-lane groups walk
+// the tile in bin order, longest first.  Inputs and outputs stay in the tile's contiguous row range, so the
+// permutation costs no extra HBM traffic.  Which group handles which row depends on atomic order, the value
+// written for a row does not.
+constexpr int DIST_TILE = 2048, DIST_BINS = 24;
+template <int G, int KIND>
 __global__ __launch_bounds__(256) void distance_kernel(DevGeo pts, DevGeo other, const uint32_t* __restrict__ rows,
                                                        double* __restrict__ out) {
-    const int lane = threadIdx.x & (G - 1);
-    const int64_t groups = (int64_t)gridDim.x * (256 / G);
-    for (int64_t i = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G; i < pts.n_geoms; i += groups) {
-        const int64_t j = rows ? (int64_t)rows[i] : i;
-        const double2 p = pts.xy[i];
-        double d;
-        if (!dev::valid_row(pts.validity, i) || !dev::valid_row(other.validity, j) || isnan(p.x) || isnan(p.y))
-            d = NAN;
-        else
-            d = point_geom_distance<G>(other, j, p.x, p.y, lane);
-        if (lane == 0) out[i] = d;
+    __shared__ uint16_t s_perm[DIST_TILE];
+    __shared__ int s_cnt[DIST_BINS], s_start[DIST_BINS];
+    const int tid = threadIdx.x, lane = tid & (G - 1);
+    const int64_t n = pts.n_geoms;
+    for (int64_t base = (int64_t)blockIdx.x * DIST_TILE; base < n; base += (int64_t)gridDim.x * DIST_TILE) {
+        const int tile_rows = (int)(n - base < DIST_TILE ? n - base : DIST_TILE);
+        if (tid < DIST_BINS) s_cnt[tid] = 0;
+        __syncthreads();
+        int bin[DIST_TILE / 256], rank[DIST_TILE / 256];
+#pragma unroll
+        for (int k = 0; k < DIST_TILE / 256; ++k) {
+            const int li = k * 256 + tid;
+            bin[k] = -1;
+            if (li < tile_rows) {
+                const int64_t i = base + li;
+                const int64_t j = rows ? (int64_t)rows[i] : i;
+                const int w = geom_work(other, j);
+                bin[k] = w <= 1 ? 0 : (32 - __clz(w - 1));  // ceil(log2(w)); w < 2^23 -> bin < DIST_BINS
+                if (bin[k] >= DIST_BINS) bin[k] = DIST_BINS - 1;
+                rank[k] = atomicAdd(&s_cnt[bin[k]], 1);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {  // longest rows first
+            int run = 0;
+            for (int b = DIST_BINS - 1; b >= 0; --b) {
+                s_start[b] = run;
+                run += s_cnt[b];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < DIST_TILE / 256; ++k)
+            if (bin[k] >= 0) s_perm[s_start[bin[k]] + rank[k]] = (uint16_t)(k * 256 + tid);
+        __syncthreads();
+        for (int e = tid / G; e < tile_rows; e += 256 / G) {
+            const int64_t i = base + s_perm[e];
+            const int64_t j = rows ? (int64_t)rows[i] : i;
+            const double2 p = pts.xy[i];
+            double d;
+            if (!dev::valid_row(pts.validity, i) || !dev::valid_row(other.validity, j) || isnan(p.x) || isnan(p.y))
+                d = NAN;
+            else
+                d = point_geom_distance<G, KIND>(other, j, p.x, p.y, lane);
+            if (lane == 0) out[i] = d;
+        }
+        __syncthreads();
     }
 }
 
@@ -362,17 +420,31 @@ int32_t gpk_distance_rowwise(const gpk_geoarray* a, const gpk_geoarray* b, const
             rows_dev = r;
         }
     }
-    const int G = other->d.type == GPK_GEOM_POINT ? 1 : pick_group_rows(other->d);
-    const dim3 grid = coop_grid(n, G), block(256);
-    switch (G) {
-    case 1: GPK_LAUNCH("gpk_distance", distance_kernel<1>, grid, block, 0, s, pts->d, other->d, rows_dev, out_dev); break;
-    case 2: GPK_LAUNCH("gpk_distance", distance_kernel<2>, grid, block, 0, s, pts->d, other->d, rows_dev, out_dev); break;
-    case 4: GPK_LAUNCH("gpk_distance", distance_kernel<4>, grid, block, 0, s, pts->d, other->d, rows_dev, out_dev); break;
-    case 8: GPK_LAUNCH("gpk_distance", distance_kernel<8>, grid, block, 0, s, pts->d, other->d, rows_dev, out_dev); break;
-    case 16: GPK_LAUNCH("gpk_distance", distance_kernel<16>, grid, block, 0, s, pts->d, other->d, rows_dev, out_dev); break;
-    case 32: GPK_LAUNCH("gpk_distance", distance_kernel<32>, grid, block, 0, s, pts->d, other->d, rows_dev, out_dev); break;
-    default: GPK_LAUNCH("gpk_distance", distance_kernel<64>, grid, block, 0, s, pts->d, other->d, rows_dev, out_dev); break;
+    int G = other->d.type == GPK_GEOM_POINT ? 1 : pick_group_rows(other->d);
+    G = G <= 1 ? 1 : (G <= 8 ? 8 : 32);  // instantiated group sizes
+    int64_t n_tiles = (n + DIST_TILE - 1) / DIST_TILE;
+    if (n_tiles > (int64_t)cu_count() * 16) n_tiles = (int64_t)cu_count() * 16;
+    const dim3 grid((unsigned)n_tiles), block(256);
+#define DIST_LAUNCH(GG, KK) GPK_LAUNCH("gpk_distance", (distance_kernel<GG, KK>), grid, block, 0, s, pts->d, other->d, rows_dev, out_dev)
+#define DIST_BY_G(KK)                  \
+    do {                               \
+        if (G == 1)                    \
+            DIST_LAUNCH(1, KK);        \
+        else if (G == 8)               \
+            DIST_LAUNCH(8, KK);        \
+        else                           \
+            DIST_LAUNCH(32, KK);       \
+    } while (0)
+    switch (other->d.type) {
+    case GPK_GEOM_POINT: DIST_LAUNCH(1, GPK_GEOM_POINT); break;
+    case GPK_GEOM_MULTIPOINT: DIST_BY_G(GPK_GEOM_MULTIPOINT); break;
+    case GPK_GEOM_LINESTRING: DIST_BY_G(GPK_GEOM_LINESTRING); break;
+    case GPK_GEOM_MULTILINESTRING: DIST_BY_G(GPK_GEOM_MULTILINESTRING); break;
+    case GPK_GEOM_POLYGON: DIST_BY_G(GPK_GEOM_POLYGON); break;
+    default: DIST_BY_G(GPK_GEOM_MULTIPOLYGON); break;
     }
+#undef DIST_BY_G
+#undef DIST_LAUNCH
     return copy_out(out, out_space, out_dev, ob, s);
 }
 
