@@ -45,6 +45,7 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--index-per-step", action="store_true", help="rebuild the right-side index inside every step")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and broadcast the right side even at world size 1 (path test)")
     args = ap.parse_args()
 
     import torch
@@ -68,8 +69,10 @@ def main() -> None:
         sys.exit(3)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     lib = _abi.lib()
@@ -79,7 +82,7 @@ def main() -> None:
     # ---- inputs: synthetic C2, resident in HBM before the timed region ---------------------------
     n, m = args.points, args.polys
     polys_host = synth.star_polygons(m, args.verts) if rank == 0 else None
-    if world > 1:
+    if use_dist:
         polys_host = broadcast_geoarray(polys_host, 0, device=dev)  # RCCL, once, outside the timed region
     pts_host = synth.uniform_points(n, seed=synth.SEED + 1 + rank)  # each rank: its own shard of the left series
     pts_xy = torch.from_numpy(pts_host.xy).to(dev)
@@ -97,7 +100,7 @@ def main() -> None:
         return join_pairs_device(pts, polys, idx, "intersects", counts, pairs, left_row_base=0, stream=stream)
 
     def barrier() -> None:
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -114,7 +117,7 @@ def main() -> None:
     t1 = time.perf_counter()
     lib.gpk_profile_enable(0)
     elapsed = t1 - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -129,7 +132,7 @@ def main() -> None:
     lib.gpk_profile_reset()
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -198,7 +201,7 @@ def main() -> None:
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pts_host, polys_host, counts, args.cpu_seconds)
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
