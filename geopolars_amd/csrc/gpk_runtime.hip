@@ -76,16 +76,27 @@ struct ProfRec {
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static std::vector<ProfRec*> g_prof;
+static std::vector<ProfRec*> g_prof_pool;  // recycled records: hipEventCreate is not free inside a timed region
 
 bool profiling_enabled() { return g_prof_on; }
 void profile_begin(const char* name, hipStream_t s, void** token) {
-    ProfRec* r = new ProfRec;
-    r->name = name;
-    if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess) {
-        delete r;
-        *token = nullptr;
-        return;
+    ProfRec* r = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (!g_prof_pool.empty()) {
+            r = g_prof_pool.back();
+            g_prof_pool.pop_back();
+        }
     }
+    if (!r) {
+        r = new ProfRec;
+        if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess) {
+            delete r;
+            *token = nullptr;
+            return;
+        }
+    }
+    r->name = name;
     (void)hipEventRecord(r->a, s);
     *token = r;
 }
@@ -308,11 +319,7 @@ int32_t gpk_profile_enable(int32_t on) {
 }
 int32_t gpk_profile_reset(void) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    for (ProfRec* r : g_prof) {
-        (void)hipEventDestroy(r->a);
-        (void)hipEventDestroy(r->b);
-        delete r;
-    }
+    for (ProfRec* r : g_prof) g_prof_pool.push_back(r);
     g_prof.clear();
     return GPK_OK;
 }

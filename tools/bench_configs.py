@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Single-GPU shares of BASELINE.json configs[3] (C4) and configs[4] (C5) at a chosen scale: wall times of
+index build and join through the host-buffer API, with a parity spot check against the CPU oracle on a
+prefix.  Not the driver's bench; numbers go to DESIGN.md / profiles/."""
+import argparse, json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from geopolars_amd import synth
+from geopolars_amd.dist import slice_rows
+from geopolars_amd.geoseries import GeoSeries
+from geopolars_amd.spatial_index import SpatialIndex, join_pairs
+from oracle import pyoracle as O
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--c4", type=int, default=1_000_000)
+ap.add_argument("--c5-points", type=int, default=6_250_000)
+ap.add_argument("--c5-polys", type=int, default=1_000_000)
+a = ap.parse_args()
+
+def t(f):
+    t0 = time.perf_counter(); r = f(); return r, (time.perf_counter() - t0) * 1e3
+
+# ---- C4: polygon x polygon intersects join ------------------------------------------------------------
+L = synth.clustered_polygons(a.c4, seed=41, mean_neighbours=4.0); R = synth.clustered_polygons(a.c4, seed=42, mean_neighbours=4.0)
+ls, rs = GeoSeries(L), GeoSeries(R)
+ls.device(); rs.device()
+idx, ms_idx = t(lambda: SpatialIndex(rs))
+(pairs, counts), ms_join = t(lambda: join_pairs(ls, rs, "intersects", r_index=idx))
+(pairs, counts), ms_join2 = t(lambda: join_pairs(ls, rs, "intersects", r_index=idx))
+k = min(a.c4, 20000)
+ep, ec, _ = O.spatial_join(slice_rows(L, 0, k), R, "intersects", mode=1)
+ok = np.array_equal(counts[:k], ec) and np.array_equal(pairs[: len(ep)], ep)
+print(json.dumps({"config": "C4 share", "left": a.c4, "right": a.c4, "index_build_ms": ms_idx, "join_ms_first": ms_join, "join_ms": ms_join2, "pairs": int(len(pairs)), "parity_prefix_rows": k, "parity": bool(ok)}), flush=True)
+del ls, rs, idx
+
+# ---- C5: points within power-law multipolygons + area ---------------------------------------------------
+MP = synth.powerlaw_multipolygons(a.c5_polys, seed=51); P = synth.uniform_points(a.c5_points, seed=52)
+ms_, ps = GeoSeries(MP), GeoSeries(P)
+ms_.device(); ps.device()
+idx, ms_idx = t(lambda: SpatialIndex(ms_))
+(pairs, counts), ms_join = t(lambda: join_pairs(ps, ms_, "within", r_index=idx))
+(pairs, counts), ms_join2 = t(lambda: join_pairs(ps, ms_, "within", r_index=idx))
+area, ms_area = t(lambda: ms_.area())
+area, ms_area2 = t(lambda: ms_.area())
+k = min(a.c5_points, 200000)
+ep, ec, _ = O.spatial_join(slice_rows(P, 0, k), MP, "within", mode=1)
+ok = np.array_equal(counts[:k], ec) and np.array_equal(pairs[: len(ep)], ep)
+ea = O.area(MP)
+ok_area = bool(np.all(np.abs(area - ea) <= 1e-9 * np.maximum(np.abs(ea), 1e-300)))
+print(json.dumps({"config": "C5 share", "points": a.c5_points, "multipolygons": a.c5_polys, "coords": int(MP.n_coords), "index_build_ms": ms_idx, "index_bytes": idx.nbytes(), "join_ms_first": ms_join, "join_ms": ms_join2, "pairs": int(len(pairs)), "area_ms": ms_area2, "parity_prefix_rows": k, "parity": bool(ok), "area_parity": ok_area}), flush=True)
