@@ -481,38 +481,81 @@ __device__ __forceinline__ void for_each_bbox_candidate(const IndexView& ix, con
         }
 }
 
+// Stage 1: candidates.  One lane per left row lists the right rows whose closed bbox overlaps the row's bbox
+// (count pass, then fill pass into the row's slice, sorted by right id: the hits then come out sorted).
 template <bool WRITE>
-__global__ __launch_bounds__(256) void bbox_join_kernel(DevGeo left, DevGeo right, IndexView ix, const double4* __restrict__ lbbox,
-                                                         int32_t* __restrict__ counts, const int32_t* __restrict__ offsets,
-                                                         uint32_t left_base, uint2* __restrict__ pairs, int64_t capacity) {
+__global__ __launch_bounds__(256) void bbox_cand_kernel(DevGeo left, DevGeo right, IndexView ix, const double4* __restrict__ lbbox,
+                                                         int32_t* __restrict__ cand_cnt, const int32_t* __restrict__ cand_off,
+                                                         uint32_t* __restrict__ cand_r) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= left.n_geoms) return;
     int cnt = 0;
-    const int64_t o0 = WRITE ? (int64_t)offsets[i] : 0;
+    const int64_t o0 = WRITE ? (int64_t)cand_off[i] : 0;
     if (dev::valid_row(left.validity, i)) {
         const GridParams g = *ix.grid;
         for_each_bbox_candidate(ix, g, lbbox[i], [&](int j) {
             if (!dev::valid_row(right.validity, j)) return;
-            if (!polygonal_intersects_polygonal(left, i, right, j)) return;
-            if (WRITE && o0 + cnt < capacity) pairs[o0 + cnt] = make_uint2(left_base + (uint32_t)i, (uint32_t)j);
+            if (WRITE) cand_r[o0 + cnt] = (uint32_t)j;
             ++cnt;
         });
     }
     if (!WRITE) {
-        counts[i] = cnt;
+        cand_cnt[i] = cnt;
         return;
     }
-    // candidates arrive in cell order: sort this row's hits by right id (rows are short)
-    const int64_t m = o0 + cnt <= capacity ? cnt : (capacity > o0 ? capacity - o0 : 0);
-    for (int64_t a = 1; a < m; ++a) {
-        const uint2 key = pairs[o0 + a];
-        int64_t b = a - 1;
-        while (b >= 0 && pairs[o0 + b].y > key.y) {
-            pairs[o0 + b + 1] = pairs[o0 + b];
+    for (int a = 1; a < cnt; ++a) {  // rows have a handful of candidates
+        const uint32_t key = cand_r[o0 + a];
+        int b = a - 1;
+        while (b >= 0 && cand_r[o0 + b] > key) {
+            cand_r[o0 + b + 1] = cand_r[o0 + b];
             --b;
         }
-        pairs[o0 + b + 1] = key;
+        cand_r[o0 + b + 1] = key;
     }
+}
+
+// Stage 2: exact refine, JOIN_GS lanes per candidate pair (pairs are independent: the unit of parallelism is the
+// pair, not the row, so ragged candidate lists do not unbalance waves).
+constexpr int JOIN_GS = 16;
+__device__ __forceinline__ int64_t row_of_candidate(const int32_t* __restrict__ off, int64_t n_rows, int64_t c) {
+    int64_t lo = 0, hi = n_rows;  // largest row with off[row] <= c
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)off[mid] <= c)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(256) void pair_refine_kernel(DevGeo left, DevGeo right, const int32_t* __restrict__ cand_off,
+                                                           const uint32_t* __restrict__ cand_r, int64_t n_cand,
+                                                           uint8_t* __restrict__ hit) {
+    const int lane = threadIdx.x & (JOIN_GS - 1);
+    const int64_t groups = (int64_t)gridDim.x * (256 / JOIN_GS);
+    for (int64_t c = (int64_t)blockIdx.x * (256 / JOIN_GS) + threadIdx.x / JOIN_GS; c < n_cand; c += groups) {
+        const int64_t i = row_of_candidate(cand_off, left.n_geoms, c);
+        const bool h = polygonal_intersects_polygonal_group<JOIN_GS>(left, i, right, (int64_t)cand_r[c], lane);
+        if (lane == 0) hit[c] = h;
+    }
+}
+
+// Stage 3: per-row hit counts, then (after a scan) the (l, r) pairs in candidate order == sorted by (l, r).
+template <bool WRITE>
+__global__ __launch_bounds__(256) void pair_emit_kernel(int64_t n_rows, const int32_t* __restrict__ cand_off,
+                                                         const uint32_t* __restrict__ cand_r, const uint8_t* __restrict__ hit,
+                                                         int32_t* __restrict__ counts, const int32_t* __restrict__ offsets,
+                                                         uint32_t left_base, uint2* __restrict__ pairs, int64_t capacity) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    int cnt = 0;
+    const int64_t o0 = WRITE ? (int64_t)offsets[i] : 0;
+    for (int c = cand_off[i]; c < cand_off[i + 1]; ++c) {
+        if (!hit[c]) continue;
+        if (WRITE && o0 + cnt < capacity) pairs[o0 + cnt] = make_uint2(left_base + (uint32_t)i, cand_r[c]);
+        ++cnt;
+    }
+    if (!WRITE) counts[i] = cnt;
 }
 
 __global__ void i32_to_u32_copy_kernel(const int32_t* __restrict__ in, uint32_t* __restrict__ out, int64_t n) {
@@ -526,46 +569,83 @@ static inline dim3 grid_for(int64_t n, int block) {
     return dim3((unsigned)(b > 0 ? b : 1));
 }
 
-// polygonal x polygonal: count -> scan -> write (each row's hits sorted by right id)
+// polygonal x polygonal: candidates (count, scan, fill) -> pair-parallel exact refine -> hits (count, scan, emit)
 static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, const gpk_index* right_index, uint32_t left_row_base,
                          uint32_t* out_counts, uint32_t* out_pairs, int64_t pair_capacity, int64_t* n_pairs, int32_t out_space,
                          hipStream_t s) {
     const int64_t n = left->d.n_geoms;
     const bool host_out = out_space != GPK_MEM_DEVICE;
     const bool want_pairs = pair_capacity > 0;
-    // left bboxes first (gpk_bounds uses the workspace itself), into an allocation of their own
-    double4* lbbox = nullptr;
-    GPK_HIP(hipMalloc((void**)&lbbox, sizeof(double4) * (size_t)n));
+    // per-call allocations that outlive a workspace reset (gpk_bounds uses the workspace itself)
+    void* owned[3] = {nullptr, nullptr, nullptr};
     auto done = [&](int32_t rc) {
-        (void)hipFree(lbbox);
+        for (void* p : owned)
+            if (p) (void)hipFree(p);
         return rc;
     };
+    double4* lbbox = nullptr;
+    GPK_HIP(hipMalloc((void**)&lbbox, sizeof(double4) * (size_t)n));
+    owned[0] = lbbox;
     int32_t rc = gpk_bounds(left, (double*)lbbox, GPK_MEM_DEVICE, (void*)s);
     if (rc != GPK_OK) return done(rc);
     const int64_t nb = (n + 255) / 256;
     const size_t pairs_bytes = sizeof(uint32_t) * 2 * (size_t)pair_capacity;
-    size_t need = 2 * align256(sizeof(int32_t) * (size_t)(n + 1)) + align256(sizeof(unsigned long long) * (size_t)(nb + 2)) + 1024;
+    const size_t i32n = align256(sizeof(int32_t) * (size_t)(n + 1));
+    size_t need = 4 * i32n + align256(sizeof(unsigned long long) * (size_t)(nb + 2)) + 1024;
     if (host_out && out_counts) need += align256(sizeof(uint32_t) * (size_t)n);
     if (host_out && want_pairs) need += align256(pairs_bytes);
     rc = workspace().begin(need);
     if (rc != GPK_OK) return done(rc);
+    int32_t* cand_cnt = (int32_t*)workspace().take(sizeof(int32_t) * (size_t)(n + 1));
+    int32_t* cand_off = (int32_t*)workspace().take(sizeof(int32_t) * (size_t)(n + 1));
     int32_t* counts = (int32_t*)workspace().take(sizeof(int32_t) * (size_t)(n + 1));
     int32_t* offsets = (int32_t*)workspace().take(sizeof(int32_t) * (size_t)(n + 1));
     unsigned long long* btot = (unsigned long long*)workspace().take(sizeof(unsigned long long) * (size_t)(nb + 2));
     uint32_t* counts_out = out_counts ? (host_out ? (uint32_t*)workspace().take(sizeof(uint32_t) * (size_t)n) : out_counts) : nullptr;
     uint32_t* pairs_dev = want_pairs ? (host_out ? (uint32_t*)workspace().take(pairs_bytes) : out_pairs) : nullptr;
-    auto run = [&]() -> int32_t {
-        GPK_LAUNCH("gpk_bbox_join_count", bbox_join_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, left->d, right->d, right_index->v,
-                   lbbox, counts, (const int32_t*)nullptr, left_row_base, (uint2*)nullptr, (int64_t)0);
+
+    int32_t n_cand = 0;
+    auto stage1 = [&]() -> int32_t {
+        GPK_LAUNCH("gpk_bbox_cand_count", bbox_cand_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, left->d, right->d, right_index->v,
+                   lbbox, cand_cnt, (const int32_t*)nullptr, (uint32_t*)nullptr);
+        GPK_TRY(exclusive_scan_i32(cand_cnt, n, cand_off, nullptr, btot, s));
+        GPK_HIP(hipMemcpyAsync(&n_cand, cand_off + n, sizeof n_cand, hipMemcpyDeviceToHost, s));
+        GPK_HIP(hipStreamSynchronize(s));
+        return GPK_OK;
+    };
+    rc = stage1();
+    if (rc != GPK_OK) return done(rc);
+    uint32_t* cand_r = nullptr;
+    uint8_t* hit = nullptr;
+    {
+        hipError_t e = hipMalloc((void**)&cand_r, sizeof(uint32_t) * (size_t)(n_cand > 0 ? n_cand : 1));
+        owned[1] = cand_r;
+        if (e == hipSuccess) e = hipMalloc((void**)&hit, (size_t)(n_cand > 0 ? n_cand : 1));
+        owned[2] = hit;
+        if (e != hipSuccess) return done(fail(GPK_ERR_OOM, "spatial_join: candidate buffers (%d pairs): %s", n_cand, hipGetErrorString(e)));
+    }
+    auto stage23 = [&]() -> int32_t {
+        GPK_LAUNCH("gpk_bbox_cand_fill", bbox_cand_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, left->d, right->d, right_index->v,
+                   lbbox, cand_cnt, (const int32_t*)cand_off, cand_r);
+        if (n_cand > 0) {
+            int64_t blocks = ((int64_t)n_cand + (256 / JOIN_GS) - 1) / (256 / JOIN_GS);
+            const int64_t cap = (int64_t)cu_count() * 64;
+            if (blocks > cap) blocks = cap;
+            GPK_LAUNCH("gpk_pair_refine", pair_refine_kernel, dim3((unsigned)blocks), dim3(256), 0, s, left->d, right->d,
+                       (const int32_t*)cand_off, (const uint32_t*)cand_r, (int64_t)n_cand, hit);
+        }
+        GPK_LAUNCH("gpk_pair_count", pair_emit_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, n, (const int32_t*)cand_off,
+                   (const uint32_t*)cand_r, (const uint8_t*)hit, counts, (const int32_t*)nullptr, left_row_base, (uint2*)nullptr, (int64_t)0);
         GPK_TRY(exclusive_scan_i32(counts, n, offsets, nullptr, btot, s));
         if (counts_out)
             GPK_LAUNCH("gpk_counts_copy", i32_to_u32_copy_kernel, dim3((unsigned)nb), dim3(256), 0, s, counts, counts_out, n);
         if (want_pairs)
-            GPK_LAUNCH("gpk_bbox_join_write", bbox_join_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, left->d, right->d,
-                       right_index->v, lbbox, counts, offsets, left_row_base, (uint2*)pairs_dev, pair_capacity);
+            GPK_LAUNCH("gpk_pair_emit", pair_emit_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, n, (const int32_t*)cand_off,
+                       (const uint32_t*)cand_r, (const uint8_t*)hit, counts, (const int32_t*)offsets, left_row_base, (uint2*)pairs_dev,
+                       pair_capacity);
         return GPK_OK;
     };
-    rc = run();
+    rc = stage23();
     if (rc != GPK_OK) return done(rc);
     int32_t total = 0;
     hipError_t e = hipMemcpyAsync(&total, offsets + n, sizeof total, hipMemcpyDeviceToHost, s);

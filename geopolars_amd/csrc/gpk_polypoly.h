@@ -118,4 +118,103 @@ __device__ inline bool polygonal_intersects_polygonal(const DevGeo& a, int64_t i
 }
 
 
+
+// ---- G lanes cooperating on one (A, B) pair ----------------------------------------------------------
+// Same boolean as polygonal_intersects_polygonal.  Lane k owns segments k, k+G, ... of B (flattened over B's
+// rings) and tests each against every segment of A with box pruning; a group-wide OR after every round allows
+// early exit.  If no boundary pair touches, a ring never changes side of the other polygon's boundary, so ONE
+// vertex per ring decides containment (upstream tests every endpoint; the outcome is identical).
+template <int G>
+__device__ __forceinline__ bool group_any(bool v) {
+    int x = v ? 1 : 0;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) x |= __shfl_xor(x, o, 64);
+    return x != 0;
+}
+
+template <int G>
+__device__ inline bool polygon_intersects_polygon_group(const DevGeo& a, int ar0, int ar1, const DevGeo& b, int br0, int br1, int lane) {
+    if (ar1 <= ar0 || br1 <= br0) return false;
+    const int a_c0 = a.ring_off[ar0], a_c1 = a.ring_off[ar1];
+    const int b_c0 = b.ring_off[br0], b_c1 = b.ring_off[br1];
+    if (a.ring_off[ar0 + 1] == a_c0 || b.ring_off[br0 + 1] == b_c0) return false;  // empty exterior
+    // exterior bboxes, cooperatively (has_disjoint_bboxes)
+    double amnx = INFINITY, amny = INFINITY, amxx = -INFINITY, amxy = -INFINITY;
+    for (int i = a_c0 + lane; i < a.ring_off[ar0 + 1]; i += G) {
+        const double2 p = a.xy[i];
+        amnx = fmin(amnx, p.x); amny = fmin(amny, p.y); amxx = fmax(amxx, p.x); amxy = fmax(amxy, p.y);
+    }
+    double bmnx = INFINITY, bmny = INFINITY, bmxx = -INFINITY, bmxy = -INFINITY;
+    for (int i = b_c0 + lane; i < b.ring_off[br0 + 1]; i += G) {
+        const double2 p = b.xy[i];
+        bmnx = fmin(bmnx, p.x); bmny = fmin(bmny, p.y); bmxx = fmax(bmxx, p.x); bmxy = fmax(bmxy, p.y);
+    }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) {
+        amnx = fmin(amnx, __shfl_xor(amnx, o, 64)); amny = fmin(amny, __shfl_xor(amny, o, 64));
+        amxx = fmax(amxx, __shfl_xor(amxx, o, 64)); amxy = fmax(amxy, __shfl_xor(amxy, o, 64));
+        bmnx = fmin(bmnx, __shfl_xor(bmnx, o, 64)); bmny = fmin(bmny, __shfl_xor(bmny, o, 64));
+        bmxx = fmax(bmxx, __shfl_xor(bmxx, o, 64)); bmxy = fmax(bmxy, __shfl_xor(bmxy, o, 64));
+    }
+    if (amxx < bmnx || amxy < bmny || bmxx < amnx || bmxy < amny) return false;
+
+    // boundary x boundary: coordinate index j of B starts a segment unless it is the last coordinate of its ring
+    for (int j0 = b_c0; j0 < b_c1; j0 += G) {
+        const int j = j0 + lane;
+        bool found = false;
+        if (j + 1 < b_c1) {
+            // ring of j: B has few rings; find by scan
+            int rb = br0;
+            while (rb + 1 < br1 && b.ring_off[rb + 1] <= j) ++rb;
+            if (j + 1 < b.ring_off[rb + 1]) {
+                const double2 q0 = b.xy[j], q1 = b.xy[j + 1];
+                const double qlx = fmin(q0.x, q1.x), qhx = fmax(q0.x, q1.x), qly = fmin(q0.y, q1.y), qhy = fmax(q0.y, q1.y);
+                for (int ra = ar0; ra < ar1 && !found; ++ra) {
+                    const int a0 = a.ring_off[ra], a1 = a.ring_off[ra + 1];
+                    for (int i = a0; i + 1 < a1; ++i) {
+                        const double2 p0 = a.xy[i], p1 = a.xy[i + 1];
+                        if (fmax(p0.x, p1.x) < qlx || fmin(p0.x, p1.x) > qhx || fmax(p0.y, p1.y) < qly || fmin(p0.y, p1.y) > qhy) continue;
+                        if (line_intersects_line(p0, p1, q0, q1)) {
+                            found = true;
+                            break;
+                        }
+                    }
+                }
+            }
+        }
+        if (group_any<G>(found)) return true;
+    }
+    // containment: one vertex per ring of B against A, then A's exterior against B
+    bool inside = false;
+    for (int rb = br0 + lane; rb < br1; rb += G) {
+        const int c = b.ring_off[rb];
+        if (b.ring_off[rb + 1] > c) {
+            const double2 q = b.xy[c];
+            inside |= dev::polygon_pos(a, ar0, ar1, q.x, q.y) != dev::POS_OUTSIDE;
+        }
+    }
+    if (lane == 0) {
+        const double2 p = a.xy[a_c0];
+        inside |= dev::polygon_pos(b, br0, br1, p.x, p.y) != dev::POS_OUTSIDE;
+    }
+    return group_any<G>(inside);
+}
+
+template <int G>
+__device__ inline bool polygonal_intersects_polygonal_group(const DevGeo& a, int64_t ia, const DevGeo& b, int64_t ib, int lane) {
+    int a0, a1, b0, b1;
+    dev::geom_parts(a, ia, a0, a1);
+    dev::geom_parts(b, ib, b0, b1);
+    for (int p = a0; p < a1; ++p) {
+        int ar0, ar1;
+        dev::part_rings(a, p, ar0, ar1);
+        for (int q = b0; q < b1; ++q) {
+            int br0, br1;
+            dev::part_rings(b, q, br0, br1);
+            if (polygon_intersects_polygon_group<G>(a, ar0, ar1, b, br0, br1, lane)) return true;
+        }
+    }
+    return false;
+}
+
 }  // namespace gpk

@@ -90,20 +90,17 @@ def join_pairs(
     n_pairs = C.c_int64(0)
     rh = r_index.handle if r_index is not None else None
     pred = PREDICATES[predicate]
-    _abi.check(
-        lib.gpk_spatial_join(
-            left.device().handle, right.device().handle, rh, pred, left_row_base, counts.ctypes.data, None, 0, C.byref(n_pairs), MEM_HOST, None
+    capacity = max(1024, 2 * n)  # one call in the common case; the ABI reports the exact total when this is too small
+    while True:
+        pairs = np.empty((capacity, 2), dtype=np.uint32)
+        rc = lib.gpk_spatial_join(
+            left.device().handle, right.device().handle, rh, pred, left_row_base, counts.ctypes.data, pairs.ctypes.data, capacity, C.byref(n_pairs), MEM_HOST, None
         )
-    )
-    total = int(n_pairs.value)
-    pairs = np.empty((total, 2), dtype=np.uint32)
-    if total:
-        _abi.check(
-            lib.gpk_spatial_join(
-                left.device().handle, right.device().handle, rh, pred, left_row_base, None, pairs.ctypes.data, total, C.byref(n_pairs), MEM_HOST, None
-            )
-        )
-    return pairs, counts
+        if rc == _abi.GPK_ERR_CAPACITY and int(n_pairs.value) > capacity:
+            capacity = int(n_pairs.value)
+            continue
+        _abi.check(rc)
+        return pairs[: int(n_pairs.value)].copy(), counts
 
 
 def join_pairs_device(left: DeviceGeoArray, right: DeviceGeoArray, r_index: SpatialIndex, predicate: str, out_counts, out_pairs, left_row_base: int = 0, stream: int = 0) -> int:
