@@ -111,14 +111,19 @@ __global__ void cell_sort_kernel(const int32_t* __restrict__ cell_off, int64_t n
 #ifndef GPK_PIP_GS
 #define GPK_PIP_GS 8
 #endif
-constexpr int PIP_BLOCK = 256;                 // threads per work-group
+#ifndef GPK_PIP_BLOCK
+#define GPK_PIP_BLOCK 256
+#endif
+constexpr int PIP_BLOCK = GPK_PIP_BLOCK;       // threads per work-group of pip_tile
+constexpr int WR_BLOCK = 256;                  // threads per work-group of pip_write
 constexpr int PIP_PPT = GPK_PIP_PPT;           // points per thread, strided by PIP_BLOCK (coalesced 16-byte loads)
 constexpr int PIP_TILE = PIP_BLOCK * PIP_PPT;  // points per work-group
 constexpr int PIP_GS = GPK_PIP_GS;             // lanes cooperating on one queued (point, part) pair
 constexpr int PIP_QCAP = PIP_TILE;             // LDS queue capacity (overflow is resolved inline, still exact)
 constexpr int PIP_SUPER_SHIFT = 6;             // 64 tiles per super-tile (two-level prefix of the tile totals)
 constexpr int PIP_WPT = 8;                     // writer: consecutive points per thread
-constexpr int PIP_WTILE = PIP_BLOCK * PIP_WPT;  // writer: points per work-group (a multiple of PIP_TILE)
+constexpr int PIP_WTILE = WR_BLOCK * PIP_WPT;  // writer: points per work-group (a multiple of PIP_TILE)
+static_assert(PIP_WTILE % PIP_TILE == 0, "a writer tile is a whole number of pip_tile tiles");
 // per-point result code handed from pip_tile to pip_write: a geometry id (exactly one hit), CODE_NONE, or
 // CODE_MULTI (several hits: the writer re-enumerates them with the generic walk)
 constexpr uint32_t CODE_NONE = 0xFFFFFFFFu, CODE_MULTI = 0xFFFFFFFEu;
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(PIP_BLOCK) void pip_tile_kernel(DevGeo pts, DevGeo 
 // bytes per hit; only CODE_MULTI rows touch geometry again.  There is no separate scan kernel: a work-group
 // gets its global offset from the two-level totals (<= 64 tile totals + the super-tile totals before them,
 // summed by one wave), each thread owns PIP_WPT consecutive points, one block scan orders the threads.
-__global__ __launch_bounds__(PIP_BLOCK) void pip_write_kernel(DevGeo pts, DevGeo polys, IndexView ix,
+__global__ __launch_bounds__(WR_BLOCK) void pip_write_kernel(DevGeo pts, DevGeo polys, IndexView ix,
                                                                const uint32_t* __restrict__ code,
                                                                const unsigned long long* __restrict__ block_tot,
                                                                const unsigned long long* __restrict__ super_tot,
@@ -395,7 +400,7 @@ __global__ __launch_bounds__(PIP_BLOCK) void pip_write_kernel(DevGeo pts, DevGeo
                                                                uint2* __restrict__ pairs, int64_t capacity,
                                                                unsigned long long* __restrict__ grand,
                                                                unsigned long long* __restrict__ grand_host) {
-    __shared__ unsigned long long lds[PIP_BLOCK / 64 + 1];
+    __shared__ unsigned long long lds[WR_BLOCK / 64 + 1];
     __shared__ unsigned long long s_base;
     const int tid = threadIdx.x;
     const int64_t first_tile = (int64_t)blockIdx.x * (PIP_WTILE / PIP_TILE);
@@ -429,7 +434,7 @@ __global__ __launch_bounds__(PIP_BLOCK) void pip_write_kernel(DevGeo pts, DevGeo
         mine += cnt[k];
     }
     unsigned long long tot;
-    const unsigned long long ex = dev::block_exclusive_scan<unsigned long long, PIP_BLOCK>((unsigned long long)mine, lds, &tot);
+    const unsigned long long ex = dev::block_exclusive_scan<unsigned long long, WR_BLOCK>((unsigned long long)mine, lds, &tot);
     // (block_exclusive_scan's barriers also publish s_base)
     int64_t o = (int64_t)(s_base + ex);
     if (blockIdx.x == gridDim.x - 1 && tid == 0) {
@@ -868,7 +873,7 @@ int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right, co
         J_LAUNCH("gpk_pip_tile_generic", pip_tile_kernel<false>, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
                  right_index->v, right_index->pip, counts_dev, code, btot, stot);
     // the writer also produces the grand total; in count-only mode it runs without a pair buffer
-    J_LAUNCH("gpk_pip_write", pip_write_kernel, dim3((unsigned)n_wblocks), dim3(PIP_BLOCK), 0, s, left->d, right->d, right_index->v,
+    J_LAUNCH("gpk_pip_write", pip_write_kernel, dim3((unsigned)n_wblocks), dim3(WR_BLOCK), 0, s, left->d, right->d, right_index->v,
              code, btot, stot, n_blocks, left_row_base, (uint2*)pairs_dev, pair_capacity, grand, pinned_total);
 #undef J_LAUNCH
 
