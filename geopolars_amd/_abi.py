@@ -85,6 +85,7 @@ _PROTOS = {
     "gpk_bounds": (C.c_int32, [_VP, _VP, C.c_int32, _VP]),
     "gpk_euclidean_length": (C.c_int32, [_VP, _VP, C.c_int32, _VP]),
     "gpk_affine_transform": (C.c_int32, [_VP, C.POINTER(C.c_double), _VP, C.c_int32, _VP]),
+    "gpk_affine_transform_rows": (C.c_int32, [_VP, _VP, _VP, C.c_int32, _VP]),
     "gpk_convex_hull": (C.c_int32, [_VP, _VP, _VP, C.c_int32, _VP]),
     "gpk_distance_rowwise": (C.c_int32, [_VP, _VP, _VP, _VP, C.c_int32, _VP]),
     "gpk_predicate_rowwise": (C.c_int32, [_VP, _VP, _VP, C.c_int32, _VP, C.c_int32, _VP]),

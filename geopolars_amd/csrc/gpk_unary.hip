@@ -548,6 +548,33 @@ __global__ __launch_bounds__(256) void affine_kernel(const double2* __restrict__
 }
 
 // ---- host drivers ------------------------------------------------------------------------------
+// per-row matrices: G lanes walk the contiguous coordinate range of one geometry
+__device__ __forceinline__ void geom_coords(const DevGeo& a, int64_t g, int& c0, int& c1) {
+    switch (a.type) {
+    case GPK_GEOM_POINT: c0 = (int)g; c1 = (int)g + 1; break;
+    case GPK_GEOM_LINESTRING:
+    case GPK_GEOM_MULTIPOINT: c0 = a.geom_off[g]; c1 = a.geom_off[g + 1]; break;
+    case GPK_GEOM_POLYGON:
+    case GPK_GEOM_MULTILINESTRING: c0 = a.ring_off[a.geom_off[g]]; c1 = a.ring_off[a.geom_off[g + 1]]; break;
+    default: c0 = a.ring_off[a.part_off[a.geom_off[g]]]; c1 = a.ring_off[a.part_off[a.geom_off[g + 1]]];
+    }
+}
+template <int G>
+__global__ __launch_bounds__(256) void affine_rows_kernel(DevGeo a, const double* __restrict__ mats, double2* __restrict__ out) {
+    const int lane = threadIdx.x & (G - 1);
+    const int64_t groups = (int64_t)gridDim.x * (256 / G);
+    for (int64_t g = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G; g < a.n_geoms; g += groups) {
+        int c0, c1;
+        geom_coords(a, g, c0, c1);
+        const double m0 = mats[6 * g], m1 = mats[6 * g + 1], m2 = mats[6 * g + 2], m3 = mats[6 * g + 3], m4 = mats[6 * g + 4],
+                     m5 = mats[6 * g + 5];
+        for (int i = c0 + lane; i < c1; i += G) {
+            const double2 p = a.xy[i];
+            out[i] = make_double2((m0 * p.x + m1 * p.y) + m2, (m3 * p.x + m4 * p.y) + m5);
+        }
+    }
+}
+
 // Lanes per coordinate sequence: ~8 vertices per lane.  Fewer lanes per ring means fewer xor-shuffle
 // reduction steps per vertex (with G = 64 on 65-vertex rings the reductions outweighed the streaming work 3:1)
 // while a group still reads G consecutive vertices (>= 64 contiguous bytes) per load.
@@ -756,6 +783,38 @@ int32_t gpk_affine_transform(const gpk_geoarray* a, const double m[6], double* o
     const int64_t cap = (int64_t)cu_count() * 8;
     if (blocks > cap) blocks = cap;
     GPK_LAUNCH("gpk_affine", affine_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a->d.xy, n, m[0], m[1], m[2], m[3], m[4], m[5], (double2*)out_dev);
+    return copy_out(out_xy, out_space, out_dev, ob, s);
+}
+
+int32_t gpk_affine_transform_rows(const gpk_geoarray* a, const double* matrices, double* out_xy, int32_t out_space, void* stream) {
+    if (!a || !matrices || !out_xy) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
+    GPK_TRY(require_device());
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = a->d.n_coords, ng = a->d.n_geoms;
+    if (n == 0 || ng == 0) return GPK_OK;
+    const size_t ob = sizeof(double) * 2 * (size_t)n, mb = sizeof(double) * 6 * (size_t)ng;
+    void* out_dev = out_xy;
+    const double* mats_dev = matrices;
+    if (out_space != GPK_MEM_DEVICE) {
+        GPK_TRY(workspace().begin(align256(ob) + align256(mb) + 512));
+        out_dev = workspace().take(ob);
+        double* m = (double*)workspace().take(mb);
+        GPK_HIP(hipMemcpyAsync(m, matrices, mb, hipMemcpyHostToDevice, s));
+        mats_dev = m;
+    }
+    const int G = pick_group(n, ng);
+    const int64_t per_block = 256 / G;
+    int64_t blocks = (ng + per_block - 1) / per_block;
+    const int64_t cap = (int64_t)cu_count() * 16;
+    if (blocks > cap) blocks = cap;
+    const dim3 grid((unsigned)blocks), block(256);
+    switch (G) {
+    case 4: GPK_LAUNCH("gpk_affine_rows", affine_rows_kernel<4>, grid, block, 0, s, a->d, mats_dev, (double2*)out_dev); break;
+    case 8: GPK_LAUNCH("gpk_affine_rows", affine_rows_kernel<8>, grid, block, 0, s, a->d, mats_dev, (double2*)out_dev); break;
+    case 16: GPK_LAUNCH("gpk_affine_rows", affine_rows_kernel<16>, grid, block, 0, s, a->d, mats_dev, (double2*)out_dev); break;
+    case 32: GPK_LAUNCH("gpk_affine_rows", affine_rows_kernel<32>, grid, block, 0, s, a->d, mats_dev, (double2*)out_dev); break;
+    default: GPK_LAUNCH("gpk_affine_rows", affine_rows_kernel<64>, grid, block, 0, s, a->d, mats_dev, (double2*)out_dev); break;
+    }
     return copy_out(out_xy, out_space, out_dev, ob, s);
 }
 

@@ -191,15 +191,16 @@ class GeoSeries:
         return np.tile(np.array([[float(x), float(y)]]), (len(self), 1))
 
     def _per_row_affine(self, mats: np.ndarray) -> "GeoSeries":
-        # rows share a matrix only when the origin is a fixed point; otherwise group by row.
+        """One matrix per geometry (per-geometry origins): a single HIP launch, G lanes per geometry."""
         if len(mats) == 0:
             return self
-        if np.all(mats == mats[0]):
-            return self.affine_transform(mats[0])
-        parts = []
-        for i in range(len(self)):
-            parts.append(_take_rows(self.array, i).affine_row(mats[i]))
-        return GeoSeries(_concat_like(self.array, parts))
+        a = self.array
+        mats = np.ascontiguousarray(mats, dtype=np.float64).reshape(len(self), 6)
+        out = np.empty_like(a.xy)
+        _abi.check(_abi.lib().gpk_affine_transform_rows(self.device().handle, mats.ctypes.data, out.ctypes.data, MEM_HOST, None))
+        return GeoSeries(
+            GeoArrowArray(a.geom_type, out, a.geom_offsets, a.part_offsets, a.ring_offsets, a.validity, n_geoms=a.n_geoms)
+        )
 
     def rotate(self, angle: float, origin: TransformOrigin = "center") -> "GeoSeries":
         """angle in degrees, counter-clockwise, about `origin` (geoseries.rs:85-93)."""
@@ -267,43 +268,3 @@ def _abi_name(t: int) -> str:
     from .geoarrow import GEOM_NAMES
 
     return GEOM_NAMES.get(t, f"type {t}")
-
-
-class _RowView:
-    def __init__(self, arr: GeoArrowArray):
-        self.arr = arr
-
-    def affine_row(self, m) -> GeoArrowArray:
-        return GeoSeries(self.arr).affine_transform(m).array
-
-
-def _take_rows(a: GeoArrowArray, i: int) -> _RowView:
-    """Single-row slice (used only by per-row origins of rotate/scale/skew)."""
-    if a.geom_type == GEOM_POINT:
-        return _RowView(GeoArrowArray.from_points(a.xy[i : i + 1]))
-    g0, g1 = int(a.geom_offsets[i]), int(a.geom_offsets[i + 1])
-    if a.geom_type in (GEOM_LINESTRING, GEOM_MULTIPOINT):
-        return _RowView(GeoArrowArray(a.geom_type, a.xy[g0:g1], geom_offsets=np.array([0, g1 - g0], np.int32)))
-    if a.geom_type in (GEOM_POLYGON, GEOM_MULTILINESTRING):
-        ro = a.ring_offsets[g0 : g1 + 1]
-        return _RowView(
-            GeoArrowArray(a.geom_type, a.xy[ro[0] : ro[-1]], geom_offsets=np.array([0, g1 - g0], np.int32), ring_offsets=ro - ro[0])
-        )
-    po = a.part_offsets[g0 : g1 + 1]
-    ro = a.ring_offsets[po[0] : po[-1] + 1]
-    return _RowView(
-        GeoArrowArray(
-            a.geom_type,
-            a.xy[ro[0] : ro[-1]],
-            geom_offsets=np.array([0, g1 - g0], np.int32),
-            part_offsets=po - po[0],
-            ring_offsets=ro - ro[0],
-        )
-    )
-
-
-def _concat_like(proto: GeoArrowArray, parts: Sequence[GeoArrowArray]) -> GeoArrowArray:
-    xy = np.concatenate([p.xy for p in parts]) if parts else np.zeros((0, 2))
-    return GeoArrowArray(
-        proto.geom_type, xy, proto.geom_offsets, proto.part_offsets, proto.ring_offsets, proto.validity, n_geoms=proto.n_geoms
-    )

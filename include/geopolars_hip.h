@@ -134,6 +134,11 @@ int32_t gpk_euclidean_length(const gpk_geoarray* a, double* out, int32_t out_spa
  * out_xy[2*n_coords]; offsets are unchanged and shared with the input. */
 int32_t gpk_affine_transform(const gpk_geoarray* a, const double m[6], double* out_xy,
                              int32_t out_space, void* stream);
+/* rotate / scale / skew about a per-geometry origin (geoseries.rs:85-139,163-174; TransformOrigin of
+ * py-geopolars/src/utils.rs:5-27 = centroid | bbox center | point) reduce to one affine matrix PER ROW:
+ * matrices[6*n_geoms] in the same [a, b, xoff, d, e, yoff] order, living in `out_space`. */
+int32_t gpk_affine_transform_rows(const gpk_geoarray* a, const double* matrices, double* out_xy,
+                                  int32_t out_space, void* stream);
 /* convex_hull: geoseries.rs:23-26,196-198.  Output = POLYGON array, one closed CCW ring per geometry.
  * out_ring_offsets[n_geoms+1]; out_xy capacity must be >= 2*(n_coords + n_geoms) doubles. */
 int32_t gpk_convex_hull(const gpk_geoarray* a, double* out_xy, int32_t* out_ring_offsets,

@@ -184,3 +184,49 @@ def test_centroid_polygon_fully_covered_by_hole(gpk, oracle):
     exp, _ = oracle.centroid(a)
     _close(GeoSeries(a).centroid().array.xy, exp)
     assert exp.tolist() == [[2.0, 2.0], [2.0, 2.0]]
+
+
+def _affine_rows_reference(a: GeoArrowArray, mats: np.ndarray, oracle) -> np.ndarray:
+    """row-by-row application of the oracle's affine (bit-exact reference for per-geometry matrices)"""
+    from geopolars_amd.dist import slice_rows
+
+    out = np.empty_like(a.xy)
+    w = 0
+    for g in range(len(a)):
+        row = slice_rows(a, g, g + 1)
+        out[w : w + row.n_coords] = oracle.affine_transform(row, mats[g])
+        w += row.n_coords
+    return out
+
+
+@pytest.mark.parametrize("name", ["holes", "multipoly", "lines"])
+@pytest.mark.parametrize("origin", ["center", "centroid", (3.0, -2.0)])
+def test_rotate_scale_skew_per_geometry_origin(gpk, oracle, name, origin):
+    """geoseries.rs:85-139: rotate / scale / skew about centroid | bbox center | point == one affine matrix per row."""
+    import math
+
+    a = _arrays()[name]
+    if name == "multipoly":
+        from geopolars_amd.dist import slice_rows
+
+        a = slice_rows(a, 0, 200)
+    if name == "holes":  # drop the empty polygon: its origin is undefined (NaN) in both implementations
+        a = GeoArrowArray.from_polygons([[[(0, 0), (10, 0), (10, 10), (0, 10)], [(2, 2), (2, 8), (8, 8), (8, 2)]], [[(0, 0), (0, 5), (5, 5), (5, 0)]]])
+    s = GeoSeries(a)
+    if origin == "center":
+        b = oracle.bounds(a)
+        o = np.stack([(b[:, 0] + b[:, 2]) / 2.0, (b[:, 1] + b[:, 3]) / 2.0], axis=1)
+    elif origin == "centroid":
+        o = s.centroid().array.xy  # the GPU centroid itself is checked elsewhere; matrices must match bit for bit
+    else:
+        o = np.tile(np.array([origin], dtype=np.float64), (len(a), 1))
+    z = np.zeros(len(a))
+    t = math.radians(30.0)
+    c, sn = math.cos(t), math.sin(t)
+    rot = np.stack([z + c, z - sn, o[:, 0] - c * o[:, 0] + sn * o[:, 1], z + sn, z + c, o[:, 1] - sn * o[:, 0] - c * o[:, 1]], axis=1)
+    assert np.array_equal(s.rotate(30.0, origin).array.xy, _affine_rows_reference(a, rot, oracle))
+    sc = np.stack([z + 2.0, z, o[:, 0] * (1 - 2.0), z, z + 0.5, o[:, 1] * (1 - 0.5)], axis=1)
+    assert np.array_equal(s.scale(2.0, 0.5, origin).array.xy, _affine_rows_reference(a, sc, oracle))
+    tx, ty = math.tan(math.radians(10.0)), math.tan(math.radians(-5.0))
+    sk = np.stack([z + 1.0, z + tx, -o[:, 1] * tx, z + ty, z + 1.0, -o[:, 0] * ty], axis=1)
+    assert np.array_equal(s.skew(10.0, -5.0, origin).array.xy, _affine_rows_reference(a, sk, oracle))
