@@ -79,6 +79,8 @@ _PROTOS = {
     "gpk_geoarray_free": (C.c_int32, [_VP]),
     "gpk_geoarray_nbytes": (C.c_int32, [_VP, C.POINTER(C.c_int64)]),
     "gpk_wkb_decode": (C.c_int32, [_VP, _VP, C.c_int64, _VP, C.POINTER(C.c_int64), _VP, _VP, _VP, _VP]),
+    "gpk_geoarray_from_wkb": (C.c_int32, [_VP, _VP, C.c_int64, _VP, C.c_int32, _VP, C.POINTER(_VP), C.POINTER(C.c_int32)]),
+    "gpk_geoarray_download": (C.c_int32, [_VP, C.POINTER(C.c_int64), _VP, _VP, _VP, _VP, _VP]),
     "gpk_area": (C.c_int32, [_VP, _VP, C.c_int32, _VP]),
     "gpk_signed_area": (C.c_int32, [_VP, _VP, C.c_int32, _VP]),
     "gpk_centroid": (C.c_int32, [_VP, _VP, _VP, C.c_int32, _VP]),

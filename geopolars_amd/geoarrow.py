@@ -262,6 +262,41 @@ class DeviceGeoArray:
         _abi.check(_abi.lib().gpk_geoarray_upload(C.byref(d), stream, C.byref(out)))
         return DeviceGeoArray(out.value, geom_type, int(d.n_geoms), int(d.n_coords), keepalive=tensors)
 
+    @staticmethod
+    def from_wkb(values: np.ndarray, offsets: np.ndarray, validity: Optional[np.ndarray] = None, stream: int = 0) -> "DeviceGeoArray":
+        """Arrow BinaryArray<i32> of WKB (host buffers) -> device-resident GeoArrow, decoded ON the GPU
+        (gpk_geoarray_from_wkb): only the raw WKB bytes cross PCIe."""
+        values = np.ascontiguousarray(values, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        n = len(offsets) - 1
+        out = C.c_void_p()
+        gt = C.c_int32(-1)
+        _abi.check(
+            _abi.lib().gpk_geoarray_from_wkb(
+                values.ctypes.data if len(values) else None, offsets.ctypes.data, n, _ptr(validity) if validity is not None else None, _abi.MEM_HOST, stream, C.byref(out), C.byref(gt)
+            )
+        )
+        self = DeviceGeoArray(out.value, int(gt.value), n, -1)
+        sizes = (C.c_int64 * 4)()
+        _abi.check(_abi.lib().gpk_geoarray_download(self.handle, sizes, None, None, None, None, stream))
+        self.n_coords = int(sizes[0])
+        self._validity = None if validity is None else np.ascontiguousarray(validity, dtype=np.uint8)
+        return self
+
+    def download(self, stream: int = 0) -> GeoArrowArray:
+        """Copy the device buffers back as a host GeoArrowArray."""
+        lib = _abi.lib()
+        sizes = (C.c_int64 * 4)()
+        _abi.check(lib.gpk_geoarray_download(self.handle, sizes, None, None, None, None, stream))
+        n_coords, n_parts, n_rings, n_geoms = (int(v) for v in sizes)
+        gt = self.geom_type
+        xy = np.empty((n_coords, 2), dtype=np.float64)
+        go = np.empty(n_geoms + 1, dtype=np.int32) if gt != GEOM_POINT else None
+        po = np.empty(n_parts + 1, dtype=np.int32) if gt == GEOM_MULTIPOLYGON else None
+        ro = np.empty(n_rings + 1, dtype=np.int32) if gt in (GEOM_POLYGON, GEOM_MULTILINESTRING, GEOM_MULTIPOLYGON) else None
+        _abi.check(lib.gpk_geoarray_download(self.handle, sizes, xy.ctypes.data if n_coords else None, _ptr(go), _ptr(po), _ptr(ro), stream))
+        return GeoArrowArray(gt, xy, geom_offsets=go, part_offsets=po, ring_offsets=ro, validity=getattr(self, "_validity", None), n_geoms=n_geoms)
+
     def nbytes(self) -> int:
         n = C.c_int64(0)
         _abi.check(_abi.lib().gpk_geoarray_nbytes(self.handle, C.byref(n)))

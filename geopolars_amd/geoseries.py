@@ -37,10 +37,17 @@ TransformOrigin = Union[str, tuple]
 
 
 class GeoSeries:
-    def __init__(self, array: GeoArrowArray, name: str = "geometry"):
-        self.array = array
+    def __init__(self, array: Optional[GeoArrowArray], name: str = "geometry", device: Optional[DeviceGeoArray] = None):
+        self._array = array
         self.name = name  # output column name is always "geometry" (util.rs:22,43,52)
-        self._dev: Optional[DeviceGeoArray] = None
+        self._dev: Optional[DeviceGeoArray] = device
+
+    @property
+    def array(self) -> GeoArrowArray:
+        """Host GeoArrow buffers; a series decoded on the GPU downloads them on first use."""
+        if self._array is None:
+            self._array = self._dev.download()
+        return self._array
 
     # ---- construction --------------------------------------------------------------------------
     @staticmethod
@@ -48,11 +55,16 @@ class GeoSeries:
         return GeoSeries(GeoArrowArray.from_arrow_wkb(column))
 
     @staticmethod
+    def from_wkb_device(values, offsets, validity=None) -> "GeoSeries":
+        """WKB column decoded on the GPU: only the raw bytes are uploaded (gpk_geoarray_from_wkb)."""
+        return GeoSeries(None, device=DeviceGeoArray.from_wkb(values, offsets, validity))
+
+    @staticmethod
     def from_points(xy) -> "GeoSeries":
         return GeoSeries(GeoArrowArray.from_points(xy))
 
     def __len__(self) -> int:
-        return len(self.array)
+        return self._dev.n_geoms if self._array is None else len(self._array)
 
     def device(self) -> DeviceGeoArray:
         """Upload on first use ("copied once to HBM"); later operators reuse the resident copy."""

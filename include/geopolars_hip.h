@@ -114,6 +114,18 @@ int32_t gpk_wkb_decode(const uint8_t* wkb_values, const int32_t* wkb_offsets, in
                        const uint8_t* validity, int64_t counts[5], double* xy,
                        int32_t* geom_offsets, int32_t* part_offsets, int32_t* ring_offsets);
 
+/* The same decode on the GPU: the raw WKB column (values + offsets, in `mem_space`) is copied to HBM once and
+ * decoded there into a device-resident handle (scan -> prefix sums -> fill); the GeoArrow SoA never exists on
+ * the host.  Little-endian ISO WKB / EWKB+SRID, 2D, types 1-6, same promotion rules as gpk_wkb_decode;
+ * big-endian or Z/M input is reported (GPK_ERR_MISMATCHED_GEOMETRY) so the caller can use the host decoder. */
+int32_t gpk_geoarray_from_wkb(const uint8_t* wkb_values, const int32_t* wkb_offsets, int64_t n_rows,
+                              const uint8_t* validity, int32_t mem_space, void* stream,
+                              gpk_geoarray** out, int32_t* out_geom_type);
+/* Device -> host copy of a handle's GeoArrow buffers.  sizes[4] = {n_coords, n_parts, n_rings, n_geoms} is always
+ * filled; NULL buffers are skipped (call once with NULLs to size the buffers). */
+int32_t gpk_geoarray_download(const gpk_geoarray* a, int64_t sizes[4], double* xy, int32_t* geom_offsets,
+                              int32_t* part_offsets, int32_t* ring_offsets, void* stream);
+
 /* ---- unary operators: GeoSeries::{area, centroid, envelope/bounds, affine_transform, ...} --- */
 /* out arrays live in `out_space`; sizes are in elements.                                      */
 /* area: geoseries.rs:14-16,188-190.  out[n_geoms] */

@@ -1,0 +1,93 @@
+"""Device-side WKB decoding (gpk_geoarray_from_wkb) vs the host decoder and vs the arrays the WKB was made from."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from geopolars_amd import _abi, synth
+from geopolars_amd.geoarrow import DeviceGeoArray, GeoArrowArray
+from geopolars_amd.geoseries import GeoSeries
+from tests.wkb_util import encode_wkb
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def same(a: GeoArrowArray, b: GeoArrowArray):
+    assert a.geom_type == b.geom_type and len(a) == len(b)
+    assert np.array_equal(a.xy, b.xy, equal_nan=True)
+    for k in ("geom_offsets", "part_offsets", "ring_offsets"):
+        x, y = getattr(a, k), getattr(b, k)
+        assert (x is None) == (y is None), k
+        if x is not None:
+            assert np.array_equal(x, y), k
+
+
+@pytest.mark.parametrize("name", ["cities", "naturalearth_cities", "naturalearth_lowres", "nybb"])
+def test_fixture_columns_device_equals_host(gpk, name):
+    z = np.load(os.path.join(GOLD, f"{name}.npz"))
+    host = GeoArrowArray.from_wkb(z["wkb_values"], z["wkb_offsets"])
+    dev = DeviceGeoArray.from_wkb(z["wkb_values"], z["wkb_offsets"])
+    same(dev.download(), host)
+
+
+@pytest.mark.parametrize(
+    "make",
+    [
+        lambda: synth.uniform_points(200_000),
+        lambda: synth.random_linestrings(20_000),
+        lambda: synth.star_polygons(30_000, 17),
+        lambda: synth.powerlaw_multipolygons(20_000),
+    ],
+)
+def test_synthetic_roundtrip(gpk, make):
+    a = make()
+    values, offsets = encode_wkb(a)
+    dev = DeviceGeoArray.from_wkb(values, offsets)
+    same(dev.download(), a)
+    same(GeoArrowArray.from_wkb(values, offsets), a)
+
+
+def test_mixed_polygon_multipolygon_is_promoted(gpk):
+    a = synth.powerlaw_multipolygons(5000, seed=9)
+    single = np.diff(a.geom_offsets) == 1
+    values, offsets = encode_wkb(a, multi_rows=~single)  # single-part rows written as plain Polygon
+    assert single.any() and (~single).any()
+    same(DeviceGeoArray.from_wkb(values, offsets).download(), a)
+
+
+def test_nulls_multipoints_and_operators_on_a_device_decoded_series(gpk, oracle):
+    polys = synth.star_polygons(999, 12)
+    keep = np.ones(len(polys), np.uint8)
+    keep[::7] = 0
+    validity = np.packbits(keep, bitorder="little")
+    pn = GeoArrowArray(polys.geom_type, polys.xy, polys.geom_offsets, ring_offsets=polys.ring_offsets, validity=validity)
+    values, offsets = encode_wkb(pn)
+    s = GeoSeries.from_wkb_device(values, offsets, validity)
+    host = GeoArrowArray.from_wkb(values, offsets, validity)
+    assert len(s) == 999
+    exp = oracle.area(host)
+    got = s.area()  # runs on the handle that was decoded on the device
+    assert np.array_equal(np.isnan(got), np.isnan(exp)) and np.allclose(got[keep == 1], exp[keep == 1], rtol=1e-9)
+    same(s.array, host)
+    mp = GeoArrowArray(_abi.GEOM_MULTIPOINT, np.arange(20.0).reshape(10, 2), geom_offsets=np.array([0, 3, 3, 10], np.int32))
+    values, offsets = encode_wkb(mp)
+    same(DeviceGeoArray.from_wkb(values, offsets).download(), mp)
+
+
+def test_unsupported_input_is_reported(gpk):
+    be = struct.pack(">BIdd", 0, 1, 1.0, 2.0)
+    with pytest.raises(_abi.MismatchedGeometry):
+        DeviceGeoArray.from_wkb(np.frombuffer(be, np.uint8), np.array([0, len(be)], np.int32))
+    z = struct.pack("<BIddd", 1, 1001, 0, 0, 0)
+    with pytest.raises(_abi.MismatchedGeometry):
+        DeviceGeoArray.from_wkb(np.frombuffer(z, np.uint8), np.array([0, len(z)], np.int32))
+    pt = struct.pack("<BIdd", 1, 1, 1.0, 2.0)
+    ls = struct.pack("<BII", 1, 2, 1) + struct.pack("<dd", 0, 0)
+    with pytest.raises(_abi.MismatchedGeometry):
+        DeviceGeoArray.from_wkb(np.frombuffer(pt + ls, np.uint8), np.array([0, len(pt), len(pt) + len(ls)], np.int32))
+    with pytest.raises(_abi.MismatchedGeometry):
+        DeviceGeoArray.from_wkb(np.frombuffer(pt[:-3], np.uint8), np.array([0, len(pt) - 3], np.int32))
+    empty = DeviceGeoArray.from_wkb(np.zeros(0, np.uint8), np.zeros(1, np.int32))
+    assert empty.n_geoms == 0
