@@ -13,6 +13,7 @@
 
 #include "gpk_device.h"
 #include "gpk_polypoly.h"
+#include "gpk_scan.h"
 
 namespace gpk {
 
@@ -316,6 +317,161 @@ __global__ __launch_bounds__(256) void distance_kernel(DevGeo pts, DevGeo other,
     }
 }
 
+// ---- distance, rows grouped by target (point x LINESTRING with a row map) ------------------------------
+// When many rows point at the same linestring (C3: 10M rows -> 100k linestrings) the row-major kernel above
+// re-reads every linestring ~100 times from L2/MALL (10 GB of gather traffic for 98 MB of coordinates) and
+// spends lanes on per-row reductions.  Grouped: a counting sort orders the rows by target; one WAVE owns one
+// target, stages its vertices in LDS once, and every lane walks the segments for its own point (LDS broadcast
+// reads, no cross-lane reduction).  Which lane handles which row depends on atomic order; the value written
+// for a row does not.
+// Both passes aggregate equal keys inside a wave before touching memory (clustered row maps put many rows of
+// one target in the same wave: 64 same-address atomics would serialise): up to two rounds of "lanes that share
+// the first remaining lane's key go together", the rest falls back to one atomic per lane.
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void dist_sort_kernel(const uint32_t* __restrict__ rows, int64_t n, int32_t* __restrict__ counter,
+                                                        uint32_t* __restrict__ perm) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bool todo = i < n;
+    const uint32_t key = todo ? rows[i] : 0u;
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        const unsigned long long rest = __ballot(todo);
+        if (!rest) break;
+        const int leader = __ffsll((long long)rest) - 1;
+        const uint32_t lkey = __shfl(key, leader, 64);
+        const bool mine = todo && key == lkey;
+        const unsigned long long same = __ballot(mine);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&counter[lkey], (int)__popcll(same));
+        base = __shfl(base, leader, 64);
+        if (mine) {
+            if (SCATTER) perm[base + (int)__popcll(same & ((1ull << lane) - 1ull))] = (uint32_t)i;
+            todo = false;
+        }
+    }
+    if (todo) {
+        const int slot = atomicAdd(&counter[key], 1);
+        if (SCATTER) perm[slot] = (uint32_t)i;
+    }
+}
+
+__global__ void dist_batches_kernel(const int32_t* __restrict__ cnt, int64_t L, int32_t* __restrict__ nb) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < L) nb[t] = (cnt[t] + 63) >> 6;
+}
+
+// squared distance to one segment with the start-point terms carried from the previous segment (|p - a|^2 of
+// this segment is |p - b|^2 of the last one).  Explicit fma: this kernel's results only need the 1e-9 contract;
+// the zero / non-zero outcome is decided separately by the exact re-walk below.
+struct SegState {
+    double ax, ay, qx, qy, na2;  // vertex a, p - a, |p - a|^2
+};
+__device__ __forceinline__ void seg_step(SegState& st, double2 b, double px, double py, Frac& best, int& maybe) {
+    const double rx = px - b.x, ry = py - b.y;
+    const double nb2 = __builtin_fma(rx, rx, ry * ry);
+    const double dx = b.x - st.ax, dy = b.y - st.ay;
+    const double d2 = __builtin_fma(dx, dx, dy * dy);
+    const double dot = __builtin_fma(st.qx, dx, st.qy * dy);
+    const double cross = __builtin_fma(st.qx, dy, -(st.qy * dx));
+    Frac c;
+    const bool at_a = d2 == 0.0 || dot <= 0.0, at_b = dot >= d2;
+    c.num = at_a ? st.na2 : (at_b ? nb2 : cross * cross);
+    c.den = (at_a || at_b) ? 1.0 : d2;
+    if (frac_less(c, best)) best = c;
+    // candidates for upstream's "point is on the linestring" short-circuit: a vertex hit, or |tx - ty| within reach
+    // of f64::EPSILON (tx - ty == cross / (dx dy)); everything else is certainly not on the segment
+    maybe |= (int)(st.na2 == 0.0 || nb2 == 0.0 || fabs(cross) <= 1.7763568394002505e-15 * fabs(dx * dy));
+    st.ax = b.x;
+    st.ay = b.y;
+    st.qx = rx;
+    st.qy = ry;
+    st.na2 = nb2;
+}
+
+constexpr int DG_CHUNK = 256;  // vertices staged per wave (4 KB: keeps ~10 work-groups per CU resident); longer linestrings are streamed in passes
+__global__ __launch_bounds__(256) void distance_grouped_kernel(DevGeo pts, DevGeo ls, const int32_t* __restrict__ off,
+                                                               const int32_t* __restrict__ item_off,
+                                                               const uint32_t* __restrict__ perm, double* __restrict__ out) {
+    __shared__ double2 s_xy[4][DG_CHUNK + 1];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double2* sv = s_xy[wave];
+    const int64_t L = ls.n_geoms;
+    const int64_t n_items = item_off[L];
+    // one work item = (target, batch of 64 rows of that target)
+    for (int64_t it = (int64_t)blockIdx.x * 4 + wave; it < n_items; it += (int64_t)gridDim.x * 4) {
+        int64_t lo = 0, hi = L;  // largest t with item_off[t] <= it
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)item_off[mid] <= it)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const int64_t t = lo;
+        const int r = off[t] + (int)(it - item_off[t]) * 64 + lane;
+        const bool active = r < off[t + 1];
+        const int c0 = ls.geom_off[t], nv = ls.geom_off[t + 1] - c0;
+        const uint32_t i = active ? perm[r] : 0u;
+        double2 p = make_double2(NAN, NAN);
+        if (active && dev::valid_row(pts.validity, i)) p = pts.xy[i];
+        Frac best{INFINITY, 1.0};
+        int maybe = 0;
+        SegState st{0, 0, 0, 0, 0};
+        for (int cb = 0; cb < nv; cb += DG_CHUNK) {  // one pass unless the linestring exceeds DG_CHUNK + 1 vertices
+            const int m = nv - cb < DG_CHUNK + 1 ? nv - cb : DG_CHUNK + 1;
+            __builtin_amdgcn_wave_barrier();
+            for (int k = lane; k < m; k += 64) sv[k] = ls.xy[c0 + cb + k];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (cb == 0) {
+                const double2 a = sv[0];
+                st.ax = a.x;
+                st.ay = a.y;
+                st.qx = p.x - a.x;
+                st.qy = p.y - a.y;
+                st.na2 = __builtin_fma(st.qx, st.qx, st.qy * st.qy);
+                if (nv == 1) maybe |= (int)(st.na2 == 0.0);
+            }
+#pragma unroll 4
+            for (int k = 1; k < m; ++k) seg_step(st, sv[k], p.x, p.y, best, maybe);
+        }
+        // exact replay of line_string_contains_point for the (rare) lanes that came close
+        int eps_hit = 0;
+        if (__any(maybe)) {
+            if (nv <= DG_CHUNK + 1) {
+                if (maybe) {
+                    if (nv == 1) eps_hit = (int)(sv[0].x == p.x && sv[0].y == p.y);
+                    for (int k = 0; k + 1 < nv && !eps_hit; ++k) {
+                        const double2 a = sv[k], b = sv[k + 1];
+                        const double cr = (p.x - a.x) * (b.y - a.y) - (p.y - a.y) * (b.x - a.x);
+                        eps_hit = (int)((a.x == p.x && a.y == p.y) || (b.x == p.x && b.y == p.y) ||
+                                        segment_contains_eps(p.x, p.y, a.x, a.y, b.x, b.y, cr, (b.x - a.x) * (b.y - a.y)));
+                    }
+                }
+            } else if (maybe) {  // streamed linestring: replay from global memory
+                for (int k = 0; k + 1 < nv && !eps_hit; ++k) {
+                    const double2 a = ls.xy[c0 + k], b = ls.xy[c0 + k + 1];
+                    const double cr = (p.x - a.x) * (b.y - a.y) - (p.y - a.y) * (b.x - a.x);
+                    eps_hit = (int)((a.x == p.x && a.y == p.y) || (b.x == p.x && b.y == p.y) ||
+                                    segment_contains_eps(p.x, p.y, a.x, a.y, b.x, b.y, cr, (b.x - a.x) * (b.y - a.y)));
+                }
+            }
+        }
+        if (active) {
+            double d;
+            if (!dev::valid_row(ls.validity, t) || isnan(p.x) || isnan(p.y))
+                d = NAN;
+            else if (nv == 0 || eps_hit)
+                d = 0.0;
+            else
+                d = frac_sqrt(best);
+            out[i] = d;
+        }
+    }
+}
+
 // ---- row-wise predicates: point x polygonal (cooperative), everything else one lane per row -------------
 template <int G>
 __global__ __launch_bounds__(256) void point_poly_predicate_kernel(DevGeo pts, DevGeo polys,
@@ -419,6 +575,46 @@ int32_t gpk_distance_rowwise(const gpk_geoarray* a, const gpk_geoarray* b, const
             GPK_HIP(hipMemcpyAsync(r, b_rows, sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice, s));
             rows_dev = r;
         }
+    }
+    // many rows per linestring: group the rows by target and stage each linestring in LDS once
+    if (b_rows && other->d.type == GPK_GEOM_LINESTRING && other->d.n_geoms > 0 && n >= 8 * other->d.n_geoms) {
+        const int64_t L = other->d.n_geoms;
+        void* tmp = nullptr;  // off | cursor | cnt | batches | item_off (L+1 each) | perm (n) | scan totals
+        const size_t ib = align256(sizeof(int32_t) * (size_t)(L + 1));
+        const size_t total = 5 * ib + align256(sizeof(uint32_t) * (size_t)n) + align256(sizeof(unsigned long long) * (size_t)((L + 255) / 256 + 4));
+        GPK_HIP(hipMalloc(&tmp, total));
+        auto fin = [&](int32_t rc) {
+            (void)hipStreamSynchronize(s);
+            (void)hipFree(tmp);
+            return rc;
+        };
+        char* base = (char*)tmp;
+        int32_t* g_off = (int32_t*)base;
+        int32_t* g_cur = (int32_t*)(base + ib);
+        int32_t* g_cnt = (int32_t*)(base + 2 * ib);
+        int32_t* g_nb = (int32_t*)(base + 3 * ib);
+        int32_t* g_item = (int32_t*)(base + 4 * ib);
+        uint32_t* perm = (uint32_t*)(base + 5 * ib);
+        unsigned long long* btot = (unsigned long long*)(base + 5 * ib + align256(sizeof(uint32_t) * (size_t)n));
+        auto run = [&]() -> int32_t {
+            GPK_HIP(hipMemsetAsync(g_cnt, 0, sizeof(int32_t) * (size_t)(L + 1), s));
+            const dim3 rg((unsigned)((n + 255) / 256));
+            GPK_LAUNCH("gpk_dist_hist", dist_sort_kernel<false>, rg, dim3(256), 0, s, rows_dev, n, g_cnt, (uint32_t*)nullptr);
+            GPK_TRY(exclusive_scan_i32(g_cnt, L, g_off, g_cur, btot, s));
+            GPK_LAUNCH("gpk_dist_batches", dist_batches_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, s, (const int32_t*)g_cnt, L, g_nb);
+            GPK_TRY(exclusive_scan_i32(g_nb, L, g_item, nullptr, btot, s));
+            GPK_LAUNCH("gpk_dist_scatter", dist_sort_kernel<true>, rg, dim3(256), 0, s, rows_dev, n, g_cur, perm);
+            int64_t blocks = (n / 64 + L + 3) / 4;  // upper bound on the number of (target, 64-row batch) items
+            const int64_t cap = (int64_t)cu_count() * 16;
+            if (blocks > cap) blocks = cap;
+            GPK_LAUNCH("gpk_distance_grouped", distance_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pts->d, other->d,
+                       (const int32_t*)g_off, (const int32_t*)g_item, (const uint32_t*)perm, out_dev);
+            return GPK_OK;
+        };
+        const int32_t rc = run();
+        if (rc != GPK_OK) return fin(rc);
+        const int32_t rc2 = copy_out(out, out_space, out_dev, ob, s);
+        return fin(rc2);
     }
     int G = other->d.type == GPK_GEOM_POINT ? 1 : pick_group_rows(other->d);
     G = G <= 1 ? 1 : (G <= 8 ? 8 : 32);  // instantiated group sizes

@@ -13,4 +13,11 @@ out = torch.empty(npts, dtype=torch.float64, device=dev)
 for label, rows in (("i mod 100000", np.arange(npts) % nls), ("i mod 1000 (L2-resident)", np.arange(npts) % 1000), ("i // 100 (each linestring 100 consecutive rows)", np.arange(npts) // 100)):
     r = torch.from_numpy(rows.astype(np.int32)).to(dev)
     ms, k = timed(lib, lambda s: _abi.check(lib.gpk_distance_rowwise(dp.handle, dl.handle, r.data_ptr(), out.data_ptr(), _abi.MEM_DEVICE, s)), reps=5)
-    print(label, round(ms, 3), "ms")
+    lib.gpk_profile_enable(1)
+    _abi.check(lib.gpk_distance_rowwise(dp.handle, dl.handle, r.data_ptr(), out.data_ptr(), _abi.MEM_DEVICE, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize(); lib.gpk_profile_enable(0)
+    parts = {}
+    for name in (b"gpk_dist_hist", b"gpk_dist_scatter", b"gpk_dist_batches", b"gpk_scan", b"gpk_distance_grouped", b"gpk_distance"):
+        m, c = C.c_double(0), C.c_int64(0); lib.gpk_profile_query(name, C.byref(m), C.byref(c)); parts[name.decode()] = round(m.value, 3)
+    lib.gpk_profile_reset()
+    print(label, round(ms, 3), "ms (sum of kernels)", parts)
