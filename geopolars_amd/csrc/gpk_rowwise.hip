@@ -500,14 +500,19 @@ __global__ __launch_bounds__(256) void point_poly_predicate_kernel(DevGeo pts, D
     }
 }
 
+// row-wise intersects(polygon, polygon): 16 lanes per row (gpk_polypoly.h, same routine as the join's refine)
+constexpr int PP_GS = 16;
 __global__ __launch_bounds__(256) void poly_poly_intersects_kernel(DevGeo a, DevGeo b, const uint32_t* __restrict__ rows,
                                                                     uint8_t* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n_geoms) return;
-    const int64_t j = rows ? (int64_t)rows[i] : i;
-    bool hit = false;
-    if (dev::valid_row(a.validity, i) && dev::valid_row(b.validity, j)) hit = polygonal_intersects_polygonal(a, i, b, j);
-    out[i] = hit;
+    const int lane = threadIdx.x & (PP_GS - 1);
+    const int64_t groups = (int64_t)gridDim.x * (256 / PP_GS);
+    for (int64_t i = (int64_t)blockIdx.x * (256 / PP_GS) + threadIdx.x / PP_GS; i < a.n_geoms; i += groups) {
+        const int64_t j = rows ? (int64_t)rows[i] : i;
+        bool hit = false;
+        if (dev::valid_row(a.validity, i) && dev::valid_row(b.validity, j))
+            hit = polygonal_intersects_polygonal_group<PP_GS>(a, i, b, j, lane);
+        if (lane == 0) out[i] = hit;
+    }
 }
 
 __global__ void point_point_equal_kernel(DevGeo a, DevGeo b, const uint32_t* __restrict__ rows, uint8_t* __restrict__ out) {
@@ -706,7 +711,7 @@ int32_t gpk_predicate_rowwise(const gpk_geoarray* a, const gpk_geoarray* b, cons
         }
 #undef PP
     } else if (predicate == GPK_PRED_INTERSECTS && is_polygonal(ta) && is_polygonal(tb)) {
-        GPK_LAUNCH("gpk_poly_poly_intersects", poly_poly_intersects_kernel, flat, block, 0, s, a->d, b->d, rows_dev, out_dev);
+        GPK_LAUNCH("gpk_poly_poly_intersects", poly_poly_intersects_kernel, coop_grid(n, PP_GS), block, 0, s, a->d, b->d, rows_dev, out_dev);
     } else if (ta == GPK_GEOM_POINT && tb == GPK_GEOM_POINT) {
         GPK_LAUNCH("gpk_point_point_equal", point_point_equal_kernel, flat, block, 0, s, a->d, b->d, rows_dev, out_dev);
     } else if ((predicate == GPK_PRED_CONTAINS && is_polygonal(ta) && is_polygonal(tb)) ||
