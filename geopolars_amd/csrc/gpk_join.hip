@@ -178,8 +178,11 @@ struct QEntry {  // 32 bytes: one queued (point, part) pair with its exterior sl
 //            dense in the only expensive part of the kernel.
 //   finalize: rows with exactly one part hit map part -> geometry; rows with several hits (overlapping
 //            polygons / multipolygon parts) are recomputed by the generic walk so that counts are per geometry.
+#ifndef GPK_PIP_MINWAVES
+#define GPK_PIP_MINWAVES 1
+#endif
 template <bool RASTER>
-__global__ __launch_bounds__(PIP_BLOCK) void pip_tile_kernel(DevGeo pts, DevGeo polys, IndexView ix, PipView pv,
+__global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(DevGeo pts, DevGeo polys, IndexView ix, PipView pv,
                                                               uint32_t* __restrict__ counts,
                                                               uint32_t* __restrict__ code,
                                                               unsigned long long* __restrict__ block_tot,

@@ -107,6 +107,28 @@ class GeoSeries:
         idx = np.concatenate([np.arange(s, e) for s, e in zip(starts, ends)]) if len(self) else np.zeros(0, int)
         return GeoSeries(GeoArrowArray(GEOM_LINESTRING, a.xy[idx.astype(np.int64)], geom_offsets=off))
 
+    def is_ring(self) -> np.ndarray:
+        """geoseries.rs:75-81: True for features that are closed (first coordinate == last); LineStrings only."""
+        self._require(GEOM_LINESTRING, "is_ring")
+        a = self.array
+        o = a.geom_offsets
+        n = np.diff(o)
+        first = a.xy[np.minimum(o[:-1], max(a.n_coords - 1, 0))] if a.n_coords else np.zeros((len(self), 2))
+        last = a.xy[np.maximum(o[1:] - 1, 0)] if a.n_coords else np.zeros((len(self), 2))
+        return (n > 0) & np.all(first == last, axis=1)
+
+    def explode(self) -> "GeoSeries":
+        """geoseries.rs:49-50: multi-part geometries -> one row per part (pure offset surgery: the coordinate
+        buffer is shared, benches/explode.rs explodes 45,000 two-point MultiPoints this way)."""
+        a = self.array
+        if a.geom_type == GEOM_MULTIPOINT:
+            return GeoSeries(GeoArrowArray.from_points(a.xy))
+        if a.geom_type == GEOM_MULTILINESTRING:
+            return GeoSeries(GeoArrowArray(GEOM_LINESTRING, a.xy, geom_offsets=a.ring_offsets))
+        if a.geom_type == GEOM_MULTIPOLYGON:
+            return GeoSeries(GeoArrowArray(GEOM_POLYGON, a.xy, geom_offsets=a.part_offsets, ring_offsets=a.ring_offsets))
+        return GeoSeries(a)
+
     def _require(self, t: int, op: str) -> None:
         if self.array.geom_type != t:
             raise _abi.MismatchedGeometry(

@@ -125,3 +125,55 @@ def test_polygon_contains_polygon_is_reported_unsupported(gpk):
     a = GeoSeries(synth.clustered_polygons(10, seed=1))
     with pytest.raises(_abi.MismatchedGeometry):
         join_pairs(a, a, "contains")
+
+
+def test_count_only_and_capacity_contract(gpk, oracle):
+    """C ABI contract of gpk_spatial_join: count-only calls (no pair buffer) and a too-small pair buffer
+    (GPK_ERR_CAPACITY with the exact total reported, the first `capacity` pairs written)."""
+    import ctypes as C
+
+    from geopolars_amd import _abi
+    from geopolars_amd._abi import MEM_HOST, PREDICATES
+
+    polys = GeoSeries(synth.star_polygons(50, 16))
+    pts = GeoSeries(synth.uniform_points(30_000))
+    exp_pairs, exp_counts, _ = oracle.spatial_join(pts.array, polys.array, "intersects", mode=1)
+    lib = _abi.lib()
+    n_pairs = C.c_int64(-1)
+    counts = np.empty(len(pts), dtype=np.uint32)
+    rc = lib.gpk_spatial_join(pts.device().handle, polys.device().handle, None, PREDICATES["intersects"], 0, counts.ctypes.data, None, 0, C.byref(n_pairs), MEM_HOST, None)
+    assert rc == _abi.GPK_OK and n_pairs.value == len(exp_pairs) and np.array_equal(counts, exp_counts)
+    rc = lib.gpk_spatial_join(pts.device().handle, polys.device().handle, None, PREDICATES["intersects"], 0, None, None, 0, C.byref(n_pairs), MEM_HOST, None)
+    assert rc == _abi.GPK_OK and n_pairs.value == len(exp_pairs)
+    cap = len(exp_pairs) // 2
+    small = np.zeros((cap, 2), dtype=np.uint32)
+    rc = lib.gpk_spatial_join(pts.device().handle, polys.device().handle, None, PREDICATES["intersects"], 0, None, small.ctypes.data, cap, C.byref(n_pairs), MEM_HOST, None)
+    assert rc == _abi.GPK_ERR_CAPACITY and n_pairs.value == len(exp_pairs)
+    assert "capacity" in _abi.last_error()
+    assert np.array_equal(small, exp_pairs[:cap])
+    rc = lib.gpk_spatial_join(pts.device().handle, polys.device().handle, None, 99, 0, None, None, 0, C.byref(n_pairs), MEM_HOST, None)
+    assert rc == _abi.GPK_ERR_INVALID_ARGUMENT
+
+
+def test_join_from_threads(gpk, oracle):
+    """the ABI is re-entrant: per-thread scratch arenas, shared immutable handles (like Arc<SpatialIndex>)."""
+    import threading
+
+    polys = GeoSeries(synth.star_polygons(80, 20))
+    idx = SpatialIndex(polys)
+    sets = [synth.uniform_points(20_000, seed=100 + k) for k in range(4)]
+    expected = [oracle.spatial_join(p, polys.array, "intersects", mode=1)[0] for p in sets]
+    results = [None] * 4
+
+    def work(k):
+        s = GeoSeries(sets[k])
+        for _ in range(3):
+            results[k] = join_pairs(s, polys, "intersects", r_index=idx)[0]
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k in range(4):
+        assert np.array_equal(results[k], expected[k])

@@ -187,3 +187,13 @@ def test_geoseries_structural_accessors():
         s.x()
     arr = polys.to_pyarrow()
     assert len(arr) == 3 and arr[0].as_py()[0][0] == [0.0, 0.0]
+
+
+def test_explode_and_is_ring_structural():
+    mp = GeoArrowArray.from_multipolygons([[[[(0, 0), (1, 0), (0, 1)]], [[(5, 5), (6, 5), (5, 6)]]], [[[(2, 2), (3, 2), (2, 3)]]]])
+    ex = GeoSeries(mp).explode().array
+    assert ex.geom_type == _abi.GEOM_POLYGON and len(ex) == 3 and ex.ring_offsets.tolist() == [0, 4, 8, 12]
+    pts = GeoArrowArray(_abi.GEOM_MULTIPOINT, np.arange(8.0).reshape(4, 2), geom_offsets=np.array([0, 2, 4], np.int32))
+    assert len(GeoSeries(pts).explode()) == 4  # benches/explode.rs: two-point MultiPoints -> points
+    ls = GeoArrowArray.from_linestrings([[(0, 0), (1, 0), (1, 1), (0, 0)], [(0, 0), (1, 1)], [(2, 2)]])
+    assert GeoSeries(ls).is_ring().tolist() == [True, False, True]
