@@ -119,6 +119,7 @@ constexpr int WR_BLOCK = 256;                  // threads per work-group of pip_
 constexpr int PIP_PPT = GPK_PIP_PPT;           // points per thread, strided by PIP_BLOCK (coalesced 16-byte loads)
 constexpr int PIP_TILE = PIP_BLOCK * PIP_PPT;  // points per work-group
 constexpr int PIP_GS = GPK_PIP_GS;             // lanes cooperating on one queued (point, part) pair
+constexpr int PIP_OVF = 256;                   // per-tile overflow list for points with more than PIP_KHIT hits
 constexpr int PIP_QCAP = PIP_TILE;             // LDS queue capacity (overflow is resolved inline, still exact)
 constexpr int PIP_SUPER_SHIFT = 6;             // 64 tiles per super-tile (two-level prefix of the tile totals)
 constexpr int PIP_WPT = 8;                     // writer: consecutive points per thread
@@ -127,6 +128,10 @@ static_assert(PIP_WTILE % PIP_TILE == 0, "a writer tile is a whole number of pip
 // per-point result code handed from pip_tile to pip_write: a geometry id (exactly one hit), CODE_NONE, or
 // CODE_MULTI (several hits: the writer re-enumerates them with the generic walk)
 constexpr uint32_t CODE_NONE = 0xFFFFFFFFu, CODE_MULTI = 0xFFFFFFFEu;
+// a code with the top bit set (and not one of the two above) is 0x80000000 | offset into the multi-hit pool:
+// pool[offset] = m, then the m geometry ids (ascending) of a point that lies in several geometries
+constexpr uint32_t CODE_POOL = 0x80000000u;
+constexpr int PIP_KHIT = 2;  // part hits remembered per point in LDS; rows with more take the generic walk
 
 // Visits every right-side row whose closed bbox contains the point, in ascending id order.
 template <typename F>
@@ -186,10 +191,13 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
                                                               uint32_t* __restrict__ counts,
                                                               uint32_t* __restrict__ code,
                                                               unsigned long long* __restrict__ block_tot,
-                                                              unsigned long long* __restrict__ super_tot) {
+                                                              unsigned long long* __restrict__ super_tot,
+                                                              uint32_t* __restrict__ multi_pool, uint32_t multi_cap,
+                                                              uint32_t* __restrict__ multi_top) {
     __shared__ QEntry q[RASTER ? PIP_QCAP : 1];
-    __shared__ uint32_t s_cnt[PIP_TILE], s_hit[PIP_TILE];
-    __shared__ uint32_t q_n;
+    __shared__ uint32_t s_cnt[PIP_TILE], s_hit[PIP_TILE * PIP_KHIT];
+    __shared__ uint32_t q_n, ovf_n;
+    __shared__ uint2 s_ovf[RASTER ? PIP_OVF : 1];  // (point slot, part) hits beyond a point's PIP_KHIT inline slots
     __shared__ unsigned long long lds[PIP_BLOCK / 64 + 1];
     const int tid = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.x * PIP_TILE;
@@ -198,7 +206,7 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
     if (RASTER) {
 #pragma unroll
         for (int k = 0; k < PIP_PPT; ++k) s_cnt[k * PIP_BLOCK + tid] = 0;
-        if (tid == 0) q_n = 0;
+        if (tid == 0) q_n = 0, ovf_n = 0;
         __syncthreads();
 
         const int lane64 = tid & 63;
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
                 } else {
                     const int li = k * PIP_BLOCK + tid;
                     s_cnt[li] = 1;  // only this lane touches s_cnt[li] before the barrier
-                    s_hit[li] = payload >> 1;
+                    s_hit[li * PIP_KHIT] = payload >> 1;
                 }
             }
         }
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
                 if (lab == 1u) {
                     const int li = k * PIP_BLOCK + tid;
                     s_cnt[li] = 1;
-                    s_hit[li] = qpart[k];
+                    s_hit[li * PIP_KHIT] = qpart[k];
                 } else if (lab == 2u) {
                     want[k] = true;
                     const bool upper = ((fy[k] / SLAB_DIV) & 1) != 0;
@@ -284,7 +292,19 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
                 }
             }
         }
-        // stage E: wave-aggregated queue push
+        // stage E, one round per k: queue pushes (wave-aggregated), then — when the queue is filling up, and after
+        // the last round — phase 2 drains it.  Boundary-dominated right sides (small overlapping polygons) queue more
+        // than one pair per point; draining between rounds keeps them on the cooperative path.
+        auto record = [&](int li, uint32_t part) {  // phase 1: only this lane touches s_cnt[li] between barriers
+            const uint32_t sl = s_cnt[li]++;
+            if (sl < (uint32_t)PIP_KHIT) {
+                s_hit[li * PIP_KHIT + sl] = part;
+            } else {
+                const uint32_t o = atomicAdd(&ovf_n, 1u);
+                if (o < (uint32_t)PIP_OVF) s_ovf[o] = make_uint2((uint32_t)li, part);
+            }
+        };
+        const int glane = tid & (PIP_GS - 1);
 #pragma unroll
         for (int k = 0; k < PIP_PPT; ++k) {
             const int li = k * PIP_BLOCK + tid;
@@ -301,55 +321,58 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
                     if (slot < (uint32_t)PIP_QCAP) {
                         q[slot] = QEntry{p[k].x, p[k].y, part, (uint32_t)e0[k], (uint32_t)(e1[k] - e0[k]), (uint32_t)li | qflag[k]};
                     } else if (pip::part_pos_single(pv, polys, (int)part, p[k].x, p[k].y) == dev::POS_INSIDE) {
-                        s_cnt[li] += 1;
-                        s_hit[li] = part;
+                        record(li, part);
                     }
                 }
             }
-        }
-        // cells where several parts meet (shared borders, overlaps): per-lane walk of the entry list
-#pragma unroll
-        for (int k = 0; k < PIP_PPT; ++k) {
-            if ((word[k] >> 30) != CELL_TAG_LIST) continue;
-            const int li = k * PIP_BLOCK + tid;
-            const uint32_t off = word[k] & 0x3FFFFFFFu;
-            const uint32_t m = pv.list[off];
-            for (uint32_t t = 0; t < m; ++t) {
-                const uint32_t e = pv.list[off + 1 + t];
-                const uint32_t part = e >> 1;
-                if (e & 1u) {
-                    const PartInfo pq = pv.part_info[part];
-                    const int j = (fy[k] / SLAB_DIV) - pq.row0;
-                    if (j < 0 || j >= pq.nrows) continue;
-                    const int a0 = pv.slab_off[pq.slab_base + j], a1 = pv.slab_off[pq.slab_base + j + 1];
-                    if (a1 <= a0) continue;
-                    const uint32_t slot = atomicAdd(&q_n, 1u);
-                    if (slot < (uint32_t)PIP_QCAP) {
-                        q[slot] = QEntry{p[k].x, p[k].y, part, (uint32_t)a0, (uint32_t)(a1 - a0),
-                                         (uint32_t)li | (pq.n_rings > 1 ? 0x80000000u : 0u)};
-                        continue;
+            // cells where several parts meet (shared borders, overlaps): per-lane walk of the entry list
+            if ((word[k] >> 30) == CELL_TAG_LIST) {
+                const uint32_t off = word[k] & 0x3FFFFFFFu;
+                const uint32_t m = pv.list[off];
+                for (uint32_t t = 0; t < m; ++t) {
+                    const uint32_t e = pv.list[off + 1 + t];
+                    const uint32_t part = e >> 1;
+                    if (e & 1u) {
+                        const PartInfo pq = pv.part_info[part];
+                        const int j = (fy[k] / SLAB_DIV) - pq.row0;
+                        if (j < 0 || j >= pq.nrows) continue;
+                        const int a0 = pv.slab_off[pq.slab_base + j], a1 = pv.slab_off[pq.slab_base + j + 1];
+                        if (a1 <= a0) continue;
+                        const uint32_t slot = atomicAdd(&q_n, 1u);
+                        if (slot < (uint32_t)PIP_QCAP) {
+                            q[slot] = QEntry{p[k].x, p[k].y, part, (uint32_t)a0, (uint32_t)(a1 - a0),
+                                             (uint32_t)li | (pq.n_rings > 1 ? 0x80000000u : 0u)};
+                            continue;
+                        }
+                        if (pip::part_pos_single(pv, polys, (int)part, p[k].x, p[k].y) != dev::POS_INSIDE) continue;
                     }
-                    if (pip::part_pos_single(pv, polys, (int)part, p[k].x, p[k].y) != dev::POS_INSIDE) continue;
+                    record(li, part);
                 }
-                s_cnt[li] += 1;
-                s_hit[li] = part;
             }
-        }
-        __syncthreads();
-
-        const uint32_t nq = GPK_ABLATE == 1 ? 0u : (q_n < (uint32_t)PIP_QCAP ? q_n : (uint32_t)PIP_QCAP);
-        const int glane = tid & (PIP_GS - 1);
-        for (uint32_t e = tid / PIP_GS; e < nq; e += PIP_BLOCK / PIP_GS) {
-            const QEntry en = q[e];
-            const int pos = pip::part_pos_group_from_edges<PIP_GS>(pv, polys, (int)en.part, (en.li_flags >> 31) ? 2 : 1, (int)en.e0,
-                                                                   (int)en.cnt, en.px, en.py, glane);
-            if (glane == 0 && pos == dev::POS_INSIDE) {
-                const uint32_t li = en.li_flags & 0x7FFFFFFFu;
-                atomicAdd(&s_cnt[li], 1u);
-                s_hit[li] = en.part;  // with several hits the row is recomputed below, so any writer may win
+            __syncthreads();
+            const uint32_t queued = q_n;  // uniform: read after the barrier
+            if (k + 1 < PIP_PPT && queued <= (uint32_t)PIP_QCAP / 2) continue;
+            // phase 2
+            const uint32_t nq = GPK_ABLATE == 1 ? 0u : (queued < (uint32_t)PIP_QCAP ? queued : (uint32_t)PIP_QCAP);
+            for (uint32_t e = tid / PIP_GS; e < nq; e += PIP_BLOCK / PIP_GS) {
+                const QEntry en = q[e];
+                const int pos = pip::part_pos_group_from_edges<PIP_GS>(pv, polys, (int)en.part, (en.li_flags >> 31) ? 2 : 1, (int)en.e0,
+                                                                       (int)en.cnt, en.px, en.py, glane);
+                if (glane == 0 && pos == dev::POS_INSIDE) {
+                    const uint32_t li2 = en.li_flags & 0x7FFFFFFFu;
+                    const uint32_t sl = atomicAdd(&s_cnt[li2], 1u);
+                    if (sl < (uint32_t)PIP_KHIT) {
+                        s_hit[li2 * PIP_KHIT + sl] = en.part;
+                    } else {
+                        const uint32_t o = atomicAdd(&ovf_n, 1u);
+                        if (o < (uint32_t)PIP_OVF) s_ovf[o] = make_uint2(li2, en.part);
+                    }
+                }
             }
+            __syncthreads();
+            if (tid == 0) q_n = 0;
+            __syncthreads();
         }
-        __syncthreads();
     }
 
     unsigned long long local = 0;
@@ -358,18 +381,78 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
         const int li = k * PIP_BLOCK + tid;
         const int64_t i = base + li;
         if (i >= n) continue;
-        uint32_t cnt = 0, first = CODE_NONE;
+        uint32_t cnt = 0, first = CODE_NONE, pool_code = CODE_MULTI;
         bool generic = !RASTER;
         if (RASTER) {
             cnt = s_cnt[li];
-            if (cnt == 1) {
-                first = pv.part_geom ? pv.part_geom[s_hit[li]] : s_hit[li];
-                if (!dev::valid_row(polys.validity, first)) {
-                    cnt = 0;
-                    first = CODE_NONE;
+            if (cnt >= 1 && cnt <= (uint32_t)PIP_KHIT) {
+                // part hits -> geometry hits: ascending, each geometry once, null geometries dropped (written out
+                // for PIP_KHIT == 2 so that nothing is a runtime-indexed register array)
+                static_assert(PIP_KHIT == 2, "the finalize step is written for two remembered hits");
+                uint32_t g0 = CODE_NONE, g1 = CODE_NONE, m = 0;
+                {
+                    const uint32_t part = s_hit[li * PIP_KHIT];
+                    const uint32_t geom = pv.part_geom ? pv.part_geom[part] : part;
+                    if (dev::valid_row(polys.validity, geom)) {
+                        g0 = geom;
+                        m = 1;
+                    }
                 }
-            } else if (cnt > 1) {
-                generic = true;
+                if (cnt == 2) {
+                    const uint32_t part = s_hit[li * PIP_KHIT + 1];
+                    const uint32_t geom = pv.part_geom ? pv.part_geom[part] : part;
+                    if (dev::valid_row(polys.validity, geom)) {
+                        if (m == 0) {
+                            g0 = geom;
+                            m = 1;
+                        } else if (geom != g0) {
+                            g1 = geom > g0 ? geom : g0;
+                            g0 = geom > g0 ? g0 : geom;
+                            m = 2;
+                        }
+                    }
+                }
+                cnt = m;
+                if (m >= 1) first = g0;
+                if (m == 2) {
+                    const uint32_t at = atomicAdd(multi_top, 3u);
+                    if (at + 3u <= multi_cap) {
+                        multi_pool[at] = 2u;
+                        multi_pool[at + 1] = g0;
+                        multi_pool[at + 2] = g1;
+                        pool_code = CODE_POOL | at;
+                    }
+                }
+            } else if (cnt > (uint32_t)PIP_KHIT) {
+                // more hits than inline slots: the rest sit in the tile's overflow list.  Collect all of them into a
+                // pool segment, then sort + dedup there (a handful of words, one lane).
+                const uint32_t novf = ovf_n;
+                const uint32_t at = novf <= (uint32_t)PIP_OVF ? atomicAdd(multi_top, cnt + 1u) : 0xFFFFFFFFu;
+                if (novf > (uint32_t)PIP_OVF || at + cnt + 1u > multi_cap) {
+                    generic = true;
+                } else {
+                    uint32_t* seg = multi_pool + at + 1;
+                    uint32_t m = 0;
+                    auto put = [&](uint32_t part) {
+                        const uint32_t geom = pv.part_geom ? pv.part_geom[part] : part;
+                        if (!dev::valid_row(polys.validity, geom)) return;
+                        uint32_t j = m;  // insertion into the ascending prefix; equal geometry: drop
+                        while (j > 0 && seg[j - 1] > geom) --j;
+                        if (j > 0 && seg[j - 1] == geom) return;
+                        for (uint32_t t = m; t > j; --t) seg[t] = seg[t - 1];
+                        seg[j] = geom;
+                        ++m;
+                    };
+                    for (int h = 0; h < PIP_KHIT; ++h) put(s_hit[li * PIP_KHIT + h]);
+                    for (uint32_t o = 0; o < novf; ++o) {
+                        const uint2 e = s_ovf[o];
+                        if (e.x == (uint32_t)li) put(e.y);
+                    }
+                    multi_pool[at] = m;
+                    cnt = m;
+                    if (m >= 1) first = seg[0];
+                    if (m >= 2) pool_code = CODE_POOL | at;
+                }
             }
         }
         if (generic) {
@@ -380,7 +463,7 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
             }
         }
         if (counts) dev::store_stream(counts + i, cnt);
-        dev::store_stream(code + i, cnt == 0 ? CODE_NONE : (cnt == 1 ? first : CODE_MULTI));
+        dev::store_stream(code + i, cnt == 0 ? CODE_NONE : (cnt == 1 ? first : pool_code));
         local += cnt;
     }
     unsigned long long tot;
@@ -399,6 +482,7 @@ __global__ __launch_bounds__(WR_BLOCK) void pip_write_kernel(DevGeo pts, DevGeo 
                                                                const uint32_t* __restrict__ code,
                                                                const unsigned long long* __restrict__ block_tot,
                                                                const unsigned long long* __restrict__ super_tot,
+                                                               const uint32_t* __restrict__ multi_pool,
                                                                int64_t n_tiles, uint32_t left_base,
                                                                uint2* __restrict__ pairs, int64_t capacity,
                                                                unsigned long long* __restrict__ grand,
@@ -429,6 +513,7 @@ __global__ __launch_bounds__(WR_BLOCK) void pip_write_kernel(DevGeo pts, DevGeo 
 #pragma unroll
     for (int k = 0; k < PIP_WPT; ++k) {
         cnt[k] = c[k] == CODE_NONE ? 0u : 1u;
+        if (c[k] != CODE_NONE && c[k] != CODE_MULTI && (c[k] & CODE_POOL)) cnt[k] = multi_pool[c[k] & ~CODE_POOL];
         if (c[k] == CODE_MULTI) {
             uint32_t first;
             const double2 p = pts.xy[i0 + k];
@@ -449,6 +534,14 @@ __global__ __launch_bounds__(WR_BLOCK) void pip_write_kernel(DevGeo pts, DevGeo 
     for (int k = 0; k < PIP_WPT; ++k) {
         if (cnt[k] == 0) continue;
         const uint32_t l = left_base + (uint32_t)(i0 + k);
+        if (c[k] != CODE_MULTI && (c[k] & CODE_POOL)) {  // several geometries, listed in the pool
+            const uint32_t at = c[k] & ~CODE_POOL;
+            for (uint32_t t = 0; t < cnt[k]; ++t) {
+                if (o < capacity) pairs[o] = make_uint2(l, multi_pool[at + 1 + t]);
+                ++o;
+            }
+            continue;
+        }
         if (c[k] != CODE_MULTI) {
             if (o < capacity) pairs[o] = make_uint2(l, c[k]);
             ++o;
@@ -840,15 +933,19 @@ int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right, co
     const size_t pairs_bytes = sizeof(uint32_t) * 2 * (size_t)pair_capacity;
     const int64_t n_super = (n_blocks >> PIP_SUPER_SHIFT) + 1;
     const int64_t n_wblocks = (n + PIP_WTILE - 1) / PIP_WTILE;
-    size_t need = align256(counts_bytes + 64) /*code*/ + align256(sizeof(unsigned long long) * (size_t)(n_blocks + n_super + 2)) + 1024;
+    const uint32_t multi_cap = (uint32_t)(n < (int64_t)0x18000000 ? 2 * n + 1024 : (int64_t)0x30000000);  // words in the multi-hit pool
+    size_t need = align256(counts_bytes + 64) /*code*/ + align256(sizeof(unsigned long long) * (size_t)(n_blocks + n_super + 3)) +
+                  align256(sizeof(uint32_t) * (size_t)multi_cap) + 1024;
     if (host_out && out_counts) need += align256(counts_bytes);
     if (host_out && want_pairs) need += align256(pairs_bytes);
     int32_t rc = workspace().begin(need);
     if (rc != GPK_OK) return done(rc);
     uint32_t* code = (uint32_t*)workspace().take(counts_bytes + 64);
-    unsigned long long* btot = (unsigned long long*)workspace().take(sizeof(unsigned long long) * (size_t)(n_blocks + n_super + 2));
+    unsigned long long* btot = (unsigned long long*)workspace().take(sizeof(unsigned long long) * (size_t)(n_blocks + n_super + 3));
     unsigned long long* stot = btot + n_blocks;     // n_super super-tile totals
     unsigned long long* grand = stot + n_super;     // total hits
+    uint32_t* multi_top = (uint32_t*)(grand + 1);   // words used in the multi-hit pool (zeroed with the totals)
+    uint32_t* multi_pool = (uint32_t*)workspace().take(sizeof(uint32_t) * (size_t)multi_cap);
     uint32_t* counts_dev = out_counts ? (host_out ? (uint32_t*)workspace().take(counts_bytes) : out_counts) : nullptr;
     uint32_t* pairs_dev = want_pairs ? (host_out ? (uint32_t*)workspace().take(pairs_bytes) : out_pairs) : nullptr;
 
@@ -866,18 +963,18 @@ int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right, co
     } while (0)
 
     {
-        const hipError_t me = hipMemsetAsync(stot, 0, sizeof(unsigned long long) * (size_t)(n_super + 1), s);
+        const hipError_t me = hipMemsetAsync(stot, 0, sizeof(unsigned long long) * (size_t)(n_super + 2), s);
         if (me != hipSuccess) return done(fail(GPK_ERR_DEVICE, "spatial_join: %s", hipGetErrorString(me)));
     }
     if (right_index->pip.R > 0)
         J_LAUNCH("gpk_pip_tile", pip_tile_kernel<true>, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
-                 right_index->v, right_index->pip, counts_dev, code, btot, stot);
+                 right_index->v, right_index->pip, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top);
     else
         J_LAUNCH("gpk_pip_tile_generic", pip_tile_kernel<false>, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
-                 right_index->v, right_index->pip, counts_dev, code, btot, stot);
+                 right_index->v, right_index->pip, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top);
     // the writer also produces the grand total; in count-only mode it runs without a pair buffer
     J_LAUNCH("gpk_pip_write", pip_write_kernel, dim3((unsigned)n_wblocks), dim3(WR_BLOCK), 0, s, left->d, right->d, right_index->v,
-             code, btot, stot, n_blocks, left_row_base, (uint2*)pairs_dev, pair_capacity, grand, pinned_total);
+             code, btot, stot, (const uint32_t*)multi_pool, n_blocks, left_row_base, (uint2*)pairs_dev, pair_capacity, grand, pinned_total);
 #undef J_LAUNCH
 
     unsigned long long total = 0;

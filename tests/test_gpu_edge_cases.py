@@ -60,6 +60,18 @@ def test_overlapping_and_nested_polygons_multi_hit(gpk, oracle):
     assert np.all(np.diff(exp_pairs[:, 0].astype(np.int64)) >= 0)
 
 
+def test_sparse_three_to_six_hit_rows_use_the_overflow_list(gpk, oracle):
+    """power-law multipolygons overlap irregularly: most rows have 0-2 hits, a few have 3-6 (the rows that go through
+    the tile's overflow list and the multi-hit pool), with multipolygon parts mapped back to geometry ids"""
+    mp = synth.powerlaw_multipolygons(4000, seed=77, domain=300.0)
+    pts = synth.uniform_points(60_000, seed=78, domain=300.0)
+    exp_pairs, exp_counts, _ = oracle.spatial_join(pts, mp, "within", mode=1)
+    got_pairs, got_counts = join_pairs(GeoSeries(pts), GeoSeries(mp), "within")
+    assert np.array_equal(got_counts, exp_counts) and np.array_equal(got_pairs, exp_pairs)
+    hist = np.bincount(exp_counts)
+    assert len(hist) > 3 and hist[2] > 0 and hist[3:].sum() > 0, hist
+
+
 def test_multipolygon_with_overlapping_parts_counts_geometry_once(gpk, oracle):
     mp = GeoArrowArray.from_multipolygons(
         [

@@ -20,6 +20,22 @@ a = ap.parse_args()
 def t(f):
     t0 = time.perf_counter(); r = f(); return r, (time.perf_counter() - t0) * 1e3
 
+import ctypes as C
+from geopolars_amd._abi import lib as _lib
+def kernel_ms(f, names):
+    """Per-kernel device time (ms) of one call of f, from the library's event profiler."""
+    L = _lib()
+    L.gpk_profile_reset(); L.gpk_profile_enable(1)
+    f()
+    L.gpk_profile_enable(0)
+    out = {}
+    for nm in names:
+        ms, cnt = C.c_double(0), C.c_int64(0)
+        L.gpk_profile_query(nm.encode(), C.byref(ms), C.byref(cnt))
+        if cnt.value: out[nm] = ms.value
+    L.gpk_profile_reset()
+    return out
+
 # ---- C4: polygon x polygon intersects join ------------------------------------------------------------
 L = synth.clustered_polygons(a.c4, seed=41, mean_neighbours=4.0); R = synth.clustered_polygons(a.c4, seed=42, mean_neighbours=4.0)
 ls, rs = GeoSeries(L), GeoSeries(R)
@@ -27,10 +43,11 @@ ls.device(); rs.device()
 idx, ms_idx = t(lambda: SpatialIndex(rs))
 (pairs, counts), ms_join = t(lambda: join_pairs(ls, rs, "intersects", r_index=idx))
 (pairs, counts), ms_join2 = t(lambda: join_pairs(ls, rs, "intersects", r_index=idx))
+kms4 = kernel_ms(lambda: join_pairs(ls, rs, "intersects", r_index=idx), ["gpk_bbox_cand_count", "gpk_bbox_cand_fill", "gpk_pair_refine", "gpk_pair_count", "gpk_pair_emit"])
 k = min(a.c4, 20000)
 ep, ec, _ = O.spatial_join(slice_rows(L, 0, k), R, "intersects", mode=1)
 ok = np.array_equal(counts[:k], ec) and np.array_equal(pairs[: len(ep)], ep)
-print(json.dumps({"config": "C4 share", "left": a.c4, "right": a.c4, "index_build_ms": ms_idx, "join_ms_first": ms_join, "join_ms": ms_join2, "pairs": int(len(pairs)), "parity_prefix_rows": k, "parity": bool(ok)}), flush=True)
+print(json.dumps({"config": "C4 share", "left": a.c4, "right": a.c4, "index_build_ms": ms_idx, "join_ms_first": ms_join, "join_ms": ms_join2, "kernel_ms": kms4, "pairs": int(len(pairs)), "parity_prefix_rows": k, "parity": bool(ok)}), flush=True)
 del ls, rs, idx
 
 # ---- C5: points within power-law multipolygons + area ---------------------------------------------------
@@ -40,6 +57,7 @@ ms_.device(); ps.device()
 idx, ms_idx = t(lambda: SpatialIndex(ms_))
 (pairs, counts), ms_join = t(lambda: join_pairs(ps, ms_, "within", r_index=idx))
 (pairs, counts), ms_join2 = t(lambda: join_pairs(ps, ms_, "within", r_index=idx))
+kms = kernel_ms(lambda: join_pairs(ps, ms_, "within", r_index=idx), ["gpk_pip_tile", "gpk_pip_write"])
 area, ms_area = t(lambda: ms_.area())
 area, ms_area2 = t(lambda: ms_.area())
 k = min(a.c5_points, 200000)
@@ -47,4 +65,4 @@ ep, ec, _ = O.spatial_join(slice_rows(P, 0, k), MP, "within", mode=1)
 ok = np.array_equal(counts[:k], ec) and np.array_equal(pairs[: len(ep)], ep)
 ea = O.area(MP)
 ok_area = bool(np.all(np.abs(area - ea) <= 1e-9 * np.maximum(np.abs(ea), 1e-300)))
-print(json.dumps({"config": "C5 share", "points": a.c5_points, "multipolygons": a.c5_polys, "coords": int(MP.n_coords), "index_build_ms": ms_idx, "index_bytes": idx.nbytes(), "join_ms_first": ms_join, "join_ms": ms_join2, "pairs": int(len(pairs)), "area_ms": ms_area2, "parity_prefix_rows": k, "parity": bool(ok), "area_parity": ok_area}), flush=True)
+print(json.dumps({"config": "C5 share", "points": a.c5_points, "multipolygons": a.c5_polys, "coords": int(MP.n_coords), "index_build_ms": ms_idx, "index_bytes": idx.nbytes(), "join_ms_first": ms_join, "join_ms": ms_join2, "kernel_ms": kms, "pairs": int(len(pairs)), "area_ms": ms_area2, "parity_prefix_rows": k, "parity": bool(ok), "area_parity": ok_area}), flush=True)
