@@ -72,10 +72,9 @@ namespace dev {
 // Monotone non-decreasing in v (subtract, multiply by a non-negative constant, floor, clamp), so
 // minx <= px <= maxx implies cell(minx) <= cell(px) <= cell(maxx): no candidate can be missed.
 __device__ __forceinline__ int cell_of(double v, double v0, double inv, int g) {
-    const double f = floor((v - v0) * inv);
-    if (!(f >= 0.0)) return 0;
-    if (f >= (double)g) return g - 1;
-    return (int)f;
+    // branch-free: negative / NaN products clamp to 0 (fmax drops the NaN), large ones to g - 1; the conversion
+    // truncates, which is floor() on the clamped non-negative value
+    return (int)fmin(fmax((v - v0) * inv, 0.0), (double)(g - 1));
 }
 }  // namespace dev
 

@@ -120,7 +120,10 @@ constexpr int PIP_PPT = GPK_PIP_PPT;           // points per thread, strided by 
 constexpr int PIP_TILE = PIP_BLOCK * PIP_PPT;  // points per work-group
 constexpr int PIP_GS = GPK_PIP_GS;             // lanes cooperating on one queued (point, part) pair
 constexpr int PIP_OVF = 256;                   // per-tile overflow list for points with more than PIP_KHIT hits
-constexpr int PIP_QCAP = PIP_TILE;             // LDS queue capacity (overflow is resolved inline, still exact)
+#ifndef GPK_PIP_QCAP
+#define GPK_PIP_QCAP (GPK_PIP_BLOCK * GPK_PIP_PPT)
+#endif
+constexpr int PIP_QCAP = GPK_PIP_QCAP;             // LDS queue capacity (overflow is resolved inline, still exact)
 constexpr int PIP_SUPER_SHIFT = 6;             // 64 tiles per super-tile (two-level prefix of the tile totals)
 constexpr int PIP_WPT = 8;                     // writer: consecutive points per thread
 constexpr int PIP_WTILE = WR_BLOCK * PIP_WPT;  // writer: points per work-group (a multiple of PIP_TILE)
@@ -186,6 +189,14 @@ struct QEntry {  // 32 bytes: one queued (point, part) pair with its exterior sl
 #ifndef GPK_PIP_MINWAVES
 #define GPK_PIP_MINWAVES 1
 #endif
+#ifndef GPK_PIP_NT
+#define GPK_PIP_NT 2  // bit 0: non-temporal point loads (measured slower), bit 1: non-temporal result stores
+#endif
+#if GPK_ABLATE == 6  // tuning builds only: level-1 interiors only, no barriers in the queue rounds
+#define PIP_SYNC() (void)0
+#else
+#define PIP_SYNC() __syncthreads()
+#endif
 template <bool RASTER>
 __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(DevGeo pts, DevGeo polys, IndexView ix, PipView pv,
                                                               uint32_t* __restrict__ counts,
@@ -198,10 +209,17 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
     __shared__ uint32_t s_cnt[PIP_TILE], s_hit[PIP_TILE * PIP_KHIT];
     __shared__ uint32_t q_n, ovf_n;
     __shared__ uint2 s_ovf[RASTER ? PIP_OVF : 1];  // (point slot, part) hits beyond a point's PIP_KHIT inline slots
-    __shared__ unsigned long long lds[PIP_BLOCK / 64 + 1];
+    __shared__ unsigned long long s_tot;  // hits of the tile
+#ifdef GPK_PIP_PAD_LDS
+    __shared__ uint32_t s_pad[GPK_PIP_PAD_LDS / 4];  // tuning builds: lower the occupancy
+    if (blockIdx.x == 0x7FFFFFFFu) s_pad[threadIdx.x] = 1, s_tot = s_pad[3];
+#endif
     const int tid = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.x * PIP_TILE;
     const int64_t n = pts.n_geoms;
+    const uint32_t rem = (uint32_t)(n - base < (int64_t)PIP_TILE ? n - base : (int64_t)PIP_TILE);  // points in this tile
+    const double2* __restrict__ tile_xy = pts.xy + base;
+    if (tid == 0) s_tot = 0;
 
     if (RASTER) {
 #pragma unroll
@@ -212,29 +230,30 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
         const int lane64 = tid & 63;
         double2 p[PIP_PPT];
         uint32_t word[PIP_PPT];
-        int fy[PIP_PPT];
+        uint32_t fy[PIP_PPT];
         bool want[PIP_PPT];
         PartInfo pi[PIP_PPT];
         int e0[PIP_PPT], e1[PIP_PPT];
         // stage A: points (coalesced 16-byte loads)
 #pragma unroll
         for (int k = 0; k < PIP_PPT; ++k) {
-            const int64_t i = base + k * PIP_BLOCK + tid;
-            const bool ok = i < n && dev::valid_row(pts.validity, i);
-            p[k] = ok ? dev::load_stream(pts.xy + i) : make_double2(NAN, NAN);
+            const uint32_t t = (uint32_t)(k * PIP_BLOCK + tid);  // scalar tile base + 32-bit lane offset
+            const bool ok = t < rem && dev::valid_row(pts.validity, base + t);
+            p[k] = ok ? ((GPK_PIP_NT & 1) ? dev::load_stream(tile_xy + t) : tile_xy[t]) : make_double2(NAN, NAN);
         }
         // stage B: raster words (one 4-byte gather per point).  Columns/rows are computed at PIP_SUB x the
         // raster resolution (an exact power-of-two rescale of the same monotone function): `/ PIP_SUB` is the
         // level-1 cell, `% PIP_SUB` the level-2 sub-cell, and sy / (PIP_SUB / PIP_SLAB_MUL) the slab row.
         constexpr int S = PIP_SUB, SLAB_DIV = PIP_SUB / PIP_SLAB_MUL;
-        int sx[PIP_PPT];
+        uint32_t sx[PIP_PPT];
 #pragma unroll
         for (int k = 0; k < PIP_PPT; ++k) {
-            sx[k] = dev::cell_of(p[k].x, pv.rx0, pv.inv_fw * S, pv.R * S);
-            fy[k] = dev::cell_of(p[k].y, pv.ry0, pv.inv_fh * S, pv.R * S);
-            word[k] = (p[k].x == p[k].x && p[k].y == p[k].y) ? pv.cell[(int64_t)(fy[k] / S) * pv.R + (sx[k] / S)] : 0u;
+            sx[k] = (uint32_t)dev::cell_of(p[k].x, pv.rx0, pv.inv_fw * S, pv.R * S);
+            fy[k] = (uint32_t)dev::cell_of(p[k].y, pv.ry0, pv.inv_fh * S, pv.R * S);
+            word[k] = (p[k].x == p[k].x && p[k].y == p[k].y) ? pv.cell[(fy[k] / S) * (uint32_t)pv.R + (sx[k] / S)] : 0u;
             if (GPK_ABLATE == 2) word[k] = 0u;  // tuning builds only
-            if (GPK_ABLATE == 3) word[k] = (word[k] >> 30) == CELL_TAG_SINGLE && !(word[k] & 1u) ? word[k] : 0u;
+            if (GPK_ABLATE == 4) word[k] = word[k] == 0x12345678u ? word[k] : 0u;  // keep loads + gather, drop the rest
+            if (GPK_ABLATE == 3 || GPK_ABLATE == 6) word[k] = (word[k] >> 30) == CELL_TAG_SINGLE && !(word[k] & 1u) ? word[k] : 0u;
         }
         // stage C: decided cells; level-2 record gather (32 B) or PartInfo gather for inline boundary entries
         SubCell sc[PIP_PPT];
@@ -274,7 +293,7 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
                     const int li = k * PIP_BLOCK + tid;
                     s_cnt[li] = 1;
                     s_hit[li * PIP_KHIT] = qpart[k];
-                } else if (lab == 2u) {
+                } else if (lab == 2u && GPK_ABLATE != 5) {
                     want[k] = true;
                     const bool upper = ((fy[k] / SLAB_DIV) & 1) != 0;
                     e0[k] = (int)(upper ? sc[k].e1 : sc[k].e0);
@@ -349,7 +368,7 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
                     record(li, part);
                 }
             }
-            __syncthreads();
+            PIP_SYNC();
             const uint32_t queued = q_n;  // uniform: read after the barrier
             if (k + 1 < PIP_PPT && queued <= (uint32_t)PIP_QCAP / 2) continue;
             // phase 2
@@ -369,18 +388,21 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
                     }
                 }
             }
-            __syncthreads();
+            PIP_SYNC();
             if (tid == 0) q_n = 0;
-            __syncthreads();
+            PIP_SYNC();
         }
     }
 
-    unsigned long long local = 0;
+    if (!RASTER) __syncthreads();  // s_tot = 0 visible
+    uint32_t* __restrict__ tile_counts = counts ? counts + base : nullptr;
+    uint32_t* __restrict__ tile_code = code + base;
+    unsigned long long wave_hits = 0;  // rows with exactly one hit, counted by ballot (uniform per wave)
 #pragma unroll
     for (int k = 0; k < PIP_PPT; ++k) {
         const int li = k * PIP_BLOCK + tid;
         const int64_t i = base + li;
-        if (i >= n) continue;
+        if ((uint32_t)li >= rem) continue;
         uint32_t cnt = 0, first = CODE_NONE, pool_code = CODE_MULTI;
         bool generic = !RASTER;
         if (RASTER) {
@@ -462,13 +484,21 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
                 generic_point(polys, ix, pp.x, pp.y, cnt, first);
             }
         }
-        if (counts) dev::store_stream(counts + i, cnt);
-        dev::store_stream(code + i, cnt == 0 ? CODE_NONE : (cnt == 1 ? first : pool_code));
-        local += cnt;
+        const uint32_t cd = cnt == 0 ? CODE_NONE : (cnt == 1 ? first : pool_code);
+        if (GPK_PIP_NT & 2) {
+            if (tile_counts) dev::store_stream(tile_counts + (uint32_t)li, cnt);
+            dev::store_stream(tile_code + (uint32_t)li, cd);
+        } else {
+            if (tile_counts) tile_counts[(uint32_t)li] = cnt;
+            tile_code[(uint32_t)li] = cd;
+        }
+        wave_hits += (unsigned long long)__popcll(__ballot(cnt == 1));
+        if (cnt >= 2) atomicAdd(&s_tot, (unsigned long long)cnt);
     }
-    unsigned long long tot;
-    (void)dev::block_exclusive_scan<unsigned long long, PIP_BLOCK>(local, lds, &tot);
+    if ((tid & 63) == 0 && wave_hits) atomicAdd(&s_tot, wave_hits);
+    __syncthreads();
     if (tid == 0) {
+        const unsigned long long tot = s_tot;
         block_tot[blockIdx.x] = tot;
         if (tot) atomicAdd(&super_tot[blockIdx.x >> PIP_SUPER_SHIFT], tot);  // integer adds: order-independent
     }
