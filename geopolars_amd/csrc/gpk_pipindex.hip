@@ -159,23 +159,24 @@ __device__ __forceinline__ void for_each_touched_cell(const FineGrid& g, double2
 
 template <bool FILL>
 __global__ void mark_kernel(DevGeo a, FineGrid g, const int32_t* __restrict__ ring_part,
-                            unsigned long long* __restrict__ counter, unsigned long long* __restrict__ keys) {
+                            int32_t* __restrict__ cnt_or_off, unsigned long long* __restrict__ keys) {
+    // count pass: cnt[i] = cells touched by the edge that starts at coordinate i; fill pass: the edge writes its keys
+    // at off[i].. (exclusive scan of the counts) — no atomics, deterministic layout
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_coords) return;
     int r;
     double2 s, e;
-    if (!edge_at(a, (int)i, r, s, e)) return;
+    if (!edge_at(a, (int)i, r, s, e)) {
+        if (!FILL) cnt_or_off[i] = 0;
+        return;
+    }
     const unsigned long long part = (unsigned long long)ring_part[r];
-    unsigned long long n = 0;
+    int64_t n = FILL ? (int64_t)cnt_or_off[i] : 0;
     for_each_touched_cell(g, s, e, [&](int ci, int cj) {
-        if (FILL) {
-            const unsigned long long slot = atomicAdd(counter, 1ull);
-            keys[slot] = ((unsigned long long)(cj * g.R + ci) << 32) | part;
-        } else {
-            ++n;
-        }
+        if (FILL) keys[n] = ((unsigned long long)(cj * g.R + ci) << 32) | part;
+        ++n;
     });
-    if (!FILL && n) atomicAdd(counter, n);
+    if (!FILL) cnt_or_off[i] = (int32_t)(n < 0x7FFFFFFF ? n : 0x7FFFFFFF);
 }
 
 __global__ void unique_flags_kernel(const unsigned long long* __restrict__ sorted, int64_t n, int32_t* __restrict__ flag) {
@@ -500,15 +501,16 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
     pv.slab_edges = edges;
 
     // ---- boundary marks: (cell, part) keys, sorted + unique ---------------------------------------
-    unsigned long long* counter;
-    GPK_TRY(t.alloc(&counter, 2));
-    GPK_HIP(hipMemsetAsync(counter, 0, 2 * sizeof(unsigned long long), s));
-    GPK_LAUNCH("gpk_pipidx_mark_count", mark_kernel<false>, blocks_for(d.n_coords), dim3(256), 0, s, d, g, ring_part, counter,
+    int32_t *mark_cnt, *mark_off;
+    GPK_TRY(t.alloc(&mark_cnt, (size_t)d.n_coords + 1));
+    GPK_TRY(t.alloc(&mark_off, (size_t)d.n_coords + 1));
+    GPK_LAUNCH("gpk_pipidx_mark_count", mark_kernel<false>, blocks_for(d.n_coords), dim3(256), 0, s, d, g, ring_part, mark_cnt,
                (unsigned long long*)nullptr);
-    unsigned long long n_marks_raw = 0;
-    GPK_HIP(hipMemcpyAsync(&n_marks_raw, counter, sizeof n_marks_raw, hipMemcpyDeviceToHost, s));
+    GPK_TRY(exclusive_scan_i32(mark_cnt, d.n_coords, mark_off, nullptr, btot, s));
+    unsigned long long n_marks_raw = 0;  // the scan keeps its grand total in 64 bits
+    GPK_HIP(hipMemcpyAsync(&n_marks_raw, btot + (d.n_coords + 255) / 256, sizeof n_marks_raw, hipMemcpyDeviceToHost, s));
     GPK_HIP(hipStreamSynchronize(s));
-    if (n_marks_raw > (1ull << 31))
+    if (n_marks_raw >= (1ull << 31))
         return GPK_OK;  // pathological (huge edges over a fine raster): leave the accelerator off
     unsigned long long *keys, *sorted, *marks;
     GPK_TRY(t.alloc(&keys, (size_t)n_marks_raw));
@@ -516,7 +518,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
     GPK_TRY(t.alloc(&marks, (size_t)n_marks_raw));
     int64_t n_marks = 0;
     if (n_marks_raw > 0) {
-        GPK_LAUNCH("gpk_pipidx_mark_fill", mark_kernel<true>, blocks_for(d.n_coords), dim3(256), 0, s, d, g, ring_part, counter + 1, keys);
+        GPK_LAUNCH("gpk_pipidx_mark_fill", mark_kernel<true>, blocks_for(d.n_coords), dim3(256), 0, s, d, g, ring_part, mark_off, keys);
         size_t tmp_bytes = 0;
         GPK_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, keys, sorted, (size_t)n_marks_raw, 0, 64, s));
         char* tmp;
