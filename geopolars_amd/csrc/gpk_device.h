@@ -196,6 +196,39 @@ __device__ inline bool polygonal_hits_point(const DevGeo& a, int64_t g, double c
     return false;
 }
 
+// ---- all-reduce over G consecutive lanes with DPP row operations --------------------------------
+// G = 4, 8, 16 (a group never straddles a 16-lane DPP row): quad permutes for xor 1 / xor 2, row_half_mirror to join
+// the two quads of an 8-lane half row, row_ror:4 / row_ror:8 to join the quads of a row.  One VALU mov per 32-bit
+// word and step, instead of a ds_bpermute round trip through the LDS crossbar.  All lanes of the group must be active.
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    return __hiloint2double(dpp_mov<CTRL>(__double2hiint(v)), dpp_mov<CTRL>(__double2loint(v)));
+}
+template <int G, typename T, typename Op>
+__device__ __forceinline__ T group_allreduce(T v, Op op) {
+    static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16, "group_allreduce: G lanes within one DPP row");
+    if constexpr (G >= 2) v = op(v, dpp_mov<0xB1>(v));   // quad_perm [1,0,3,2]
+    if constexpr (G >= 4) v = op(v, dpp_mov<0x4E>(v));   // quad_perm [2,3,0,1]
+    if constexpr (G == 8) v = op(v, dpp_mov<0x141>(v));  // row_half_mirror
+    if constexpr (G == 16) {
+        v = op(v, dpp_mov<0x124>(v));  // row_ror:4
+        v = op(v, dpp_mov<0x128>(v));  // row_ror:8
+    }
+    return v;
+}
+template <int G>
+__device__ __forceinline__ int group_sum(int v) { return group_allreduce<G>(v, [](int a, int b) { return a + b; }); }
+template <int G>
+__device__ __forceinline__ int group_or(int v) { return group_allreduce<G>(v, [](int a, int b) { return a | b; }); }
+template <int G>
+__device__ __forceinline__ double group_min(double v) { return group_allreduce<G>(v, [](double a, double b) { return fmin(a, b); }); }
+template <int G>
+__device__ __forceinline__ double group_max(double v) { return group_allreduce<G>(v, [](double a, double b) { return fmax(a, b); }); }
+
 // ---- wave64 helpers ------------------------------------------------------------------------
 __device__ __forceinline__ double wave_min(double v) {
 #pragma unroll

@@ -617,7 +617,7 @@ __device__ __forceinline__ void for_each_bbox_candidate(const IndexView& ix, con
 template <bool WRITE>
 __global__ __launch_bounds__(256) void bbox_cand_kernel(DevGeo left, DevGeo right, IndexView ix, const double4* __restrict__ lbbox,
                                                          int32_t* __restrict__ cand_cnt, const int32_t* __restrict__ cand_off,
-                                                         uint32_t* __restrict__ cand_r) {
+                                                         uint32_t* __restrict__ cand_r, uint32_t* __restrict__ cand_l) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= left.n_geoms) return;
     int cnt = 0;
@@ -643,6 +643,7 @@ __global__ __launch_bounds__(256) void bbox_cand_kernel(DevGeo left, DevGeo righ
         }
         cand_r[o0 + b + 1] = key;
     }
+    for (int a = 0; a < cnt; ++a) cand_l[o0 + a] = (uint32_t)i;  // left row of every candidate: the refine reads it directly
 }
 
 // Stage 2: exact refine, JOIN_GS lanes per candidate pair (pairs are independent: the unit of parallelism is the
@@ -659,14 +660,17 @@ __device__ __forceinline__ int64_t row_of_candidate(const int32_t* __restrict__ 
     }
     return lo;
 }
-__global__ __launch_bounds__(256) void pair_refine_kernel(DevGeo left, DevGeo right, const int32_t* __restrict__ cand_off,
+__global__ __launch_bounds__(256) void pair_refine_kernel(DevGeo left, DevGeo right, const uint32_t* __restrict__ cand_l,
                                                            const uint32_t* __restrict__ cand_r, int64_t n_cand,
+                                                           const double4* __restrict__ lbbox, const double4* __restrict__ rbbox,
                                                            uint8_t* __restrict__ hit) {
+    __shared__ double4 seg_lists[(256 / JOIN_GS) * 2 * PP_LIST];  // one in-window segment list per group (gpk_polypoly.h)
     const int lane = threadIdx.x & (JOIN_GS - 1);
+    double4* seg_list = seg_lists + (threadIdx.x / JOIN_GS) * 2 * PP_LIST;
     const int64_t groups = (int64_t)gridDim.x * (256 / JOIN_GS);
     for (int64_t c = (int64_t)blockIdx.x * (256 / JOIN_GS) + threadIdx.x / JOIN_GS; c < n_cand; c += groups) {
-        const int64_t i = row_of_candidate(cand_off, left.n_geoms, c);
-        const bool h = polygonal_intersects_polygonal_group<JOIN_GS>(left, i, right, (int64_t)cand_r[c], lane);
+        const int64_t i = (int64_t)cand_l[c];
+        const bool h = polygonal_intersects_polygonal_group<JOIN_GS>(left, i, right, (int64_t)cand_r[c], lane, seg_list, lbbox, rbbox);
         if (lane == 0) hit[c] = h;
     }
 }
@@ -708,7 +712,7 @@ static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, co
     const bool host_out = out_space != GPK_MEM_DEVICE;
     const bool want_pairs = pair_capacity > 0;
     // per-call allocations that outlive a workspace reset (gpk_bounds uses the workspace itself)
-    void* owned[3] = {nullptr, nullptr, nullptr};
+    void* owned[4] = {nullptr, nullptr, nullptr, nullptr};
     auto done = [&](int32_t rc) {
         for (void* p : owned)
             if (p) (void)hipFree(p);
@@ -738,7 +742,7 @@ static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, co
     int32_t n_cand = 0;
     auto stage1 = [&]() -> int32_t {
         GPK_LAUNCH("gpk_bbox_cand_count", bbox_cand_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, left->d, right->d, right_index->v,
-                   lbbox, cand_cnt, (const int32_t*)nullptr, (uint32_t*)nullptr);
+                   lbbox, cand_cnt, (const int32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
         GPK_TRY(exclusive_scan_i32(cand_cnt, n, cand_off, nullptr, btot, s));
         GPK_HIP(hipMemcpyAsync(&n_cand, cand_off + n, sizeof n_cand, hipMemcpyDeviceToHost, s));
         GPK_HIP(hipStreamSynchronize(s));
@@ -746,24 +750,27 @@ static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, co
     };
     rc = stage1();
     if (rc != GPK_OK) return done(rc);
-    uint32_t* cand_r = nullptr;
+    uint32_t *cand_r = nullptr, *cand_l = nullptr;
     uint8_t* hit = nullptr;
     {
         hipError_t e = hipMalloc((void**)&cand_r, sizeof(uint32_t) * (size_t)(n_cand > 0 ? n_cand : 1));
         owned[1] = cand_r;
+        if (e == hipSuccess) e = hipMalloc((void**)&cand_l, sizeof(uint32_t) * (size_t)(n_cand > 0 ? n_cand : 1));
+        owned[3] = cand_l;
         if (e == hipSuccess) e = hipMalloc((void**)&hit, (size_t)(n_cand > 0 ? n_cand : 1));
         owned[2] = hit;
         if (e != hipSuccess) return done(fail(GPK_ERR_OOM, "spatial_join: candidate buffers (%d pairs): %s", n_cand, hipGetErrorString(e)));
     }
     auto stage23 = [&]() -> int32_t {
         GPK_LAUNCH("gpk_bbox_cand_fill", bbox_cand_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, left->d, right->d, right_index->v,
-                   lbbox, cand_cnt, (const int32_t*)cand_off, cand_r);
+                   lbbox, cand_cnt, (const int32_t*)cand_off, cand_r, cand_l);
         if (n_cand > 0) {
             int64_t blocks = ((int64_t)n_cand + (256 / JOIN_GS) - 1) / (256 / JOIN_GS);
             const int64_t cap = (int64_t)cu_count() * 64;
             if (blocks > cap) blocks = cap;
             GPK_LAUNCH("gpk_pair_refine", pair_refine_kernel, dim3((unsigned)blocks), dim3(256), 0, s, left->d, right->d,
-                       (const int32_t*)cand_off, (const uint32_t*)cand_r, (int64_t)n_cand, hit);
+                       (const uint32_t*)cand_l, (const uint32_t*)cand_r, (int64_t)n_cand, (const double4*)lbbox,
+                       right_index->v.bbox, hit);
         }
         GPK_LAUNCH("gpk_pair_count", pair_emit_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, n, (const int32_t*)cand_off,
                    (const uint32_t*)cand_r, (const uint8_t*)hit, counts, (const int32_t*)nullptr, left_row_base, (uint2*)nullptr, (int64_t)0);

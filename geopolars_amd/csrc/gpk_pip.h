@@ -69,10 +69,10 @@ __device__ __forceinline__ int ring_pos_group(const PipView& pv, int r, double p
         const double4 ed = pv.slab_edges[k];
         on |= (int)dev::ring_edge(ed.x, ed.y, ed.z, ed.w, px, py, wn);
     }
-#pragma unroll
-    for (int o = GS / 2; o > 0; o >>= 1) {
-        wn += __shfl_xor(wn, o, 64);
-        on |= __shfl_xor(on, o, 64);
+    {  // one packed reduction: winding sum in the high half, on-boundary count in the low half
+        const int packed = dev::group_sum<GS>(wn * 65536 + on);
+        wn = packed >> 16;
+        on = packed & 0xFFFF;
     }
     if (on) return dev::POS_BOUNDARY;
     return wn == 0 ? dev::POS_OUTSIDE : dev::POS_INSIDE;
@@ -87,10 +87,10 @@ __device__ __forceinline__ int part_pos_group_from_edges(const PipView& pv, cons
         const double4 ed = pv.slab_edges[e0 + k];
         on |= (int)dev::ring_edge(ed.x, ed.y, ed.z, ed.w, px, py, wn);
     }
-#pragma unroll
-    for (int o = GS / 2; o > 0; o >>= 1) {
-        wn += __shfl_xor(wn, o, 64);
-        on |= __shfl_xor(on, o, 64);
+    {  // one packed reduction: winding sum in the high half, on-boundary count in the low half
+        const int packed = dev::group_sum<GS>(wn * 65536 + on);
+        wn = packed >> 16;
+        on = packed & 0xFFFF;
     }
     if (on) return dev::POS_BOUNDARY;
     if (wn == 0) return dev::POS_OUTSIDE;

@@ -126,82 +126,213 @@ __device__ inline bool polygonal_intersects_polygonal(const DevGeo& a, int64_t i
 // vertex per ring decides containment (upstream tests every endpoint; the outcome is identical).
 template <int G>
 __device__ __forceinline__ bool group_any(bool v) {
-    int x = v ? 1 : 0;
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) x |= __shfl_xor(x, o, 64);
-    return x != 0;
+    return dev::group_or<G>(v ? 1 : 0) != 0;
 }
 
+// Ring-relative position of (cx, cy), G lanes striding over the ring's edges: winding contributions add up, the
+// on-boundary flag ORs.  Same value on every lane of the group.
 template <int G>
-__device__ inline bool polygon_intersects_polygon_group(const DevGeo& a, int ar0, int ar1, const DevGeo& b, int br0, int br1, int lane) {
+__device__ inline int coord_pos_ring_group(const double2* __restrict__ ring, int n, double cx, double cy, int lane) {
+    if (n == 0) return dev::POS_OUTSIDE;
+    if (n == 1) {
+        const double2 s = ring[0];
+        return (cx == s.x && cy == s.y) ? dev::POS_BOUNDARY : dev::POS_OUTSIDE;
+    }
+    int wn = 0, on = 0;
+    for (int i = lane; i + 1 < n; i += G) {
+        const double2 s = ring[i], e = ring[i + 1];
+        on |= dev::ring_edge(s.x, s.y, e.x, e.y, cx, cy, wn) ? 1 : 0;
+    }
+    {  // one packed reduction: winding sum in the high half, on-boundary count in the low half
+        const int packed = dev::group_sum<G>(wn * 65536 + on);
+        wn = packed >> 16;
+        on = packed & 0xFFFF;
+    }
+    if (on) return dev::POS_BOUNDARY;
+    return wn == 0 ? dev::POS_OUTSIDE : dev::POS_INSIDE;
+}
+// Polygon::coordinate_position, cooperatively (dev::polygon_pos is the one-lane form)
+template <int G>
+__device__ inline int polygon_pos_group(const DevGeo& a, int r0, int r1, double cx, double cy, int lane) {
+    if (r1 <= r0) return dev::POS_OUTSIDE;
+    int c0 = a.ring_off[r0], c1 = a.ring_off[r0 + 1];
+    if (c1 == c0) return dev::POS_OUTSIDE;
+    const int pe = coord_pos_ring_group<G>(a.xy + c0, c1 - c0, cx, cy, lane);
+    if (pe != dev::POS_INSIDE) return pe;
+    for (int r = r0 + 1; r < r1; ++r) {
+        c0 = a.ring_off[r];
+        c1 = a.ring_off[r + 1];
+        const int ph = coord_pos_ring_group<G>(a.xy + c0, c1 - c0, cx, cy, lane);
+        if (ph == dev::POS_BOUNDARY) return dev::POS_BOUNDARY;
+        if (ph == dev::POS_INSIDE) return dev::POS_OUTSIDE;
+    }
+    return dev::POS_INSIDE;
+}
+
+// bboxes of a polygon's exterior (.x.. of `ext`) and of all its rings (`all`), G lanes, same value on every lane
+// `known` (optional): the exterior's box when the caller already has it (bounds of a Polygon row)
+template <int G>
+__device__ inline void polygon_bboxes_group(const DevGeo& a, int r0, int r1, int lane, const double4* known, double4& ext, double4& all) {
+    double mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+    const int c0 = a.ring_off[r0], ce = a.ring_off[r0 + 1], c1 = a.ring_off[r1];
+    if (known) {
+        mnx = known->x; mny = known->y; mxx = known->z; mxy = known->w;
+    } else {
+        for (int i = c0 + lane; i < ce; i += G) {
+            const double2 p = a.xy[i];
+            mnx = fmin(mnx, p.x); mny = fmin(mny, p.y); mxx = fmax(mxx, p.x); mxy = fmax(mxy, p.y);
+        }
+        mnx = dev::group_min<G>(mnx); mny = dev::group_min<G>(mny); mxx = dev::group_max<G>(mxx); mxy = dev::group_max<G>(mxy);
+    }
+    ext = make_double4(mnx, mny, mxx, mxy);
+    if (ce < c1) {  // holes: invalid input may have them poke out of the exterior, and pruning must never change the answer
+        for (int i = ce + lane; i < c1; i += G) {
+            const double2 p = a.xy[i];
+            mnx = fmin(mnx, p.x); mny = fmin(mny, p.y); mxx = fmax(mxx, p.x); mxy = fmax(mxy, p.y);
+        }
+        mnx = dev::group_min<G>(mnx); mny = dev::group_min<G>(mny); mxx = dev::group_max<G>(mxx); mxy = dev::group_max<G>(mxy);
+    }
+    all = make_double4(mnx, mny, mxx, mxy);
+}
+
+// Same boolean as polygon_intersects_polygon, G lanes per pair, with WINDOW CLIPPING: two segments can only meet
+// inside the intersection of the two polygons' boxes, so
+//   1. B's segments whose box misses A's box are dropped; the survivors are compacted (ballot within the group)
+//      into a per-group LDS list of PP_LIST entries (endpoints, 32 B each); A's segments likewise into a second list;
+//   2. list x list: lane k owns entries k, k+G, ... of A's list and walks B's list (LDS broadcasts), with a
+//      group-wide early exit; lists that fill up are processed in chunks;
+//   3. if no boundary pair touches, a ring never changes side of the other polygon's boundary, so ONE vertex per ring
+//      decides containment (upstream tests every endpoint; the outcome is identical) — evaluated cooperatively.
+// Neighbouring polygons overlap in a small window, which takes the O(n*m) pruning loop down to the few segments
+// that can matter.  seg_list: 2 * PP_LIST double4 owned by this group (all lanes of a group sit in one wave).
+constexpr int PP_VOTE = 4;   // list entries between two group votes in the cross test
+constexpr int PP_LIST = 32;  // per list; a group owns two lists (2 * PP_LIST double4 = 2 KB)
+template <int G>
+__device__ inline bool polygon_intersects_polygon_group(const DevGeo& a, int ar0, int ar1, const DevGeo& b, int br0, int br1, int lane,
+                                                        double4* __restrict__ seg_list, const double4* a_box = nullptr,
+                                                        const double4* b_box = nullptr) {
+    static_assert(G <= 64 && (G & (G - 1)) == 0 && PP_LIST >= G, "group size");
     if (ar1 <= ar0 || br1 <= br0) return false;
     const int a_c0 = a.ring_off[ar0], a_c1 = a.ring_off[ar1];
     const int b_c0 = b.ring_off[br0], b_c1 = b.ring_off[br1];
     if (a.ring_off[ar0 + 1] == a_c0 || b.ring_off[br0 + 1] == b_c0) return false;  // empty exterior
-    // exterior bboxes, cooperatively (has_disjoint_bboxes)
-    double amnx = INFINITY, amny = INFINITY, amxx = -INFINITY, amxy = -INFINITY;
-    for (int i = a_c0 + lane; i < a.ring_off[ar0 + 1]; i += G) {
-        const double2 p = a.xy[i];
-        amnx = fmin(amnx, p.x); amny = fmin(amny, p.y); amxx = fmax(amxx, p.x); amxy = fmax(amxy, p.y);
-    }
-    double bmnx = INFINITY, bmny = INFINITY, bmxx = -INFINITY, bmxy = -INFINITY;
-    for (int i = b_c0 + lane; i < b.ring_off[br0 + 1]; i += G) {
-        const double2 p = b.xy[i];
-        bmnx = fmin(bmnx, p.x); bmny = fmin(bmny, p.y); bmxx = fmax(bmxx, p.x); bmxy = fmax(bmxy, p.y);
-    }
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) {
-        amnx = fmin(amnx, __shfl_xor(amnx, o, 64)); amny = fmin(amny, __shfl_xor(amny, o, 64));
-        amxx = fmax(amxx, __shfl_xor(amxx, o, 64)); amxy = fmax(amxy, __shfl_xor(amxy, o, 64));
-        bmnx = fmin(bmnx, __shfl_xor(bmnx, o, 64)); bmny = fmin(bmny, __shfl_xor(bmny, o, 64));
-        bmxx = fmax(bmxx, __shfl_xor(bmxx, o, 64)); bmxy = fmax(bmxy, __shfl_xor(bmxy, o, 64));
-    }
-    if (amxx < bmnx || amxy < bmny || bmxx < amnx || bmxy < amny) return false;
+    double4 ea, fa, eb, fb;
+    polygon_bboxes_group<G>(a, ar0, ar1, lane, a_box, ea, fa);
+    polygon_bboxes_group<G>(b, br0, br1, lane, b_box, eb, fb);
+    if (ea.z < eb.x || ea.w < eb.y || eb.z < ea.x || eb.w < ea.y) return false;  // has_disjoint_bboxes (exteriors)
 
-    // boundary x boundary: coordinate index j of B starts a segment unless it is the last coordinate of its ring
-    for (int j0 = b_c0; j0 < b_c1; j0 += G) {
-        const int j = j0 + lane;
-        bool found = false;
-        if (j + 1 < b_c1) {
-            // ring of j: B has few rings; find by scan
-            int rb = br0;
-            while (rb + 1 < br1 && b.ring_off[rb + 1] <= j) ++rb;
-            if (j + 1 < b.ring_off[rb + 1]) {
-                const double2 q0 = b.xy[j], q1 = b.xy[j + 1];
-                const double qlx = fmin(q0.x, q1.x), qhx = fmax(q0.x, q1.x), qly = fmin(q0.y, q1.y), qhy = fmax(q0.y, q1.y);
-                for (int ra = ar0; ra < ar1 && !found; ++ra) {
-                    const int a0 = a.ring_off[ra], a1 = a.ring_off[ra + 1];
-                    for (int i = a0; i + 1 < a1; ++i) {
-                        const double2 p0 = a.xy[i], p1 = a.xy[i + 1];
-                        if (fmax(p0.x, p1.x) < qlx || fmin(p0.x, p1.x) > qhx || fmax(p0.y, p1.y) < qly || fmin(p0.y, p1.y) > qhy) continue;
-                        if (line_intersects_line(p0, p1, q0, q1)) {
+    const int gbase = (int)(threadIdx.x & 63) & ~(G - 1);  // first lane of this group within its wave
+    const unsigned long long gmask_all = G == 64 ? ~0ull : ((1ull << G) - 1ull);
+    double4* __restrict__ list_b = seg_list;            // in-window segments of B
+    double4* __restrict__ list_a = seg_list + PP_LIST;  // in-window segments of A
+    auto lds_sync = [] {  // the lanes of a group sit in one wave: a compiler-level fence orders the LDS traffic
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // one round of compaction: lane's segment (c, c + 1) of polygon `g` is appended to `list` when its box meets `box`
+    auto append_round = [&](const DevGeo& g, int r0, int r1, int c_end, int c, const double4& box, double4* list, int& m) {
+        bool keep = false;
+        double2 q0 = make_double2(0.0, 0.0), q1 = q0;
+        if (c + 1 < c_end) {
+            int r = r0;  // ring of c: few rings; find by scan
+            while (r + 1 < r1 && g.ring_off[r + 1] <= c) ++r;
+            if (c + 1 < g.ring_off[r + 1]) {
+                q0 = g.xy[c];
+                q1 = g.xy[c + 1];
+                keep = !(fmax(q0.x, q1.x) < box.x || fmin(q0.x, q1.x) > box.z || fmax(q0.y, q1.y) < box.y || fmin(q0.y, q1.y) > box.w);
+            }
+        }
+        const unsigned long long mine = (__ballot(keep) >> gbase) & gmask_all;
+        if (keep) list[m + __popcll(mine & ((1ull << lane) - 1ull))] = make_double4(q0.x, q0.y, q1.x, q1.y);
+        m += __popcll(mine);
+    };
+    // every segment of list_a[0..ma) against every segment of list_b[0..mb): lane k owns entries k, k + G, ... of A
+    auto cross = [&](int ma, int mb) -> bool {
+#if defined(GPK_PP_ABLATE) && GPK_PP_ABLATE == 1
+        return false;
+#endif
+        lds_sync();
+        bool hit = false;
+        for (int i0 = 0; i0 < ma && !hit; i0 += G) {
+            const bool active = i0 + lane < ma;
+            const double4 pa = active ? list_a[i0 + lane] : make_double4(0.0, 0.0, 0.0, 0.0);
+            const double2 p0 = make_double2(pa.x, pa.y), p1 = make_double2(pa.z, pa.w);
+            const double plx = fmin(p0.x, p1.x), phx = fmax(p0.x, p1.x), ply = fmin(p0.y, p1.y), phy = fmax(p0.y, p1.y);
+            // B's list in steps of PP_VOTE entries with a group vote in between: most candidate pairs do intersect, and
+            // the first crossing found ends the whole pair
+            for (int e0 = 0; e0 < mb && !hit; e0 += PP_VOTE) {
+                bool found = false;
+                if (active) {
+                    const int e1 = e0 + PP_VOTE < mb ? e0 + PP_VOTE : mb;
+                    for (int e = e0; e < e1; ++e) {
+                        const double4 q = list_b[e];
+                        if (fmax(q.x, q.z) < plx || fmin(q.x, q.z) > phx || fmax(q.y, q.w) < ply || fmin(q.y, q.w) > phy) continue;
+                        if (line_intersects_line(p0, p1, make_double2(q.x, q.y), make_double2(q.z, q.w))) {
                             found = true;
                             break;
                         }
                     }
                 }
+                hit = group_any<G>(found);
             }
         }
-        if (group_any<G>(found)) return true;
+        __builtin_amdgcn_wave_barrier();  // the lists may be overwritten after this point
+        return hit;
+    };
+    // all of A (compacted in chunks of at most PP_LIST) against the current chunk of B
+    auto against_a = [&](int mb) -> bool {
+        int ma = 0;
+        for (int i0 = a_c0; i0 < a_c1; i0 += G) {
+            append_round(a, ar0, ar1, a_c1, i0 + lane, fb, list_a, ma);
+            if (ma + G > PP_LIST) {
+                if (cross(ma, mb)) return true;
+                ma = 0;
+            }
+        }
+        return ma > 0 && cross(ma, mb);
+    };
+
+#if defined(GPK_PP_ABLATE) && GPK_PP_ABLATE == 4
+    return ea.x > fb.z * 3.0;  // bboxes only
+#endif
+    int mb = 0;  // entries in list_b (uniform within the group)
+    for (int j0 = b_c0; j0 < b_c1; j0 += G) {
+        append_round(b, br0, br1, b_c1, j0 + lane, fa, list_b, mb);
+        if (mb + G > PP_LIST) {  // the next round might not fit
+            if (against_a(mb)) return true;
+            mb = 0;
+        }
     }
+    if (mb > 0 && against_a(mb)) return true;
+
+#if defined(GPK_PP_ABLATE) && GPK_PP_ABLATE == 2
+    return false;
+#endif
+#if defined(GPK_PP_ABLATE) && GPK_PP_ABLATE == 3
+    return mb > 1000;
+#endif
     // containment: one vertex per ring of B against A, then A's exterior against B
-    bool inside = false;
-    for (int rb = br0 + lane; rb < br1; rb += G) {
+    for (int rb = br0; rb < br1; ++rb) {
         const int c = b.ring_off[rb];
         if (b.ring_off[rb + 1] > c) {
             const double2 q = b.xy[c];
-            inside |= dev::polygon_pos(a, ar0, ar1, q.x, q.y) != dev::POS_OUTSIDE;
+            if (polygon_pos_group<G>(a, ar0, ar1, q.x, q.y, lane) != dev::POS_OUTSIDE) return true;
         }
     }
-    if (lane == 0) {
-        const double2 p = a.xy[a_c0];
-        inside |= dev::polygon_pos(b, br0, br1, p.x, p.y) != dev::POS_OUTSIDE;
-    }
-    return group_any<G>(inside);
+    const double2 p = a.xy[a_c0];
+    return polygon_pos_group<G>(b, br0, br1, p.x, p.y, lane) != dev::POS_OUTSIDE;
 }
 
 template <int G>
-__device__ inline bool polygonal_intersects_polygonal_group(const DevGeo& a, int64_t ia, const DevGeo& b, int64_t ib, int lane) {
+// a_boxes / b_boxes (optional): per-geometry exterior bounds (gpk_bounds layout); used for Polygon rows, where the
+// geometry's bounds ARE its one exterior's box
+__device__ inline bool polygonal_intersects_polygonal_group(const DevGeo& a, int64_t ia, const DevGeo& b, int64_t ib, int lane,
+                                                            double4* __restrict__ seg_list, const double4* a_boxes = nullptr,
+                                                            const double4* b_boxes = nullptr) {
+    const double4 abox = a_boxes ? a_boxes[ia] : make_double4(0, 0, 0, 0), bbox = b_boxes ? b_boxes[ib] : make_double4(0, 0, 0, 0);
+    const double4* ah = a_boxes && a.type == GPK_GEOM_POLYGON ? &abox : nullptr;
+    const double4* bh = b_boxes && b.type == GPK_GEOM_POLYGON ? &bbox : nullptr;
     int a0, a1, b0, b1;
     dev::geom_parts(a, ia, a0, a1);
     dev::geom_parts(b, ib, b0, b1);
@@ -211,7 +342,7 @@ __device__ inline bool polygonal_intersects_polygonal_group(const DevGeo& a, int
         for (int q = b0; q < b1; ++q) {
             int br0, br1;
             dev::part_rings(b, q, br0, br1);
-            if (polygon_intersects_polygon_group<G>(a, ar0, ar1, b, br0, br1, lane)) return true;
+            if (polygon_intersects_polygon_group<G>(a, ar0, ar1, b, br0, br1, lane, seg_list, ah, bh)) return true;
         }
     }
     return false;

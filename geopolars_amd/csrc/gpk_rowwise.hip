@@ -504,13 +504,15 @@ __global__ __launch_bounds__(256) void point_poly_predicate_kernel(DevGeo pts, D
 constexpr int PP_GS = 16;
 __global__ __launch_bounds__(256) void poly_poly_intersects_kernel(DevGeo a, DevGeo b, const uint32_t* __restrict__ rows,
                                                                     uint8_t* __restrict__ out) {
+    __shared__ double4 seg_lists[(256 / PP_GS) * 2 * PP_LIST];
     const int lane = threadIdx.x & (PP_GS - 1);
+    double4* seg_list = seg_lists + (threadIdx.x / PP_GS) * 2 * PP_LIST;
     const int64_t groups = (int64_t)gridDim.x * (256 / PP_GS);
     for (int64_t i = (int64_t)blockIdx.x * (256 / PP_GS) + threadIdx.x / PP_GS; i < a.n_geoms; i += groups) {
         const int64_t j = rows ? (int64_t)rows[i] : i;
         bool hit = false;
         if (dev::valid_row(a.validity, i) && dev::valid_row(b.validity, j))
-            hit = polygonal_intersects_polygonal_group<PP_GS>(a, i, b, j, lane);
+            hit = polygonal_intersects_polygonal_group<PP_GS>(a, i, b, j, lane, seg_list);
         if (lane == 0) out[i] = hit;
     }
 }

@@ -90,7 +90,7 @@ def join_pairs(
     n_pairs = C.c_int64(0)
     rh = r_index.handle if r_index is not None else None
     pred = PREDICATES[predicate]
-    capacity = max(1024, 2 * n)  # one call in the common case; the ABI reports the exact total when this is too small
+    capacity = max(1024, 4 * n)  # one call in the common case; the ABI reports the exact total when this is too small
     while True:
         pairs = np.empty((capacity, 2), dtype=np.uint32)
         rc = lib.gpk_spatial_join(

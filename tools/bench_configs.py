@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--c4", type=int, default=1_000_000)
 ap.add_argument("--c5-points", type=int, default=6_250_000)
 ap.add_argument("--c5-polys", type=int, default=1_000_000)
+ap.add_argument("--only", choices=["c4", "c5"], default=None)
 a = ap.parse_args()
 
 def t(f):
@@ -37,6 +38,8 @@ def kernel_ms(f, names):
     return out
 
 # ---- C4: polygon x polygon intersects join ------------------------------------------------------------
+if a.only == "c5":
+    a.c4 = 1000
 L = synth.clustered_polygons(a.c4, seed=41, mean_neighbours=4.0); R = synth.clustered_polygons(a.c4, seed=42, mean_neighbours=4.0)
 ls, rs = GeoSeries(L), GeoSeries(R)
 ls.device(); rs.device()
@@ -51,6 +54,8 @@ print(json.dumps({"config": "C4 share", "left": a.c4, "right": a.c4, "index_buil
 del ls, rs, idx
 
 # ---- C5: points within power-law multipolygons + area ---------------------------------------------------
+if a.only == "c4":
+    sys.exit(0)
 MP = synth.powerlaw_multipolygons(a.c5_polys, seed=51); P = synth.uniform_points(a.c5_points, seed=52)
 ms_, ps = GeoSeries(MP), GeoSeries(P)
 ms_.device(); ps.device()
