@@ -98,7 +98,9 @@ _PROTOS = {
         C.c_int32,
         [_VP, _VP, _VP, C.c_int32, C.c_uint32, _VP, _VP, C.c_int64, C.POINTER(C.c_int64), C.c_int32, _VP],
     ),
+    "gpk_spatial_join_async": (C.c_int32, [_VP, _VP, _VP, C.c_int32, C.c_uint32, _VP, _VP, C.c_int64, _VP, _VP]),
     "gpk_profile_enable": (C.c_int32, [C.c_int32]),
+    "gpk_profile_filter": (C.c_int32, [C.c_char_p]),
     "gpk_profile_reset": (C.c_int32, []),
     "gpk_profile_query": (C.c_int32, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }

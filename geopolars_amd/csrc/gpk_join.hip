@@ -806,6 +806,68 @@ static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, co
     return done(GPK_OK);
 }
 
+// Enqueues the point x polygonal join on `s` (memset of the totals, pip_tile, pip_write) and returns without waiting.
+// Device scratch comes from the calling thread's workspace; *total_out (device or device-mapped, may be NULL) receives
+// the number of hits when the stream gets there.
+static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* right, const gpk_index* right_index, uint32_t left_row_base,
+                                uint32_t* out_counts, uint32_t* out_pairs, int64_t pair_capacity, bool host_out,
+                                unsigned long long* total_out, hipStream_t s, uint32_t** counts_dev_out, uint32_t** pairs_dev_out,
+                                unsigned long long** grand_out) {
+    const int64_t n = left->d.n_geoms;
+    const int64_t n_blocks = (n + PIP_TILE - 1) / PIP_TILE;
+    const bool want_pairs = pair_capacity > 0;
+    const size_t counts_bytes = sizeof(uint32_t) * (size_t)n;
+    const size_t pairs_bytes = sizeof(uint32_t) * 2 * (size_t)pair_capacity;
+    const int64_t n_super = (n_blocks >> PIP_SUPER_SHIFT) + 1;
+    const int64_t n_wblocks = (n + PIP_WTILE - 1) / PIP_WTILE;
+    const uint32_t multi_cap = (uint32_t)(n < (int64_t)0x18000000 ? 2 * n + 1024 : (int64_t)0x30000000);  // words in the multi-hit pool
+    size_t need = align256(counts_bytes + 64) /*code*/ + align256(sizeof(unsigned long long) * (size_t)(n_blocks + n_super + 3)) +
+                  align256(sizeof(uint32_t) * (size_t)multi_cap) + 1024;
+    if (host_out && out_counts) need += align256(counts_bytes);
+    if (host_out && want_pairs) need += align256(pairs_bytes);
+    int32_t rc = workspace().begin(need);
+    if (rc != GPK_OK) return rc;
+    uint32_t* code = (uint32_t*)workspace().take(counts_bytes + 64);
+    unsigned long long* btot = (unsigned long long*)workspace().take(sizeof(unsigned long long) * (size_t)(n_blocks + n_super + 3));
+    unsigned long long* stot = btot + n_blocks;     // n_super super-tile totals
+    unsigned long long* grand = stot + n_super;     // total hits
+    uint32_t* multi_top = (uint32_t*)(grand + 1);   // words used in the multi-hit pool (zeroed with the totals)
+    uint32_t* multi_pool = (uint32_t*)workspace().take(sizeof(uint32_t) * (size_t)multi_cap);
+    uint32_t* counts_dev = out_counts ? (host_out ? (uint32_t*)workspace().take(counts_bytes) : out_counts) : nullptr;
+    uint32_t* pairs_dev = want_pairs ? (host_out ? (uint32_t*)workspace().take(pairs_bytes) : out_pairs) : nullptr;
+
+
+#define J_LAUNCH(...)                          \
+    do {                                       \
+        auto _f = [&]() -> int32_t {           \
+            GPK_LAUNCH(__VA_ARGS__);           \
+            return GPK_OK;                     \
+        };                                     \
+        int32_t _rc = _f();                    \
+        if (_rc != GPK_OK) return _rc;         \
+    } while (0)
+
+    {
+        const hipError_t me = hipMemsetAsync(stot, 0, sizeof(unsigned long long) * (size_t)(n_super + 2), s);
+        if (me != hipSuccess) return fail(GPK_ERR_DEVICE, "spatial_join: %s", hipGetErrorString(me));
+    }
+    if (right_index->pip.R > 0)
+        J_LAUNCH("gpk_pip_tile", pip_tile_kernel<true>, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
+                 right_index->v, right_index->pip, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top);
+    else
+        J_LAUNCH("gpk_pip_tile_generic", pip_tile_kernel<false>, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
+                 right_index->v, right_index->pip, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top);
+    // the writer also produces the grand total; in count-only mode it runs without a pair buffer
+    J_LAUNCH("gpk_pip_write", pip_write_kernel, dim3((unsigned)n_wblocks), dim3(WR_BLOCK), 0, s, left->d, right->d, right_index->v,
+             code, btot, stot, (const uint32_t*)multi_pool, n_blocks, left_row_base, (uint2*)pairs_dev, pair_capacity, grand, total_out);
+#undef J_LAUNCH
+
+    *counts_dev_out = counts_dev;
+    *pairs_dev_out = pairs_dev;
+    *grand_out = grand;
+    return GPK_OK;
+}
+
 }  // namespace gpk
 
 using namespace gpk;
@@ -963,56 +1025,17 @@ int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right, co
     const int64_t n = left->d.n_geoms;
     if (n == 0) return done(GPK_OK);
     if (polypoly) return done(bbox_join(left, right, right_index, left_row_base, out_counts, out_pairs, pair_capacity, n_pairs, out_space, s));
-    const int64_t n_blocks = (n + PIP_TILE - 1) / PIP_TILE;
     const bool host_out = out_space != GPK_MEM_DEVICE;
     const bool want_pairs = pair_capacity > 0;
     const size_t counts_bytes = sizeof(uint32_t) * (size_t)n;
     const size_t pairs_bytes = sizeof(uint32_t) * 2 * (size_t)pair_capacity;
-    const int64_t n_super = (n_blocks >> PIP_SUPER_SHIFT) + 1;
-    const int64_t n_wblocks = (n + PIP_WTILE - 1) / PIP_WTILE;
-    const uint32_t multi_cap = (uint32_t)(n < (int64_t)0x18000000 ? 2 * n + 1024 : (int64_t)0x30000000);  // words in the multi-hit pool
-    size_t need = align256(counts_bytes + 64) /*code*/ + align256(sizeof(unsigned long long) * (size_t)(n_blocks + n_super + 3)) +
-                  align256(sizeof(uint32_t) * (size_t)multi_cap) + 1024;
-    if (host_out && out_counts) need += align256(counts_bytes);
-    if (host_out && want_pairs) need += align256(pairs_bytes);
-    int32_t rc = workspace().begin(need);
-    if (rc != GPK_OK) return done(rc);
-    uint32_t* code = (uint32_t*)workspace().take(counts_bytes + 64);
-    unsigned long long* btot = (unsigned long long*)workspace().take(sizeof(unsigned long long) * (size_t)(n_blocks + n_super + 3));
-    unsigned long long* stot = btot + n_blocks;     // n_super super-tile totals
-    unsigned long long* grand = stot + n_super;     // total hits
-    uint32_t* multi_top = (uint32_t*)(grand + 1);   // words used in the multi-hit pool (zeroed with the totals)
-    uint32_t* multi_pool = (uint32_t*)workspace().take(sizeof(uint32_t) * (size_t)multi_cap);
-    uint32_t* counts_dev = out_counts ? (host_out ? (uint32_t*)workspace().take(counts_bytes) : out_counts) : nullptr;
-    uint32_t* pairs_dev = want_pairs ? (host_out ? (uint32_t*)workspace().take(pairs_bytes) : out_pairs) : nullptr;
-
     static thread_local unsigned long long* pinned_total = nullptr;  // device-mapped host word: no D2H copy per call
     if (!pinned_total && hipHostMalloc((void**)&pinned_total, 64, hipHostMallocMapped) != hipSuccess) pinned_total = nullptr;
-
-#define J_LAUNCH(...)                          \
-    do {                                       \
-        auto _f = [&]() -> int32_t {           \
-            GPK_LAUNCH(__VA_ARGS__);           \
-            return GPK_OK;                     \
-        };                                     \
-        int32_t _rc = _f();                    \
-        if (_rc != GPK_OK) return done(_rc);   \
-    } while (0)
-
-    {
-        const hipError_t me = hipMemsetAsync(stot, 0, sizeof(unsigned long long) * (size_t)(n_super + 2), s);
-        if (me != hipSuccess) return done(fail(GPK_ERR_DEVICE, "spatial_join: %s", hipGetErrorString(me)));
-    }
-    if (right_index->pip.R > 0)
-        J_LAUNCH("gpk_pip_tile", pip_tile_kernel<true>, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
-                 right_index->v, right_index->pip, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top);
-    else
-        J_LAUNCH("gpk_pip_tile_generic", pip_tile_kernel<false>, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
-                 right_index->v, right_index->pip, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top);
-    // the writer also produces the grand total; in count-only mode it runs without a pair buffer
-    J_LAUNCH("gpk_pip_write", pip_write_kernel, dim3((unsigned)n_wblocks), dim3(WR_BLOCK), 0, s, left->d, right->d, right_index->v,
-             code, btot, stot, (const uint32_t*)multi_pool, n_blocks, left_row_base, (uint2*)pairs_dev, pair_capacity, grand, pinned_total);
-#undef J_LAUNCH
+    uint32_t *counts_dev = nullptr, *pairs_dev = nullptr;
+    unsigned long long* grand = nullptr;
+    int32_t rc = pip_join_enqueue(left, right, right_index, left_row_base, out_counts, out_pairs, pair_capacity, host_out, pinned_total, s,
+                                  &counts_dev, &pairs_dev, &grand);
+    if (rc != GPK_OK) return done(rc);
 
     unsigned long long total = 0;
     hipError_t e = hipSuccess;
@@ -1036,6 +1059,31 @@ int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right, co
         return done(fail(GPK_ERR_CAPACITY, "spatial_join: %lld pairs but capacity %lld", (long long)total,
                          (long long)pair_capacity));
     return done(GPK_OK);
+}
+
+int32_t gpk_spatial_join_async(const gpk_geoarray* left, const gpk_geoarray* right, const gpk_index* right_index, int32_t predicate,
+                               uint32_t left_row_base, uint32_t* out_counts, uint32_t* out_pairs, int64_t pair_capacity,
+                               int64_t* n_pairs_dev, void* stream) {
+    if (!left || !right || !right_index) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument (the stream-ordered join needs a prebuilt index)");
+    if (predicate != GPK_PRED_INTERSECTS && predicate != GPK_PRED_CONTAINS && predicate != GPK_PRED_WITHIN)
+        return fail(GPK_ERR_INVALID_ARGUMENT, "unknown predicate %d", predicate);
+    if (pair_capacity < 0 || (pair_capacity > 0 && !out_pairs))
+        return fail(GPK_ERR_INVALID_ARGUMENT, "pair_capacity without out_pairs");
+    GPK_TRY(require_device());
+    if (!(left->d.type == GPK_GEOM_POINT && is_polygonal(right->d.type)))
+        return fail(GPK_ERR_MISMATCHED_GEOMETRY,
+                    "spatial_join_async: only point x polygon/multipolygon is stream-ordered (left type %d x right type %d)",
+                    left->d.type, right->d.type);
+    if (right_index->n_geoms != right->d.n_geoms) return fail(GPK_ERR_INVALID_ARGUMENT, "right_index was built over a different array");
+    hipStream_t s = (hipStream_t)stream;
+    if (left->d.n_geoms == 0) {
+        if (n_pairs_dev) GPK_HIP(hipMemsetAsync(n_pairs_dev, 0, sizeof(int64_t), s));
+        return GPK_OK;
+    }
+    uint32_t *counts_dev, *pairs_dev;
+    unsigned long long* grand;
+    return pip_join_enqueue(left, right, right_index, left_row_base, out_counts, out_pairs, pair_capacity, /*host_out=*/false,
+                            (unsigned long long*)n_pairs_dev, s, &counts_dev, &pairs_dev, &grand);
 }
 
 }  // extern "C"

@@ -75,14 +75,17 @@ struct ProfRec {
 };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
+static std::string g_prof_filter;  // when non-empty only kernels whose name contains it are bracketed
 static std::vector<ProfRec*> g_prof;
 static std::vector<ProfRec*> g_prof_pool;  // recycled records: hipEventCreate is not free inside a timed region
 
 bool profiling_enabled() { return g_prof_on; }
 void profile_begin(const char* name, hipStream_t s, void** token) {
     ProfRec* r = nullptr;
+    *token = nullptr;
     {
         std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (!g_prof_filter.empty() && !strstr(name, g_prof_filter.c_str())) return;
         if (!g_prof_pool.empty()) {
             r = g_prof_pool.back();
             g_prof_pool.pop_back();
@@ -315,6 +318,11 @@ int32_t gpk_geoarray_nbytes(const gpk_geoarray* a, int64_t* out_bytes) {
 // ---- profiling ABI ---------------------------------------------------------------------------
 int32_t gpk_profile_enable(int32_t on) {
     g_prof_on = on != 0;
+    return GPK_OK;
+}
+int32_t gpk_profile_filter(const char* substr) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_filter = substr ? substr : "";
     return GPK_OK;
 }
 int32_t gpk_profile_reset(void) {

@@ -125,6 +125,26 @@ def join_pairs_device(left: DeviceGeoArray, right: DeviceGeoArray, r_index: Spat
     return int(n_pairs.value)
 
 
+def join_pairs_enqueue(left: DeviceGeoArray, right: DeviceGeoArray, r_index: SpatialIndex, predicate: str, out_counts, out_pairs, n_pairs_out, left_row_base: int = 0, stream: int = 0) -> None:
+    """Stream-ordered variant of join_pairs_device (gpk_spatial_join_async): the join is enqueued on `stream` and
+    this returns without waiting.  n_pairs_out: a 1-element int64 CUDA tensor that receives the total (read it
+    after synchronising; pairs beyond out_pairs' capacity are dropped)."""
+    _abi.check(
+        _abi.lib().gpk_spatial_join_async(
+            left.handle,
+            right.handle,
+            r_index.handle,
+            PREDICATES[predicate],
+            left_row_base,
+            out_counts.data_ptr() if out_counts is not None else None,
+            out_pairs.data_ptr() if out_pairs is not None else None,
+            out_pairs.shape[0] if out_pairs is not None else 0,
+            n_pairs_out.data_ptr() if n_pairs_out is not None else None,
+            stream,
+        )
+    )
+
+
 def spatial_join(lhs, rhs, options: Optional[SpatialJoinArgs] = None):
     """spatial_join(lhs, rhs, SpatialJoinArgs) over pyarrow Tables with a WKB `geometry` column
     (spatial_index.rs:44-45).  Returns a pyarrow Table shaped like the reference's result:

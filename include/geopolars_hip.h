@@ -189,9 +189,28 @@ int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right,
                          uint32_t* out_counts, uint32_t* out_pairs, int64_t pair_capacity,
                          int64_t* n_pairs, int32_t out_space, void* stream);
 
+/*
+ * Stream-ordered form of gpk_spatial_join for callers that keep everything in HBM (the idiom a pipeline of
+ * kernels on one HIP stream wants; the reference's call is synchronous, spatial_index.rs:44-58): the join is
+ * ENQUEUED on `stream` and the call returns without waiting.
+ *   - point x polygon / multipolygon only, `right_index` required (nothing to build or free behind the stream);
+ *   - out_counts / out_pairs are device buffers (either may be NULL as above);
+ *   - *n_pairs_dev (device or device-mapped host memory, may be NULL) receives the total number of hits when the
+ *     stream reaches that point; pairs beyond pair_capacity are dropped, so compare the two after synchronising.
+ * Scratch comes from the calling thread's workspace: stream-ordered calls of one thread must use one stream (or
+ * be separated by a synchronisation).
+ */
+int32_t gpk_spatial_join_async(const gpk_geoarray* left, const gpk_geoarray* right,
+                               const gpk_index* right_index, int32_t predicate, uint32_t left_row_base,
+                               uint32_t* out_counts, uint32_t* out_pairs, int64_t pair_capacity,
+                               int64_t* n_pairs_dev, void* stream);
+
 /* ---- profiling hooks (bench.py's roofline leg) -------------------------------------------- */
 /* When enabled every kernel launch is bracketed by hipEvents on its stream. */
 int32_t gpk_profile_enable(int32_t on);
+/* Restrict the bracketing to kernels whose name contains `substr` (NULL or "" = every kernel).  Every event pair
+ * drains the stream around its kernel (a few microseconds), so a timed region brackets only what it reports. */
+int32_t gpk_profile_filter(const char* substr);
 int32_t gpk_profile_reset(void);
 /* accumulated milliseconds + launch count of kernels whose name contains `substr` */
 int32_t gpk_profile_query(const char* substr, double* out_ms, int64_t* out_launches);

@@ -177,3 +177,34 @@ def test_join_from_threads(gpk, oracle):
         t.join()
     for k in range(4):
         assert np.array_equal(results[k], expected[k])
+
+
+def test_stream_ordered_join_matches_blocking_join(gpk, oracle):
+    """gpk_spatial_join_async: several joins queued on one stream without a host wait in between give the same
+    counts / pairs / total as the blocking call and the oracle; pairs beyond the capacity are dropped, the total is not."""
+    import torch
+
+    from geopolars_amd.spatial_index import join_pairs_enqueue
+
+    polys_h = synth.star_polygons(300, 24)
+    pts_h = synth.uniform_points(200_000, seed=7)
+    exp_pairs, exp_counts, _ = oracle.spatial_join(pts_h, polys_h, "intersects", mode=1)
+    polys, pts = GeoSeries(polys_h), GeoSeries(pts_h)
+    idx = SpatialIndex(polys)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for cap in (len(pts_h.xy), 1000, 0):
+        counts = torch.full((len(pts_h.xy),), -1, dtype=torch.int32, device=dev)
+        pairs = torch.full((max(cap, 1), 2), -1, dtype=torch.int32, device=dev)
+        total = torch.full((1,), -1, dtype=torch.int64, device=dev)
+        join_pairs_enqueue(pts.device(), polys.device(), idx, "intersects", counts, pairs if cap else None, total, stream=stream)
+        outs.append((cap, counts, pairs, total))
+    torch.cuda.synchronize()
+    for cap, counts, pairs, total in outs:
+        assert int(total.item()) == len(exp_pairs)
+        assert np.array_equal(counts.cpu().numpy().view(np.uint32), exp_counts)
+        k = min(cap, len(exp_pairs))
+        assert np.array_equal(pairs.cpu().numpy().view(np.uint32)[:k], exp_pairs[:k])
+        if cap:
+            assert np.all(pairs.cpu().numpy()[k:] == -1)  # nothing written past the capacity / the total
