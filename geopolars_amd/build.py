@@ -31,6 +31,7 @@ SOURCES = [
     "gpk_hull.hip",
     "gpk_wkb.cpp",
     "gpk_wkb_device.hip",
+    "gpk_wkb_encode.hip",
 ]
 
 FLAGS = [
@@ -94,6 +95,7 @@ def build_variant(name: str, defines: list[str]) -> str:
         objs.append(obj)
     out = os.path.join(vdir, f"{name}.so")
     r = subprocess.run([_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out, *objs], capture_output=True, text=True)
+    shutil.rmtree(odir, ignore_errors=True)  # objects of a variant are not reused; keep the snapshot sent to the GPU box small
     if r.returncode != 0:
         raise RuntimeError(r.stderr)
     return out

@@ -255,3 +255,114 @@ extern "C" int32_t gpk_wkb_decode(const uint8_t* values, const int32_t* offsets,
     counts[4] = s.n_coords;
     return GPK_OK;
 }
+
+// ---- GeoArrow -> WKB, host side (from_geom_vec of util.rs:11-24) -------------------------------------
+// Two passes over the rows: sizes -> offsets, then the bytes.  Same byte stream as the device encoder
+// (gpk_wkb_encode.hip): little-endian ISO WKB, 2D, one type per column, zero-length records for null rows.
+namespace {
+struct Writer {
+    uint8_t* p;
+    void u8(uint8_t v) { *p++ = v; }
+    void u32(uint32_t v) {
+        memcpy(p, &v, 4);  // little-endian hosts only (x86-64 here)
+        p += 4;
+    }
+    void header(uint32_t type, uint32_t count) {
+        u8(1);
+        u32(type);
+        u32(count);
+    }
+    void coords(const double* xy, int64_t c0, int64_t c1) {
+        memcpy(p, xy + 2 * c0, sizeof(double) * 2 * (size_t)(c1 - c0));
+        p += 16 * (c1 - c0);
+    }
+};
+inline bool row_valid(const uint8_t* v, int64_t i) { return !v || ((v[i >> 3] >> (i & 7)) & 1); }
+int64_t host_row_bytes(const gpk_geoarrow_desc* d, int64_t g) {
+    if (!row_valid(d->validity, g)) return 0;
+    const int32_t* go = d->geom_offsets;
+    switch (d->geom_type) {
+    case GPK_GEOM_POINT: return 21;
+    case GPK_GEOM_LINESTRING: return 9 + 16 * (int64_t)(go[g + 1] - go[g]);
+    case GPK_GEOM_MULTIPOINT: return 9 + 21 * (int64_t)(go[g + 1] - go[g]);
+    case GPK_GEOM_POLYGON:
+    case GPK_GEOM_MULTILINESTRING:
+        return 9 + (d->geom_type == GPK_GEOM_POLYGON ? 4 : 9) * (int64_t)(go[g + 1] - go[g]) +
+               16 * (int64_t)(d->ring_offsets[go[g + 1]] - d->ring_offsets[go[g]]);
+    default: {
+        const int32_t r0 = d->part_offsets[go[g]], r1 = d->part_offsets[go[g + 1]];
+        return 9 + 9 * (int64_t)(go[g + 1] - go[g]) + 4 * (int64_t)(r1 - r0) + 16 * (int64_t)(d->ring_offsets[r1] - d->ring_offsets[r0]);
+    }
+    }
+}
+}  // namespace
+
+extern "C" int32_t gpk_wkb_encode(const gpk_geoarrow_desc* d, int32_t* out_offsets, uint8_t* out_values, int64_t capacity,
+                                  int64_t* n_bytes) {
+    using gpk::fail;
+    if (!d || !n_bytes) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (d->mem_space != GPK_MEM_HOST) return fail(GPK_ERR_INVALID_ARGUMENT, "gpk_wkb_encode takes host buffers (use gpk_geoarray_to_wkb for a device handle)");
+    if (capacity < 0 || (capacity > 0 && !out_values)) return fail(GPK_ERR_INVALID_ARGUMENT, "capacity without out_values");
+    const int t = d->geom_type;
+    if (t != GPK_GEOM_POINT && t != GPK_GEOM_LINESTRING && t != GPK_GEOM_POLYGON && t != GPK_GEOM_MULTIPOINT &&
+        t != GPK_GEOM_MULTILINESTRING && t != GPK_GEOM_MULTIPOLYGON)
+        return fail(GPK_ERR_MISMATCHED_GEOMETRY, "unknown geometry type %d", t);
+    if (d->n_geoms > 0 && ((t != GPK_GEOM_POINT && !d->geom_offsets) ||
+                           ((t == GPK_GEOM_POLYGON || t == GPK_GEOM_MULTILINESTRING || t == GPK_GEOM_MULTIPOLYGON) && !d->ring_offsets) ||
+                           (t == GPK_GEOM_MULTIPOLYGON && !d->part_offsets) || (d->n_coords > 0 && !d->xy)))
+        return fail(GPK_ERR_INVALID_OFFSETS, "missing offsets / coordinates for geometry type %d", t);
+    int64_t total = 0;
+    if (out_offsets) out_offsets[0] = 0;
+    for (int64_t g = 0; g < d->n_geoms; ++g) {
+        total += host_row_bytes(d, g);
+        if (total > 0x7FFFFFFFLL)
+            return fail(GPK_ERR_CAPACITY, "wkb_encode: the column does not fit BinaryArray<i32> offsets; encode row slices");
+        if (out_offsets) out_offsets[g + 1] = (int32_t)total;
+    }
+    *n_bytes = total;
+    if (!out_values) return GPK_OK;
+    if (total > capacity) return fail(GPK_ERR_CAPACITY, "wkb_encode: %lld bytes but capacity %lld", (long long)total, (long long)capacity);
+    Writer w{out_values};
+    const int32_t *go = d->geom_offsets, *po = d->part_offsets, *ro = d->ring_offsets;
+    auto polygon = [&](int32_t r0, int32_t r1) {
+        w.header(3u, (uint32_t)(r1 - r0));
+        for (int32_t r = r0; r < r1; ++r) {
+            w.u32((uint32_t)(ro[r + 1] - ro[r]));
+            w.coords(d->xy, ro[r], ro[r + 1]);
+        }
+    };
+    for (int64_t g = 0; g < d->n_geoms; ++g) {
+        if (!row_valid(d->validity, g)) continue;
+        switch (t) {
+        case GPK_GEOM_POINT:
+            w.u8(1);
+            w.u32(1u);
+            w.coords(d->xy, g, g + 1);
+            break;
+        case GPK_GEOM_LINESTRING:
+            w.header(2u, (uint32_t)(go[g + 1] - go[g]));
+            w.coords(d->xy, go[g], go[g + 1]);
+            break;
+        case GPK_GEOM_MULTIPOINT:
+            w.header(4u, (uint32_t)(go[g + 1] - go[g]));
+            for (int32_t i = go[g]; i < go[g + 1]; ++i) {
+                w.u8(1);
+                w.u32(1u);
+                w.coords(d->xy, i, i + 1);
+            }
+            break;
+        case GPK_GEOM_POLYGON: polygon(go[g], go[g + 1]); break;
+        case GPK_GEOM_MULTILINESTRING:
+            w.header(5u, (uint32_t)(go[g + 1] - go[g]));
+            for (int32_t l = go[g]; l < go[g + 1]; ++l) {
+                w.header(2u, (uint32_t)(ro[l + 1] - ro[l]));
+                w.coords(d->xy, ro[l], ro[l + 1]);
+            }
+            break;
+        default:
+            w.header(6u, (uint32_t)(go[g + 1] - go[g]));
+            for (int32_t q = go[g]; q < go[g + 1]; ++q) polygon(po[q], po[q + 1]);
+        }
+    }
+    return GPK_OK;
+}

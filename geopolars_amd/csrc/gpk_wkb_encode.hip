@@ -1,0 +1,207 @@
+// gpk_wkb_encode.hip — GeoArrow -> WKB on the GPU (second half: geometry-valued results —
+// centroid, convex_hull, envelope, affine_transform — leave the reference as WKB `binary` series through
+// from_geom_vec, geopolars/geopolars-geo/src/util.rs:11-24; this writes that column straight from the HBM-resident
+// GeoArrow buffers).  Little-endian ISO WKB, 2D, the single type of the array for every row; null rows are
+// zero-length (validity travels separately).
+//   sizes   : one lane per row -> bytes of its record (closed form from the offsets);
+//   scan    : exclusive scan -> Arrow i32 offsets;
+//   headers : one lane per row writes the geometry header (and the member headers of multi types);
+//   bodies  : 8 lanes per ring / linestring write `count` + coordinates (16-byte unaligned stores).
+// A record's bytes depend only on the row's own offsets, so every stage is a map; HBM-bound
+// (16 B read + 16 B written per coordinate).
+#include "gpk_device.h"
+#include "gpk_scan.h"
+
+namespace gpk {
+
+constexpr int WKB_GS = 8;  // lanes per ring / linestring in the body kernel
+
+__device__ __forceinline__ void put_u32(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+__device__ __forceinline__ void put_xy(uint8_t* p, double2 v) { __builtin_memcpy(p, &v, 16); }
+__device__ __forceinline__ void put_header(uint8_t* p, uint32_t type, uint32_t count) {  // byte order, type, count
+    p[0] = 1;
+    put_u32(p + 1, type);
+    put_u32(p + 5, count);
+}
+
+__device__ __forceinline__ int64_t wkb_row_bytes(const DevGeo& a, int64_t g) {
+    if (!dev::valid_row(a.validity, g)) return 0;
+    switch (a.type) {
+    case GPK_GEOM_POINT: return 21;
+    case GPK_GEOM_LINESTRING: return 9 + 16 * (int64_t)(a.geom_off[g + 1] - a.geom_off[g]);
+    case GPK_GEOM_MULTIPOINT: return 9 + 21 * (int64_t)(a.geom_off[g + 1] - a.geom_off[g]);
+    case GPK_GEOM_POLYGON:
+    case GPK_GEOM_MULTILINESTRING: {
+        const int r0 = a.geom_off[g], r1 = a.geom_off[g + 1];
+        const int64_t per = a.type == GPK_GEOM_POLYGON ? 4 : 9;
+        return 9 + per * (r1 - r0) + 16 * (int64_t)(a.ring_off[r1] - a.ring_off[r0]);
+    }
+    default: {  // MULTIPOLYGON
+        const int p0 = a.geom_off[g], p1 = a.geom_off[g + 1];
+        const int r0 = a.part_off[p0], r1 = a.part_off[p1];
+        return 9 + 9 * (int64_t)(p1 - p0) + 4 * (int64_t)(r1 - r0) + 16 * (int64_t)(a.ring_off[r1] - a.ring_off[r0]);
+    }
+    }
+}
+
+__global__ __launch_bounds__(256) void wkb_sizes_kernel(DevGeo a, int32_t* __restrict__ sizes) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.n_geoms) return;
+    const int64_t b = wkb_row_bytes(a, g);
+    sizes[g] = (int32_t)(b < 0x7FFFFFFF ? b : 0x7FFFFFFF);  // the host has bounded the column below 2 GiB
+}
+
+// geometry headers; POINT rows are complete here, MULTIPOLYGON rows also get their member polygon headers
+__global__ __launch_bounds__(256) void wkb_headers_kernel(DevGeo a, const int32_t* __restrict__ off, uint8_t* __restrict__ out) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.n_geoms || !dev::valid_row(a.validity, g)) return;
+    uint8_t* p = out + off[g];
+    switch (a.type) {
+    case GPK_GEOM_POINT:
+        p[0] = 1;
+        put_u32(p + 1, 1u);
+        put_xy(p + 5, a.xy[g]);  // an empty point is NaN NaN in both encodings
+        break;
+    case GPK_GEOM_LINESTRING: put_header(p, 2u, (uint32_t)(a.geom_off[g + 1] - a.geom_off[g])); break;
+    case GPK_GEOM_MULTIPOINT: put_header(p, 4u, (uint32_t)(a.geom_off[g + 1] - a.geom_off[g])); break;
+    case GPK_GEOM_POLYGON: put_header(p, 3u, (uint32_t)(a.geom_off[g + 1] - a.geom_off[g])); break;
+    case GPK_GEOM_MULTILINESTRING: put_header(p, 5u, (uint32_t)(a.geom_off[g + 1] - a.geom_off[g])); break;
+    default: {
+        const int p0 = a.geom_off[g], p1 = a.geom_off[g + 1];
+        put_header(p, 6u, (uint32_t)(p1 - p0));
+        const int rbase = a.part_off[p0], cbase = a.ring_off[rbase];
+        for (int q = p0; q < p1; ++q) {
+            const int r0 = a.part_off[q], r1 = a.part_off[q + 1];
+            uint8_t* ph = p + 9 + 9 * (int64_t)(q - p0) + 4 * (int64_t)(r0 - rbase) + 16 * (int64_t)(a.ring_off[r0] - cbase);
+            put_header(ph, 3u, (uint32_t)(r1 - r0));
+        }
+    }
+    }
+}
+
+// largest index i in [0, n) with off[i] <= v  (off ascending, off[0] <= v < off[n])
+__device__ __forceinline__ int owner_of(const int32_t* __restrict__ off, int64_t n, int v) {
+    int64_t lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (off[mid] <= v)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return (int)lo;
+}
+
+// bodies: WKB_GS lanes per sequence (LINESTRING: a row; POLYGON / MULTILINESTRING / MULTIPOLYGON: a ring / member line)
+__global__ __launch_bounds__(256) void wkb_bodies_kernel(DevGeo a, const int32_t* __restrict__ off, uint8_t* __restrict__ out) {
+    const int lane = threadIdx.x & (WKB_GS - 1);
+    const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WKB_GS;
+    const int64_t n_seq = a.type == GPK_GEOM_LINESTRING ? a.n_geoms : a.n_rings;
+    if (q >= n_seq) return;
+    int c0, c1;
+    uint8_t* p;  // where this sequence's coordinates start
+    if (a.type == GPK_GEOM_LINESTRING) {
+        if (!dev::valid_row(a.validity, q)) return;
+        c0 = a.geom_off[q];
+        c1 = a.geom_off[q + 1];
+        p = out + off[q] + 9;
+    } else {
+        const int r = (int)q;
+        c0 = a.ring_off[r];
+        c1 = a.ring_off[r + 1];
+        if (a.type == GPK_GEOM_MULTIPOLYGON) {
+            const int part = owner_of(a.part_off, a.n_parts, r);
+            const int g = owner_of(a.geom_off, a.n_geoms, part);
+            if (!dev::valid_row(a.validity, g)) return;
+            const int p0 = a.geom_off[g], rbase = a.part_off[p0];
+            uint8_t* rh = out + off[g] + 9 + 9 * (int64_t)(part - p0 + 1) + 4 * (int64_t)(r - rbase) + 16 * (int64_t)(c0 - a.ring_off[rbase]);
+            if (lane == 0) put_u32(rh, (uint32_t)(c1 - c0));
+            p = rh + 4;
+        } else {
+            const int g = owner_of(a.geom_off, a.n_geoms, r);
+            if (!dev::valid_row(a.validity, g)) return;
+            const int r0 = a.geom_off[g];
+            const bool poly = a.type == GPK_GEOM_POLYGON;
+            uint8_t* rh = out + off[g] + 9 + (poly ? 4 : 9) * (int64_t)(r - r0) + 16 * (int64_t)(c0 - a.ring_off[r0]);
+            if (lane == 0) {
+                if (poly)
+                    put_u32(rh, (uint32_t)(c1 - c0));
+                else
+                    put_header(rh, 2u, (uint32_t)(c1 - c0));
+            }
+            p = rh + (poly ? 4 : 9);
+        }
+    }
+    for (int i = c0 + lane; i < c1; i += WKB_GS) put_xy(p + 16 * (int64_t)(i - c0), a.xy[i]);
+}
+
+// MULTIPOINT members: one lane per coordinate, 21 bytes each
+__global__ __launch_bounds__(256) void wkb_multipoint_kernel(DevGeo a, const int32_t* __restrict__ off, uint8_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_coords) return;
+    const int g = owner_of(a.geom_off, a.n_geoms, (int)i);
+    if (!dev::valid_row(a.validity, g)) return;
+    uint8_t* p = out + off[g] + 9 + 21 * (int64_t)(i - a.geom_off[g]);
+    p[0] = 1;
+    put_u32(p + 1, 1u);
+    put_xy(p + 5, a.xy[i]);
+}
+
+}  // namespace gpk
+
+using namespace gpk;
+
+extern "C" int32_t gpk_geoarray_to_wkb(const gpk_geoarray* a, int32_t* out_offsets, uint8_t* out_values, int64_t capacity,
+                                       int64_t* n_bytes, int32_t out_space, void* stream) {
+    if (!a || !n_bytes) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (capacity < 0 || (capacity > 0 && !out_values)) return fail(GPK_ERR_INVALID_ARGUMENT, "capacity without out_values");
+    GPK_TRY(require_device());
+    hipStream_t s = (hipStream_t)stream;
+    const DevGeo& d = a->d;
+    const int64_t n = d.n_geoms;
+    *n_bytes = 0;
+    // upper bound of the column (every row valid): it must fit Arrow's i32 offsets
+    const int64_t bound = 21 * d.n_coords + 9 * (n + d.n_parts + d.n_rings);
+    if (bound > 0x7FFFFFFFLL)
+        return fail(GPK_ERR_CAPACITY, "to_wkb: up to %lld bytes do not fit BinaryArray<i32> offsets; encode row slices", (long long)bound);
+    const bool host_out = out_space != GPK_MEM_DEVICE;
+    const int64_t nb = (n + 255) / 256;
+    size_t need = 2 * align256(sizeof(int32_t) * (size_t)(n + 1)) + align256(sizeof(unsigned long long) * (size_t)(nb + 2)) + 1024;
+    if (host_out && out_values) need += align256((size_t)capacity);
+    GPK_TRY(workspace().begin(need));
+    int32_t* sizes = (int32_t*)workspace().take(sizeof(int32_t) * (size_t)(n + 1));
+    int32_t* off_dev = (host_out || !out_offsets) ? (int32_t*)workspace().take(sizeof(int32_t) * (size_t)(n + 1)) : out_offsets;
+    unsigned long long* btot = (unsigned long long*)workspace().take(sizeof(unsigned long long) * (size_t)(nb + 2));
+    uint8_t* val_dev = out_values ? (host_out ? (uint8_t*)workspace().take((size_t)capacity) : out_values) : nullptr;
+
+    int32_t total = 0;
+    if (n > 0) {
+        GPK_LAUNCH("gpk_wkb_sizes", wkb_sizes_kernel, dim3((unsigned)nb), dim3(256), 0, s, d, sizes);
+        GPK_TRY(exclusive_scan_i32(sizes, n, off_dev, nullptr, btot, s));
+        GPK_HIP(hipMemcpyAsync(&total, off_dev + n, sizeof total, hipMemcpyDeviceToHost, s));
+        GPK_HIP(hipStreamSynchronize(s));
+    } else {
+        GPK_HIP(hipMemsetAsync(off_dev, 0, sizeof(int32_t), s));
+    }
+    *n_bytes = (int64_t)total;
+    if (out_offsets && host_out) GPK_TRY(copy_out(out_offsets, out_space, off_dev, sizeof(int32_t) * (size_t)(n + 1), s));
+    if (!out_values) return GPK_OK;  // size query
+    if ((int64_t)total > capacity)
+        return fail(GPK_ERR_CAPACITY, "to_wkb: %lld bytes but capacity %lld", (long long)total, (long long)capacity);
+    if (n > 0 && total > 0) {
+        GPK_LAUNCH("gpk_wkb_headers", wkb_headers_kernel, dim3((unsigned)nb), dim3(256), 0, s, d, (const int32_t*)off_dev, val_dev);
+        if (d.type == GPK_GEOM_MULTIPOINT) {
+            if (d.n_coords > 0)
+                GPK_LAUNCH("gpk_wkb_multipoint", wkb_multipoint_kernel, dim3((unsigned)((d.n_coords + 255) / 256)), dim3(256), 0, s, d,
+                           (const int32_t*)off_dev, val_dev);
+        } else if (d.type != GPK_GEOM_POINT) {
+            const int64_t n_seq = d.type == GPK_GEOM_LINESTRING ? n : d.n_rings;
+            if (n_seq > 0)
+                GPK_LAUNCH("gpk_wkb_bodies", wkb_bodies_kernel, dim3((unsigned)((n_seq * WKB_GS + 255) / 256)), dim3(256), 0, s, d,
+                           (const int32_t*)off_dev, val_dev);
+        }
+    }
+    if (host_out) GPK_TRY(copy_out(out_values, out_space, val_dev, (size_t)total, s));
+    GPK_HIP(hipStreamSynchronize(s));
+    return GPK_OK;
+}

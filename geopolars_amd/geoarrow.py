@@ -194,6 +194,27 @@ class GeoArrowArray:
         return GeoArrowArray.from_wkb(values, offsets, validity)
 
     # ---- export --------------------------------------------------------------------------------
+    def to_wkb(self) -> tuple[np.ndarray, np.ndarray]:
+        """-> (values uint8, offsets int32) of the WKB BinaryArray<i32> (from_geom_vec, util.rs:11-24), encoded on
+        the host (gpk_wkb_encode); null rows are zero-length."""
+        lib = _abi.lib()
+        d = self.desc()
+        n_bytes = C.c_int64(0)
+        offsets = np.zeros(self.n_geoms + 1, dtype=np.int32)
+        _abi.check(lib.gpk_wkb_encode(C.byref(d), offsets.ctypes.data, None, 0, C.byref(n_bytes)))
+        values = np.empty(int(n_bytes.value), dtype=np.uint8)
+        if len(values):
+            _abi.check(lib.gpk_wkb_encode(C.byref(d), offsets.ctypes.data, values.ctypes.data, len(values), C.byref(n_bytes)))
+        return values, offsets
+
+    def to_arrow_wkb(self):
+        """pyarrow binary array of WKB (the column type of every reference fixture)."""
+        import pyarrow as pa
+
+        values, offsets = self.to_wkb()
+        valid = None if self.validity is None else pa.py_buffer(np.ascontiguousarray(self.validity).tobytes())
+        return pa.Array.from_buffers(pa.binary(), self.n_geoms, [valid, pa.py_buffer(offsets.tobytes()), pa.py_buffer(values.tobytes())])
+
     def to_pyarrow(self):
         """GeoArrow nested list array (interleaved FixedSizeList<f64,2> coordinates)."""
         import pyarrow as pa
@@ -282,6 +303,18 @@ class DeviceGeoArray:
         self.n_coords = int(sizes[0])
         self._validity = None if validity is None else np.ascontiguousarray(validity, dtype=np.uint8)
         return self
+
+    def to_wkb(self, stream: int = 0) -> tuple[np.ndarray, np.ndarray]:
+        """-> (values uint8, offsets int32): the WKB column, ENCODED ON THE GPU from the device-resident buffers
+        (gpk_geoarray_to_wkb); only the finished bytes cross PCIe."""
+        lib = _abi.lib()
+        n_bytes = C.c_int64(0)
+        offsets = np.zeros(self.n_geoms + 1, dtype=np.int32)
+        _abi.check(lib.gpk_geoarray_to_wkb(self.handle, offsets.ctypes.data, None, 0, C.byref(n_bytes), _abi.MEM_HOST, stream))
+        values = np.empty(int(n_bytes.value), dtype=np.uint8)
+        if len(values):
+            _abi.check(lib.gpk_geoarray_to_wkb(self.handle, offsets.ctypes.data, values.ctypes.data, len(values), C.byref(n_bytes), _abi.MEM_HOST, stream))
+        return values, offsets
 
     def download(self, stream: int = 0) -> GeoArrowArray:
         """Copy the device buffers back as a host GeoArrowArray."""

@@ -54,6 +54,14 @@ class GeoSeries:
     def from_wkb(column) -> "GeoSeries":
         return GeoSeries(GeoArrowArray.from_arrow_wkb(column))
 
+    def to_wkb(self, on_device: bool = True) -> tuple[np.ndarray, np.ndarray]:
+        """The series as a WKB column (values uint8, offsets int32) — the form geometry-valued results leave the
+        reference in (from_geom_vec, util.rs:11-24).  Encoded on the GPU by default; on_device=False uses the host
+        encoder (no device needed)."""
+        if on_device:
+            return self.device().to_wkb()
+        return self.array.to_wkb()
+
     @staticmethod
     def from_wkb_device(values, offsets, validity=None) -> "GeoSeries":
         """WKB column decoded on the GPU: only the raw bytes are uploaded (gpk_geoarray_from_wkb)."""

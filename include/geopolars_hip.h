@@ -121,6 +121,19 @@ int32_t gpk_wkb_decode(const uint8_t* wkb_values, const int32_t* wkb_offsets, in
 int32_t gpk_geoarray_from_wkb(const uint8_t* wkb_values, const int32_t* wkb_offsets, int64_t n_rows,
                               const uint8_t* validity, int32_t mem_space, void* stream,
                               gpk_geoarray** out, int32_t* out_geom_type);
+/* GeoArrow -> WKB BinaryArray<i32>: the column format geometry-valued results leave the reference in
+ * (from_geom_vec, util.rs:11-24).  Little-endian ISO WKB, 2D, one WKB type per column (the array's), zero-length
+ * records for null rows (the validity bitmap travels separately).
+ *   out_offsets[n_geoms + 1]   Arrow offsets (may be NULL)
+ *   out_values[capacity]       WKB bytes (NULL + capacity 0 = size query)
+ *   *n_bytes                   total bytes, always set; GPK_ERR_CAPACITY when > capacity, or when the column
+ *                              cannot fit i32 offsets (encode row slices)
+ * gpk_wkb_encode: host buffers in, host buffers out, no device.  gpk_geoarray_to_wkb: encodes a device-resident
+ * handle ON the GPU (sizes -> scan -> headers -> bodies); outputs in `out_space`. */
+int32_t gpk_wkb_encode(const gpk_geoarrow_desc* desc, int32_t* out_offsets, uint8_t* out_values,
+                       int64_t capacity, int64_t* n_bytes);
+int32_t gpk_geoarray_to_wkb(const gpk_geoarray* a, int32_t* out_offsets, uint8_t* out_values,
+                            int64_t capacity, int64_t* n_bytes, int32_t out_space, void* stream);
 /* Device -> host copy of a handle's GeoArrow buffers.  sizes[4] = {n_coords, n_parts, n_rings, n_geoms} is always
  * filled; NULL buffers are skipped (call once with NULLs to size the buffers). */
 int32_t gpk_geoarray_download(const gpk_geoarray* a, int64_t sizes[4], double* xy, int32_t* geom_offsets,

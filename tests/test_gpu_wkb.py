@@ -91,3 +91,64 @@ def test_unsupported_input_is_reported(gpk):
         DeviceGeoArray.from_wkb(np.frombuffer(pt[:-3], np.uint8), np.array([0, len(pt) - 3], np.int32))
     empty = DeviceGeoArray.from_wkb(np.zeros(0, np.uint8), np.zeros(1, np.int32))
     assert empty.n_geoms == 0
+
+
+# ---- GeoArrow -> WKB on the device (gpk_geoarray_to_wkb) ---------------------------------------------
+@pytest.mark.parametrize(
+    "make",
+    [
+        lambda: synth.uniform_points(200_000),
+        lambda: synth.random_linestrings(20_000),
+        lambda: synth.star_polygons(30_000, 17),
+        lambda: synth.powerlaw_multipolygons(20_000),
+        lambda: GeoArrowArray(_abi.GEOM_MULTIPOINT, np.arange(2000.0).reshape(1000, 2), geom_offsets=np.array([0, 3, 3, 10, 1000], np.int32)),
+    ],
+)
+def test_device_encoder_is_byte_identical_to_host_and_independent_writer(gpk, make):
+    a = make()
+    ev, eo = encode_wkb(a)
+    dv, do = GeoSeries(a).to_wkb(on_device=True)
+    hv, ho = a.to_wkb()
+    assert np.array_equal(do, eo) and np.array_equal(dv, ev)
+    assert np.array_equal(ho, eo) and np.array_equal(hv, ev)
+    same(DeviceGeoArray.from_wkb(dv, do).download(), a)  # decode(encode(x)) == x, both on the GPU
+
+
+def test_device_encoder_multilinestrings_nulls_and_capacity(gpk):
+    import ctypes as C
+
+    ml = synth.random_linestrings(640)
+    go = np.concatenate([[0, 1, 1], np.arange(10, 641, 10)]).astype(np.int32)
+    a = GeoArrowArray(_abi.GEOM_MULTILINESTRING, ml.xy, geom_offsets=go, ring_offsets=ml.geom_offsets)
+    ev, eo = encode_wkb(a)
+    dv, do = GeoSeries(a).to_wkb()
+    assert np.array_equal(do, eo) and np.array_equal(dv, ev)
+    polys = synth.powerlaw_multipolygons(3000, seed=11)
+    keep = np.ones(len(polys), np.uint8)
+    keep[::5] = 0
+    pn = GeoArrowArray(polys.geom_type, polys.xy, polys.geom_offsets, part_offsets=polys.part_offsets, ring_offsets=polys.ring_offsets,
+                       validity=np.packbits(keep, bitorder="little"))
+    ev, eo = encode_wkb(pn)
+    s = GeoSeries(pn)
+    dv, do = s.to_wkb()
+    assert np.array_equal(do, eo) and np.array_equal(dv, ev)
+    lib = _abi.lib()
+    nb = C.c_int64(0)
+    small = np.empty(100, np.uint8)
+    rc = lib.gpk_geoarray_to_wkb(s.device().handle, None, small.ctypes.data, 100, C.byref(nb), _abi.MEM_HOST, None)
+    assert rc == _abi.GPK_ERR_CAPACITY and nb.value == len(ev)
+
+
+@pytest.mark.parametrize("name", ["cities", "naturalearth_lowres", "nybb"])
+def test_geometry_valued_results_leave_as_wkb(gpk, oracle, name):
+    """centroid() of a fixture column, written as the WKB point column the reference's from_geom_vec would produce"""
+    z = np.load(os.path.join(GOLD, f"{name}.npz"))
+    s = GeoSeries.from_wkb_device(z["wkb_values"], z["wkb_offsets"])
+    c = s.centroid()
+    values, offsets = c.to_wkb()
+    exp = oracle.centroid(s.array)
+    exp_xy = exp[0] if isinstance(exp, tuple) else exp
+    back = GeoArrowArray.from_wkb(values, offsets)
+    assert back.geom_type == _abi.GEOM_POINT and len(back) == len(s)
+    ok = ~np.isnan(exp_xy[:, 0])
+    assert np.allclose(back.xy[ok], exp_xy[ok], rtol=1e-9, atol=0)
