@@ -101,6 +101,9 @@ _PROTOS = {
     "gpk_spatial_join_async": (C.c_int32, [_VP, _VP, _VP, C.c_int32, C.c_uint32, _VP, _VP, C.c_int64, _VP, _VP]),
     "gpk_wkb_encode": (C.c_int32, [_VP, _VP, _VP, C.c_int64, C.POINTER(C.c_int64)]),
     "gpk_geoarray_to_wkb": (C.c_int32, [_VP, _VP, _VP, C.c_int64, C.POINTER(C.c_int64), C.c_int32, _VP]),
+    "gpk_join_indices": (C.c_int32, [_VP, _VP, C.c_int64, C.c_int64, C.c_uint32, C.c_int32, _VP, _VP, C.c_int64, C.POINTER(C.c_int64), C.c_int32, _VP]),
+    "gpk_take_fixed": (C.c_int32, [_VP, C.c_int32, _VP, C.c_int64, _VP, C.c_int64, _VP, _VP, C.c_int32, _VP]),
+    "gpk_take_binary": (C.c_int32, [_VP, _VP, _VP, C.c_int64, _VP, C.c_int64, _VP, _VP, C.c_int64, C.POINTER(C.c_int64), _VP, C.c_int32, _VP]),
     "gpk_profile_enable": (C.c_int32, [C.c_int32]),
     "gpk_profile_filter": (C.c_int32, [C.c_char_p]),
     "gpk_profile_reset": (C.c_int32, []),

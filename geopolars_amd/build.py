@@ -32,6 +32,7 @@ SOURCES = [
     "gpk_wkb.cpp",
     "gpk_wkb_device.hip",
     "gpk_wkb_encode.hip",
+    "gpk_take.hip",
 ]
 
 FLAGS = [

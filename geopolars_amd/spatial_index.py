@@ -145,6 +145,67 @@ def join_pairs_enqueue(left: DeviceGeoArray, right: DeviceGeoArray, r_index: Spa
     )
 
 
+JOIN_TYPES = {"inner": 0, "left": 1}  # GPK_JOIN_*
+
+
+def join_indices(counts: np.ndarray, pairs: np.ndarray, join_type: str = "inner", left_row_base: int = 0) -> tuple[np.ndarray, np.ndarray]:
+    """(hit counts, sorted (l, r) pairs) -> i64 row indices (l, r) of the joined table (gpk_join_indices; the two
+    u64 index Series of spatial_index.rs:147-159 followed by inner_join / left_join).  Left join: unmatched left
+    rows appear once with r = -1."""
+    lib = _abi.lib()
+    counts = np.ascontiguousarray(counts, dtype=np.uint32)
+    pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+    n_rows = C.c_int64(0)
+    jt = JOIN_TYPES[join_type]
+    args = (counts.ctypes.data, pairs.ctypes.data if len(pairs) else None, len(counts), len(pairs), left_row_base, jt)
+    _abi.check(lib.gpk_join_indices(*args, None, None, 0, C.byref(n_rows), MEM_HOST, None))
+    n = int(n_rows.value)
+    li, ri = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.int64)
+    if n:
+        _abi.check(lib.gpk_join_indices(*args, li.ctypes.data, ri.ctypes.data, n, C.byref(n_rows), MEM_HOST, None))
+    return li, ri
+
+
+def take_column(column, idx: np.ndarray):
+    """pyarrow column gathered by i64 row indices on the GPU (gpk_take_fixed / gpk_take_binary); -1 gives a null.
+    Fixed-width primitives, booleans, binary and string columns — the types the reference's fixtures carry; anything
+    else is reported (there is no host fallback)."""
+    import pyarrow as pa
+
+    lib = _abi.lib()
+    arr = column.combine_chunks() if isinstance(column, pa.ChunkedArray) else column
+    if arr.offset != 0:
+        arr = pa.concat_arrays([arr])  # re-base a sliced array so the raw buffers start at row 0
+    t = arr.type
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    n_idx, n = len(idx), len(arr)
+    bufs = arr.buffers()
+    validity = np.frombuffer(bufs[0], dtype=np.uint8) if bufs[0] is not None else None
+    vptr = validity.ctypes.data if validity is not None else None
+    out_valid = np.zeros((n_idx + 7) // 8, dtype=np.uint8)
+    if pa.types.is_binary(t) or pa.types.is_string(t):
+        offsets = np.frombuffer(bufs[1], dtype=np.int32)[: n + 1] if bufs[1] is not None else np.zeros(1, np.int32)
+        values = np.frombuffer(bufs[2], dtype=np.uint8) if bufs[2] is not None and bufs[2].size else np.zeros(1, np.uint8)
+        n_bytes = C.c_int64(0)
+        out_off = np.zeros(n_idx + 1, dtype=np.int32)
+        args = (values.ctypes.data, offsets.ctypes.data, vptr, n, idx.ctypes.data, n_idx, out_off.ctypes.data)
+        _abi.check(lib.gpk_take_binary(*args, None, 0, C.byref(n_bytes), out_valid.ctypes.data, MEM_HOST, None))
+        out_vals = np.empty(max(int(n_bytes.value), 1), dtype=np.uint8)
+        if n_bytes.value:
+            _abi.check(lib.gpk_take_binary(*args, out_vals.ctypes.data, int(n_bytes.value), C.byref(n_bytes), out_valid.ctypes.data, MEM_HOST, None))
+        return pa.Array.from_buffers(t, n_idx, [pa.py_buffer(out_valid.tobytes()), pa.py_buffer(out_off.tobytes()), pa.py_buffer(out_vals[: int(n_bytes.value)].tobytes())])
+    if pa.types.is_boolean(t):
+        bits = 1
+    elif pa.types.is_primitive(t):
+        bits = t.bit_width
+    else:
+        raise _abi.GeopolarsHipError(_abi.GPK_ERR_INVALID_ARGUMENT, f"join assembly: column type {t} is not supported")
+    data = np.frombuffer(bufs[1], dtype=np.uint8) if bufs[1] is not None else np.zeros(16, np.uint8)
+    out = np.zeros((n_idx + 7) // 8 if bits == 1 else n_idx * (bits // 8), dtype=np.uint8)
+    _abi.check(lib.gpk_take_fixed(data.ctypes.data, bits, vptr, n, idx.ctypes.data, n_idx, out.ctypes.data if len(out) else None, out_valid.ctypes.data, MEM_HOST, None))
+    return pa.Array.from_buffers(t, n_idx, [pa.py_buffer(out_valid.tobytes()), pa.py_buffer(out.tobytes())])
+
+
 def spatial_join(lhs, rhs, options: Optional[SpatialJoinArgs] = None):
     """spatial_join(lhs, rhs, SpatialJoinArgs) over pyarrow Tables with a WKB `geometry` column
     (spatial_index.rs:44-45).  Returns a pyarrow Table shaped like the reference's result:
@@ -159,21 +220,12 @@ def spatial_join(lhs, rhs, options: Optional[SpatialJoinArgs] = None):
     rgeo = GeoSeries.from_wkb(rhs.column("geometry"))
     r_index = options.r_index or SpatialIndex(rgeo)
     pairs, counts = join_pairs(lgeo, rgeo, options.predicate, r_index)
-    li = pairs[:, 0].astype(np.int64)
-    ri = pairs[:, 1].astype(np.int64)
-    if options.join_type == "left":
-        # left join keeps unmatched left rows with null right columns
-        unmatched = np.nonzero(counts == 0)[0]
-        li_all = np.concatenate([li, unmatched])
-        ri_all = np.concatenate([ri, np.full(len(unmatched), -1, dtype=np.int64)])
-        order = np.argsort(li_all, kind="stable")
-        li, ri = li_all[order], ri_all[order]
+    li, ri = join_indices(counts, pairs, options.join_type)  # i64 row indices, r = -1 for unmatched left rows
     cols, names = [], []
     for name in lhs.column_names:
-        cols.append(lhs.column(name).combine_chunks().take(pa.array(li)))
+        cols.append(take_column(lhs.column(name), li))
         names.append(name + (options.l_suffix or ""))
-    ri_arr = pa.array(ri, mask=ri < 0)
     for name in rhs.column_names:
-        cols.append(rhs.column(name).combine_chunks().take(ri_arr))
+        cols.append(take_column(rhs.column(name), ri))
         names.append(name + (options.r_suffix or ""))
     return pa.table(cols, names=names)

@@ -218,6 +218,30 @@ int32_t gpk_spatial_join_async(const gpk_geoarray* left, const gpk_geoarray* rig
                                uint32_t* out_counts, uint32_t* out_pairs, int64_t pair_capacity,
                                int64_t* n_pairs_dev, void* stream);
 
+/* ---- join assembly (spatial_index.rs:145-203) ------------------------------------------------ */
+/* The reference turns the (l, r) pairs into two u64 index Series and lets polars `inner_join` / `left_join` pull
+ * the attribute columns (spatial_index.rs:147-199).  Here: the row indices of the joined table, then a gather per
+ * column.  All buffers of one call live in `space`. */
+#define GPK_JOIN_INNER 0
+#define GPK_JOIN_LEFT  1
+/* (counts[n_left], sorted pairs[2*n_pairs] as produced by gpk_spatial_join with `left_row_base`) -> out_l / out_r
+ * [capacity] i64 row indices, sorted by l.  Left join: a left row without hits appears once with r = -1
+ * (JoinType::Left, spatial_index.rs:186-199); other join types do not exist upstream (:200-202).
+ * *n_rows is always set (capacity 0 = size query; GPK_ERR_CAPACITY when it does not fit). */
+int32_t gpk_join_indices(const uint32_t* counts, const uint32_t* pairs, int64_t n_left, int64_t n_pairs,
+                         uint32_t left_row_base, int32_t join_type, int64_t* out_l, int64_t* out_r,
+                         int64_t capacity, int64_t* n_rows, int32_t space, void* stream);
+/* out[i] = values[idx[i]] for a fixed-width Arrow column (elem_bits 1 = boolean bitmap, 8, 16, 32, 64, 128);
+ * idx[i] = -1 (or out of range) and null source rows give a null: out_validity (Arrow bitmap, may be NULL). */
+int32_t gpk_take_fixed(const void* values, int32_t elem_bits, const uint8_t* validity, int64_t n_values,
+                       const int64_t* idx, int64_t n_idx, void* out_values, uint8_t* out_validity,
+                       int32_t space, void* stream);
+/* The same for an Arrow Binary / Utf8 column (i32 offsets + bytes; the reference's geometry column is one).
+ * out_offsets[n_idx + 1]; out_values NULL + capacity 0 = size query; *n_bytes always set. */
+int32_t gpk_take_binary(const uint8_t* values, const int32_t* offsets, const uint8_t* validity, int64_t n_values,
+                        const int64_t* idx, int64_t n_idx, int32_t* out_offsets, uint8_t* out_values,
+                        int64_t capacity, int64_t* n_bytes, uint8_t* out_validity, int32_t space, void* stream);
+
 /* ---- profiling hooks (bench.py's roofline leg) -------------------------------------------- */
 /* When enabled every kernel launch is bracketed by hipEvents on its stream. */
 int32_t gpk_profile_enable(int32_t on);
