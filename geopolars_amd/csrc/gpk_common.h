@@ -50,11 +50,23 @@ struct DevGeo {
 
 }  // namespace gpk
 
+// Coordinate sequences (rings / linestrings) of an array bucketed by length, built on first use by the streaming
+// reductions (gpk_unary.hip) and kept with the handle: arrays are immutable, the classification is paid once.
+struct gpk_seq_classes {
+    int64_t count[4];  // sequences per class: three lane-group classes, then "long" (whole work-group)
+    int64_t begin[4];  // start of each class in `lists`
+    int32_t* lists;    // device, ids grouped by class; nullptr when a single class holds every sequence
+    // the "long" class is cut into chunks of SEQ_CHUNK coordinates, one work-group each (a 100k-vertex ring would
+    // otherwise be one work-group's job): chunk_begin[k] = first chunk of the k-th long sequence (count[3] + 1 entries)
+    int32_t* chunk_begin;
+    int64_t n_chunks;
+};
 struct gpk_geoarray {
     gpk::DevGeo d;
     int device;
     void* owned[5];  // hipMalloc'ed copies (xy, geom_off, part_off, ring_off, validity) or nullptr
     int64_t nbytes;
+    gpk_seq_classes* classes;  // lazily built (under a lock), freed with the handle
 };
 
 namespace gpk {

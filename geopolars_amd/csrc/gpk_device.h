@@ -197,8 +197,8 @@ __device__ inline bool polygonal_hits_point(const DevGeo& a, int64_t g, double c
 }
 
 // ---- all-reduce over G consecutive lanes with DPP row operations --------------------------------
-// G = 4, 8, 16 (a group never straddles a 16-lane DPP row): quad permutes for xor 1 / xor 2, row_half_mirror to join
-// the two quads of an 8-lane half row, row_ror:4 / row_ror:8 to join the quads of a row.  One VALU mov per 32-bit
+// G = 2, 4, 8, 16 (a group never straddles a 16-lane DPP row): quad permutes for xor 1 / xor 2, row_half_mirror to join
+// the two quads of an 8-lane half row, row_mirror to join the two halves of a row.  One VALU mov per 32-bit
 // word and step, instead of a ds_bpermute round trip through the LDS crossbar.  All lanes of the group must be active.
 template <int CTRL>
 __device__ __forceinline__ int dpp_mov(int v) {
@@ -213,15 +213,14 @@ __device__ __forceinline__ T group_allreduce(T v, Op op) {
     static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16, "group_allreduce: G lanes within one DPP row");
     if constexpr (G >= 2) v = op(v, dpp_mov<0xB1>(v));   // quad_perm [1,0,3,2]
     if constexpr (G >= 4) v = op(v, dpp_mov<0x4E>(v));   // quad_perm [2,3,0,1]
-    if constexpr (G == 8) v = op(v, dpp_mov<0x141>(v));  // row_half_mirror
-    if constexpr (G == 16) {
-        v = op(v, dpp_mov<0x124>(v));  // row_ror:4
-        v = op(v, dpp_mov<0x128>(v));  // row_ror:8
-    }
-    return v;
+    if constexpr (G >= 8) v = op(v, dpp_mov<0x141>(v));   // row_half_mirror: lane i <-> 7 - i of its half row
+    if constexpr (G == 16) v = op(v, dpp_mov<0x140>(v));  // row_mirror: lane i <-> 15 - i
+    return v;  // every step pairs two lanes symmetrically, so a commutative op leaves the same bits on all lanes
 }
 template <int G>
 __device__ __forceinline__ int group_sum(int v) { return group_allreduce<G>(v, [](int a, int b) { return a + b; }); }
+template <int G>
+__device__ __forceinline__ double group_sum(double v) { return group_allreduce<G>(v, [](double a, double b) { return a + b; }); }
 template <int G>
 __device__ __forceinline__ int group_or(int v) { return group_allreduce<G>(v, [](int a, int b) { return a | b; }); }
 template <int G>

@@ -305,6 +305,11 @@ int32_t gpk_geoarray_free(gpk_geoarray* a) {
     if (!a) return GPK_OK;
     for (int i = 0; i < 5; ++i)
         if (a->owned[i]) (void)hipFree(a->owned[i]);
+    if (a->classes) {
+        if (a->classes->lists) (void)hipFree(a->classes->lists);
+        if (a->classes->chunk_begin) (void)hipFree(a->classes->chunk_begin);
+        delete a->classes;
+    }
     delete a;
     return GPK_OK;
 }

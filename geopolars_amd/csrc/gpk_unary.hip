@@ -6,14 +6,17 @@
 //   affine_transform     geoseries.rs:11-12,184-186   (AffineTransform::apply, no FMA)
 //
 // Layout: every reduction is two stages.  Stage 1 streams the coordinate buffer once (16 B per
-// vertex, double2 loads) with G lanes cooperating on one coordinate sequence (ring / linestring),
-// G a power of two picked from the mean sequence length so that the 64 lanes of a wave cover 64/G
-// neighbouring sequences = one contiguous stretch of the buffer.  Per-sequence partials land in a
+// vertex, double2 loads) with G lanes cooperating on one coordinate sequence (ring / linestring);
+// sequences are bucketed by length once per array (G = 2 / 8 / 16 lanes, whole work-group for the
+// longest) so that a wave walks sequences of similar length.  Per-sequence partials land in a
 // small stats array (8 B x K per sequence).  Stage 2 is one thread per geometry folding its rings
-// with the polygon / multipolygon rules.  Reduction order is fixed (xor-tree), so results are
-// bit-reproducible run to run.
+// with the polygon / multipolygon rules.  Reduction order is fixed (DPP pairing tree), so results
+// are bit-reproducible run to run.
+#include <mutex>
+
 #include "gpk_device.h"
 #include "gpk_index.h"
+#include "gpk_scan.h"
 
 namespace gpk {
 
@@ -37,30 +40,10 @@ constexpr unsigned M_AREA = 1u << 0, M_CENT = 1u << 1, M_LEN = 1u << 2, M_BBOX =
 // pass to sequences whose ring area came out zero (the only rings whose centroid needs the length partials)
 constexpr unsigned M_LENC = 1u << 5, M_DEGEN = 1u << 6;
 
-template <int G>
-__device__ __forceinline__ double group_sum(double v) {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-template <int G>
-__device__ __forceinline__ double group_min(double v) {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) {
-        const double w = __shfl_xor(v, o, 64);
-        v = w < v ? w : v;
-    }
-    return v;
-}
-template <int G>
-__device__ __forceinline__ double group_max(double v) {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) {
-        const double w = __shfl_xor(v, o, 64);
-        v = w > v ? w : v;
-    }
-    return v;
-}
+// group reductions: DPP row operations (gpk_device.h) — G <= 16 everywhere in this file
+using dev::group_max;
+using dev::group_min;
+using dev::group_sum;
 
 // Stage 1: per-sequence partials.  stats is [ST_COUNT][n_seq] (SoA so stage 2 reads are coalesced).
 constexpr int SEQ_LONG = 512;  // sequences longer than this are reduced by a whole work-group (seq_stats_long_kernel)
@@ -130,71 +113,148 @@ __device__ __forceinline__ void seq_store(const SeqPartial& a, double* __restric
     }
 }
 
-// list the sequences the group kernel skips (power-law data: a few giant rings would otherwise be walked by
-// one lane group while the rest of the chip idles); order in the list is irrelevant, every entry is reduced
-// independently and deterministically
-__global__ void find_long_kernel(const int32_t* __restrict__ seq_off, int64_t n_seq, int32_t* __restrict__ long_ws) {
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_seq) return;
-    if (seq_off[s + 1] - seq_off[s] > SEQ_LONG) long_ws[1 + atomicAdd(&long_ws[0], 1)] = (int32_t)s;
-}
+// ---- size classes ---------------------------------------------------------------------------------------------
+// Lanes per sequence by length: ~8 vertices per lane keeps the reduction steps per vertex low (with 64 lanes on
+// 65-vertex rings the reductions outweighed the streaming work 3:1) while a group still reads G consecutive vertices
+// per load.  Sequences are bucketed once per array (gpk_seq_classes) so that the lanes of a wave walk sequences of
+// similar length whatever the length distribution of the column (power-law data: a few giant rings would otherwise be
+// walked by one lane group while the rest of the chip idles).  Order inside a bucket is irrelevant: every sequence is
+// reduced independently and deterministically.
+constexpr int SEQ_LANES[3] = {2, 8, 16};
+constexpr int SEQ_MAXLEN[3] = {16, 128, SEQ_LONG};  // class k takes lengths <= SEQ_MAXLEN[k] (and > SEQ_MAXLEN[k-1])
+__device__ __forceinline__ int seq_class_of(int n) { return n <= SEQ_MAXLEN[0] ? 0 : (n <= SEQ_MAXLEN[1] ? 1 : (n <= SEQ_MAXLEN[2] ? 2 : 3)); }
 
-template <unsigned MASK>
-__global__ __launch_bounds__(256) void seq_stats_long_kernel(const double2* __restrict__ xy, const int32_t* __restrict__ seq_off,
-                                                             int64_t n_seq, const int32_t* __restrict__ long_ws,
-                                                             double* __restrict__ stats) {
-    __shared__ double red[12][4];
-    const int n_long = long_ws[0];
-    for (int k = blockIdx.x; k < n_long; k += gridDim.x) {
-        const int64_t s = long_ws[1 + k];
-        if ((MASK & M_DEGEN) && stats[ST_AREA2 * n_seq + s] != 0.0) continue;
-        const int c0 = seq_off[s], c1 = seq_off[s + 1];
-        const double2 first = xy[c0], last = xy[c1 - 1];
-        const bool closed_ring = first.x == last.x && first.y == last.y;
-        SeqPartial a;
-        for (int i = c0 + threadIdx.x; i < c1; i += 256) seq_accumulate<MASK>(a, xy, i, c1, first, closed_ring);
-        double v[12] = {a.a2, a.acx, a.acy, a.len, a.lmx, a.lmy, a.sx, a.sy, a.mnx, a.mny, a.mxx, a.mxy};
+// FILL = false: counts per class (one atomic per wave and class); FILL = true: ids appended at the class cursors
+template <bool FILL>
+__global__ __launch_bounds__(256) void seq_classify_kernel(const int32_t* __restrict__ seq_off, int64_t n_seq, int32_t* __restrict__ cursor,
+                                                            int32_t* __restrict__ lists) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = s < n_seq ? seq_class_of(seq_off[s + 1] - seq_off[s]) : -1;
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-        for (int j = 0; j < 12; ++j) {
-            if (j < 8)
-                v[j] = dev::wave_sum(v[j]);
-            else if (j < 10)
-                v[j] = dev::wave_min(v[j]);
-            else
-                v[j] = dev::wave_max(v[j]);
-        }
-        __syncthreads();  // red[] reuse across iterations
-        if ((threadIdx.x & 63) == 0)
-#pragma unroll
-            for (int j = 0; j < 12; ++j) red[j][threadIdx.x >> 6] = v[j];
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            SeqPartial r;
-            double t[12];
-#pragma unroll
-            for (int j = 0; j < 12; ++j) {
-                t[j] = red[j][0];
-                for (int w = 1; w < 4; ++w) t[j] = j < 8 ? t[j] + red[j][w] : (j < 10 ? fmin(t[j], red[j][w]) : fmax(t[j], red[j][w]));
-            }
-            r.a2 = t[0]; r.acx = t[1]; r.acy = t[2]; r.len = t[3]; r.lmx = t[4]; r.lmy = t[5]; r.sx = t[6]; r.sy = t[7];
-            r.mnx = t[8]; r.mny = t[9]; r.mxx = t[10]; r.mxy = t[11];
-            seq_store<MASK>(r, stats, n_seq, s);
+    for (int k = 0; k < 4; ++k) {
+        const unsigned long long m = __ballot(c == k);
+        if (!m) continue;
+        const int leader = __ffsll((long long)m) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&cursor[k], __popcll(m));
+        if (FILL) {
+            base = __shfl(base, leader, 64);
+            if (c == k) lists[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)s;
         }
     }
 }
 
+constexpr int SEQ_CHUNK = 8192;  // coordinates of a long sequence reduced by one work-group
+__global__ void long_chunk_count_kernel(const int32_t* __restrict__ seq_off, const int32_t* __restrict__ list, int64_t n_list,
+                                        int32_t* __restrict__ chunks) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_list) return;
+    const int64_t s = list ? (int64_t)list[k] : k;
+    const int n = seq_off[s + 1] - seq_off[s];
+    chunks[k] = n > 0 ? (n + SEQ_CHUNK - 1) / SEQ_CHUNK : 1;
+}
+
+// one work-group per chunk of a long sequence.  A sequence that fits one chunk is stored directly; the chunks of a
+// longer one leave 12-double partials in `part` that seq_long_combine_kernel folds in chunk order (deterministic).
+template <unsigned MASK>
+__device__ __forceinline__ void seq_stats_long_body(const double2* __restrict__ xy, const int32_t* __restrict__ seq_off, int64_t n_seq,
+                                                    const int32_t* __restrict__ list, int64_t n_list,
+                                                    const int32_t* __restrict__ chunk_begin, int64_t n_chunks, double* __restrict__ part,
+                                                    double* __restrict__ stats, int block, int n_blocks) {
+    __shared__ double red[12][4];
+    for (int64_t w = block; w < n_chunks; w += n_blocks) {
+        int64_t lo = 0, hi = n_list;  // largest k with chunk_begin[k] <= w (uniform across the work-group)
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)chunk_begin[mid] <= w)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const int64_t k = lo;
+        const int64_t s = list ? (int64_t)list[k] : k;
+        if ((MASK & M_DEGEN) && stats[ST_AREA2 * n_seq + s] != 0.0) continue;
+        const int c0 = seq_off[s], c1 = seq_off[s + 1];
+        const int n_ch = chunk_begin[k + 1] - chunk_begin[k];
+        const int j = (int)(w - chunk_begin[k]);
+        double2 first = make_double2(0, 0), last = make_double2(0, 0);
+        if (c1 > c0) {
+            first = xy[c0];
+            last = xy[c1 - 1];
+        }
+        const bool closed_ring = c1 - c0 >= 3 && first.x == last.x && first.y == last.y;
+        SeqPartial a;
+        const int b0 = c0 + j * SEQ_CHUNK, b1 = b0 + SEQ_CHUNK < c1 ? b0 + SEQ_CHUNK : c1;
+        for (int i = b0 + threadIdx.x; i < b1; i += 256) seq_accumulate<MASK>(a, xy, i, c1, first, closed_ring);
+        double v[12] = {a.a2, a.acx, a.acy, a.len, a.lmx, a.lmy, a.sx, a.sy, a.mnx, a.mny, a.mxx, a.mxy};
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            if (q < 8)
+                v[q] = dev::wave_sum(v[q]);
+            else if (q < 10)
+                v[q] = dev::wave_min(v[q]);
+            else
+                v[q] = dev::wave_max(v[q]);
+        }
+        __syncthreads();  // red[] reuse across iterations
+        if ((threadIdx.x & 63) == 0)
+#pragma unroll
+            for (int q = 0; q < 12; ++q) red[q][threadIdx.x >> 6] = v[q];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t[12];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                t[q] = red[q][0];
+                for (int x = 1; x < 4; ++x) t[q] = q < 8 ? t[q] + red[q][x] : (q < 10 ? fmin(t[q], red[q][x]) : fmax(t[q], red[q][x]));
+            }
+            if (n_ch == 1) {
+                SeqPartial r;
+                r.a2 = t[0]; r.acx = t[1]; r.acy = t[2]; r.len = t[3]; r.lmx = t[4]; r.lmy = t[5]; r.sx = t[6]; r.sy = t[7];
+                r.mnx = t[8]; r.mny = t[9]; r.mxx = t[10]; r.mxy = t[11];
+                seq_store<MASK>(r, stats, n_seq, s);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 12; ++q) part[12 * w + q] = t[q];
+            }
+        }
+    }
+}
+template <unsigned MASK>
+__global__ void seq_long_combine_kernel(const int32_t* __restrict__ list, int64_t n_list, const int32_t* __restrict__ chunk_begin,
+                                        const double* __restrict__ part, int64_t n_seq, double* __restrict__ stats) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_list) return;
+    const int w0 = chunk_begin[k], w1 = chunk_begin[k + 1];
+    if (w1 - w0 <= 1) return;  // stored by its only chunk
+    const int64_t s = list ? (int64_t)list[k] : k;
+    if ((MASK & M_DEGEN) && stats[ST_AREA2 * n_seq + s] != 0.0) return;
+    double t[12];
+    for (int q = 0; q < 12; ++q) t[q] = part[12 * (int64_t)w0 + q];
+    for (int w = w0 + 1; w < w1; ++w)
+        for (int q = 0; q < 12; ++q) {
+            const double x = part[12 * (int64_t)w + q];
+            t[q] = q < 8 ? t[q] + x : (q < 10 ? fmin(t[q], x) : fmax(t[q], x));
+        }
+    SeqPartial r;
+    r.a2 = t[0]; r.acx = t[1]; r.acy = t[2]; r.len = t[3]; r.lmx = t[4]; r.lmy = t[5]; r.sx = t[6]; r.sy = t[7];
+    r.mnx = t[8]; r.mny = t[9]; r.mxx = t[10]; r.mxy = t[11];
+    seq_store<MASK>(r, stats, n_seq, s);
+}
+
 template <int G, unsigned MASK>
-__global__ __launch_bounds__(256) void seq_stats_kernel(const double2* __restrict__ xy,
-                                                        const int32_t* __restrict__ seq_off,
-                                                        int64_t n_seq, double* __restrict__ stats) {
+__device__ __forceinline__ void seq_stats_group_body(const double2* __restrict__ xy, const int32_t* __restrict__ seq_off, int64_t n_seq,
+                                                     double* __restrict__ stats, const int32_t* __restrict__ list, int64_t n_list, int block,
+                                                     int n_blocks) {
+    // one size class: the sequences list[0..n_list) (every sequence in order when list == nullptr), G lanes each
     const int lane = threadIdx.x & (G - 1);
-    const int64_t groups_per_grid = (int64_t)gridDim.x * (blockDim.x / G);
-    for (int64_t s = (int64_t)blockIdx.x * (blockDim.x / G) + threadIdx.x / G; s < n_seq;
-         s += groups_per_grid) {
+    const int64_t groups_per_grid = (int64_t)n_blocks * (256 / G);
+    for (int64_t k = (int64_t)block * (256 / G) + threadIdx.x / G; k < n_list; k += groups_per_grid) {
+        const int64_t s = list ? (int64_t)list[k] : k;
         if ((MASK & M_DEGEN) && stats[ST_AREA2 * n_seq + s] != 0.0) continue;  // group-uniform
         const int c0 = seq_off[s], c1 = seq_off[s + 1];
         const int n = c1 - c0;
-        if (n > SEQ_LONG) continue;  // reduced by seq_stats_long_kernel
         double a2 = 0, acx = 0, acy = 0, len = 0, lmx = 0, lmy = 0, sx_ = 0, sy_ = 0;
         double mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
         double2 first = make_double2(0, 0), last = make_double2(0, 0);
@@ -575,9 +635,40 @@ __global__ __launch_bounds__(256) void affine_rows_kernel(DevGeo a, const double
     }
 }
 
-// Lanes per coordinate sequence: ~8 vertices per lane.  Fewer lanes per ring means fewer xor-shuffle
-// reduction steps per vertex (with G = 64 on 65-vertex rings the reductions outweighed the streaming work 3:1)
-// while a group still reads G consecutive vertices (>= 64 contiguous bytes) per load.
+// ONE launch for all size classes: consecutive ranges of work-groups take the long chunks, then the 2-, 8- and 16-lane
+// classes (the long chunks first: they are the longest-running work-groups).  Separate launches would each pay a
+// launch gap and a tail on columns where a class holds only a few sequences.
+struct SeqPlan {
+    const int32_t* list[4];  // ids per class (nullptr = all sequences in order)
+    int64_t count[4];
+    int blocks[4];           // work-groups given to: class 0, 1, 2, long
+    const int32_t* chunk_begin;
+    int64_t n_chunks;
+    double* long_part;
+};
+template <unsigned MASK>
+__global__ __launch_bounds__(256) void seq_stats_kernel(const double2* __restrict__ xy, const int32_t* __restrict__ seq_off, int64_t n_seq,
+                                                        double* __restrict__ stats, SeqPlan p) {
+    int b = blockIdx.x;
+    if (b < p.blocks[3]) {
+        seq_stats_long_body<MASK>(xy, seq_off, n_seq, p.list[3], p.count[3], p.chunk_begin, p.n_chunks, p.long_part, stats, b, p.blocks[3]);
+        return;
+    }
+    b -= p.blocks[3];
+    if (b < p.blocks[0]) {
+        seq_stats_group_body<2, MASK>(xy, seq_off, n_seq, stats, p.list[0], p.count[0], b, p.blocks[0]);
+        return;
+    }
+    b -= p.blocks[0];
+    if (b < p.blocks[1]) {
+        seq_stats_group_body<8, MASK>(xy, seq_off, n_seq, stats, p.list[1], p.count[1], b, p.blocks[1]);
+        return;
+    }
+    b -= p.blocks[1];
+    seq_stats_group_body<16, MASK>(xy, seq_off, n_seq, stats, p.list[2], p.count[2], b, p.blocks[2]);
+}
+
+// lanes per geometry for the per-row affine kernel: ~8 vertices per lane
 static int pick_group(int64_t n_coords, int64_t n_seq) {
     const double mean = n_seq > 0 ? (double)n_coords / (double)n_seq : 1.0;
     int g = 4;
@@ -595,30 +686,117 @@ static void seq_view(const DevGeo& a, const int32_t** seq_off, int64_t* n_seq) {
     }
 }
 
+// classification of an array's sequences, built once per handle (the lock also orders concurrent first uses)
+static std::mutex g_classes_mu;
+static int32_t seq_classes_of(const gpk_geoarray* a, hipStream_t s, const gpk_seq_classes** out) {
+    std::lock_guard<std::mutex> lk(g_classes_mu);
+    if (a->classes) {
+        *out = a->classes;
+        return GPK_OK;
+    }
+    const int32_t* seq_off;
+    int64_t n_seq;
+    seq_view(a->d, &seq_off, &n_seq);
+    gpk_seq_classes* c = new gpk_seq_classes;
+    memset(c, 0, sizeof *c);
+    auto bail = [&](int32_t rc) {
+        if (c->lists) (void)hipFree(c->lists);
+        if (c->chunk_begin) (void)hipFree(c->chunk_begin);
+        delete c;
+        return rc;
+    };
+    if (n_seq > 0) {
+        int32_t* cursor = nullptr;
+        hipError_t e = hipMalloc((void**)&cursor, 4 * sizeof(int32_t));
+        if (e != hipSuccess) return bail(fail(GPK_ERR_OOM, "size classes: %s", hipGetErrorString(e)));
+        int32_t h[4] = {0, 0, 0, 0};
+        auto run = [&]() -> int32_t {
+            GPK_HIP(hipMemsetAsync(cursor, 0, 4 * sizeof(int32_t), s));
+            GPK_LAUNCH("gpk_seq_classify", seq_classify_kernel<false>, dim3((unsigned)((n_seq + 255) / 256)), dim3(256), 0, s, seq_off, n_seq, cursor,
+                       (int32_t*)nullptr);
+            GPK_HIP(hipMemcpyAsync(h, cursor, sizeof h, hipMemcpyDeviceToHost, s));
+            GPK_HIP(hipStreamSynchronize(s));
+            int64_t run_begin = 0;
+            bool single = false;
+            for (int k = 0; k < 4; ++k) {
+                c->count[k] = h[k];
+                c->begin[k] = run_begin;
+                run_begin += h[k];
+                single |= (int64_t)h[k] == n_seq;
+            }
+            if (single) return GPK_OK;  // one class holds everything: kernels walk the sequences in order, no list
+            GPK_HIP(hipMalloc((void**)&c->lists, sizeof(int32_t) * (size_t)n_seq));
+            int32_t b32[4] = {(int32_t)c->begin[0], (int32_t)c->begin[1], (int32_t)c->begin[2], (int32_t)c->begin[3]};
+            GPK_HIP(hipMemcpyAsync(cursor, b32, sizeof b32, hipMemcpyHostToDevice, s));
+            GPK_LAUNCH("gpk_seq_classify", seq_classify_kernel<true>, dim3((unsigned)((n_seq + 255) / 256)), dim3(256), 0, s, seq_off, n_seq, cursor,
+                       c->lists);
+            GPK_HIP(hipStreamSynchronize(s));
+            return GPK_OK;
+        };
+        int32_t rc = run();
+        (void)hipFree(cursor);
+        if (rc == GPK_OK && c->count[3] > 0) {  // chunks of the long sequences (exclusive scan over the long list)
+            const int64_t nl = c->count[3], nb = (nl + 255) / 256;
+            int32_t* chunks = nullptr;
+            unsigned long long* btot = nullptr;
+            auto run2 = [&]() -> int32_t {
+                GPK_HIP(hipMalloc((void**)&chunks, sizeof(int32_t) * (size_t)(nl + 1)));
+                GPK_HIP(hipMalloc((void**)&btot, sizeof(unsigned long long) * (size_t)(nb + 2)));
+                GPK_HIP(hipMalloc((void**)&c->chunk_begin, sizeof(int32_t) * (size_t)(nl + 1)));
+                const int32_t* list = c->lists ? c->lists + c->begin[3] : nullptr;
+                GPK_LAUNCH("gpk_seq_long_chunks", long_chunk_count_kernel, dim3((unsigned)nb), dim3(256), 0, s, seq_off, list, nl, chunks);
+                GPK_TRY(exclusive_scan_i32(chunks, nl, c->chunk_begin, nullptr, btot, s));
+                int32_t total = 0;
+                GPK_HIP(hipMemcpyAsync(&total, c->chunk_begin + nl, sizeof total, hipMemcpyDeviceToHost, s));
+                GPK_HIP(hipStreamSynchronize(s));
+                c->n_chunks = total;
+                return GPK_OK;
+            };
+            rc = run2();
+            if (chunks) (void)hipFree(chunks);
+            if (btot) (void)hipFree(btot);
+        }
+        if (rc != GPK_OK) return bail(rc);
+    }
+    const_cast<gpk_geoarray*>(a)->classes = c;
+    *out = c;
+    return GPK_OK;
+}
+
 template <unsigned MASK>
-static int32_t launch_seq_stats(const DevGeo& a, double* stats, int32_t* long_ws, hipStream_t s, const char* name) {
+static int32_t launch_seq_stats(const gpk_geoarray* arr, double* stats, double* long_part, hipStream_t s, const char* name) {
+    const DevGeo& a = arr->d;
     const int32_t* seq_off;
     int64_t n_seq;
     seq_view(a, &seq_off, &n_seq);
     if (n_seq == 0) return GPK_OK;
-    if (!(MASK & M_DEGEN)) {  // the degenerate-only second pass reuses the list of the first pass
-        GPK_HIP(hipMemsetAsync(long_ws, 0, sizeof(int32_t), s));
-        GPK_LAUNCH("gpk_find_long", find_long_kernel, dim3((unsigned)((n_seq + 255) / 256)), dim3(256), 0, s, seq_off, n_seq, long_ws);
-    }
-    GPK_LAUNCH("gpk_seq_long", (seq_stats_long_kernel<MASK>), dim3(1024), dim3(256), 0, s, a.xy, seq_off, n_seq, long_ws, stats);
-    const int G = pick_group(a.n_coords, n_seq);
-    const int64_t groups_per_block = 256 / G;
-    int64_t blocks = (n_seq + groups_per_block - 1) / groups_per_block;
+    const gpk_seq_classes* c;
+    GPK_TRY(seq_classes_of(arr, s, &c));
     const int64_t cap = (int64_t)cu_count() * 16;
-    if (blocks > cap) blocks = cap;
-    dim3 grid((unsigned)blocks), block(256);
-    switch (G) {
-    case 4: GPK_LAUNCH(name, (seq_stats_kernel<4, MASK>), grid, block, 0, s, a.xy, seq_off, n_seq, stats); break;
-    case 8: GPK_LAUNCH(name, (seq_stats_kernel<8, MASK>), grid, block, 0, s, a.xy, seq_off, n_seq, stats); break;
-    case 16: GPK_LAUNCH(name, (seq_stats_kernel<16, MASK>), grid, block, 0, s, a.xy, seq_off, n_seq, stats); break;
-    case 32: GPK_LAUNCH(name, (seq_stats_kernel<32, MASK>), grid, block, 0, s, a.xy, seq_off, n_seq, stats); break;
-    default: GPK_LAUNCH(name, (seq_stats_kernel<64, MASK>), grid, block, 0, s, a.xy, seq_off, n_seq, stats); break;
+    SeqPlan p;
+    int total_blocks = 0;
+    for (int k = 0; k < 4; ++k) {
+        p.list[k] = c->lists ? (const int32_t*)(c->lists + c->begin[k]) : (const int32_t*)nullptr;
+        p.count[k] = c->count[k];
+        int64_t blocks;
+        if (k == 3) {
+            blocks = c->n_chunks < 4096 ? c->n_chunks : 4096;
+        } else {
+            const int64_t groups_per_block = 256 / SEQ_LANES[k];
+            blocks = (c->count[k] + groups_per_block - 1) / groups_per_block;
+            if (blocks > cap) blocks = cap;
+        }
+        p.blocks[k] = c->count[k] > 0 ? (int)blocks : 0;
+        total_blocks += p.blocks[k];
     }
+    p.chunk_begin = c->chunk_begin;
+    p.n_chunks = c->n_chunks;
+    p.long_part = long_part;
+    static_assert(SEQ_LANES[0] == 2 && SEQ_LANES[1] == 8 && SEQ_LANES[2] == 16, "seq_stats_kernel's dispatch");
+    if (total_blocks > 0) GPK_LAUNCH(name, (seq_stats_kernel<MASK>), dim3((unsigned)total_blocks), dim3(256), 0, s, a.xy, seq_off, n_seq, stats, p);
+    if (c->n_chunks > c->count[3])  // some sequence spans several chunks
+        GPK_LAUNCH("gpk_seq_long_combine", (seq_long_combine_kernel<MASK>), dim3((unsigned)((c->count[3] + 255) / 256)), dim3(256), 0, s, p.list[3],
+                   c->count[3], (const int32_t*)c->chunk_begin, (const double*)long_part, n_seq, stats);
     return GPK_OK;
 }
 
@@ -630,7 +808,7 @@ static inline dim3 grid_for(int64_t n, int block = 256) {
 // common prologue: stats + output staging in the workspace
 struct UnaryCtx {
     double* stats = nullptr;
-    int32_t* long_ws = nullptr;  // [0] = count, then the ids of the sequences longer than SEQ_LONG
+    double* long_part = nullptr;  // chunk partials of the long sequences (seq_stats_long_kernel)
     void* out_dev = nullptr;
     void* out2_dev = nullptr;
     int64_t n_seq = 0;
@@ -644,10 +822,15 @@ static int32_t unary_begin(const gpk_geoarray* a, size_t out_bytes, size_t out2_
     if (a->d.type == GPK_GEOM_POINT) c->n_seq = 0;
     const size_t stats_bytes = sizeof(double) * ST_COUNT * (size_t)c->n_seq;
     const bool stage = out_space != GPK_MEM_DEVICE;
-    const size_t long_bytes = sizeof(int32_t) * (size_t)(c->n_seq + 1);
-    GPK_TRY(workspace().begin(align256(stats_bytes) + align256(long_bytes) + (stage ? align256(out_bytes) + align256(out2_bytes) : 0) + 1024));
+    size_t part_bytes = 0;
+    if (c->n_seq > 0) {
+        const gpk_seq_classes* cl;
+        GPK_TRY(seq_classes_of(a, (hipStream_t) nullptr, &cl));
+        part_bytes = sizeof(double) * 12 * (size_t)cl->n_chunks;
+    }
+    GPK_TRY(workspace().begin(align256(stats_bytes) + align256(part_bytes) + (stage ? align256(out_bytes) + align256(out2_bytes) : 0) + 1024));
     c->stats = (double*)workspace().take(stats_bytes ? stats_bytes : 8);
-    c->long_ws = (int32_t*)workspace().take(long_bytes);
+    c->long_part = part_bytes ? (double*)workspace().take(part_bytes) : nullptr;
     c->out_dev = stage ? workspace().take(out_bytes ? out_bytes : 8) : out;
     c->out2_dev = out2 ? (stage ? workspace().take(out2_bytes ? out2_bytes : 8) : out2) : nullptr;
     return GPK_OK;
@@ -669,10 +852,13 @@ int32_t ring_bboxes(const gpk_geoarray* a, double4* out_dev, hipStream_t s) {
     int64_t n_seq;
     seq_view(a->d, &seq_off, &n_seq);
     if (n_seq == 0) return GPK_OK;
-    GPK_TRY(workspace().begin(sizeof(double) * ST_COUNT * (size_t)n_seq + sizeof(int32_t) * (size_t)(n_seq + 1) + 1024));
+    const gpk_seq_classes* cl;
+    GPK_TRY(seq_classes_of(a, s, &cl));
+    const size_t part_bytes = sizeof(double) * 12 * (size_t)cl->n_chunks;
+    GPK_TRY(workspace().begin(align256(sizeof(double) * ST_COUNT * (size_t)n_seq) + align256(part_bytes) + 1024));
     double* stats = (double*)workspace().take(sizeof(double) * ST_COUNT * (size_t)n_seq);
-    int32_t* long_ws = (int32_t*)workspace().take(sizeof(int32_t) * (size_t)(n_seq + 1));
-    GPK_TRY(launch_seq_stats<M_BBOX>(a->d, stats, long_ws, s, "gpk_seq_bbox"));
+    double* long_part = part_bytes ? (double*)workspace().take(part_bytes) : nullptr;
+    GPK_TRY(launch_seq_stats<M_BBOX>(a, stats, long_part, s, "gpk_seq_bbox"));
     GPK_LAUNCH("gpk_stats_to_bbox", stats_to_bbox_kernel, grid_for(n_seq), dim3(256), 0, s, stats, seq_off, n_seq, out_dev);
     return GPK_OK;
 }
@@ -693,7 +879,7 @@ static int32_t area_impl(const gpk_geoarray* a, double* out, int32_t out_space, 
     if (a->d.type == GPK_GEOM_POINT) {
         GPK_LAUNCH("gpk_point_unary", point_unary_kernel, grid_for(n), dim3(256), 0, s, a->d, 0, (double*)c.out_dev, (uint8_t*)nullptr);
     } else {
-        if (is_polygonal(a->d.type)) GPK_TRY(launch_seq_stats<M_AREA>(a->d, c.stats, c.long_ws, s, "gpk_ring_area"));
+        if (is_polygonal(a->d.type)) GPK_TRY(launch_seq_stats<M_AREA>(a, c.stats, c.long_part, s, "gpk_ring_area"));
         if (is_signed)
             GPK_LAUNCH("gpk_area_combine", area_combine_kernel<true>, grid_for(n), dim3(256), 0, s, a->d, c.stats, c.n_seq, (double*)c.out_dev);
         else
@@ -719,7 +905,7 @@ int32_t gpk_euclidean_length(const gpk_geoarray* a, double* out, int32_t out_spa
     if (a->d.type == GPK_GEOM_POINT) {
         GPK_LAUNCH("gpk_point_unary", point_unary_kernel, grid_for(n), dim3(256), 0, s, a->d, 0, (double*)c.out_dev, (uint8_t*)nullptr);
     } else {
-        if (a->d.type != GPK_GEOM_MULTIPOINT) GPK_TRY(launch_seq_stats<M_LEN>(a->d, c.stats, c.long_ws, s, "gpk_seq_length"));
+        if (a->d.type != GPK_GEOM_MULTIPOINT) GPK_TRY(launch_seq_stats<M_LEN>(a, c.stats, c.long_part, s, "gpk_seq_length"));
         GPK_LAUNCH("gpk_length_combine", length_combine_kernel, grid_for(n), dim3(256), 0, s, a->d, c.stats, c.n_seq, (double*)c.out_dev);
     }
     return copy_out(out, out_space, c.out_dev, ob, s);
@@ -735,7 +921,7 @@ int32_t gpk_bounds(const gpk_geoarray* a, double* out4, int32_t out_space, void*
     if (a->d.type == GPK_GEOM_POINT) {
         GPK_LAUNCH("gpk_point_unary", point_unary_kernel, grid_for(n), dim3(256), 0, s, a->d, 2, (double*)c.out_dev, (uint8_t*)nullptr);
     } else {
-        GPK_TRY(launch_seq_stats<M_BBOX>(a->d, c.stats, c.long_ws, s, "gpk_seq_bbox"));
+        GPK_TRY(launch_seq_stats<M_BBOX>(a, c.stats, c.long_part, s, "gpk_seq_bbox"));
         GPK_LAUNCH("gpk_bounds_combine", bounds_combine_kernel, grid_for(n), dim3(256), 0, s, a->d, c.stats, c.n_seq, (double*)c.out_dev);
     }
     return copy_out(out4, out_space, c.out_dev, ob, s);
@@ -753,13 +939,13 @@ int32_t gpk_centroid(const gpk_geoarray* a, double* out_xy, uint8_t* out_valid, 
         GPK_LAUNCH("gpk_point_unary", point_unary_kernel, grid_for(n), dim3(256), 0, s, a->d, 1, (double*)c.out_dev, (uint8_t*)c.out2_dev);
     } else {
         if (a->d.type == GPK_GEOM_MULTIPOINT)
-            GPK_TRY(launch_seq_stats<M_SUM>(a->d, c.stats, c.long_ws, s, "gpk_seq_sum"));
+            GPK_TRY(launch_seq_stats<M_SUM>(a, c.stats, c.long_part, s, "gpk_seq_sum"));
         else if (is_polygonal(a->d.type)) {
-            GPK_TRY(launch_seq_stats<M_CENT>(a->d, c.stats, c.long_ws, s, "gpk_ring_centroid"));
+            GPK_TRY(launch_seq_stats<M_CENT>(a, c.stats, c.long_part, s, "gpk_ring_centroid"));
             // zero-area rings degrade to their linestring centroid: a second pass that skips everything else
-            GPK_TRY(launch_seq_stats<M_LENC | M_DEGEN>(a->d, c.stats, c.long_ws, s, "gpk_ring_centroid_degenerate"));
+            GPK_TRY(launch_seq_stats<M_LENC | M_DEGEN>(a, c.stats, c.long_part, s, "gpk_ring_centroid_degenerate"));
         } else {
-            GPK_TRY(launch_seq_stats<M_LENC>(a->d, c.stats, c.long_ws, s, "gpk_line_centroid"));
+            GPK_TRY(launch_seq_stats<M_LENC>(a, c.stats, c.long_part, s, "gpk_line_centroid"));
         }
         GPK_LAUNCH("gpk_centroid_combine", centroid_combine_kernel, grid_for(n), dim3(256), 0, s, a->d, c.stats, c.n_seq, (double*)c.out_dev, (uint8_t*)c.out2_dev);
     }

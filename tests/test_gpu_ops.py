@@ -24,6 +24,28 @@ def _close(got, exp, rtol=RTOL):
     assert not bad.any(), f"max rel err {np.max(np.abs(g - e) / scale):.3e}"
 
 
+def _ring(n, r, cx, cy, phase=0.0):
+    t = phase + 2 * np.pi * np.arange(n) / n
+    rr = r * (1.0 + 0.3 * np.sin(7 * t))
+    return [(cx + rr[i] * np.cos(t[i]), cy + rr[i] * np.sin(t[i])) for i in range(n)]
+
+
+def _ragged_polygons():
+    """every size class of the streaming reductions in one array: rings of 3..16, 17..128, 129..512 vertices, one-chunk
+    long rings, rings spanning several 8192-coordinate chunks (one with a long hole), a degenerate zero-area giant"""
+    sizes = [3, 4, 15, 16, 17, 100, 128, 129, 400, 512, 513, 5000, 8191, 8192, 8193, 30000, 70001]
+    polys = [[_ring(n, 10.0 + k, 100.0 * k, 50.0)] for k, n in enumerate(sizes)]
+    polys.append([_ring(40000, 50.0, -500.0, -500.0), _ring(20000, 10.0, -500.0, -500.0, 0.5)[::-1]])
+    line = [(float(i), 2.0 * i) for i in range(9000)]
+    polys.append([line + line[-2::-1]])  # 17999-coordinate ring of zero area: length-weighted centroid, chunked
+    return GeoArrowArray.from_polygons(polys)
+
+
+def _giant_linestrings():
+    rng = np.random.default_rng(12)
+    return GeoArrowArray.from_linestrings([np.cumsum(rng.normal(size=(n, 2)), axis=0).tolist() for n in (2, 9, 600, 8192, 8193, 50000)])
+
+
 def _arrays():
     return {
         "stars": synth.star_polygons(300, 64),
@@ -31,6 +53,8 @@ def _arrays():
         "clustered": synth.clustered_polygons(2000),
         "multipoly": synth.powerlaw_multipolygons(1500),
         "lines": synth.random_linestrings(800),
+        "ragged": _ragged_polygons(),
+        "giant_lines": _giant_linestrings(),
         "points": synth.uniform_points(5000),
         "holes": GeoArrowArray.from_polygons(
             [

@@ -44,11 +44,12 @@ def timed(lib, fn, reps=10):
     lib.gpk_profile_query(b"", C.byref(ms), C.byref(cnt))
     out = {}
     # per-kernel breakdown
-    for name in (b"gpk_ring_area", b"gpk_area_combine", b"gpk_seq_bbox", b"gpk_bounds_combine", b"gpk_ring_centroid", b"gpk_centroid_combine", b"gpk_affine", b"gpk_distance", b"gpk_seq_length", b"gpk_length_combine"):
+    # per-kernel breakdown: ms per call of the operator (a name may cover several launches)
+    for name in (b"gpk_ring_area", b"gpk_seq_bbox", b"gpk_ring_centroid", b"gpk_seq_long_combine", b"gpk_area_combine", b"gpk_bounds_combine", b"gpk_centroid_combine", b"gpk_affine", b"gpk_distance", b"gpk_length_combine"):
         m, c = C.c_double(0), C.c_int64(0)
         lib.gpk_profile_query(name, C.byref(m), C.byref(c))
         if c.value:
-            out[name.decode()] = m.value / c.value
+            out[name.decode()] = m.value / reps
     lib.gpk_profile_reset()
     return ms.value / reps, out
 
