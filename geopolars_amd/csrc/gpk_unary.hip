@@ -89,6 +89,40 @@ __device__ __forceinline__ void seq_accumulate(SeqPartial& a, const double2* __r
         }
     }
 }
+// the same accumulation with the vertex and its successor already in registers
+template <unsigned MASK>
+__device__ __forceinline__ void seq_accumulate_pq(SeqPartial& a, double2 p, double2 q, bool has_q, double2 first, bool closed_ring) {
+    if (MASK & M_BBOX) {
+        a.mnx = p.x < a.mnx ? p.x : a.mnx;
+        a.mny = p.y < a.mny ? p.y : a.mny;
+        a.mxx = p.x > a.mxx ? p.x : a.mxx;
+        a.mxy = p.y > a.mxy ? p.y : a.mxy;
+    }
+    if (MASK & M_SUM) {
+        a.sx += p.x;
+        a.sy += p.y;
+    }
+    if ((MASK & (M_AREA | M_CENT | M_LEN | M_LENC)) && has_q) {
+        if ((MASK & (M_AREA | M_CENT)) && closed_ring) {
+            const double sx = p.x - first.x, sy = p.y - first.y;
+            const double ex = q.x - first.x, ey = q.y - first.y;
+            const double cr = sx * ey - sy * ex;
+            a.a2 += cr;
+            if (MASK & M_CENT) {
+                a.acx += (ex + sx) * cr;
+                a.acy += (ey + sy) * cr;
+            }
+        }
+        if (MASK & (M_LEN | M_LENC)) {
+            const double l = hypot(q.x - p.x, q.y - p.y);
+            a.len += l;
+            if (MASK & M_LENC) {
+                a.lmx += (p.x + q.x) / 2.0 * l;
+                a.lmy += (p.y + q.y) / 2.0 * l;
+            }
+        }
+    }
+}
 template <unsigned MASK>
 __device__ __forceinline__ void seq_store(const SeqPartial& a, double* __restrict__ stats, int64_t n_seq, int64_t s) {
     if (MASK & (M_AREA | M_CENT)) stats[ST_AREA2 * n_seq + s] = a.a2;
@@ -264,8 +298,23 @@ __device__ __forceinline__ void seq_stats_group_body(const double2* __restrict__
         }
         // twice_signed_ring_area: < 3 coords or open -> 0 (area.rs); centroid's add_ring uses the same
         const bool closed_ring = n >= 3 && first.x == last.x && first.y == last.y;
-        for (int i = c0 + lane; i < c1; i += G) {
-            const double2 p = xy[i];
+        // ONE load per vertex: lane l holds vertex c0 + t*G + l in round t; the edge's other end is the neighbour lane's
+        // vertex (DPP row shift), and for the group's last lane the first lane's vertex of the NEXT round, which is
+        // prefetched one round ahead anyway.  Trip count is uniform within the group (all its lanes stay active for DPP).
+        constexpr bool EDGES = (MASK & (M_AREA | M_CENT | M_LEN | M_LENC)) != 0;
+        int i = c0 + lane;
+        double2 cur = i < c1 ? xy[i] : make_double2(0.0, 0.0);
+        for (int base = c0; base < c1; base += G, i += G) {
+            const double2 nxt = i + G < c1 ? xy[i + G] : make_double2(0.0, 0.0);
+            const double2 p = cur;
+            double2 q = make_double2(0.0, 0.0);
+            if (EDGES) {
+                const double ax = dev::dpp_mov<0x101>(cur.x), ay = dev::dpp_mov<0x101>(cur.y);                  // row_shl:1
+                const double bx = dev::dpp_mov<0x110 + G - 1>(nxt.x), by = dev::dpp_mov<0x110 + G - 1>(nxt.y);  // row_shr:G-1
+                q = lane == G - 1 ? make_double2(bx, by) : make_double2(ax, ay);
+            }
+            cur = nxt;
+            if (i >= c1) continue;
             if (MASK & M_BBOX) {
                 mnx = p.x < mnx ? p.x : mnx;
                 mny = p.y < mny ? p.y : mny;
@@ -276,8 +325,7 @@ __device__ __forceinline__ void seq_stats_group_body(const double2* __restrict__
                 sx_ += p.x;
                 sy_ += p.y;
             }
-            if ((MASK & (M_AREA | M_CENT | M_LEN | M_LENC)) && i + 1 < c1) {
-                const double2 q = xy[i + 1];
+            if (EDGES && i + 1 < c1) {
                 if ((MASK & (M_AREA | M_CENT)) && closed_ring) {
                     const double sx = p.x - first.x, sy = p.y - first.y;
                     const double ex = q.x - first.x, ey = q.y - first.y;
@@ -635,6 +683,104 @@ __global__ __launch_bounds__(256) void affine_rows_kernel(DevGeo a, const double
     }
 }
 
+// ---- class 0 (sequences of at most SEQ_MAXLEN[0] coordinates: building footprints, parcels) -------------------------
+// Two lanes per sequence means a wave works on 32 sequences at a time; loading them straight from global memory costs
+// one partially used load instruction per round and sequence pair (the texture-address units, not HBM, set the pace:
+// 3.0 TB/s on 9-coordinate rings).  Instead the wave copies the whole coordinate span of its 32 sequences into LDS with
+// full-width coalesced loads and the lanes read their vertices from there.  Spans wider than TINY_SPAN (sequences of
+// other classes in between) fall back to direct loads for that round.
+constexpr int TINY_SPAN = 512;  // coordinates staged per wave and round (8 KB)
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int w = __shfl_xor(v, o, 64);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int w = __shfl_xor(v, o, 64);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+template <unsigned MASK>
+__device__ __forceinline__ void seq_stats_tiny_body(const double2* __restrict__ xy, const int32_t* __restrict__ seq_off, int64_t n_seq,
+                                                    double* __restrict__ stats, const int32_t* __restrict__ list, int64_t n_list, int block,
+                                                    int n_blocks, double2* __restrict__ lds) {
+    constexpr int G = 2;
+    const int lane64 = threadIdx.x & 63, lane = threadIdx.x & (G - 1), wave = threadIdx.x >> 6;
+    double2* __restrict__ buf = lds + wave * TINY_SPAN;
+    const int64_t per_round = (int64_t)n_blocks * (256 / G);
+    for (int64_t k0 = (int64_t)block * (256 / G) + wave * (64 / G); k0 < n_list; k0 += per_round) {  // wave-uniform trip count
+        const int64_t k = k0 + lane64 / G;
+        bool act = k < n_list;
+        int64_t s = 0;
+        int c0 = 0, c1 = 0;
+        if (act) {
+            s = list ? (int64_t)list[k] : k;
+            c0 = seq_off[s];
+            c1 = seq_off[s + 1];
+            if ((MASK & M_DEGEN) && stats[ST_AREA2 * n_seq + s] != 0.0) act = false;
+        }
+        const bool has = act && c1 > c0;
+        const int lo = wave_min_i32(has ? c0 : 0x7FFFFFFF), hi = wave_max_i32(has ? c1 : (int)0x80000000);
+        const bool staged = hi > lo && hi - lo <= TINY_SPAN;  // wave-uniform
+        if (staged) {
+            __builtin_amdgcn_wave_barrier();  // the previous round's reads are done
+            for (int t = lane64; t < hi - lo; t += 64) buf[t] = xy[lo + t];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (act) {
+            const int n = c1 - c0;
+            SeqPartial a;
+            double2 first = make_double2(0, 0), last = make_double2(0, 0);
+            if (n > 0) {
+                first = staged ? buf[c0 - lo] : xy[c0];
+                last = staged ? buf[c1 - 1 - lo] : xy[c1 - 1];
+            }
+            const bool closed_ring = n >= 3 && first.x == last.x && first.y == last.y;
+            for (int i = c0 + lane; i < c1; i += G) {
+                const bool has_q = i + 1 < c1;
+                double2 p, q = make_double2(0, 0);
+                if (staged) {
+                    p = buf[i - lo];
+                    if (has_q) q = buf[i + 1 - lo];
+                } else {
+                    p = xy[i];
+                    if (has_q) q = xy[i + 1];
+                }
+                seq_accumulate_pq<MASK>(a, p, q, has_q, first, closed_ring);
+            }
+            if (MASK & (M_AREA | M_CENT)) a.a2 = group_sum<G>(a.a2);
+            if (MASK & M_CENT) {
+                a.acx = group_sum<G>(a.acx);
+                a.acy = group_sum<G>(a.acy);
+            }
+            if (MASK & M_LENC) {
+                a.lmx = group_sum<G>(a.lmx);
+                a.lmy = group_sum<G>(a.lmy);
+            }
+            if (MASK & (M_LEN | M_LENC)) a.len = group_sum<G>(a.len);
+            if (MASK & M_BBOX) {
+                a.mnx = group_min<G>(a.mnx);
+                a.mny = group_min<G>(a.mny);
+                a.mxx = group_max<G>(a.mxx);
+                a.mxy = group_max<G>(a.mxy);
+            }
+            if (MASK & M_SUM) {
+                a.sx = group_sum<G>(a.sx);
+                a.sy = group_sum<G>(a.sy);
+            }
+            if (lane == 0) seq_store<MASK>(a, stats, n_seq, s);
+        }
+    }
+}
+
 // ONE launch for all size classes: consecutive ranges of work-groups take the long chunks, then the 2-, 8- and 16-lane
 // classes (the long chunks first: they are the longest-running work-groups).  Separate launches would each pay a
 // launch gap and a tail on columns where a class holds only a few sequences.
@@ -656,7 +802,14 @@ __global__ __launch_bounds__(256) void seq_stats_kernel(const double2* __restric
     }
     b -= p.blocks[3];
     if (b < p.blocks[0]) {
-        seq_stats_group_body<2, MASK>(xy, seq_off, n_seq, stats, p.list[0], p.count[0], b, p.blocks[0]);
+        // a column of short sequences only: consecutive sequences are adjacent in memory, stage them through LDS.  In a
+        // mixed column the 32 sequences of a round are interleaved with longer ones (half of the rounds of the power-law
+        // test column span more than TINY_SPAN coordinates and the rest load 50 % foreign bytes): lane groups then.
+        extern __shared__ double2 tiny_lds[];  // 4 waves x TINY_SPAN coordinates, allocated only for the staged form
+        if (p.list[0] == nullptr)
+            seq_stats_tiny_body<MASK>(xy, seq_off, n_seq, stats, p.list[0], p.count[0], b, p.blocks[0], tiny_lds);
+        else
+            seq_stats_group_body<2, MASK>(xy, seq_off, n_seq, stats, p.list[0], p.count[0], b, p.blocks[0]);
         return;
     }
     b -= p.blocks[0];
@@ -793,7 +946,9 @@ static int32_t launch_seq_stats(const gpk_geoarray* arr, double* stats, double* 
     p.n_chunks = c->n_chunks;
     p.long_part = long_part;
     static_assert(SEQ_LANES[0] == 2 && SEQ_LANES[1] == 8 && SEQ_LANES[2] == 16, "seq_stats_kernel's dispatch");
-    if (total_blocks > 0) GPK_LAUNCH(name, (seq_stats_kernel<MASK>), dim3((unsigned)total_blocks), dim3(256), 0, s, a.xy, seq_off, n_seq, stats, p);
+    const size_t tiny_lds = (p.blocks[0] > 0 && !p.list[0]) ? sizeof(double2) * 4 * TINY_SPAN : 0;
+    if (total_blocks > 0)
+        GPK_LAUNCH(name, (seq_stats_kernel<MASK>), dim3((unsigned)total_blocks), dim3(256), tiny_lds, s, a.xy, seq_off, n_seq, stats, p);
     if (c->n_chunks > c->count[3])  // some sequence spans several chunks
         GPK_LAUNCH("gpk_seq_long_combine", (seq_long_combine_kernel<MASK>), dim3((unsigned)((c->count[3] + 255) / 256)), dim3(256), 0, s, p.list[3],
                    c->count[3], (const int32_t*)c->chunk_begin, (const double*)long_part, n_seq, stats);
