@@ -127,6 +127,7 @@ constexpr int PIP_QCAP = GPK_PIP_QCAP;             // LDS queue capacity (overfl
 constexpr int PIP_SUPER_SHIFT = 6;             // 64 tiles per super-tile (two-level prefix of the tile totals)
 constexpr int PIP_WPT = 8;                     // writer: consecutive points per thread
 constexpr int PIP_WTILE = WR_BLOCK * PIP_WPT;  // writer: points per work-group (a multiple of PIP_TILE)
+constexpr int WR_CAP = PIP_WTILE;              // writer: pairs of one tile compacted in LDS (16 KB) before the coalesced copy-out
 static_assert(PIP_WTILE % PIP_TILE == 0, "a writer tile is a whole number of pip_tile tiles");
 // per-point result code handed from pip_tile to pip_write: a geometry id (exactly one hit), CODE_NONE, or
 // CODE_MULTI (several hits: the writer re-enumerates them with the generic walk)
@@ -519,6 +520,7 @@ __global__ __launch_bounds__(WR_BLOCK) void pip_write_kernel(DevGeo pts, DevGeo 
                                                                unsigned long long* __restrict__ grand_host) {
     __shared__ unsigned long long lds[WR_BLOCK / 64 + 1];
     __shared__ unsigned long long s_base;
+    __shared__ uint2 s_pairs[WR_CAP];
     const int tid = threadIdx.x;
     const int64_t first_tile = (int64_t)blockIdx.x * (PIP_WTILE / PIP_TILE);
     if (tid < 64) {
@@ -560,31 +562,40 @@ __global__ __launch_bounds__(WR_BLOCK) void pip_write_kernel(DevGeo pts, DevGeo 
         if (grand_host) *grand_host = s_base + tot;
     }
     if (!pairs) return;
+    // Pairs are compacted in LDS and copied out by consecutive lanes (full-line stores); a tile with more pairs than the
+    // LDS list holds (heavily overlapping right sides) writes them straight from the owning lanes instead.
+    const bool via_lds = tot <= (unsigned long long)WR_CAP;  // uniform across the work-group
+    const int64_t out_base = (int64_t)s_base;
+    auto emit = [&](int64_t at, uint2 v) {
+        if (via_lds)
+            s_pairs[at - out_base] = v;
+        else if (at < capacity)
+            pairs[at] = v;
+    };
 #pragma unroll
     for (int k = 0; k < PIP_WPT; ++k) {
         if (cnt[k] == 0) continue;
         const uint32_t l = left_base + (uint32_t)(i0 + k);
         if (c[k] != CODE_MULTI && (c[k] & CODE_POOL)) {  // several geometries, listed in the pool
             const uint32_t at = c[k] & ~CODE_POOL;
-            for (uint32_t t = 0; t < cnt[k]; ++t) {
-                if (o < capacity) pairs[o] = make_uint2(l, multi_pool[at + 1 + t]);
-                ++o;
-            }
+            for (uint32_t t = 0; t < cnt[k]; ++t) emit(o++, make_uint2(l, multi_pool[at + 1 + t]));
             continue;
         }
         if (c[k] != CODE_MULTI) {
-            if (o < capacity) pairs[o] = make_uint2(l, c[k]);
-            ++o;
+            emit(o++, make_uint2(l, c[k]));
             continue;
         }
         const double2 p = pts.xy[i0 + k];
         const GridParams g = *ix.grid;
         for_each_candidate(ix, g, p.x, p.y, [&](int j) {
-            if (dev::valid_row(polys.validity, j) && dev::polygonal_hits_point<false>(polys, j, p.x, p.y)) {
-                if (o < capacity) pairs[o] = make_uint2(l, (uint32_t)j);
-                ++o;
-            }
+            if (dev::valid_row(polys.validity, j) && dev::polygonal_hits_point<false>(polys, j, p.x, p.y)) emit(o++, make_uint2(l, (uint32_t)j));
         });
+    }
+    if (via_lds) {
+        __syncthreads();
+        const int n_out = (int)tot;
+        for (int t = tid; t < n_out; t += WR_BLOCK)
+            if (out_base + t < capacity) pairs[out_base + t] = s_pairs[t];
     }
 }
 
