@@ -3,9 +3,9 @@
 //
 // The hull of a point set is unique, so any exact algorithm returns the same ring up to its start
 // vertex; this kernel emits it starting at the lexicographically smallest vertex.  One lane per
-// geometry: in-place heap sort of a scratch copy, then a monotone chain driven by the exact
+// geometry: in-place heap sort of a copy (LDS, or global scratch for large geometries), then a monotone chain driven by the exact
 // orientation kernel.  Irregular per-row output sizes go through size -> scan -> compact.
-// This is the lowest-traffic operator of the surface and is not tuned.
+// This is the lowest-traffic operator of the surface; the sort's working set sits in LDS.
 #include "gpk_device.h"
 #include "gpk_scan.h"
 
@@ -13,36 +13,89 @@ namespace gpk {
 
 __device__ __forceinline__ bool xy_less(double2 a, double2 b) { return a.x < b.x || (a.x == b.x && a.y < b.y); }
 
-__device__ inline void heap_sort(double2* v, int n) {
-    for (int start = n / 2 - 1; start >= 0; --start) {
-        int root = start;
-        for (;;) {
-            int child = 2 * root + 1;
-            if (child >= n) break;
-            if (child + 1 < n && xy_less(v[child], v[child + 1])) ++child;
-            if (!xy_less(v[root], v[child])) break;
-            const double2 t = v[root];
-            v[root] = v[child];
-            v[child] = t;
-            root = child;
-        }
-    }
-    for (int end = n - 1; end > 0; --end) {
-        const double2 t = v[0];
-        v[0] = v[end];
-        v[end] = t;
-        int root = 0;
+// in-place heap sort of n points reached through ld(i) / st(i, v) (global scratch or the lane's LDS column)
+template <typename LD, typename ST>
+__device__ __forceinline__ void heap_sort(LD ld, ST st, int n) {
+    auto sift = [&](int root, int end) {
+        double2 rv = ld(root);
         for (;;) {
             int child = 2 * root + 1;
             if (child >= end) break;
-            if (child + 1 < end && xy_less(v[child], v[child + 1])) ++child;
-            if (!xy_less(v[root], v[child])) break;
-            const double2 u = v[root];
-            v[root] = v[child];
-            v[child] = u;
+            double2 cv = ld(child);
+            if (child + 1 < end) {
+                const double2 c2 = ld(child + 1);
+                if (xy_less(cv, c2)) {
+                    cv = c2;
+                    ++child;
+                }
+            }
+            if (!xy_less(rv, cv)) break;
+            st(root, cv);
             root = child;
         }
+        st(root, rv);
+    };
+    for (int start = n / 2 - 1; start >= 0; --start) sift(start, n);
+    for (int end = n - 1; end > 0; --end) {
+        const double2 t = ld(0);
+        st(0, ld(end));
+        st(end, t);
+        sift(0, end);
     }
+}
+
+// sort + dedup + monotone chain over the points ld(0..n); the hull is written to h (global), closed; returns its size.
+// The two topmost stack entries live in registers, so the chain touches memory once per push and once per pop.
+template <typename LD, typename ST>
+__device__ __forceinline__ int hull_of(LD ld, ST st, int n, double2* __restrict__ h) {
+    heap_sort(ld, st, n);
+    int m = 0;
+    {
+        double2 prev = make_double2(0, 0);
+        for (int i = 0; i < n; ++i) {
+            const double2 v = ld(i);
+            if (m == 0 || v.x != prev.x || v.y != prev.y) {
+                st(m++, v);
+                prev = v;
+            }
+        }
+    }
+    const double2 p0 = ld(0);
+    int k = 0;
+    if (m < 3) {
+        for (int i = 0; i < m; ++i) h[k++] = ld(i);
+    } else {
+        double2 t1 = p0, t2 = p0;  // h[k-1], h[k-2]
+        auto push = [&](double2 v) {
+            h[k++] = v;
+            t2 = t1;
+            t1 = v;
+        };
+        auto pop = [&]() {
+            --k;
+            t1 = t2;
+            if (k >= 2) t2 = h[k - 2];
+        };
+        for (int i = 0; i < m; ++i) {
+            const double2 v = ld(i);
+            while (k >= 2 && dev::orient2d(t2.x, t2.y, t1.x, t1.y, v.x, v.y) <= 0) pop();
+            push(v);
+        }
+        const int lo = k + 1;
+        for (int i = m - 2; i >= 0; --i) {
+            const double2 v = ld(i);
+            while (k >= lo && dev::orient2d(t2.x, t2.y, t1.x, t1.y, v.x, v.y) <= 0) pop();
+            push(v);
+        }
+        --k;
+        if (k < 3) {  // all collinear: the two extremes
+            k = 2;
+            h[0] = p0;
+            h[1] = ld(m - 1);
+        }
+    }
+    h[k] = h[0];  // close the ring
+    return k + 1;
 }
 
 __device__ __forceinline__ void geom_coord_range(const DevGeo& a, int64_t g, int& c0, int& c1) {
@@ -69,48 +122,45 @@ __device__ __forceinline__ void geom_coord_range(const DevGeo& a, int64_t g, int
     }
 }
 
-// scratch layout per geometry g with coordinate range [c0, c1): sorted copy at sorted[c0..c1),
-// chain stack at stack[2*c0 + 2*g .. 2*c1 + 2*g + 2)
-__global__ void hull_kernel(DevGeo a, double2* __restrict__ sorted, double2* __restrict__ stack,
-                            int32_t* __restrict__ sizes) {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= a.n_geoms) return;
-    int c0, c1;
-    geom_coord_range(a, g, c0, c1);
-    const int n = c1 - c0;
-    if (!dev::valid_row(a.validity, g) || n == 0) {
-        sizes[g] = 0;
-        return;
+// scratch layout per geometry g with coordinate range [c0, c1): sorted copy at sorted[c0..c1) (global path only),
+// chain stack at stack[2*c0 + 2*g .. 2*c1 + 2*g + 2).
+// One lane per geometry, one wave per work-group.  When every geometry of the wave has at most HULL_CAP points (the
+// closing duplicate of a ring does not count) the lanes keep their points in LDS, interleaved (element i of lane l at
+// [i * 64 + l]: conflict-free for equal i, and the sort's data-dependent indices never leave the lane's column); the heap
+// sort then runs out of LDS instead of making ~800 scattered global accesses per geometry (2M x 64-vertex polygons:
+// 70 ms -> see DESIGN.md).  Larger geometries sort in global scratch as before.
+constexpr int HULL_CAP = 64;
+__global__ __launch_bounds__(64) void hull_kernel(DevGeo a, double2* __restrict__ sorted, double2* __restrict__ stack,
+                                                  int32_t* __restrict__ sizes) {
+    __shared__ double2 lds[HULL_CAP * 64];
+    const int lane = threadIdx.x;
+    const int64_t g = (int64_t)blockIdx.x * 64 + lane;
+    int c0 = 0, c1 = 0;
+    bool act = g < a.n_geoms;
+    if (act) {
+        geom_coord_range(a, g, c0, c1);
+        if (!dev::valid_row(a.validity, g) || c1 == c0) {
+            sizes[g] = 0;
+            act = false;
+        }
     }
-    double2* p = sorted + c0;
+    int n = c1 - c0;
+    if (act && n >= 2) {  // a closing duplicate would only be removed by the dedup pass: drop it before sorting
+        const double2 f = a.xy[c0], l = a.xy[c1 - 1];
+        if (f.x == l.x && f.y == l.y) --n;
+    }
+    const bool fits = !act || n <= HULL_CAP;
+    const bool all_fit = __all(fits);  // wave-uniform
+    if (!act) return;
     double2* h = stack + 2 * (int64_t)c0 + 2 * g;
-    for (int i = 0; i < n; ++i) p[i] = a.xy[c0 + i];
-    heap_sort(p, n);
-    int m = 0;
-    for (int i = 0; i < n; ++i)
-        if (m == 0 || p[i].x != p[m - 1].x || p[i].y != p[m - 1].y) p[m++] = p[i];
-    int k = 0;
-    if (m < 3) {
-        for (int i = 0; i < m; ++i) h[k++] = p[i];
+    if (all_fit) {
+        for (int i = 0; i < n; ++i) lds[i * 64 + lane] = a.xy[c0 + i];
+        sizes[g] = hull_of([&](int i) { return lds[i * 64 + lane]; }, [&](int i, double2 v) { lds[i * 64 + lane] = v; }, n, h);
     } else {
-        for (int i = 0; i < m; ++i) {
-            while (k >= 2 && dev::orient2d(h[k - 2].x, h[k - 2].y, h[k - 1].x, h[k - 1].y, p[i].x, p[i].y) <= 0) --k;
-            h[k++] = p[i];
-        }
-        const int lo = k + 1;
-        for (int i = m - 2; i >= 0; --i) {
-            while (k >= lo && dev::orient2d(h[k - 2].x, h[k - 2].y, h[k - 1].x, h[k - 1].y, p[i].x, p[i].y) <= 0) --k;
-            h[k++] = p[i];
-        }
-        --k;
-        if (k < 3) {  // all collinear: the two extremes
-            k = 2;
-            h[0] = p[0];
-            h[1] = p[m - 1];
-        }
+        double2* p = sorted + c0;
+        for (int i = 0; i < n; ++i) p[i] = a.xy[c0 + i];
+        sizes[g] = hull_of([&](int i) { return p[i]; }, [&](int i, double2 v) { p[i] = v; }, n, h);
     }
-    h[k] = h[0];  // close the ring
-    sizes[g] = k + 1;
 }
 
 __global__ void hull_compact_kernel(DevGeo a, const double2* __restrict__ stack, const int32_t* __restrict__ off,
@@ -153,7 +203,7 @@ extern "C" int32_t gpk_convex_hull(const gpk_geoarray* a, double* out_xy, int32_
         return copy_out(out_ring_offsets, out_space, off_dev, sizeof(int32_t), s);
     }
     const dim3 grid((unsigned)nb), block(256);
-    GPK_LAUNCH("gpk_hull", hull_kernel, grid, block, 0, s, a->d, sorted, stack, sizes);
+    GPK_LAUNCH("gpk_hull", hull_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, a->d, sorted, stack, sizes);
     GPK_TRY(exclusive_scan_i32(sizes, n, off_dev, nullptr, btot, s));
     GPK_LAUNCH("gpk_hull_compact", hull_compact_kernel, grid, block, 0, s, a->d, stack, off_dev, out_dev);
     if (host_out) {

@@ -28,7 +28,8 @@ struct WkbCursor {
             ok = false;
             return 0;
         }
-        const uint32_t v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+        uint32_t v;
+        __builtin_memcpy(&v, p, 4);  // one (unaligned) dword load: legal on gfx9+ under HSA, little-endian like the payload
         p += 4;
         return v;
     }
@@ -37,11 +38,10 @@ struct WkbCursor {
             ok = false;
             return 0.0;
         }
-        unsigned long long v = 0;
-#pragma unroll
-        for (int i = 7; i >= 0; --i) v = (v << 8) | p[i];
+        double v;
+        __builtin_memcpy(&v, p, 8);
         p += 8;
-        return __longlong_as_double((long long)v);
+        return v;
     }
     __device__ __forceinline__ void skip(size_t n) {
         if (p + n > end)
@@ -81,7 +81,9 @@ struct RowCount {
 // `emit` < 0: count only.  Otherwise write coordinates from position `emit` and ring / part end offsets.
 template <bool FILL>
 __device__ inline bool parse_row(WkbCursor& r, RowCount& rc, double2* __restrict__ xy, int64_t cpos, int32_t* __restrict__ ring_off,
-                                 int64_t rpos, int32_t* __restrict__ part_off, int64_t ppos, bool out_point) {
+                                 int64_t rpos, int32_t* __restrict__ part_off, int64_t ppos, bool out_point,
+                                 const uint8_t* __restrict__ values = nullptr, int32_t* __restrict__ seq_src = nullptr,
+                                 int64_t seq_pos = 0) {
     const int t = r.header();
     if (!t) return false;
     rc.type = t;
@@ -101,11 +103,15 @@ __device__ inline bool parse_row(WkbCursor& r, RowCount& rc, double2* __restrict
         ++parts_done;
         if (FILL && part_off) part_off[ppos + parts_done] = (int32_t)(rpos + rc.rings);
     };
+    // a run of n coordinates (linestring / ring body) is never read here: the scan only needs its length, and the fill
+    // records where it starts so that wkb_copy_kernel moves it with many lanes (a 100k-vertex ring is one header to
+    // the lane that owns the row)
+    int seqs_done = 0;
     auto coords_run = [&](uint32_t n) {
-        for (uint32_t i = 0; i < n && r.ok; ++i) {
-            const double x = r.f64(), y = r.f64();
-            if (r.ok) put(x, y);
-        }
+        if (FILL && seq_src) seq_src[seq_pos + seqs_done] = (int32_t)(r.p - values);
+        ++seqs_done;
+        r.skip(16 * (size_t)n);
+        if (r.ok) rc.coords += (int32_t)n;
     };
     auto polygon_body = [&]() {
         const uint32_t nr = r.u32();
@@ -195,7 +201,8 @@ __global__ void wkb_extent_kernel(const RowCount* __restrict__ rows, int64_t n_r
 __global__ void wkb_fill_kernel(const uint8_t* __restrict__ values, const int32_t* __restrict__ offsets, int64_t n_rows,
                                 const uint8_t* __restrict__ validity, int out_type, const int32_t* __restrict__ cpos,
                                 const int32_t* __restrict__ rpos, const int32_t* __restrict__ ppos, double2* __restrict__ xy,
-                                int32_t* __restrict__ geom_off, int32_t* __restrict__ part_off, int32_t* __restrict__ ring_off) {
+                                int32_t* __restrict__ geom_off, int32_t* __restrict__ part_off, int32_t* __restrict__ ring_off,
+                                int32_t* __restrict__ seq_src) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rows) return;
     const bool out_point = out_type == GPK_GEOM_POINT;
@@ -204,8 +211,11 @@ __global__ void wkb_fill_kernel(const uint8_t* __restrict__ values, const int32_
     if (dev::valid_row(validity, i)) {
         WkbCursor r{values + offsets[i], values + offsets[i + 1], true};
         RowCount rc;
+        // sequences are numbered like the rings (ring types) or like the rows (a LINESTRING column: one per row)
         (void)parse_row<true>(r, rc, xy, cpos[i], has_ring ? ring_off : nullptr, has_ring ? rpos[i] : 0, has_part ? part_off : nullptr,
-                              has_part ? ppos[i] : 0, out_point);
+                              has_part ? ppos[i] : 0, out_point, values, seq_src, has_ring ? (int64_t)rpos[i] : i);
+    } else if (seq_src && !has_ring) {
+        seq_src[i] = 0;  // null row of a LINESTRING column: an empty sequence
     } else if (out_point) {
         xy[cpos[i]] = make_double2(NAN, NAN);
     }
@@ -218,6 +228,44 @@ __global__ void wkb_fill_kernel(const uint8_t* __restrict__ values, const int32_
         // level-1 offsets: end position of row i at the column's first nesting level
         const int32_t* lvl = has_part ? ppos : (has_ring ? rpos : cpos);
         geom_off[i + 1] = lvl[i + 1];
+    }
+}
+
+// ---- coordinate runs: WKB bytes -> xy ---------------------------------------------------------------------------
+// sequence q (a ring / member line, or the row of a LINESTRING column) starts at values + seq_src[q] and fills
+// xy[seq_off[q] .. seq_off[q + 1]).  8 lanes per sequence; sequences longer than WKB_LONG are listed for
+// wkb_copy_long_kernel, which spreads each of them over the whole grid.
+constexpr int WKB_COPY_GS = 8, WKB_LONG = 4096;
+__device__ __forceinline__ double2 load_xy_unaligned(const uint8_t* p) {
+    double2 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+__global__ __launch_bounds__(256) void wkb_copy_kernel(const uint8_t* __restrict__ values, const int32_t* __restrict__ seq_src,
+                                                        const int32_t* __restrict__ seq_off, int64_t n_seq, double2* __restrict__ xy,
+                                                        int32_t* __restrict__ long_list) {
+    const int lane = threadIdx.x & (WKB_COPY_GS - 1);
+    const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WKB_COPY_GS;
+    if (q >= n_seq) return;
+    const int c0 = seq_off[q], n = seq_off[q + 1] - c0;
+    if (n <= 0) return;
+    if (n > WKB_LONG) {
+        if (lane == 0) long_list[1 + atomicAdd(&long_list[0], 1)] = (int32_t)q;
+        return;
+    }
+    const uint8_t* src = values + seq_src[q];
+    for (int i = lane; i < n; i += WKB_COPY_GS) xy[c0 + i] = load_xy_unaligned(src + 16 * (size_t)i);
+}
+__global__ __launch_bounds__(256) void wkb_copy_long_kernel(const uint8_t* __restrict__ values, const int32_t* __restrict__ seq_src,
+                                                             const int32_t* __restrict__ seq_off, const int32_t* __restrict__ long_list,
+                                                             double2* __restrict__ xy) {
+    const int n_long = long_list[0];
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int k = 0; k < n_long; ++k) {
+        const int q = long_list[1 + k];
+        const int c0 = seq_off[q], n = seq_off[q + 1] - c0;
+        const uint8_t* src = values + seq_src[q];
+        for (int64_t i = tid; i < n; i += stride) xy[c0 + i] = load_xy_unaligned(src + 16 * (size_t)i);
     }
 }
 
@@ -234,7 +282,7 @@ extern "C" int32_t gpk_geoarray_from_wkb(const uint8_t* wkb_values, const int32_
     if (n_rows > INT32_MAX) return fail(GPK_ERR_INVALID_OFFSETS, "column exceeds i32 offsets");
 
     // temporaries of this call (freed on every path); the decoded buffers are owned by the returned handle
-    void* tmp[12] = {nullptr};
+    void* tmp[16] = {nullptr};
     int n_tmp = 0;
     gpk_geoarray* a = nullptr;
     auto done = [&](int32_t rc) {
@@ -361,12 +409,29 @@ extern "C" int32_t gpk_geoarray_from_wkb(const uint8_t* wkb_values, const int32_
         a->owned[4] = vcopy;
         W_HIP(hipMemcpyAsync(vcopy, validity_dev, (size_t)((n_rows + 7) / 8), hipMemcpyDeviceToDevice, s));
     }
+    // coordinate runs of line / polygon columns are moved by wkb_copy_kernel from the positions the fill records
+    const bool has_seq = out_type == GPK_GEOM_LINESTRING || has_ring;
+    const int64_t n_seq = has_ring ? (int64_t)tot_r : n_rows;
+    int32_t *seq_src = nullptr, *long_list = nullptr;
+    if (has_seq && n_rows > 0) {
+        W_TRY(dalloc((void**)&seq_src, sizeof(int32_t) * (size_t)(n_seq + 1), true));
+        W_TRY(dalloc((void**)&long_list, sizeof(int32_t) * (size_t)(n_seq + 2), true));
+        W_HIP(hipMemsetAsync(long_list, 0, sizeof(int32_t), s));
+    }
     auto launch3 = [&]() -> int32_t {
-        if (n_rows > 0)
+        if (n_rows > 0) {
             GPK_LAUNCH("gpk_wkb_fill", wkb_fill_kernel, grid, block, 0, s, values_dev, offsets_dev, n_rows, validity_dev, out_type,
-                       (const int32_t*)cpos, (const int32_t*)rpos, (const int32_t*)ppos, xy, go, po, ro);
-        else if (go)
+                       (const int32_t*)cpos, (const int32_t*)rpos, (const int32_t*)ppos, xy, go, po, ro, seq_src);
+            if (has_seq && n_seq > 0 && tot_c > 0) {
+                const int32_t* seq_off = has_ring ? (const int32_t*)ro : (const int32_t*)go;
+                GPK_LAUNCH("gpk_wkb_copy", wkb_copy_kernel, dim3((unsigned)((n_seq * WKB_COPY_GS + 255) / 256)), dim3(256), 0, s, values_dev,
+                           (const int32_t*)seq_src, seq_off, n_seq, xy, long_list);
+                GPK_LAUNCH("gpk_wkb_copy_long", wkb_copy_long_kernel, dim3((unsigned)(cu_count() * 8)), dim3(256), 0, s, values_dev,
+                           (const int32_t*)seq_src, seq_off, (const int32_t*)long_list, xy);
+            }
+        } else if (go) {
             GPK_HIP(hipMemsetAsync(go, 0, sizeof(int32_t), s));
+        }
         return GPK_OK;
     };
     W_TRY(launch3());

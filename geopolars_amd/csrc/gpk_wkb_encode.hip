@@ -92,47 +92,69 @@ __device__ __forceinline__ int owner_of(const int32_t* __restrict__ off, int64_t
     return (int)lo;
 }
 
-// bodies: WKB_GS lanes per sequence (LINESTRING: a row; POLYGON / MULTILINESTRING / MULTIPOLYGON: a ring / member line)
-__global__ __launch_bounds__(256) void wkb_bodies_kernel(DevGeo a, const int32_t* __restrict__ off, uint8_t* __restrict__ out) {
+// where sequence q's coordinates go in the output (and, by the group's first lane, its own header): LINESTRING: a row;
+// POLYGON / MULTILINESTRING / MULTIPOLYGON: a ring / member line.  nullptr for a null row.
+__device__ __forceinline__ uint8_t* wkb_seq_dst(const DevGeo& a, const int32_t* __restrict__ off, uint8_t* __restrict__ out, int64_t q,
+                                                bool write_header, int& c0, int& c1) {
+    if (a.type == GPK_GEOM_LINESTRING) {
+        c0 = a.geom_off[q];
+        c1 = a.geom_off[q + 1];
+        if (!dev::valid_row(a.validity, q)) return nullptr;
+        return out + off[q] + 9;
+    }
+    const int r = (int)q;
+    c0 = a.ring_off[r];
+    c1 = a.ring_off[r + 1];
+    if (a.type == GPK_GEOM_MULTIPOLYGON) {
+        const int part = owner_of(a.part_off, a.n_parts, r);
+        const int g = owner_of(a.geom_off, a.n_geoms, part);
+        if (!dev::valid_row(a.validity, g)) return nullptr;
+        const int p0 = a.geom_off[g], rbase = a.part_off[p0];
+        uint8_t* rh = out + off[g] + 9 + 9 * (int64_t)(part - p0 + 1) + 4 * (int64_t)(r - rbase) + 16 * (int64_t)(c0 - a.ring_off[rbase]);
+        if (write_header) put_u32(rh, (uint32_t)(c1 - c0));
+        return rh + 4;
+    }
+    const int g = owner_of(a.geom_off, a.n_geoms, r);
+    if (!dev::valid_row(a.validity, g)) return nullptr;
+    const int r0 = a.geom_off[g];
+    const bool poly = a.type == GPK_GEOM_POLYGON;
+    uint8_t* rh = out + off[g] + 9 + (poly ? 4 : 9) * (int64_t)(r - r0) + 16 * (int64_t)(c0 - a.ring_off[r0]);
+    if (write_header) {
+        if (poly)
+            put_u32(rh, (uint32_t)(c1 - c0));
+        else
+            put_header(rh, 2u, (uint32_t)(c1 - c0));
+    }
+    return rh + (poly ? 4 : 9);
+}
+
+// bodies: WKB_GS lanes per sequence; sequences longer than WKB_ENC_LONG are listed for wkb_bodies_long_kernel, which
+// spreads each of them over the whole grid (a 100k-vertex ring would otherwise be 8 lanes' job)
+constexpr int WKB_ENC_LONG = 4096;
+__global__ __launch_bounds__(256) void wkb_bodies_kernel(DevGeo a, const int32_t* __restrict__ off, uint8_t* __restrict__ out,
+                                                          int32_t* __restrict__ long_list) {
     const int lane = threadIdx.x & (WKB_GS - 1);
     const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WKB_GS;
     const int64_t n_seq = a.type == GPK_GEOM_LINESTRING ? a.n_geoms : a.n_rings;
     if (q >= n_seq) return;
     int c0, c1;
-    uint8_t* p;  // where this sequence's coordinates start
-    if (a.type == GPK_GEOM_LINESTRING) {
-        if (!dev::valid_row(a.validity, q)) return;
-        c0 = a.geom_off[q];
-        c1 = a.geom_off[q + 1];
-        p = out + off[q] + 9;
-    } else {
-        const int r = (int)q;
-        c0 = a.ring_off[r];
-        c1 = a.ring_off[r + 1];
-        if (a.type == GPK_GEOM_MULTIPOLYGON) {
-            const int part = owner_of(a.part_off, a.n_parts, r);
-            const int g = owner_of(a.geom_off, a.n_geoms, part);
-            if (!dev::valid_row(a.validity, g)) return;
-            const int p0 = a.geom_off[g], rbase = a.part_off[p0];
-            uint8_t* rh = out + off[g] + 9 + 9 * (int64_t)(part - p0 + 1) + 4 * (int64_t)(r - rbase) + 16 * (int64_t)(c0 - a.ring_off[rbase]);
-            if (lane == 0) put_u32(rh, (uint32_t)(c1 - c0));
-            p = rh + 4;
-        } else {
-            const int g = owner_of(a.geom_off, a.n_geoms, r);
-            if (!dev::valid_row(a.validity, g)) return;
-            const int r0 = a.geom_off[g];
-            const bool poly = a.type == GPK_GEOM_POLYGON;
-            uint8_t* rh = out + off[g] + 9 + (poly ? 4 : 9) * (int64_t)(r - r0) + 16 * (int64_t)(c0 - a.ring_off[r0]);
-            if (lane == 0) {
-                if (poly)
-                    put_u32(rh, (uint32_t)(c1 - c0));
-                else
-                    put_header(rh, 2u, (uint32_t)(c1 - c0));
-            }
-            p = rh + (poly ? 4 : 9);
-        }
+    uint8_t* p = wkb_seq_dst(a, off, out, q, lane == 0, c0, c1);
+    if (!p) return;
+    if (c1 - c0 > WKB_ENC_LONG) {
+        if (lane == 0) long_list[1 + atomicAdd(&long_list[0], 1)] = (int32_t)q;
+        return;
     }
     for (int i = c0 + lane; i < c1; i += WKB_GS) put_xy(p + 16 * (int64_t)(i - c0), a.xy[i]);
+}
+__global__ __launch_bounds__(256) void wkb_bodies_long_kernel(DevGeo a, const int32_t* __restrict__ off, uint8_t* __restrict__ out,
+                                                               const int32_t* __restrict__ long_list) {
+    const int n_long = long_list[0];
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int k = 0; k < n_long; ++k) {
+        int c0, c1;
+        uint8_t* p = wkb_seq_dst(a, off, out, long_list[1 + k], false, c0, c1);  // the header was written by wkb_bodies_kernel
+        for (int64_t i = c0 + tid; i < c1; i += stride) put_xy(p + 16 * (i - c0), a.xy[i]);
+    }
 }
 
 // MULTIPOINT members: one lane per coordinate, 21 bytes each
@@ -161,18 +183,22 @@ extern "C" int32_t gpk_geoarray_to_wkb(const gpk_geoarray* a, int32_t* out_offse
     const int64_t n = d.n_geoms;
     *n_bytes = 0;
     // upper bound of the column (every row valid): it must fit Arrow's i32 offsets
-    const int64_t bound = 21 * d.n_coords + 9 * (n + d.n_parts + d.n_rings);
+    const bool pointish = d.type == GPK_GEOM_POINT || d.type == GPK_GEOM_MULTIPOINT;
+    const int64_t bound = (pointish ? 21 : 16) * d.n_coords + 9 * (n + d.n_parts + d.n_rings);
     if (bound > 0x7FFFFFFFLL)
         return fail(GPK_ERR_CAPACITY, "to_wkb: up to %lld bytes do not fit BinaryArray<i32> offsets; encode row slices", (long long)bound);
     const bool host_out = out_space != GPK_MEM_DEVICE;
     const int64_t nb = (n + 255) / 256;
-    size_t need = 2 * align256(sizeof(int32_t) * (size_t)(n + 1)) + align256(sizeof(unsigned long long) * (size_t)(nb + 2)) + 1024;
+    const int64_t n_seq_enc = d.type == GPK_GEOM_LINESTRING ? n : d.n_rings;
+    size_t need = 2 * align256(sizeof(int32_t) * (size_t)(n + 1)) + align256(sizeof(unsigned long long) * (size_t)(nb + 2)) +
+                  align256(sizeof(int32_t) * (size_t)(n_seq_enc + 2)) + 1024;
     if (host_out && out_values) need += align256((size_t)capacity);
     GPK_TRY(workspace().begin(need));
     int32_t* sizes = (int32_t*)workspace().take(sizeof(int32_t) * (size_t)(n + 1));
     int32_t* off_dev = (host_out || !out_offsets) ? (int32_t*)workspace().take(sizeof(int32_t) * (size_t)(n + 1)) : out_offsets;
     unsigned long long* btot = (unsigned long long*)workspace().take(sizeof(unsigned long long) * (size_t)(nb + 2));
     uint8_t* val_dev = out_values ? (host_out ? (uint8_t*)workspace().take((size_t)capacity) : out_values) : nullptr;
+    int32_t* long_list = (int32_t*)workspace().take(sizeof(int32_t) * (size_t)(n_seq_enc + 2));
 
     int32_t total = 0;
     if (n > 0) {
@@ -195,10 +221,14 @@ extern "C" int32_t gpk_geoarray_to_wkb(const gpk_geoarray* a, int32_t* out_offse
                 GPK_LAUNCH("gpk_wkb_multipoint", wkb_multipoint_kernel, dim3((unsigned)((d.n_coords + 255) / 256)), dim3(256), 0, s, d,
                            (const int32_t*)off_dev, val_dev);
         } else if (d.type != GPK_GEOM_POINT) {
-            const int64_t n_seq = d.type == GPK_GEOM_LINESTRING ? n : d.n_rings;
-            if (n_seq > 0)
+            const int64_t n_seq = n_seq_enc;
+            if (n_seq > 0) {
+                GPK_HIP(hipMemsetAsync(long_list, 0, sizeof(int32_t), s));
                 GPK_LAUNCH("gpk_wkb_bodies", wkb_bodies_kernel, dim3((unsigned)((n_seq * WKB_GS + 255) / 256)), dim3(256), 0, s, d,
-                           (const int32_t*)off_dev, val_dev);
+                           (const int32_t*)off_dev, val_dev, long_list);
+                GPK_LAUNCH("gpk_wkb_bodies_long", wkb_bodies_long_kernel, dim3((unsigned)(cu_count() * 8)), dim3(256), 0, s, d,
+                           (const int32_t*)off_dev, val_dev, (const int32_t*)long_list);
+            }
         }
     }
     if (host_out) GPK_TRY(copy_out(out_values, out_space, val_dev, (size_t)total, s));

@@ -45,7 +45,7 @@ def timed(lib, fn, reps=10):
     out = {}
     # per-kernel breakdown
     # per-kernel breakdown: ms per call of the operator (a name may cover several launches)
-    for name in (b"gpk_ring_area", b"gpk_seq_bbox", b"gpk_ring_centroid", b"gpk_seq_long_combine", b"gpk_area_combine", b"gpk_bounds_combine", b"gpk_centroid_combine", b"gpk_affine", b"gpk_distance", b"gpk_length_combine"):
+    for name in (b"gpk_ring_area", b"gpk_seq_bbox", b"gpk_ring_centroid", b"gpk_seq_long_combine", b"gpk_area_combine", b"gpk_bounds_combine", b"gpk_centroid_combine", b"gpk_affine", b"gpk_distance", b"gpk_length_combine", b"gpk_seq_length", b"gpk_hull", b"gpk_wkb"):
         m, c = C.c_double(0), C.c_int64(0)
         lib.gpk_profile_query(name, C.byref(m), C.byref(c))
         if c.value:
@@ -92,7 +92,29 @@ def main():
         report("centroid", wname, ms, k, 16 * v + off_bytes + 17 * n)
         ms, k = timed(lib, lambda s: _abi.check(lib.gpk_affine_transform(d.handle, m6, outxy.data_ptr(), MEM_DEVICE, s)))
         report("affine_transform", wname, ms, k, 32 * v)
-        del d, out1, out2, out4, outv, outxy
+        ms, k = timed(lib, lambda s: _abi.check(lib.gpk_euclidean_length(d.handle, out1.data_ptr(), MEM_DEVICE, s)))
+        report("euclidean_length", wname, ms, k, 16 * v + off_bytes + 8 * n)
+        if wname.startswith("2M"):
+            hxy = torch.empty((v + n, 2), dtype=torch.float64, device=dev)
+            hoff = torch.empty(n + 1, dtype=torch.int32, device=dev)
+            ms, k = timed(lib, lambda s: _abi.check(lib.gpk_convex_hull(d.handle, hxy.data_ptr(), hoff.data_ptr(), MEM_DEVICE, s)), reps=3)
+            report("convex_hull", wname, ms, k, 32 * v + off_bytes)
+            del hxy, hoff
+        # GeoArrow -> WKB on the device: coordinates in, WKB bytes out
+        nb = C.c_int64(0)
+        _abi.check(lib.gpk_geoarray_to_wkb(d.handle, None, None, 0, C.byref(nb), MEM_DEVICE, None))
+        wkb = torch.empty(int(nb.value), dtype=torch.uint8, device=dev)
+        woff = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        ms, k = timed(lib, lambda s: _abi.check(lib.gpk_geoarray_to_wkb(d.handle, woff.data_ptr(), wkb.data_ptr(), int(nb.value), C.byref(nb), MEM_DEVICE, s)), reps=5)
+        report("to_wkb", wname, ms, k, 16 * v + off_bytes + int(nb.value) + 4 * n)
+        # WKB -> GeoArrow on the device (the bytes are already in HBM)
+        def decode(s):
+            out, gt = C.c_void_p(), C.c_int32(-1)
+            _abi.check(lib.gpk_geoarray_from_wkb(wkb.data_ptr(), woff.data_ptr(), n, None, MEM_DEVICE, s, C.byref(out), C.byref(gt)))
+            lib.gpk_geoarray_free(out)
+        ms, k = timed(lib, decode, reps=3)
+        report("from_wkb", wname, ms, k, int(nb.value) + 4 * n + 16 * v + off_bytes)
+        del d, out1, out2, out4, outv, outxy, wkb, woff
         torch.cuda.empty_cache()
 
     # ---- C3: 10M points x 100k linestrings, row-wise distance -----------------------------------------
