@@ -290,7 +290,8 @@ __global__ void sub_flag_kernel(const uint32_t* __restrict__ cell, int64_t n_cel
 // PIP_SUB^2 lanes per flagged cell: lane k labels sub-cell (k % PIP_SUB, k / PIP_SUB).  A sub-cell is "test
 // exactly" when any edge of ANY ring of the part (taken from the rings' slabs of this raster row) is not strictly
 // on one side of the sub-cell's padded rectangle; otherwise it inherits the exact position of its centre.
-__global__ void sub_build_kernel(DevGeo a, PipView pv, FineGrid g, const int32_t* __restrict__ flag,
+constexpr int SUB_EDGE_CAP = 48;  // edges of a cell's slab rows kept in LDS per wave (sub_build_kernel)
+__global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, FineGrid g, const int32_t* __restrict__ flag,
                                  const int32_t* __restrict__ pos, int64_t n_cells, const uint32_t* __restrict__ cell,
                                  SubCell* __restrict__ sub) {
     constexpr int S = PIP_SUB, SS = PIP_SUB * PIP_SUB;
@@ -307,24 +308,64 @@ __global__ void sub_build_kernel(DevGeo a, PipView pv, FineGrid g, const int32_t
     const double yl = g.ry0 + (double)sj * fh2 - py2, yh = g.ry0 + (double)(sj + 1) * fh2 + py2;
     int r0, r1;
     dev::part_rings(a, part, r0, r1);
-    bool touched = false;
-    for (int r = r0; r < r1 && !touched; ++r)
-        for (int h = 0; h < PIP_SLAB_MUL && !touched; ++h) {
+    // The 64 lanes of a wave label the 64 sub-cells of ONE cell, so they share its slab rows.  First the wave picks the
+    // edges whose box meets the (padded) cell at all — lane j looks at edge j, survivors are compacted by ballot into an
+    // LDS list — then every lane tests only those few against its own sub-cell (a slab row holds every edge of the ring
+    // that crosses the row anywhere in x; a cell sees one to three of them).
+    __shared__ double4 s_edges[256 / 64][SUB_EDGE_CAP];
+    const int wave = threadIdx.x >> 6, lane64 = threadIdx.x & 63;
+    // the cell = the union of its padded sub-cells, written with the very expressions the corner lanes use below
+    const double cxl = g.rx0 + (double)(S * ci) * fw2 - px2, cxh = g.rx0 + (double)(S * ci + S) * fw2 + px2;
+    const double cyl = g.ry0 + (double)(S * cj) * fh2 - py2, cyh = g.ry0 + (double)(S * cj + S) * fh2 + py2;
+    int n_list = 0;         // wave-uniform
+    bool list_ok = true;    // false: more than SUB_EDGE_CAP edges meet the cell -> every lane walks the slabs itself
+    for (int r = r0; r < r1 && list_ok; ++r)
+        for (int h = 0; h < PIP_SLAB_MUL && list_ok; ++h) {
             int e0, e1;
             if (!pip::slab_range(pv, r, PIP_SLAB_MUL * cj + h, e0, e1)) continue;
-            for (int e = e0; e < e1 && !touched; ++e) {
-                const double4 ed = pv.slab_edges[e];
-                // cheap reject: edge bbox vs padded rectangle (closed)
-                if (fmax(ed.x, ed.z) < xl || fmin(ed.x, ed.z) > xh || fmax(ed.y, ed.w) < yl || fmin(ed.y, ed.w) > yh) continue;
-                const int o1 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yl);
-                const int o2 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yl);
-                const int o3 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yh);
-                const int o4 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yh);
-                const bool all_pos = o1 > 0 && o2 > 0 && o3 > 0 && o4 > 0;
-                const bool all_neg = o1 < 0 && o2 < 0 && o3 < 0 && o4 < 0;
-                touched = !(all_pos || all_neg);
+            for (int eb = e0; eb < e1 && list_ok; eb += 64) {
+                const int e = eb + lane64;
+                bool keep = false;
+                double4 ed = make_double4(0, 0, 0, 0);
+                if (e < e1) {
+                    ed = pv.slab_edges[e];
+                    keep = !(fmax(ed.x, ed.z) < cxl || fmin(ed.x, ed.z) > cxh || fmax(ed.y, ed.w) < cyl || fmin(ed.y, ed.w) > cyh);
+                }
+                const unsigned long long m = __ballot(keep);
+                const int add = __popcll(m);
+                if (n_list + add > SUB_EDGE_CAP) {
+                    list_ok = false;
+                    break;
+                }
+                if (keep) s_edges[wave][n_list + __popcll(m & ((1ull << lane64) - 1ull))] = ed;
+                n_list += add;
             }
         }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    auto edge_touches = [&](const double4 ed) {
+        // cheap reject: edge bbox vs padded rectangle (closed)
+        if (fmax(ed.x, ed.z) < xl || fmin(ed.x, ed.z) > xh || fmax(ed.y, ed.w) < yl || fmin(ed.y, ed.w) > yh) return false;
+        const int o1 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yl);
+        const int o2 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yl);
+        const int o3 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yh);
+        const int o4 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yh);
+        const bool all_pos = o1 > 0 && o2 > 0 && o3 > 0 && o4 > 0;
+        const bool all_neg = o1 < 0 && o2 < 0 && o3 < 0 && o4 < 0;
+        return !(all_pos || all_neg);
+    };
+    bool touched = false;
+    if (list_ok) {
+        for (int e = 0; e < n_list && !touched; ++e) touched = edge_touches(s_edges[wave][e]);
+    } else {
+        for (int r = r0; r < r1 && !touched; ++r)
+            for (int h = 0; h < PIP_SLAB_MUL && !touched; ++h) {
+                int e0, e1;
+                if (!pip::slab_range(pv, r, PIP_SLAB_MUL * cj + h, e0, e1)) continue;
+                for (int e = e0; e < e1 && !touched; ++e) touched = edge_touches(pv.slab_edges[e]);
+            }
+    }
     uint32_t label = 2u;
     if (!touched) {
         const double cx = g.rx0 + ((double)si + 0.5) * fw2, cy = g.ry0 + ((double)sj + 0.5) * fh2;
