@@ -60,6 +60,7 @@ struct gpk_seq_classes {
     // otherwise be one work-group's job): chunk_begin[k] = first chunk of the k-th long sequence (count[3] + 1 entries)
     int32_t* chunk_begin;
     int64_t n_chunks;
+    bool one_to_one;  // sequence s is exactly geometry s (LINESTRING column; POLYGON column of single-ring polygons)
 };
 struct gpk_geoarray {
     gpk::DevGeo d;

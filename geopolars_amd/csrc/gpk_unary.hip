@@ -147,6 +147,31 @@ __device__ __forceinline__ void seq_store(const SeqPartial& a, double* __restric
     }
 }
 
+// Columns whose sequences ARE their geometries (a LINESTRING column; a POLYGON column of single-ring polygons, the usual
+// shape of building / parcel data) skip the per-geometry combine: stage 1 writes the operator's result itself.
+enum { FIN_NONE = 0, FIN_AREA = 1, FIN_SIGNED_AREA = 2, FIN_BOUNDS = 3, FIN_LENGTH = 4 };
+struct FinalOut {
+    double* out;              // result column (bounds: 4 doubles per row)
+    const uint8_t* validity;  // of the geometries (= sequences)
+};
+template <unsigned MASK, int FIN>
+__device__ __forceinline__ void seq_store_any(const SeqPartial& a, double* __restrict__ stats, int64_t n_seq, int64_t s, bool empty,
+                                              const FinalOut& f) {
+    if (FIN == FIN_NONE) {
+        seq_store<MASK>(a, stats, n_seq, s);
+        return;
+    }
+    const bool valid = dev::valid_row(f.validity, s);
+    if (FIN == FIN_AREA) f.out[s] = valid ? fabs(fabs(a.a2 / 2.0)) : NAN;  // area_combine_kernel for one ring
+    if (FIN == FIN_SIGNED_AREA) {
+        const double h = a.a2 / 2.0;
+        f.out[s] = valid ? (h < 0.0 ? -fabs(h) : fabs(h)) : NAN;
+    }
+    if (FIN == FIN_LENGTH) f.out[s] = valid ? 0.0 + a.len : NAN;
+    if (FIN == FIN_BOUNDS)
+        reinterpret_cast<double4*>(f.out)[s] = (valid && !empty) ? make_double4(a.mnx, a.mny, a.mxx, a.mxy) : make_double4(NAN, NAN, NAN, NAN);
+}
+
 // ---- size classes ---------------------------------------------------------------------------------------------
 // Lanes per sequence by length: ~8 vertices per lane keeps the reduction steps per vertex low (with 64 lanes on
 // 65-vertex rings the reductions outweighed the streaming work 3:1) while a group still reads G consecutive vertices
@@ -191,11 +216,11 @@ __global__ void long_chunk_count_kernel(const int32_t* __restrict__ seq_off, con
 
 // one work-group per chunk of a long sequence.  A sequence that fits one chunk is stored directly; the chunks of a
 // longer one leave 12-double partials in `part` that seq_long_combine_kernel folds in chunk order (deterministic).
-template <unsigned MASK>
+template <unsigned MASK, int FIN>
 __device__ __forceinline__ void seq_stats_long_body(const double2* __restrict__ xy, const int32_t* __restrict__ seq_off, int64_t n_seq,
                                                     const int32_t* __restrict__ list, int64_t n_list,
                                                     const int32_t* __restrict__ chunk_begin, int64_t n_chunks, double* __restrict__ part,
-                                                    double* __restrict__ stats, int block, int n_blocks) {
+                                                    double* __restrict__ stats, int block, int n_blocks, const FinalOut& fin) {
     __shared__ double red[12][4];
     for (int64_t w = block; w < n_chunks; w += n_blocks) {
         int64_t lo = 0, hi = n_list;  // largest k with chunk_begin[k] <= w (uniform across the work-group)
@@ -247,7 +272,7 @@ __device__ __forceinline__ void seq_stats_long_body(const double2* __restrict__ 
                 SeqPartial r;
                 r.a2 = t[0]; r.acx = t[1]; r.acy = t[2]; r.len = t[3]; r.lmx = t[4]; r.lmy = t[5]; r.sx = t[6]; r.sy = t[7];
                 r.mnx = t[8]; r.mny = t[9]; r.mxx = t[10]; r.mxy = t[11];
-                seq_store<MASK>(r, stats, n_seq, s);
+                seq_store_any<MASK, FIN>(r, stats, n_seq, s, c1 <= c0, fin);
             } else {
 #pragma unroll
                 for (int q = 0; q < 12; ++q) part[12 * w + q] = t[q];
@@ -255,9 +280,9 @@ __device__ __forceinline__ void seq_stats_long_body(const double2* __restrict__ 
         }
     }
 }
-template <unsigned MASK>
+template <unsigned MASK, int FIN>
 __global__ void seq_long_combine_kernel(const int32_t* __restrict__ list, int64_t n_list, const int32_t* __restrict__ chunk_begin,
-                                        const double* __restrict__ part, int64_t n_seq, double* __restrict__ stats) {
+                                        const double* __restrict__ part, int64_t n_seq, double* __restrict__ stats, FinalOut fin) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_list) return;
     const int w0 = chunk_begin[k], w1 = chunk_begin[k + 1];
@@ -274,13 +299,13 @@ __global__ void seq_long_combine_kernel(const int32_t* __restrict__ list, int64_
     SeqPartial r;
     r.a2 = t[0]; r.acx = t[1]; r.acy = t[2]; r.len = t[3]; r.lmx = t[4]; r.lmy = t[5]; r.sx = t[6]; r.sy = t[7];
     r.mnx = t[8]; r.mny = t[9]; r.mxx = t[10]; r.mxy = t[11];
-    seq_store<MASK>(r, stats, n_seq, s);
+    seq_store_any<MASK, FIN>(r, stats, n_seq, s, false, fin);
 }
 
-template <int G, unsigned MASK>
+template <int G, unsigned MASK, int FIN>
 __device__ __forceinline__ void seq_stats_group_body(const double2* __restrict__ xy, const int32_t* __restrict__ seq_off, int64_t n_seq,
                                                      double* __restrict__ stats, const int32_t* __restrict__ list, int64_t n_list, int block,
-                                                     int n_blocks) {
+                                                     int n_blocks, const FinalOut& fin) {
     // one size class: the sequences list[0..n_list) (every sequence in order when list == nullptr), G lanes each
     const int lane = threadIdx.x & (G - 1);
     const int64_t groups_per_grid = (int64_t)n_blocks * (256 / G);
@@ -367,26 +392,10 @@ __device__ __forceinline__ void seq_stats_group_body(const double2* __restrict__
             sy_ = group_sum<G>(sy_);
         }
         if (lane == 0) {
-            if (MASK & (M_AREA | M_CENT)) stats[ST_AREA2 * n_seq + s] = a2;
-            if (MASK & M_CENT) {
-                stats[ST_ACX * n_seq + s] = acx;
-                stats[ST_ACY * n_seq + s] = acy;
-            }
-            if (MASK & M_LENC) {
-                stats[ST_LMX * n_seq + s] = lmx;
-                stats[ST_LMY * n_seq + s] = lmy;
-            }
-            if (MASK & (M_LEN | M_LENC)) stats[ST_LEN * n_seq + s] = len;
-            if (MASK & M_BBOX) {
-                stats[ST_MINX * n_seq + s] = mnx;
-                stats[ST_MINY * n_seq + s] = mny;
-                stats[ST_MAXX * n_seq + s] = mxx;
-                stats[ST_MAXY * n_seq + s] = mxy;
-            }
-            if (MASK & M_SUM) {
-                stats[ST_SUMX * n_seq + s] = sx_;
-                stats[ST_SUMY * n_seq + s] = sy_;
-            }
+            SeqPartial r;
+            r.a2 = a2; r.acx = acx; r.acy = acy; r.len = len; r.lmx = lmx; r.lmy = lmy; r.sx = sx_; r.sy = sy_;
+            r.mnx = mnx; r.mny = mny; r.mxx = mxx; r.mxy = mxy;
+            seq_store_any<MASK, FIN>(r, stats, n_seq, s, n == 0, fin);
         }
     }
 }
@@ -706,10 +715,10 @@ __device__ __forceinline__ int wave_max_i32(int v) {
     }
     return v;
 }
-template <unsigned MASK>
+template <unsigned MASK, int FIN>
 __device__ __forceinline__ void seq_stats_tiny_body(const double2* __restrict__ xy, const int32_t* __restrict__ seq_off, int64_t n_seq,
                                                     double* __restrict__ stats, const int32_t* __restrict__ list, int64_t n_list, int block,
-                                                    int n_blocks, double2* __restrict__ lds) {
+                                                    int n_blocks, double2* __restrict__ lds, const FinalOut& fin) {
     constexpr int G = 2;
     const int lane64 = threadIdx.x & 63, lane = threadIdx.x & (G - 1), wave = threadIdx.x >> 6;
     double2* __restrict__ buf = lds + wave * TINY_SPAN;
@@ -776,7 +785,7 @@ __device__ __forceinline__ void seq_stats_tiny_body(const double2* __restrict__ 
                 a.sx = group_sum<G>(a.sx);
                 a.sy = group_sum<G>(a.sy);
             }
-            if (lane == 0) seq_store<MASK>(a, stats, n_seq, s);
+            if (lane == 0) seq_store_any<MASK, FIN>(a, stats, n_seq, s, n == 0, fin);
         }
     }
 }
@@ -792,12 +801,12 @@ struct SeqPlan {
     int64_t n_chunks;
     double* long_part;
 };
-template <unsigned MASK>
+template <unsigned MASK, int FIN>
 __global__ __launch_bounds__(256) void seq_stats_kernel(const double2* __restrict__ xy, const int32_t* __restrict__ seq_off, int64_t n_seq,
-                                                        double* __restrict__ stats, SeqPlan p) {
+                                                        double* __restrict__ stats, SeqPlan p, FinalOut fin) {
     int b = blockIdx.x;
     if (b < p.blocks[3]) {
-        seq_stats_long_body<MASK>(xy, seq_off, n_seq, p.list[3], p.count[3], p.chunk_begin, p.n_chunks, p.long_part, stats, b, p.blocks[3]);
+        seq_stats_long_body<MASK, FIN>(xy, seq_off, n_seq, p.list[3], p.count[3], p.chunk_begin, p.n_chunks, p.long_part, stats, b, p.blocks[3], fin);
         return;
     }
     b -= p.blocks[3];
@@ -807,18 +816,18 @@ __global__ __launch_bounds__(256) void seq_stats_kernel(const double2* __restric
         // test column span more than TINY_SPAN coordinates and the rest load 50 % foreign bytes): lane groups then.
         extern __shared__ double2 tiny_lds[];  // 4 waves x TINY_SPAN coordinates, allocated only for the staged form
         if (p.list[0] == nullptr)
-            seq_stats_tiny_body<MASK>(xy, seq_off, n_seq, stats, p.list[0], p.count[0], b, p.blocks[0], tiny_lds);
+            seq_stats_tiny_body<MASK, FIN>(xy, seq_off, n_seq, stats, p.list[0], p.count[0], b, p.blocks[0], tiny_lds, fin);
         else
-            seq_stats_group_body<2, MASK>(xy, seq_off, n_seq, stats, p.list[0], p.count[0], b, p.blocks[0]);
+            seq_stats_group_body<2, MASK, FIN>(xy, seq_off, n_seq, stats, p.list[0], p.count[0], b, p.blocks[0], fin);
         return;
     }
     b -= p.blocks[0];
     if (b < p.blocks[1]) {
-        seq_stats_group_body<8, MASK>(xy, seq_off, n_seq, stats, p.list[1], p.count[1], b, p.blocks[1]);
+        seq_stats_group_body<8, MASK, FIN>(xy, seq_off, n_seq, stats, p.list[1], p.count[1], b, p.blocks[1], fin);
         return;
     }
     b -= p.blocks[1];
-    seq_stats_group_body<16, MASK>(xy, seq_off, n_seq, stats, p.list[2], p.count[2], b, p.blocks[2]);
+    seq_stats_group_body<16, MASK, FIN>(xy, seq_off, n_seq, stats, p.list[2], p.count[2], b, p.blocks[2], fin);
 }
 
 // lanes per geometry for the per-row affine kernel: ~8 vertices per lane
@@ -837,6 +846,12 @@ static void seq_view(const DevGeo& a, const int32_t** seq_off, int64_t* n_seq) {
         *seq_off = a.ring_off;
         *n_seq = a.n_rings;
     }
+}
+
+// POLYGON column: does every polygon own exactly the ring with its own index?  (flag[0] stays 1 when so)
+__global__ void one_ring_each_kernel(const int32_t* __restrict__ geom_off, int64_t n, int32_t* __restrict__ flag) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g <= n && geom_off[g] != (int32_t)g) atomicAnd(flag, 0);
 }
 
 // classification of an array's sequences, built once per handle (the lock also orders concurrent first uses)
@@ -887,6 +902,23 @@ static int32_t seq_classes_of(const gpk_geoarray* a, hipStream_t s, const gpk_se
             return GPK_OK;
         };
         int32_t rc = run();
+        if (rc == GPK_OK) {
+            if (a->d.type == GPK_GEOM_LINESTRING || a->d.type == GPK_GEOM_MULTIPOINT) {
+                c->one_to_one = true;
+            } else if (a->d.type == GPK_GEOM_POLYGON && a->d.n_rings == a->d.n_geoms) {
+                auto run3 = [&]() -> int32_t {
+                    int32_t one = 1;
+                    GPK_HIP(hipMemcpyAsync(cursor, &one, sizeof one, hipMemcpyHostToDevice, s));
+                    GPK_LAUNCH("gpk_one_ring_each", one_ring_each_kernel, dim3((unsigned)((a->d.n_geoms + 256) / 256)), dim3(256), 0, s, a->d.geom_off,
+                               a->d.n_geoms, cursor);
+                    GPK_HIP(hipMemcpyAsync(&one, cursor, sizeof one, hipMemcpyDeviceToHost, s));
+                    GPK_HIP(hipStreamSynchronize(s));
+                    c->one_to_one = one != 0;
+                    return GPK_OK;
+                };
+                rc = run3();
+            }
+        }
         (void)hipFree(cursor);
         if (rc == GPK_OK && c->count[3] > 0) {  // chunks of the long sequences (exclusive scan over the long list)
             const int64_t nl = c->count[3], nb = (nl + 255) / 256;
@@ -916,8 +948,9 @@ static int32_t seq_classes_of(const gpk_geoarray* a, hipStream_t s, const gpk_se
     return GPK_OK;
 }
 
-template <unsigned MASK>
-static int32_t launch_seq_stats(const gpk_geoarray* arr, double* stats, double* long_part, hipStream_t s, const char* name) {
+template <unsigned MASK, int FIN = FIN_NONE>
+static int32_t launch_seq_stats(const gpk_geoarray* arr, double* stats, double* long_part, hipStream_t s, const char* name,
+                                FinalOut fin = FinalOut{nullptr, nullptr}) {
     const DevGeo& a = arr->d;
     const int32_t* seq_off;
     int64_t n_seq;
@@ -948,10 +981,10 @@ static int32_t launch_seq_stats(const gpk_geoarray* arr, double* stats, double* 
     static_assert(SEQ_LANES[0] == 2 && SEQ_LANES[1] == 8 && SEQ_LANES[2] == 16, "seq_stats_kernel's dispatch");
     const size_t tiny_lds = (p.blocks[0] > 0 && !p.list[0]) ? sizeof(double2) * 4 * TINY_SPAN : 0;
     if (total_blocks > 0)
-        GPK_LAUNCH(name, (seq_stats_kernel<MASK>), dim3((unsigned)total_blocks), dim3(256), tiny_lds, s, a.xy, seq_off, n_seq, stats, p);
+        GPK_LAUNCH(name, (seq_stats_kernel<MASK, FIN>), dim3((unsigned)total_blocks), dim3(256), tiny_lds, s, a.xy, seq_off, n_seq, stats, p, fin);
     if (c->n_chunks > c->count[3])  // some sequence spans several chunks
-        GPK_LAUNCH("gpk_seq_long_combine", (seq_long_combine_kernel<MASK>), dim3((unsigned)((c->count[3] + 255) / 256)), dim3(256), 0, s, p.list[3],
-                   c->count[3], (const int32_t*)c->chunk_begin, (const double*)long_part, n_seq, stats);
+        GPK_LAUNCH("gpk_seq_long_combine", (seq_long_combine_kernel<MASK, FIN>), dim3((unsigned)((c->count[3] + 255) / 256)), dim3(256), 0, s, p.list[3],
+                   c->count[3], (const int32_t*)c->chunk_begin, (const double*)long_part, n_seq, stats, fin);
     return GPK_OK;
 }
 
@@ -1034,6 +1067,16 @@ static int32_t area_impl(const gpk_geoarray* a, double* out, int32_t out_space, 
     if (a->d.type == GPK_GEOM_POINT) {
         GPK_LAUNCH("gpk_point_unary", point_unary_kernel, grid_for(n), dim3(256), 0, s, a->d, 0, (double*)c.out_dev, (uint8_t*)nullptr);
     } else {
+        const gpk_seq_classes* cl = nullptr;
+        if (is_polygonal(a->d.type)) GPK_TRY(seq_classes_of(a, s, &cl));
+        if (cl && cl->one_to_one) {  // single-ring polygons: stage 1 writes the areas, no combine pass
+            const FinalOut fin{(double*)c.out_dev, a->d.validity};
+            if (is_signed)
+                GPK_TRY((launch_seq_stats<M_AREA, FIN_SIGNED_AREA>(a, c.stats, c.long_part, s, "gpk_ring_area", fin)));
+            else
+                GPK_TRY((launch_seq_stats<M_AREA, FIN_AREA>(a, c.stats, c.long_part, s, "gpk_ring_area", fin)));
+            return copy_out(out, out_space, c.out_dev, ob, s);
+        }
         if (is_polygonal(a->d.type)) GPK_TRY(launch_seq_stats<M_AREA>(a, c.stats, c.long_part, s, "gpk_ring_area"));
         if (is_signed)
             GPK_LAUNCH("gpk_area_combine", area_combine_kernel<true>, grid_for(n), dim3(256), 0, s, a->d, c.stats, c.n_seq, (double*)c.out_dev);
@@ -1060,6 +1103,12 @@ int32_t gpk_euclidean_length(const gpk_geoarray* a, double* out, int32_t out_spa
     if (a->d.type == GPK_GEOM_POINT) {
         GPK_LAUNCH("gpk_point_unary", point_unary_kernel, grid_for(n), dim3(256), 0, s, a->d, 0, (double*)c.out_dev, (uint8_t*)nullptr);
     } else {
+        const gpk_seq_classes* cl = nullptr;
+        if (a->d.type != GPK_GEOM_MULTIPOINT) GPK_TRY(seq_classes_of(a, s, &cl));
+        if (cl && cl->one_to_one) {
+            GPK_TRY((launch_seq_stats<M_LEN, FIN_LENGTH>(a, c.stats, c.long_part, s, "gpk_seq_length", FinalOut{(double*)c.out_dev, a->d.validity})));
+            return copy_out(out, out_space, c.out_dev, ob, s);
+        }
         if (a->d.type != GPK_GEOM_MULTIPOINT) GPK_TRY(launch_seq_stats<M_LEN>(a, c.stats, c.long_part, s, "gpk_seq_length"));
         GPK_LAUNCH("gpk_length_combine", length_combine_kernel, grid_for(n), dim3(256), 0, s, a->d, c.stats, c.n_seq, (double*)c.out_dev);
     }
@@ -1076,8 +1125,14 @@ int32_t gpk_bounds(const gpk_geoarray* a, double* out4, int32_t out_space, void*
     if (a->d.type == GPK_GEOM_POINT) {
         GPK_LAUNCH("gpk_point_unary", point_unary_kernel, grid_for(n), dim3(256), 0, s, a->d, 2, (double*)c.out_dev, (uint8_t*)nullptr);
     } else {
-        GPK_TRY(launch_seq_stats<M_BBOX>(a, c.stats, c.long_part, s, "gpk_seq_bbox"));
-        GPK_LAUNCH("gpk_bounds_combine", bounds_combine_kernel, grid_for(n), dim3(256), 0, s, a->d, c.stats, c.n_seq, (double*)c.out_dev);
+        const gpk_seq_classes* cl;
+        GPK_TRY(seq_classes_of(a, s, &cl));
+        if (cl->one_to_one) {  // stage 1 writes the boxes, no combine pass
+            GPK_TRY((launch_seq_stats<M_BBOX, FIN_BOUNDS>(a, c.stats, c.long_part, s, "gpk_seq_bbox", FinalOut{(double*)c.out_dev, a->d.validity})));
+        } else {
+            GPK_TRY(launch_seq_stats<M_BBOX>(a, c.stats, c.long_part, s, "gpk_seq_bbox"));
+            GPK_LAUNCH("gpk_bounds_combine", bounds_combine_kernel, grid_for(n), dim3(256), 0, s, a->d, c.stats, c.n_seq, (double*)c.out_dev);
+        }
     }
     return copy_out(out4, out_space, c.out_dev, ob, s);
 }

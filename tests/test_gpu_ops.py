@@ -4,7 +4,7 @@ bit-exact (no reduction-order freedom); booleans bit-exact."""
 import numpy as np
 import pytest
 
-from geopolars_amd import synth
+from geopolars_amd import _abi, synth
 from geopolars_amd.geoarrow import GeoArrowArray
 from geopolars_amd.geoseries import GeoSeries
 
@@ -254,3 +254,29 @@ def test_rotate_scale_skew_per_geometry_origin(gpk, oracle, name, origin):
     tx, ty = math.tan(math.radians(10.0)), math.tan(math.radians(-5.0))
     sk = np.stack([z + 1.0, z + tx, -o[:, 1] * tx, z + ty, z + 1.0, -o[:, 0] * ty], axis=1)
     assert np.array_equal(s.skew(10.0, -5.0, origin).array.xy, _affine_rows_reference(a, sk, oracle))
+
+
+def test_one_to_one_columns_skip_the_combine_pass_and_keep_nulls_and_empties(gpk, oracle):
+    """single-ring polygon, linestring and multipoint columns finish in stage 1 (no per-geometry combine): null rows
+    still give NaN, empty rows NaN bounds / zero measures, clockwise rings a negative signed area"""
+    polys = synth.star_polygons(5000, 7)
+    xy = polys.xy.copy()
+    ro = polys.ring_offsets
+    for r in range(0, 5000, 3):  # every third ring clockwise
+        xy[ro[r] : ro[r + 1]] = polys.xy[ro[r] : ro[r + 1]][::-1]
+    keep = np.ones(5000, np.uint8)
+    keep[::11] = 0
+    a = GeoArrowArray(polys.geom_type, xy, polys.geom_offsets, ring_offsets=polys.ring_offsets, validity=np.packbits(keep, bitorder="little"))
+    s = GeoSeries(a)
+    _close(s.area(), oracle.area(a))
+    _close(s.signed_area(), oracle.area(a, signed=True))
+    assert (s.signed_area()[keep == 1] < 0).any()
+    _close(s.euclidean_length(), oracle.euclidean_length(a))
+    assert np.array_equal(s.bounds(), oracle.bounds(a), equal_nan=True)
+    assert np.isnan(s.area()[0]) and np.isnan(s.bounds()[0]).all()
+    lines = GeoArrowArray.from_linestrings([[(0, 0), (3, 4)], [], [(1, 1)], [(0, 0), (1, 0), (1, 1), (0, 1), (0, 0)]] * 300)
+    sl = GeoSeries(lines)
+    _close(sl.euclidean_length(), oracle.euclidean_length(lines))
+    assert np.array_equal(sl.bounds(), oracle.bounds(lines), equal_nan=True)
+    mp = GeoArrowArray(_abi.GEOM_MULTIPOINT, np.arange(40.0).reshape(20, 2), geom_offsets=np.array([0, 3, 3, 10, 20], np.int32))
+    assert np.array_equal(GeoSeries(mp).bounds(), oracle.bounds(mp), equal_nan=True)
