@@ -10,6 +10,9 @@
 // winding number and any-hit flags are folded with xor-shuffles inside the group.  That is the
 // "bin on vertex count so lanes in a wave see similar work" rule of the north star applied per call.
 #include <cfloat>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
 
 #include "gpk_device.h"
 #include "gpk_polypoly.h"
@@ -356,6 +359,43 @@ __global__ __launch_bounds__(256) void dist_sort_kernel(const uint32_t* __restri
     }
 }
 
+// How local is the row map?  Counts the lanes whose key is within one of their right neighbour's (ascending or equal
+// runs: `i mod L`, sorted maps, blocks of one target).  Local maps make the counting sort's atomics land on neighbouring
+// counters (one cache line per wave); a random map makes every lane's atomic its own line, and a radix sort wins.
+// A sample is enough: DIST_PROBE_BLOCKS chunks of 256 rows spread evenly over the map (one atomic per wave on a single
+// word — sampling every row would cost 1.9 ms in that atomic alone).
+constexpr int DIST_PROBE_BLOCKS = 256;
+__global__ __launch_bounds__(256) void dist_probe_kernel(const uint32_t* __restrict__ rows, int64_t n, unsigned long long* __restrict__ local) {
+    const int64_t i = (int64_t)blockIdx.x * (n / gridDim.x) + threadIdx.x;
+    const uint32_t k = i < n ? rows[i] : 0u, kn = i + 1 < n ? rows[i + 1] : k;
+    const unsigned long long m = __ballot(i + 1 < n && (kn - k <= 1u));
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(local, (unsigned long long)__popcll(m));
+}
+__global__ void iota_u32_kernel(uint32_t* __restrict__ v, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = (uint32_t)i;
+}
+// off[t] = first position of key t in the sorted keys (t = 0..L), cnt[t] = rows of target t
+__global__ void sorted_offsets_kernel(const uint32_t* __restrict__ keys, int64_t n, int64_t L, int32_t* __restrict__ off,
+                                      int32_t* __restrict__ cnt) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > L) return;
+    auto lower = [&](uint32_t key) {
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (keys[mid] < key)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        return lo;
+    };
+    const int64_t a = lower((uint32_t)t);
+    off[t] = (int32_t)a;
+    if (t < L) cnt[t] = (int32_t)(lower((uint32_t)t + 1u) - a);
+}
+
 __global__ void dist_batches_kernel(const int32_t* __restrict__ cnt, int64_t L, int32_t* __restrict__ nb) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < L) nb[t] = (cnt[t] + 63) >> 6;
@@ -590,9 +630,11 @@ int32_t gpk_distance_rowwise(const gpk_geoarray* a, const gpk_geoarray* b, const
         const size_t ib = align256(sizeof(int32_t) * (size_t)(L + 1));
         const size_t total = 5 * ib + align256(sizeof(uint32_t) * (size_t)n) + align256(sizeof(unsigned long long) * (size_t)((L + 255) / 256 + 4));
         GPK_HIP(hipMalloc(&tmp, total));
+        void* sort_tmp_free = nullptr;
         auto fin = [&](int32_t rc) {
             (void)hipStreamSynchronize(s);
             (void)hipFree(tmp);
+            if (sort_tmp_free) (void)hipFree(sort_tmp_free);
             return rc;
         };
         char* base = (char*)tmp;
@@ -603,14 +645,39 @@ int32_t gpk_distance_rowwise(const gpk_geoarray* a, const gpk_geoarray* b, const
         int32_t* g_item = (int32_t*)(base + 4 * ib);
         uint32_t* perm = (uint32_t*)(base + 5 * ib);
         unsigned long long* btot = (unsigned long long*)(base + 5 * ib + align256(sizeof(uint32_t) * (size_t)n));
+        void* sort_tmp = nullptr;  // radix-sort path only
         auto run = [&]() -> int32_t {
-            GPK_HIP(hipMemsetAsync(g_cnt, 0, sizeof(int32_t) * (size_t)(L + 1), s));
             const dim3 rg((unsigned)((n + 255) / 256));
-            GPK_LAUNCH("gpk_dist_hist", dist_sort_kernel<false>, rg, dim3(256), 0, s, rows_dev, n, g_cnt, (uint32_t*)nullptr);
-            GPK_TRY(exclusive_scan_i32(g_cnt, L, g_off, g_cur, btot, s));
+            // rows grouped by target: counting sort for local row maps, radix sort (rocPRIM) for scattered ones
+            unsigned long long h_local = 0, *d_local = btot;
+            GPK_HIP(hipMemsetAsync(d_local, 0, sizeof(unsigned long long), s));
+            const int probe_blocks = n >= 256 * DIST_PROBE_BLOCKS ? DIST_PROBE_BLOCKS : 1;
+            GPK_LAUNCH("gpk_dist_probe", dist_probe_kernel, dim3((unsigned)probe_blocks), dim3(256), 0, s, rows_dev, n, d_local);
+            GPK_HIP(hipMemcpyAsync(&h_local, d_local, sizeof h_local, hipMemcpyDeviceToHost, s));
+            GPK_HIP(hipStreamSynchronize(s));
+            const int64_t sampled = (int64_t)probe_blocks * 256 < n ? (int64_t)probe_blocks * 256 : n;
+            if (2 * (int64_t)h_local >= sampled) {
+                GPK_HIP(hipMemsetAsync(g_cnt, 0, sizeof(int32_t) * (size_t)(L + 1), s));
+                GPK_LAUNCH("gpk_dist_hist", dist_sort_kernel<false>, rg, dim3(256), 0, s, rows_dev, n, g_cnt, (uint32_t*)nullptr);
+                GPK_TRY(exclusive_scan_i32(g_cnt, L, g_off, g_cur, btot, s));
+                GPK_LAUNCH("gpk_dist_scatter", dist_sort_kernel<true>, rg, dim3(256), 0, s, rows_dev, n, g_cur, perm);
+            } else {
+                int bits = 1;
+                while (bits < 32 && (1ll << bits) < L) ++bits;
+                size_t tb = 0;
+                GPK_HIP(rocprim::radix_sort_pairs(nullptr, tb, rows_dev, (uint32_t*)nullptr, (const uint32_t*)nullptr, perm, (size_t)n, 0, bits, s));
+                const size_t nbytes = align256(sizeof(uint32_t) * (size_t)n);
+                GPK_HIP(hipMalloc(&sort_tmp, 2 * nbytes + tb + 256));
+                uint32_t* iota = (uint32_t*)sort_tmp;
+                uint32_t* keys_sorted = (uint32_t*)((char*)sort_tmp + nbytes);
+                void* rp_tmp = (char*)sort_tmp + 2 * nbytes;
+                GPK_LAUNCH("gpk_dist_iota", iota_u32_kernel, rg, dim3(256), 0, s, iota, n);
+                GPK_HIP(rocprim::radix_sort_pairs(rp_tmp, tb, rows_dev, keys_sorted, (const uint32_t*)iota, perm, (size_t)n, 0, bits, s));
+                GPK_LAUNCH("gpk_dist_offsets", sorted_offsets_kernel, dim3((unsigned)((L + 256) / 256)), dim3(256), 0, s, (const uint32_t*)keys_sorted, n,
+                           L, g_off, g_cnt);
+            }
             GPK_LAUNCH("gpk_dist_batches", dist_batches_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, s, (const int32_t*)g_cnt, L, g_nb);
             GPK_TRY(exclusive_scan_i32(g_nb, L, g_item, nullptr, btot, s));
-            GPK_LAUNCH("gpk_dist_scatter", dist_sort_kernel<true>, rg, dim3(256), 0, s, rows_dev, n, g_cur, perm);
             int64_t blocks = (n / 64 + L + 3) / 4;  // upper bound on the number of (target, 64-row batch) items
             const int64_t cap = (int64_t)cu_count() * 16;
             if (blocks > cap) blocks = cap;
@@ -619,6 +686,7 @@ int32_t gpk_distance_rowwise(const gpk_geoarray* a, const gpk_geoarray* b, const
             return GPK_OK;
         };
         const int32_t rc = run();
+        sort_tmp_free = sort_tmp;
         if (rc != GPK_OK) return fin(rc);
         const int32_t rc2 = copy_out(out, out_space, out_dev, ob, s);
         return fin(rc2);

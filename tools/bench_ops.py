@@ -51,6 +51,14 @@ def timed(lib, fn, reps=10):
         if c.value:
             out[name.decode()] = m.value / reps
     lib.gpk_profile_reset()
+    # wall time per call on the stream (library kernels that are not bracketed, e.g. rocPRIM sorts, and launch gaps included)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn(stream)
+    e1.record()
+    torch.cuda.synchronize()
+    out["wall_ms_per_call"] = e0.elapsed_time(e1) / reps
     return ms.value / reps, out
 
 
