@@ -89,6 +89,9 @@ class Workspace {
     int device_ = -1;
 };
 Workspace& workspace();
+// second and third per-thread arenas for calls whose scratch is sized in stages (the polygon x polygon join learns its
+// candidate count only after a first pass, and gpk_bounds inside it uses workspace() itself)
+Workspace& workspace_aux(int which);
 
 inline size_t align256(size_t n) { return (n + 255) & ~size_t(255); }
 

@@ -729,9 +729,9 @@ static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, co
             if (p) (void)hipFree(p);
         return rc;
     };
-    double4* lbbox = nullptr;
-    GPK_HIP(hipMalloc((void**)&lbbox, sizeof(double4) * (size_t)n));
-    owned[0] = lbbox;
+    // left boxes and the candidate buffers live in the thread's auxiliary arenas (no hipMalloc / hipFree per call)
+    GPK_TRY(workspace_aux(0).begin(sizeof(double4) * (size_t)n + 256));
+    double4* lbbox = (double4*)workspace_aux(0).take(sizeof(double4) * (size_t)n);
     int32_t rc = gpk_bounds(left, (double*)lbbox, GPK_MEM_DEVICE, (void*)s);
     if (rc != GPK_OK) return done(rc);
     const int64_t nb = (n + 255) / 256;
@@ -764,13 +764,12 @@ static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, co
     uint32_t *cand_r = nullptr, *cand_l = nullptr;
     uint8_t* hit = nullptr;
     {
-        hipError_t e = hipMalloc((void**)&cand_r, sizeof(uint32_t) * (size_t)(n_cand > 0 ? n_cand : 1));
-        owned[1] = cand_r;
-        if (e == hipSuccess) e = hipMalloc((void**)&cand_l, sizeof(uint32_t) * (size_t)(n_cand > 0 ? n_cand : 1));
-        owned[3] = cand_l;
-        if (e == hipSuccess) e = hipMalloc((void**)&hit, (size_t)(n_cand > 0 ? n_cand : 1));
-        owned[2] = hit;
-        if (e != hipSuccess) return done(fail(GPK_ERR_OOM, "spatial_join: candidate buffers (%d pairs): %s", n_cand, hipGetErrorString(e)));
+        const size_t nc1 = (size_t)(n_cand > 0 ? n_cand : 1);
+        rc = workspace_aux(1).begin(2 * align256(sizeof(uint32_t) * nc1) + align256(nc1) + 256);
+        if (rc != GPK_OK) return done(rc);
+        cand_r = (uint32_t*)workspace_aux(1).take(sizeof(uint32_t) * nc1);
+        cand_l = (uint32_t*)workspace_aux(1).take(sizeof(uint32_t) * nc1);
+        hit = (uint8_t*)workspace_aux(1).take(nc1);
     }
     auto stage23 = [&]() -> int32_t {
         GPK_LAUNCH("gpk_bbox_cand_fill", bbox_cand_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, left->d, right->d, right_index->v,

@@ -67,6 +67,10 @@ Workspace& workspace() {
     static thread_local Workspace ws;
     return ws;
 }
+Workspace& workspace_aux(int which) {
+    static thread_local Workspace aux[2];
+    return aux[which & 1];
+}
 
 // ---- profiling -----------------------------------------------------------------------------
 struct ProfRec {
