@@ -81,6 +81,7 @@ class Workspace {
     // between begin() calls.
     int32_t begin(size_t total_bytes);
     void* take(size_t bytes);
+    void trim(size_t keep_max);  // give the arena back when it has grown beyond keep_max bytes (after a device sync)
     ~Workspace();
 
   private:

@@ -411,15 +411,19 @@ __global__ void sub_commit_kernel(const int32_t* __restrict__ flag, const int32_
 using namespace gpk;
 
 namespace {
-struct Temps {  // hipMalloc'ed scratch of the build, released on every exit path
+struct Temps {  // scratch of the build: carved from the thread's auxiliary arena, hipMalloc'ed (and released on every
+                // exit path) only when the arena's estimate was too small
     void* p[32] = {nullptr};
     int n = 0;
     template <typename T>
     int32_t alloc(T** out, size_t count) {
-        void* q = nullptr;
-        hipError_t e = hipMalloc(&q, sizeof(T) * (count ? count : 1));
-        if (e != hipSuccess) return fail(GPK_ERR_OOM, "index build: hipMalloc(%zu) failed: %s", sizeof(T) * count, hipGetErrorString(e));
-        p[n++] = q;
+        const size_t bytes = sizeof(T) * (count ? count : 1);
+        void* q = gpk::workspace_aux(1).take(bytes);
+        if (!q) {
+            hipError_t e = hipMalloc(&q, bytes);
+            if (e != hipSuccess) return fail(GPK_ERR_OOM, "index build: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+            if (n < 32) p[n++] = q;
+        }
         *out = (T*)q;
         return GPK_OK;
     }
@@ -458,6 +462,14 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
     if (!(g.pad_x > ulp64) || !(g.pad_y > ulp64)) return GPK_OK;
 
     const int64_t n_rings = d.n_rings, n_parts = d.n_parts, n_cells = (int64_t)R * R;
+    // arena estimate for the temporaries: per-ring and per-cell arrays plus ~3 boundary marks per coordinate (24-byte
+    // keys x 3 copies + flags); anything beyond it falls back to hipMalloc inside Temps
+    // (capped: a multi-gigabyte arena costs more to map than the individual allocations it replaces)
+    {
+        size_t est = (size_t)n_rings * 64 + (size_t)n_cells * 24 + (size_t)d.n_coords * 120 + (1u << 20);
+        if (est > (size_t(256) << 20)) est = size_t(256) << 20;
+        (void)workspace_aux(1).begin(est);
+    }
     Temps t;
     int slot = 4;  // ix->owned[0..3] belong to the coarse directory
     auto keep = [&](void* p) {

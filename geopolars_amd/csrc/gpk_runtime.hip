@@ -60,6 +60,13 @@ void* Workspace::take(size_t bytes) {
     used_ += bytes;
     return p;
 }
+void Workspace::trim(size_t keep_max) {
+    if (!base_ || cap_ <= keep_max) return;
+    (void)hipDeviceSynchronize();
+    (void)hipFree(base_);
+    base_ = nullptr;
+    cap_ = used_ = 0;
+}
 Workspace::~Workspace() {
     // process teardown: the HIP runtime may already be gone; leak rather than crash.
 }
