@@ -659,7 +659,10 @@ __global__ __launch_bounds__(256) void bbox_cand_kernel(DevGeo left, DevGeo righ
 
 // Stage 2: exact refine, JOIN_GS lanes per candidate pair (pairs are independent: the unit of parallelism is the
 // pair, not the row, so ragged candidate lists do not unbalance waves).
-constexpr int JOIN_GS = 16;
+#ifndef GPK_JOIN_GS
+#define GPK_JOIN_GS 16
+#endif
+constexpr int JOIN_GS = GPK_JOIN_GS;
 __device__ __forceinline__ int64_t row_of_candidate(const int32_t* __restrict__ off, int64_t n_rows, int64_t c) {
     int64_t lo = 0, hi = n_rows;  // largest row with off[row] <= c
     while (hi - lo > 1) {

@@ -206,7 +206,10 @@ __device__ inline void polygon_bboxes_group(const DevGeo& a, int r0, int r1, int
 // Neighbouring polygons overlap in a small window, which takes the O(n*m) pruning loop down to the few segments
 // that can matter.  seg_list: 2 * PP_LIST double4 owned by this group (all lanes of a group sit in one wave).
 constexpr int PP_VOTE = 4;   // list entries between two group votes in the cross test
-constexpr int PP_LIST = 32;  // per list; a group owns two lists (2 * PP_LIST double4 = 2 KB)
+#ifndef GPK_PP_LIST
+#define GPK_PP_LIST 32
+#endif
+constexpr int PP_LIST = GPK_PP_LIST;  // per list; a group owns two lists (2 * PP_LIST double4 = 2 KB)
 template <int G>
 __device__ inline bool polygon_intersects_polygon_group(const DevGeo& a, int ar0, int ar1, const DevGeo& b, int br0, int br1, int lane,
                                                         double4* __restrict__ seg_list, const double4* a_box = nullptr,
