@@ -149,19 +149,28 @@ __device__ __forceinline__ void seq_store(const SeqPartial& a, double* __restric
 
 // Columns whose sequences ARE their geometries (a LINESTRING column; a POLYGON column of single-ring polygons, the usual
 // shape of building / parcel data) skip the per-geometry combine: stage 1 writes the operator's result itself.
-enum { FIN_NONE = 0, FIN_AREA = 1, FIN_SIGNED_AREA = 2, FIN_BOUNDS = 3, FIN_LENGTH = 4 };
+enum { FIN_NONE = 0, FIN_AREA, FIN_SIGNED_AREA, FIN_BOUNDS, FIN_LENGTH, FIN_CENT_POLY, FIN_CENT_DEGEN, FIN_CENT_LINE, FIN_CENT_MPOINT };
 struct FinalOut {
-    double* out;              // result column (bounds: 4 doubles per row)
+    double* out;              // result column (bounds: 4 doubles per row, centroid: 2)
     const uint8_t* validity;  // of the geometries (= sequences)
+    uint8_t* out_valid;       // centroid: "has a centroid" flags (may be nullptr)
 };
+// centroid of a row that contributes as a linestring (Centroid::add_line_string, centroid.rs): length-weighted
+// midpoints, or the start point when every segment is degenerate; same arithmetic as wc_add_linestring + the final divide
+__device__ __forceinline__ double2 line_centroid(const SeqPartial& a, double2 first, int n) {
+    if (a.len > 0.0) return make_double2(a.lmx / a.len, a.lmy / a.len);
+    const double k = n == 1 ? 1.0 : (double)(n - 1);
+    return make_double2(first.x * k / k, first.y * k / k);
+}
 template <unsigned MASK, int FIN>
-__device__ __forceinline__ void seq_store_any(const SeqPartial& a, double* __restrict__ stats, int64_t n_seq, int64_t s, bool empty,
-                                              const FinalOut& f) {
+__device__ __forceinline__ void seq_store_any(const SeqPartial& a, double* __restrict__ stats, int64_t n_seq, int64_t s, int c0, int c1,
+                                              const double2* __restrict__ xy, const FinalOut& f) {
     if (FIN == FIN_NONE) {
         seq_store<MASK>(a, stats, n_seq, s);
         return;
     }
     const bool valid = dev::valid_row(f.validity, s);
+    const int n = c1 - c0;
     if (FIN == FIN_AREA) f.out[s] = valid ? fabs(fabs(a.a2 / 2.0)) : NAN;  // area_combine_kernel for one ring
     if (FIN == FIN_SIGNED_AREA) {
         const double h = a.a2 / 2.0;
@@ -169,7 +178,33 @@ __device__ __forceinline__ void seq_store_any(const SeqPartial& a, double* __res
     }
     if (FIN == FIN_LENGTH) f.out[s] = valid ? 0.0 + a.len : NAN;
     if (FIN == FIN_BOUNDS)
-        reinterpret_cast<double4*>(f.out)[s] = (valid && !empty) ? make_double4(a.mnx, a.mny, a.mxx, a.mxy) : make_double4(NAN, NAN, NAN, NAN);
+        reinterpret_cast<double4*>(f.out)[s] = (valid && n > 0) ? make_double4(a.mnx, a.mny, a.mxx, a.mxy) : make_double4(NAN, NAN, NAN, NAN);
+    if (FIN == FIN_CENT_POLY || FIN == FIN_CENT_DEGEN || FIN == FIN_CENT_LINE || FIN == FIN_CENT_MPOINT) {
+        double2* out2 = reinterpret_cast<double2*>(f.out);
+        if (FIN == FIN_CENT_POLY) stats[ST_AREA2 * n_seq + s] = a.a2;  // the degenerate-only second pass filters on it
+        if (!valid || n == 0) {
+            if (FIN != FIN_CENT_DEGEN) {  // (the second pass leaves what the first one wrote)
+                out2[s] = make_double2(NAN, NAN);
+                if (f.out_valid) f.out_valid[s] = 0;
+            }
+            return;
+        }
+        double2 r;
+        if (FIN == FIN_CENT_POLY) {
+            const double area = a.a2 / 2.0;
+            if (area == 0.0) return;  // zero-area ring: the second pass writes its linestring centroid
+            const double2 sh = xy[c0];
+            const double w = fabs(area);
+            const double cx = a.acx / (6.0 * area) + sh.x, cy = a.acy / (6.0 * area) + sh.y;
+            r = make_double2(cx * w / w, cy * w / w);  // wc_add + the final divide of centroid_combine_kernel
+        } else if (FIN == FIN_CENT_MPOINT) {
+            r = make_double2(a.sx / (double)n, a.sy / (double)n);
+        } else {
+            r = line_centroid(a, xy[c0], n);
+        }
+        out2[s] = r;
+        if (f.out_valid) f.out_valid[s] = 1;
+    }
 }
 
 // ---- size classes ---------------------------------------------------------------------------------------------
@@ -272,7 +307,7 @@ __device__ __forceinline__ void seq_stats_long_body(const double2* __restrict__ 
                 SeqPartial r;
                 r.a2 = t[0]; r.acx = t[1]; r.acy = t[2]; r.len = t[3]; r.lmx = t[4]; r.lmy = t[5]; r.sx = t[6]; r.sy = t[7];
                 r.mnx = t[8]; r.mny = t[9]; r.mxx = t[10]; r.mxy = t[11];
-                seq_store_any<MASK, FIN>(r, stats, n_seq, s, c1 <= c0, fin);
+                seq_store_any<MASK, FIN>(r, stats, n_seq, s, c0, c1, xy, fin);
             } else {
 #pragma unroll
                 for (int q = 0; q < 12; ++q) part[12 * w + q] = t[q];
@@ -282,7 +317,8 @@ __device__ __forceinline__ void seq_stats_long_body(const double2* __restrict__ 
 }
 template <unsigned MASK, int FIN>
 __global__ void seq_long_combine_kernel(const int32_t* __restrict__ list, int64_t n_list, const int32_t* __restrict__ chunk_begin,
-                                        const double* __restrict__ part, int64_t n_seq, double* __restrict__ stats, FinalOut fin) {
+                                        const double* __restrict__ part, int64_t n_seq, double* __restrict__ stats, FinalOut fin,
+                                        const int32_t* __restrict__ seq_off, const double2* __restrict__ xy) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_list) return;
     const int w0 = chunk_begin[k], w1 = chunk_begin[k + 1];
@@ -299,7 +335,7 @@ __global__ void seq_long_combine_kernel(const int32_t* __restrict__ list, int64_
     SeqPartial r;
     r.a2 = t[0]; r.acx = t[1]; r.acy = t[2]; r.len = t[3]; r.lmx = t[4]; r.lmy = t[5]; r.sx = t[6]; r.sy = t[7];
     r.mnx = t[8]; r.mny = t[9]; r.mxx = t[10]; r.mxy = t[11];
-    seq_store_any<MASK, FIN>(r, stats, n_seq, s, false, fin);
+    seq_store_any<MASK, FIN>(r, stats, n_seq, s, seq_off[s], seq_off[s + 1], xy, fin);
 }
 
 template <int G, unsigned MASK, int FIN>
@@ -395,7 +431,7 @@ __device__ __forceinline__ void seq_stats_group_body(const double2* __restrict__
             SeqPartial r;
             r.a2 = a2; r.acx = acx; r.acy = acy; r.len = len; r.lmx = lmx; r.lmy = lmy; r.sx = sx_; r.sy = sy_;
             r.mnx = mnx; r.mny = mny; r.mxx = mxx; r.mxy = mxy;
-            seq_store_any<MASK, FIN>(r, stats, n_seq, s, n == 0, fin);
+            seq_store_any<MASK, FIN>(r, stats, n_seq, s, c0, c1, xy, fin);
         }
     }
 }
@@ -785,7 +821,7 @@ __device__ __forceinline__ void seq_stats_tiny_body(const double2* __restrict__ 
                 a.sx = group_sum<G>(a.sx);
                 a.sy = group_sum<G>(a.sy);
             }
-            if (lane == 0) seq_store_any<MASK, FIN>(a, stats, n_seq, s, n == 0, fin);
+            if (lane == 0) seq_store_any<MASK, FIN>(a, stats, n_seq, s, c0, c1, xy, fin);
         }
     }
 }
@@ -950,7 +986,7 @@ static int32_t seq_classes_of(const gpk_geoarray* a, hipStream_t s, const gpk_se
 
 template <unsigned MASK, int FIN = FIN_NONE>
 static int32_t launch_seq_stats(const gpk_geoarray* arr, double* stats, double* long_part, hipStream_t s, const char* name,
-                                FinalOut fin = FinalOut{nullptr, nullptr}) {
+                                FinalOut fin = FinalOut{nullptr, nullptr, nullptr}) {
     const DevGeo& a = arr->d;
     const int32_t* seq_off;
     int64_t n_seq;
@@ -984,7 +1020,7 @@ static int32_t launch_seq_stats(const gpk_geoarray* arr, double* stats, double* 
         GPK_LAUNCH(name, (seq_stats_kernel<MASK, FIN>), dim3((unsigned)total_blocks), dim3(256), tiny_lds, s, a.xy, seq_off, n_seq, stats, p, fin);
     if (c->n_chunks > c->count[3])  // some sequence spans several chunks
         GPK_LAUNCH("gpk_seq_long_combine", (seq_long_combine_kernel<MASK, FIN>), dim3((unsigned)((c->count[3] + 255) / 256)), dim3(256), 0, s, p.list[3],
-                   c->count[3], (const int32_t*)c->chunk_begin, (const double*)long_part, n_seq, stats, fin);
+                   c->count[3], (const int32_t*)c->chunk_begin, (const double*)long_part, n_seq, stats, fin, seq_off, a.xy);
     return GPK_OK;
 }
 
@@ -1070,7 +1106,7 @@ static int32_t area_impl(const gpk_geoarray* a, double* out, int32_t out_space, 
         const gpk_seq_classes* cl = nullptr;
         if (is_polygonal(a->d.type)) GPK_TRY(seq_classes_of(a, s, &cl));
         if (cl && cl->one_to_one) {  // single-ring polygons: stage 1 writes the areas, no combine pass
-            const FinalOut fin{(double*)c.out_dev, a->d.validity};
+            const FinalOut fin{(double*)c.out_dev, a->d.validity, nullptr};
             if (is_signed)
                 GPK_TRY((launch_seq_stats<M_AREA, FIN_SIGNED_AREA>(a, c.stats, c.long_part, s, "gpk_ring_area", fin)));
             else
@@ -1106,7 +1142,7 @@ int32_t gpk_euclidean_length(const gpk_geoarray* a, double* out, int32_t out_spa
         const gpk_seq_classes* cl = nullptr;
         if (a->d.type != GPK_GEOM_MULTIPOINT) GPK_TRY(seq_classes_of(a, s, &cl));
         if (cl && cl->one_to_one) {
-            GPK_TRY((launch_seq_stats<M_LEN, FIN_LENGTH>(a, c.stats, c.long_part, s, "gpk_seq_length", FinalOut{(double*)c.out_dev, a->d.validity})));
+            GPK_TRY((launch_seq_stats<M_LEN, FIN_LENGTH>(a, c.stats, c.long_part, s, "gpk_seq_length", FinalOut{(double*)c.out_dev, a->d.validity, nullptr})));
             return copy_out(out, out_space, c.out_dev, ob, s);
         }
         if (a->d.type != GPK_GEOM_MULTIPOINT) GPK_TRY(launch_seq_stats<M_LEN>(a, c.stats, c.long_part, s, "gpk_seq_length"));
@@ -1128,7 +1164,7 @@ int32_t gpk_bounds(const gpk_geoarray* a, double* out4, int32_t out_space, void*
         const gpk_seq_classes* cl;
         GPK_TRY(seq_classes_of(a, s, &cl));
         if (cl->one_to_one) {  // stage 1 writes the boxes, no combine pass
-            GPK_TRY((launch_seq_stats<M_BBOX, FIN_BOUNDS>(a, c.stats, c.long_part, s, "gpk_seq_bbox", FinalOut{(double*)c.out_dev, a->d.validity})));
+            GPK_TRY((launch_seq_stats<M_BBOX, FIN_BOUNDS>(a, c.stats, c.long_part, s, "gpk_seq_bbox", FinalOut{(double*)c.out_dev, a->d.validity, nullptr})));
         } else {
             GPK_TRY(launch_seq_stats<M_BBOX>(a, c.stats, c.long_part, s, "gpk_seq_bbox"));
             GPK_LAUNCH("gpk_bounds_combine", bounds_combine_kernel, grid_for(n), dim3(256), 0, s, a->d, c.stats, c.n_seq, (double*)c.out_dev);
@@ -1148,6 +1184,21 @@ int32_t gpk_centroid(const gpk_geoarray* a, double* out_xy, uint8_t* out_valid, 
     if (a->d.type == GPK_GEOM_POINT) {
         GPK_LAUNCH("gpk_point_unary", point_unary_kernel, grid_for(n), dim3(256), 0, s, a->d, 1, (double*)c.out_dev, (uint8_t*)c.out2_dev);
     } else {
+        const gpk_seq_classes* cl;
+        GPK_TRY(seq_classes_of(a, s, &cl));
+        if (cl->one_to_one) {  // stage 1 writes the centroids: no stats round trip, no combine pass
+            const FinalOut fin{(double*)c.out_dev, a->d.validity, (uint8_t*)c.out2_dev};
+            if (a->d.type == GPK_GEOM_MULTIPOINT) {
+                GPK_TRY((launch_seq_stats<M_SUM, FIN_CENT_MPOINT>(a, c.stats, c.long_part, s, "gpk_seq_sum", fin)));
+            } else if (a->d.type == GPK_GEOM_POLYGON) {
+                GPK_TRY((launch_seq_stats<M_CENT, FIN_CENT_POLY>(a, c.stats, c.long_part, s, "gpk_ring_centroid", fin)));
+                GPK_TRY((launch_seq_stats<M_LENC | M_DEGEN, FIN_CENT_DEGEN>(a, c.stats, c.long_part, s, "gpk_ring_centroid_degenerate", fin)));
+            } else {
+                GPK_TRY((launch_seq_stats<M_LENC, FIN_CENT_LINE>(a, c.stats, c.long_part, s, "gpk_line_centroid", fin)));
+            }
+            if (out_valid) GPK_TRY(copy_out(out_valid, out_space, c.out2_dev, vb, s));
+            return copy_out(out_xy, out_space, c.out_dev, ob, s);
+        }
         if (a->d.type == GPK_GEOM_MULTIPOINT)
             GPK_TRY(launch_seq_stats<M_SUM>(a, c.stats, c.long_part, s, "gpk_seq_sum"));
         else if (is_polygonal(a->d.type)) {

@@ -280,3 +280,21 @@ def test_one_to_one_columns_skip_the_combine_pass_and_keep_nulls_and_empties(gpk
     assert np.array_equal(sl.bounds(), oracle.bounds(lines), equal_nan=True)
     mp = GeoArrowArray(_abi.GEOM_MULTIPOINT, np.arange(40.0).reshape(20, 2), geom_offsets=np.array([0, 3, 3, 10, 20], np.int32))
     assert np.array_equal(GeoSeries(mp).bounds(), oracle.bounds(mp), equal_nan=True)
+    # centroids of the same one-to-one columns, degenerate single-ring polygons included
+    for arr in (a, lines, mp):
+        exp_c, exp_v = oracle.centroid(arr)
+        got = GeoSeries(arr).centroid()
+        _close(got.array.xy, exp_c)
+    degenerate = GeoArrowArray.from_polygons(
+        [
+            [[(0, 0), (4, 0), (4, 3), (0, 3)]],
+            [[(1, 1), (2, 2), (3, 3), (1, 1)]],  # zero-area ring -> linestring centroid
+            [[(4, 4), (4, 4), (4, 4), (4, 4)]],  # all-identical ring -> point centroid
+            [[(0, 0), (0, 5), (5, 5), (5, 0)]],  # clockwise
+        ]
+        * 500
+        + [[_ring(20000, 3.0, 7.0, 7.0)], [[(float(i), 2.0 * i) for i in range(9000)] + [(float(i), 2.0 * i) for i in range(8998, -1, -1)]]]
+    )
+    exp_c, exp_v = oracle.centroid(degenerate)
+    got = GeoSeries(degenerate).centroid()
+    _close(got.array.xy, exp_c)
