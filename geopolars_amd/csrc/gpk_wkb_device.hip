@@ -290,7 +290,18 @@ extern "C" int32_t gpk_geoarray_from_wkb(const uint8_t* wkb_values, const int32_
         if (rc != GPK_OK && a) gpk_geoarray_free(a);
         return rc;
     };
+    // temporaries come from the thread's auxiliary arena while they fit (capped: mapping gigabytes costs more than the
+    // allocations it replaces); the decoded buffers are the handle's own allocations
+    {
+        size_t est = (size_t)n_rows * 64 + (1u << 20);
+        if (est > (size_t(256) << 20)) est = size_t(256) << 20;
+        (void)workspace_aux(1).begin(est);
+    }
     auto dalloc = [&](void** p, size_t bytes, bool temporary) -> int32_t {
+        if (temporary) {
+            *p = workspace_aux(1).take(bytes ? bytes : 8);
+            if (*p) return GPK_OK;
+        }
         hipError_t e = hipMalloc(p, bytes ? bytes : 8);
         if (e != hipSuccess) return fail(GPK_ERR_OOM, "gpk_geoarray_from_wkb: hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
         if (temporary) tmp[n_tmp++] = *p;

@@ -51,29 +51,73 @@ __global__ __launch_bounds__(256) void wkb_sizes_kernel(DevGeo a, int32_t* __res
     sizes[g] = (int32_t)(b < 0x7FFFFFFF ? b : 0x7FFFFFFF);  // the host has bounded the column below 2 GiB
 }
 
-// geometry headers; POINT rows are complete here, MULTIPOLYGON rows also get their member polygon headers
-__global__ __launch_bounds__(256) void wkb_headers_kernel(DevGeo a, const int32_t* __restrict__ off, uint8_t* __restrict__ out) {
+// geometry headers; POINT rows are complete here.  For the ring types the lane also walks the row's rings / member lines:
+// it writes their headers (count, or a full LineString header) and records where each one's coordinates start
+// (seq_dst[r], -1 for a null row), so the body kernel needs no search for the owner of a ring.
+__global__ __launch_bounds__(256) void wkb_headers_kernel(DevGeo a, const int32_t* __restrict__ off, uint8_t* __restrict__ out,
+                                                           int32_t* __restrict__ seq_dst) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= a.n_geoms || !dev::valid_row(a.validity, g)) return;
-    uint8_t* p = out + off[g];
+    if (g >= a.n_geoms) return;
+    const bool valid = dev::valid_row(a.validity, g);
+    const int32_t o = off[g];
+    uint8_t* p = out + o;
     switch (a.type) {
     case GPK_GEOM_POINT:
+        if (!valid) return;
         p[0] = 1;
         put_u32(p + 1, 1u);
         put_xy(p + 5, a.xy[g]);  // an empty point is NaN NaN in both encodings
         break;
-    case GPK_GEOM_LINESTRING: put_header(p, 2u, (uint32_t)(a.geom_off[g + 1] - a.geom_off[g])); break;
-    case GPK_GEOM_MULTIPOINT: put_header(p, 4u, (uint32_t)(a.geom_off[g + 1] - a.geom_off[g])); break;
-    case GPK_GEOM_POLYGON: put_header(p, 3u, (uint32_t)(a.geom_off[g + 1] - a.geom_off[g])); break;
-    case GPK_GEOM_MULTILINESTRING: put_header(p, 5u, (uint32_t)(a.geom_off[g + 1] - a.geom_off[g])); break;
+    case GPK_GEOM_LINESTRING:
+        seq_dst[g] = valid ? o + 9 : -1;
+        if (valid) put_header(p, 2u, (uint32_t)(a.geom_off[g + 1] - a.geom_off[g]));
+        break;
+    case GPK_GEOM_MULTIPOINT:
+        if (valid) put_header(p, 4u, (uint32_t)(a.geom_off[g + 1] - a.geom_off[g]));
+        break;
+    case GPK_GEOM_POLYGON:
+    case GPK_GEOM_MULTILINESTRING: {
+        const int r0 = a.geom_off[g], r1 = a.geom_off[g + 1];
+        const bool poly = a.type == GPK_GEOM_POLYGON;
+        if (valid) put_header(p, poly ? 3u : 5u, (uint32_t)(r1 - r0));
+        int32_t at = o + 9;
+        for (int r = r0; r < r1; ++r) {
+            const int n = a.ring_off[r + 1] - a.ring_off[r];
+            if (!valid) {
+                seq_dst[r] = -1;
+                continue;
+            }
+            if (poly)
+                put_u32(out + at, (uint32_t)n);
+            else
+                put_header(out + at, 2u, (uint32_t)n);
+            at += poly ? 4 : 9;
+            seq_dst[r] = at;
+            at += 16 * n;
+        }
+        break;
+    }
     default: {
         const int p0 = a.geom_off[g], p1 = a.geom_off[g + 1];
-        put_header(p, 6u, (uint32_t)(p1 - p0));
-        const int rbase = a.part_off[p0], cbase = a.ring_off[rbase];
+        if (valid) put_header(p, 6u, (uint32_t)(p1 - p0));
+        int32_t at = o + 9;
         for (int q = p0; q < p1; ++q) {
             const int r0 = a.part_off[q], r1 = a.part_off[q + 1];
-            uint8_t* ph = p + 9 + 9 * (int64_t)(q - p0) + 4 * (int64_t)(r0 - rbase) + 16 * (int64_t)(a.ring_off[r0] - cbase);
-            put_header(ph, 3u, (uint32_t)(r1 - r0));
+            if (valid) {
+                put_header(out + at, 3u, (uint32_t)(r1 - r0));
+                at += 9;
+            }
+            for (int r = r0; r < r1; ++r) {
+                const int n = a.ring_off[r + 1] - a.ring_off[r];
+                if (!valid) {
+                    seq_dst[r] = -1;
+                    continue;
+                }
+                put_u32(out + at, (uint32_t)n);
+                at += 4;
+                seq_dst[r] = at;
+                at += 16 * n;
+            }
         }
     }
     }
@@ -92,67 +136,37 @@ __device__ __forceinline__ int owner_of(const int32_t* __restrict__ off, int64_t
     return (int)lo;
 }
 
-// where sequence q's coordinates go in the output (and, by the group's first lane, its own header): LINESTRING: a row;
-// POLYGON / MULTILINESTRING / MULTIPOLYGON: a ring / member line.  nullptr for a null row.
-__device__ __forceinline__ uint8_t* wkb_seq_dst(const DevGeo& a, const int32_t* __restrict__ off, uint8_t* __restrict__ out, int64_t q,
-                                                bool write_header, int& c0, int& c1) {
-    if (a.type == GPK_GEOM_LINESTRING) {
-        c0 = a.geom_off[q];
-        c1 = a.geom_off[q + 1];
-        if (!dev::valid_row(a.validity, q)) return nullptr;
-        return out + off[q] + 9;
-    }
-    const int r = (int)q;
-    c0 = a.ring_off[r];
-    c1 = a.ring_off[r + 1];
-    if (a.type == GPK_GEOM_MULTIPOLYGON) {
-        const int part = owner_of(a.part_off, a.n_parts, r);
-        const int g = owner_of(a.geom_off, a.n_geoms, part);
-        if (!dev::valid_row(a.validity, g)) return nullptr;
-        const int p0 = a.geom_off[g], rbase = a.part_off[p0];
-        uint8_t* rh = out + off[g] + 9 + 9 * (int64_t)(part - p0 + 1) + 4 * (int64_t)(r - rbase) + 16 * (int64_t)(c0 - a.ring_off[rbase]);
-        if (write_header) put_u32(rh, (uint32_t)(c1 - c0));
-        return rh + 4;
-    }
-    const int g = owner_of(a.geom_off, a.n_geoms, r);
-    if (!dev::valid_row(a.validity, g)) return nullptr;
-    const int r0 = a.geom_off[g];
-    const bool poly = a.type == GPK_GEOM_POLYGON;
-    uint8_t* rh = out + off[g] + 9 + (poly ? 4 : 9) * (int64_t)(r - r0) + 16 * (int64_t)(c0 - a.ring_off[r0]);
-    if (write_header) {
-        if (poly)
-            put_u32(rh, (uint32_t)(c1 - c0));
-        else
-            put_header(rh, 2u, (uint32_t)(c1 - c0));
-    }
-    return rh + (poly ? 4 : 9);
-}
-
-// bodies: WKB_GS lanes per sequence; sequences longer than WKB_ENC_LONG are listed for wkb_bodies_long_kernel, which
-// spreads each of them over the whole grid (a 100k-vertex ring would otherwise be 8 lanes' job)
+// bodies: WKB_GS lanes per sequence (a ring / member line, or the row of a LINESTRING column) copy its coordinates to
+// out + seq_dst[q]; sequences longer than WKB_ENC_LONG are listed for wkb_bodies_long_kernel, which spreads each of them
+// over the whole grid (a 100k-vertex ring would otherwise be 8 lanes' job)
 constexpr int WKB_ENC_LONG = 4096;
-__global__ __launch_bounds__(256) void wkb_bodies_kernel(DevGeo a, const int32_t* __restrict__ off, uint8_t* __restrict__ out,
+__global__ __launch_bounds__(256) void wkb_bodies_kernel(DevGeo a, const int32_t* __restrict__ seq_dst, uint8_t* __restrict__ out,
                                                           int32_t* __restrict__ long_list) {
     const int lane = threadIdx.x & (WKB_GS - 1);
     const int64_t q = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / WKB_GS;
-    const int64_t n_seq = a.type == GPK_GEOM_LINESTRING ? a.n_geoms : a.n_rings;
+    const bool rows = a.type == GPK_GEOM_LINESTRING;
+    const int64_t n_seq = rows ? a.n_geoms : a.n_rings;
     if (q >= n_seq) return;
-    int c0, c1;
-    uint8_t* p = wkb_seq_dst(a, off, out, q, lane == 0, c0, c1);
-    if (!p) return;
+    const int32_t dst = seq_dst[q];
+    if (dst < 0) return;
+    const int32_t* so = rows ? a.geom_off : a.ring_off;
+    const int c0 = so[q], c1 = so[q + 1];
     if (c1 - c0 > WKB_ENC_LONG) {
         if (lane == 0) long_list[1 + atomicAdd(&long_list[0], 1)] = (int32_t)q;
         return;
     }
+    uint8_t* p = out + dst;
     for (int i = c0 + lane; i < c1; i += WKB_GS) put_xy(p + 16 * (int64_t)(i - c0), a.xy[i]);
 }
-__global__ __launch_bounds__(256) void wkb_bodies_long_kernel(DevGeo a, const int32_t* __restrict__ off, uint8_t* __restrict__ out,
+__global__ __launch_bounds__(256) void wkb_bodies_long_kernel(DevGeo a, const int32_t* __restrict__ seq_dst, uint8_t* __restrict__ out,
                                                                const int32_t* __restrict__ long_list) {
     const int n_long = long_list[0];
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    const int32_t* so = a.type == GPK_GEOM_LINESTRING ? a.geom_off : a.ring_off;
     for (int k = 0; k < n_long; ++k) {
-        int c0, c1;
-        uint8_t* p = wkb_seq_dst(a, off, out, long_list[1 + k], false, c0, c1);  // the header was written by wkb_bodies_kernel
+        const int q = long_list[1 + k];
+        const int c0 = so[q], c1 = so[q + 1];
+        uint8_t* p = out + seq_dst[q];
         for (int64_t i = c0 + tid; i < c1; i += stride) put_xy(p + 16 * (i - c0), a.xy[i]);
     }
 }
@@ -191,7 +205,7 @@ extern "C" int32_t gpk_geoarray_to_wkb(const gpk_geoarray* a, int32_t* out_offse
     const int64_t nb = (n + 255) / 256;
     const int64_t n_seq_enc = d.type == GPK_GEOM_LINESTRING ? n : d.n_rings;
     size_t need = 2 * align256(sizeof(int32_t) * (size_t)(n + 1)) + align256(sizeof(unsigned long long) * (size_t)(nb + 2)) +
-                  align256(sizeof(int32_t) * (size_t)(n_seq_enc + 2)) + 1024;
+                  2 * align256(sizeof(int32_t) * (size_t)(n_seq_enc + 2)) + 1024;
     if (host_out && out_values) need += align256((size_t)capacity);
     GPK_TRY(workspace().begin(need));
     int32_t* sizes = (int32_t*)workspace().take(sizeof(int32_t) * (size_t)(n + 1));
@@ -199,6 +213,7 @@ extern "C" int32_t gpk_geoarray_to_wkb(const gpk_geoarray* a, int32_t* out_offse
     unsigned long long* btot = (unsigned long long*)workspace().take(sizeof(unsigned long long) * (size_t)(nb + 2));
     uint8_t* val_dev = out_values ? (host_out ? (uint8_t*)workspace().take((size_t)capacity) : out_values) : nullptr;
     int32_t* long_list = (int32_t*)workspace().take(sizeof(int32_t) * (size_t)(n_seq_enc + 2));
+    int32_t* seq_dst = (int32_t*)workspace().take(sizeof(int32_t) * (size_t)(n_seq_enc + 2));
 
     int32_t total = 0;
     if (n > 0) {
@@ -215,7 +230,7 @@ extern "C" int32_t gpk_geoarray_to_wkb(const gpk_geoarray* a, int32_t* out_offse
     if ((int64_t)total > capacity)
         return fail(GPK_ERR_CAPACITY, "to_wkb: %lld bytes but capacity %lld", (long long)total, (long long)capacity);
     if (n > 0 && total > 0) {
-        GPK_LAUNCH("gpk_wkb_headers", wkb_headers_kernel, dim3((unsigned)nb), dim3(256), 0, s, d, (const int32_t*)off_dev, val_dev);
+        GPK_LAUNCH("gpk_wkb_headers", wkb_headers_kernel, dim3((unsigned)nb), dim3(256), 0, s, d, (const int32_t*)off_dev, val_dev, seq_dst);
         if (d.type == GPK_GEOM_MULTIPOINT) {
             if (d.n_coords > 0)
                 GPK_LAUNCH("gpk_wkb_multipoint", wkb_multipoint_kernel, dim3((unsigned)((d.n_coords + 255) / 256)), dim3(256), 0, s, d,
@@ -225,9 +240,9 @@ extern "C" int32_t gpk_geoarray_to_wkb(const gpk_geoarray* a, int32_t* out_offse
             if (n_seq > 0) {
                 GPK_HIP(hipMemsetAsync(long_list, 0, sizeof(int32_t), s));
                 GPK_LAUNCH("gpk_wkb_bodies", wkb_bodies_kernel, dim3((unsigned)((n_seq * WKB_GS + 255) / 256)), dim3(256), 0, s, d,
-                           (const int32_t*)off_dev, val_dev, long_list);
+                           (const int32_t*)seq_dst, val_dev, long_list);
                 GPK_LAUNCH("gpk_wkb_bodies_long", wkb_bodies_long_kernel, dim3((unsigned)(cu_count() * 8)), dim3(256), 0, s, d,
-                           (const int32_t*)off_dev, val_dev, (const int32_t*)long_list);
+                           (const int32_t*)seq_dst, val_dev, (const int32_t*)long_list);
             }
         }
     }
