@@ -105,6 +105,8 @@ __global__ void cell_sort_kernel(const int32_t* __restrict__ cell_off, int64_t n
 #ifndef GPK_PIP_PPT
 #define GPK_PIP_PPT 2
 #endif
+// GPK_ABLATE (tuning builds only, tools/pmc_ablate.sh): 1 = no exact phase, 2 = every cell empty, 3 = level-1 interiors only,
+// 5 = level-2 labels without queue pushes.  0 in the shipped library.
 #ifndef GPK_ABLATE
 #define GPK_ABLATE 0
 #endif
@@ -193,11 +195,7 @@ struct QEntry {  // 32 bytes: one queued (point, part) pair with its exterior sl
 #ifndef GPK_PIP_NT
 #define GPK_PIP_NT 2  // bit 0: non-temporal point loads (measured slower), bit 1: non-temporal result stores
 #endif
-#if GPK_ABLATE == 6  // tuning builds only: level-1 interiors only, no barriers in the queue rounds
-#define PIP_SYNC() (void)0
-#else
 #define PIP_SYNC() __syncthreads()
-#endif
 template <bool RASTER>
 __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(DevGeo pts, DevGeo polys, IndexView ix, PipView pv,
                                                               uint32_t* __restrict__ counts,
@@ -211,10 +209,6 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
     __shared__ uint32_t q_n, ovf_n;
     __shared__ uint2 s_ovf[RASTER ? PIP_OVF : 1];  // (point slot, part) hits beyond a point's PIP_KHIT inline slots
     __shared__ unsigned long long s_tot;  // hits of the tile
-#ifdef GPK_PIP_PAD_LDS
-    __shared__ uint32_t s_pad[GPK_PIP_PAD_LDS / 4];  // tuning builds: lower the occupancy
-    if (blockIdx.x == 0x7FFFFFFFu) s_pad[threadIdx.x] = 1, s_tot = s_pad[3];
-#endif
     const int tid = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.x * PIP_TILE;
     const int64_t n = pts.n_geoms;
@@ -253,8 +247,7 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
             fy[k] = (uint32_t)dev::cell_of(p[k].y, pv.ry0, pv.inv_fh * S, pv.R * S);
             word[k] = (p[k].x == p[k].x && p[k].y == p[k].y) ? pv.cell[(fy[k] / S) * (uint32_t)pv.R + (sx[k] / S)] : 0u;
             if (GPK_ABLATE == 2) word[k] = 0u;  // tuning builds only
-            if (GPK_ABLATE == 4) word[k] = word[k] == 0x12345678u ? word[k] : 0u;  // keep loads + gather, drop the rest
-            if (GPK_ABLATE == 3 || GPK_ABLATE == 6) word[k] = (word[k] >> 30) == CELL_TAG_SINGLE && !(word[k] & 1u) ? word[k] : 0u;
+            if (GPK_ABLATE == 3) word[k] = (word[k] >> 30) == CELL_TAG_SINGLE && !(word[k] & 1u) ? word[k] : 0u;
         }
         // stage C: decided cells; level-2 record gather (32 B) or PartInfo gather for inline boundary entries
         SubCell sc[PIP_PPT];

@@ -252,9 +252,6 @@ __device__ inline bool polygon_intersects_polygon_group(const DevGeo& a, int ar0
     };
     // every segment of list_a[0..ma) against every segment of list_b[0..mb): lane k owns entries k, k + G, ... of A
     auto cross = [&](int ma, int mb) -> bool {
-#if defined(GPK_PP_ABLATE) && GPK_PP_ABLATE == 1
-        return false;
-#endif
         lds_sync();
         bool hit = false;
         for (int i0 = 0; i0 < ma && !hit; i0 += G) {
@@ -296,9 +293,6 @@ __device__ inline bool polygon_intersects_polygon_group(const DevGeo& a, int ar0
         return ma > 0 && cross(ma, mb);
     };
 
-#if defined(GPK_PP_ABLATE) && GPK_PP_ABLATE == 4
-    return ea.x > fb.z * 3.0;  // bboxes only
-#endif
     int mb = 0;  // entries in list_b (uniform within the group)
     for (int j0 = b_c0; j0 < b_c1; j0 += G) {
         append_round(b, br0, br1, b_c1, j0 + lane, fa, list_b, mb);
@@ -309,12 +303,6 @@ __device__ inline bool polygon_intersects_polygon_group(const DevGeo& a, int ar0
     }
     if (mb > 0 && against_a(mb)) return true;
 
-#if defined(GPK_PP_ABLATE) && GPK_PP_ABLATE == 2
-    return false;
-#endif
-#if defined(GPK_PP_ABLATE) && GPK_PP_ABLATE == 3
-    return mb > 1000;
-#endif
     // containment: one vertex per ring of B against A, then A's exterior against B
     for (int rb = br0; rb < br1; ++rb) {
         const int c = b.ring_off[rb];
