@@ -53,12 +53,24 @@ struct SubCell {  // level-2 record of a raster cell crossed by edges of exactly
     uint32_t e0, e1, e2;  // exterior-ring slab of the cell's lower slab row = [e0, e1), upper = [e1, e2)
     uint32_t labels[4];   // 8 x 8 sub-cells, 2 bits each (x fastest): 0 outside, 1 strictly inside, 2 test exactly
 };
+// level-2 record of a raster cell crossed by exactly TWO parts (and holding nothing else): the shared borders of a
+// tessellation — administrative boundaries, census tracts — where every boundary cell is of this kind.
+// 64 bytes; the first 32 are laid out like SubCell for slot A, so a kernel loads it the same way.
+//   labels: 0 in neither, 1 strictly inside A, 2 strictly inside B, 3 test both exactly
+struct SubCell2 {
+    SubCell a;              // slot A: part_flags, its slab ranges, the labels
+    uint32_t b_part_flags;  // part B | (B has holes) << 31
+    uint32_t b_e0, b_e1, b_e2;
+    uint32_t pad[4];
+};
+constexpr uint32_t SUB2_BIT = 1u << 29;         // in a CELL_TAG_SUB payload: the index refers to PipView::sub2
 struct PipView {
     int32_t R;  // 0 = accelerator not built (degenerate extent): kernels use the generic walk
     double rx0, ry0, fw, fh, inv_fw, inv_fh;
     const uint32_t* cell;
     const uint32_t* list;
     const SubCell* sub;              // level-2 records (cell tag 3)
+    const SubCell2* sub2;            // two-part level-2 records (cell tag 3, payload & SUB2_BIT)
     const uint32_t* part_geom;       // nullptr for POLYGON arrays (part == geometry)
     const PartInfo* part_info;       // n_parts
     const int32_t* ring_row0;

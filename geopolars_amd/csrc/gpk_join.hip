@@ -196,7 +196,8 @@ struct QEntry {  // 32 bytes: one queued (point, part) pair with its exterior sl
 #define GPK_PIP_NT 2  // bit 0: non-temporal point loads (measured slower), bit 1: non-temporal result stores
 #endif
 #define PIP_SYNC() __syncthreads()
-template <bool RASTER>
+// SUB2: the index holds two-part level-2 records (PipView::sub2); the variant without them stays as lean as it was
+template <bool RASTER, bool SUB2>
 __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(DevGeo pts, DevGeo polys, IndexView ix, PipView pv,
                                                               uint32_t* __restrict__ counts,
                                                               uint32_t* __restrict__ code,
@@ -251,13 +252,21 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
         }
         // stage C: decided cells; level-2 record gather (32 B) or PartInfo gather for inline boundary entries
         SubCell sc[PIP_PPT];
-        bool has_sub[PIP_PPT];
+        uint4 scb[PIP_PPT];  // second part of a two-part record (SubCell2): b_part_flags, b_e0, b_e1, b_e2
+        bool has_sub[PIP_PPT], has_sub2[PIP_PPT], want_b[PIP_PPT];
 #pragma unroll
         for (int k = 0; k < PIP_PPT; ++k) {
             const uint32_t tag = word[k] >> 30, payload = word[k] & 0x3FFFFFFFu;
             want[k] = false;
+            want_b[k] = false;
             has_sub[k] = tag == CELL_TAG_SUB;
-            if (has_sub[k]) {
+            has_sub2[k] = SUB2 && has_sub[k] && (payload & SUB2_BIT);
+            scb[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (has_sub2[k]) {
+                const SubCell2* __restrict__ r2 = pv.sub2 + (payload & (SUB2_BIT - 1u));
+                sc[k] = r2->a;
+                scb[k] = *reinterpret_cast<const uint4*>(&r2->b_part_flags);
+            } else if (has_sub[k]) {
                 sc[k] = pv.sub[payload];
             } else if (tag == CELL_TAG_SINGLE) {
                 if (payload & 1u) {
@@ -283,16 +292,32 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
                 const uint32_t lw = wsel == 0 ? sc[k].labels[0] : (wsel == 1 ? sc[k].labels[1] : (wsel == 2 ? sc[k].labels[2] : sc[k].labels[3]));
                 const uint32_t lab = (lw >> (2 * (idx & 15))) & 3u;
                 qpart[k] = sc[k].part_flags & 0x7FFFFFFFu;
-                if (lab == 1u) {
+                if (!SUB2 || !has_sub2[k]) {
+                    if (lab == 1u) {
+                        const int li = k * PIP_BLOCK + tid;
+                        s_cnt[li] = 1;
+                        s_hit[li * PIP_KHIT] = qpart[k];
+                    } else if (lab == 2u && GPK_ABLATE != 5) {
+                        want[k] = true;
+                        const bool upper = ((fy[k] / SLAB_DIV) & 1) != 0;
+                        e0[k] = (int)(upper ? sc[k].e1 : sc[k].e0);
+                        e1[k] = (int)(upper ? sc[k].e2 : sc[k].e1);
+                        qflag[k] = sc[k].part_flags & 0x80000000u;
+                    }
+                } else {  // two parts share the cell (gpk_index.h: SubCell2)
                     const int li = k * PIP_BLOCK + tid;
-                    s_cnt[li] = 1;
-                    s_hit[li * PIP_KHIT] = qpart[k];
-                } else if (lab == 2u && GPK_ABLATE != 5) {
-                    want[k] = true;
-                    const bool upper = ((fy[k] / SLAB_DIV) & 1) != 0;
-                    e0[k] = (int)(upper ? sc[k].e1 : sc[k].e0);
-                    e1[k] = (int)(upper ? sc[k].e2 : sc[k].e1);
-                    qflag[k] = sc[k].part_flags & 0x80000000u;
+                    want_b[k] = lab == 3u;
+                    if (lab == 1u || lab == 2u) {
+                        s_cnt[li] = 1;
+                        s_hit[li * PIP_KHIT] = lab == 1u ? qpart[k] : (scb[k].x & 0x7FFFFFFFu);
+                    }
+                    if (lab == 3u) {
+                        want[k] = true;
+                        const bool upper = ((fy[k] / SLAB_DIV) & 1) != 0;
+                        e0[k] = (int)(upper ? sc[k].e1 : sc[k].e0);
+                        e1[k] = (int)(upper ? sc[k].e2 : sc[k].e1);
+                        qflag[k] = sc[k].part_flags & 0x80000000u;
+                    }
                 }
             } else if (want[k]) {
                 const int j = (fy[k] / SLAB_DIV) - pi[k].row0;
@@ -338,7 +363,19 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
                     }
                 }
             }
-            // cells where several parts meet (shared borders, overlaps): per-lane walk of the entry list
+            if (SUB2 && want_b[k]) {  // second part of a two-part cell: rare enough for one LDS atomic per lane
+                const bool upper = ((fy[k] / SLAB_DIV) & 1) != 0;
+                const uint32_t b0 = upper ? scb[k].z : scb[k].y, b1 = upper ? scb[k].w : scb[k].z;
+                const uint32_t bpart = scb[k].x & 0x7FFFFFFFu;
+                if (b1 > b0) {
+                    const uint32_t slot = atomicAdd(&q_n, 1u);
+                    if (slot < (uint32_t)PIP_QCAP)
+                        q[slot] = QEntry{p[k].x, p[k].y, bpart, b0, b1 - b0, (uint32_t)li | (scb[k].x & 0x80000000u)};
+                    else if (pip::part_pos_single(pv, polys, (int)bpart, p[k].x, p[k].y) == dev::POS_INSIDE)
+                        record(li, bpart);
+                }
+            }
+            // cells where several parts meet (three or more, or two that both cover it): per-lane walk of the entry list
             if ((word[k] >> 30) == CELL_TAG_LIST) {
                 const uint32_t off = word[k] & 0x3FFFFFFFu;
                 const uint32_t m = pv.list[off];
@@ -858,10 +895,14 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         if (me != hipSuccess) return fail(GPK_ERR_DEVICE, "spatial_join: %s", hipGetErrorString(me));
     }
     if (right_index->pip.R > 0)
-        J_LAUNCH("gpk_pip_tile", pip_tile_kernel<true>, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
-                 right_index->v, right_index->pip, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top);
+        if (right_index->pip.sub2)
+            J_LAUNCH("gpk_pip_tile", (pip_tile_kernel<true, true>), dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
+                     right_index->v, right_index->pip, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top);
+        else
+            J_LAUNCH("gpk_pip_tile", (pip_tile_kernel<true, false>), dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
+                     right_index->v, right_index->pip, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top);
     else
-        J_LAUNCH("gpk_pip_tile_generic", pip_tile_kernel<false>, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
+        J_LAUNCH("gpk_pip_tile_generic", (pip_tile_kernel<false, false>), dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
                  right_index->v, right_index->pip, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top);
     // the writer also produces the grand total; in count-only mode it runs without a pair buffer
     J_LAUNCH("gpk_pip_write", pip_write_kernel, dim3((unsigned)n_wblocks), dim3(WR_BLOCK), 0, s, left->d, right->d, right_index->v,

@@ -15,6 +15,8 @@
 //   * an unmarked cell is connected and meets no edge of q, so the exact position of its centre with
 //     respect to q (holes included) is the position of every point that maps to the cell;
 //   * border cells (where out-of-extent points are clamped) never get an "inside" label.
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -280,34 +282,55 @@ __global__ void cell_build_kernel(DevGeo a, IndexView ix, PipView pv, FineGrid g
 }
 
 // ---- level 2: cells crossed by exactly one part -----------------------------------------------------
-__global__ void sub_flag_kernel(const uint32_t* __restrict__ cell, int64_t n_cells, int32_t* __restrict__ flag) {
+// flag[c] = 1: the cell is crossed by exactly one part and nothing else is there (SubCell); flag2[c] = 1: the cell
+// holds exactly two parts and both cross it (SubCell2).  (A covering part + a crossing one was tried as a second record
+// kind: no gain on the power-law multipolygon column, 12 ms more build time.)
+__global__ void sub_flag_kernel(const uint32_t* __restrict__ cell, const uint32_t* __restrict__ list, int64_t n_cells,
+                                int32_t* __restrict__ flag, int32_t* __restrict__ flag2) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_cells) return;
     const uint32_t w = cell[c];
-    flag[c] = ((w >> 30) == CELL_TAG_SINGLE && (w & 1u)) ? 1 : 0;
+    const uint32_t tag = w >> 30;
+    flag[c] = (tag == CELL_TAG_SINGLE && (w & 1u)) ? 1 : 0;
+    int f2 = 0;
+    if (tag == CELL_TAG_LIST) {
+        const uint32_t off = w & 0x3FFFFFFFu;
+        if (list[off] == 2u) f2 = (list[off + 1] & list[off + 2] & 1u) ? 1 : 0;  // two entries, both crossing the cell
+    }
+    flag2[c] = f2;
 }
 
 // PIP_SUB^2 lanes per flagged cell: lane k labels sub-cell (k % PIP_SUB, k / PIP_SUB).  A sub-cell is "test
-// exactly" when any edge of ANY ring of the part (taken from the rings' slabs of this raster row) is not strictly
-// on one side of the sub-cell's padded rectangle; otherwise it inherits the exact position of its centre.
+// exactly" when any edge of ANY ring of a part that crosses the cell (taken from the rings' slabs of this raster row)
+// is not strictly on one side of the sub-cell's padded rectangle; otherwise it inherits the exact position of its
+// centre.  NP = 1: SubCell records (one crossing part); NP = 2: SubCell2 records (two parts, see gpk_index.h).
 constexpr int SUB_EDGE_CAP = 48;  // edges of a cell's slab rows kept in LDS per wave (sub_build_kernel)
+template <int NP>
 __global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, FineGrid g, const int32_t* __restrict__ flag,
-                                 const int32_t* __restrict__ pos, int64_t n_cells, const uint32_t* __restrict__ cell,
-                                 SubCell* __restrict__ sub) {
+                                                        const int32_t* __restrict__ pos, int64_t n_cells, const uint32_t* __restrict__ cell,
+                                                        const uint32_t* __restrict__ list, SubCell* __restrict__ sub,
+                                                        SubCell2* __restrict__ sub2) {
     constexpr int S = PIP_SUB, SS = PIP_SUB * PIP_SUB;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t c = t / SS;
     const int k = (int)(t % SS);
     if (c >= n_cells || !flag[c]) return;
     const uint32_t w = cell[c];  // still the level-1 word: sub_commit_kernel rewrites it afterwards
-    const int part = (int)((w & 0x3FFFFFFFu) >> 1);
+    int part[2] = {0, 0};
+    bool crosses[2] = {true, true};
+    if (NP == 1) {
+        part[0] = (int)((w & 0x3FFFFFFFu) >> 1);
+    } else {
+        const uint32_t off = w & 0x3FFFFFFFu;
+        const uint32_t ea = list[off + 1], eb = list[off + 2];
+        part[0] = (int)(ea >> 1);
+        part[1] = (int)(eb >> 1);
+    }
     const int ci = (int)(c % g.R), cj = (int)(c / g.R);
     const int si = S * ci + (k % S), sj = S * cj + (k / S);
     const double fw2 = g.fw / S, fh2 = g.fh / S, px2 = g.pad_x / S, py2 = g.pad_y / S;
     const double xl = g.rx0 + (double)si * fw2 - px2, xh = g.rx0 + (double)(si + 1) * fw2 + px2;
     const double yl = g.ry0 + (double)sj * fh2 - py2, yh = g.ry0 + (double)(sj + 1) * fh2 + py2;
-    int r0, r1;
-    dev::part_rings(a, part, r0, r1);
     // The 64 lanes of a wave label the 64 sub-cells of ONE cell, so they share its slab rows.  First the wave picks the
     // edges whose box meets the (padded) cell at all — lane j looks at edge j, survivors are compacted by ballot into an
     // LDS list — then every lane tests only those few against its own sub-cell (a slab row holds every edge of the ring
@@ -319,28 +342,33 @@ __global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, Fi
     const double cyl = g.ry0 + (double)(S * cj) * fh2 - py2, cyh = g.ry0 + (double)(S * cj + S) * fh2 + py2;
     int n_list = 0;         // wave-uniform
     bool list_ok = true;    // false: more than SUB_EDGE_CAP edges meet the cell -> every lane walks the slabs itself
-    for (int r = r0; r < r1 && list_ok; ++r)
-        for (int h = 0; h < PIP_SLAB_MUL && list_ok; ++h) {
-            int e0, e1;
-            if (!pip::slab_range(pv, r, PIP_SLAB_MUL * cj + h, e0, e1)) continue;
-            for (int eb = e0; eb < e1 && list_ok; eb += 64) {
-                const int e = eb + lane64;
-                bool keep = false;
-                double4 ed = make_double4(0, 0, 0, 0);
-                if (e < e1) {
-                    ed = pv.slab_edges[e];
-                    keep = !(fmax(ed.x, ed.z) < cxl || fmin(ed.x, ed.z) > cxh || fmax(ed.y, ed.w) < cyl || fmin(ed.y, ed.w) > cyh);
+    for (int q = 0; q < NP && list_ok; ++q) {
+        if (!crosses[q]) continue;
+        int r0, r1;
+        dev::part_rings(a, part[q], r0, r1);
+        for (int r = r0; r < r1 && list_ok; ++r)
+            for (int h = 0; h < PIP_SLAB_MUL && list_ok; ++h) {
+                int e0, e1;
+                if (!pip::slab_range(pv, r, PIP_SLAB_MUL * cj + h, e0, e1)) continue;
+                for (int eb = e0; eb < e1 && list_ok; eb += 64) {
+                    const int e = eb + lane64;
+                    bool keep = false;
+                    double4 ed = make_double4(0, 0, 0, 0);
+                    if (e < e1) {
+                        ed = pv.slab_edges[e];
+                        keep = !(fmax(ed.x, ed.z) < cxl || fmin(ed.x, ed.z) > cxh || fmax(ed.y, ed.w) < cyl || fmin(ed.y, ed.w) > cyh);
+                    }
+                    const unsigned long long m = __ballot(keep);
+                    const int add = __popcll(m);
+                    if (n_list + add > SUB_EDGE_CAP) {
+                        list_ok = false;
+                        break;
+                    }
+                    if (keep) s_edges[wave][n_list + __popcll(m & ((1ull << lane64) - 1ull))] = ed;
+                    n_list += add;
                 }
-                const unsigned long long m = __ballot(keep);
-                const int add = __popcll(m);
-                if (n_list + add > SUB_EDGE_CAP) {
-                    list_ok = false;
-                    break;
-                }
-                if (keep) s_edges[wave][n_list + __popcll(m & ((1ull << lane64) - 1ull))] = ed;
-                n_list += add;
             }
-        }
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -359,30 +387,45 @@ __global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, Fi
     if (list_ok) {
         for (int e = 0; e < n_list && !touched; ++e) touched = edge_touches(s_edges[wave][e]);
     } else {
-        for (int r = r0; r < r1 && !touched; ++r)
-            for (int h = 0; h < PIP_SLAB_MUL && !touched; ++h) {
-                int e0, e1;
-                if (!pip::slab_range(pv, r, PIP_SLAB_MUL * cj + h, e0, e1)) continue;
-                for (int e = e0; e < e1 && !touched; ++e) touched = edge_touches(pv.slab_edges[e]);
-            }
+        for (int q = 0; q < NP && !touched; ++q) {
+            if (!crosses[q]) continue;
+            int r0, r1;
+            dev::part_rings(a, part[q], r0, r1);
+            for (int r = r0; r < r1 && !touched; ++r)
+                for (int h = 0; h < PIP_SLAB_MUL && !touched; ++h) {
+                    int e0, e1;
+                    if (!pip::slab_range(pv, r, PIP_SLAB_MUL * cj + h, e0, e1)) continue;
+                    for (int e = e0; e < e1 && !touched; ++e) touched = edge_touches(pv.slab_edges[e]);
+                }
+        }
     }
-    uint32_t label = 2u;
+    const uint32_t test_label = NP == 2 ? 3u : 2u;
+    uint32_t label = test_label;
     if (!touched) {
         const double cx = g.rx0 + ((double)si + 0.5) * fw2, cy = g.ry0 + ((double)sj + 0.5) * fh2;
         // the centre must map to this very sub-cell under the point-side function (S x the level-1 scale)
         const bool ok = dev::cell_of(cx, g.rx0, g.inv_fw * S, g.R * S) == si && dev::cell_of(cy, g.ry0, g.inv_fh * S, g.R * S) == sj;
         if (ok) {
-            const int p = pip::part_pos_single(pv, a, part, cx, cy);
-            label = p == dev::POS_INSIDE ? 1u : (p == dev::POS_OUTSIDE ? 0u : 2u);
+            if (NP == 1) {
+                const int p = pip::part_pos_single(pv, a, part[0], cx, cy);
+                label = p == dev::POS_INSIDE ? 1u : (p == dev::POS_OUTSIDE ? 0u : 2u);
+            } else {
+                const int pa = pip::part_pos_single(pv, a, part[0], cx, cy), pb = pip::part_pos_single(pv, a, part[1], cx, cy);
+                if (pa == dev::POS_BOUNDARY || pb == dev::POS_BOUNDARY)
+                    label = 3u;
+                else if (pa == dev::POS_INSIDE && pb == dev::POS_INSIDE)
+                    label = 3u;  // untouched by either boundary yet inside both: overlapping parts, leave it to the exact test
+                else
+                    label = pa == dev::POS_INSIDE ? 1u : (pb == dev::POS_INSIDE ? 2u : 0u);
+            }
         }
     }
-    SubCell* rec = sub + pos[c];
-    if (k == 0) {
-        const PartInfo pi = pv.part_info[part];
-        // exterior slabs of the cell's PIP_SLAB_MUL (= 2) slab rows are adjacent in slab_off: [e0,e1) and [e1,e2)
+    // exterior slabs of the cell's PIP_SLAB_MUL (= 2) slab rows are adjacent in slab_off: [e0,e1) and [e1,e2)
+    auto slabs_of = [&](int p, uint32_t& flags, uint32_t& e0, uint32_t& e1, uint32_t& e2) {
+        const PartInfo pi = pv.part_info[p];
         const int j0 = PIP_SLAB_MUL * cj - pi.row0, j1 = j0 + 1;
         const bool lo_ok = j0 >= 0 && j0 < pi.nrows, hi_ok = j1 >= 0 && j1 < pi.nrows;
-        uint32_t e0 = 0, e1 = 0, e2 = 0;
+        e0 = e1 = e2 = 0;
         if (lo_ok) {
             e0 = (uint32_t)pv.slab_off[pi.slab_base + j0];
             e1 = (uint32_t)pv.slab_off[pi.slab_base + j0 + 1];
@@ -392,18 +435,26 @@ __global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, Fi
             if (!lo_ok) e0 = e1 = (uint32_t)pv.slab_off[pi.slab_base + j1];
             e2 = (uint32_t)pv.slab_off[pi.slab_base + j1 + 1];
         }
-        rec->part_flags = (uint32_t)part | (pi.n_rings > 1 ? 0x80000000u : 0u);
-        rec->e0 = e0;
-        rec->e1 = e1;
-        rec->e2 = e2;
+        flags = (uint32_t)p | (pi.n_rings > 1 ? 0x80000000u : 0u);
+    };
+    SubCell* rec = NP == 1 ? sub + pos[c] : &sub2[pos[c]].a;
+    if (k == 0) {
+        slabs_of(part[0], rec->part_flags, rec->e0, rec->e1, rec->e2);
+        if (NP == 2) {
+            SubCell2* r2 = sub2 + pos[c];
+            slabs_of(part[1], r2->b_part_flags, r2->b_e0, r2->b_e1, r2->b_e2);
+        }
     }
     atomicOr(&rec->labels[k >> 4], label << (2 * (k & 15)));
 }
-__global__ void sub_commit_kernel(const int32_t* __restrict__ flag, const int32_t* __restrict__ pos, int64_t n_cells,
-                                  uint32_t* __restrict__ cell) {
+__global__ void sub_commit_kernel(const int32_t* __restrict__ flag, const int32_t* __restrict__ pos, const int32_t* __restrict__ flag2,
+                                  const int32_t* __restrict__ pos2, int64_t n_cells, uint32_t* __restrict__ cell) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_cells || !flag[c]) return;
-    cell[c] = (CELL_TAG_SUB << 30) | (uint32_t)pos[c];
+    if (c >= n_cells) return;
+    if (flag[c])
+        cell[c] = (CELL_TAG_SUB << 30) | (uint32_t)pos[c];
+    else if (flag2 && flag2[c])
+        cell[c] = (CELL_TAG_SUB << 30) | SUB2_BIT | (uint32_t)pos2[c];
 }
 
 }  // namespace gpk
@@ -617,29 +668,52 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
     pv.list = list;
 
     // ---- level 2 ------------------------------------------------------------------------------------
-    int32_t n_sub = 0;
+    int32_t n_sub = 0, n_sub2 = 0;
     SubCell* sub = nullptr;
+    SubCell2* sub2 = nullptr;
     static_assert(PIP_SLAB_MUL == 2, "SubCell stores exactly two adjacent slab ranges");
     if (g.pad_x / PIP_SUB > ulp64 && g.pad_y / PIP_SUB > ulp64 && R * PIP_SUB <= 32768) {
-        int32_t *sflag, *spos;
+        int32_t *sflag, *spos, *sflag2, *spos2;
         GPK_TRY(t.alloc(&sflag, (size_t)n_cells + 1));
         GPK_TRY(t.alloc(&spos, (size_t)n_cells + 1));
-        GPK_LAUNCH("gpk_pipidx_sub_flag", sub_flag_kernel, blocks_for(n_cells), dim3(256), 0, s, cell, n_cells, sflag);
+        GPK_TRY(t.alloc(&sflag2, (size_t)n_cells + 1));
+        GPK_TRY(t.alloc(&spos2, (size_t)n_cells + 1));
+        GPK_LAUNCH("gpk_pipidx_sub_flag", sub_flag_kernel, blocks_for(n_cells), dim3(256), 0, s, cell, (const uint32_t*)list, n_cells, sflag, sflag2);
         GPK_TRY(exclusive_scan_i32(sflag, n_cells, spos, nullptr, btot, s));
+        GPK_TRY(exclusive_scan_i32(sflag2, n_cells, spos2, nullptr, btot, s));
         GPK_HIP(hipMemcpyAsync(&n_sub, spos + n_cells, sizeof n_sub, hipMemcpyDeviceToHost, s));
+        GPK_HIP(hipMemcpyAsync(&n_sub2, spos2 + n_cells, sizeof n_sub2, hipMemcpyDeviceToHost, s));
         GPK_HIP(hipStreamSynchronize(s));
+        if ((unsigned)n_sub >= SUB2_BIT || (unsigned)n_sub2 >= SUB2_BIT) n_sub = n_sub2 = 0;  // would not fit the cell word: no level 2
+        // two-part records make the join kernel carry a second part per point and cost a second labelling pass: they pay off
+        // when shared borders are THE boundary shape (a tessellation: 17 two-part cells per one-part cell); columns of
+        // overlapping polygons have about as many of either kind, most of their sub-cells end up "test both", and the pass
+        // only added 12 ms to a 36 ms build — those keep the entry lists
+        if (getenv("GPK_DEBUG_INDEX")) fprintf(stderr, "[gpk] level 2: %d one-part cells, %d two-part cells of %lld\n", n_sub, n_sub2, (long long)n_cells);
+        if ((int64_t)n_sub2 < 4 * (int64_t)n_sub) n_sub2 = 0;
         if (n_sub > 0) {
             GPK_HIP(hipMalloc((void**)&sub, sizeof(SubCell) * (size_t)n_sub));
             keep(sub);
             GPK_HIP(hipMemsetAsync(sub, 0, sizeof(SubCell) * (size_t)n_sub, s));
-            GPK_LAUNCH("gpk_pipidx_sub_build", sub_build_kernel, blocks_for(n_cells * PIP_SUB * PIP_SUB), dim3(256), 0, s, d, pv, g, sflag, spos,
-                       n_cells, (const uint32_t*)cell, sub);
-            GPK_LAUNCH("gpk_pipidx_sub_commit", sub_commit_kernel, blocks_for(n_cells), dim3(256), 0, s, sflag, spos, n_cells, cell);
+            GPK_LAUNCH("gpk_pipidx_sub_build", sub_build_kernel<1>, blocks_for(n_cells * PIP_SUB * PIP_SUB), dim3(256), 0, s, d, pv, g, sflag, spos,
+                       n_cells, (const uint32_t*)cell, (const uint32_t*)list, sub, (SubCell2*)nullptr);
+        }
+        if (n_sub2 > 0) {
+            GPK_HIP(hipMalloc((void**)&sub2, sizeof(SubCell2) * (size_t)n_sub2));
+            keep(sub2);
+            GPK_HIP(hipMemsetAsync(sub2, 0, sizeof(SubCell2) * (size_t)n_sub2, s));
+            GPK_LAUNCH("gpk_pipidx_sub2_build", sub_build_kernel<2>, blocks_for(n_cells * PIP_SUB * PIP_SUB), dim3(256), 0, s, d, pv, g, sflag2, spos2,
+                       n_cells, (const uint32_t*)cell, (const uint32_t*)list, (SubCell*)nullptr, sub2);
+        }
+        if (n_sub > 0 || n_sub2 > 0) {
+            GPK_LAUNCH("gpk_pipidx_sub_commit", sub_commit_kernel, blocks_for(n_cells), dim3(256), 0, s, sflag, spos, n_sub2 > 0 ? sflag2 : nullptr,
+                       spos2, n_cells, cell);
             GPK_HIP(hipStreamSynchronize(s));
         }
     }
     pv.sub = sub;
-    ix->nbytes += (int64_t)(sizeof(SubCell) * (size_t)n_sub);
+    pv.sub2 = sub2;
+    ix->nbytes += (int64_t)(sizeof(SubCell) * (size_t)n_sub + sizeof(SubCell2) * (size_t)n_sub2);
     ix->pip = pv;
     ix->nbytes += (int64_t)(sizeof(uint32_t) * (size_t)n_cells + sizeof(uint32_t) * (size_t)list_len + sizeof(double4) * (size_t)n_edges +
                             sizeof(int32_t) * (size_t)(n_slabs + 1) + sizeof(int32_t) * (size_t)(2 * n_rings + 1) +

@@ -163,3 +163,31 @@ def powerlaw_multipolygons(n: int, seed: int = SEED + 5, domain: float = DOMAIN,
         part_offsets=part_off.astype(np.int32),
         ring_offsets=ring_off.astype(np.int32),
     )
+
+
+def tessellation(g: int = 32, sub: int = 16, seed: int = SEED + 6, domain: float = DOMAIN) -> GeoArrowArray:
+    """g x g quads covering the domain whose sides are SHARED jittered polylines of `sub` segments: neighbours have every
+    boundary vertex in common, every point of the domain lies in exactly one polygon or on a shared border (administrative
+    boundaries, census tracts).  4 * sub distinct vertices per polygon."""
+    rng = np.random.default_rng(seed)
+    cell = domain / g
+    t = np.arange(1, sub) / sub
+    amp = 0.2 * cell / sub
+    # interior points of every horizontal side (row j, column i) and vertical side (row j, column i); the outer frame stays straight
+    hx = np.empty((g + 1, g, sub - 1, 2))
+    vx = np.empty((g, g + 1, sub - 1, 2))
+    hx[..., 0] = (np.arange(g)[None, :, None] + t[None, None, :]) * cell
+    hx[..., 1] = np.arange(g + 1)[:, None, None] * cell + rng.uniform(-amp, amp, (g + 1, g, sub - 1)) * ((np.arange(g + 1) > 0) & (np.arange(g + 1) < g))[:, None, None]
+    vx[..., 1] = (np.arange(g)[:, None, None] + t[None, None, :]) * cell
+    vx[..., 0] = np.arange(g + 1)[None, :, None] * cell + rng.uniform(-amp, amp, (g, g + 1, sub - 1)) * ((np.arange(g + 1) > 0) & (np.arange(g + 1) < g))[None, :, None]
+    n_v = 4 * sub + 1
+    xy = np.empty((g * g, n_v, 2))
+    for j in range(g):
+        for i in range(g):
+            ring = np.concatenate(
+                [[(i * cell, j * cell)], hx[j, i], [((i + 1) * cell, j * cell)], vx[j, i + 1], [((i + 1) * cell, (j + 1) * cell)], hx[j + 1, i][::-1],
+                 [(i * cell, (j + 1) * cell)], vx[j, i][::-1], [(i * cell, j * cell)]]
+            )
+            xy[j * g + i] = ring
+    offs = (np.arange(g * g + 1) * n_v).astype(np.int32)
+    return GeoArrowArray(GEOM_POLYGON, xy.reshape(-1, 2), geom_offsets=np.arange(g * g + 1, dtype=np.int32), ring_offsets=offs)

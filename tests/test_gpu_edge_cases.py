@@ -167,3 +167,34 @@ def test_rowwise_predicates_on_degenerate_inputs(gpk, oracle):
     m = np.isfinite(d_exp) & (d_exp < 1e300)
     assert np.allclose(d_got[m], d_exp[m], rtol=1e-9, atol=0)
     assert np.array_equal(d_got[~m], d_exp[~m], equal_nan=True)
+
+
+def test_tessellation_shared_borders_two_part_cells(gpk, oracle):
+    """polygons that share every border: all boundary cells hold two crossing parts (two-part level-2 records).  Points on
+    shared edges / vertices intersect both neighbours (or four at a corner) and are contained in none."""
+    tess = synth.tessellation(12, 8, seed=5)
+    rng = np.random.default_rng(6)
+    ro = tess.ring_offsets
+    verts = tess.xy[np.unique(rng.integers(0, tess.n_coords, 3000))]
+    mids = (tess.xy[:-1] + tess.xy[1:])[np.setdiff1d(np.arange(tess.n_coords - 1), ro[1:-1] - 1)][::5] / 2.0  # edge midpoints (exact: halves)
+    pts = GeoArrowArray.from_points(np.concatenate([synth.uniform_points(150_000, seed=7).xy, verts, mids, verts + 1e-9]))
+    for pred in ("intersects", "within"):
+        exp_pairs, exp_counts, _ = oracle.spatial_join(pts, tess, pred, mode=1)
+        got_pairs, got_counts = join_pairs(GeoSeries(pts), GeoSeries(tess), pred)
+        assert np.array_equal(got_counts, exp_counts), pred
+        assert np.array_equal(got_pairs, exp_pairs), pred
+    hist = np.bincount(exp_counts)
+    assert hist[0] > 1000 and hist[1] > 100_000  # border points are contained in no polygon, interior points in exactly one
+
+
+def test_small_polygons_inside_big_ones(gpk, oracle):
+    """cells covered by one part and crossed by another (entry lists): rows with two hits"""
+    big = [[[(x, y), (x + 250.0, y), (x + 250.0, y + 250.0), (x, y + 250.0)]] for x in (0.0, 250.0, 500.0, 750.0) for y in (0.0, 250.0, 500.0, 750.0)]
+    stars = synth.star_polygons(900, 16, seed=11)
+    small = [[stars.xy[stars.ring_offsets[r] : stars.ring_offsets[r + 1] - 1].tolist()] for r in range(len(stars))]
+    polys = GeoArrowArray.from_polygons(big + small)
+    pts = GeoArrowArray.from_points(np.concatenate([synth.uniform_points(200_000, seed=12).xy, synth.adversarial_points(stars, seed=13).xy]))
+    exp_pairs, exp_counts, _ = oracle.spatial_join(pts, polys, "intersects", mode=1)
+    got_pairs, got_counts = join_pairs(GeoSeries(pts), GeoSeries(polys), "intersects")
+    assert np.array_equal(got_counts, exp_counts) and np.array_equal(got_pairs, exp_pairs)
+    assert np.bincount(exp_counts)[2] > 10_000

@@ -15,7 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--c4", type=int, default=1_000_000)
 ap.add_argument("--c5-points", type=int, default=6_250_000)
 ap.add_argument("--c5-polys", type=int, default=1_000_000)
-ap.add_argument("--only", choices=["c4", "c5"], default=None)
+ap.add_argument("--only", choices=["c4", "c5", "tess"], default=None)
 a = ap.parse_args()
 
 def t(f):
@@ -37,6 +37,21 @@ def kernel_ms(f, names):
     L.gpk_profile_reset()
     return out
 
+# ---- tessellation: 10M points in 1024 polygons that share every border (administrative-boundary shape) -------------------
+if a.only in (None, "tess"):
+    T = synth.tessellation(32, 16); P = synth.uniform_points(10_000_000, seed=61)
+    ts, ps = GeoSeries(T), GeoSeries(P)
+    ts.device(); ps.device()
+    idx, ms_idx = t(lambda: SpatialIndex(ts))
+    kms = kernel_ms(lambda: join_pairs(ps, ts, "intersects", r_index=idx), ["gpk_pip_tile", "gpk_pip_write"])
+    (pairs, counts), ms_join = t(lambda: join_pairs(ps, ts, "intersects", r_index=idx))
+    k = 300_000
+    ep, ec, _ = O.spatial_join(slice_rows(P, 0, k), T, "intersects", mode=1)
+    ok = np.array_equal(counts[:k], ec) and np.array_equal(pairs[: len(ep)], ep)
+    print(json.dumps({"config": "tessellation", "points": len(P), "polygons": len(T), "coords": int(T.n_coords), "index_build_ms": ms_idx, "join_ms": ms_join, "kernel_ms": kms, "pairs": int(len(pairs)), "parity_prefix_rows": k, "parity": bool(ok)}), flush=True)
+    del ts, ps, idx
+    if a.only == "tess":
+        sys.exit(0)
 # ---- C4: polygon x polygon intersects join ------------------------------------------------------------
 if a.only == "c5":
     a.c4 = 1000
