@@ -12,6 +12,10 @@
 //                work-group totals (no scan kernel).
 // (A single-pass variant with decoupled look-back was measured and was slower on MI355X: the in-order
 // commit makes finished work-groups hold their LDS/wave slots while they wait — see DESIGN.md.)
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
 #include "gpk_device.h"
 #include "gpk_index.h"
 #include "gpk_pip.h"
@@ -719,6 +723,44 @@ __global__ __launch_bounds__(256) void pair_refine_kernel(DevGeo left, DevGeo ri
     }
 }
 
+// Contains<Coord> for Line / LineString / MultiLineString (geo 0.27 algorithm/contains/{line,line_string}.rs), reached from
+// the join dispatch spatial_index.rs:126-135 (`line.contains(point)` whichever side the point is on): the point lies on
+// the linestring and is not one of its two end points (unless the linestring is closed).  Exact orientation.
+__device__ inline bool line_contains_coord(double2 s, double2 e, double px, double py) {
+    if (s.x == e.x && s.y == e.y) return s.x == px && s.y == py;
+    if ((px == s.x && py == s.y) || (px == e.x && py == e.y)) return false;
+    return dev::orient2d(s.x, s.y, e.x, e.y, px, py) == 0 && dev::value_in_between(px, s.x, e.x) && dev::value_in_between(py, s.y, e.y);
+}
+__device__ inline bool linestring_contains_coord(const double2* __restrict__ xy, int n, double px, double py) {
+    if (n == 0) return false;
+    const double2 f = xy[0], l = xy[n - 1];
+    if ((px == f.x && py == f.y) || (px == l.x && py == l.y)) return f.x == l.x && f.y == l.y;
+    for (int i = 0; i + 1 < n; ++i) {
+        const double2 a = xy[i], b = xy[i + 1];
+        if (line_contains_coord(a, b, px, py)) return true;
+        if (i > 0 && px == a.x && py == a.y) return true;
+    }
+    return false;
+}
+__device__ inline bool lineal_contains_point(const DevGeo& a, int64_t g, double px, double py) {
+    if (a.type == GPK_GEOM_LINESTRING) return linestring_contains_coord(a.xy + a.geom_off[g], a.geom_off[g + 1] - a.geom_off[g], px, py);
+    for (int l = a.geom_off[g]; l < a.geom_off[g + 1]; ++l)  // MULTILINESTRING: any member
+        if (linestring_contains_coord(a.xy + a.ring_off[l], a.ring_off[l + 1] - a.ring_off[l], px, py)) return true;
+    return false;
+}
+__global__ __launch_bounds__(256) void lineal_point_refine_kernel(DevGeo left, DevGeo right, const uint32_t* __restrict__ cand_l,
+                                                                   const uint32_t* __restrict__ cand_r, int64_t n_cand,
+                                                                   uint8_t* __restrict__ hit) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cand) return;
+    const int64_t i = cand_l[c], j = cand_r[c];
+    const bool point_left = left.type == GPK_GEOM_POINT;
+    const double2 p = point_left ? left.xy[i] : right.xy[j];
+    bool h = false;
+    if (p.x == p.x && p.y == p.y) h = point_left ? lineal_contains_point(right, j, p.x, p.y) : lineal_contains_point(left, i, p.x, p.y);
+    hit[c] = h;
+}
+
 // Stage 3: per-row hit counts, then (after a scan) the (l, r) pairs in candidate order == sorted by (l, r).
 template <bool WRITE>
 __global__ __launch_bounds__(256) void pair_emit_kernel(int64_t n_rows, const int32_t* __restrict__ cand_off,
@@ -749,9 +791,10 @@ static inline dim3 grid_for(int64_t n, int block) {
 }
 
 // polygonal x polygonal: candidates (count, scan, fill) -> pair-parallel exact refine -> hits (count, scan, emit)
+enum { REFINE_POLYGONAL = 0, REFINE_LINEAL_POINT = 1 };
 static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, const gpk_index* right_index, uint32_t left_row_base,
                          uint32_t* out_counts, uint32_t* out_pairs, int64_t pair_capacity, int64_t* n_pairs, int32_t out_space,
-                         hipStream_t s) {
+                         hipStream_t s, int refine = REFINE_POLYGONAL) {
     const int64_t n = left->d.n_geoms;
     const bool host_out = out_space != GPK_MEM_DEVICE;
     const bool want_pairs = pair_capacity > 0;
@@ -811,9 +854,13 @@ static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, co
             int64_t blocks = ((int64_t)n_cand + (256 / JOIN_GS) - 1) / (256 / JOIN_GS);
             const int64_t cap = (int64_t)cu_count() * 64;
             if (blocks > cap) blocks = cap;
-            GPK_LAUNCH("gpk_pair_refine", pair_refine_kernel, dim3((unsigned)blocks), dim3(256), 0, s, left->d, right->d,
-                       (const uint32_t*)cand_l, (const uint32_t*)cand_r, (int64_t)n_cand, (const double4*)lbbox,
-                       right_index->v.bbox, hit);
+            if (refine == REFINE_LINEAL_POINT)
+                GPK_LAUNCH("gpk_lineal_point_refine", lineal_point_refine_kernel, dim3((unsigned)(((int64_t)n_cand + 255) / 256)), dim3(256), 0, s,
+                           left->d, right->d, (const uint32_t*)cand_l, (const uint32_t*)cand_r, (int64_t)n_cand, hit);
+            else
+                GPK_LAUNCH("gpk_pair_refine", pair_refine_kernel, dim3((unsigned)blocks), dim3(256), 0, s, left->d, right->d,
+                           (const uint32_t*)cand_l, (const uint32_t*)cand_r, (int64_t)n_cand, (const double4*)lbbox,
+                           right_index->v.bbox, hit);
         }
         GPK_LAUNCH("gpk_pair_count", pair_emit_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, n, (const int32_t*)cand_off,
                    (const uint32_t*)cand_r, (const uint8_t*)hit, counts, (const int32_t*)nullptr, left_row_base, (uint2*)nullptr, (int64_t)0);
@@ -913,6 +960,96 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
     *pairs_dev_out = pairs_dev;
     *grand_out = grand;
     return GPK_OK;
+}
+
+// ---- polygonal LEFT x point RIGHT (spatial_index.rs:92,96: `poly.contains(point)` whichever side the polygon is on) -----
+// The same join with the roles swapped — the polygons get the index, the points stream through pip_tile — followed
+// by a transpose: the (point, polygon) pairs come out sorted by point, the caller wants (l = polygon, r = point) sorted
+// by (l, r): a radix sort of 64-bit keys.
+__global__ __launch_bounds__(256) void swap_keys_kernel(const uint2* __restrict__ pairs, int64_t n, unsigned long long* __restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = ((unsigned long long)pairs[i].y << 32) | pairs[i].x;  // (polygon, point)
+}
+__global__ __launch_bounds__(256) void swap_emit_kernel(const unsigned long long* __restrict__ sorted, int64_t n, int64_t capacity,
+                                                         uint32_t left_base, uint2* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && i < capacity) out[i] = make_uint2(left_base + (uint32_t)(sorted[i] >> 32), (uint32_t)sorted[i]);
+}
+__global__ __launch_bounds__(256) void swap_counts_kernel(const unsigned long long* __restrict__ sorted, int64_t n, int64_t n_left,
+                                                           uint32_t* __restrict__ counts) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_left) return;
+    auto lower = [&](unsigned long long key) {
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (sorted[mid] < key)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        return lo;
+    };
+    counts[g] = (uint32_t)(lower((unsigned long long)(g + 1) << 32) - lower((unsigned long long)g << 32));
+}
+
+static int32_t swapped_pip_join(const gpk_geoarray* polys, const gpk_geoarray* pts, uint32_t left_row_base, uint32_t* out_counts,
+                                uint32_t* out_pairs, int64_t pair_capacity, int64_t* n_pairs, int32_t out_space, hipStream_t s) {
+    const int64_t n_left = polys->d.n_geoms, n_pts = pts->d.n_geoms;
+    const bool host_out = out_space != GPK_MEM_DEVICE;
+    const bool want_pairs = pair_capacity > 0;
+    *n_pairs = 0;
+    gpk_index* lix = nullptr;
+    GPK_TRY(gpk_index_build(polys, (void*)s, &lix));
+    auto done = [&](int32_t rc) {
+        gpk_index_free(lix);
+        return rc;
+    };
+    int64_t total = 0;
+    int32_t rc = n_pts > 0 ? gpk_spatial_join(pts, polys, lix, GPK_PRED_CONTAINS, 0, nullptr, nullptr, 0, &total, GPK_MEM_DEVICE, (void*)s) : GPK_OK;
+    if (rc != GPK_OK) return done(rc);
+    *n_pairs = total;
+    // scratch in the thread's auxiliary arenas (the inner joins recycle the main workspace)
+    const size_t t1 = (size_t)(total > 0 ? total : 1);
+    size_t sort_bytes = 0;
+    int bits = 33;
+    while (bits < 64 && (1ll << (bits - 32)) < n_left) ++bits;
+    GPK_HIP(rocprim::radix_sort_keys(nullptr, sort_bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, t1, 0, bits, s));
+    rc = workspace_aux(0).begin(align256(8 * t1) * 3 + align256(sort_bytes + 256) + align256(4 * (size_t)(n_left + 1)) +
+                                (host_out && want_pairs ? align256(8 * (size_t)pair_capacity) : 0) + 1024);
+    if (rc != GPK_OK) return done(rc);
+    uint2* tmp_pairs = (uint2*)workspace_aux(0).take(8 * t1);
+    unsigned long long* keys = (unsigned long long*)workspace_aux(0).take(8 * t1);
+    unsigned long long* sorted = (unsigned long long*)workspace_aux(0).take(8 * t1);
+    void* sort_tmp = workspace_aux(0).take(sort_bytes + 256);
+    uint32_t* counts_dev = out_counts ? (host_out ? (uint32_t*)workspace_aux(0).take(4 * (size_t)(n_left + 1)) : out_counts) : nullptr;
+    uint2* pairs_dev = want_pairs ? (host_out ? (uint2*)workspace_aux(0).take(8 * (size_t)pair_capacity) : (uint2*)out_pairs) : nullptr;
+    auto run = [&]() -> int32_t {
+        if (total > 0) {
+            int64_t again = 0;
+            GPK_TRY(gpk_spatial_join(pts, polys, lix, GPK_PRED_CONTAINS, 0, nullptr, (uint32_t*)tmp_pairs, total, &again, GPK_MEM_DEVICE, (void*)s));
+            const dim3 g((unsigned)((total + 255) / 256));
+            GPK_LAUNCH("gpk_swap_keys", swap_keys_kernel, g, dim3(256), 0, s, (const uint2*)tmp_pairs, total, keys);
+            GPK_HIP(rocprim::radix_sort_keys(sort_tmp, sort_bytes, (const unsigned long long*)keys, sorted, (size_t)total, 0, bits, s));
+            if (pairs_dev)
+                GPK_LAUNCH("gpk_swap_emit", swap_emit_kernel, g, dim3(256), 0, s, (const unsigned long long*)sorted, total, pair_capacity, left_row_base,
+                           pairs_dev);
+        }
+        if (counts_dev && n_left > 0)
+            GPK_LAUNCH("gpk_swap_counts", swap_counts_kernel, dim3((unsigned)((n_left + 255) / 256)), dim3(256), 0, s,
+                       (const unsigned long long*)sorted, total, n_left, counts_dev);
+        if (host_out) {
+            if (out_counts) GPK_TRY(copy_out(out_counts, out_space, counts_dev, 4 * (size_t)n_left, s));
+            if (want_pairs) GPK_TRY(copy_out(out_pairs, out_space, pairs_dev, 8 * (size_t)(total < pair_capacity ? total : pair_capacity), s));
+        }
+        GPK_HIP(hipStreamSynchronize(s));
+        return GPK_OK;
+    };
+    rc = run();
+    if (rc != GPK_OK) return done(rc);
+    if (want_pairs && total > pair_capacity)
+        return done(fail(GPK_ERR_CAPACITY, "spatial_join: %lld pairs but capacity %lld", (long long)total, (long long)pair_capacity));
+    return done(GPK_OK);
 }
 
 }  // namespace gpk
@@ -1049,13 +1186,22 @@ int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right, co
     // dispatch table of spatial_index.rs:89-137
     const bool pip = left->d.type == GPK_GEOM_POINT && is_polygonal(right->d.type);
     const bool polypoly = is_polygonal(left->d.type) && is_polygonal(right->d.type);
+    if (is_polygonal(left->d.type) && right->d.type == GPK_GEOM_POINT)  // the same test with the polygon on the left (:92,96)
+        return swapped_pip_join(left, right, left_row_base, out_counts, out_pairs, pair_capacity, n_pairs, out_space, s);
     if (polypoly && predicate != GPK_PRED_INTERSECTS)
         return fail(GPK_ERR_MISMATCHED_GEOMETRY,
                     "spatial_join: contains/within(polygon, polygon) is a DE-9IM relate upstream and is not implemented");
-    if (!pip && !polypoly)
-        return fail(GPK_ERR_MISMATCHED_GEOMETRY,
-                    "spatial_join: left type %d x right type %d is not supported by this build",
-                    left->d.type, right->d.type);
+    auto lineal = [](int32_t t) { return t == GPK_GEOM_LINESTRING || t == GPK_GEOM_MULTILINESTRING; };
+    const bool lineal_point = (left->d.type == GPK_GEOM_POINT && lineal(right->d.type)) || (lineal(left->d.type) && right->d.type == GPK_GEOM_POINT);
+    if (!pip && !polypoly && !lineal_point) {  // `_ => false` (spatial_index.rs:136): an empty join, not an error
+        if (out_counts && left->d.n_geoms > 0) {
+            if (out_space == GPK_MEM_DEVICE)
+                GPK_HIP(hipMemsetAsync(out_counts, 0, sizeof(uint32_t) * (size_t)left->d.n_geoms, s));
+            else
+                memset(out_counts, 0, sizeof(uint32_t) * (size_t)left->d.n_geoms);
+        }
+        return GPK_OK;
+    }
 
     gpk_index* tmp_index = nullptr;
     if (!right_index) {  // built on the fly, like spatial_index.rs:60-71
@@ -1072,6 +1218,8 @@ int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right, co
     const int64_t n = left->d.n_geoms;
     if (n == 0) return done(GPK_OK);
     if (polypoly) return done(bbox_join(left, right, right_index, left_row_base, out_counts, out_pairs, pair_capacity, n_pairs, out_space, s));
+    if (lineal_point)
+        return done(bbox_join(left, right, right_index, left_row_base, out_counts, out_pairs, pair_capacity, n_pairs, out_space, s, REFINE_LINEAL_POINT));
     const bool host_out = out_space != GPK_MEM_DEVICE;
     const bool want_pairs = pair_capacity > 0;
     const size_t counts_bytes = sizeof(uint32_t) * (size_t)n;

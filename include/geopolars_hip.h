@@ -195,6 +195,10 @@ int32_t gpk_index_nbytes(const gpk_index* idx, int64_t* out_bytes);
  *   out_pairs[2*cap]     u32 (l, r) interleaved (may be NULL when cap == 0: count-only mode)
  *   *n_pairs             total hits (always set; GPK_ERR_CAPACITY if > cap and pairs requested)
  * `right_index` may be NULL (built on the fly like spatial_index.rs:60-71).
+ * Geometry dispatch = the match of spatial_index.rs:89-137: point <-> polygon / multipolygon on either side
+ * (`poly.contains(point)` whatever the predicate), polygonal x polygonal `intersects` (`contains` there is a DE-9IM relate
+ * upstream: GPK_ERR_MISMATCHED_GEOMETRY), point <-> linestring / multilinestring on either side (`line.contains(point)`);
+ * every other combination is upstream's `_ => false`: an empty result, not an error.
  * `left_row_base` is added to every emitted l (row-sharded multi-GPU runs).
  */
 int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right,

@@ -3,7 +3,7 @@ oracle, bit-exact on counts and sorted (l, r) pairs."""
 import numpy as np
 import pytest
 
-from geopolars_amd import synth
+from geopolars_amd import _abi, synth
 from geopolars_amd.geoarrow import GeoArrowArray
 from geopolars_amd.geoseries import GeoSeries
 from geopolars_amd.spatial_index import SpatialIndex, join_pairs
@@ -208,3 +208,46 @@ def test_stream_ordered_join_matches_blocking_join(gpk, oracle):
         assert np.array_equal(pairs.cpu().numpy().view(np.uint32)[:k], exp_pairs[:k])
         if cap:
             assert np.all(pairs.cpu().numpy()[k:] == -1)  # nothing written past the capacity / the total
+
+
+def test_join_dispatch_arms_of_the_reference(gpk, oracle):
+    """every arm of the match in spatial_index.rs:89-137: polygon LEFT x point RIGHT (the same `poly.contains(point)`),
+    Line / LineString / MultiLineString <-> Point (`line.contains(point)`), and `_ => false` for everything else"""
+    polys = synth.star_polygons(300, 16)
+    pts = synth.uniform_points(40_000, seed=21)
+    # polygon on the left: the transpose of the point-left join, sorted by (polygon, point)
+    exp_pairs, exp_counts, _ = oracle.spatial_join(polys, pts, "intersects", mode=1)
+    got_pairs, got_counts = join_pairs(GeoSeries(polys), GeoSeries(pts), "intersects")
+    assert np.array_equal(got_counts, exp_counts) and np.array_equal(got_pairs, exp_pairs) and len(exp_pairs) > 5000
+    fwd, _ = join_pairs(GeoSeries(pts), GeoSeries(polys), "intersects")
+    assert np.array_equal(np.sort(fwd[:, 0].astype(np.int64) * 1000 + fwd[:, 1]), np.sort(got_pairs[:, 1].astype(np.int64) * 1000 + got_pairs[:, 0]))
+    shifted, _ = join_pairs(GeoSeries(polys), GeoSeries(pts), "within", left_row_base=50)
+    assert np.array_equal(shifted[:, 0], exp_pairs[:, 0] + 50)
+    mp = synth.powerlaw_multipolygons(400, seed=3, domain=300.0)
+    p2 = synth.uniform_points(20_000, seed=4, domain=300.0)
+    exp_pairs, exp_counts, _ = oracle.spatial_join(mp, p2, "contains", mode=1)
+    got_pairs, got_counts = join_pairs(GeoSeries(mp), GeoSeries(p2), "contains")
+    assert np.array_equal(got_counts, exp_counts) and np.array_equal(got_pairs, exp_pairs)
+
+    # lines and points: points ON the lines (vertices, end points, segment midpoints) and off them
+    rng = np.random.default_rng(8)
+    lines = GeoArrowArray.from_linestrings(
+        [np.cumsum(rng.integers(-4, 5, (int(n), 2)), axis=0).astype(float).tolist() for n in rng.integers(2, 12, 400)]
+        + [[(0, 0), (4, 0), (4, 4), (0, 4), (0, 0)], [(7, 7), (7, 7)], []]
+    )
+    on = np.concatenate([lines.xy[::2], (lines.xy[:-1] + lines.xy[1:])[::3] / 2.0, [[0.0, 0.0], [7.0, 7.0], [2.0, 0.0]]])
+    lp = GeoArrowArray.from_points(np.concatenate([on, rng.integers(-30, 30, (3000, 2)).astype(float), [[np.nan, np.nan]]]))
+    for left, right in ((lp, lines), (lines, lp)):
+        exp_pairs, exp_counts, _ = oracle.spatial_join(left, right, "intersects", mode=0)
+        got_pairs, got_counts = join_pairs(GeoSeries(left), GeoSeries(right), "intersects")
+        assert np.array_equal(got_counts, exp_counts) and np.array_equal(got_pairs, exp_pairs)
+        assert 50 < len(exp_pairs)
+    ml = GeoArrowArray(_abi.GEOM_MULTILINESTRING, lines.xy, geom_offsets=np.array([0, 3, 3, 200, len(lines)], np.int32), ring_offsets=lines.geom_offsets)
+    exp_pairs, exp_counts, _ = oracle.spatial_join(lp, ml, "contains", mode=0)
+    got_pairs, got_counts = join_pairs(GeoSeries(lp), GeoSeries(ml), "contains")
+    assert np.array_equal(got_counts, exp_counts) and np.array_equal(got_pairs, exp_pairs)
+
+    # `_ => false`: an empty join, not an error
+    for left, right in ((pts, pts), (lines, lines), (lines, polys), (polys, lines)):
+        got_pairs, got_counts = join_pairs(GeoSeries(left), GeoSeries(right), "intersects")
+        assert len(got_pairs) == 0 and not got_counts.any() and len(got_counts) == len(left)
