@@ -3,7 +3,8 @@
 //
 // The hull of a point set is unique, so any exact algorithm returns the same ring up to its start
 // vertex; this kernel emits it starting at the lexicographically smallest vertex.  One lane per
-// geometry: in-place heap sort of a copy (LDS, or global scratch for large geometries), then a monotone chain driven by the exact
+// geometry for the chain, 16 lanes per geometry for the sort (bitonic network in LDS; heap sort in global scratch for large
+// geometries), then a monotone chain driven by the exact
 // orientation kernel.  Irregular per-row output sizes go through size -> scan -> compact.
 // This is the lowest-traffic operator of the surface; the sort's working set sits in LDS.
 #include "gpk_device.h"
@@ -44,56 +45,62 @@ __device__ __forceinline__ void heap_sort(LD ld, ST st, int n) {
     }
 }
 
-// sort + dedup + monotone chain over the points ld(0..n); the hull is written to h (global), closed; returns its size.
-// The two topmost stack entries live in registers, so the chain touches memory once per push and once per pop.
-template <typename LD, typename ST>
-__device__ __forceinline__ int hull_of(LD ld, ST st, int n, double2* __restrict__ h) {
-    heap_sort(ld, st, n);
-    int m = 0;
-    {
-        double2 prev = make_double2(0, 0);
-        for (int i = 0; i < n; ++i) {
-            const double2 v = ld(i);
-            if (m == 0 || v.x != prev.x || v.y != prev.y) {
-                st(m++, v);
-                prev = v;
-            }
-        }
-    }
-    const double2 p0 = ld(0);
-    int k = 0;
-    if (m < 3) {
-        for (int i = 0; i < m; ++i) h[k++] = ld(i);
-    } else {
-        double2 t1 = p0, t2 = p0;  // h[k-1], h[k-2]
-        auto push = [&](double2 v) {
-            h[k++] = v;
-            t2 = t1;
-            t1 = v;
-        };
-        auto pop = [&]() {
-            --k;
-            t1 = t2;
-            if (k >= 2) t2 = h[k - 2];
-        };
-        for (int i = 0; i < m; ++i) {
-            const double2 v = ld(i);
-            while (k >= 2 && dev::orient2d(t2.x, t2.y, t1.x, t1.y, v.x, v.y) <= 0) pop();
-            push(v);
-        }
-        const int lo = k + 1;
-        for (int i = m - 2; i >= 0; --i) {
-            const double2 v = ld(i);
-            while (k >= lo && dev::orient2d(t2.x, t2.y, t1.x, t1.y, v.x, v.y) <= 0) pop();
-            push(v);
-        }
+// monotone chain over n SORTED points read through ld(0..n) (duplicates allowed: they are skipped on the fly, in both
+// directions).  The stack holds point INDICES, behind put(k, i) / get(k) (the lane's column of an LDS tile, or global
+// scratch for geometries too large for it): a stack of coordinates in global memory turned every push into a partial
+// cache-line write from half a million concurrent streams.  The two topmost entries also live in registers as
+// coordinates, so a step reads one point, and one more per pop.  The closed hull is written to h; returns its size.
+template <typename LD, typename PUT, typename GET>
+__device__ __forceinline__ int chain_of(LD ld, int n, PUT put, GET get, double2* __restrict__ h) {
+    const double2 p0 = ld(0), pl = ld(n - 1);
+    int k = 0, m = 0;          // stack depth, distinct points seen
+    double2 t1 = p0, t2 = p0;  // points of stack entries k-1, k-2
+    auto push = [&](int i, double2 v) {
+        put(k++, i);
+        t2 = t1;
+        t1 = v;
+    };
+    auto pop = [&]() {
         --k;
-        if (k < 3) {  // all collinear: the two extremes
-            k = 2;
-            h[0] = p0;
-            h[1] = ld(m - 1);
-        }
+        t1 = t2;
+        if (k >= 2) t2 = ld(get(k - 2));
+    };
+    double2 prev = make_double2(0, 0);
+    double2 nxt = p0;  // the next point is loaded one step ahead of its use
+    for (int i = 0; i < n; ++i) {
+        const double2 v = nxt;
+        if (i + 1 < n) nxt = ld(i + 1);
+        if (i > 0 && v.x == prev.x && v.y == prev.y) continue;
+        prev = v;
+        ++m;
+        while (k >= 2 && dev::orient2d(t2.x, t2.y, t1.x, t1.y, v.x, v.y) <= 0) pop();
+        push(i, v);
     }
+    if (m < 3) {  // one or two distinct points
+        h[0] = p0;
+        if (m == 2) h[1] = pl;
+        h[m] = p0;
+        return m + 1;
+    }
+    const int lo = k + 1;
+    prev = pl;  // the last distinct point is already on the stack: the way back starts below it
+    nxt = n >= 2 ? ld(n - 2) : p0;
+    for (int i = n - 2; i >= 0; --i) {
+        const double2 v = nxt;
+        if (i > 0) nxt = ld(i - 1);
+        if (v.x == prev.x && v.y == prev.y) continue;
+        prev = v;
+        while (k >= lo && dev::orient2d(t2.x, t2.y, t1.x, t1.y, v.x, v.y) <= 0) pop();
+        push(i, v);
+    }
+    --k;
+    if (k < 3) {  // all collinear: the two extremes
+        h[0] = p0;
+        h[1] = pl;
+        h[2] = p0;
+        return 3;
+    }
+    for (int j = 0; j < k; ++j) h[j] = ld(get(j));
     h[k] = h[0];  // close the ring
     return k + 1;
 }
@@ -122,44 +129,96 @@ __device__ __forceinline__ void geom_coord_range(const DevGeo& a, int64_t g, int
     }
 }
 
-// scratch layout per geometry g with coordinate range [c0, c1): sorted copy at sorted[c0..c1) (global path only),
-// chain stack at stack[2*c0 + 2*g .. 2*c1 + 2*g + 2).
-// One lane per geometry, one wave per work-group.  When every geometry of the wave has at most HULL_CAP points (the
-// closing duplicate of a ring does not count) the lanes keep their points in LDS, interleaved (element i of lane l at
-// [i * 64 + l]: conflict-free for equal i, and the sort's data-dependent indices never leave the lane's column); the heap
-// sort then runs out of LDS instead of making ~800 scattered global accesses per geometry (2M x 64-vertex polygons:
-// 70 ms -> see DESIGN.md).  Larger geometries sort in global scratch as before.
-constexpr int HULL_CAP = 64;
-__global__ __launch_bounds__(64) void hull_kernel(DevGeo a, double2* __restrict__ sorted, double2* __restrict__ stack,
-                                                  int32_t* __restrict__ sizes) {
-    __shared__ double2 lds[HULL_CAP * 64];
-    const int lane = threadIdx.x;
-    const int64_t g = (int64_t)blockIdx.x * 64 + lane;
-    int c0 = 0, c1 = 0;
-    bool act = g < a.n_geoms;
-    if (act) {
-        geom_coord_range(a, g, c0, c1);
-        if (!dev::valid_row(a.validity, g) || c1 == c0) {
-            sizes[g] = 0;
-            act = false;
-        }
-    }
+// scratch layout per geometry g with coordinate range [c0, c1): sorted copy at sorted[c0..c0 + n_pts[g]), chain stack at
+// stack[2*c0 + 2*g .. 2*c1 + 2*g + 2).  Three stages:
+//   hull_sort_kernel      HULL_GS lanes per geometry of at most HULL_CAP points: a bitonic network over the geometry's
+//                         points in LDS (coalesced loads and stores, no data-dependent addressing, 16 geometries per
+//                         work-group) — the lane-per-geometry heap sort made ~800 scattered accesses per geometry;
+//   hull_sort_big_kernel  one lane per geometry beyond HULL_CAP: heap sort in global scratch;
+//   hull_chain_kernel     one lane per geometry: monotone chain over its sorted points (sequential reads).
+// The closing duplicate of a ring is dropped before sorting (the chain skips duplicates anyway).
+constexpr int HULL_CAP = 128, HULL_GS = 16;
+__device__ __forceinline__ int hull_points(const DevGeo& a, int64_t g, int& c0) {  // -1: null / empty row
+    int c1;
+    geom_coord_range(a, g, c0, c1);
+    if (!dev::valid_row(a.validity, g) || c1 == c0) return -1;
     int n = c1 - c0;
-    if (act && n >= 2) {  // a closing duplicate would only be removed by the dedup pass: drop it before sorting
+    if (n >= 2) {
         const double2 f = a.xy[c0], l = a.xy[c1 - 1];
         if (f.x == l.x && f.y == l.y) --n;
     }
-    const bool fits = !act || n <= HULL_CAP;
-    const bool all_fit = __all(fits);  // wave-uniform
-    if (!act) return;
-    double2* h = stack + 2 * (int64_t)c0 + 2 * g;
+    return n;
+}
+__global__ __launch_bounds__(256) void hull_sort_kernel(DevGeo a, double2* __restrict__ sorted, int32_t* __restrict__ n_pts) {
+    __shared__ double2 lds[(256 / HULL_GS) * HULL_CAP];
+    const int lane = threadIdx.x & (HULL_GS - 1);
+    const int64_t g = ((int64_t)blockIdx.x * 256 + threadIdx.x) / HULL_GS;
+    if (g >= a.n_geoms) return;
+    int c0;
+    const int n = hull_points(a, g, c0);
+    if (lane == 0) n_pts[g] = n;
+    if (n <= 0 || n > HULL_CAP) return;  // empty, or left to hull_sort_big_kernel
+    double2* __restrict__ v = lds + (threadIdx.x / HULL_GS) * HULL_CAP;
+    int P = 2;
+    while (P < n) P <<= 1;
+    for (int i = lane; i < P; i += HULL_GS) v[i] = i < n ? a.xy[c0 + i] : make_double2(INFINITY, INFINITY);  // sentinels sort last
+    auto sync = [] {  // the lanes of a group sit in one wave
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            sync();
+            for (int t = lane; t < P / 2; t += HULL_GS) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i + j;  // 2j * (t / j) + t % j for a power of two j
+                const bool up = (i & k) == 0;
+                const double2 x = v[i], y = v[l];
+                if (xy_less(y, x) == up) {
+                    v[i] = y;
+                    v[l] = x;
+                }
+            }
+        }
+    sync();
+    for (int i = lane; i < n; i += HULL_GS) sorted[c0 + i] = v[i];
+}
+__global__ __launch_bounds__(256) void hull_sort_big_kernel(DevGeo a, double2* __restrict__ sorted, const int32_t* __restrict__ n_pts) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= a.n_geoms) return;
+    const int n = n_pts[g];
+    if (n <= HULL_CAP) return;
+    int c0, c1;
+    geom_coord_range(a, g, c0, c1);
+    double2* p = sorted + c0;
+    for (int i = 0; i < n; ++i) p[i] = a.xy[c0 + i];
+    heap_sort([&](int i) { return p[i]; }, [&](int i, double2 v) { p[i] = v; }, n);
+}
+// one wave per work-group: when every geometry of the wave has at most HULL_STACK points the index stacks sit in an LDS
+// tile, interleaved by lane (entry k of lane l at [k * 64 + l]); otherwise the wave keeps them in global scratch
+constexpr int HULL_STACK = 129;  // stack depth: up to n + 1 entries for n points
+__global__ __launch_bounds__(64) void hull_chain_kernel(DevGeo a, const double2* __restrict__ sorted, const int32_t* __restrict__ n_pts,
+                                                         double2* __restrict__ stack, int32_t* __restrict__ idx_scratch,
+                                                         int32_t* __restrict__ sizes) {
+    __shared__ uint16_t s_idx[(HULL_STACK + 1) * 64];
+    const int lane = threadIdx.x;
+    const int64_t g = (int64_t)blockIdx.x * 64 + lane;
+    const int n = g < a.n_geoms ? n_pts[g] : 0;
+    const bool all_fit = __all(n <= HULL_STACK - 1);  // wave-uniform
+    if (n <= 0) {
+        if (g < a.n_geoms) sizes[g] = 0;
+        return;
+    }
+    int c0, c1;
+    geom_coord_range(a, g, c0, c1);
+    const double2* __restrict__ p = sorted + c0;
+    double2* __restrict__ h = stack + 2 * (int64_t)c0 + 2 * g;
+    auto ld = [&](int i) { return p[i]; };
     if (all_fit) {
-        for (int i = 0; i < n; ++i) lds[i * 64 + lane] = a.xy[c0 + i];
-        sizes[g] = hull_of([&](int i) { return lds[i * 64 + lane]; }, [&](int i, double2 v) { lds[i * 64 + lane] = v; }, n, h);
+        sizes[g] = chain_of(ld, n, [&](int k, int i) { s_idx[k * 64 + lane] = (uint16_t)i; }, [&](int k) { return (int)s_idx[k * 64 + lane]; }, h);
     } else {
-        double2* p = sorted + c0;
-        for (int i = 0; i < n; ++i) p[i] = a.xy[c0 + i];
-        sizes[g] = hull_of([&](int i) { return p[i]; }, [&](int i, double2 v) { p[i] = v; }, n, h);
+        int32_t* __restrict__ st = idx_scratch + 2 * (int64_t)c0 + 2 * g;
+        sizes[g] = chain_of(ld, n, [&](int k, int i) { st[k] = i; }, [&](int k) { return (int)st[k]; }, h);
     }
 }
 
@@ -189,12 +248,15 @@ extern "C" int32_t gpk_convex_hull(const gpk_geoarray* a, double* out_xy, int32_
     const int64_t nb = (n + 255) / 256;
     const bool host_out = out_space != GPK_MEM_DEVICE;
     size_t need = align256(sizeof(double2) * (size_t)(nc + 1)) + align256(sizeof(double2) * (2 * (size_t)nc + 2 * (size_t)n + 2)) +
-                  align256(off_bytes) + align256(sizeof(unsigned long long) * (size_t)(nb + 2)) + 1024;
+                  2 * align256(off_bytes) + align256(sizeof(unsigned long long) * (size_t)(nb + 2)) +
+                  align256(sizeof(int32_t) * (2 * (size_t)nc + 2 * (size_t)n + 2)) + 1024;
     if (host_out) need += align256(sizeof(double2) * cap_coords) + align256(off_bytes);
     GPK_TRY(workspace().begin(need));
     double2* sorted = (double2*)workspace().take(sizeof(double2) * (size_t)(nc + 1));
     double2* stack = (double2*)workspace().take(sizeof(double2) * (2 * (size_t)nc + 2 * (size_t)n + 2));
     int32_t* sizes = (int32_t*)workspace().take(off_bytes);
+    int32_t* n_pts = (int32_t*)workspace().take(off_bytes);
+    int32_t* idx_scratch = (int32_t*)workspace().take(sizeof(int32_t) * (2 * (size_t)nc + 2 * (size_t)n + 2));
     unsigned long long* btot = (unsigned long long*)workspace().take(sizeof(unsigned long long) * (size_t)(nb + 2));
     double2* out_dev = host_out ? (double2*)workspace().take(sizeof(double2) * cap_coords) : (double2*)out_xy;
     int32_t* off_dev = host_out ? (int32_t*)workspace().take(off_bytes) : out_ring_offsets;
@@ -203,7 +265,10 @@ extern "C" int32_t gpk_convex_hull(const gpk_geoarray* a, double* out_xy, int32_
         return copy_out(out_ring_offsets, out_space, off_dev, sizeof(int32_t), s);
     }
     const dim3 grid((unsigned)nb), block(256);
-    GPK_LAUNCH("gpk_hull", hull_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, a->d, sorted, stack, sizes);
+    GPK_LAUNCH("gpk_hull_sort", hull_sort_kernel, dim3((unsigned)((n * HULL_GS + 255) / 256)), dim3(256), 0, s, a->d, sorted, n_pts);
+    GPK_LAUNCH("gpk_hull_sort_big", hull_sort_big_kernel, grid, block, 0, s, a->d, sorted, (const int32_t*)n_pts);
+    GPK_LAUNCH("gpk_hull_chain", hull_chain_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, a->d, (const double2*)sorted, (const int32_t*)n_pts, stack,
+               idx_scratch, sizes);
     GPK_TRY(exclusive_scan_i32(sizes, n, off_dev, nullptr, btot, s));
     GPK_LAUNCH("gpk_hull_compact", hull_compact_kernel, grid, block, 0, s, a->d, stack, off_dev, out_dev);
     if (host_out) {
