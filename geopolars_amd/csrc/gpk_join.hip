@@ -999,6 +999,16 @@ static int32_t swapped_pip_join(const gpk_geoarray* polys, const gpk_geoarray* p
     const bool host_out = out_space != GPK_MEM_DEVICE;
     const bool want_pairs = pair_capacity > 0;
     *n_pairs = 0;
+    if (n_left == 0) return GPK_OK;
+    if (n_pts == 0) {  // nothing on the right: every polygon has zero hits
+        if (out_counts) {
+            if (host_out)
+                memset(out_counts, 0, sizeof(uint32_t) * (size_t)n_left);
+            else
+                GPK_HIP(hipMemsetAsync(out_counts, 0, sizeof(uint32_t) * (size_t)n_left, s));
+        }
+        return GPK_OK;
+    }
     gpk_index* lix = nullptr;
     GPK_TRY(gpk_index_build(polys, (void*)s, &lix));
     auto done = [&](int32_t rc) {
@@ -1006,7 +1016,7 @@ static int32_t swapped_pip_join(const gpk_geoarray* polys, const gpk_geoarray* p
         return rc;
     };
     int64_t total = 0;
-    int32_t rc = n_pts > 0 ? gpk_spatial_join(pts, polys, lix, GPK_PRED_CONTAINS, 0, nullptr, nullptr, 0, &total, GPK_MEM_DEVICE, (void*)s) : GPK_OK;
+    int32_t rc = gpk_spatial_join(pts, polys, lix, GPK_PRED_CONTAINS, 0, nullptr, nullptr, 0, &total, GPK_MEM_DEVICE, (void*)s);
     if (rc != GPK_OK) return done(rc);
     *n_pairs = total;
     // scratch in the thread's auxiliary arenas (the inner joins recycle the main workspace)

@@ -95,6 +95,14 @@ def test_empty_and_nan_inputs(gpk):
     nanpts = GeoSeries(GeoArrowArray.from_points([[np.nan, np.nan], [np.nan, 1.0]]))
     pairs, counts = join_pairs(nanpts, polys)
     assert pairs.shape == (0, 2) and counts.tolist() == [0, 0]
+    # the polygon-left arm with an empty side
+    pairs, counts = join_pairs(polys, empty)
+    assert pairs.shape == (0, 2) and counts.tolist() == [0] * 10
+    pairs, counts = join_pairs(polys, nanpts)
+    assert pairs.shape == (0, 2) and counts.tolist() == [0] * 10
+    lines = GeoSeries(GeoArrowArray.from_linestrings([[(0, 0), (1, 1)], []]))
+    pairs, counts = join_pairs(lines, empty)
+    assert pairs.shape == (0, 2) and counts.tolist() == [0, 0]
 
 
 @pytest.mark.parametrize("n,neigh", [(500, 4.0), (6000, 12.0)])
