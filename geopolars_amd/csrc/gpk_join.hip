@@ -1233,7 +1233,6 @@ int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right, co
     const bool host_out = out_space != GPK_MEM_DEVICE;
     const bool want_pairs = pair_capacity > 0;
     const size_t counts_bytes = sizeof(uint32_t) * (size_t)n;
-    const size_t pairs_bytes = sizeof(uint32_t) * 2 * (size_t)pair_capacity;
     static thread_local unsigned long long* pinned_total = nullptr;  // device-mapped host word: no D2H copy per call
     if (!pinned_total && hipHostMalloc((void**)&pinned_total, 64, hipHostMallocMapped) != hipSuccess) pinned_total = nullptr;
     uint32_t *counts_dev = nullptr, *pairs_dev = nullptr;
