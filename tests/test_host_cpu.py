@@ -250,3 +250,18 @@ def test_wkb_encoder_matches_independent_writer_and_handles_nulls():
     assert lib.gpk_wkb_encode(C.byref(d), None, None, 0, C.byref(nb)) == _abi.GPK_OK and nb.value == len(v)
     small = np.empty(10, np.uint8)
     assert lib.gpk_wkb_encode(C.byref(d), None, small.ctypes.data, 10, C.byref(nb)) == _abi.GPK_ERR_CAPACITY and nb.value == len(v)
+
+
+def test_plain_c_client_links_and_fails_loudly_without_a_device(tmp_path):
+    """include/geopolars_hip.h compiled as strict C99 by gcc, linked against the library, run as a process"""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "geopolars_amd")
+    exe = str(tmp_path / "c_abi_client")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c_abi_client.c"),
+           "-o", exe, "-L", lib_dir, "-lgeopolars_hip", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
