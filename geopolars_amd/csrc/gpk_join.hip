@@ -121,7 +121,10 @@ __global__ void cell_sort_kernel(const int32_t* __restrict__ cell_off, int64_t n
 #define GPK_PIP_BLOCK 256
 #endif
 constexpr int PIP_BLOCK = GPK_PIP_BLOCK;       // threads per work-group of pip_tile
-constexpr int WR_BLOCK = 256;                  // threads per work-group of pip_write
+#ifndef GPK_WR_BLOCK
+#define GPK_WR_BLOCK 256
+#endif
+constexpr int WR_BLOCK = GPK_WR_BLOCK;                  // threads per work-group of pip_write
 constexpr int PIP_PPT = GPK_PIP_PPT;           // points per thread, strided by PIP_BLOCK (coalesced 16-byte loads)
 constexpr int PIP_TILE = PIP_BLOCK * PIP_PPT;  // points per work-group
 constexpr int PIP_GS = GPK_PIP_GS;             // lanes cooperating on one queued (point, part) pair
