@@ -318,6 +318,199 @@ static int polygonal_intersects_polygonal(const gpk_geoarrow_desc* a, int64_t ia
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Contains<Polygon> for Polygon / MultiPolygon — reached from spatial_index.rs:99-101 and :107-111.
+ * geo 0.27 implements it as `self.relate(rhs).is_contains()` (DE-9IM pattern T*****FF*: interiors
+ * meet, nothing of rhs in the exterior of self).  For VALID operands that is the set statement
+ * "rhs is not empty and rhs is a subset of self (both closed)", which is what this section decides,
+ * with exact orientations only (no constructed intersection points):
+ *   (1) no vertex of rhs is Outside self, and no piece of an rhs edge leaves self.  The pieces of an
+ *       edge between two consecutive touch points with a ring lie on one side of that ring, and the
+ *       side is visible at the touch point from the direction of the edge: against the sector of the
+ *       ring's two incident edges when the touch point is a ring vertex, against the ring edge when
+ *       an end point of the rhs edge lies inside a ring edge; a proper crossing has a piece on
+ *       either side.  Leaving self = outside its exterior ring or inside one of its holes, so the
+ *       test is ring by ring.
+ *   (2) no hole of self is swallowed by rhs: with (1) a hole's interior misses every ring of rhs, so
+ *       it lies inside or outside each of them as a whole; it is swallowed when it is inside (or
+ *       equal to) the exterior of rhs and outside every hole of rhs.
+ * A MultiPolygon contains a (valid, hence connected) polygon iff one member does; a multipolygon rhs
+ * (row-wise predicate only) is contained iff it is not empty and every member is.
+ * PARITY: unpinned against the upstream relate (no Rust here, no golden vector in the reference);
+ * pinned to the set statement by tests/test_oracle_rational.py (rational edge splitting).  Rings
+ * that are unclosed, have fewer than 4 coordinates or no turning extreme vertex make the operand
+ * invalid: the answer is then false.
+ * ---------------------------------------------------------------------------------------------- */
+enum { DIR_IN = 1, DIR_OUT = 2 }; /* bits: a piece strictly inside / strictly outside the ring */
+enum { REL_IN = 0, REL_OUT = 1, REL_SAME = 2 };
+
+typedef struct {
+    const double* xy; /* closed ring: xy[m] == xy[0] */
+    int64_t m;        /* number of edges */
+    int ccw;          /* +1 counter-clockwise, -1 clockwise */
+} cring;
+
+static inline int same_xy(const double* a, const double* b) { return a[0] == b[0] && a[1] == b[1]; }
+static inline const double* cr_v(const cring* r, int64_t i) { return r->xy + 2 * i; }
+static int64_t cr_prev_distinct(const cring* r, int64_t i) {
+    for (int64_t k = 1; k < r->m; ++k) {
+        const int64_t j = (i - k % r->m + r->m) % r->m;
+        if (!same_xy(cr_v(r, j), cr_v(r, i))) return j;
+    }
+    return -1;
+}
+static int64_t cr_next_distinct(const cring* r, int64_t i) {
+    for (int64_t k = 1; k < r->m; ++k) {
+        const int64_t j = (i + k) % r->m;
+        if (!same_xy(cr_v(r, j), cr_v(r, i))) return j;
+    }
+    return -1;
+}
+static inline int orient_pts(const double* a, const double* b, const double* c) {
+    return gpko_orient2d(a[0], a[1], b[0], b[1], c[0], c[1]);
+}
+/* orientation of a simple ring = turn at its lexicographically smallest vertex (always convex) */
+static int cring_init(cring* r, const double* xy, int64_t n) {
+    if (n < 4 || !same_xy(xy, xy + 2 * (n - 1))) return 0;
+    r->xy = xy;
+    r->m = n - 1;
+    int64_t k = 0;
+    for (int64_t i = 1; i < r->m; ++i)
+        if (xy[2 * i] < xy[2 * k] || (xy[2 * i] == xy[2 * k] && xy[2 * i + 1] < xy[2 * k + 1])) k = i;
+    const int64_t p = cr_prev_distinct(r, k), q = cr_next_distinct(r, k);
+    if (p < 0 || q < 0) return 0;
+    r->ccw = orient_pts(cr_v(r, p), cr_v(r, k), cr_v(r, q));
+    return r->ccw != 0;
+}
+/* w lies on the line through v and t (t != v, w != v): on the same side of v as t? */
+static inline int same_ray(const double* v, const double* t, const double* w) {
+    if (t[0] != v[0]) return (t[0] > v[0]) == (w[0] > v[0]);
+    return (t[1] > v[1]) == (w[1] > v[1]);
+}
+/* the piece of the segment vertex_i -> w next to vertex_i: strictly inside the ring (DIR_IN),
+ * strictly outside (DIR_OUT), or running along one of the two incident edges (0) */
+static int dir_at_vertex(const cring* r, int64_t i, const double* w) {
+    const double* v = cr_v(r, i);
+    int64_t ip = cr_prev_distinct(r, i), iq = cr_next_distinct(r, i);
+    if (r->ccw < 0) { const int64_t t = ip; ip = iq; iq = t; } /* walk it with the inside on the left */
+    const double *p = cr_v(r, ip), *q = cr_v(r, iq);
+    const int o1 = orient_pts(p, v, w), o2 = orient_pts(v, q, w);
+    if (o1 == 0 && same_ray(v, p, w)) return 0;
+    if (o2 == 0 && same_ray(v, q, w)) return 0;
+    const int turn = orient_pts(p, v, q);
+    int in;
+    if (turn > 0) in = o1 > 0 && o2 > 0;      /* convex corner: between the two edges */
+    else if (turn < 0) in = o1 > 0 || o2 > 0; /* reflex corner */
+    else in = o1 > 0;                          /* straight through */
+    return in ? DIR_IN : DIR_OUT;
+}
+static inline int strictly_between(const double* p, const double* a, const double* b) {
+    return !same_xy(p, a) && !same_xy(p, b) && value_in_between(p[0], a[0], b[0]) && value_in_between(p[1], a[1], b[1]);
+}
+/* DIR_IN / DIR_OUT bits of the pieces of segment pq next to its touch points with ring r */
+static int edge_ring_flags(const double* p, const double* q, const cring* r) {
+    if (same_xy(p, q)) return 0;
+    const double lx = fmin(p[0], q[0]), hx = fmax(p[0], q[0]), ly = fmin(p[1], q[1]), hy = fmax(p[1], q[1]);
+    int fl = 0;
+    for (int64_t i = 0; i < r->m; ++i) {
+        const double *a = cr_v(r, i), *b = r->xy + 2 * (i + 1);
+        if (fmax(a[0], b[0]) < lx || fmin(a[0], b[0]) > hx || fmax(a[1], b[1]) < ly || fmin(a[1], b[1]) > hy) continue;
+        const int oa = orient_pts(p, q, a);
+        if (oa == 0 && value_in_between(a[0], p[0], q[0]) && value_in_between(a[1], p[1], q[1])) {
+            if (!same_xy(a, q)) fl |= dir_at_vertex(r, i, q);
+            if (!same_xy(a, p)) fl |= dir_at_vertex(r, i, p);
+        }
+        if (same_xy(a, b)) continue;
+        const int ob = orient_pts(p, q, b);
+        const int op = orient_pts(a, b, p) * r->ccw, oq = orient_pts(a, b, q) * r->ccw;
+        if (op == 0 && strictly_between(p, a, b)) fl |= oq > 0 ? DIR_IN : (oq < 0 ? DIR_OUT : 0);
+        if (oq == 0 && strictly_between(q, a, b)) fl |= op > 0 ? DIR_IN : (op < 0 ? DIR_OUT : 0);
+        if (oa * ob < 0 && op * oq < 0) fl |= DIR_IN | DIR_OUT;
+    }
+    return fl;
+}
+/* where the interior of ring h lies relative to ring r, given that it does not meet r */
+static int ring_rel(const cring* h, const cring* r) {
+    for (int64_t i = 0; i < h->m; ++i) {
+        const int pos = gpko_coord_pos_ring(h->xy[2 * i], h->xy[2 * i + 1], r->xy, r->m + 1);
+        if (pos == GPKO_INSIDE) return REL_IN;
+        if (pos == GPKO_OUTSIDE) return REL_OUT;
+    }
+    for (int64_t i = 0; i < h->m; ++i) {
+        const int fl = edge_ring_flags(cr_v(h, i), h->xy + 2 * (i + 1), r);
+        if (fl & DIR_IN) return REL_IN;
+        if (fl & DIR_OUT) return REL_OUT;
+    }
+    return REL_SAME;
+}
+/* rings of one polygon as crings (empty holes skipped); 0 = empty or invalid polygon */
+static int64_t polygon_crings(const gpk_geoarrow_desc* a, ring_span s, cring** out) {
+    *out = NULL;
+    if (s.r1 <= s.r0) return 0;
+    cring* rs = (cring*)malloc(sizeof(cring) * (size_t)(s.r1 - s.r0));
+    int64_t k = 0;
+    for (int64_t r = s.r0; r < s.r1; ++r) {
+        int64_t n;
+        const double* xy = ring_xy(a, r, &n);
+        if (n == 0 && r > s.r0) continue;
+        if (!cring_init(&rs[k], xy, n)) {
+            free(rs);
+            return 0;
+        }
+        ++k;
+    }
+    *out = rs;
+    return k;
+}
+static int polygon_contains_polygon(const gpk_geoarrow_desc* a, ring_span sa, const gpk_geoarrow_desc* b, ring_span sb) {
+    double ba[4], bbx[4];
+    if (!span_bbox(a, sa, ba) || !span_bbox(b, sb, bbx)) return 0;
+    if (bbx[0] < ba[0] || bbx[1] < ba[1] || bbx[2] > ba[2] || bbx[3] > ba[3]) return 0;
+    cring *ra, *rb;
+    const int64_t na = polygon_crings(a, sa, &ra);
+    const int64_t nb = na ? polygon_crings(b, sb, &rb) : 0;
+    int ok = na > 0 && nb > 0;
+    /* (1) the boundary of b stays in a */
+    for (int64_t k = 0; ok && k < nb; ++k)
+        for (int64_t i = 0; ok && i < rb[k].m; ++i)
+            if (polygon_pos(a, sa, rb[k].xy[2 * i], rb[k].xy[2 * i + 1]) == GPKO_OUTSIDE) ok = 0;
+    for (int64_t k = 0; ok && k < nb; ++k)
+        for (int64_t i = 0; ok && i < rb[k].m; ++i)
+            for (int64_t j = 0; ok && j < na; ++j) {
+                const int fl = edge_ring_flags(cr_v(&rb[k], i), rb[k].xy + 2 * (i + 1), &ra[j]);
+                if (fl & (j == 0 ? DIR_OUT : DIR_IN)) ok = 0;
+            }
+    /* (2) no hole of a is swallowed by b */
+    for (int64_t j = 1; ok && j < na; ++j) {
+        if (ring_rel(&ra[j], &rb[0]) == REL_OUT) continue;
+        int swallowed = 1;
+        for (int64_t k = 1; swallowed && k < nb; ++k)
+            if (ring_rel(&ra[j], &rb[k]) != REL_OUT) swallowed = 0;
+        if (swallowed) ok = 0;
+    }
+    if (na) free(ra);
+    if (nb) free(rb);
+    return ok;
+}
+static inline int span_is_empty(const gpk_geoarrow_desc* a, ring_span s) {
+    return s.r1 <= s.r0 || a->ring_offsets[s.r0 + 1] == a->ring_offsets[s.r0];
+}
+static int polygonal_contains_polygonal(const gpk_geoarrow_desc* a, int64_t ia, const gpk_geoarrow_desc* b, int64_t ib) {
+    int64_t a0, a1, b0, b1;
+    geom_parts(a, ia, &a0, &a1);
+    geom_parts(b, ib, &b0, &b1);
+    int members = 0;
+    for (int64_t q = b0; q < b1; ++q) {
+        const ring_span sb = part_rings(b, q);
+        if (span_is_empty(b, sb)) continue; /* an empty member adds nothing to the set */
+        int inside = 0;
+        for (int64_t p = a0; p < a1 && !inside; ++p) inside = polygon_contains_polygon(a, part_rings(a, p), b, sb);
+        if (!inside) return 0;
+        ++members;
+    }
+    return members > 0;
+}
+
 /* Contains<Coord> for Line / LineString (geo 0.27 algorithm/contains/{line,line_string}.rs) —
  * reached from spatial_index.rs:126-135 */
 static int line_contains_coord(const double s[2], const double e[2], double px, double py) {
@@ -370,7 +563,9 @@ int32_t gpko_predicate_pair(const gpk_geoarrow_desc* a, int64_t ia, const gpk_ge
     }
     if (is_polygonal(a) && is_polygonal(b)) {
         if (predicate == GPK_PRED_INTERSECTS) return polygonal_intersects_polygonal(a, ia, b, ib);
-        return -1; /* Polygon.contains(Polygon) is a full DE-9IM relate upstream: not restated */
+        /* contains: only (Multi)Polygon x Polygon has an arm (spatial_index.rs:99-101,107-111) */
+        if (predicate == GPK_PRED_CONTAINS && tb == GPK_GEOM_POLYGON) return polygonal_contains_polygonal(a, ia, b, ib);
+        return 0; /* `_ => false`, spatial_index.rs:136 */
     }
     if (ta == GPK_GEOM_POINT && (tb == GPK_GEOM_LINESTRING || tb == GPK_GEOM_MULTILINESTRING)) {
         if (point_is_empty(a, ia)) return 0;
@@ -403,6 +598,7 @@ static int rowwise_pair(const gpk_geoarrow_desc* a, int64_t ia, const gpk_geoarr
         if (ta == GPK_GEOM_POINT && tb == GPK_GEOM_POINT)
             return !point_is_empty(a, ia) && a->xy[2 * ia] == b->xy[2 * ib] &&
                    a->xy[2 * ia + 1] == b->xy[2 * ib + 1];
+        if (is_polygonal(a) && is_polygonal(b)) return polygonal_contains_polygonal(a, ia, b, ib);
         return 0;
     }
     /* intersects */

@@ -159,3 +159,194 @@ def test_point_segment_distance_matches_rational(oracle, p, a, b):
     exp = math.sqrt(float(exp2))
     assert (exp2 == 0) == (got == 0.0)  # zero / non-zero is exact
     assert abs(got - exp) <= 1e-12 * max(exp, 1e-300)
+
+
+# ---- contains(polygon, polygon): the set statement "B is not empty and B is a subset of A" -----------------------
+def _closed(ring):
+    return list(ring) + [ring[0]]
+
+
+def _edges(ring):
+    r = _closed(ring)
+    return [(r[i], r[i + 1]) for i in range(len(ring)) if r[i] != r[i + 1]]
+
+
+def _cross(u, v):
+    return u[0] * v[1] - u[1] * v[0]
+
+
+def _split_params(p, q, rings):
+    """parameters t in [0, 1] at which segment pq meets an edge of one of the rings (ends of collinear overlaps included)"""
+    d = (q[0] - p[0], q[1] - p[1])
+    ts = {F(0), F(1)}
+    for ring in rings:
+        for a, b in _edges(ring):
+            e = (b[0] - a[0], b[1] - a[1])
+            ap = (a[0] - p[0], a[1] - p[1])
+            den = _cross(d, e)
+            if den != 0:
+                t, u = F(_cross(ap, e), den), F(_cross(ap, d), den)
+                if 0 <= t <= 1 and 0 <= u <= 1:
+                    ts.add(t)
+            elif _cross(ap, d) == 0:
+                dd = d[0] * d[0] + d[1] * d[1]
+                for c in (a, b):
+                    t = F((c[0] - p[0]) * d[0] + (c[1] - p[1]) * d[1], dd)
+                    if 0 <= t <= 1:
+                        ts.add(t)
+    return sorted(ts)
+
+
+def _pieces(ring, others):
+    """mid points of the pieces into which the rings `others` cut the edges of `ring` (rational coordinates)"""
+    out = []
+    for p, q in _edges(ring):
+        ts = _split_params(p, q, others)
+        for t0, t1 in zip(ts, ts[1:]):
+            t = (t0 + t1) / 2
+            out.append((p[0] + t * (q[0] - p[0]), p[1] + t * (q[1] - p[1])))
+    return out
+
+
+def _poly_pos(poly, p) -> int:
+    """-1 outside, 0 boundary, 1 inside for polygon = [exterior, hole, ...]"""
+    e = in_or_on(poly[0], p)
+    if e <= 0:
+        return e
+    for h in poly[1:]:
+        k = in_or_on(h, p)
+        if k == 0:
+            return 0
+        if k > 0:
+            return -1
+    return 1
+
+
+def contains_bruteforce(pa, pb) -> bool:
+    # (1) every vertex and every piece of the boundary of B lies in A (closed)
+    for ring in pb:
+        if any(_poly_pos(pa, v) < 0 for v in ring):
+            return False
+        if any(_poly_pos(pa, m) < 0 for m in _pieces(ring, pa)):
+            return False
+    # (2) no hole of A lies in B: look at the pieces of the hole's boundary
+    for hole in pa[1:]:
+        mids = _pieces(hole, pb)
+        pos = [_poly_pos(pb, m) for m in mids]
+        if any(x > 0 for x in pos):
+            return False  # a piece of the hole boundary in the interior of B: B covers points of the hole
+        if all(x == 0 for x in pos) and all(in_or_on(pb[0], m) == 0 for m in mids):
+            return False  # the hole IS the exterior ring of B: B fills the hole
+    return True
+
+
+def star_with_hole(cx, cy, radii, hole_radii, touch):
+    """outer star plus, optionally, a hole on the same fan (radius strictly smaller in every direction, equal in at most
+    one direction when `touch`: a hole may touch the exterior in one point)"""
+    outer = star(cx, cy, radii)
+    if hole_radii is None:
+        return [outer]
+    hr = [max(1, min(h, r - 1)) for h, r in zip(hole_radii, radii)]
+    if any(r < 2 for r in radii):
+        return [outer]
+    if touch is not None:
+        hr[touch] = radii[touch]
+    return [outer, star(cx, cy, hr)]
+
+
+small = st.integers(-6, 6)
+polys_with_holes = st.builds(
+    star_with_hole,
+    small,
+    small,
+    st.lists(st.integers(1, 10), min_size=8, max_size=8),
+    st.one_of(st.none(), st.lists(st.integers(1, 9), min_size=8, max_size=8)),
+    st.one_of(st.none(), st.integers(0, 7)),
+)
+
+
+@settings(max_examples=600, deadline=None)
+@given(polys_with_holes, polys_with_holes)
+def test_polygon_contains_polygon_matches_rational_set_statement(oracle, pa, pb):
+    a, b = GeoArrowArray.from_polygons([pa]), GeoArrowArray.from_polygons([pb])
+    got = bool(oracle.predicate_rowwise(a, b, "contains")[0])
+    assert got == contains_bruteforce(pa, pb)
+    assert bool(oracle.predicate_rowwise(b, a, "within")[0]) == got
+    if got:  # a subset with an interior intersects
+        assert bool(oracle.predicate_rowwise(a, b, "intersects")[0])
+
+
+def test_polygon_contains_polygon_known_cases(oracle):
+    sq = lambda x0, y0, x1, y1: [(x0, y0), (x1, y0), (x1, y1), (x0, y1)]
+    cw = lambda r: list(reversed(r))
+    big, inner, hole = sq(0, 0, 10, 10), sq(2, 2, 4, 4), sq(3, 3, 7, 7)
+    u_shape = [(0, 0), (10, 0), (10, 10), (7, 10), (7, 3), (3, 3), (3, 10), (0, 10)]
+    cases = [
+        ([big], [inner], True),
+        ([big], [big], True),  # equal polygons: relate says contains
+        ([cw(big)], [inner], True),  # ring orientation of either operand is irrelevant
+        ([big], [cw(inner)], True),
+        ([inner], [big], False),
+        ([big], [sq(0, 0, 5, 5)], True),  # shares two boundary edges
+        ([big], [sq(5, 5, 12, 8)], False),  # pokes out
+        ([big], [sq(10, 0, 12, 5)], False),  # outside, shares an edge
+        ([big, hole], [inner], False),  # overlaps the hole
+        ([big, hole], [sq(3, 3, 7, 7)], False),  # fills the hole exactly
+        ([big, hole], [sq(0, 0, 3, 3)], True),  # touches the hole at one corner
+        ([big, hole], [sq(1, 1, 9, 9)], False),  # swallows the hole
+        ([big, hole], [sq(1, 1, 9, 9), sq(2, 2, 8, 8)], True),  # ... unless its own hole covers it
+        ([big, hole], [sq(1, 1, 9, 9), hole], True),  # ... exactly
+        ([big, hole], [sq(1, 1, 9, 9), sq(4, 4, 6, 6)], False),  # own hole too small
+        ([u_shape], [[(3, 10), (7, 10), (5, 12)]], False),
+        ([u_shape], [[(0, 10), (3, 10), (3, 3), (7, 3), (7, 10), (10, 10), (10, 0), (0, 0)]], True),
+        ([u_shape], [[(1, 9), (9, 9), (9, 1), (1, 1)]], False),  # edge crosses the notch between two touch points
+        ([u_shape], [[(3, 10), (7, 10), (7, 3), (3, 3)]], False),  # fills the notch: boundary in A, interior outside
+        ([u_shape], [[(0, 10), (3, 10), (10, 10), (10, 0), (0, 0)]], False),  # closes the notch with a collinear edge
+    ]
+    for pa, pb, exp in cases:
+        a, b = GeoArrowArray.from_polygons([pa]), GeoArrowArray.from_polygons([pb])
+        assert contains_bruteforce(pa, pb) == exp, (pa, pb)
+        assert bool(oracle.predicate_rowwise(a, b, "contains")[0]) == exp, (pa, pb)
+    # multipolygon operands: a member must hold the whole right polygon; a multipolygon right side needs every member held
+    two = GeoArrowArray.from_multipolygons([[[sq(0, 0, 4, 4)], [sq(6, 0, 10, 4)]]])
+    assert bool(oracle.predicate_rowwise(two, GeoArrowArray.from_polygons([[sq(7, 1, 9, 3)]]), "contains")[0])
+    assert not bool(oracle.predicate_rowwise(two, GeoArrowArray.from_polygons([[sq(3, 1, 7, 3)]]), "contains")[0])
+    assert bool(oracle.predicate_rowwise(GeoArrowArray.from_polygons([[big]]), two, "contains")[0])
+    assert not bool(oracle.predicate_rowwise(GeoArrowArray.from_polygons([[sq(0, 0, 5, 5)]]), two, "contains")[0])
+    # empty and invalid operands are never contained / never contain
+    empty = GeoArrowArray.from_polygons([[]])
+    assert not bool(oracle.predicate_rowwise(GeoArrowArray.from_polygons([[big]]), empty, "contains")[0])
+    assert not bool(oracle.predicate_rowwise(empty, GeoArrowArray.from_polygons([[big]]), "contains")[0])
+
+
+def concentric_pair(rng):
+    """A = star with a hole; B = star on the same fan squeezed between A's hole and A's exterior, often touching or
+    coinciding with either, with an own hole that may or may not cover A's hole: the cases rule (2) exists for."""
+    ro = [rng.randint(4, 10) for _ in range(8)]
+    rh = [rng.randint(1, r - 1) for r in ro]
+    pa = [star(0, 0, ro)] + ([star(0, 0, rh)] if rng.random() < 0.8 else [])
+    bo = [rng.randint(max(1, h - 1), r) if rng.random() < 0.8 else r for h, r in zip(rh, ro)]
+    if rng.random() < 0.2:
+        bo = list(ro)
+    if rng.random() < 0.1:
+        bo = list(rh)
+    bh = [max(1, min(rng.randint(h - 1, h + 1), o - 1)) if rng.random() < 0.7 else min(h, o) for h, o in zip(rh, bo)]
+    if rng.random() < 0.3:
+        bh = [min(h, o) for h, o in zip(rh, bo)]
+    pb = [star(0, 0, bo)]
+    if rng.random() < 0.7 and all(o >= 2 for o in bo) and all(0 < h <= o for h, o in zip(bh, bo)) and sum(h == o for h, o in zip(bh, bo)) <= 1:
+        pb.append(star(0, 0, bh))
+    return pa, pb
+
+
+def test_polygon_contains_polygon_concentric_rings(oracle):
+    import random
+
+    rng = random.Random(20241008)
+    pairs = [concentric_pair(rng) for _ in range(1500)]
+    a = GeoArrowArray.from_polygons([p for p, _ in pairs])
+    b = GeoArrowArray.from_polygons([q for _, q in pairs])
+    got = oracle.predicate_rowwise(a, b, "contains").astype(bool)
+    exp = np.array([contains_bruteforce(p, q) for p, q in pairs])
+    assert 300 < exp.sum() < 1200  # both answers are well represented
+    assert np.array_equal(got, exp)
