@@ -103,12 +103,15 @@ void profile_end(void* token, hipStream_t s);
 
 // Launch wrapper: every kernel of the library goes through this so bench.py can read per-kernel
 // HIP-event durations on the launching stream (gpk_profile_query).
+bool debug_sync();  // GPK_DEBUG_SYNC=1: name every launch on stderr and wait for it (locating a faulting kernel)
 #define GPK_LAUNCH(name, kernel, grid, block, shmem, stream, ...)                        \
     do {                                                                                 \
         void* _tok = nullptr;                                                            \
         if (::gpk::profiling_enabled()) ::gpk::profile_begin(name, stream, &_tok);       \
+        if (::gpk::debug_sync()) fprintf(stderr, "[gpk] launch %s\n", name);              \
         hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);             \
         if (_tok) ::gpk::profile_end(_tok, stream);                                      \
+        if (::gpk::debug_sync()) (void)hipStreamSynchronize(stream);                     \
         hipError_t _le = hipGetLastError();                                              \
         if (_le != hipSuccess)                                                           \
             return ::gpk::fail(GPK_ERR_DEVICE, "launch of %s failed: %s", name,          \

@@ -20,6 +20,8 @@
 #include "gpk_index.h"
 #include "gpk_pip.h"
 #include "gpk_polypoly.h"
+#include "gpk_contains.h"
+#include "gpk_lineal.h"
 #include "gpk_scan.h"
 
 namespace gpk {
@@ -726,31 +728,23 @@ __global__ __launch_bounds__(256) void pair_refine_kernel(DevGeo left, DevGeo ri
     }
 }
 
-// Contains<Coord> for Line / LineString / MultiLineString (geo 0.27 algorithm/contains/{line,line_string}.rs), reached from
-// the join dispatch spatial_index.rs:126-135 (`line.contains(point)` whichever side the point is on): the point lies on
-// the linestring and is not one of its two end points (unless the linestring is closed).  Exact orientation.
-__device__ inline bool line_contains_coord(double2 s, double2 e, double px, double py) {
-    if (s.x == e.x && s.y == e.y) return s.x == px && s.y == py;
-    if ((px == s.x && py == s.y) || (px == e.x && py == e.y)) return false;
-    return dev::orient2d(s.x, s.y, e.x, e.y, px, py) == 0 && dev::value_in_between(px, s.x, e.x) && dev::value_in_between(py, s.y, e.y);
-}
-__device__ inline bool linestring_contains_coord(const double2* __restrict__ xy, int n, double px, double py) {
-    if (n == 0) return false;
-    const double2 f = xy[0], l = xy[n - 1];
-    if ((px == f.x && py == f.y) || (px == l.x && py == l.y)) return f.x == l.x && f.y == l.y;
-    for (int i = 0; i + 1 < n; ++i) {
-        const double2 a = xy[i], b = xy[i + 1];
-        if (line_contains_coord(a, b, px, py)) return true;
-        if (i > 0 && px == a.x && py == a.y) return true;
+// Contains<Polygon> for Polygon / MultiPolygon (spatial_index.rs:99-101,107-111; gpk_contains.h): the right polygon can only
+// lie in a left geometry whose box holds its box, which settles most candidates of the (closed-overlap) candidate list.
+__global__ __launch_bounds__(256) void pair_contains_kernel(DevGeo left, DevGeo right, const uint32_t* __restrict__ cand_l,
+                                                             const uint32_t* __restrict__ cand_r, int64_t n_cand,
+                                                             const double4* __restrict__ lbbox, const double4* __restrict__ rbbox,
+                                                             uint8_t* __restrict__ hit) {
+    const int lane = threadIdx.x & (JOIN_GS - 1);
+    const int64_t groups = (int64_t)gridDim.x * (256 / JOIN_GS);
+    for (int64_t c = (int64_t)blockIdx.x * (256 / JOIN_GS) + threadIdx.x / JOIN_GS; c < n_cand; c += groups) {
+        const int64_t i = (int64_t)cand_l[c], j = (int64_t)cand_r[c];
+        const double4 lb = lbbox[i], rb = rbbox[j];
+        bool h = false;
+        if (rb.x >= lb.x && rb.y >= lb.y && rb.z <= lb.z && rb.w <= lb.w) h = cont::polygonal_contains_polygonal_group<JOIN_GS>(left, i, right, j, lane);
+        if (lane == 0) hit[c] = h;
     }
-    return false;
 }
-__device__ inline bool lineal_contains_point(const DevGeo& a, int64_t g, double px, double py) {
-    if (a.type == GPK_GEOM_LINESTRING) return linestring_contains_coord(a.xy + a.geom_off[g], a.geom_off[g + 1] - a.geom_off[g], px, py);
-    for (int l = a.geom_off[g]; l < a.geom_off[g + 1]; ++l)  // MULTILINESTRING: any member
-        if (linestring_contains_coord(a.xy + a.ring_off[l], a.ring_off[l + 1] - a.ring_off[l], px, py)) return true;
-    return false;
-}
+
 __global__ __launch_bounds__(256) void lineal_point_refine_kernel(DevGeo left, DevGeo right, const uint32_t* __restrict__ cand_l,
                                                                    const uint32_t* __restrict__ cand_r, int64_t n_cand,
                                                                    uint8_t* __restrict__ hit) {
@@ -794,7 +788,7 @@ static inline dim3 grid_for(int64_t n, int block) {
 }
 
 // polygonal x polygonal: candidates (count, scan, fill) -> pair-parallel exact refine -> hits (count, scan, emit)
-enum { REFINE_POLYGONAL = 0, REFINE_LINEAL_POINT = 1 };
+enum { REFINE_POLYGONAL = 0, REFINE_LINEAL_POINT = 1, REFINE_CONTAINS = 2 };
 static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, const gpk_index* right_index, uint32_t left_row_base,
                          uint32_t* out_counts, uint32_t* out_pairs, int64_t pair_capacity, int64_t* n_pairs, int32_t out_space,
                          hipStream_t s, int refine = REFINE_POLYGONAL) {
@@ -860,6 +854,10 @@ static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, co
             if (refine == REFINE_LINEAL_POINT)
                 GPK_LAUNCH("gpk_lineal_point_refine", lineal_point_refine_kernel, dim3((unsigned)(((int64_t)n_cand + 255) / 256)), dim3(256), 0, s,
                            left->d, right->d, (const uint32_t*)cand_l, (const uint32_t*)cand_r, (int64_t)n_cand, hit);
+            else if (refine == REFINE_CONTAINS)
+                GPK_LAUNCH("gpk_pair_contains", pair_contains_kernel, dim3((unsigned)blocks), dim3(256), 0, s, left->d, right->d,
+                           (const uint32_t*)cand_l, (const uint32_t*)cand_r, (int64_t)n_cand, (const double4*)lbbox,
+                           right_index->v.bbox, hit);
             else
                 GPK_LAUNCH("gpk_pair_refine", pair_refine_kernel, dim3((unsigned)blocks), dim3(256), 0, s, left->d, right->d,
                            (const uint32_t*)cand_l, (const uint32_t*)cand_r, (int64_t)n_cand, (const double4*)lbbox,
@@ -1201,12 +1199,11 @@ int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right, co
     const bool polypoly = is_polygonal(left->d.type) && is_polygonal(right->d.type);
     if (is_polygonal(left->d.type) && right->d.type == GPK_GEOM_POINT)  // the same test with the polygon on the left (:92,96)
         return swapped_pip_join(left, right, left_row_base, out_counts, out_pairs, pair_capacity, n_pairs, out_space, s);
-    if (polypoly && predicate != GPK_PRED_INTERSECTS)
-        return fail(GPK_ERR_MISMATCHED_GEOMETRY,
-                    "spatial_join: contains/within(polygon, polygon) is a DE-9IM relate upstream and is not implemented");
+    // polygonal pairs: `intersects` (:102-104,112-123) and `contains` with a POLYGON on the right (:99-101,107-111) have arms
+    const bool polypoly_arm = polypoly && (predicate == GPK_PRED_INTERSECTS || (predicate == GPK_PRED_CONTAINS && right->d.type == GPK_GEOM_POLYGON));
     auto lineal = [](int32_t t) { return t == GPK_GEOM_LINESTRING || t == GPK_GEOM_MULTILINESTRING; };
     const bool lineal_point = (left->d.type == GPK_GEOM_POINT && lineal(right->d.type)) || (lineal(left->d.type) && right->d.type == GPK_GEOM_POINT);
-    if (!pip && !polypoly && !lineal_point) {  // `_ => false` (spatial_index.rs:136): an empty join, not an error
+    if (!pip && !polypoly_arm && !lineal_point) {  // `_ => false` (spatial_index.rs:136): an empty join, not an error
         if (out_counts && left->d.n_geoms > 0) {
             if (out_space == GPK_MEM_DEVICE)
                 GPK_HIP(hipMemsetAsync(out_counts, 0, sizeof(uint32_t) * (size_t)left->d.n_geoms, s));
@@ -1230,7 +1227,9 @@ int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right, co
 
     const int64_t n = left->d.n_geoms;
     if (n == 0) return done(GPK_OK);
-    if (polypoly) return done(bbox_join(left, right, right_index, left_row_base, out_counts, out_pairs, pair_capacity, n_pairs, out_space, s));
+    if (polypoly)
+        return done(bbox_join(left, right, right_index, left_row_base, out_counts, out_pairs, pair_capacity, n_pairs, out_space, s,
+                              predicate == GPK_PRED_CONTAINS ? REFINE_CONTAINS : REFINE_POLYGONAL));
     if (lineal_point)
         return done(bbox_join(left, right, right_index, left_row_base, out_counts, out_pairs, pair_capacity, n_pairs, out_space, s, REFINE_LINEAL_POINT));
     const bool host_out = out_space != GPK_MEM_DEVICE;

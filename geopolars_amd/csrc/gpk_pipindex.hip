@@ -549,7 +549,8 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
     keep(slab_base);
     GPK_TRY(t.alloc(&nrows, (size_t)n_rings));
     unsigned long long* btot;
-    const int64_t max_scan = n_cells > d.n_coords ? n_cells : d.n_coords;
+    int64_t max_scan = n_cells > d.n_coords ? n_cells : d.n_coords;  // longest array scanned with btot (grown below for the slabs)
+    if (n_rings > max_scan) max_scan = n_rings;
     GPK_TRY(t.alloc(&btot, (size_t)((max_scan + 255) / 256 + 4)));
     FineGrid gs = g;  // slab rows: PIP_SLAB_MUL per raster row (exact power-of-two refinement of the same function)
     gs.R = g.R * PIP_SLAB_MUL;
@@ -562,6 +563,10 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
     int32_t n_slabs = 0;
     GPK_HIP(hipMemcpyAsync(&n_slabs, slab_base + n_rings, sizeof n_slabs, hipMemcpyDeviceToHost, s));
     GPK_HIP(hipStreamSynchronize(s));
+    if ((int64_t)n_slabs > max_scan) {  // few-vertex rings spanning many slab rows: more slabs than coordinates
+        max_scan = n_slabs;
+        GPK_TRY(t.alloc(&btot, (size_t)((max_scan + 255) / 256 + 4)));
+    }
     int32_t *slab_cnt, *slab_off = nullptr, *cursor;
     GPK_TRY(t.alloc(&slab_cnt, (size_t)n_slabs + 1));
     GPK_TRY(t.alloc(&cursor, (size_t)n_slabs + 1));

@@ -16,6 +16,8 @@
 
 #include "gpk_device.h"
 #include "gpk_polypoly.h"
+#include "gpk_contains.h"
+#include "gpk_lineal.h"
 #include "gpk_scan.h"
 
 namespace gpk {
@@ -557,6 +559,35 @@ __global__ __launch_bounds__(256) void poly_poly_intersects_kernel(DevGeo a, Dev
     }
 }
 
+// row-wise contains(polygonal, polygonal) (gpk_contains.h); within(a, b) = contains(b, a): `swap` exchanges the roles
+__global__ __launch_bounds__(256) void poly_poly_contains_kernel(DevGeo a, DevGeo b, const uint32_t* __restrict__ rows, bool swap,
+                                                                  uint8_t* __restrict__ out) {
+    const int lane = threadIdx.x & (PP_GS - 1);
+    const int64_t groups = (int64_t)gridDim.x * (256 / PP_GS);
+    for (int64_t i = (int64_t)blockIdx.x * (256 / PP_GS) + threadIdx.x / PP_GS; i < a.n_geoms; i += groups) {
+        const int64_t j = rows ? (int64_t)rows[i] : i;
+        bool hit = false;
+        if (dev::valid_row(a.validity, i) && dev::valid_row(b.validity, j))
+            hit = swap ? cont::polygonal_contains_polygonal_group<PP_GS>(b, j, a, i, lane)
+                       : cont::polygonal_contains_polygonal_group<PP_GS>(a, i, b, j, lane);
+        if (lane == 0) out[i] = hit;
+    }
+}
+
+// row-wise contains(lineal, point) / within(point, lineal): one lane per row (gpk_lineal.h)
+__global__ void lineal_point_contains_kernel(DevGeo a, DevGeo b, const uint32_t* __restrict__ rows, bool lineal_is_a,
+                                             uint8_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_geoms) return;
+    const int64_t j = rows ? (int64_t)rows[i] : i;
+    bool hit = false;
+    if (dev::valid_row(a.validity, i) && dev::valid_row(b.validity, j)) {
+        const double2 p = lineal_is_a ? b.xy[j] : a.xy[i];
+        if (p.x == p.x && p.y == p.y) hit = lineal_is_a ? lineal_contains_point(a, i, p.x, p.y) : lineal_contains_point(b, j, p.x, p.y);
+    }
+    out[i] = hit;
+}
+
 __global__ void point_point_equal_kernel(DevGeo a, DevGeo b, const uint32_t* __restrict__ rows, uint8_t* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_geoms) return;
@@ -749,6 +780,7 @@ int32_t gpk_predicate_rowwise(const gpk_geoarray* a, const gpk_geoarray* b, cons
 
     // contains(a, b): a polygonal, b point -> Inside.  within(a, b) == contains(b, a): a point, b polygonal.
     // intersects: either order, boundary counts.
+    auto is_lineal = [](int t) { return t == GPK_GEOM_LINESTRING || t == GPK_GEOM_MULTILINESTRING; };
     const bool a_poly_b_pt = is_polygonal(ta) && tb == GPK_GEOM_POINT;
     const bool a_pt_b_poly = ta == GPK_GEOM_POINT && is_polygonal(tb);
     bool run_pp = false, boundary = false, rows_index_polys = false;
@@ -784,10 +816,13 @@ int32_t gpk_predicate_rowwise(const gpk_geoarray* a, const gpk_geoarray* b, cons
         GPK_LAUNCH("gpk_poly_poly_intersects", poly_poly_intersects_kernel, coop_grid(n, PP_GS), block, 0, s, a->d, b->d, rows_dev, out_dev);
     } else if (ta == GPK_GEOM_POINT && tb == GPK_GEOM_POINT) {
         GPK_LAUNCH("gpk_point_point_equal", point_point_equal_kernel, flat, block, 0, s, a->d, b->d, rows_dev, out_dev);
-    } else if ((predicate == GPK_PRED_CONTAINS && is_polygonal(ta) && is_polygonal(tb)) ||
-               (predicate == GPK_PRED_WITHIN && is_polygonal(ta) && is_polygonal(tb))) {
-        return fail(GPK_ERR_MISMATCHED_GEOMETRY,
-                    "contains/within(polygon, polygon) is a DE-9IM relate upstream and is not implemented");
+    } else if (is_polygonal(ta) && is_polygonal(tb)) {  // contains / within
+        GPK_LAUNCH("gpk_poly_poly_contains", poly_poly_contains_kernel, coop_grid(n, PP_GS), block, 0, s, a->d, b->d, rows_dev,
+                   predicate == GPK_PRED_WITHIN, out_dev);
+    } else if ((predicate == GPK_PRED_CONTAINS && is_lineal(ta) && tb == GPK_GEOM_POINT) ||
+               (predicate == GPK_PRED_WITHIN && ta == GPK_GEOM_POINT && is_lineal(tb))) {
+        GPK_LAUNCH("gpk_lineal_point_contains", lineal_point_contains_kernel, flat, block, 0, s, a->d, b->d, rows_dev,
+                   predicate == GPK_PRED_CONTAINS, out_dev);
     } else {
         // combinations the reference's dispatch table maps to `false` (spatial_index.rs:136)
         GPK_LAUNCH("gpk_fill_u8", fill_u8_kernel, flat, block, 0, s, out_dev, n, (uint8_t)0);

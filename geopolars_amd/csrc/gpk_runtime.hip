@@ -91,6 +91,13 @@ static std::vector<ProfRec*> g_prof;
 static std::vector<ProfRec*> g_prof_pool;  // recycled records: hipEventCreate is not free inside a timed region
 
 bool profiling_enabled() { return g_prof_on; }
+bool debug_sync() {
+    static const bool on = [] {
+        const char* e = getenv("GPK_DEBUG_SYNC");
+        return e && *e && *e != '0';
+    }();
+    return on;
+}
 void profile_begin(const char* name, hipStream_t s, void** token) {
     ProfRec* r = nullptr;
     *token = nullptr;

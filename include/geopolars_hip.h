@@ -177,7 +177,10 @@ int32_t gpk_convex_hull(const gpk_geoarray* a, double* out_xy, int32_t* out_ring
 int32_t gpk_distance_rowwise(const gpk_geoarray* a, const gpk_geoarray* b, const uint32_t* b_rows,
                              double* out, int32_t out_space, void* stream);
 /* contains / within / intersects row-wise (north-star additions to the trait; semantics from the
- * dispatch table spatial_index.rs:89-137).  out[n] bytes 0/1. */
+ * dispatch table spatial_index.rs:89-137, geo 0.27 traits).  out[n] bytes 0/1.  Pairs with an answer:
+ * point x polygonal (all three), polygonal x polygonal (intersects; contains / within = "the contained side
+ * is not empty and a subset of the other", every member of a multipolygon counted), lineal contains point /
+ * point within lineal, point x point (equality); any other pair is false. */
 int32_t gpk_predicate_rowwise(const gpk_geoarray* a, const gpk_geoarray* b, const uint32_t* b_rows,
                               int32_t predicate, uint8_t* out, int32_t out_space, void* stream);
 
@@ -196,9 +199,10 @@ int32_t gpk_index_nbytes(const gpk_index* idx, int64_t* out_bytes);
  *   *n_pairs             total hits (always set; GPK_ERR_CAPACITY if > cap and pairs requested)
  * `right_index` may be NULL (built on the fly like spatial_index.rs:60-71).
  * Geometry dispatch = the match of spatial_index.rs:89-137: point <-> polygon / multipolygon on either side
- * (`poly.contains(point)` whatever the predicate), polygonal x polygonal `intersects` (`contains` there is a DE-9IM relate
- * upstream: GPK_ERR_MISMATCHED_GEOMETRY), point <-> linestring / multilinestring on either side (`line.contains(point)`);
- * every other combination is upstream's `_ => false`: an empty result, not an error.
+ * (`poly.contains(point)` whatever the predicate), polygonal x polygonal `intersects`, polygon / multipolygon x POLYGON
+ * `contains` (:99-101,107-111; upstream's DE-9IM relate restated as "right is not empty and a subset of left"),
+ * point <-> linestring / multilinestring on either side (`line.contains(point)`); every other combination (e.g. `contains`
+ * with a multipolygon on the right, `within` for polygonal pairs) is upstream's `_ => false`: an empty result, not an error.
  * `left_row_base` is added to every emitted l (row-sharded multi-GPU runs).
  */
 int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right,

@@ -375,8 +375,10 @@ static int cring_init(cring* r, const double* xy, int64_t n) {
     r->xy = xy;
     r->m = n - 1;
     int64_t k = 0;
-    for (int64_t i = 1; i < r->m; ++i)
+    for (int64_t i = 0; i < r->m; ++i) {
+        if (isnan(xy[2 * i]) || isnan(xy[2 * i + 1])) return 0;
         if (xy[2 * i] < xy[2 * k] || (xy[2 * i] == xy[2 * k] && xy[2 * i + 1] < xy[2 * k + 1])) k = i;
+    }
     const int64_t p = cr_prev_distinct(r, k), q = cr_next_distinct(r, k);
     if (p < 0 || q < 0) return 0;
     r->ccw = orient_pts(cr_v(r, p), cr_v(r, k), cr_v(r, q));

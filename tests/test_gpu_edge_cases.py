@@ -198,3 +198,23 @@ def test_small_polygons_inside_big_ones(gpk, oracle):
     got_pairs, got_counts = join_pairs(GeoSeries(pts), GeoSeries(polys), "intersects")
     assert np.array_equal(got_counts, exp_counts) and np.array_equal(got_pairs, exp_pairs)
     assert np.bincount(exp_counts)[2] > 10_000
+
+
+def test_few_vertex_rings_spanning_the_whole_raster(gpk, oracle):
+    """Rings with 8 vertices that each cover most of the extent: far more slab rows than coordinates (the scan scratch
+    of the index build is sized by the longest scanned array, which here is the slab table), hundreds of overlapping
+    parts per cell, and points on the integer lattice (vertices, edges) and off it."""
+    import random
+
+    from .lattice import concentric_pair, random_pair
+
+    rng = random.Random(77)
+    polys = [p for pair in (concentric_pair(rng) for _ in range(100)) for p in pair] + [p for pair in (random_pair(rng) for _ in range(100)) for p in pair]
+    right = GeoArrowArray.from_polygons(polys)
+    g = np.random.default_rng(78)
+    pts = np.concatenate([g.integers(-14, 15, (6000, 2)).astype(np.float64), g.integers(-28, 29, (6000, 2)) / 2.0, g.uniform(-14, 14, (6000, 2))])
+    left = GeoArrowArray.from_points(pts)
+    exp_pairs, exp_counts, _ = oracle.spatial_join(left, right, "intersects", mode=1)
+    assert exp_counts.max() > 50
+    got_pairs, got_counts = join_pairs(GeoSeries(left), GeoSeries(right), "intersects")
+    assert np.array_equal(got_counts, exp_counts) and np.array_equal(got_pairs, exp_pairs)

@@ -127,14 +127,6 @@ def test_multipolygon_polygon_intersects_join(gpk, oracle):
         assert np.array_equal(got_counts, exp_counts) and np.array_equal(got_pairs, exp_pairs)
 
 
-def test_polygon_contains_polygon_is_reported_unsupported(gpk):
-    from geopolars_amd import _abi
-
-    a = GeoSeries(synth.clustered_polygons(10, seed=1))
-    with pytest.raises(_abi.MismatchedGeometry):
-        join_pairs(a, a, "contains")
-
-
 def test_count_only_and_capacity_contract(gpk, oracle):
     """C ABI contract of gpk_spatial_join: count-only calls (no pair buffer) and a too-small pair buffer
     (GPK_ERR_CAPACITY with the exact total reported, the first `capacity` pairs written)."""

@@ -12,6 +12,8 @@ from hypothesis import strategies as st
 from geopolars_amd import _abi
 from geopolars_amd.geoarrow import GeoArrowArray
 
+from .lattice import concentric_pair, random_pair, star, star_with_hole
+
 F = Fraction
 coord = st.integers(-50, 50)
 point = st.tuples(coord, coord)
@@ -31,12 +33,6 @@ def seg_intersect(a, b, c, d) -> bool:
     if o1 != o2 and o3 != o4:
         return True
     return on_segment(a, b, c) or on_segment(a, b, d) or on_segment(c, d, a) or on_segment(c, d, b)
-
-
-def star(cx, cy, radii):
-    """simple polygon with integer vertices: one vertex per direction of a fixed fan of 8 integer directions"""
-    dirs = [(1, 0), (1, 1), (0, 1), (-1, 1), (-1, 0), (-1, -1), (0, -1), (1, -1)]
-    return [(cx + r * dx, cy + r * dy) for r, (dx, dy) in zip(radii, dirs)]
 
 
 stars = st.builds(star, coord, coord, st.lists(st.integers(1, 12), min_size=8, max_size=8))
@@ -240,20 +236,6 @@ def contains_bruteforce(pa, pb) -> bool:
     return True
 
 
-def star_with_hole(cx, cy, radii, hole_radii, touch):
-    """outer star plus, optionally, a hole on the same fan (radius strictly smaller in every direction, equal in at most
-    one direction when `touch`: a hole may touch the exterior in one point)"""
-    outer = star(cx, cy, radii)
-    if hole_radii is None:
-        return [outer]
-    hr = [max(1, min(h, r - 1)) for h, r in zip(hole_radii, radii)]
-    if any(r < 2 for r in radii):
-        return [outer]
-    if touch is not None:
-        hr[touch] = radii[touch]
-    return [outer, star(cx, cy, hr)]
-
-
 small = st.integers(-6, 6)
 polys_with_holes = st.builds(
     star_with_hole,
@@ -319,26 +301,6 @@ def test_polygon_contains_polygon_known_cases(oracle):
     assert not bool(oracle.predicate_rowwise(empty, GeoArrowArray.from_polygons([[big]]), "contains")[0])
 
 
-def concentric_pair(rng):
-    """A = star with a hole; B = star on the same fan squeezed between A's hole and A's exterior, often touching or
-    coinciding with either, with an own hole that may or may not cover A's hole: the cases rule (2) exists for."""
-    ro = [rng.randint(4, 10) for _ in range(8)]
-    rh = [rng.randint(1, r - 1) for r in ro]
-    pa = [star(0, 0, ro)] + ([star(0, 0, rh)] if rng.random() < 0.8 else [])
-    bo = [rng.randint(max(1, h - 1), r) if rng.random() < 0.8 else r for h, r in zip(rh, ro)]
-    if rng.random() < 0.2:
-        bo = list(ro)
-    if rng.random() < 0.1:
-        bo = list(rh)
-    bh = [max(1, min(rng.randint(h - 1, h + 1), o - 1)) if rng.random() < 0.7 else min(h, o) for h, o in zip(rh, bo)]
-    if rng.random() < 0.3:
-        bh = [min(h, o) for h, o in zip(rh, bo)]
-    pb = [star(0, 0, bo)]
-    if rng.random() < 0.7 and all(o >= 2 for o in bo) and all(0 < h <= o for h, o in zip(bh, bo)) and sum(h == o for h, o in zip(bh, bo)) <= 1:
-        pb.append(star(0, 0, bh))
-    return pa, pb
-
-
 def test_polygon_contains_polygon_concentric_rings(oracle):
     import random
 
@@ -349,4 +311,17 @@ def test_polygon_contains_polygon_concentric_rings(oracle):
     got = oracle.predicate_rowwise(a, b, "contains").astype(bool)
     exp = np.array([contains_bruteforce(p, q) for p, q in pairs])
     assert 300 < exp.sum() < 1200  # both answers are well represented
+    assert np.array_equal(got, exp)
+
+
+def test_polygon_contains_polygon_random_neighbours(oracle):
+    import random
+
+    rng = random.Random(5)
+    pairs = [random_pair(rng) for _ in range(3000)]
+    a = GeoArrowArray.from_polygons([p for p, _ in pairs])
+    b = GeoArrowArray.from_polygons([q for _, q in pairs])
+    got = oracle.predicate_rowwise(a, b, "contains").astype(bool)
+    exp = np.array([contains_bruteforce(p, q) for p, q in pairs])
+    assert 50 < exp.sum() < 1500
     assert np.array_equal(got, exp)
