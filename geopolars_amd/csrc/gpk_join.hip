@@ -663,11 +663,15 @@ __device__ __forceinline__ void for_each_bbox_candidate(const IndexView& ix, con
 }
 
 // Stage 1: candidates.  One lane per left row lists the right rows whose closed bbox overlaps the row's bbox
-// (count pass, then fill pass into the row's slice, sorted by right id: the hits then come out sorted).
+// (count pass, then fill pass into the row's slice, sorted by right id: the hits then come out sorted).  Rows with a
+// handful of candidates sort their slice in place; a row with more than CAND_INLINE_SORT (one country against a
+// column of parcels) raises *big_rows in the count pass and every slice goes through one segmented radix sort instead.
+constexpr int CAND_INLINE_SORT = 48;
 template <bool WRITE>
 __global__ __launch_bounds__(256) void bbox_cand_kernel(DevGeo left, DevGeo right, IndexView ix, const double4* __restrict__ lbbox,
                                                          int32_t* __restrict__ cand_cnt, const int32_t* __restrict__ cand_off,
-                                                         uint32_t* __restrict__ cand_r, uint32_t* __restrict__ cand_l) {
+                                                         uint32_t* __restrict__ cand_r, uint32_t* __restrict__ cand_l,
+                                                         int32_t* __restrict__ big_rows) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= left.n_geoms) return;
     int cnt = 0;
@@ -682,9 +686,10 @@ __global__ __launch_bounds__(256) void bbox_cand_kernel(DevGeo left, DevGeo righ
     }
     if (!WRITE) {
         cand_cnt[i] = cnt;
+        if (cnt > CAND_INLINE_SORT) *big_rows = 1;
         return;
     }
-    for (int a = 1; a < cnt; ++a) {  // rows have a handful of candidates
+    for (int a = 1; a < cnt && cnt <= CAND_INLINE_SORT; ++a) {  // rows have a handful of candidates
         const uint32_t key = cand_r[o0 + a];
         int b = a - 1;
         while (b >= 0 && cand_r[o0 + b] > key) {
@@ -810,7 +815,7 @@ static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, co
     const int64_t nb = (n + 255) / 256;
     const size_t pairs_bytes = sizeof(uint32_t) * 2 * (size_t)pair_capacity;
     const size_t i32n = align256(sizeof(int32_t) * (size_t)(n + 1));
-    size_t need = 4 * i32n + align256(sizeof(unsigned long long) * (size_t)(nb + 2)) + 1024;
+    size_t need = 4 * i32n + align256(sizeof(unsigned long long) * (size_t)(nb + 2)) + 256 + 1024;
     if (host_out && out_counts) need += align256(sizeof(uint32_t) * (size_t)n);
     if (host_out && want_pairs) need += align256(pairs_bytes);
     rc = workspace().begin(need);
@@ -820,33 +825,54 @@ static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, co
     int32_t* counts = (int32_t*)workspace().take(sizeof(int32_t) * (size_t)(n + 1));
     int32_t* offsets = (int32_t*)workspace().take(sizeof(int32_t) * (size_t)(n + 1));
     unsigned long long* btot = (unsigned long long*)workspace().take(sizeof(unsigned long long) * (size_t)(nb + 2));
+    int32_t* big_rows = (int32_t*)workspace().take(256);
     uint32_t* counts_out = out_counts ? (host_out ? (uint32_t*)workspace().take(sizeof(uint32_t) * (size_t)n) : out_counts) : nullptr;
     uint32_t* pairs_dev = want_pairs ? (host_out ? (uint32_t*)workspace().take(pairs_bytes) : out_pairs) : nullptr;
 
-    int32_t n_cand = 0;
+    int32_t n_cand = 0, has_big_rows = 0;
     auto stage1 = [&]() -> int32_t {
+        GPK_HIP(hipMemsetAsync(big_rows, 0, sizeof(int32_t), s));
         GPK_LAUNCH("gpk_bbox_cand_count", bbox_cand_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, left->d, right->d, right_index->v,
-                   lbbox, cand_cnt, (const int32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+                   lbbox, cand_cnt, (const int32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, big_rows);
         GPK_TRY(exclusive_scan_i32(cand_cnt, n, cand_off, nullptr, btot, s));
         GPK_HIP(hipMemcpyAsync(&n_cand, cand_off + n, sizeof n_cand, hipMemcpyDeviceToHost, s));
+        GPK_HIP(hipMemcpyAsync(&has_big_rows, big_rows, sizeof has_big_rows, hipMemcpyDeviceToHost, s));
         GPK_HIP(hipStreamSynchronize(s));
         return GPK_OK;
     };
     rc = stage1();
     if (rc != GPK_OK) return done(rc);
-    uint32_t *cand_r = nullptr, *cand_l = nullptr;
+    uint32_t *cand_r = nullptr, *cand_l = nullptr, *cand_sorted = nullptr;
     uint8_t* hit = nullptr;
+    void* seg_tmp = nullptr;
+    size_t seg_bytes = 0;
+    unsigned seg_bits = 1;
+    while (seg_bits < 32 && ((int64_t)1 << seg_bits) < right->d.n_geoms) ++seg_bits;
     {
         const size_t nc1 = (size_t)(n_cand > 0 ? n_cand : 1);
-        rc = workspace_aux(1).begin(2 * align256(sizeof(uint32_t) * nc1) + align256(nc1) + 256);
+        if (has_big_rows) {
+            const hipError_t qe = rocprim::segmented_radix_sort_keys(nullptr, seg_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (unsigned)n_cand,
+                                                                     (unsigned)n, (const int32_t*)cand_off, (const int32_t*)cand_off + 1, 0, seg_bits, s);
+            if (qe != hipSuccess) return done(fail(GPK_ERR_DEVICE, "spatial_join: %s", hipGetErrorString(qe)));
+        }
+        rc = workspace_aux(1).begin((has_big_rows ? 3 : 2) * align256(sizeof(uint32_t) * nc1) + align256(nc1) + align256(seg_bytes) + 512);
         if (rc != GPK_OK) return done(rc);
         cand_r = (uint32_t*)workspace_aux(1).take(sizeof(uint32_t) * nc1);
         cand_l = (uint32_t*)workspace_aux(1).take(sizeof(uint32_t) * nc1);
         hit = (uint8_t*)workspace_aux(1).take(nc1);
+        if (has_big_rows) {
+            cand_sorted = (uint32_t*)workspace_aux(1).take(sizeof(uint32_t) * nc1);
+            seg_tmp = workspace_aux(1).take(seg_bytes ? seg_bytes : 1);
+        }
     }
     auto stage23 = [&]() -> int32_t {
         GPK_LAUNCH("gpk_bbox_cand_fill", bbox_cand_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, left->d, right->d, right_index->v,
-                   lbbox, cand_cnt, (const int32_t*)cand_off, cand_r, cand_l);
+                   lbbox, cand_cnt, (const int32_t*)cand_off, cand_r, cand_l, big_rows);
+        if (has_big_rows && n_cand > 0) {  // some slice is long: sort every slice by right id, segment = left row
+            GPK_HIP(rocprim::segmented_radix_sort_keys(seg_tmp, seg_bytes, (const uint32_t*)cand_r, cand_sorted, (unsigned)n_cand, (unsigned)n,
+                                                       (const int32_t*)cand_off, (const int32_t*)cand_off + 1, 0, seg_bits, s));
+            cand_r = cand_sorted;
+        }
         if (n_cand > 0) {
             int64_t blocks = ((int64_t)n_cand + (256 / JOIN_GS) - 1) / (256 / JOIN_GS);
             const int64_t cap = (int64_t)cu_count() * 64;

@@ -251,3 +251,22 @@ def test_join_dispatch_arms_of_the_reference(gpk, oracle):
     for left, right in ((pts, pts), (lines, lines), (lines, polys), (polys, lines)):
         got_pairs, got_counts = join_pairs(GeoSeries(left), GeoSeries(right), "intersects")
         assert len(got_pairs) == 0 and not got_counts.any() and len(got_counts) == len(left)
+
+
+def test_one_row_with_tens_of_thousands_of_candidates(gpk, oracle):
+    """one polygon over the whole domain against a column of small ones (and the reverse): a candidate slice far beyond
+    the in-place sort of the fill pass goes through the segmented radix sort; pairs still come out sorted by (l, r)."""
+    rng = np.random.default_rng(8)
+    huge = synth.star_polygons(1, 64)
+    c = rng.uniform(0, 1000, (40_000, 2))
+    rings = np.empty((len(c), 5, 2))
+    for k, (sx, sy) in enumerate(((-1, -1), (1, -1), (1, 1), (-1, 1), (-1, -1))):
+        rings[:, k, 0] = c[:, 0] + sx * 0.5
+        rings[:, k, 1] = c[:, 1] + sy * 0.5
+    small = GeoArrowArray(_abi.GEOM_POLYGON, rings.reshape(-1, 2), geom_offsets=np.arange(len(c) + 1, dtype=np.int32), ring_offsets=np.arange(0, 5 * len(c) + 1, 5, dtype=np.int32))
+    for pred in ("intersects", "contains"):
+        for l, r in ((huge, small), (small, huge)):
+            exp_pairs, exp_counts, _ = oracle.spatial_join(l, r, pred, mode=1)
+            got_pairs, got_counts = join_pairs(GeoSeries(l), GeoSeries(r), pred)
+            assert np.array_equal(got_counts, exp_counts) and np.array_equal(got_pairs, exp_pairs)
+    assert len(exp_pairs) == 0  # a small square never contains the big star
