@@ -15,7 +15,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--c4", type=int, default=1_000_000)
 ap.add_argument("--c5-points", type=int, default=6_250_000)
 ap.add_argument("--c5-polys", type=int, default=1_000_000)
-ap.add_argument("--only", choices=["c4", "c5", "tess"], default=None)
+ap.add_argument("--only", choices=["c4", "c5", "tess", "contains"], default=None)
+ap.add_argument("--districts", type=int, default=100_000)
+ap.add_argument("--parcels", type=int, default=1_000_000)
 a = ap.parse_args()
 
 def t(f):
@@ -37,6 +39,22 @@ def kernel_ms(f, names):
     L.gpk_profile_reset()
     return out
 
+# ---- contains join: districts (8-64 vertices) x parcels (4-12 vertices, ~50x smaller) — spatial_index.rs:99-101 ----------
+if a.only == "contains":
+    D = synth.clustered_polygons(a.districts, seed=71, mean_neighbours=2.0)
+    Pc = synth.clustered_polygons(a.parcels, seed=72, mean_neighbours=0.02, min_verts=4, max_verts=12)
+    ds, pcs = GeoSeries(D), GeoSeries(Pc)
+    ds.device(); pcs.device()
+    idx, ms_idx = t(lambda: SpatialIndex(pcs))
+    (pairs, counts), ms_join = t(lambda: join_pairs(ds, pcs, "contains", r_index=idx))
+    (pairs, counts), ms_join2 = t(lambda: join_pairs(ds, pcs, "contains", r_index=idx))
+    kms = kernel_ms(lambda: join_pairs(ds, pcs, "contains", r_index=idx), ["gpk_bbox_cand_count", "gpk_bbox_cand_fill", "gpk_pair_contains", "gpk_pair_count", "gpk_pair_emit"])
+    (ipairs, _), ms_int = t(lambda: join_pairs(ds, pcs, "intersects", r_index=idx))
+    k = min(a.districts, 5000)
+    ep, ec, _ = O.spatial_join(slice_rows(D, 0, k), Pc, "contains", mode=1)
+    ok = np.array_equal(counts[:k], ec) and np.array_equal(pairs[: len(ep)], ep)
+    print(json.dumps({"config": "contains join", "left": a.districts, "right": a.parcels, "index_build_ms": ms_idx, "join_ms_first": ms_join, "join_ms": ms_join2, "kernel_ms": kms, "pairs": int(len(pairs)), "intersects_pairs": int(len(ipairs)), "intersects_join_ms": ms_int, "parity_prefix_rows": k, "parity": bool(ok)}), flush=True)
+    sys.exit(0)
 # ---- tessellation: 10M points in 1024 polygons that share every border (administrative-boundary shape) -------------------
 if a.only in (None, "tess"):
     T = synth.tessellation(32, 16); P = synth.uniform_points(10_000_000, seed=61)
