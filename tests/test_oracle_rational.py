@@ -325,3 +325,125 @@ def test_polygon_contains_polygon_random_neighbours(oracle):
     exp = np.array([contains_bruteforce(p, q) for p, q in pairs])
     assert 50 < exp.sum() < 1500
     assert np.array_equal(got, exp)
+
+
+# ---- more unpinned operators against exact / high-precision restatements -------------------------------------------------
+def _ring_moments(ring):
+    """(2*signed area, 6*area*cx, 6*area*cy) of a ring in exact integers"""
+    n = len(ring)
+    a2 = mx = my = 0
+    for i in range(n):
+        (x0, y0), (x1, y1) = ring[i], ring[(i + 1) % n]
+        w = x0 * y1 - x1 * y0
+        a2 += w
+        mx += (x0 + x1) * w
+        my += (y0 + y1) * w
+    return a2, mx, my
+
+
+@settings(max_examples=200, deadline=None)
+@given(st.lists(polys_with_holes, min_size=1, max_size=4))
+def test_area_and_centroid_of_polygons_with_holes_and_multipolygons(oracle, polys):
+    """area = |exterior| - sum |holes|; centroid = area-weighted mean of the rings' centroids with holes negative
+    (geo 0.27 area.rs / centroid.rs), rational arithmetic; the multipolygon of the same members adds the members up"""
+
+    def poly_stats(p):
+        a2 = mx = my = F(0)
+        for k, ring in enumerate(p):
+            r2, rx, ry = _ring_moments(ring)
+            s = 1 if r2 > 0 else -1  # orientation-free: work with |ring area| and its centroid
+            sign = 1 if k == 0 else -1
+            a2 += sign * s * r2
+            mx += sign * s * rx
+            my += sign * s * ry
+        return a2, mx, my
+
+    a = GeoArrowArray.from_polygons(polys)
+    area = oracle.area(a)
+    c, valid = oracle.centroid(a)
+    tot = [F(0), F(0), F(0)]
+    for i, p in enumerate(polys):
+        a2, mx, my = poly_stats(p)
+        assert a2 > 0 and valid[i]
+        assert area[i] == float(a2 / 2)
+        assert abs(c[i, 0] - float(mx / (3 * a2))) <= 1e-12 * max(1.0, abs(float(mx / (3 * a2))))
+        assert abs(c[i, 1] - float(my / (3 * a2))) <= 1e-12 * max(1.0, abs(float(my / (3 * a2))))
+        tot = [tot[0] + a2, tot[1] + mx, tot[2] + my]
+    m = GeoArrowArray.from_multipolygons([[p for p in polys]])
+    assert oracle.area(m)[0] == float(tot[0] / 2)
+    cm, vm = oracle.centroid(m)
+    assert vm[0]
+    assert abs(cm[0, 0] - float(tot[1] / (3 * tot[0]))) <= 1e-12 * max(1.0, abs(float(tot[1] / (3 * tot[0]))))
+    assert abs(cm[0, 1] - float(tot[2] / (3 * tot[0]))) <= 1e-12 * max(1.0, abs(float(tot[2] / (3 * tot[0]))))
+
+
+@settings(max_examples=200, deadline=None)
+@given(polys_with_holes, st.lists(point, min_size=1, max_size=12))
+def test_point_predicates_and_distance_against_polygon_with_hole(oracle, poly, pts):
+    """contains = strictly inside; intersects = inside or on the boundary; within(point, polygon) = contains;
+    distance = 0 unless outside (or in the hole), then the nearest boundary segment (Appendix A.4)"""
+    n = len(pts)
+    a = GeoArrowArray.from_polygons([poly] * n)
+    p = GeoArrowArray.from_points(pts)
+    pos = [_poly_pos(poly, q) for q in pts]
+    assert oracle.predicate_rowwise(a, p, "contains").tolist() == [x > 0 for x in pos]
+    assert oracle.predicate_rowwise(p, a, "within").tolist() == [x > 0 for x in pos]
+    assert oracle.predicate_rowwise(a, p, "intersects").tolist() == [x >= 0 for x in pos]
+    assert oracle.predicate_rowwise(p, a, "intersects").tolist() == [x >= 0 for x in pos]
+    d = oracle.distance_rowwise(p, a)
+    for i, q in enumerate(pts):
+        if pos[i] >= 0:
+            assert d[i] == 0.0
+            continue
+        best = None
+        for ring in poly:
+            for s, e in _edges(ring):
+                ab = (e[0] - s[0], e[1] - s[1])
+                ap = (q[0] - s[0], q[1] - s[1])
+                t = min(max(F(ap[0] * ab[0] + ap[1] * ab[1], ab[0] ** 2 + ab[1] ** 2), F(0)), F(1))
+                d2 = (F(ap[0]) - t * ab[0]) ** 2 + (F(ap[1]) - t * ab[1]) ** 2
+                best = d2 if best is None or d2 < best else best
+        exp = math.sqrt(float(best))
+        assert d[i] > 0.0 and abs(d[i] - exp) <= 1e-12 * exp
+
+
+@settings(max_examples=200, deadline=None)
+@given(st.lists(st.lists(point, min_size=0, max_size=9), min_size=1, max_size=5))
+def test_length_centroid_and_bounds_of_linestrings_and_multipoints(oracle, lines):
+    ls = GeoArrowArray.from_linestrings(lines)
+    length = oracle.euclidean_length(ls)
+    c, valid = oracle.centroid(ls)
+    b = oracle.bounds(ls)
+    for i, l in enumerate(lines):
+        segs = [(l[k], l[k + 1]) for k in range(len(l) - 1)]
+        lens = [math.hypot(e[0] - s[0], e[1] - s[1]) for s, e in segs]
+        tot = math.fsum(lens)
+        assert abs(length[i] - tot) <= 1e-12 * max(tot, 1e-300)
+        if not l:
+            assert not valid[i] and np.isnan(b[i]).all()
+            continue
+        assert b[i].tolist() == [min(x for x, _ in l), min(y for _, y in l), max(x for x, _ in l), max(y for _, y in l)]
+        assert valid[i]
+        if tot > 0:  # length-weighted mean of the segment mid points
+            ex = math.fsum(w * (s[0] + e[0]) / 2 for w, (s, e) in zip(lens, segs)) / tot
+            ey = math.fsum(w * (s[1] + e[1]) / 2 for w, (s, e) in zip(lens, segs)) / tot
+        else:  # all coordinates equal (or one coordinate): the mean of the points
+            ex, ey = float(F(sum(x for x, _ in l), len(l))), float(F(sum(y for _, y in l), len(l)))
+        assert abs(c[i, 0] - ex) <= 1e-12 * max(1.0, abs(ex)) and abs(c[i, 1] - ey) <= 1e-12 * max(1.0, abs(ey))
+    flat = [q for l in lines for q in l]
+    if flat:
+        mp = GeoArrowArray(_abi.GEOM_MULTIPOINT, np.array(flat, dtype=np.float64), geom_offsets=np.array([0, len(flat)], np.int32))
+        cm, vm = oracle.centroid(mp)
+        assert vm[0]
+        assert abs(cm[0, 0] - float(F(sum(x for x, _ in flat), len(flat)))) <= 1e-12 * 50
+        assert abs(cm[0, 1] - float(F(sum(y for _, y in flat), len(flat)))) <= 1e-12 * 50
+
+
+@settings(max_examples=100, deadline=None)
+@given(stars, st.lists(st.integers(-8, 8), min_size=6, max_size=6))
+def test_affine_transform_with_integer_matrices_is_exact(oracle, ring, m):
+    """[a, b, xoff, d, e, yoff] (upstream order, geo 0.27 AffineTransform::new): small integers leave no rounding"""
+    a = GeoArrowArray.from_polygons([[ring]])
+    out = oracle.affine_transform(a, m)
+    exp = [(m[0] * x + m[1] * y + m[2], m[3] * x + m[4] * y + m[5]) for x, y in _closed(ring)]
+    assert out.tolist() == [[float(x), float(y)] for x, y in exp]
