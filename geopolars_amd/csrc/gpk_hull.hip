@@ -3,8 +3,8 @@
 //
 // The hull of a point set is unique, so any exact algorithm returns the same ring up to its start
 // vertex; this kernel emits it starting at the lexicographically smallest vertex.  One lane per
-// geometry for the chain, 16 lanes per geometry for the sort (bitonic network in LDS; heap sort in global scratch for large
-// geometries), then a monotone chain driven by the exact
+// geometry for the chain, 16 lanes per geometry for the sort (bitonic network in LDS; a work-group per geometry beyond 128
+// points), then a monotone chain driven by the exact
 // orientation kernel.  Irregular per-row output sizes go through size -> scan -> compact.
 // This is the lowest-traffic operator of the surface; the sort's working set sits in LDS.
 #include "gpk_device.h"
@@ -13,37 +13,6 @@
 namespace gpk {
 
 __device__ __forceinline__ bool xy_less(double2 a, double2 b) { return a.x < b.x || (a.x == b.x && a.y < b.y); }
-
-// in-place heap sort of n points reached through ld(i) / st(i, v) (global scratch or the lane's LDS column)
-template <typename LD, typename ST>
-__device__ __forceinline__ void heap_sort(LD ld, ST st, int n) {
-    auto sift = [&](int root, int end) {
-        double2 rv = ld(root);
-        for (;;) {
-            int child = 2 * root + 1;
-            if (child >= end) break;
-            double2 cv = ld(child);
-            if (child + 1 < end) {
-                const double2 c2 = ld(child + 1);
-                if (xy_less(cv, c2)) {
-                    cv = c2;
-                    ++child;
-                }
-            }
-            if (!xy_less(rv, cv)) break;
-            st(root, cv);
-            root = child;
-        }
-        st(root, rv);
-    };
-    for (int start = n / 2 - 1; start >= 0; --start) sift(start, n);
-    for (int end = n - 1; end > 0; --end) {
-        const double2 t = ld(0);
-        st(0, ld(end));
-        st(end, t);
-        sift(0, end);
-    }
-}
 
 // monotone chain over n SORTED points read through ld(0..n) (duplicates allowed: they are skipped on the fly, in both
 // directions).  The stack holds point INDICES, behind put(k, i) / get(k) (the lane's column of an LDS tile, or global
@@ -134,7 +103,7 @@ __device__ __forceinline__ void geom_coord_range(const DevGeo& a, int64_t g, int
 //   hull_sort_kernel      HULL_GS lanes per geometry of at most HULL_CAP points: a bitonic network over the geometry's
 //                         points in LDS (coalesced loads and stores, no data-dependent addressing, 16 geometries per
 //                         work-group) — the lane-per-geometry heap sort made ~800 scattered accesses per geometry;
-//   hull_sort_big_kernel  one lane per geometry beyond HULL_CAP: heap sort in global scratch;
+//   hull_sort_big_kernel  one work-group per geometry beyond HULL_CAP: bitonic network in LDS / in the global scratch;
 //   hull_chain_kernel     one lane per geometry: monotone chain over its sorted points (sequential reads).
 // The closing duplicate of a ring is dropped before sorting (the chain skips duplicates anyway).
 constexpr int HULL_CAP = 128, HULL_GS = 16;
@@ -149,14 +118,18 @@ __device__ __forceinline__ int hull_points(const DevGeo& a, int64_t g, int& c0) 
     }
     return n;
 }
-__global__ __launch_bounds__(256) void hull_sort_kernel(DevGeo a, double2* __restrict__ sorted, int32_t* __restrict__ n_pts) {
+__global__ __launch_bounds__(256) void hull_sort_kernel(DevGeo a, double2* __restrict__ sorted, int32_t* __restrict__ n_pts,
+                                                        int32_t* __restrict__ big_list, int32_t* __restrict__ big_count) {
     __shared__ double2 lds[(256 / HULL_GS) * HULL_CAP];
     const int lane = threadIdx.x & (HULL_GS - 1);
     const int64_t g = ((int64_t)blockIdx.x * 256 + threadIdx.x) / HULL_GS;
     if (g >= a.n_geoms) return;
     int c0;
     const int n = hull_points(a, g, c0);
-    if (lane == 0) n_pts[g] = n;
+    if (lane == 0) {
+        n_pts[g] = n;
+        if (n > HULL_CAP) big_list[atomicAdd(big_count, 1)] = (int32_t)g;  // order is irrelevant: one work-group each
+    }
     if (n <= 0 || n > HULL_CAP) return;  // empty, or left to hull_sort_big_kernel
     double2* __restrict__ v = lds + (threadIdx.x / HULL_GS) * HULL_CAP;
     int P = 2;
@@ -183,16 +156,47 @@ __global__ __launch_bounds__(256) void hull_sort_kernel(DevGeo a, double2* __res
     sync();
     for (int i = lane; i < n; i += HULL_GS) sorted[c0 + i] = v[i];
 }
-__global__ __launch_bounds__(256) void hull_sort_big_kernel(DevGeo a, double2* __restrict__ sorted, const int32_t* __restrict__ n_pts) {
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= a.n_geoms) return;
-    const int n = n_pts[g];
-    if (n <= HULL_CAP) return;
-    int c0, c1;
-    geom_coord_range(a, g, c0, c1);
-    double2* p = sorted + c0;
-    for (int i = 0; i < n; ++i) p[i] = a.xy[c0 + i];
-    heap_sort([&](int i) { return p[i]; }, [&](int i, double2 v) { p[i] = v; }, n);
+// One work-group per geometry beyond HULL_CAP points (their ids were appended to big_list by hull_sort_kernel): the
+// normalised bitonic network — every comparator ascending, so a partner index beyond n is simply skipped, which is the
+// same as padding with +inf — over the geometry's points in LDS (up to HULL_BIG_LDS of them) or in place in the global
+// scratch.  A 100k-point ring takes 153 steps of 256 lanes instead of 3.4M dependent accesses of one lane.
+constexpr int HULL_BIG_LDS = 4096;
+__global__ __launch_bounds__(256) void hull_sort_big_kernel(DevGeo a, double2* __restrict__ sorted, const int32_t* __restrict__ n_pts,
+                                                            const int32_t* __restrict__ big_list, const int32_t* __restrict__ big_count) {
+    __shared__ double2 lds[HULL_BIG_LDS];
+    const int n_big = *big_count;
+    for (int b = blockIdx.x; b < n_big; b += gridDim.x) {
+        const int64_t g = big_list[b];
+        const int n = n_pts[g];
+        int c0, c1;
+        geom_coord_range(a, g, c0, c1);
+        const bool in_lds = n <= HULL_BIG_LDS;
+        double2* __restrict__ v = in_lds ? lds : sorted + c0;
+        for (int i = threadIdx.x; i < n; i += 256) v[i] = a.xy[c0 + i];
+        int P = 2;
+        while (P < n) P <<= 1;
+        auto step = [&](int mask) {  // partner of i: i ^ mask; the lower index of a pair owns the exchange
+            __syncthreads();
+            for (int i = threadIdx.x; i < n; i += 256) {
+                const int l = i ^ mask;
+                if (l > i && l < n) {
+                    const double2 x = v[i], y = v[l];
+                    if (xy_less(y, x)) {
+                        v[i] = y;
+                        v[l] = x;
+                    }
+                }
+            }
+        };
+        for (int k = 2; k <= P; k <<= 1) {
+            step(k - 1);  // flip: i <-> its mirror inside the block of k
+            for (int j = k >> 2; j > 0; j >>= 1) step(j);
+        }
+        __syncthreads();
+        if (in_lds)
+            for (int i = threadIdx.x; i < n; i += 256) sorted[c0 + i] = v[i];
+        __syncthreads();  // the LDS tile is reused by the next geometry of this work-group
+    }
 }
 // one wave per work-group: when every geometry of the wave has at most HULL_STACK points the index stacks sit in an LDS
 // tile, interleaved by lane (entry k of lane l at [k * 64 + l]); otherwise the wave keeps them in global scratch
@@ -249,7 +253,7 @@ extern "C" int32_t gpk_convex_hull(const gpk_geoarray* a, double* out_xy, int32_
     const bool host_out = out_space != GPK_MEM_DEVICE;
     size_t need = align256(sizeof(double2) * (size_t)(nc + 1)) + align256(sizeof(double2) * (2 * (size_t)nc + 2 * (size_t)n + 2)) +
                   2 * align256(off_bytes) + align256(sizeof(unsigned long long) * (size_t)(nb + 2)) +
-                  align256(sizeof(int32_t) * (2 * (size_t)nc + 2 * (size_t)n + 2)) + 1024;
+                  align256(sizeof(int32_t) * (2 * (size_t)nc + 2 * (size_t)n + 2)) + align256(off_bytes) + 1024;
     if (host_out) need += align256(sizeof(double2) * cap_coords) + align256(off_bytes);
     GPK_TRY(workspace().begin(need));
     double2* sorted = (double2*)workspace().take(sizeof(double2) * (size_t)(nc + 1));
@@ -258,6 +262,7 @@ extern "C" int32_t gpk_convex_hull(const gpk_geoarray* a, double* out_xy, int32_
     int32_t* n_pts = (int32_t*)workspace().take(off_bytes);
     int32_t* idx_scratch = (int32_t*)workspace().take(sizeof(int32_t) * (2 * (size_t)nc + 2 * (size_t)n + 2));
     unsigned long long* btot = (unsigned long long*)workspace().take(sizeof(unsigned long long) * (size_t)(nb + 2));
+    int32_t* big_list = (int32_t*)workspace().take(off_bytes);  // [0, n): ids of the geometries beyond HULL_CAP points, [n]: their number
     double2* out_dev = host_out ? (double2*)workspace().take(sizeof(double2) * cap_coords) : (double2*)out_xy;
     int32_t* off_dev = host_out ? (int32_t*)workspace().take(off_bytes) : out_ring_offsets;
     if (n == 0) {
@@ -265,8 +270,14 @@ extern "C" int32_t gpk_convex_hull(const gpk_geoarray* a, double* out_xy, int32_
         return copy_out(out_ring_offsets, out_space, off_dev, sizeof(int32_t), s);
     }
     const dim3 grid((unsigned)nb), block(256);
-    GPK_LAUNCH("gpk_hull_sort", hull_sort_kernel, dim3((unsigned)((n * HULL_GS + 255) / 256)), dim3(256), 0, s, a->d, sorted, n_pts);
-    GPK_LAUNCH("gpk_hull_sort_big", hull_sort_big_kernel, grid, block, 0, s, a->d, sorted, (const int32_t*)n_pts);
+    GPK_HIP(hipMemsetAsync(big_list + n, 0, sizeof(int32_t), s));
+    GPK_LAUNCH("gpk_hull_sort", hull_sort_kernel, dim3((unsigned)((n * HULL_GS + 255) / 256)), dim3(256), 0, s, a->d, sorted, n_pts, big_list,
+               big_list + n);
+    {
+        const int64_t big_blocks = n < (int64_t)cu_count() * 8 ? n : (int64_t)cu_count() * 8;
+        GPK_LAUNCH("gpk_hull_sort_big", hull_sort_big_kernel, dim3((unsigned)big_blocks), block, 0, s, a->d, sorted, (const int32_t*)n_pts,
+                   (const int32_t*)big_list, (const int32_t*)(big_list + n));
+    }
     GPK_LAUNCH("gpk_hull_chain", hull_chain_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, a->d, (const double2*)sorted, (const int32_t*)n_pts, stack,
                idx_scratch, sizes);
     GPK_TRY(exclusive_scan_i32(sizes, n, off_dev, nullptr, btot, s));
