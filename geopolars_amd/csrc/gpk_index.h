@@ -38,19 +38,29 @@ struct IndexView {  // passed to kernels by value
 //   entry      : part << 1 | boundary.  boundary = 0 means EVERY representable point that maps to this
 //                cell is strictly inside that part (holes included) — decided once, exactly, at build
 //                time; boundary = 1 means some edge of the part may touch the cell: run the exact test.
-//   slabs      : for ring r and slab row j (PIP_SLAB_MUL slab rows per raster row) in [row0[r], row0[r] + nrows)
-//                the list of edges whose closed y-range meets the row (under the same monotone row function the points use), stored as
-//                contiguous double4 (sx, sy, ex, ey) records -> 8 lanes read one slab with 2 cache lines.
+//   slabs      : for ring r and slab row j in [row0[r], row0[r] + nrows) the list of edges whose closed y-range meets
+//                the row (under the same monotone row function the points use), stored as contiguous double4
+//                (sx, sy, ex, ey) records -> 8 lanes read one slab with 2 cache lines.  Rows are PER RING:
+//                PIP_SLAB_MUL << shift[r] slab rows per raster row, the shift (0..PIP_FINE_LOG2) chosen at build time
+//                so that a slab keeps about a dozen edges however many vertices the ring has (a 100k-vertex ring on
+//                the base rows holds hundreds of edges per slab, and every boundary-cell point walks them all).
+//                Every ring's rows are a right shift of ONE finest row function (exact power-of-two rescales of the
+//                raster row function), so edge registration and point lookup agree by monotonicity.  ring_row0[r]
+//                and PartInfo::row0 carry `row0 | shift << 24`.
 // Exactness does not depend on the raster: it only routes points; every boundary decision is made by
 // the exact winding walk over the slab's edges, which are a superset of the edges that can count.
 struct PartInfo {  // one 16-byte load tells a lane where the exterior ring's slabs of a part live
-    int32_t slab_base, row0, nrows, n_rings;
+    int32_t slab_base, row0 /* | shift << 24 */, nrows, n_rings;
 };
 constexpr int PIP_SUB = 8;       // level-2 sub-cells per raster cell side
-constexpr int PIP_SLAB_MUL = 2;  // slab rows per raster row (slabs stay ~7 edges while the level-1 table stays small)
+constexpr int PIP_SLAB_MUL = 2;  // base slab rows per raster row (slabs stay ~7 edges while the level-1 table stays small)
+constexpr int PIP_FINE_LOG2 = 6;  // finest slab rows: PIP_SLAB_MUL << 6 = 128 per raster row
+__host__ __device__ inline int slab_row0_of(int32_t packed) { return packed & 0xFFFFFF; }
+__host__ __device__ inline int slab_shift_of(int32_t packed) { return packed >> 24; }
+constexpr uint32_t SUB_INDIRECT = 1u << 30;  // in a SubCell part word: slab ranges not inline (refined ring): go through PartInfo
 struct SubCell {  // level-2 record of a raster cell crossed by edges of exactly ONE part: 32 bytes, one cache line touch
-    uint32_t part_flags;  // part | (part has holes) << 31
-    uint32_t e0, e1, e2;  // exterior-ring slab of the cell's lower slab row = [e0, e1), upper = [e1, e2)
+    uint32_t part_flags;  // part | SUB_INDIRECT | (part has holes) << 31
+    uint32_t e0, e1, e2;  // exterior-ring slab of the cell's lower base slab row = [e0, e1), upper = [e1, e2) (shift 0 only)
     uint32_t labels[4];   // 8 x 8 sub-cells, 2 bits each (x fastest): 0 outside, 1 strictly inside, 2 test exactly
 };
 // level-2 record of a raster cell crossed by exactly TWO parts (and holding nothing else): the shared borders of a
@@ -73,7 +83,7 @@ struct PipView {
     const SubCell2* sub2;            // two-part level-2 records (cell tag 3, payload & SUB2_BIT)
     const uint32_t* part_geom;       // nullptr for POLYGON arrays (part == geometry)
     const PartInfo* part_info;       // n_parts
-    const int32_t* ring_row0;
+    const int32_t* ring_row0;        // row0 | shift << 24 per ring
     const int32_t* ring_slab_base;   // n_rings + 1
     const int32_t* slab_off;         // n_slabs + 1
     const double4* slab_edges;

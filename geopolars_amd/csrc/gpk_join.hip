@@ -248,13 +248,26 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
         }
         // stage B: raster words (one 4-byte gather per point).  Columns/rows are computed at PIP_SUB x the
         // raster resolution (an exact power-of-two rescale of the same monotone function): `/ PIP_SUB` is the
-        // level-1 cell, `% PIP_SUB` the level-2 sub-cell, and sy / (PIP_SUB / PIP_SLAB_MUL) the slab row.
-        constexpr int S = PIP_SUB, SLAB_DIV = PIP_SUB / PIP_SLAB_MUL;
-        uint32_t sx[PIP_PPT];
+        // level-1 cell, `% PIP_SUB` the level-2 sub-cell.
+        // Rows are computed ONCE at the finest slab resolution (FINE per raster row); `>> FY_SUB` is the level-2 row
+        // (the value the S-scaled function returns: power-of-two rescales commute with floor and the clamps),
+        // `>> PIP_FINE_LOG2` the base slab row, `>> (PIP_FINE_LOG2 - shift)` the slab row of a refined ring.
+        constexpr int S = PIP_SUB, FINE = PIP_SLAB_MUL << PIP_FINE_LOG2, FY_SUB = PIP_FINE_LOG2 - 2;
+        static_assert(FINE == S << FY_SUB, "fine rows per level-2 row");
+        uint32_t sx[PIP_PPT], fyf[PIP_PPT];
+        // slab of the exterior ring of `part` for a point in finest row `fine`: false = p.y outside the ring's y-range
+        auto part_slab = [&](const PartInfo& pq, uint32_t fine, int& a0, int& a1) -> bool {
+            const int j = (int)(fine >> (PIP_FINE_LOG2 - slab_shift_of(pq.row0))) - slab_row0_of(pq.row0);
+            if (j < 0 || j >= pq.nrows) return false;
+            a0 = pv.slab_off[pq.slab_base + j];
+            a1 = pv.slab_off[pq.slab_base + j + 1];
+            return true;
+        };
 #pragma unroll
         for (int k = 0; k < PIP_PPT; ++k) {
             sx[k] = (uint32_t)dev::cell_of(p[k].x, pv.rx0, pv.inv_fw * S, pv.R * S);
-            fy[k] = (uint32_t)dev::cell_of(p[k].y, pv.ry0, pv.inv_fh * S, pv.R * S);
+            fyf[k] = (uint32_t)dev::cell_of(p[k].y, pv.ry0, pv.inv_fh * FINE, pv.R * FINE);
+            fy[k] = fyf[k] >> FY_SUB;
             word[k] = (p[k].x == p[k].x && p[k].y == p[k].y) ? pv.cell[(fy[k] / S) * (uint32_t)pv.R + (sx[k] / S)] : 0u;
             if (GPK_ABLATE == 2) word[k] = 0u;  // tuning builds only
             if (GPK_ABLATE == 3) word[k] = (word[k] >> 30) == CELL_TAG_SINGLE && !(word[k] & 1u) ? word[k] : 0u;
@@ -300,43 +313,39 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
                 const int wsel = idx >> 4;  // select by compares: a runtime-indexed register array would go to scratch
                 const uint32_t lw = wsel == 0 ? sc[k].labels[0] : (wsel == 1 ? sc[k].labels[1] : (wsel == 2 ? sc[k].labels[2] : sc[k].labels[3]));
                 const uint32_t lab = (lw >> (2 * (idx & 15))) & 3u;
-                qpart[k] = sc[k].part_flags & 0x7FFFFFFFu;
+                qpart[k] = sc[k].part_flags & 0x3FFFFFFFu;
+                // slab of slot A for this point: inline in the record, or through PartInfo when the ring has refined rows
+                auto slot_a = [&]() {
+                    want[k] = true;
+                    qflag[k] = sc[k].part_flags & 0x80000000u;
+                    if (sc[k].part_flags & SUB_INDIRECT) {
+                        want[k] = part_slab(pv.part_info[qpart[k]], fyf[k], e0[k], e1[k]);
+                    } else {
+                        const bool upper = ((fyf[k] >> PIP_FINE_LOG2) & 1u) != 0;
+                        e0[k] = (int)(upper ? sc[k].e1 : sc[k].e0);
+                        e1[k] = (int)(upper ? sc[k].e2 : sc[k].e1);
+                    }
+                };
                 if (!SUB2 || !has_sub2[k]) {
                     if (lab == 1u) {
                         const int li = k * PIP_BLOCK + tid;
                         s_cnt[li] = 1;
                         s_hit[li * PIP_KHIT] = qpart[k];
                     } else if (lab == 2u && GPK_ABLATE != 5) {
-                        want[k] = true;
-                        const bool upper = ((fy[k] / SLAB_DIV) & 1) != 0;
-                        e0[k] = (int)(upper ? sc[k].e1 : sc[k].e0);
-                        e1[k] = (int)(upper ? sc[k].e2 : sc[k].e1);
-                        qflag[k] = sc[k].part_flags & 0x80000000u;
+                        slot_a();
                     }
                 } else {  // two parts share the cell (gpk_index.h: SubCell2)
                     const int li = k * PIP_BLOCK + tid;
                     want_b[k] = lab == 3u;
                     if (lab == 1u || lab == 2u) {
                         s_cnt[li] = 1;
-                        s_hit[li * PIP_KHIT] = lab == 1u ? qpart[k] : (scb[k].x & 0x7FFFFFFFu);
+                        s_hit[li * PIP_KHIT] = lab == 1u ? qpart[k] : (scb[k].x & 0x3FFFFFFFu);
                     }
-                    if (lab == 3u) {
-                        want[k] = true;
-                        const bool upper = ((fy[k] / SLAB_DIV) & 1) != 0;
-                        e0[k] = (int)(upper ? sc[k].e1 : sc[k].e0);
-                        e1[k] = (int)(upper ? sc[k].e2 : sc[k].e1);
-                        qflag[k] = sc[k].part_flags & 0x80000000u;
-                    }
+                    if (lab == 3u) slot_a();
                 }
             } else if (want[k]) {
-                const int j = (fy[k] / SLAB_DIV) - pi[k].row0;
-                if (j < 0 || j >= pi[k].nrows) {
-                    want[k] = false;  // p.y outside the exterior's y-range: Outside
-                } else {
-                    e0[k] = pv.slab_off[pi[k].slab_base + j];
-                    e1[k] = pv.slab_off[pi[k].slab_base + j + 1];
-                    qflag[k] = pi[k].n_rings > 1 ? 0x80000000u : 0u;
-                }
+                want[k] = part_slab(pi[k], fyf[k], e0[k], e1[k]);  // false: p.y outside the exterior's y-range: Outside
+                qflag[k] = pi[k].n_rings > 1 ? 0x80000000u : 0u;
             }
         }
         // stage E, one round per k: queue pushes (wave-aggregated), then — when the queue is filling up, and after
@@ -373,9 +382,15 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
                 }
             }
             if (SUB2 && want_b[k]) {  // second part of a two-part cell: rare enough for one LDS atomic per lane
-                const bool upper = ((fy[k] / SLAB_DIV) & 1) != 0;
-                const uint32_t b0 = upper ? scb[k].z : scb[k].y, b1 = upper ? scb[k].w : scb[k].z;
-                const uint32_t bpart = scb[k].x & 0x7FFFFFFFu;
+                const bool upper = ((fyf[k] >> PIP_FINE_LOG2) & 1u) != 0;
+                uint32_t b0 = upper ? scb[k].z : scb[k].y, b1 = upper ? scb[k].w : scb[k].z;
+                const uint32_t bpart = scb[k].x & 0x3FFFFFFFu;
+                if (scb[k].x & SUB_INDIRECT) {
+                    int a0 = 0, a1 = 0;
+                    if (!part_slab(pv.part_info[bpart], fyf[k], a0, a1)) a0 = a1 = 0;
+                    b0 = (uint32_t)a0;
+                    b1 = (uint32_t)a1;
+                }
                 if (b1 > b0) {
                     const uint32_t slot = atomicAdd(&q_n, 1u);
                     if (slot < (uint32_t)PIP_QCAP)
@@ -393,9 +408,8 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
                     const uint32_t part = e >> 1;
                     if (e & 1u) {
                         const PartInfo pq = pv.part_info[part];
-                        const int j = (fy[k] / SLAB_DIV) - pq.row0;
-                        if (j < 0 || j >= pq.nrows) continue;
-                        const int a0 = pv.slab_off[pq.slab_base + j], a1 = pv.slab_off[pq.slab_base + j + 1];
+                        int a0, a1;
+                        if (!part_slab(pq, fyf[k], a0, a1)) continue;
                         if (a1 <= a0) continue;
                         const uint32_t slot = atomicAdd(&q_n, 1u);
                         if (slot < (uint32_t)PIP_QCAP) {

@@ -1,6 +1,6 @@
 // gpk_pip.h — exact point-vs-part tests driven by the slab tables of PipView (gpk_index.h).
 //
-// A slab holds every edge of one ring whose closed y-range meets one raster row; the point's row is
+// A slab holds every edge of one ring whose closed y-range meets one slab row of that ring; the point's row is
 // computed with the same monotone function, so the slab is a superset of the edges that
 // coord_pos_relative_to_ring (geo 0.27) can count or report as boundary for that point.  Walking the
 // slab with dev::ring_edge therefore returns exactly the ring position of the full ring walk.
@@ -12,19 +12,36 @@
 namespace gpk {
 namespace pip {
 
-// slab row of a y coordinate (an exact power-of-two refinement of the raster row function)
+// FINEST slab row of a y coordinate (an exact power-of-two refinement of the raster row function); a ring's own slab
+// row is this value shifted right by PIP_FINE_LOG2 - shift[ring]
 __device__ __forceinline__ int row_of(const PipView& pv, double py) {
-    return dev::cell_of(py, pv.ry0, pv.inv_fh * PIP_SLAB_MUL, pv.R * PIP_SLAB_MUL);
+    return dev::cell_of(py, pv.ry0, pv.inv_fh * (double)(PIP_SLAB_MUL << PIP_FINE_LOG2), pv.R * (PIP_SLAB_MUL << PIP_FINE_LOG2));
 }
 __device__ __forceinline__ int col_of(const PipView& pv, double px) { return dev::cell_of(px, pv.rx0, pv.inv_fw, pv.R); }
 
+// `row` = finest slab row (row_of)
 __device__ __forceinline__ bool slab_range(const PipView& pv, int r, int row, int& e0, int& e1) {
     const int base = pv.ring_slab_base[r], ns = pv.ring_slab_base[r + 1] - base;
-    const int j = row - pv.ring_row0[r];
+    const int rr = pv.ring_row0[r];
+    const int j = (row >> (PIP_FINE_LOG2 - slab_shift_of(rr))) - slab_row0_of(rr);
     if (j < 0 || j >= ns) return false;  // p.y outside the ring's y-range: Outside, cannot be on it
     e0 = pv.slab_off[base + j];
     e1 = pv.slab_off[base + j + 1];
     return true;
+}
+// every edge of ring r registered in a slab row that lies in raster row cj: one contiguous range (consecutive rows of a
+// ring are adjacent in slab_off; an edge that spans several of them appears once per row)
+__device__ __forceinline__ bool slab_span_of_raster_row(const PipView& pv, int r, int cj, int& e0, int& e1) {
+    const int base = pv.ring_slab_base[r], ns = pv.ring_slab_base[r + 1] - base;
+    const int rr = pv.ring_row0[r];
+    const int sh = slab_shift_of(rr);
+    int first = cj * (PIP_SLAB_MUL << sh) - slab_row0_of(rr), last = first + (PIP_SLAB_MUL << sh) - 1;
+    if (last < 0 || first >= ns) return false;
+    first = first < 0 ? 0 : first;
+    last = last >= ns ? ns - 1 : last;
+    e0 = pv.slab_off[base + first];
+    e1 = pv.slab_off[base + last + 1];
+    return e1 > e0;
 }
 
 // ---- one lane --------------------------------------------------------------------------------

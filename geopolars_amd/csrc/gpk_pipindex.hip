@@ -63,8 +63,12 @@ __global__ void part_info_kernel(DevGeo a, int64_t n_parts, const int32_t* __res
     info[p] = pi;
 }
 
-__global__ void ring_rows_kernel(const double4* __restrict__ ring_bbox, int64_t n_rings, FineGrid f,
-                                 int32_t* __restrict__ row0, int32_t* __restrict__ nrows) {
+// Slab rows of every ring.  f = the FINEST row grid (R * PIP_SLAB_MUL << PIP_FINE_LOG2 rows).  The ring's shift is the
+// smallest one (up to max_shift) that brings the expected slab — edges / rows, exact for a ring whose edges are short
+// against a row — down to SLAB_TARGET edges.
+constexpr int SLAB_TARGET = 12;
+__global__ void ring_rows_kernel(const double4* __restrict__ ring_bbox, int64_t n_rings, const int32_t* __restrict__ ring_off, FineGrid f,
+                                 int max_shift, int32_t* __restrict__ row0, int32_t* __restrict__ nrows) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rings) return;
     const double4 b = ring_bbox[r];
@@ -73,8 +77,13 @@ __global__ void ring_rows_kernel(const double4* __restrict__ ring_bbox, int64_t 
         nrows[r] = 0;
         return;
     }
-    const int j0 = frow(f, b.y), j1 = frow(f, b.w);
-    row0[r] = j0;
+    const int f0 = frow(f, b.y), f1 = frow(f, b.w);
+    const int64_t n_edges = (int64_t)ring_off[r + 1] - ring_off[r] - 1;
+    const int64_t base_rows = (f1 >> PIP_FINE_LOG2) - (f0 >> PIP_FINE_LOG2) + 1;
+    int sh = 0;
+    while (sh < max_shift && n_edges > (int64_t)SLAB_TARGET * (base_rows << sh)) ++sh;
+    const int j0 = f0 >> (PIP_FINE_LOG2 - sh), j1 = f1 >> (PIP_FINE_LOG2 - sh);
+    row0[r] = j0 | (sh << 24);
     nrows[r] = j1 - j0 + 1;
 }
 
@@ -120,9 +129,11 @@ __global__ void slab_register_kernel(DevGeo a, FineGrid f, const int32_t* __rest
     if (slab_base[r + 1] == slab_base[r]) return;
     const double ylo = s.y < e.y ? s.y : e.y, yhi = s.y > e.y ? s.y : e.y;
     if (!(ylo == ylo) || !(yhi == yhi)) return;
-    const int j0 = frow(f, ylo), j1 = frow(f, yhi);
+    const int rr = row0[r];
+    const int down = PIP_FINE_LOG2 - slab_shift_of(rr);  // f is the finest row grid
+    const int j0 = frow(f, ylo) >> down, j1 = frow(f, yhi) >> down;
     for (int j = j0; j <= j1; ++j) {
-        const int sl = slab_base[r] + (j - row0[r]);
+        const int sl = slab_base[r] + (j - slab_row0_of(rr));
         const int slot = atomicAdd(&cnt_or_cursor[sl], 1);
         if (FILL) edges[slot] = make_double4(s.x, s.y, e.x, e.y);
     }
@@ -346,28 +357,27 @@ __global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, Fi
         if (!crosses[q]) continue;
         int r0, r1;
         dev::part_rings(a, part[q], r0, r1);
-        for (int r = r0; r < r1 && list_ok; ++r)
-            for (int h = 0; h < PIP_SLAB_MUL && list_ok; ++h) {
-                int e0, e1;
-                if (!pip::slab_range(pv, r, PIP_SLAB_MUL * cj + h, e0, e1)) continue;
-                for (int eb = e0; eb < e1 && list_ok; eb += 64) {
-                    const int e = eb + lane64;
-                    bool keep = false;
-                    double4 ed = make_double4(0, 0, 0, 0);
-                    if (e < e1) {
-                        ed = pv.slab_edges[e];
-                        keep = !(fmax(ed.x, ed.z) < cxl || fmin(ed.x, ed.z) > cxh || fmax(ed.y, ed.w) < cyl || fmin(ed.y, ed.w) > cyh);
-                    }
-                    const unsigned long long m = __ballot(keep);
-                    const int add = __popcll(m);
-                    if (n_list + add > SUB_EDGE_CAP) {
-                        list_ok = false;
-                        break;
-                    }
-                    if (keep) s_edges[wave][n_list + __popcll(m & ((1ull << lane64) - 1ull))] = ed;
-                    n_list += add;
+        for (int r = r0; r < r1 && list_ok; ++r) {
+            int e0, e1;
+            if (!pip::slab_span_of_raster_row(pv, r, cj, e0, e1)) continue;
+            for (int eb = e0; eb < e1 && list_ok; eb += 64) {
+                const int e = eb + lane64;
+                bool keep = false;
+                double4 ed = make_double4(0, 0, 0, 0);
+                if (e < e1) {
+                    ed = pv.slab_edges[e];
+                    keep = !(fmax(ed.x, ed.z) < cxl || fmin(ed.x, ed.z) > cxh || fmax(ed.y, ed.w) < cyl || fmin(ed.y, ed.w) > cyh);
                 }
+                const unsigned long long m = __ballot(keep);
+                const int add = __popcll(m);
+                if (n_list + add > SUB_EDGE_CAP) {
+                    list_ok = false;
+                    break;
+                }
+                if (keep) s_edges[wave][n_list + __popcll(m & ((1ull << lane64) - 1ull))] = ed;
+                n_list += add;
             }
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -391,12 +401,11 @@ __global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, Fi
             if (!crosses[q]) continue;
             int r0, r1;
             dev::part_rings(a, part[q], r0, r1);
-            for (int r = r0; r < r1 && !touched; ++r)
-                for (int h = 0; h < PIP_SLAB_MUL && !touched; ++h) {
-                    int e0, e1;
-                    if (!pip::slab_range(pv, r, PIP_SLAB_MUL * cj + h, e0, e1)) continue;
-                    for (int e = e0; e < e1 && !touched; ++e) touched = edge_touches(pv.slab_edges[e]);
-                }
+            for (int r = r0; r < r1 && !touched; ++r) {
+                int e0, e1;
+                if (!pip::slab_span_of_raster_row(pv, r, cj, e0, e1)) continue;
+                for (int e = e0; e < e1 && !touched; ++e) touched = edge_touches(pv.slab_edges[e]);
+            }
         }
     }
     const uint32_t test_label = NP == 2 ? 3u : 2u;
@@ -420,12 +429,19 @@ __global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, Fi
             }
         }
     }
-    // exterior slabs of the cell's PIP_SLAB_MUL (= 2) slab rows are adjacent in slab_off: [e0,e1) and [e1,e2)
+    // exterior slabs of the cell's PIP_SLAB_MUL (= 2) base slab rows are adjacent in slab_off: [e0,e1) and [e1,e2); a part
+    // whose exterior has refined rows has more than two per cell: its record says SUB_INDIRECT and the join kernel goes
+    // through PartInfo for it
     auto slabs_of = [&](int p, uint32_t& flags, uint32_t& e0, uint32_t& e1, uint32_t& e2) {
         const PartInfo pi = pv.part_info[p];
-        const int j0 = PIP_SLAB_MUL * cj - pi.row0, j1 = j0 + 1;
-        const bool lo_ok = j0 >= 0 && j0 < pi.nrows, hi_ok = j1 >= 0 && j1 < pi.nrows;
         e0 = e1 = e2 = 0;
+        flags = (uint32_t)p | (pi.n_rings > 1 ? 0x80000000u : 0u);
+        if (slab_shift_of(pi.row0) != 0) {
+            flags |= SUB_INDIRECT;
+            return;
+        }
+        const int j0 = PIP_SLAB_MUL * cj - slab_row0_of(pi.row0), j1 = j0 + 1;
+        const bool lo_ok = j0 >= 0 && j0 < pi.nrows, hi_ok = j1 >= 0 && j1 < pi.nrows;
         if (lo_ok) {
             e0 = (uint32_t)pv.slab_off[pi.slab_base + j0];
             e1 = (uint32_t)pv.slab_off[pi.slab_base + j0 + 1];
@@ -435,7 +451,6 @@ __global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, Fi
             if (!lo_ok) e0 = e1 = (uint32_t)pv.slab_off[pi.slab_base + j1];
             e2 = (uint32_t)pv.slab_off[pi.slab_base + j1 + 1];
         }
-        flags = (uint32_t)p | (pi.n_rings > 1 ? 0x80000000u : 0u);
     };
     SubCell* rec = NP == 1 ? sub + pos[c] : &sub2[pos[c]].a;
     if (k == 0) {
@@ -552,35 +567,45 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
     int64_t max_scan = n_cells > d.n_coords ? n_cells : d.n_coords;  // longest array scanned with btot (grown below for the slabs)
     if (n_rings > max_scan) max_scan = n_rings;
     GPK_TRY(t.alloc(&btot, (size_t)((max_scan + 255) / 256 + 4)));
-    FineGrid gs = g;  // slab rows: PIP_SLAB_MUL per raster row (exact power-of-two refinement of the same function)
-    gs.R = g.R * PIP_SLAB_MUL;
-    gs.fw = g.fw / PIP_SLAB_MUL;
-    gs.fh = g.fh / PIP_SLAB_MUL;
-    gs.inv_fw = g.inv_fw * PIP_SLAB_MUL;
-    gs.inv_fh = g.inv_fh * PIP_SLAB_MUL;
-    GPK_LAUNCH("gpk_pipidx_ring_rows", ring_rows_kernel, blocks_for(n_rings), dim3(256), 0, s, ring_bbox, n_rings, gs, row0, nrows);
-    GPK_TRY(exclusive_scan_i32(nrows, n_rings, slab_base, nullptr, btot, s));
-    int32_t n_slabs = 0;
-    GPK_HIP(hipMemcpyAsync(&n_slabs, slab_base + n_rings, sizeof n_slabs, hipMemcpyDeviceToHost, s));
-    GPK_HIP(hipStreamSynchronize(s));
-    if ((int64_t)n_slabs > max_scan) {  // few-vertex rings spanning many slab rows: more slabs than coordinates
-        max_scan = n_slabs;
-        GPK_TRY(t.alloc(&btot, (size_t)((max_scan + 255) / 256 + 4)));
-    }
-    int32_t *slab_cnt, *slab_off = nullptr, *cursor;
-    GPK_TRY(t.alloc(&slab_cnt, (size_t)n_slabs + 1));
-    GPK_TRY(t.alloc(&cursor, (size_t)n_slabs + 1));
-    GPK_HIP(hipMalloc((void**)&slab_off, sizeof(int32_t) * (size_t)(n_slabs + 1)));
-    keep(slab_off);
-    GPK_HIP(hipMemsetAsync(slab_cnt, 0, sizeof(int32_t) * (size_t)(n_slabs + 1), s));
-    GPK_HIP(hipMemsetAsync(slab_off, 0, sizeof(int32_t) * (size_t)(n_slabs + 1), s));
-    GPK_LAUNCH("gpk_pipidx_slab_count", slab_register_kernel<false>, blocks_for(d.n_coords), dim3(256), 0, s, d, gs, row0, slab_base,
-               slab_cnt, (double4*)nullptr);
-    int32_t n_edges = 0;
-    if (n_slabs > 0) {
-        GPK_TRY(exclusive_scan_i32(slab_cnt, n_slabs, slab_off, cursor, btot, s));
-        GPK_HIP(hipMemcpyAsync(&n_edges, slab_off + n_slabs, sizeof n_edges, hipMemcpyDeviceToHost, s));
+    FineGrid gs = g;  // the FINEST slab-row grid (an exact power-of-two refinement of the raster row function); a ring's
+                      // own rows are a right shift of it (ring_rows_kernel)
+    gs.R = g.R * (PIP_SLAB_MUL << PIP_FINE_LOG2);
+    gs.fw = g.fw / (PIP_SLAB_MUL << PIP_FINE_LOG2);
+    gs.fh = g.fh / (PIP_SLAB_MUL << PIP_FINE_LOG2);
+    gs.inv_fw = g.inv_fw * (double)(PIP_SLAB_MUL << PIP_FINE_LOG2);
+    gs.inv_fh = g.inv_fh * (double)(PIP_SLAB_MUL << PIP_FINE_LOG2);
+    int32_t n_slabs = 0, n_edges = 0;
+    int32_t *slab_cnt = nullptr, *slab_off = nullptr, *cursor = nullptr;
+    // refined rows assume short edges; a ring of many LONG edges (a comb) would register each of them in every refined
+    // row, so a total far beyond the coordinate count sends the build back to the base rows
+    const int slab_off_slot = slot++;  // owned by the index from the moment it exists (released with it on any error path)
+    for (int max_shift = PIP_FINE_LOG2;; max_shift = 0) {
+        GPK_LAUNCH("gpk_pipidx_ring_rows", ring_rows_kernel, blocks_for(n_rings), dim3(256), 0, s, ring_bbox, n_rings, d.ring_off, gs, max_shift,
+                   row0, nrows);
+        GPK_TRY(exclusive_scan_i32(nrows, n_rings, slab_base, nullptr, btot, s));
+        GPK_HIP(hipMemcpyAsync(&n_slabs, slab_base + n_rings, sizeof n_slabs, hipMemcpyDeviceToHost, s));
         GPK_HIP(hipStreamSynchronize(s));
+        if ((int64_t)n_slabs > max_scan) {  // few-vertex rings spanning many slab rows: more slabs than coordinates
+            max_scan = n_slabs;
+            GPK_TRY(t.alloc(&btot, (size_t)((max_scan + 255) / 256 + 4)));
+        }
+        GPK_TRY(t.alloc(&slab_cnt, (size_t)n_slabs + 1));
+        GPK_TRY(t.alloc(&cursor, (size_t)n_slabs + 1));
+        if (slab_off) (void)hipFree(slab_off);
+        ix->owned[slab_off_slot] = slab_off = nullptr;
+        GPK_HIP(hipMalloc((void**)&slab_off, sizeof(int32_t) * (size_t)(n_slabs + 1)));
+        ix->owned[slab_off_slot] = slab_off;
+        GPK_HIP(hipMemsetAsync(slab_cnt, 0, sizeof(int32_t) * (size_t)(n_slabs + 1), s));
+        GPK_HIP(hipMemsetAsync(slab_off, 0, sizeof(int32_t) * (size_t)(n_slabs + 1), s));
+        GPK_LAUNCH("gpk_pipidx_slab_count", slab_register_kernel<false>, blocks_for(d.n_coords), dim3(256), 0, s, d, gs, row0, slab_base,
+                   slab_cnt, (double4*)nullptr);
+        n_edges = 0;
+        if (n_slabs > 0) {
+            GPK_TRY(exclusive_scan_i32(slab_cnt, n_slabs, slab_off, cursor, btot, s));
+            GPK_HIP(hipMemcpyAsync(&n_edges, slab_off + n_slabs, sizeof n_edges, hipMemcpyDeviceToHost, s));
+            GPK_HIP(hipStreamSynchronize(s));
+        }
+        if (max_shift == 0 || (int64_t)n_edges <= 8 * d.n_coords + (1 << 20)) break;
     }
     double4* edges = nullptr;
     GPK_HIP(hipMalloc((void**)&edges, sizeof(double4) * (size_t)(n_edges ? n_edges : 1)));
