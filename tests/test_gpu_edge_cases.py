@@ -218,3 +218,46 @@ def test_few_vertex_rings_spanning_the_whole_raster(gpk, oracle):
     assert exp_counts.max() > 50
     got_pairs, got_counts = join_pairs(GeoSeries(left), GeoSeries(right), "intersects")
     assert np.array_equal(got_counts, exp_counts) and np.array_equal(got_pairs, exp_pairs)
+
+
+def _wiggly_ring(n, cx, cy, r_lo, r_hi, seed, reverse=False):
+    rng = np.random.default_rng(seed)
+    ang = 2 * np.pi * (np.arange(n) + rng.uniform(0, 0.9, n)) / n
+    rad = rng.uniform(r_lo, r_hi, n)
+    ring = np.stack([cx + rad * np.cos(ang), cy + rad * np.sin(ang)], 1)
+    ring = np.concatenate([ring, ring[:1]])
+    return ring[::-1] if reverse else ring
+
+
+def test_refined_slab_rows_of_dense_rings(gpk, oracle):
+    """A 30k-vertex exterior and a 6k-vertex hole put ~30 edges into a base slab row, so both rings get refined rows
+    (shift 2): level-2 records of the part are SUB_INDIRECT (slab through PartInfo), the hole walk uses the hole's own
+    row shift, and the small polygon on top turns some cells into entry lists."""
+    ext = _wiggly_ring(30_000, 500, 500, 380, 450, 1)
+    hole = _wiggly_ring(6_000, 520, 480, 90, 110, 2, reverse=True)
+    small = _wiggly_ring(40, 150, 500, 20, 30, 3)
+    xy = np.concatenate([ext, hole, small])
+    polys = GeoArrowArray(
+        _abi.GEOM_POLYGON, xy, geom_offsets=np.array([0, 2, 3], np.int32), ring_offsets=np.array([0, len(ext), len(ext) + len(hole), len(xy)], np.int32)
+    )
+    rng = np.random.default_rng(4)
+    ang = rng.uniform(0, 2 * np.pi, 30_000)
+    near_ext = np.stack([500 + rng.uniform(375, 455, 30_000) * np.cos(ang), 500 + rng.uniform(375, 455, 30_000) * np.sin(ang)], 1)
+    near_hole = np.stack([520 + rng.uniform(85, 115, 30_000) * np.cos(ang), 480 + rng.uniform(85, 115, 30_000) * np.sin(ang)], 1)
+    pts = np.concatenate([rng.uniform(0, 1000, (30_000, 2)), near_ext, near_hole, ext[::40], hole[::20], (ext[:-1:50] + ext[1::50]) / 2])
+    exp_pairs, exp_counts = check_join(oracle, GeoArrowArray.from_points(pts), polys)
+    assert 20_000 < len(exp_pairs) < len(pts) and exp_counts.max() == 2
+
+
+def test_refined_slab_rows_in_two_part_cells(gpk, oracle):
+    """a 12 x 12 tessellation whose shared borders have 3000 segments per side: two-part level-2 records (SubCell2) whose
+    parts both have refined rows"""
+    t = synth.tessellation(12, 3000)
+    rng = np.random.default_rng(5)
+    k = rng.integers(0, len(t.xy), 40_000)
+    on_border = t.xy[k]
+    near_border = on_border + rng.uniform(-0.02, 0.02, on_border.shape)
+    pts = np.concatenate([rng.uniform(0, 1000, (60_000, 2)), on_border, near_border])
+    exp_pairs, exp_counts = check_join(oracle, GeoArrowArray.from_points(pts), t)
+    # a border vertex is on the boundary of both neighbours: contained in neither; everything else is in exactly one cell
+    assert exp_counts.max() == 1 and 35_000 < (exp_counts == 0).sum() < 45_000
