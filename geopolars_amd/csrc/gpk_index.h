@@ -35,7 +35,7 @@ struct IndexView {  // passed to kernels by value
 //                labelling, plus the slab location, so most of its points finish with one more gather.
 //                (Level 1 is kept coarse — 1 MB at R = 512 — so that its gathers stay L2 hits; the
 //                effective resolution is 8R.)
-//   entry      : part << 1 | boundary.  boundary = 0 means EVERY representable point that maps to this
+//   entry      : part << 1 | boundary (list cells: see PipView::lrec).  boundary = 0 means EVERY representable point that maps to this
 //                cell is strictly inside that part (holes included) — decided once, exactly, at build
 //                time; boundary = 1 means some edge of the part may touch the cell: run the exact test.
 //   slabs      : for ring r and slab row j in [row0[r], row0[r] + nrows) the list of edges whose closed y-range meets
@@ -81,6 +81,8 @@ struct PipView {
     const uint32_t* list;
     const SubCell* sub;              // level-2 records (cell tag 3)
     const SubCell2* sub2;            // two-part level-2 records (cell tag 3, payload & SUB2_BIT)
+    const SubCell* lrec;             // level-2 records of the BOUNDARY entries of list cells: when set, such an entry is
+                                     // `record index << 1 | 1` (the record names the part), else `part << 1 | 1`
     const uint32_t* part_geom;       // nullptr for POLYGON arrays (part == geometry)
     const PartInfo* part_info;       // n_parts
     const int32_t* ring_row0;        // row0 | shift << 24 per ring

@@ -405,16 +405,41 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
                 const uint32_t m = pv.list[off];
                 for (uint32_t t = 0; t < m; ++t) {
                     const uint32_t e = pv.list[off + 1 + t];
-                    const uint32_t part = e >> 1;
+                    uint32_t part = e >> 1;
                     if (e & 1u) {
-                        const PartInfo pq = pv.part_info[part];
                         int a0, a1;
-                        if (!part_slab(pq, fyf[k], a0, a1)) continue;
+                        uint32_t holes;
+                        if (pv.lrec) {  // the entry names a level-2 record: most points finish on its label
+                            const SubCell rc = pv.lrec[e >> 1];
+                            part = rc.part_flags & 0x3FFFFFFFu;
+                            const int idx = (fy[k] % S) * S + (sx[k] % S);
+                            const int wsel = idx >> 4;
+                            const uint32_t lw = wsel == 0 ? rc.labels[0] : (wsel == 1 ? rc.labels[1] : (wsel == 2 ? rc.labels[2] : rc.labels[3]));
+                            const uint32_t lab = (lw >> (2 * (idx & 15))) & 3u;
+                            if (lab == 0u) continue;
+                            if (lab == 2u) {
+                                holes = rc.part_flags & 0x80000000u;
+                                if (rc.part_flags & SUB_INDIRECT) {
+                                    if (!part_slab(pv.part_info[part], fyf[k], a0, a1)) continue;
+                                } else {
+                                    const bool upper = ((fyf[k] >> PIP_FINE_LOG2) & 1u) != 0;
+                                    a0 = (int)(upper ? rc.e1 : rc.e0);
+                                    a1 = (int)(upper ? rc.e2 : rc.e1);
+                                }
+                            }
+                            if (lab == 1u) {
+                                record(li, part);
+                                continue;
+                            }
+                        } else {
+                            const PartInfo pq = pv.part_info[part];
+                            if (!part_slab(pq, fyf[k], a0, a1)) continue;
+                            holes = pq.n_rings > 1 ? 0x80000000u : 0u;
+                        }
                         if (a1 <= a0) continue;
                         const uint32_t slot = atomicAdd(&q_n, 1u);
                         if (slot < (uint32_t)PIP_QCAP) {
-                            q[slot] = QEntry{p[k].x, p[k].y, part, (uint32_t)a0, (uint32_t)(a1 - a0),
-                                             (uint32_t)li | (pq.n_rings > 1 ? 0x80000000u : 0u)};
+                            q[slot] = QEntry{p[k].x, p[k].y, part, (uint32_t)a0, (uint32_t)(a1 - a0), (uint32_t)li | holes};
                             continue;
                         }
                         if (pip::part_pos_single(pv, polys, (int)part, p[k].x, p[k].y) != dev::POS_INSIDE) continue;

@@ -316,20 +316,27 @@ __global__ void sub_flag_kernel(const uint32_t* __restrict__ cell, const uint32_
 // is not strictly on one side of the sub-cell's padded rectangle; otherwise it inherits the exact position of its
 // centre.  NP = 1: SubCell records (one crossing part); NP = 2: SubCell2 records (two parts, see gpk_index.h).
 constexpr int SUB_EDGE_CAP = 48;  // edges of a cell's slab rows kept in LDS per wave (sub_build_kernel)
-template <int NP>
+// WORK (NP = 1 only): the records are those of (cell, part) work items — the boundary entries of list cells,
+// work_cell[w] / work_part[w] -> sub[w] — instead of one per flagged cell.
+template <int NP, bool WORK = false>
 __global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, FineGrid g, const int32_t* __restrict__ flag,
                                                         const int32_t* __restrict__ pos, int64_t n_cells, const uint32_t* __restrict__ cell,
                                                         const uint32_t* __restrict__ list, SubCell* __restrict__ sub,
-                                                        SubCell2* __restrict__ sub2) {
+                                                        SubCell2* __restrict__ sub2, const int32_t* __restrict__ work_cell = nullptr,
+                                                        const uint32_t* __restrict__ work_part = nullptr, int64_t n_work = 0) {
+    static_assert(!WORK || NP == 1, "work items carry one part");
     constexpr int S = PIP_SUB, SS = PIP_SUB * PIP_SUB;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t c = t / SS;
+    const int64_t item = t / SS;  // a cell, or a work item
     const int k = (int)(t % SS);
-    if (c >= n_cells || !flag[c]) return;
+    if (WORK ? item >= n_work : (item >= n_cells || !flag[item])) return;
+    const int64_t c = WORK ? (int64_t)work_cell[item] : item;
     const uint32_t w = cell[c];  // still the level-1 word: sub_commit_kernel rewrites it afterwards
     int part[2] = {0, 0};
     bool crosses[2] = {true, true};
-    if (NP == 1) {
+    if (WORK) {
+        part[0] = (int)work_part[item];
+    } else if (NP == 1) {
         part[0] = (int)((w & 0x3FFFFFFFu) >> 1);
     } else {
         const uint32_t off = w & 0x3FFFFFFFu;
@@ -452,7 +459,7 @@ __global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, Fi
             e2 = (uint32_t)pv.slab_off[pi.slab_base + j1 + 1];
         }
     };
-    SubCell* rec = NP == 1 ? sub + pos[c] : &sub2[pos[c]].a;
+    SubCell* rec = WORK ? sub + item : (NP == 1 ? sub + pos[c] : &sub2[pos[c]].a);
     if (k == 0) {
         slabs_of(part[0], rec->part_flags, rec->e0, rec->e1, rec->e2);
         if (NP == 2) {
@@ -472,6 +479,41 @@ __global__ void sub_commit_kernel(const int32_t* __restrict__ flag, const int32_
         cell[c] = (CELL_TAG_SUB << 30) | SUB2_BIT | (uint32_t)pos2[c];
 }
 
+// ---- level 2 for list cells: one SubCell per boundary entry ------------------------------------------------------------
+// Right sides whose parts overlap (or are about as large as a raster cell) have most points in list cells, and at the
+// level-1 resolution nearly every entry there is a boundary entry: PartInfo + slab gathers + an exact walk per entry
+// and point, nine times out of ten to learn "outside".  With a record per boundary entry the point reads one 32-byte
+// record per entry and only its "test" sub-cells reach the queue.
+__global__ void lrec_count_kernel(const uint32_t* __restrict__ cell, const uint32_t* __restrict__ list, int64_t n_cells,
+                                  int32_t* __restrict__ cnt) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cells) return;
+    const uint32_t w = cell[c];
+    int n = 0;
+    if ((w >> 30) == CELL_TAG_LIST) {
+        const uint32_t off = w & 0x3FFFFFFFu, m = list[off];
+        for (uint32_t t = 0; t < m; ++t) n += (int)(list[off + 1 + t] & 1u);
+    }
+    cnt[c] = n;
+}
+__global__ void lrec_assign_kernel(const uint32_t* __restrict__ cell, uint32_t* __restrict__ list, int64_t n_cells,
+                                   const int32_t* __restrict__ pos, int32_t* __restrict__ work_cell, uint32_t* __restrict__ work_part) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cells) return;
+    const uint32_t w = cell[c];
+    if ((w >> 30) != CELL_TAG_LIST) return;
+    const uint32_t off = w & 0x3FFFFFFFu, m = list[off];
+    int32_t o = pos[c];
+    for (uint32_t t = 0; t < m; ++t) {
+        const uint32_t e = list[off + 1 + t];
+        if (!(e & 1u)) continue;
+        work_cell[o] = (int32_t)c;
+        work_part[o] = e >> 1;
+        list[off + 1 + t] = ((uint32_t)o << 1) | 1u;  // the entry now names its record
+        ++o;
+    }
+}
+
 }  // namespace gpk
 
 using namespace gpk;
@@ -479,7 +521,7 @@ using namespace gpk;
 namespace {
 struct Temps {  // scratch of the build: carved from the thread's auxiliary arena, hipMalloc'ed (and released on every
                 // exit path) only when the arena's estimate was too small
-    void* p[32] = {nullptr};
+    void* p[48] = {nullptr};
     int n = 0;
     template <typename T>
     int32_t alloc(T** out, size_t count) {
@@ -488,7 +530,7 @@ struct Temps {  // scratch of the build: carved from the thread's auxiliary aren
         if (!q) {
             hipError_t e = hipMalloc(&q, bytes);
             if (e != hipSuccess) return fail(GPK_ERR_OOM, "index build: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-            if (n < 32) p[n++] = q;
+            if (n < 48) p[n++] = q;
         }
         *out = (T*)q;
         return GPK_OK;
@@ -510,8 +552,12 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
     const double w = hg.inv_w > 0.0 ? (double)hg.gx / hg.inv_w : 0.0, h = hg.inv_h > 0.0 ? (double)hg.gy / hg.inv_h : 0.0;
     if (!(w > 0.0) || !(h > 0.0) || !std::isfinite(w) || !std::isfinite(h)) return GPK_OK;  // degenerate extent
 
-    int R = 64;
-    while (R < 2048 && (double)R < 2.0 * sqrt((double)d.n_coords)) R <<= 1;
+    int R = 64, r_max = 2048;
+    if (const char* e = getenv("GPK_PIP_RMAX")) {  // tuning knob: cap of the level-1 raster side (power of two, 64..4096)
+        const int v = atoi(e);
+        if (v >= 64 && v <= 4096 && (v & (v - 1)) == 0) r_max = v;
+    }
+    while (R < r_max && (double)R < 2.0 * sqrt((double)d.n_coords)) R <<= 1;
     FineGrid g;
     g.R = R;
     g.fw = w / (double)(R - 3);
@@ -702,7 +748,8 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
     SubCell* sub = nullptr;
     SubCell2* sub2 = nullptr;
     static_assert(PIP_SLAB_MUL == 2, "SubCell stores exactly two adjacent slab ranges");
-    if (g.pad_x / PIP_SUB > ulp64 && g.pad_y / PIP_SUB > ulp64 && R * PIP_SUB <= 32768) {
+    const bool level2_ok = g.pad_x / PIP_SUB > ulp64 && g.pad_y / PIP_SUB > ulp64 && R * PIP_SUB <= 32768;
+    if (level2_ok) {
         int32_t *sflag, *spos, *sflag2, *spos2;
         GPK_TRY(t.alloc(&sflag, (size_t)n_cells + 1));
         GPK_TRY(t.alloc(&spos, (size_t)n_cells + 1));
@@ -743,7 +790,39 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
     }
     pv.sub = sub;
     pv.sub2 = sub2;
-    ix->nbytes += (int64_t)(sizeof(SubCell) * (size_t)n_sub + sizeof(SubCell2) * (size_t)n_sub2);
+    // records for the boundary entries of the cells that stayed lists (after the commit: two-part cells are gone)
+    int32_t n_lrec = 0;
+    SubCell* lrec = nullptr;
+    if (level2_ok && list_len > 0 && !getenv("GPK_NO_LIST_RECORDS")) {
+        int32_t *lcnt, *lpos;
+        GPK_TRY(t.alloc(&lcnt, (size_t)n_cells + 1));
+        GPK_TRY(t.alloc(&lpos, (size_t)n_cells + 1));
+        GPK_LAUNCH("gpk_pipidx_lrec_count", lrec_count_kernel, blocks_for(n_cells), dim3(256), 0, s, (const uint32_t*)cell, (const uint32_t*)list, n_cells,
+                   lcnt);
+        GPK_TRY(exclusive_scan_i32(lcnt, n_cells, lpos, nullptr, btot, s));
+        GPK_HIP(hipMemcpyAsync(&n_lrec, lpos + n_cells, sizeof n_lrec, hipMemcpyDeviceToHost, s));
+        GPK_HIP(hipStreamSynchronize(s));
+        if (getenv("GPK_DEBUG_INDEX")) fprintf(stderr, "[gpk] level 2: %d boundary entries in list cells (list length %d)\n", n_lrec, list_len);
+        if (n_lrec > 0 && (int64_t)n_lrec < (int64_t)1 << 28) {  // 2^28 records = 8 GB: beyond that the lists stay plain
+            int32_t* work_cell;
+            uint32_t* work_part;
+            GPK_TRY(t.alloc(&work_cell, (size_t)n_lrec));
+            GPK_TRY(t.alloc(&work_part, (size_t)n_lrec));
+            GPK_HIP(hipMalloc((void**)&lrec, sizeof(SubCell) * (size_t)n_lrec));
+            keep(lrec);
+            GPK_HIP(hipMemsetAsync(lrec, 0, sizeof(SubCell) * (size_t)n_lrec, s));
+            GPK_LAUNCH("gpk_pipidx_lrec_assign", lrec_assign_kernel, blocks_for(n_cells), dim3(256), 0, s, (const uint32_t*)cell, list, n_cells,
+                       (const int32_t*)lpos, work_cell, work_part);
+            GPK_LAUNCH("gpk_pipidx_lrec_build", (sub_build_kernel<1, true>), blocks_for((int64_t)n_lrec * PIP_SUB * PIP_SUB), dim3(256), 0, s, d, pv, g,
+                       (const int32_t*)nullptr, (const int32_t*)nullptr, n_cells, (const uint32_t*)cell, (const uint32_t*)list, lrec, (SubCell2*)nullptr,
+                       (const int32_t*)work_cell, (const uint32_t*)work_part, (int64_t)n_lrec);
+            GPK_HIP(hipStreamSynchronize(s));
+        } else {
+            n_lrec = 0;
+        }
+    }
+    pv.lrec = lrec;
+    ix->nbytes += (int64_t)(sizeof(SubCell) * (size_t)n_sub + sizeof(SubCell2) * (size_t)n_sub2 + sizeof(SubCell) * (size_t)n_lrec);
     ix->pip = pv;
     ix->nbytes += (int64_t)(sizeof(uint32_t) * (size_t)n_cells + sizeof(uint32_t) * (size_t)list_len + sizeof(double4) * (size_t)n_edges +
                             sizeof(int32_t) * (size_t)(n_slabs + 1) + sizeof(int32_t) * (size_t)(2 * n_rings + 1) +
