@@ -94,3 +94,22 @@ def test_row_sharded_join_equals_unsharded(oracle, k):
         counts.append(c)
     assert np.array_equal(np.concatenate(parts), full_pairs)
     assert np.array_equal(np.concatenate(counts), full_counts)
+
+
+@pytest.mark.parametrize("pred", ["intersects", "contains"])
+def test_row_sharded_polygon_join_equals_unsharded(oracle, pred):
+    """the same property with a polygonal left side (C4: shards cut the left column by rows, offsets are rebased)"""
+    left = synth.clustered_polygons(3000, seed=5, mean_neighbours=6.0)
+    right = synth.clustered_polygons(20_000, seed=6, mean_neighbours=0.2, min_verts=4, max_verts=10)
+    full_pairs, full_counts, _ = oracle.spatial_join(left, right, pred, mode=1)
+    assert len(full_pairs) > 500
+    parts, counts = [], []
+    for r in range(4):
+        lo, hi = shard_rows(len(left), 4, r)
+        p, c, _ = oracle.spatial_join(slice_rows(left, lo, hi), right, pred, mode=1)
+        p = p.copy()
+        p[:, 0] += lo
+        parts.append(p)
+        counts.append(c)
+    assert np.array_equal(np.concatenate(parts), full_pairs)
+    assert np.array_equal(np.concatenate(counts), full_counts)
