@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Single-GPU shares of BASELINE.json configs[3] (C4) and configs[4] (C5) at a chosen scale: wall times of
 index build and join through the host-buffer API, with a parity spot check against the CPU oracle on a
-prefix.  Not the driver's bench; numbers go to DESIGN.md / profiles/."""
+prefix (which is why it lives under tests/: the oracle is test infrastructure).  Not the driver's bench; numbers go to
+DESIGN.md / profiles/."""
 import argparse, json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

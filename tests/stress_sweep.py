@@ -3,10 +3,11 @@
 thousands of tiny ones, identical geometries, zero-area rings, extreme magnitudes, one geometry with thousands of
 parts or holes, all-null / all-empty columns, skewed row maps), every result compared with the CPU oracle.
 
-    python tools/stress.py [--start K] [--only NAME]
+    python tests/stress_sweep.py [--start K] [--only NAME]
 
 Each regime prints its name BEFORE it runs (a GPU memory fault aborts the process: the last name printed is the
-culprit; rerun with GPK_DEBUG_SYNC=1 --only NAME to get the kernel).  Exit code 0 = every regime agreed."""
+culprit; rerun with GPK_DEBUG_SYNC=1 --only NAME to get the kernel).  Exit code 0 = every regime agreed.
+Lives under tests/ because it checks against the CPU oracle (test infrastructure); pytest does not collect it."""
 from __future__ import annotations
 
 import argparse
@@ -16,7 +17,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # tests/ -> repo root
 sys.path.insert(0, ROOT)
 
 from geopolars_amd import _abi, synth  # noqa: E402
