@@ -55,3 +55,20 @@ def concentric_pair(rng):
     if rng.random() < 0.7 and all(o >= 2 for o in bo) and all(0 < h <= o for h, o in zip(bh, bo)) and sum(h == o for h, o in zip(bh, bo)) <= 1:
         pb.append(star(0, 0, bh))
     return pa, pb
+
+
+def nudged(poly, rng, prob=0.1):
+    """the polygon scaled by 0.1 (coordinates no longer exactly representable) with a few coordinates moved by one or two
+    units of 2^-50: exact touches become hair-thin gaps or overlaps that only exact orientations resolve"""
+    out = []
+    for ring in poly:
+        r = []
+        for x, y in ring:
+            fx, fy = x * 0.1, y * 0.1
+            if rng.random() < prob:
+                fx += rng.choice((-2, -1, 1, 2)) * 2.0**-50
+            if rng.random() < prob:
+                fy += rng.choice((-2, -1, 1, 2)) * 2.0**-50
+            r.append((fx, fy))
+        out.append(r)
+    return out

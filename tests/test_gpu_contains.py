@@ -11,7 +11,7 @@ from geopolars_amd.geoarrow import GeoArrowArray
 from geopolars_amd.geoseries import GeoSeries
 from geopolars_amd.spatial_index import join_pairs
 
-from .lattice import concentric_pair, random_pair
+from .lattice import concentric_pair, nudged, random_pair
 
 pytestmark = pytest.mark.gpu
 
@@ -137,3 +137,20 @@ def test_rowwise_linestring_contains_point(gpk, oracle):
     assert exp.any() and not exp.all()
     assert np.array_equal(GeoSeries(lines).contains(GeoSeries(p)), exp)
     assert np.array_equal(GeoSeries(p).within(GeoSeries(lines)), exp)
+
+
+def test_rowwise_contains_on_inexact_floats(gpk, oracle):
+    """lattice pairs scaled by 0.1 and nudged by a few ulps: touches turn into hair-thin gaps and overlaps, the orientation
+    filter gives up and the expansion path decides — on the GPU exactly as in the oracle (which is pinned to the doubles'
+    rational values in test_oracle_rational.py)"""
+    rng = random.Random(21)
+    pairs = []
+    for _ in range(6000):
+        pa, pb = concentric_pair(rng) if rng.random() < 0.6 else random_pair(rng)
+        pairs.append((nudged(pa, rng), nudged(pb, rng)))
+    a = GeoArrowArray.from_polygons([p for p, _ in pairs])
+    b = GeoArrowArray.from_polygons([q for _, q in pairs])
+    exp = oracle.predicate_rowwise(a, b, "contains").astype(bool)
+    assert 300 < exp.sum() < 5000
+    assert np.array_equal(GeoSeries(a).contains(GeoSeries(b)), exp)
+    assert np.array_equal(GeoSeries(b).within(GeoSeries(a)), exp)

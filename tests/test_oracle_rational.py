@@ -12,7 +12,7 @@ from hypothesis import strategies as st
 from geopolars_amd import _abi
 from geopolars_amd.geoarrow import GeoArrowArray
 
-from .lattice import concentric_pair, random_pair, star, star_with_hole
+from .lattice import concentric_pair, nudged, random_pair, star, star_with_hole
 
 F = Fraction
 coord = st.integers(-50, 50)
@@ -447,3 +447,24 @@ def test_affine_transform_with_integer_matrices_is_exact(oracle, ring, m):
     out = oracle.affine_transform(a, m)
     exp = [(m[0] * x + m[1] * y + m[2], m[3] * x + m[4] * y + m[5]) for x, y in _closed(ring)]
     assert out.tolist() == [[float(x), float(y)] for x, y in exp]
+
+
+def test_polygon_contains_polygon_on_inexact_floats(oracle):
+    """the same pairs scaled by 0.1 (no longer exactly representable) and nudged by a few ulps: relations that were exact
+    touches become hair-thin gaps or overlaps, which only exact orientations (adaptive expansion path) resolve; the brute
+    force works on the doubles' exact rational values"""
+    import random
+
+    rng = random.Random(11)
+
+    pairs = []
+    for _ in range(700):
+        pa, pb = concentric_pair(rng) if rng.random() < 0.6 else random_pair(rng)
+        pairs.append((nudged(pa, rng), nudged(pb, rng)))
+    a = GeoArrowArray.from_polygons([p for p, _ in pairs])
+    b = GeoArrowArray.from_polygons([q for _, q in pairs])
+    got = oracle.predicate_rowwise(a, b, "contains").astype(bool)
+    exact = lambda poly: [[(F(x), F(y)) for x, y in ring] for ring in poly]
+    exp = np.array([contains_bruteforce(exact(p), exact(q)) for p, q in pairs])
+    assert 40 < exp.sum() < 600
+    assert np.array_equal(got, exp)
