@@ -72,3 +72,19 @@ def nudged(poly, rng, prob=0.1):
             r.append((fx, fy))
         out.append(r)
     return out
+
+
+def load_contains_golden():
+    """tests/golden/contains_lattice.npz -> (a, b, expected): 4000 polygon pairs and contains(a, b) from the rational
+    brute force (tests/golden/make_contains_golden.py)"""
+    import os
+
+    import numpy as np
+
+    from geopolars_amd import _abi
+    from geopolars_amd.geoarrow import GeoArrowArray
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "contains_lattice.npz"))
+    a = GeoArrowArray(_abi.GEOM_POLYGON, z["a_xy"], geom_offsets=z["a_geom_offsets"], ring_offsets=z["a_ring_offsets"])
+    b = GeoArrowArray(_abi.GEOM_POLYGON, z["b_xy"], geom_offsets=z["b_geom_offsets"], ring_offsets=z["b_ring_offsets"])
+    return a, b, z["contains"].astype(bool)

@@ -154,3 +154,13 @@ def test_rowwise_contains_on_inexact_floats(gpk, oracle):
     assert 300 < exp.sum() < 5000
     assert np.array_equal(GeoSeries(a).contains(GeoSeries(b)), exp)
     assert np.array_equal(GeoSeries(b).within(GeoSeries(a)), exp)
+
+
+def test_rowwise_contains_matches_the_rational_golden(gpk):
+    """answers computed with Fraction arithmetic by tests/golden/make_contains_golden.py: no oracle between the GPU and
+    the exact result"""
+    from .lattice import load_contains_golden
+
+    a, b, exp = load_contains_golden()
+    assert np.array_equal(GeoSeries(a).contains(GeoSeries(b)), exp)
+    assert np.array_equal(GeoSeries(b).within(GeoSeries(a)), exp)

@@ -468,3 +468,13 @@ def test_polygon_contains_polygon_on_inexact_floats(oracle):
     exp = np.array([contains_bruteforce(exact(p), exact(q)) for p, q in pairs])
     assert 40 < exp.sum() < 600
     assert np.array_equal(got, exp)
+
+
+def test_oracle_reproduces_the_contains_golden(oracle):
+    """the committed brute-force answers (tests/golden/contains_lattice.npz) — the same file the GPU test reads"""
+    from .lattice import load_contains_golden
+
+    a, b, exp = load_contains_golden()
+    assert len(exp) == 4000 and 300 < exp.sum() < 1000
+    assert np.array_equal(oracle.predicate_rowwise(a, b, "contains").astype(bool), exp)
+    assert np.array_equal(oracle.predicate_rowwise(b, a, "within").astype(bool), exp)
