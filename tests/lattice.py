@@ -74,9 +74,9 @@ def nudged(poly, rng, prob=0.1):
     return out
 
 
-def load_contains_golden():
-    """tests/golden/contains_lattice.npz -> (a, b, expected): 4000 polygon pairs and contains(a, b) from the rational
-    brute force (tests/golden/make_contains_golden.py)"""
+def load_contains_golden(key="contains"):
+    """tests/golden/contains_lattice.npz -> (a, b, expected): 4000 polygon pairs and contains(a, b) / intersects(a, b) from
+    the rational brute force (tests/golden/make_contains_golden.py)"""
     import os
 
     import numpy as np
@@ -87,4 +87,4 @@ def load_contains_golden():
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "contains_lattice.npz"))
     a = GeoArrowArray(_abi.GEOM_POLYGON, z["a_xy"], geom_offsets=z["a_geom_offsets"], ring_offsets=z["a_ring_offsets"])
     b = GeoArrowArray(_abi.GEOM_POLYGON, z["b_xy"], geom_offsets=z["b_geom_offsets"], ring_offsets=z["b_ring_offsets"])
-    return a, b, z["contains"].astype(bool)
+    return a, b, z[key].astype(bool)

@@ -164,3 +164,6 @@ def test_rowwise_contains_matches_the_rational_golden(gpk):
     a, b, exp = load_contains_golden()
     assert np.array_equal(GeoSeries(a).contains(GeoSeries(b)), exp)
     assert np.array_equal(GeoSeries(b).within(GeoSeries(a)), exp)
+    exp_i = load_contains_golden(key="intersects")[2]
+    assert np.array_equal(GeoSeries(a).intersects(GeoSeries(b)), exp_i)
+    assert np.array_equal(GeoSeries(b).intersects(GeoSeries(a)), exp_i)

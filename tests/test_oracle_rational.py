@@ -218,6 +218,15 @@ def _poly_pos(poly, p) -> int:
     return 1
 
 
+def intersects_bruteforce(pa, pb) -> bool:
+    """the closed sets meet: two boundary segments meet, or a vertex of one polygon is not outside the other (with holes)"""
+    ea = [e for ring in pa for e in _edges(ring)]
+    eb = [e for ring in pb for e in _edges(ring)]
+    if any(seg_intersect(a0, a1, b0, b1) for a0, a1 in ea for b0, b1 in eb):
+        return True
+    return any(_poly_pos(pa, v) >= 0 for ring in pb for v in ring) or any(_poly_pos(pb, v) >= 0 for ring in pa for v in ring)
+
+
 def contains_bruteforce(pa, pb) -> bool:
     # (1) every vertex and every piece of the boundary of B lies in A (closed)
     for ring in pb:
@@ -478,3 +487,6 @@ def test_oracle_reproduces_the_contains_golden(oracle):
     assert len(exp) == 4000 and 300 < exp.sum() < 1000
     assert np.array_equal(oracle.predicate_rowwise(a, b, "contains").astype(bool), exp)
     assert np.array_equal(oracle.predicate_rowwise(b, a, "within").astype(bool), exp)
+    exp_i = load_contains_golden(key="intersects")[2]
+    assert exp_i.sum() > exp.sum() and not exp_i.all()
+    assert np.array_equal(oracle.predicate_rowwise(a, b, "intersects").astype(bool), exp_i)
