@@ -56,3 +56,31 @@ def test_hip_path_reproduces_the_ops_golden(gpk):
     s, p = GeoSeries(polys), GeoSeries(pts)
     h = s.convex_hull().array
     _check(z, s.area(), s.centroid().array.xy, h.xy, h.ring_offsets, s.contains(p), s.intersects(p), p.within(s), p.distance(s), rtol=1e-9)
+
+
+def _load_join():
+    z = np.load(os.path.join(HERE, "golden", "join_lattice.npz"))
+    polys = GeoArrowArray(_abi.GEOM_POLYGON, z["xy"], geom_offsets=z["geom_offsets"], ring_offsets=z["ring_offsets"])
+    return polys, GeoArrowArray.from_points(z["points"]), z["pairs"]
+
+
+def test_oracle_reproduces_the_join_golden(oracle):
+    """tests/golden/join_lattice.npz: point-in-polygon pairs from an even-odd ring walk in Python integers (1251 point /
+    polygon incidences lie exactly on a boundary and must be rejected, KA-1)"""
+    polys, pts, exp = _load_join()
+    for mode in (0, 1):  # brute force and grid directory
+        pairs, counts, _ = oracle.spatial_join(pts, polys, "intersects", mode=mode)
+        assert np.array_equal(pairs, exp) and np.array_equal(counts, np.bincount(exp[:, 0], minlength=len(pts)))
+    back, _, _ = oracle.spatial_join(polys, pts, "contains", mode=0)  # polygon on the left: the transposed pairs
+    assert np.array_equal(back[np.lexsort((back[:, 0], back[:, 1]))][:, ::-1], exp)
+
+
+@pytest.mark.gpu
+def test_hip_join_reproduces_the_join_golden(gpk):
+    from geopolars_amd.spatial_index import join_pairs
+
+    polys, pts, exp = _load_join()
+    pairs, counts = join_pairs(GeoSeries(pts), GeoSeries(polys), "intersects")
+    assert np.array_equal(pairs, exp) and np.array_equal(counts, np.bincount(exp[:, 0], minlength=len(pts)))
+    back, _ = join_pairs(GeoSeries(polys), GeoSeries(pts), "contains")
+    assert np.array_equal(back[np.lexsort((back[:, 0], back[:, 1]))][:, ::-1], exp)
