@@ -84,3 +84,34 @@ def test_hip_join_reproduces_the_join_golden(gpk):
     assert np.array_equal(pairs, exp) and np.array_equal(counts, np.bincount(exp[:, 0], minlength=len(pts)))
     back, _ = join_pairs(GeoSeries(polys), GeoSeries(pts), "contains")
     assert np.array_equal(back[np.lexsort((back[:, 0], back[:, 1]))][:, ::-1], exp)
+
+
+def _load_lines():
+    z = np.load(os.path.join(HERE, "golden", "lines_lattice.npz"))
+    return z, GeoArrowArray(_abi.GEOM_LINESTRING, z["xy"], geom_offsets=z["geom_offsets"]), GeoArrowArray.from_points(z["points"])
+
+
+def _check_lines(z, length, centroid, bounds, contains, within, distance, rtol):
+    ok = z["centroid_valid"]
+    assert np.allclose(length, z["length"], rtol=rtol, atol=0)
+    assert np.isnan(centroid[~ok]).all() and np.allclose(centroid[ok], z["centroid"][ok], rtol=rtol, atol=rtol)
+    assert np.array_equal(bounds, z["bounds"], equal_nan=True)
+    assert np.array_equal(contains, z["contains"]) and np.array_equal(within, z["contains"])
+    assert not np.isnan(distance).any() and np.array_equal(distance == 0, z["distance"] == 0)
+    assert np.allclose(distance, z["distance"], rtol=rtol, atol=0)
+
+
+def test_oracle_reproduces_the_lines_golden(oracle):
+    z, lines, pts = _load_lines()
+    c, valid = oracle.centroid(lines)
+    assert np.array_equal(valid, z["centroid_valid"])
+    c = np.where(valid[:, None], c, np.nan)
+    _check_lines(z, oracle.euclidean_length(lines), c, oracle.bounds(lines), oracle.predicate_rowwise(lines, pts, "contains").astype(bool),
+                 oracle.predicate_rowwise(pts, lines, "within").astype(bool), oracle.distance_rowwise(pts, lines), rtol=1e-12)
+
+
+@pytest.mark.gpu
+def test_hip_path_reproduces_the_lines_golden(gpk):
+    z, lines, pts = _load_lines()
+    s, p = GeoSeries(lines), GeoSeries(pts)
+    _check_lines(z, s.euclidean_length(), s.centroid().array.xy, s.bounds(), s.contains(p), p.within(s), p.distance(s), rtol=1e-9)
