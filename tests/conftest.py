@@ -8,6 +8,15 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+try:  # property tests run the same examples on every machine (the long randomised runs are done offline)
+    from hypothesis import settings as _hyp_settings
+
+    _hyp_settings.register_profile("repeatable", derandomize=True)
+    _hyp_settings.load_profile("repeatable")
+except ImportError:  # hypothesis is only needed by the property tests themselves
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
