@@ -215,8 +215,19 @@ class GeoSeries:
             GeoArrowArray(a.geom_type, out, a.geom_offsets, a.part_offsets, a.ring_offsets, a.validity, n_geoms=a.n_geoms)
         )
 
-    def translate(self, x: float = 0.0, y: float = 0.0) -> "GeoSeries":
-        return self.affine_transform([1.0, 0.0, x, 0.0, 1.0, y])
+    def translate(self, xoff: float = 0.0, yoff: float = 0.0) -> "GeoSeries":
+        """geoseries.rs:163-174; parameter names of the Python surface (georust/geoseries.py:278)"""
+        return self.affine_transform([1.0, 0.0, xoff, 0.0, 1.0, yoff])
+
+    # ---- operators of the reference surface that are off this backend's path (DESIGN.md §8) -------------------
+    def geodesic_length(self, method: str = "geodesic") -> np.ndarray:
+        raise NotImplementedError("geodesic_length (geoseries.rs:52-58) is not on the accelerated path: use the reference's CPU implementation")
+
+    def simplify(self, tolerance: float) -> "GeoSeries":
+        raise NotImplementedError("simplify (geoseries.rs:108-116) is not on the accelerated path: use the reference's CPU implementation")
+
+    def to_crs(self, from_crs: str, to_crs: str) -> "GeoSeries":
+        raise NotImplementedError("to_crs (geoseries.rs:148-151, PROJ) is not on the accelerated path: use the reference's CPU implementation")
 
     def _origin(self, origin: TransformOrigin) -> np.ndarray:
         """TransformOrigin (py-geopolars/src/utils.rs:5-27): 'centroid' | 'center' (of the bbox) |

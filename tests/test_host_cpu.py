@@ -265,3 +265,17 @@ def test_plain_c_client_links_and_fails_loudly_without_a_device(tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+
+
+def test_off_path_operators_say_so():
+    """geodesic_length / simplify / to_crs belong to the reference surface but not to this backend: a clear
+    error instead of an AttributeError; translate takes the Python surface's parameter names"""
+    import inspect
+
+    from geopolars_amd.geoseries import GeoSeries
+
+    s = GeoSeries(GeoArrowArray.from_points([(0.0, 0.0)]))
+    for call in (lambda: s.geodesic_length(), lambda: s.simplify(1.0), lambda: s.to_crs("EPSG:4326", "EPSG:3857")):
+        with pytest.raises(NotImplementedError, match="not on the accelerated path"):
+            call()
+    assert list(inspect.signature(GeoSeries.translate).parameters)[1:] == ["xoff", "yoff"]
