@@ -279,3 +279,34 @@ def test_off_path_operators_say_so():
         with pytest.raises(NotImplementedError, match="not on the accelerated path"):
             call()
     assert list(inspect.signature(GeoSeries.translate).parameters)[1:] == ["xoff", "yoff"]
+
+
+def test_wkb_host_codec_round_trip_on_random_structures():
+    """encode -> decode is the identity on ragged columns: multipolygons with empty rows, empty members' neighbours, holes,
+    rings of 1..9 coordinates; linestrings and multipoints with empty rows (host codec, gpk_wkb.cpp)"""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    coord = st.tuples(st.integers(-1000, 1000), st.integers(-1000, 1000))
+    ring = st.lists(coord, min_size=1, max_size=9)
+    polygon = st.lists(ring, min_size=1, max_size=3)
+    multipolygon = st.lists(polygon, min_size=0, max_size=3)
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.lists(multipolygon, min_size=1, max_size=6), st.lists(st.lists(coord, min_size=0, max_size=6), min_size=1, max_size=6))
+    def run(mps, lines):
+        cases = [
+            GeoArrowArray.from_multipolygons(mps, close=False),
+            GeoArrowArray.from_linestrings(lines),
+            GeoArrowArray(_abi.GEOM_MULTIPOINT, np.array([c for l in lines for c in l], dtype=np.float64).reshape(-1, 2),
+                          geom_offsets=np.concatenate([[0], np.cumsum([len(l) for l in lines])]).astype(np.int32)),
+        ]
+        for a in cases:
+            v, o = a.to_wkb()
+            b = GeoArrowArray.from_wkb(v, o)
+            assert b.geom_type == a.geom_type and np.array_equal(b.xy, a.xy) and np.array_equal(b.geom_offsets, a.geom_offsets)
+            for name in ("part_offsets", "ring_offsets"):
+                x, y = getattr(a, name), getattr(b, name)
+                assert (x is None) == (y is None) and (x is None or np.array_equal(x, y)), name
+
+    run()
