@@ -37,6 +37,8 @@ MEM_DEVICE = 1
 PRED_INTERSECTS = 0
 PRED_CONTAINS = 1
 PRED_WITHIN = 2
+INDEX_BBOX_GRID = 1
+INDEX_PIP = 2
 PREDICATES = {"intersects": PRED_INTERSECTS, "contains": PRED_CONTAINS, "within": PRED_WITHIN}
 
 
@@ -92,6 +94,7 @@ _PROTOS = {
     "gpk_distance_rowwise": (C.c_int32, [_VP, _VP, _VP, _VP, C.c_int32, _VP]),
     "gpk_predicate_rowwise": (C.c_int32, [_VP, _VP, _VP, C.c_int32, _VP, C.c_int32, _VP]),
     "gpk_index_build": (C.c_int32, [_VP, _VP, C.POINTER(_VP)]),
+    "gpk_index_build_ex": (C.c_int32, [_VP, C.c_int32, _VP, _VP, C.POINTER(_VP)]),
     "gpk_index_free": (C.c_int32, [_VP]),
     "gpk_index_nbytes": (C.c_int32, [_VP, C.POINTER(C.c_int64)]),
     "gpk_spatial_join": (

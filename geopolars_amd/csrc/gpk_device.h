@@ -31,6 +31,11 @@ __device__ __forceinline__ void store_stream(uint32_t* p, uint32_t v) { __builti
 __device__ __forceinline__ bool valid_row(const uint8_t* validity, int64_t i) {
     return !validity || ((validity[i >> 3] >> (i & 7)) & 1);
 }
+// a row a caller's index map points at: out-of-range indices behave like null rows (the gather semantics of
+// gpk_take_*; include/geopolars_hip.h states the contract for `b_rows`)
+__device__ __forceinline__ bool row_ok(const DevGeo& g, int64_t j) {
+    return (uint64_t)j < (uint64_t)g.n_geoms && valid_row(g.validity, j);
+}
 
 // ---- exact orientation -------------------------------------------------------------------------
 __device__ __forceinline__ void two_sum(double a, double b, double& s, double& e) {

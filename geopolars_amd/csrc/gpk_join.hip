@@ -869,18 +869,23 @@ static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, co
     uint32_t* pairs_dev = want_pairs ? (host_out ? (uint32_t*)workspace().take(pairs_bytes) : out_pairs) : nullptr;
 
     int32_t n_cand = 0, has_big_rows = 0;
+    unsigned long long cand_total = 0;  // the 64-bit grand total of the scan: cand_off[n] is its truncation to i32
     auto stage1 = [&]() -> int32_t {
         GPK_HIP(hipMemsetAsync(big_rows, 0, sizeof(int32_t), s));
         GPK_LAUNCH("gpk_bbox_cand_count", bbox_cand_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, left->d, right->d, right_index->v,
                    lbbox, cand_cnt, (const int32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, big_rows);
         GPK_TRY(exclusive_scan_i32(cand_cnt, n, cand_off, nullptr, btot, s));
-        GPK_HIP(hipMemcpyAsync(&n_cand, cand_off + n, sizeof n_cand, hipMemcpyDeviceToHost, s));
+        GPK_HIP(hipMemcpyAsync(&cand_total, btot + nb, sizeof cand_total, hipMemcpyDeviceToHost, s));
         GPK_HIP(hipMemcpyAsync(&has_big_rows, big_rows, sizeof has_big_rows, hipMemcpyDeviceToHost, s));
         GPK_HIP(hipStreamSynchronize(s));
         return GPK_OK;
     };
     rc = stage1();
     if (rc != GPK_OK) return done(rc);
+    // candidate offsets are i32 (one slice per left row): more than 2^31 - 1 bbox candidates cannot be addressed
+    if (cand_total > (unsigned long long)INT32_MAX)
+        return done(fail(GPK_ERR_CAPACITY, "spatial_join: %llu bbox candidates exceed the i32 candidate offsets: shard the left side", cand_total));
+    n_cand = (int32_t)cand_total;
     uint32_t *cand_r = nullptr, *cand_l = nullptr, *cand_sorted = nullptr;
     uint8_t* hit = nullptr;
     void* seg_tmp = nullptr;
@@ -941,8 +946,8 @@ static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, co
     };
     rc = stage23();
     if (rc != GPK_OK) return done(rc);
-    int32_t total = 0;
-    hipError_t e = hipMemcpyAsync(&total, offsets + n, sizeof total, hipMemcpyDeviceToHost, s);
+    unsigned long long total = 0;  // 64-bit grand total of the hit scan (hits <= candidates <= INT32_MAX, checked above)
+    hipError_t e = hipMemcpyAsync(&total, btot + nb, sizeof total, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return done(fail(GPK_ERR_DEVICE, "spatial_join: %s", hipGetErrorString(e)));
     *n_pairs = (int64_t)total;
@@ -1149,6 +1154,10 @@ int32_t gpk_index_nbytes(const gpk_index* idx, int64_t* out_bytes) {
 }
 
 int32_t gpk_index_build(const gpk_geoarray* a, void* stream, gpk_index** out) {
+    return gpk_index_build_ex(a, GPK_INDEX_BBOX_GRID | GPK_INDEX_PIP, nullptr, stream, out);
+}
+
+int32_t gpk_index_build_ex(const gpk_geoarray* a, int32_t parts, const double* bbox4_dev, void* stream, gpk_index** out) {
     if (!a || !out) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
     *out = nullptr;
     GPK_TRY(require_device());
@@ -1183,6 +1192,16 @@ int32_t gpk_index_build(const gpk_geoarray* a, void* stream, gpk_index** out) {
         int32_t _rc = (expr);                    \
         if (_rc != GPK_OK) return cleanup(_rc);  \
     } while (0)
+// a failed launch must release the half-built index too (GPK_LAUNCH returns from the enclosing function)
+#define IX_LAUNCH(...)                           \
+    do {                                         \
+        auto _f = [&]() -> int32_t {             \
+            GPK_LAUNCH(__VA_ARGS__);             \
+            return GPK_OK;                       \
+        };                                       \
+        int32_t _rc = _f();                      \
+        if (_rc != GPK_OK) return cleanup(_rc);  \
+    } while (0)
 
     double4* bbox = nullptr;
     GridParams* grid = nullptr;
@@ -1194,11 +1213,15 @@ int32_t gpk_index_build(const gpk_geoarray* a, void* stream, gpk_index** out) {
     IX_HIP(hipMalloc((void**)&cell_off, sizeof(int32_t) * (size_t)(n_cells + 1)));
     ix->owned[2] = cell_off;
 
-    // 1. bounding boxes (NodeEnvelope, spatial_index.rs:212-312)
-    IX_TRY(gpk_bounds(a, (double*)bbox, GPK_MEM_DEVICE, stream));
+    // 1. bounding boxes (NodeEnvelope, spatial_index.rs:212-312) — or the caller's (the leaves another rank built and
+    //    sent over xGMI: dist.all_gather_leaves)
+    if (bbox4_dev)
+        IX_HIP(hipMemcpyAsync(bbox, bbox4_dev, sizeof(double4) * (size_t)n, hipMemcpyDeviceToDevice, s));
+    else
+        IX_TRY(gpk_bounds(a, (double*)bbox, GPK_MEM_DEVICE, stream));
 
     // 2. extent + grid parameters, all on device
-    GPK_LAUNCH("gpk_index_extent", extent_kernel, dim3(1), dim3(1024), 0, s, bbox, n, gdim, gdim, grid);
+    IX_LAUNCH("gpk_index_extent", extent_kernel, dim3(1), dim3(1024), 0, s, bbox, n, gdim, gdim, grid);
 
     // 3. count, scan, fill, sort
     const int64_t n_blocks = (n_cells + 255) / 256;
@@ -1209,7 +1232,7 @@ int32_t gpk_index_build(const gpk_geoarray* a, void* stream, gpk_index** out) {
     unsigned long long* btot = (unsigned long long*)workspace().take(sizeof(unsigned long long) * (size_t)(n_blocks + 1));
     IX_HIP(hipMemsetAsync(cell_cnt, 0, sizeof(int32_t) * (size_t)(n_cells + 1), s));
     if (n > 0)
-        GPK_LAUNCH("gpk_index_count", grid_register_kernel<false>, grid_for(n, 256), dim3(256), 0, s, bbox, n, grid, cell_cnt, (int32_t*)nullptr);
+        IX_LAUNCH("gpk_index_count", grid_register_kernel<false>, grid_for(n, 256), dim3(256), 0, s, bbox, n, grid, cell_cnt, (int32_t*)nullptr);
     IX_TRY(exclusive_scan_i32(cell_cnt, n_cells, cell_off, cursor, btot, s));
     unsigned long long total = 0;
     IX_HIP(hipMemcpyAsync(&total, btot + n_blocks, sizeof total, hipMemcpyDeviceToHost, s));
@@ -1221,12 +1244,13 @@ int32_t gpk_index_build(const gpk_geoarray* a, void* stream, gpk_index** out) {
     IX_HIP(hipMalloc((void**)&items, sizeof(int32_t) * (size_t)(total > 0 ? total : 1)));
     ix->owned[3] = items;
     if (n > 0) {
-        GPK_LAUNCH("gpk_index_fill", grid_register_kernel<true>, grid_for(n, 256), dim3(256), 0, s, bbox, n, grid, cursor, items);
-        GPK_LAUNCH("gpk_index_sort", cell_sort_kernel, grid_for(n_cells, 256), dim3(256), 0, s, cell_off, n_cells, items);
+        IX_LAUNCH("gpk_index_fill", grid_register_kernel<true>, grid_for(n, 256), dim3(256), 0, s, bbox, n, grid, cursor, items);
+        IX_LAUNCH("gpk_index_sort", cell_sort_kernel, grid_for(n_cells, 256), dim3(256), 0, s, cell_off, n_cells, items);
     }
     IX_HIP(hipStreamSynchronize(s));  // the workspace may be recycled by the next call on another stream
 #undef IX_HIP
 #undef IX_TRY
+#undef IX_LAUNCH
 
     ix->v.bbox = bbox;
     ix->v.grid = grid;
@@ -1236,7 +1260,7 @@ int32_t gpk_index_build(const gpk_geoarray* a, void* stream, gpk_index** out) {
     ix->v.gy = gdim;
     ix->nbytes = (int64_t)(sizeof(double4) * (size_t)n + sizeof(GridParams) + sizeof(int32_t) * (size_t)(n_cells + 1) +
                            sizeof(int32_t) * (size_t)total);
-    {
+    if (parts & GPK_INDEX_PIP) {
         const int32_t rc = build_pip_index(a, ix, s);  // raster + slabs for polygonal arrays
         if (rc != GPK_OK) {
             gpk_index_free(ix);
@@ -1279,8 +1303,8 @@ int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right, co
     }
 
     gpk_index* tmp_index = nullptr;
-    if (!right_index) {  // built on the fly, like spatial_index.rs:60-71
-        GPK_TRY(gpk_index_build(right, stream, &tmp_index));
+    if (!right_index) {  // built on the fly, like spatial_index.rs:60-71 — only the tables this arm reads
+        GPK_TRY(gpk_index_build_ex(right, GPK_INDEX_BBOX_GRID | (pip ? GPK_INDEX_PIP : 0), nullptr, stream, &tmp_index));
         right_index = tmp_index;
     } else if (right_index->n_geoms != right->d.n_geoms) {
         return fail(GPK_ERR_INVALID_ARGUMENT, "right_index was built over a different array");

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void distance_kernel(DevGeo pts, DevGeo other,
             if (li < tile_rows) {
                 const int64_t i = base + li;
                 const int64_t j = rows ? (int64_t)rows[i] : i;
-                const int w = geom_work(other, j);
+                const int w = (uint64_t)j < (uint64_t)other.n_geoms ? geom_work(other, j) : 0;  // out-of-range map entry: a null row
                 bin[k] = w <= 1 ? 0 : (32 - __clz(w - 1));  // ceil(log2(w)); w < 2^23 -> bin < DIST_BINS
                 if (bin[k] >= DIST_BINS) bin[k] = DIST_BINS - 1;
                 rank[k] = atomicAdd(&s_cnt[bin[k]], 1);
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void distance_kernel(DevGeo pts, DevGeo other,
             const int64_t j = rows ? (int64_t)rows[i] : i;
             const double2 p = pts.xy[i];
             double d;
-            if (!dev::valid_row(pts.validity, i) || !dev::valid_row(other.validity, j) || isnan(p.x) || isnan(p.y))
+            if (!dev::valid_row(pts.validity, i) || !dev::row_ok(other, j) || isnan(p.x) || isnan(p.y))
                 d = NAN;
             else
                 d = point_geom_distance<G, KIND>(other, j, p.x, p.y, lane);
@@ -332,13 +332,19 @@ __global__ __launch_bounds__(256) void distance_kernel(DevGeo pts, DevGeo other,
 // Both passes aggregate equal keys inside a wave before touching memory (clustered row maps put many rows of
 // one target in the same wave: 64 same-address atomics would serialise): up to two rounds of "lanes that share
 // the first remaining lane's key go together", the rest falls back to one atomic per lane.
+// Map entries >= L (no such target) are counted in the extra bucket L, which no work item covers; the scatter pass gives
+// those rows their result directly: NaN, the answer of a null row.
 template <bool SCATTER>
-__global__ __launch_bounds__(256) void dist_sort_kernel(const uint32_t* __restrict__ rows, int64_t n, int32_t* __restrict__ counter,
-                                                        uint32_t* __restrict__ perm) {
+__global__ __launch_bounds__(256) void dist_sort_kernel(const uint32_t* __restrict__ rows, int64_t n, uint32_t L, int32_t* __restrict__ counter,
+                                                        uint32_t* __restrict__ perm, double* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     bool todo = i < n;
-    const uint32_t key = todo ? rows[i] : 0u;
+    uint32_t key = todo ? rows[i] : 0u;
+    if (key >= L) {
+        key = L;
+        if (SCATTER && todo) out[i] = NAN;
+    }
 #pragma unroll
     for (int round = 0; round < 2; ++round) {
         const unsigned long long rest = __ballot(todo);
@@ -373,9 +379,15 @@ __global__ __launch_bounds__(256) void dist_probe_kernel(const uint32_t* __restr
     const unsigned long long m = __ballot(i + 1 < n && (kn - k <= 1u));
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(local, (unsigned long long)__popcll(m));
 }
-__global__ void iota_u32_kernel(uint32_t* __restrict__ v, int64_t n) {
+// radix-sort grouping: row numbers, and the map clamped to L (entries without a target sort behind every real one and get NaN)
+__global__ void iota_clamp_kernel(const uint32_t* __restrict__ rows, uint32_t L, uint32_t* __restrict__ iota, uint32_t* __restrict__ keys,
+                                  double* __restrict__ out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) v[i] = (uint32_t)i;
+    if (i >= n) return;
+    iota[i] = (uint32_t)i;
+    const uint32_t k = rows[i];
+    keys[i] = k < L ? k : L;
+    if (k >= L) out[i] = NAN;
 }
 // off[t] = first position of key t in the sorted keys (t = 0..L), cnt[t] = rows of target t
 __global__ void sorted_offsets_kernel(const uint32_t* __restrict__ keys, int64_t n, int64_t L, int32_t* __restrict__ off,
@@ -526,9 +538,10 @@ __global__ __launch_bounds__(256) void point_poly_predicate_kernel(DevGeo pts, D
         // row i of the left operand pairs with row rows[i] (or i) of the right operand
         const int64_t ip = rows_index_polys ? i : (rows ? (int64_t)rows[i] : i);
         const int64_t jp = rows_index_polys ? (rows ? (int64_t)rows[i] : i) : i;
-        const double2 p = pts.xy[ip];
+        const bool ok = dev::row_ok(pts, ip) && dev::row_ok(polys, jp);
+        const double2 p = ok ? pts.xy[ip] : make_double2(NAN, NAN);
         bool hit = false;
-        if (dev::valid_row(pts.validity, ip) && dev::valid_row(polys.validity, jp) && !isnan(p.x) && !isnan(p.y)) {
+        if (ok && !isnan(p.x) && !isnan(p.y)) {
             int p0, p1;
             dev::geom_parts(polys, jp, p0, p1);
             for (int q = p0; q < p1 && !hit; ++q) {
@@ -553,7 +566,7 @@ __global__ __launch_bounds__(256) void poly_poly_intersects_kernel(DevGeo a, Dev
     for (int64_t i = (int64_t)blockIdx.x * (256 / PP_GS) + threadIdx.x / PP_GS; i < a.n_geoms; i += groups) {
         const int64_t j = rows ? (int64_t)rows[i] : i;
         bool hit = false;
-        if (dev::valid_row(a.validity, i) && dev::valid_row(b.validity, j))
+        if (dev::valid_row(a.validity, i) && dev::row_ok(b, j))
             hit = polygonal_intersects_polygonal_group<PP_GS>(a, i, b, j, lane, seg_list);
         if (lane == 0) out[i] = hit;
     }
@@ -567,7 +580,7 @@ __global__ __launch_bounds__(256) void poly_poly_contains_kernel(DevGeo a, DevGe
     for (int64_t i = (int64_t)blockIdx.x * (256 / PP_GS) + threadIdx.x / PP_GS; i < a.n_geoms; i += groups) {
         const int64_t j = rows ? (int64_t)rows[i] : i;
         bool hit = false;
-        if (dev::valid_row(a.validity, i) && dev::valid_row(b.validity, j))
+        if (dev::valid_row(a.validity, i) && dev::row_ok(b, j))
             hit = swap ? cont::polygonal_contains_polygonal_group<PP_GS>(b, j, a, i, lane)
                        : cont::polygonal_contains_polygonal_group<PP_GS>(a, i, b, j, lane);
         if (lane == 0) out[i] = hit;
@@ -581,7 +594,7 @@ __global__ void lineal_point_contains_kernel(DevGeo a, DevGeo b, const uint32_t*
     if (i >= a.n_geoms) return;
     const int64_t j = rows ? (int64_t)rows[i] : i;
     bool hit = false;
-    if (dev::valid_row(a.validity, i) && dev::valid_row(b.validity, j)) {
+    if (dev::valid_row(a.validity, i) && dev::row_ok(b, j)) {
         const double2 p = lineal_is_a ? b.xy[j] : a.xy[i];
         if (p.x == p.x && p.y == p.y) hit = lineal_is_a ? lineal_contains_point(a, i, p.x, p.y) : lineal_contains_point(b, j, p.x, p.y);
     }
@@ -592,8 +605,9 @@ __global__ void point_point_equal_kernel(DevGeo a, DevGeo b, const uint32_t* __r
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_geoms) return;
     const int64_t j = rows ? (int64_t)rows[i] : i;
-    const double2 p = a.xy[i], q = b.xy[j];
-    out[i] = dev::valid_row(a.validity, i) && dev::valid_row(b.validity, j) && p.x == q.x && p.y == q.y;
+    const bool ok = dev::valid_row(a.validity, i) && dev::row_ok(b, j);
+    const double2 p = a.xy[i], q = ok ? b.xy[j] : make_double2(NAN, NAN);
+    out[i] = ok && p.x == q.x && p.y == q.y;
 }
 
 __global__ void fill_u8_kernel(uint8_t* out, int64_t n, uint8_t v) {
@@ -689,21 +703,23 @@ int32_t gpk_distance_rowwise(const gpk_geoarray* a, const gpk_geoarray* b, const
             const int64_t sampled = (int64_t)probe_blocks * 256 < n ? (int64_t)probe_blocks * 256 : n;
             if (2 * (int64_t)h_local >= sampled) {
                 GPK_HIP(hipMemsetAsync(g_cnt, 0, sizeof(int32_t) * (size_t)(L + 1), s));
-                GPK_LAUNCH("gpk_dist_hist", dist_sort_kernel<false>, rg, dim3(256), 0, s, rows_dev, n, g_cnt, (uint32_t*)nullptr);
-                GPK_TRY(exclusive_scan_i32(g_cnt, L, g_off, g_cur, btot, s));
-                GPK_LAUNCH("gpk_dist_scatter", dist_sort_kernel<true>, rg, dim3(256), 0, s, rows_dev, n, g_cur, perm);
+                GPK_LAUNCH("gpk_dist_hist", dist_sort_kernel<false>, rg, dim3(256), 0, s, rows_dev, n, (uint32_t)L, g_cnt, (uint32_t*)nullptr, (double*)nullptr);
+                GPK_TRY(exclusive_scan_i32(g_cnt, L, g_off, g_cur, btot, s));  // g_cur[L] = g_off[L]: the bucket of map entries without a target
+                GPK_HIP(hipMemcpyAsync(g_cur + L, g_off + L, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+                GPK_LAUNCH("gpk_dist_scatter", dist_sort_kernel<true>, rg, dim3(256), 0, s, rows_dev, n, (uint32_t)L, g_cur, perm, out_dev);
             } else {
                 int bits = 1;
-                while (bits < 32 && (1ll << bits) < L) ++bits;
+                while (bits < 32 && (1ll << bits) < L + 1) ++bits;  // keys 0..L (L = "no such target")
                 size_t tb = 0;
                 GPK_HIP(rocprim::radix_sort_pairs(nullptr, tb, rows_dev, (uint32_t*)nullptr, (const uint32_t*)nullptr, perm, (size_t)n, 0, bits, s));
                 const size_t nbytes = align256(sizeof(uint32_t) * (size_t)n);
-                GPK_HIP(hipMalloc(&sort_tmp, 2 * nbytes + tb + 256));
+                GPK_HIP(hipMalloc(&sort_tmp, 3 * nbytes + tb + 256));
                 uint32_t* iota = (uint32_t*)sort_tmp;
                 uint32_t* keys_sorted = (uint32_t*)((char*)sort_tmp + nbytes);
-                void* rp_tmp = (char*)sort_tmp + 2 * nbytes;
-                GPK_LAUNCH("gpk_dist_iota", iota_u32_kernel, rg, dim3(256), 0, s, iota, n);
-                GPK_HIP(rocprim::radix_sort_pairs(rp_tmp, tb, rows_dev, keys_sorted, (const uint32_t*)iota, perm, (size_t)n, 0, bits, s));
+                uint32_t* keys_in = (uint32_t*)((char*)sort_tmp + 2 * nbytes);
+                void* rp_tmp = (char*)sort_tmp + 3 * nbytes;
+                GPK_LAUNCH("gpk_dist_iota", iota_clamp_kernel, rg, dim3(256), 0, s, rows_dev, (uint32_t)L, iota, keys_in, out_dev, n);
+                GPK_HIP(rocprim::radix_sort_pairs(rp_tmp, tb, (const uint32_t*)keys_in, keys_sorted, (const uint32_t*)iota, perm, (size_t)n, 0, bits, s));
                 GPK_LAUNCH("gpk_dist_offsets", sorted_offsets_kernel, dim3((unsigned)((L + 256) / 256)), dim3(256), 0, s, (const uint32_t*)keys_sorted, n,
                            L, g_off, g_cnt);
             }

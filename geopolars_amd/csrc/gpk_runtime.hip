@@ -271,9 +271,11 @@ int32_t gpk_geoarray_upload(const gpk_geoarrow_desc* d, void* stream, gpk_geoarr
         }
     }
 
+    int cur_dev = 0;
+    GPK_HIP(hipGetDevice(&cur_dev));  // before the handle exists: nothing to release on failure
     gpk_geoarray* a = new gpk_geoarray;
     memset(a, 0, sizeof *a);
-    GPK_HIP(hipGetDevice(&a->device));
+    a->device = cur_dev;
     a->d.type = t;
     a->d.n_geoms = d->n_geoms;
     a->d.n_parts = has_part ? n_parts : (is_polygonal(t) ? d->n_geoms : 0);

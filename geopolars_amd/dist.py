@@ -4,15 +4,23 @@ Every operator is a per-row map (geoseries.rs:141 "1-to-1 row-wise"; the join re
 per candidate pair, spatial_index.rs:83-143), so N GPUs = N independent row ranges of the LEFT
 series, one process per GPU.  The right side is either replicated (C2: 1 MB of polygons ->
 `broadcast_geoarray`) or, when it is itself produced sharded (C4/C5), exchanged ONCE with an
-all-gatherv of its GeoArrow buffers over RCCL/xGMI (`all_gatherv_geoarray`): RCCL has no native
-`v` collective, so buffers are padded to the longest shard, all-gathered, trimmed and the offsets
-rebased.  No collective touches results: output row ranges are disjoint and pairs carry a per-shard
+all-gatherv of its GeoArrow buffers over RCCL/xGMI (`all_gatherv_buffers`): RCCL has no native
+`v` collective, so every buffer is padded to the longest shard, all-gathered with ONE fixed-size
+collective, trimmed and — for offsets — rebased, all on the device the shards live on: nothing is
+staged through the host.  Lengths travel first in one small header all-gather, so every rank issues
+exactly the same sequence of collectives whatever its own shard holds (validity bitmap or not,
+empty or not).  `all_gather_leaves` ships what each rank BUILT for its shard — the per-geometry
+bounding boxes, the leaves of the reference's R-tree (spatial_index.rs:206-312) — so the gathered
+index is assembled from them (gpk_index_build_ex) instead of re-deriving them on every rank.
+No collective touches results: output row ranges are disjoint and pairs carry a per-shard
 `left_row_base`.
 
-Works on CPU tensors with the gloo backend (tests, world_size 2) and CUDA tensors with nccl (= RCCL).
+Works on CPU tensors with the gloo backend (tests, world_size 2) and CUDA tensors with nccl (= RCCL);
+the code path is the same, torch.distributed is the plumbing.
 """
 from __future__ import annotations
 
+from dataclasses import dataclass
 from typing import Optional
 
 import numpy as np
@@ -61,72 +69,146 @@ def slice_rows(a: GeoArrowArray, lo: int, hi: int) -> GeoArrowArray:
     )
 
 
-def _levels(a_type: int, geom_offsets, part_offsets, ring_offsets):
-    """offset buffers from the outermost level inwards"""
-    return [o for o in (geom_offsets, part_offsets, ring_offsets) if o is not None]
+# ---- GeoArrow buffers as tensors of one device --------------------------------------------------------
+@dataclass
+class GeoBuffers:
+    """The buffers of one single-chunk GeoArrow array as torch tensors living on ONE device (a GPU under RCCL,
+    the CPU under gloo): what the exchange moves and what DeviceGeoArray.from_device_buffers borrows."""
+
+    geom_type: int
+    xy: torch.Tensor  # (n_coords, 2) float64
+    geom_offsets: Optional[torch.Tensor] = None  # int32
+    part_offsets: Optional[torch.Tensor] = None
+    ring_offsets: Optional[torch.Tensor] = None
+    valid: Optional[torch.Tensor] = None  # (n_geoms,) uint8, one byte per row (packed to an Arrow bitmap on demand)
+
+    @property
+    def n_geoms(self) -> int:
+        return int(self.xy.shape[0]) if self.geom_type == GEOM_POINT else int(self.geom_offsets.shape[0]) - 1
+
+    @staticmethod
+    def from_host(a: GeoArrowArray, device: torch.device) -> "GeoBuffers":
+        def t(x):
+            return None if x is None else torch.from_numpy(np.ascontiguousarray(x)).to(device)
+
+        valid = None if a.validity is None else torch.from_numpy(a.is_valid().astype(np.uint8)).to(device)
+        return GeoBuffers(a.geom_type, t(a.xy), t(a.geom_offsets), t(a.part_offsets), t(a.ring_offsets), valid)
+
+    def validity_bitmap(self) -> Optional[torch.Tensor]:
+        """Arrow LSB-first bitmap of `valid`, packed on the device."""
+        if self.valid is None:
+            return None
+        n = self.valid.shape[0]
+        pad = (-n) % 8
+        v = torch.cat([self.valid, torch.zeros(pad, dtype=torch.uint8, device=self.valid.device)]) if pad else self.valid
+        w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.int32, device=v.device)
+        return (v.reshape(-1, 8).to(torch.int32) * w).sum(dim=1).to(torch.uint8)
+
+    def to_host(self) -> GeoArrowArray:
+        def h(x):
+            return None if x is None else x.cpu().numpy()
+
+        bm = self.validity_bitmap()
+        return GeoArrowArray(self.geom_type, h(self.xy), geom_offsets=h(self.geom_offsets), part_offsets=h(self.part_offsets), ring_offsets=h(self.ring_offsets), validity=h(bm), n_geoms=self.n_geoms)
+
+    def to_device_geoarray(self, stream: int = 0):
+        """Zero-copy handle over these tensors (they must live in HBM); the tensors are kept alive by the handle."""
+        from .geoarrow import DeviceGeoArray
+
+        return DeviceGeoArray.from_device_buffers(self.geom_type, self.xy, self.geom_offsets, self.part_offsets, self.ring_offsets, self.validity_bitmap(), stream=stream)
 
 
-def _gatherv(t: torch.Tensor, group=None) -> list[torch.Tensor]:
-    """all-gather of variable-length 1-D/2-D tensors: exchange lengths, pad to the max, gather, trim."""
-    world = dist.get_world_size(group)
-    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
-    lens = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(lens, n, group=group)
-    lens = [int(x.item()) for x in lens]
-    m = max(lens)
+_LEVELS = ("geom_offsets", "part_offsets", "ring_offsets")
+
+
+def _pad_gather(t: torch.Tensor, lens: list[int], group) -> list[torch.Tensor]:
+    """One fixed-size all-gather of a variable-length buffer: pad to the longest shard, gather, trim.  `lens` are the
+    first-dimension lengths of every rank's shard (from the header), so no length exchange happens here."""
+    world = len(lens)
+    m = max(max(lens), 1)
     pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     pad[: t.shape[0]] = t
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad, group=group)  # one fixed-size collective per buffer
-    return [o[:k] for o, k in zip(out, lens)]
+    out = torch.empty((world * m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return [out[k * m : k * m + lens[k]] for k in range(world)]
+
+
+def all_gatherv_buffers(local: GeoBuffers, group=None, stats: Optional[dict] = None) -> GeoBuffers:
+    """Every rank contributes its shard of the RIGHT side and receives the concatenation in rank order (the north
+    star's "RCCL all-gatherv over xGMI"), device-resident end to end.  Offsets of shard k are rebased by the child
+    lengths of shards 0..k-1, which the header already carries (an offsets buffer ends with its child's length)."""
+    world = dist.get_world_size(group)
+    dev = local.xy.device
+    present = [getattr(local, k) is not None for k in _LEVELS]
+    hdr = torch.tensor(
+        [local.xy.shape[0]] + [getattr(local, k).shape[0] if p else 0 for k, p in zip(_LEVELS, present)] + [1 if local.valid is not None else 0, local.n_geoms],
+        dtype=torch.int64,
+        device=dev,
+    )
+    all_hdr = torch.empty(world * hdr.shape[0], dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(all_hdr, hdr, group=group)
+    H = all_hdr.cpu().reshape(world, -1).tolist()  # 6 small integers per rank: the only host read of the exchange
+    n_coords = [h[0] for h in H]
+    nbytes = 0
+    xy = torch.cat(_pad_gather(local.xy, n_coords, group))
+    nbytes += xy.numel() * 8
+    out = GeoBuffers(local.geom_type, xy)
+    # child length of each level: the next present level's row count, the coordinates for the innermost
+    child_idx = {"geom_offsets": 2 if present[1] else (3 if present[2] else 0), "part_offsets": 3, "ring_offsets": 0}
+    for li, name in enumerate(_LEVELS):
+        if not present[li]:
+            continue
+        lens = [h[1 + li] for h in H]
+        parts = _pad_gather(getattr(local, name), lens, group)
+        ci = child_idx[name]
+        pieces, base = [], 0
+        for k, p in enumerate(parts):
+            child_len = (H[k][ci] - 1) if ci in (2, 3) else H[k][0]  # rows of the child level, or coordinates
+            pieces.append((p if k == 0 else p[1:]) + base)
+            base += max(child_len, 0)
+        cat = torch.cat(pieces).to(torch.int32)
+        setattr(out, name, cat)
+        nbytes += cat.numel() * 4
+    if any(h[4] for h in H):  # some shard carries nulls: every rank gathers one byte per row (same collective everywhere)
+        n_geoms = [h[5] for h in H]
+        mine = local.valid if local.valid is not None else torch.ones(local.n_geoms, dtype=torch.uint8, device=dev)
+        out.valid = torch.cat(_pad_gather(mine, n_geoms, group))
+        nbytes += out.valid.numel()
+    if stats is not None:
+        stats["gathered_bytes"] = nbytes
+    return out
+
+
+def all_gather_leaves(local_bbox: torch.Tensor, group=None) -> torch.Tensor:
+    """(n_local, 4) float64 per-geometry boxes each rank computed for ITS shard (gpk_bounds) -> the (n_total, 4) boxes
+    of the gathered right side in rank order: the R-tree leaves of spatial_index.rs:206-312 (NodeEnvelope), shipped
+    instead of recomputed.  Feed the result to SpatialIndex.from_device(..., bboxes=...)."""
+    world = dist.get_world_size(group)
+    n = torch.tensor([local_bbox.shape[0]], dtype=torch.int64, device=local_bbox.device)
+    lens = torch.empty(world, dtype=torch.int64, device=local_bbox.device)
+    dist.all_gather_into_tensor(lens, n, group=group)
+    return torch.cat(_pad_gather(local_bbox.reshape(-1, 4), [int(v) for v in lens.cpu().tolist()], group))
 
 
 def all_gatherv_geoarray(local: GeoArrowArray, device: Optional[torch.device] = None, group=None) -> GeoArrowArray:
-    """Every rank contributes its shard of the RIGHT side and receives the concatenation in rank order
-    (the north star's "RCCL all-gatherv ... to broadcast the right-side R-tree leaves").  Offsets of
-    shard k are rebased by the child lengths of shards 0..k-1."""
+    """Host-array convenience over all_gatherv_buffers: the shard goes to `device` once, the exchange runs there, the
+    result comes back once."""
     device = device or torch.device("cpu")
-    xy_parts = _gatherv(torch.from_numpy(local.xy).to(device), group)
-    xy = torch.cat(xy_parts).cpu().numpy()
-    levels_local = _levels(local.geom_type, local.geom_offsets, local.part_offsets, local.ring_offsets)
-    levels = []
-    for off in levels_local:
-        parts = _gatherv(torch.from_numpy(off.astype(np.int32)).to(device), group)
-        rebased, base = [], 0
-        for k, p in enumerate(parts):
-            p = p.cpu().numpy().astype(np.int64)
-            rebased.append((p if k == 0 else p[1:]) + base)
-            base += int(p[-1])
-        levels.append(np.concatenate(rebased).astype(np.int32))
-    names = ["geom_offsets", "part_offsets", "ring_offsets"]
-    present = [n for n, o in zip(names, (local.geom_offsets, local.part_offsets, local.ring_offsets)) if o is not None]
-    kw = dict(zip(present, levels))
-    validity = None
-    if local.validity is not None or _any_rank_has_validity(local, device, group):
-        bits = local.is_valid().astype(np.uint8)
-        vparts = _gatherv(torch.from_numpy(bits).to(device), group)
-        validity = np.packbits(torch.cat(vparts).cpu().numpy(), bitorder="little")
-    return GeoArrowArray(local.geom_type, xy, validity=validity, **kw)
-
-
-def _any_rank_has_validity(local: GeoArrowArray, device, group) -> bool:
-    flag = torch.tensor([1 if local.validity is not None else 0], dtype=torch.int32, device=device)
-    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
-    return bool(flag.item())
+    return all_gatherv_buffers(GeoBuffers.from_host(local, device), group).to_host()
 
 
 def broadcast_geoarray(a: Optional[GeoArrowArray], src: int = 0, device: Optional[torch.device] = None, group=None) -> GeoArrowArray:
     """Replicate a small right side (C2's 1k polygons) from `src` to every rank: header, then each
-    buffer with one broadcast."""
+    buffer (validity included) with one broadcast."""
     device = device or torch.device("cpu")
     rank = dist.get_rank(group)
     hdr = torch.zeros(8, dtype=torch.int64, device=device)
     if rank == src:
-        hdr[:6] = torch.tensor(
-            [a.geom_type, a.n_geoms, a.n_coords, a.n_parts if a.part_offsets is not None else -1, a.n_rings if a.ring_offsets is not None else -1, 0 if a.geom_offsets is None else 1]
+        hdr[:7] = torch.tensor(
+            [a.geom_type, a.n_geoms, a.n_coords, a.n_parts if a.part_offsets is not None else -1, a.n_rings if a.ring_offsets is not None else -1, 0 if a.geom_offsets is None else 1, 0 if a.validity is None else 1]
         )
     dist.broadcast(hdr, src, group=group)
-    gt, n_geoms, n_coords, n_parts, n_rings, has_go = (int(v) for v in hdr[:6].tolist())
+    gt, n_geoms, n_coords, n_parts, n_rings, has_go, has_valid = (int(v) for v in hdr[:7].tolist())
 
     def bc(arr, n, dtype):
         t = torch.from_numpy(np.ascontiguousarray(arr)).to(device) if rank == src else torch.empty(n, dtype=dtype, device=device)
@@ -137,4 +219,5 @@ def broadcast_geoarray(a: Optional[GeoArrowArray], src: int = 0, device: Optiona
     go = bc(a.geom_offsets if rank == src else None, n_geoms + 1, torch.int32) if has_go else None
     po = bc(a.part_offsets if rank == src else None, n_parts + 1, torch.int32) if n_parts >= 0 else None
     ro = bc(a.ring_offsets if rank == src else None, n_rings + 1, torch.int32) if n_rings >= 0 else None
-    return GeoArrowArray(gt, xy, geom_offsets=go, part_offsets=po, ring_offsets=ro, n_geoms=n_geoms)
+    validity = bc(a.validity if rank == src else None, (n_geoms + 7) // 8, torch.uint8) if has_valid else None
+    return GeoArrowArray(gt, xy, geom_offsets=go, part_offsets=po, ring_offsets=ro, validity=validity, n_geoms=n_geoms)

@@ -19,8 +19,9 @@
  *   - Pointers carry a memory space tag (GPK_MEM_HOST / GPK_MEM_DEVICE).  Host buffers are copied to
  *     HBM once by `gpk_geoarray_upload`; device buffers are borrowed (zero copy) — that is how a
  *     caller that already holds data in HBM (another kernel, a torch tensor's data_ptr) plugs in.
- *   - `stream` is a hipStream_t passed as void* (NULL = the library's own per-thread stream).  Calls
- *     with host outputs block until the result is host-visible; calls with device outputs are
+ *   - `stream` is a hipStream_t passed as void* (NULL = HIP's legacy default stream, which orders
+ *     against every other blocking stream of the device; pass your own stream for concurrency).
+ *     Calls with host outputs block until the result is host-visible; calls with device outputs are
  *     stream-ordered and do not synchronise.
  *   - Geometry handles are immutable after upload and may be shared between threads
  *     (mirrors `Arc<SpatialIndex>`, spatial_index.rs:20-21).
@@ -172,7 +173,8 @@ int32_t gpk_convex_hull(const gpk_geoarray* a, double* out_xy, int32_t* out_ring
 /* ---- row-wise binary operators ------------------------------------------------------------ */
 /* distance: geoseries.rs:141-146,248-251 ("1-to-1 row-wise").  `b_rows` (optional, same space as
  * out) maps row i of `a` to row b_rows[i] of `b` — the take() a caller would otherwise materialise;
- * NULL = identity (then n_geoms must match).  out[n_geoms(a)].  Supported: POINT x {POINT,
+ * NULL = identity (then n_geoms must match); an entry >= n_geoms(b) behaves like a null row of b
+ * (distance NaN, predicate false — the out-of-range rule of gpk_take_*).  out[n_geoms(a)].  Supported: POINT x {POINT,
  * LINESTRING, POLYGON, MULTIPOLYGON, MULTILINESTRING, MULTIPOINT} and the mirrored pairs. */
 int32_t gpk_distance_rowwise(const gpk_geoarray* a, const gpk_geoarray* b, const uint32_t* b_rows,
                              double* out, int32_t out_space, void* stream);
@@ -188,6 +190,19 @@ int32_t gpk_predicate_rowwise(const gpk_geoarray* a, const gpk_geoarray* b, cons
 /* SpatialIndex::try_from(&Series) (spatial_index.rs:320-334): bbox per geometry + a uniform-grid
  * directory over the bboxes (the GPU replacement for rstar's R-tree) + per-polygon edge slabs. */
 int32_t gpk_index_build(const gpk_geoarray* a, void* stream, gpk_index** out);
+/* The same with a choice of tables and, optionally, precomputed leaves:
+ *   parts      GPK_INDEX_BBOX_GRID (always built: what rstar holds, the candidate generator of every join arm)
+ *              | GPK_INDEX_PIP (point-in-polygon raster + edge slabs; only point x polygonal joins read them — a
+ *                polygon x polygon join served by an index without them costs a fraction of the build).  A point join
+ *                against an index built without GPK_INDEX_PIP still answers exactly, through the slow generic walk.
+ *   bbox4_dev  NULL, or n_geoms x (minx, miny, maxx, maxy) in DEVICE memory (NaN x4 = empty geometry): the leaves
+ *              another rank computed with gpk_bounds for its shard and all-gathered — the bounds
+ *              pass over the coordinates is skipped.
+ * gpk_index_build(a, ...) == gpk_index_build_ex(a, GPK_INDEX_BBOX_GRID | GPK_INDEX_PIP, NULL, ...). */
+#define GPK_INDEX_BBOX_GRID 1
+#define GPK_INDEX_PIP       2
+int32_t gpk_index_build_ex(const gpk_geoarray* a, int32_t parts, const double* bbox4_dev, void* stream,
+                           gpk_index** out);
 int32_t gpk_index_free(gpk_index* idx);
 int32_t gpk_index_nbytes(const gpk_index* idx, int64_t* out_bytes);
 

@@ -32,26 +32,44 @@ def _same(a: GeoArrowArray, b: GeoArrowArray) -> bool:
 def _worker(rank: int, world: int, port: int, kind: str, q):
     import torch.distributed as dist
 
-    from geopolars_amd.dist import all_gatherv_geoarray, broadcast_geoarray
+    import torch
+
+    from geopolars_amd.dist import all_gather_leaves, all_gatherv_geoarray, broadcast_geoarray
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        full = {"multipoly": lambda: synth.powerlaw_multipolygons(301), "poly": lambda: synth.star_polygons(57, 9), "lines": lambda: synth.random_linestrings(40), "points": lambda: synth.uniform_points(33)}[kind]()
+        nulls = kind.endswith("+nulls")
+        full = {"multipoly": lambda: synth.powerlaw_multipolygons(301), "poly": lambda: synth.star_polygons(57, 9), "lines": lambda: synth.random_linestrings(40), "points": lambda: synth.uniform_points(33)}[kind.split("+")[0]]()
         w = np.diff(full.geom_offsets) if full.geom_offsets is not None else None
         lo, hi = shard_rows(len(full), world, rank, weights=w)
+        if nulls:  # nulls in rank 0's rows only: rank 1's shard arrives WITHOUT a bitmap (from_arrow_wkb sets one only when a shard has nulls)
+            bits = np.ones(len(full), dtype=np.uint8)
+            bits[: max(1, shard_rows(len(full), world, 0, weights=w)[1]) : 3] = 0
+            full.validity = np.packbits(bits, bitorder="little")
         local = slice_rows(full, lo, hi)
+        if nulls and rank != 0:
+            assert local.is_valid().all()
+            local.validity = None
         got = all_gatherv_geoarray(local)
         ok = _same(got, full)
+        if nulls:
+            ok = ok and got.validity is not None and np.array_equal(got.is_valid(), full.is_valid())
         rep = broadcast_geoarray(full if rank == 0 else None, 0)
         ok = ok and _same(rep, full)
+        if nulls:
+            ok = ok and rep.validity is not None and np.array_equal(rep.is_valid(), full.is_valid())
+        # the leaves each rank built for its shard, gathered in rank order == the boxes of the whole column
+        box = np.arange(4 * (hi - lo), dtype=np.float64).reshape(-1, 4) + 1000.0 * rank
+        leaves = all_gather_leaves(torch.from_numpy(box)).numpy()
+        ok = ok and leaves.shape == (len(full), 4) and np.array_equal(leaves[lo:hi], box)
         q.put((rank, ok, lo, hi))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("kind", ["multipoly", "poly", "lines", "points"])
+@pytest.mark.parametrize("kind", ["multipoly", "poly", "lines", "points", "poly+nulls", "multipoly+nulls"])
 def test_all_gatherv_and_broadcast_world2(kind):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
