@@ -1,26 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py — BASELINE.json headline: predicate evals/s for the 10M-point x 1k-polygon (64-vertex)
-point-in-polygon join (`configs[1]`, "C2"), one process per GPU.
+"""bench.py — the BASELINE.json configurations of the hot path, one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--config c2|c3|c4|c5] [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one full pass of the hot path over one batch: gpk_spatial_join (candidate generation from
-the grid directory + exact refine + sorted (l, r) pair output + per-point hit counts) on 10M points
-that are already resident in HBM, against the 1k polygons.  Weak scaling: every rank owns its own
-10M-point shard of the left series (rows are independent: no data-path collective); the 1 MB right
-side is replicated once at setup by an RCCL broadcast.  `value` = logical (point, polygon) predicate
-decisions per second over all ranks = n_gpus * n_points * n_polys * K / T (bbox/grid-rejected pairs
-count as decided).
+Default = the headline, `configs[1]` ("C2"): predicate evals/s of the 10M-point x 1k-polygon (64-vertex)
+point-in-polygon join.  The other configurations print one line each in the same format:
 
-Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP-event timed on the launching
-stream) and, at N=1, `cpu_baseline` (the CPU oracle on all host cores over a bounded sample of the
-same points, which doubles as a bit-exact parity check of the GPU result).
+  c2  10M random points contains() against 1k 64-vertex polygons            gpk_spatial_join_async   weak scaling
+  c3  10M points euclidean distance to 100k linestrings (4-256 segments)    gpk_distance_rowwise     weak scaling
+  c4  1M x 1M polygon intersects() spatial join, left side row-sharded      gpk_spatial_join         strong scaling
+  c5  6.25M points (one rank's share of 50M) within() 5M power-law          gpk_spatial_join_async   weak scaling
+      multipolygons + area() of the rank's share of them                    + gpk_area
+
+A step = one full pass of the operator over one batch that is ALREADY RESIDENT IN HBM (C2 rotates through
+`--rotate` distinct input / output sets, > 256 MiB in total, so that no step finds its inputs in the Infinity
+Cache).  Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP-event timed on the launching
+stream), and at N=1 `cpu_baseline` (the CPU oracle on the host cores over a bounded sample of the same
+workload).  Every line is gated by parity: the GPU result of the last step is compared with the oracle on a
+RANDOM sample of rows (>= 200k, `--parity-rows`); a run that fails parity prints no number.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -31,220 +36,356 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (about 6.3 achievable)
+F64_VALU_PEAK = 39.3e12  # f64 vector instructions / s: 78.6 TFLOP/s FMA = 39.3 T instructions
+C5_CHUNKS = 8  # the C5 right side is the concatenation of 8 fixed chunks of 625k multipolygons (one per rank at 8 GPUs)
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--points", type=int, default=10_000_000)
-    ap.add_argument("--polys", type=int, default=1000)
-    ap.add_argument("--verts", type=int, default=64)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the cpu_baseline sample")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--index-per-step", action="store_true", help="rebuild the right-side index inside every step")
-    ap.add_argument("--sync-steps", action="store_true", help="use the synchronous gpk_spatial_join (host waits for every step) instead of the stream-ordered call")
-    ap.add_argument("--no-profile", action="store_true", help="tuning only: no HIP events around the kernels (the roofline leg reads zero)")
-    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and broadcast the right side even at world size 1 (path test)")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------------
+def source_hash() -> str:
+    """Content hash of the kernel sources: profiles/*_pmc_traffic.json names the hash it was measured at, and a
+    measurement of other sources is not reported as this build's traffic."""
+    h = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(ROOT, "geopolars_amd", "csrc", "*"))):
+        if fn.endswith((".hip", ".h", ".cpp")):
+            with open(fn, "rb") as f:
+                h.update(os.path.basename(fn).encode())
+                h.update(f.read())
+    return h.hexdigest()[:16]
 
-    import torch
-    import torch.distributed as dist
 
+def pmc_record(kernel: str):
+    """Latest committed PMC traffic record for `kernel` whose source hash matches this tree (else None + reason)."""
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")))
+    cur = source_hash()
+    for fn in reversed(cands):
+        try:
+            with open(fn) as f:
+                t = json.load(f)
+        except Exception:
+            continue
+        if t.get("kernel") != kernel:
+            continue
+        if t.get("source_hash") == cur:
+            return t, None
+        return None, f"stale: {os.path.basename(fn)} was measured at source hash {t.get('source_hash')}, this tree is {cur} (re-run tools/profile_headline.sh)"
+    return None, "no PMC record for this kernel under profiles/"
+
+
+class Ctx:
+    """torch / torch.distributed plumbing shared by every configuration."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+
+        from geopolars_amd import _abi
+
+        self.torch, self.dist, self.args = torch, dist, args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            if self.rank == 0:
+                print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}; launch with torch.distributed.run", file=sys.stderr)
+            if self.world == 1 and args.gpus > 1:
+                sys.exit(2)
+        if not torch.cuda.is_available():
+            print("bench.py: no GPU visible — libgeopolars_hip has no CPU fallback", file=sys.stderr)
+            sys.exit(3)
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        self.use_dist = self.world > 1 or args.force_dist
+        if self.use_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+        self.lib = _abi.lib()
+        self.dev_name, self.cus = _abi.device_info()
+        self.stream = torch.cuda.current_stream().cuda_stream
+
+    def barrier(self):
+        if self.use_dist:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds: float) -> float:
+        if not self.use_dist:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, v: float) -> float:
+        if not self.use_dist:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def kernel_ms(self, name: str):
+        ms, cnt = C.c_double(0), C.c_int64(0)
+        self.lib.gpk_profile_query(name.encode(), C.byref(ms), C.byref(cnt))
+        return (ms.value / max(cnt.value, 1), int(cnt.value))
+
+    def timed(self, step, dominant: str, steps: int, warmup: int, profile: bool = True):
+        """W untimed steps (every kernel bracketed by events after the first: per-kernel durations without taxing the
+        timed region), then exactly K steps between barrier + synchronize, only the dominant kernel carrying events.
+        -> (seconds max over ranks, dominant-kernel ms per launch, launches, {kernel: ms} from the warm-up)"""
+        lib = self.lib
+        lib.gpk_profile_reset()
+        lib.gpk_profile_filter(b"")
+        for w in range(warmup):
+            lib.gpk_profile_enable(1 if (profile and w > 0) else 0)
+            step(w)
+        lib.gpk_profile_enable(0)
+        self.torch.cuda.synchronize()
+        warm = self._all_kernels(max(warmup - 1, 1))
+        lib.gpk_profile_reset()
+        lib.gpk_profile_filter(dominant.encode())
+        lib.gpk_profile_enable(1 if profile else 0)
+        self.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i)
+        self.barrier()
+        t1 = time.perf_counter()
+        lib.gpk_profile_enable(0)
+        lib.gpk_profile_filter(b"")
+        k_ms, k_n = self.kernel_ms(dominant)
+        lib.gpk_profile_reset()
+        return self.max_over_ranks(t1 - t0), k_ms, k_n, warm
+
+    # substring queries: no name here is a substring of another one that can run in the same step
+    KERNELS = ("gpk_pip_tile", "gpk_pip_write", "gpk_distance_grouped", "gpk_dist_hist", "gpk_dist_scatter", "gpk_dist_probe", "gpk_dist_batches", "gpk_dist_iota",
+               "gpk_dist_offsets", "gpk_rowmap", "gpk_bbox_cand_count", "gpk_bbox_cand_fill", "gpk_pair_refine", "gpk_pair_count", "gpk_pair_emit", "gpk_counts_copy",
+               "gpk_ring_area", "gpk_area_combine", "gpk_seq_long", "gpk_scan", "gpk_seq_bbox", "gpk_bounds_combine", "gpk_stats_to_bbox")
+
+    def _all_kernels(self, calls: int) -> dict:
+        out = {}
+        for name in self.KERNELS:
+            ms, cnt = C.c_double(0), C.c_int64(0)
+            self.lib.gpk_profile_query(name.encode(), C.byref(ms), C.byref(cnt))
+            if cnt.value:
+                out[name] = ms.value / calls  # ms per step (a name may cover several launches)
+        return out
+
+    def finish(self):
+        if self.use_dist:
+            self.dist.destroy_process_group()
+
+
+def dev_array(torch, a, dev, stream):
+    """Host GeoArrowArray -> device-resident handle over torch tensors (uploaded once, outside every timed region)."""
+    from geopolars_amd.dist import GeoBuffers
+
+    return GeoBuffers.from_host(a, dev).to_device_geoarray(stream)
+
+
+def sample_rows(n: int, k: int, seed: int) -> np.ndarray:
+    k = min(n, k)
+    return np.sort(np.random.default_rng(seed).choice(n, size=k, replace=False)).astype(np.int64)
+
+
+def pairs_of_rows(pairs: np.ndarray, rows: np.ndarray) -> np.ndarray:
+    """Rows of a sorted (l, r) pair list whose l is in `rows` (sorted), with l renumbered to the position in `rows`."""
+    if len(pairs) == 0:
+        return pairs.reshape(0, 2)
+    lo = np.searchsorted(pairs[:, 0], rows, side="left")
+    hi = np.searchsorted(pairs[:, 0], rows, side="right")
+    cnt = hi - lo
+    idx = np.repeat(lo - np.concatenate([[0], np.cumsum(cnt)[:-1]]), cnt) + np.arange(int(cnt.sum()))
+    out = pairs[idx].copy()
+    out[:, 0] = np.repeat(np.arange(len(rows), dtype=pairs.dtype), cnt)
+    return out
+
+
+def base_line(ctx: Ctx, metric: str, value: float, unit: str, ms_per_step: float, scaling: str, config: dict, roofline: dict) -> dict:
+    a = ctx.args
+    return {
+        "metric": metric,
+        "value": value,
+        "unit": unit,
+        "n_gpus": ctx.world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": scaling,
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": dict(config, device=ctx.dev_name, cus=ctx.cus),
+        "roofline": roofline,
+    }
+
+
+# ======================================================================================================
+# C2 — the headline
+# ======================================================================================================
+def run_c2(ctx: Ctx) -> None:
+    torch, args, lib = ctx.torch, ctx.args, ctx.lib
     from geopolars_amd import _abi, synth
     from geopolars_amd.dist import broadcast_geoarray
     from geopolars_amd.geoarrow import DeviceGeoArray
     from geopolars_amd.spatial_index import SpatialIndex, join_pairs_device, join_pairs_enqueue
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
-    if not torch.cuda.is_available():
-        print("bench.py: no GPU visible — libgeopolars_hip has no CPU fallback", file=sys.stderr)
-        sys.exit(3)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or args.force_dist
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    lib = _abi.lib()
-    dev_name, cus = _abi.device_info()
-    stream = torch.cuda.current_stream().cuda_stream
-
-    # ---- inputs: synthetic C2, resident in HBM before the timed region ---------------------------
-    n, m = args.points, args.polys
-    polys_host = synth.star_polygons(m, args.verts) if rank == 0 else None
-    if use_dist:
+    n, m, dev, stream = args.points, args.polys, ctx.dev, ctx.stream
+    polys_host = synth.star_polygons(m, args.verts) if ctx.rank == 0 else None
+    if ctx.use_dist:
         polys_host = broadcast_geoarray(polys_host, 0, device=dev)  # RCCL, once, outside the timed region
-    pts_host = synth.uniform_points(n, seed=synth.SEED + 1 + rank)  # each rank: its own shard of the left series
-    pts_xy = torch.from_numpy(pts_host.xy).to(dev)
-    pts = DeviceGeoArray.from_device_buffers(_abi.GEOM_POINT, pts_xy, stream=stream)
     polys = DeviceGeoArray.upload(polys_host, stream=stream)
     index = SpatialIndex.from_device(polys, stream=stream)
-    counts = torch.empty(n, dtype=torch.int32, device=dev)
-    pairs = torch.empty((n, 2), dtype=torch.int32, device=dev)  # capacity: one hit per point (disjoint polygons)
-    n_pairs_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+    # `rotate` distinct input / output sets: each step reads points it has not seen for rotate-1 steps and writes outputs
+    # nobody has read (3 x (160 + 40 + 80) MB + the library's 40 MB code scratch >> the 256 MiB Infinity Cache)
+    R = max(1, args.rotate)
+    sets = []
+    t_h2d = None
+    for r in range(R):
+        pts_host = synth.uniform_points(n, seed=synth.SEED + 1 + ctx.rank + 1000 * r)  # each rank: its own shard of the left series
+        if r == 0 and ctx.rank == 0:
+            pinned = torch.from_numpy(pts_host.xy).pin_memory()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            xy = pinned.to(dev, non_blocking=True)
+            torch.cuda.synchronize()
+            t_h2d = time.perf_counter() - t0  # the PCIe leg a host-buffer boundary would add per step (never part of `value`)
+            del pinned
+        else:
+            xy = torch.from_numpy(pts_host.xy).to(dev)
+        sets.append(
+            {
+                "host": pts_host,
+                "pts": DeviceGeoArray.from_device_buffers(_abi.GEOM_POINT, xy, stream=stream),
+                "counts": torch.empty(n, dtype=torch.int32, device=dev),
+                "pairs": torch.empty((n, 2), dtype=torch.int32, device=dev),  # capacity: one hit per point (disjoint polygons)
+                "total": torch.zeros(1, dtype=torch.int64, device=dev),
+            }
+        )
     torch.cuda.synchronize()
     sync_steps = args.sync_steps or args.index_per_step
+    last = {"set": 0}
 
-    def step() -> int:
+    def step(i: int) -> None:
         """One full pass: 10M points -> counts + sorted (l, r) pairs + total, all written to HBM.  Default: the
         stream-ordered entry point (steps queue up on the HIP stream; the timed region ends with a synchronise, so
-        every step has completed); --sync-steps: the blocking entry point, host round trip per step."""
+        every step has completed); --sync-steps: the blocking entry point, one host round trip per step."""
+        s = sets[i % R]
+        last["set"] = i % R
         if sync_steps:
             idx = SpatialIndex.from_device(polys, stream=stream) if args.index_per_step else index
-            return join_pairs_device(pts, polys, idx, "intersects", counts, pairs, left_row_base=0, stream=stream)
-        join_pairs_enqueue(pts, polys, index, "intersects", counts, pairs, n_pairs_dev, left_row_base=0, stream=stream)
-        return -1
+            join_pairs_device(s["pts"], polys, idx, "intersects", s["counts"], s["pairs"], left_row_base=0, stream=stream)
+        else:
+            join_pairs_enqueue(s["pts"], polys, index, "intersects", s["counts"], s["pairs"], s["total"], left_row_base=0, stream=stream)
 
-    def barrier() -> None:
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # warm-up (untimed): every kernel of the step is bracketed by HIP events once the first step has paid the
-    # one-time costs, which gives the secondary kernel's duration without taxing the timed region
-    def kernel_ms(name: str) -> tuple[float, int]:
-        ms, cnt = C.c_double(0), C.c_int64(0)
-        lib.gpk_profile_query(name.encode(), C.byref(ms), C.byref(cnt))
-        return (ms.value / max(cnt.value, 1), int(cnt.value))
-
-    lib.gpk_profile_reset()
-    lib.gpk_profile_filter(b"")
-    for w in range(args.warmup):
-        lib.gpk_profile_enable(0 if (args.no_profile or w == 0) else 1)
-        h = step()
-    lib.gpk_profile_enable(0)
+    elapsed, k_tile, n_tile, warm = ctx.timed(step, "gpk_pip_tile", args.steps, args.warmup, profile=not args.no_profile)
+    # what the exact phase did, measured on one extra untimed step (a few atomics per tile: never inside the timed region)
+    lib.gpk_join_stats_enable(1)
+    st = (C.c_int64 * 4)()
+    lib.gpk_join_stats(st, 1)
+    step(args.warmup + args.steps)  # same set the next timed step would have used
+    lib.gpk_join_stats(st, 1)
+    lib.gpk_join_stats_enable(0)
     torch.cuda.synchronize()
-    k_write, _ = kernel_ms("gpk_pip_write")
-    # ---- timed region: only the dominant kernel carries events (each event pair drains the stream) -----
-    lib.gpk_profile_reset()
-    lib.gpk_profile_filter(b"gpk_pip_tile")
-    lib.gpk_profile_enable(0 if args.no_profile else 1)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        h = step()
-    barrier()
-    t1 = time.perf_counter()
-    lib.gpk_profile_enable(0)
-    lib.gpk_profile_filter(b"")
-    if not sync_steps:
-        h = int(n_pairs_dev.item())
-    elapsed = t1 - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    k_count, n_count = kernel_ms("gpk_pip_tile")
-    lib.gpk_profile_reset()
-
-    if rank != 0:
-        if use_dist:
-            dist.destroy_process_group()
+    s_last = sets[last["set"]]
+    h = join_pairs_device(s_last["pts"], polys, index, "intersects", s_last["counts"], s_last["pairs"], left_row_base=0, stream=stream)
+    if ctx.rank != 0:
+        ctx.finish()
         return
 
-    evals = float(world) * n * m * args.steps
+    evals = float(ctx.world) * n * m * args.steps
     ms_per_step = elapsed / args.steps * 1e3
     v_total = polys_host.n_coords
-    # algorithmic bytes of the dominant launch (gpk_pip_tile): points in, polygon coords + offsets in,
-    # hit counts out — each distinct byte once (SURVEY.md §8d; the 8H pair bytes belong to gpk_pip_write)
-    bytes_count = 16 * n + 16 * v_total + 2 * 4 * (m + 1) + 4 * n
-    bytes_join = bytes_count + 8 * h
-    achieved = bytes_count / (k_count * 1e-3) / 1e9 if k_count > 0 else 0.0
-    traffic = None  # HBM-side bytes per launch of the dominant kernel, from committed PMC passes (profiles/)
-    try:
-        import glob
-
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-        if cands and n == 10_000_000 and m == 1000:
-            with open(cands[-1]) as f:
-                t = json.load(f)
-            if t.get("kernel") == "gpk_pip_tile":
-                traffic = t["traffic_bytes_per_launch"]
-    except Exception:
-        traffic = None
-    out = {
-        "metric": "predicate evals/sec (10M pts x 1k polys point-in-polygon)",
-        "value": evals / elapsed,
-        "unit": "evals/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": ms_per_step,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f64",
-        "data": "synthetic",
-        "config": {
-            "workload": f"C2: {n} uniform points contains() against {m} {args.verts}-vertex star polygons, per GPU",
-            "points_per_gpu": n,
-            "polygons": m,
-            "vertices_per_polygon": args.verts,
-            "hits_per_step": h,
-            "algorithm": "uniform-grid bbox directory -> exact winding refine, sorted (l,r) pairs + counts",
-            "index": "rebuilt per step" if args.index_per_step else "prebuilt r_index (spatial_index.rs:20-21)",
-            "call": "gpk_spatial_join (blocking)" if sync_steps else "gpk_spatial_join_async (stream-ordered; the timed region ends synchronised)",
-            "parallelism": f"row-sharded x{world}, right side replicated",
-            "device": dev_name,
-            "cus": cus,
-            "join_bytes_per_step": bytes_join,
-            "join_GBps_end_to_end": bytes_join / (ms_per_step * 1e-3) / 1e9,
-            "kernel_ms": {"gpk_pip_tile": k_count, "gpk_pip_write (warm-up steps)": k_write},
-        },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": "gpk_pip_tile",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "launch_ms": k_count,
-            "launches": n_count,
-            "algorithmic_bytes": bytes_count,
-        },
+    # algorithmic bytes of the dominant launch (gpk_pip_tile): points in, polygon coords + offsets in, hit counts out —
+    # each distinct byte once (SURVEY.md section 8d; the 8H pair bytes belong to gpk_pip_write)
+    bytes_tile = 16 * n + 16 * v_total + 2 * 4 * (m + 1) + 4 * n
+    bytes_join = bytes_tile + 8 * h
+    achieved = bytes_tile / (k_tile * 1e-3) / 1e9 if k_tile > 0 else 0.0
+    traffic, valu_busy, traffic_note = None, None, None
+    if n == 10_000_000 and m == 1000 and args.verts == 64:
+        rec, traffic_note = pmc_record("gpk_pip_tile")
+        if rec is not None:
+            traffic, valu_busy = rec.get("traffic_bytes_per_launch"), rec.get("valu_busy")
+            traffic_note = rec.get("calibration")
+    k_write = warm.get("gpk_pip_write", 0.0)
+    queued, edges = int(st[0]), int(st[1])
+    step_s = ms_per_step * 1e-3
+    config = {
+        "workload": f"C2: {n} uniform points contains() against {m} {args.verts}-vertex star polygons, per GPU",
+        "points_per_gpu": n,
+        "polygons": m,
+        "vertices_per_polygon": args.verts,
+        "hits_per_step": h,
+        "algorithm": "uniform-grid bbox directory + two-level exact raster routing -> exact winding walk over edge slabs, sorted (l,r) pairs + counts; N x M logical pairs counted, raster-rejected pairs included",
+        "index": "rebuilt per step" if args.index_per_step else "prebuilt r_index (spatial_index.rs:20-21)",
+        "call": "gpk_spatial_join (blocking)" if sync_steps else "gpk_spatial_join_async (stream-ordered; the timed region ends synchronised)",
+        "parallelism": f"row-sharded x{ctx.world}, right side replicated",
+        "input_rotation": f"{R} distinct 10M-point inputs and output sets ({R * (16 * n + 4 * n + 8 * n) / 2**20:.0f} MiB): inputs come from HBM, not from the 256 MiB Infinity Cache",
+        "join_bytes_per_step": bytes_join,
+        "join_GBps_end_to_end": bytes_join / step_s / 1e9,
+        "kernel_ms": {"gpk_pip_tile": k_tile, "gpk_pip_write (warm-up steps)": k_write},
+        "exact_phase": {"queued_point_part_pairs_per_step": queued, "edge_tests_per_step": edges},
+        "edge_tests_per_s": edges / step_s if step_s > 0 else None,
+        "valu_busy": valu_busy,
+        "pcie_inclusive": None
+        if t_h2d is None
+        else {"h2d_ms_160MB_pinned": t_h2d * 1e3, "evals_per_s": n * m / (t_h2d + step_s), "note": "what a host-buffer boundary would deliver per GPU: one 160 MB upload per step; never reported as `value`"},
     }
-
-    if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(pts_host, polys_host, counts, args.cpu_seconds)
+    roofline = {
+        "bound": "hbm",
+        "kernel": "gpk_pip_tile",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic,
+        "traffic_note": traffic_note,
+        "launch_ms": k_tile,
+        "launches": n_tile,
+        "algorithmic_bytes": bytes_tile,
+        "source_hash": source_hash(),
+    }
+    out = base_line(ctx, "predicate evals/sec (10M pts x 1k polys point-in-polygon)", evals / elapsed, "evals/s", ms_per_step, "weak", config, roofline)
+    out["parity"] = parity_point_join(s_last["host"], polys_host, "intersects", s_last["counts"], s_last["pairs"], h, args.parity_rows)
+    if ctx.world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_join(s_last["host"], polys_host, "intersects", s_last["counts"], args.cpu_seconds)
     print(json.dumps(out), flush=True)
-    if use_dist:
-        dist.destroy_process_group()
+    ctx.finish()
 
 
-def cpu_baseline(pts_host, polys_host, gpu_counts, target_s: float) -> dict:
-    """The CPU oracle (oracle/gpk_oracle.c: C restatement of the geo-0.27 path, grid directory +
-    exact refine, OpenMP over all host cores) on a bounded prefix of the same points.  Also asserts
-    that the GPU's hit counts on that prefix are bit-identical: a run that fails parity reports no speed."""
-    from geopolars_amd.geoarrow import GeoArrowArray
+def parity_point_join(pts_host, right_host, predicate: str, gpu_counts, gpu_pairs, h: int, rows: int) -> dict:
+    """GPU counts + (l, r) pairs of a RANDOM sample of left rows vs the CPU oracle on exactly those rows: bit-exact or no number."""
     from oracle import pyoracle
 
     pyoracle.build()
     n = len(pts_host)
-    m = len(polys_host)
+    idx = sample_rows(n, rows, seed=4242)
+    ep, ec, _ = pyoracle.spatial_join(pts_host.take(idx), right_host, predicate, mode=1, n_threads=0)
+    gc = gpu_counts.cpu().numpy().astype(np.uint32)
+    gp = gpu_pairs[:h].cpu().numpy().astype(np.uint32)
+    got = pairs_of_rows(gp, idx.astype(np.uint32))
+    if not np.array_equal(gc[idx], ec) or not np.array_equal(got, ep) or int(gc.sum()) != h:
+        raise SystemExit("bench.py: GPU join differs from the CPU oracle on the parity sample — no speed reported")
+    return {"rows": int(len(idx)), "sampling": "uniform random without replacement (seed 4242)", "pairs_checked": int(len(ep)), "bit_exact": True}
+
+
+def cpu_baseline_join(left_host, right_host, predicate: str, gpu_counts, target_s: float) -> dict:
+    """The CPU oracle (oracle/gpk_oracle.c: C restatement of the geo-0.27 path, grid directory + exact refine, OpenMP over
+    all host cores) on a bounded prefix of the same left rows; also asserts bit-exact hit counts on that prefix."""
+    from oracle import pyoracle
+
+    pyoracle.build()
+    n, m = len(left_host), len(right_host)
     probe = min(n, 500_000)
     t0 = time.perf_counter()
-    pyoracle.spatial_join(GeoArrowArray.from_points(pts_host.xy[:probe]), polys_host, "intersects", mode=1, n_threads=0, capacity=probe)
+    pyoracle.spatial_join(left_host.take(np.arange(probe)), right_host, predicate, mode=1, n_threads=0, capacity=4 * probe)
     dt = max(time.perf_counter() - t0, 1e-3)
     sample = int(min(n, max(probe, probe * target_s / (2.0 * dt))))  # two timed runs of ~target_s/2 each
-    sub = GeoArrowArray.from_points(pts_host.xy[:sample])
-    best, runs, spent = None, 0, 0.0
+    sub = left_host.take(np.arange(sample))
+    best, runs, spent, threads, counts = None, 0, 0.0, 0, None
     while runs < 2 or (runs < 9 and spent < target_s / 4):  # the whole job is a fraction of a second on a big host: repeat
         t0 = time.perf_counter()
-        pairs, counts, threads = pyoracle.spatial_join(sub, polys_host, "intersects", mode=1, n_threads=0, capacity=sample)
+        _, counts, threads = pyoracle.spatial_join(sub, right_host, predicate, mode=1, n_threads=0, capacity=4 * sample)
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
         runs += 1
@@ -252,15 +393,447 @@ def cpu_baseline(pts_host, polys_host, gpu_counts, target_s: float) -> dict:
     got = gpu_counts[:sample].cpu().numpy().astype(np.uint32)
     if not np.array_equal(got, counts):
         raise SystemExit("bench.py: GPU hit counts differ from the CPU oracle on the baseline sample — no speed reported")
+    s1 = min(sample, 400_000)
+    t0 = time.perf_counter()
+    pyoracle.spatial_join(left_host.take(np.arange(s1)), right_host, predicate, mode=1, n_threads=1, capacity=4 * s1)
+    t_single = time.perf_counter() - t0
     return {
         "value": sample * m / best,
         "unit": "evals/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"first {sample} of the {n} points x {m} polygons, min of {runs} runs, grid directory + exact refine, OpenMP dynamic",
+        "sample": f"first {sample} of the {n} left rows x {m} right rows, min of {runs} runs, grid directory + exact refine, OpenMP dynamic",
+        "seconds": best,
+        "parity_checked_rows": sample,
+        "single_thread": {"value": s1 * m / t_single, "unit": "evals/s", "sample_rows": s1, "seconds": t_single},
+    }
+
+
+# ======================================================================================================
+# C3 — row-wise distance, 10M points x 100k linestrings
+# ======================================================================================================
+def run_c3(ctx: Ctx) -> None:
+    torch, args, lib = ctx.torch, ctx.args, ctx.lib
+    from geopolars_amd import _abi, synth
+
+    n, L, dev, stream = args.points, args.lines, ctx.dev, ctx.stream
+    ls_host = synth.random_linestrings(L)
+    pts_host = synth.uniform_points(n, seed=synth.SEED + 1 + ctx.rank)
+    ls, pts = dev_array(torch, ls_host, dev, stream), dev_array(torch, pts_host, dev, stream)
+    rows_mod = (np.arange(n, dtype=np.uint32) % L).astype(np.uint32)  # row-wise semantics: row i pairs with linestring i mod L
+    rows_shuf = np.random.default_rng(1).permutation(rows_mod)
+    out = torch.empty(n, dtype=torch.float64, device=dev)
+    results = {}
+    for label, rows in (("rows = i mod L", rows_mod), ("rows shuffled", rows_shuf)):
+        r_dev = torch.from_numpy(rows.view(np.int32)).to(dev)
+
+        def step(i: int) -> None:
+            _abi.check(lib.gpk_distance_rowwise(pts.handle, ls.handle, r_dev.data_ptr(), out.data_ptr(), _abi.MEM_DEVICE, stream))
+
+        elapsed, k_ms, k_n, warm = ctx.timed(step, "gpk_distance_grouped", args.steps, args.warmup)
+        results[label] = {"elapsed": elapsed, "k_ms": k_ms, "launches": k_n, "warm": warm, "parity": None}
+        if ctx.rank == 0:
+            results[label]["parity"] = parity_distance(pts_host, ls_host, rows, out, args.parity_rows)
+    if ctx.rank != 0:
+        ctx.finish()
+        return
+    main = results["rows = i mod L"]
+    ms_per_step = main["elapsed"] / args.steps * 1e3
+    v = ls_host.n_coords
+    seg = float((np.diff(ls_host.geom_offsets)[rows_mod] - 1).clip(min=0).sum())  # segment evaluations of one step
+    # 16N + 4N + 16 V_ls + 4 (L+1) + 8N, each distinct byte once
+    nbytes = 16 * n + 4 * n + 16 * v + 4 * (L + 1) + 8 * n
+    k_s = main["k_ms"] * 1e-3
+    achieved = nbytes / k_s / 1e9 if k_s > 0 else 0.0
+    instr_per_seg = 35.0  # f64 vector instructions per segment step of gpk_distance_grouped (counted in the ISA)
+    valu = seg * instr_per_seg / k_s if k_s > 0 else 0.0
+    config = {
+        "workload": f"C3: {n} points euclidean_distance to {L} linestrings (4-256 segments, {v} coordinates), row i -> linestring i mod L, per GPU",
+        "points_per_gpu": n,
+        "linestrings": L,
+        "segment_evaluations_per_step": seg,
+        "call": "gpk_distance_rowwise (device outputs; the grouping of the row map by target is part of every step)",
+        "parallelism": f"row-sharded x{ctx.world}, right side replicated",
+        "kernel_ms_per_step": main["warm"],
+        "shuffled_row_map": {
+            "ms_per_step": results["rows shuffled"]["elapsed"] / args.steps * 1e3,
+            "rows_per_s": ctx.world * n * args.steps / results["rows shuffled"]["elapsed"],
+            "kernel_ms_per_step": results["rows shuffled"]["warm"],
+            "parity": results["rows shuffled"]["parity"],
+        },
+    }
+    roofline = {
+        "bound": "hbm",
+        "kernel": "gpk_distance_grouped",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": None,
+        "launch_ms": main["k_ms"],
+        "launches": main["launches"],
+        "algorithmic_bytes": nbytes,
+        "valu": {"note": "the kernel is bound by f64 vector issue, not HBM", "achieved": valu, "peak": F64_VALU_PEAK, "unit": "f64 instr/s", "frac": valu / F64_VALU_PEAK, "instr_per_segment": instr_per_seg},
+        "source_hash": source_hash(),
+    }
+    line = base_line(ctx, "row-wise point-linestring distances/sec (10M pts x 100k linestrings)", ctx.world * n * args.steps / main["elapsed"], "rows/s", ms_per_step, "weak", config, roofline)
+    line["parity"] = main["parity"]
+    if ctx.world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline_distance(pts_host, ls_host, rows_mod, args.cpu_seconds)
+    print(json.dumps(line), flush=True)
+    ctx.finish()
+
+
+def parity_distance(pts_host, ls_host, rows, gpu_out, k: int) -> dict:
+    from oracle import pyoracle
+
+    pyoracle.build()
+    idx = sample_rows(len(pts_host), k, seed=4243)
+    exp = pyoracle.distance_rowwise(pts_host.take(idx), ls_host, rows[idx], n_threads=0)
+    got = gpu_out.cpu().numpy()[idx]
+    rel = np.abs(got - exp) / np.maximum(np.abs(exp), 1e-300)
+    ok = bool(np.all((rel <= 1e-9) | (got == exp)) and np.array_equal(got == 0.0, exp == 0.0) and np.array_equal(np.isnan(got), np.isnan(exp)))
+    if not ok:
+        raise SystemExit("bench.py: GPU distances differ from the CPU oracle beyond 1e-9 on the parity sample — no speed reported")
+    return {"rows": int(len(idx)), "sampling": "uniform random without replacement (seed 4243)", "tolerance": "1e-9 relative, zero / non-zero exact", "max_rel_err": float(rel[np.isfinite(rel)].max(initial=0.0))}
+
+
+def cpu_baseline_distance(pts_host, ls_host, rows, target_s: float) -> dict:
+    from oracle import pyoracle
+
+    n = len(pts_host)
+    probe = min(n, 200_000)
+    t0 = time.perf_counter()
+    pyoracle.distance_rowwise(pts_host.take(np.arange(probe)), ls_host, rows[:probe], n_threads=0)
+    dt = max(time.perf_counter() - t0, 1e-3)
+    sample = int(min(n, max(probe, probe * target_s / (2.0 * dt))))
+    sub = pts_host.take(np.arange(sample))
+    best, runs, spent = None, 0, 0.0
+    while runs < 2 or (runs < 9 and spent < target_s / 4):
+        t0 = time.perf_counter()
+        pyoracle.distance_rowwise(sub, ls_host, rows[:sample], n_threads=0)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        runs += 1
+        spent += dt
+    s1 = min(sample, 200_000)
+    t0 = time.perf_counter()
+    pyoracle.distance_rowwise(pts_host.take(np.arange(s1)), ls_host, rows[:s1], n_threads=1)
+    t_single = time.perf_counter() - t0
+    return {
+        "value": sample / best,
+        "unit": "rows/s",
+        "cores": os.cpu_count(),
+        "kind": "port",
+        "sample": f"first {sample} of the {n} rows, min of {runs} runs, oracle/gpk_oracle.c point-linestring distance, OpenMP over rows",
+        "seconds": best,
+        "single_thread": {"value": s1 / t_single, "unit": "rows/s", "sample_rows": s1, "seconds": t_single},
+    }
+
+
+# ======================================================================================================
+# C4 — polygon x polygon intersects join, left side row-sharded, right side gathered once
+# ======================================================================================================
+def run_c4(ctx: Ctx) -> None:
+    torch, args, lib = ctx.torch, ctx.args, ctx.lib
+    from geopolars_amd import _abi, synth
+    from geopolars_amd.dist import GeoBuffers, all_gather_leaves, all_gatherv_buffers, shard_rows, slice_rows
+    from geopolars_amd.spatial_index import SpatialIndex, join_pairs_device
+
+    n, dev, stream, W = args.polygons, ctx.dev, ctx.stream, ctx.world
+    left_full = synth.clustered_polygons(n, seed=41, mean_neighbours=4.0)
+    right_full = synth.clustered_polygons(n, seed=42, mean_neighbours=4.0)
+    # left: contiguous row ranges balanced by vertex count; right: every rank owns a row range and the ranks exchange them
+    wl = np.diff(left_full.ring_offsets)[left_full.geom_offsets[:-1]]  # exterior vertex count per row (one ring per polygon here)
+    lo, hi = shard_rows(n, W, ctx.rank, weights=wl)
+    left_host = slice_rows(left_full, lo, hi)
+    rlo, rhi = shard_rows(n, W, ctx.rank)
+    right_shard = GeoBuffers.from_host(slice_rows(right_full, rlo, rhi), dev)
+    exchange = {"ms": 0.0, "bytes": 0}
+    torch.cuda.synchronize()
+    if ctx.use_dist:
+        # what each rank built for its shard — the boxes (R-tree leaves) — travels with the geometry: one all-gatherv over xGMI
+        shard_arr = right_shard.to_device_geoarray(stream)
+        box = torch.empty((rhi - rlo, 4), dtype=torch.float64, device=dev)
+        _abi.check(lib.gpk_bounds(shard_arr.handle, box.data_ptr(), _abi.MEM_DEVICE, stream))
+        ctx.barrier()
+        t0 = time.perf_counter()
+        stats = {}
+        right_buf = all_gatherv_buffers(right_shard, stats=stats)
+        leaves = all_gather_leaves(box)
+        ctx.barrier()
+        exchange = {"ms": ctx.max_over_ranks(time.perf_counter() - t0) * 1e3, "bytes": stats["gathered_bytes"] + leaves.numel() * 8}
+    else:
+        right_buf, leaves = right_shard, None
+    right = right_buf.to_device_geoarray(stream)
+    left = dev_array(torch, left_host, dev, stream)
+    nl = hi - lo
+    build_ms = []
+    index = None
+    for _ in range(3):
+        if index is not None:
+            index.free()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        index = SpatialIndex.from_device(right, stream=stream, for_points=False, bboxes=leaves)  # bbox + grid directory: what this arm reads
+        torch.cuda.synchronize()
+        build_ms.append((time.perf_counter() - t0) * 1e3)
+    counts = torch.empty(nl, dtype=torch.int32, device=dev)
+    cap = max(8 * nl, 1024)
+    pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+    hits = {"h": 0}
+
+    def step(i: int) -> None:
+        hits["h"] = join_pairs_device(left, right, index, "intersects", counts, pairs, left_row_base=lo, stream=stream)
+
+    elapsed, k_ms, k_n, warm = ctx.timed(step, "gpk_pair_refine", args.steps, args.warmup)
+    h = hits["h"]
+    total_pairs = ctx.sum_over_ranks(float(h))
+    parity = parity_poly_join(left_host, right_full, counts, pairs, h, lo, args.parity_rows) if ctx.rank == 0 else None
+    if ctx.rank != 0:
+        ctx.finish()
+        return
+    ms_per_step = elapsed / args.steps * 1e3
+    # both coordinate sets once + bbox arrays (32 B / geometry) + 8 B per output pair (this rank's share of the left side)
+    nbytes = 16 * (left_host.n_coords + right_full.n_coords) + 32 * (nl + n) + 8 * h
+    k_s = k_ms * 1e-3
+    config = {
+        "workload": f"C4: {n} x {n} polygons (8-64 vertices, ~4 bbox neighbours) intersects() spatial join; left side row-sharded x{W} by vertex weight, right side exchanged once",
+        "left_rows_this_rank": nl,
+        "right_rows": n,
+        "pairs_total": int(total_pairs),
+        "pairs_this_rank": h,
+        "call": "gpk_spatial_join (blocking; candidate generation + 16-lane exact refine + sorted pair emit), prebuilt r_index",
+        "index": "gpk_index_build_ex(GPK_INDEX_BBOX_GRID" + (", leaves from the exchange)" if leaves is not None else ")"),
+        "index_build_ms": min(build_ms),
+        "join_ms": ms_per_step,
+        "build_plus_join_ms": min(build_ms) + ms_per_step,
+        "note_build": "spatial_join without r_index pays build + join (spatial_index.rs:47-71); `value` is the join with a prebuilt r_index (spatial_index.rs:558-624)",
+        "right_side_exchange": {"ms": exchange["ms"], "bytes": exchange["bytes"], "what": "all-gatherv of the right GeoArrow buffers + the per-geometry boxes, device-resident, outside the timed region"},
+        "kernel_ms_per_step": warm,
+        "parallelism": f"left row-sharded x{W} (strong scaling: the 1M x 1M problem is fixed), right side all-gathered",
+    }
+    achieved = nbytes / k_s / 1e9 if k_s > 0 else 0.0
+    roofline = {
+        "bound": "hbm",
+        "kernel": "gpk_pair_refine",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": None,
+        "launch_ms": k_ms,
+        "launches": k_n,
+        "algorithmic_bytes": nbytes,
+        "note": "candidate refine is VALU-bound (exact segment-pair tests), the candidate passes are gather-bound; the HBM fraction is reported as the contract asks",
+        "source_hash": source_hash(),
+    }
+    line = base_line(ctx, "polygon-pair intersects() join rows/sec (1M x 1M polygons)", n * args.steps / elapsed, "left rows/s", ms_per_step, "strong", config, roofline)
+    line["parity"] = parity
+    if W == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline_polyjoin(left_host, right_full, counts, args.cpu_seconds)
+    print(json.dumps(line), flush=True)
+    ctx.finish()
+
+
+def parity_poly_join(left_host, right_host, gpu_counts, gpu_pairs, h: int, base: int, rows: int) -> dict:
+    from oracle import pyoracle
+
+    pyoracle.build()
+    idx = sample_rows(len(left_host), rows, seed=4244)
+    ep, ec, _ = pyoracle.spatial_join(left_host.take(idx), right_host, "intersects", mode=1, n_threads=0)
+    gc = gpu_counts.cpu().numpy().astype(np.uint32)
+    gp = gpu_pairs[:h].cpu().numpy().astype(np.uint32)
+    got = pairs_of_rows(gp, (idx + base).astype(np.uint32))
+    if not np.array_equal(gc[idx], ec) or not np.array_equal(got, ep) or int(gc.sum()) != h:
+        raise SystemExit("bench.py: GPU polygon join differs from the CPU oracle on the parity sample — no speed reported")
+    return {"rows": int(len(idx)), "sampling": "uniform random without replacement (seed 4244)", "pairs_checked": int(len(ep)), "bit_exact": True}
+
+
+def cpu_baseline_polyjoin(left_host, right_host, gpu_counts, target_s: float) -> dict:
+    from oracle import pyoracle
+
+    n = len(left_host)
+    probe = min(n, 20_000)
+    t0 = time.perf_counter()
+    pyoracle.spatial_join(left_host.take(np.arange(probe)), right_host, "intersects", mode=1, n_threads=0)
+    dt = max(time.perf_counter() - t0, 1e-3)
+    sample = int(min(n, max(probe, probe * target_s / dt)))
+    t0 = time.perf_counter()
+    _, counts, threads = pyoracle.spatial_join(left_host.take(np.arange(sample)), right_host, "intersects", mode=1, n_threads=0)
+    best = time.perf_counter() - t0
+    if not np.array_equal(gpu_counts[:sample].cpu().numpy().astype(np.uint32), counts):
+        raise SystemExit("bench.py: GPU hit counts differ from the CPU oracle on the baseline sample — no speed reported")
+    return {
+        "value": sample / best,
+        "unit": "left rows/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"first {sample} of the {n} left rows against all {len(right_host)} right rows (the time includes the oracle's own grid directory build over the right side), OpenMP dynamic",
         "seconds": best,
         "parity_checked_rows": sample,
     }
+
+
+# ======================================================================================================
+# C5 — points within power-law multipolygons + area
+# ======================================================================================================
+def c5_chunk(k: int, rows: int):
+    from geopolars_amd import synth
+
+    return synth.powerlaw_multipolygons(rows, seed=51 + k)
+
+
+def run_c5(ctx: Ctx) -> None:
+    torch, args, lib = ctx.torch, ctx.args, ctx.lib
+    from geopolars_amd import _abi, synth
+    from geopolars_amd.dist import GeoBuffers, all_gatherv_buffers
+    from geopolars_amd.geoarrow import GeoArrowArray
+    from geopolars_amd.spatial_index import SpatialIndex, join_pairs_device, join_pairs_enqueue
+
+    n, M, dev, stream, W = args.points, args.multipolygons, ctx.dev, ctx.stream, ctx.world
+    if C5_CHUNKS % W:
+        raise SystemExit("bench.py --config c5: --gpus must divide 8")
+    rows_per_chunk = M // C5_CHUNKS
+    mine = range(ctx.rank * C5_CHUNKS // W, (ctx.rank + 1) * C5_CHUNKS // W)
+    t0 = time.perf_counter()
+    shard_host = GeoArrowArray.concat([c5_chunk(k, rows_per_chunk) for k in mine])
+    gen_s = time.perf_counter() - t0
+    shard = GeoBuffers.from_host(shard_host, dev)
+    exchange = {"ms": 0.0, "bytes": 0}
+    torch.cuda.synchronize()
+    if ctx.use_dist:
+        ctx.barrier()
+        t0 = time.perf_counter()
+        stats = {}
+        right_buf = all_gatherv_buffers(shard, stats=stats)
+        ctx.barrier()
+        exchange = {"ms": ctx.max_over_ranks(time.perf_counter() - t0) * 1e3, "bytes": stats["gathered_bytes"]}
+    else:
+        right_buf = shard
+    right = right_buf.to_device_geoarray(stream)
+    area_share = shard.to_device_geoarray(stream)  # area() is a per-row map: every rank keeps the rows it generated
+    n_share = shard.n_geoms
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    index = SpatialIndex.from_device(right, stream=stream)
+    torch.cuda.synchronize()
+    build_ms = (time.perf_counter() - t0) * 1e3
+    pts_host = synth.uniform_points(n, seed=52 + ctx.rank)
+    pts = dev_array(torch, pts_host, dev, stream)
+    counts = torch.empty(n, dtype=torch.int32, device=dev)
+    pairs = torch.empty((4 * n, 2), dtype=torch.int32, device=dev)
+    total = torch.zeros(1, dtype=torch.int64, device=dev)
+    area = torch.empty(n_share, dtype=torch.float64, device=dev)
+
+    def step(i: int) -> None:
+        join_pairs_enqueue(pts, right, index, "within", counts, pairs, total, left_row_base=0, stream=stream)
+        _abi.check(lib.gpk_area(area_share.handle, area.data_ptr(), _abi.MEM_DEVICE, stream))
+
+    elapsed, k_ms, k_n, warm = ctx.timed(step, "gpk_pip_tile", args.steps, args.warmup)
+    torch.cuda.synchronize()
+    h = int(total.item())
+    if h > pairs.shape[0]:
+        raise SystemExit(f"bench.py --config c5: {h} pairs exceed the pair buffer")
+    # area over ALL multipolygons of the gathered right side, once (what one GPU would do alone)
+    area_all = torch.empty(right_buf.n_geoms, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        _abi.check(lib.gpk_area(right.handle, area_all.data_ptr(), _abi.MEM_DEVICE, stream))
+    torch.cuda.synchronize()
+    area_all_ms = (time.perf_counter() - t0) * 1e3 / 3
+    if ctx.rank != 0:
+        ctx.finish()
+        return
+    right_host = right_buf.to_host() if W > 1 else shard_host
+    ms_per_step = elapsed / args.steps * 1e3
+    nbytes = 16 * n + 16 * right_host.n_coords + 4 * (right_host.n_geoms + right_host.n_parts + right_host.n_rings + 3) + 4 * n
+    k_s = k_ms * 1e-3
+    achieved = nbytes / k_s / 1e9 if k_s > 0 else 0.0
+    area_bytes = 16 * shard_host.n_coords + 4 * (shard_host.n_geoms + shard_host.n_parts + shard_host.n_rings + 3) + 8 * n_share
+    area_ms = sum(v for k, v in warm.items() if "area" in k or "seq_long" in k)
+    config = {
+        "workload": f"C5: {n} points (one rank's share of 50M) within() all {right_host.n_geoms} power-law multipolygons ({right_host.n_coords} coordinates) + area() of {n_share} of them, per GPU",
+        "points_per_gpu": n,
+        "multipolygons": right_host.n_geoms,
+        "coordinates": right_host.n_coords,
+        "hits_per_step": h,
+        "call": "gpk_spatial_join_async(within) + gpk_area, one stream",
+        "index_build_ms": build_ms,
+        "index_bytes": index.nbytes(),
+        "join_ms_per_step": sum(v for k, v in warm.items() if "pip_" in k),
+        "area_ms_per_step": area_ms,
+        "area_GBps": area_bytes / (area_ms * 1e-3) / 1e9 if area_ms > 0 else None,
+        "area_all_multipolygons_ms": area_all_ms,
+        "build_plus_step_ms": build_ms + ms_per_step,
+        "right_side_exchange": {"ms": exchange["ms"], "bytes": exchange["bytes"], "what": "all-gatherv of the right GeoArrow buffers, device-resident, outside the timed region; every rank then builds the index over the gathered column"},
+        "host_generation_s": gen_s,
+        "kernel_ms_per_step": warm,
+        "parallelism": f"points row-sharded x{W} (weak: 6.25M per GPU, 50M at 8), multipolygons replicated by the exchange",
+    }
+    roofline = {
+        "bound": "hbm",
+        "kernel": "gpk_pip_tile",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": None,
+        "launch_ms": k_ms,
+        "launches": k_n,
+        "algorithmic_bytes": nbytes,
+        "note": "latency-bound gathers into a multi-gigabyte index (raster words, level-2 records, edge slabs), not a streaming kernel; the streaming part of the step is area()",
+        "source_hash": source_hash(),
+    }
+    line = base_line(ctx, "predicate evals/sec (points within power-law multipolygons, + area)", float(W) * n * right_host.n_geoms * args.steps / elapsed, "evals/s", ms_per_step, "weak", config, roofline)
+    line["parity"] = parity_point_join(pts_host, right_host, "within", counts, pairs, h, args.parity_rows)
+    line["parity"]["area"] = parity_area(shard_host, area)
+    if W == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline_join(pts_host, right_host, "within", counts, args.cpu_seconds)
+    print(json.dumps(line), flush=True)
+    ctx.finish()
+
+
+def parity_area(host, gpu_area) -> dict:
+    from oracle import pyoracle
+
+    exp = pyoracle.area(host)
+    got = gpu_area.cpu().numpy()
+    rel = np.abs(got - exp) / np.maximum(np.abs(exp), 1e-300)
+    if not bool(np.all((rel <= 1e-9) | (got == exp))):
+        raise SystemExit("bench.py: GPU areas differ from the CPU oracle beyond 1e-9 — no speed reported")
+    return {"rows": int(len(exp)), "tolerance": "1e-9 relative", "max_rel_err": float(rel.max(initial=0.0))}
+
+
+# ------------------------------------------------------------------------------------------------------
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2")
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=None, help="left rows per GPU (c2/c3: 10M, c5: 6.25M)")
+    ap.add_argument("--polys", type=int, default=1000, help="c2: right-side polygons")
+    ap.add_argument("--verts", type=int, default=64, help="c2: vertices per polygon")
+    ap.add_argument("--lines", type=int, default=100_000, help="c3: right-side linestrings")
+    ap.add_argument("--polygons", type=int, default=1_000_000, help="c4: polygons per side")
+    ap.add_argument("--multipolygons", type=int, default=5_000_000, help="c5: right-side multipolygons (all of them on every GPU)")
+    ap.add_argument("--rotate", type=int, default=3, help="c2: distinct input/output sets cycled through by the steps (cold inputs)")
+    ap.add_argument("--parity-rows", type=int, default=300_000, help="random sample of left rows compared with the oracle")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the cpu_baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--index-per-step", action="store_true", help="c2: rebuild the right-side index inside every step")
+    ap.add_argument("--sync-steps", action="store_true", help="c2: use the synchronous gpk_spatial_join (host waits for every step)")
+    ap.add_argument("--no-profile", action="store_true", help="tuning only: no HIP events around the kernels (the roofline leg reads zero)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the exchange even at world size 1 (path test)")
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = {"c2": 20, "c3": 10, "c4": 10, "c5": 10}[args.config]
+    if args.points is None:
+        args.points = {"c2": 10_000_000, "c3": 10_000_000, "c4": 0, "c5": 6_250_000}[args.config]
+    ctx = Ctx(args)
+    {"c2": run_c2, "c3": run_c3, "c4": run_c4, "c5": run_c5}[args.config](ctx)
 
 
 if __name__ == "__main__":

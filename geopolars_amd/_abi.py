@@ -107,6 +107,8 @@ _PROTOS = {
     "gpk_join_indices": (C.c_int32, [_VP, _VP, C.c_int64, C.c_int64, C.c_uint32, C.c_int32, _VP, _VP, C.c_int64, C.POINTER(C.c_int64), C.c_int32, _VP]),
     "gpk_take_fixed": (C.c_int32, [_VP, C.c_int32, _VP, C.c_int64, _VP, C.c_int64, _VP, _VP, C.c_int32, _VP]),
     "gpk_take_binary": (C.c_int32, [_VP, _VP, _VP, C.c_int64, _VP, C.c_int64, _VP, _VP, C.c_int64, C.POINTER(C.c_int64), _VP, C.c_int32, _VP]),
+    "gpk_join_stats_enable": (C.c_int32, [C.c_int32]),
+    "gpk_join_stats": (C.c_int32, [C.POINTER(C.c_int64), C.c_int32]),
     "gpk_profile_enable": (C.c_int32, [C.c_int32]),
     "gpk_profile_filter": (C.c_int32, [C.c_char_p]),
     "gpk_profile_reset": (C.c_int32, []),

@@ -78,15 +78,19 @@ def _compile(src: str, verbose: bool) -> str:
     return obj
 
 
-def build_variant(name: str, defines: list[str]) -> str:
+def build_variant(name: str, defines: list[str], only: list[str] | None = None) -> str:
     """A/B builds for kernel tuning: same sources with extra -D flags -> geopolars_amd/variants/<name>.so
-    (select at run time with GPK_LIB_PATH)."""
+    (select at run time with GPK_LIB_PATH).  `only`: the sources the flags affect; the others are linked from the
+    objects of the in-tree build (run build() first)."""
     vdir = os.path.join(HERE, "variants")
     odir = os.path.join(OBJ, name)
     os.makedirs(vdir, exist_ok=True)
     os.makedirs(odir, exist_ok=True)
     objs = []
     for src in SOURCES:
+        if only is not None and src not in only:
+            objs.append(os.path.join(OBJ, os.path.splitext(src)[0] + ".o"))
+            continue
         obj = os.path.join(odir, os.path.splitext(src)[0] + ".o")
         lang = ["-x", "hip"] if src.endswith(".hip") else []
         cmd = [_hipcc(), *FLAGS, *[f"-D{d}" for d in defines], *lang, "-c", os.path.join(CSRC, src), "-o", obj]

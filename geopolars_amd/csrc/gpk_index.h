@@ -113,6 +113,7 @@ struct gpk_index {
     int32_t geom_type;
     void* owned[16];  // bbox, grid, cell_off, items, then the PipView tables
     int64_t nbytes;
+    int32_t pip_lean;  // 1: every raster cell names at most one part and boundary cells carry inline records (build_pip_index)
 };
 
 namespace gpk {

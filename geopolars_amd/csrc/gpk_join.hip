@@ -213,7 +213,7 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
                                                               unsigned long long* __restrict__ block_tot,
                                                               unsigned long long* __restrict__ super_tot,
                                                               uint32_t* __restrict__ multi_pool, uint32_t multi_cap,
-                                                              uint32_t* __restrict__ multi_top) {
+                                                              uint32_t* __restrict__ multi_top, unsigned long long* __restrict__ stats) {
     __shared__ QEntry q[RASTER ? PIP_QCAP : 1];
     __shared__ uint32_t s_cnt[PIP_TILE], s_hit[PIP_TILE * PIP_KHIT];
     __shared__ uint32_t q_n, ovf_n;
@@ -452,8 +452,10 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
             if (k + 1 < PIP_PPT && queued <= (uint32_t)PIP_QCAP / 2) continue;
             // phase 2
             const uint32_t nq = GPK_ABLATE == 1 ? 0u : (queued < (uint32_t)PIP_QCAP ? queued : (uint32_t)PIP_QCAP);
+            if (stats && tid == 0 && queued) atomicAdd(&stats[0], (unsigned long long)queued);  // measurement runs only
             for (uint32_t e = tid / PIP_GS; e < nq; e += PIP_BLOCK / PIP_GS) {
                 const QEntry en = q[e];
+                if (stats && glane == 0) atomicAdd(&stats[1], (unsigned long long)en.cnt);
                 const int pos = pip::part_pos_group_from_edges<PIP_GS>(pv, polys, (int)en.part, (en.li_flags >> 31) ? 2 : 1, (int)en.e0,
                                                                        (int)en.cnt, en.px, en.py, glane);
                 if (glane == 0 && pos == dev::POS_INSIDE) {
@@ -583,6 +585,178 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
     }
 }
 
+// ---- pip_tile_lean: the same tile step for right sides whose raster names at most ONE part per cell ---------------
+// (gpk_index::pip_lean: no entry lists, no two-part records, no refined rings — disjoint polygons, the C2 right side.)
+// A point then has one candidate part at most, so nothing per point lives in LDS: the lane keeps its points' results in
+// registers, the only shared structure is the queue of (point, part) pairs that need the exact walk, and a queued pair's
+// verdict comes back through its queue entry.  Versus pip_tile_kernel: no per-point LDS arrays (their initialisation, the
+// LDS atomics of phase 2, one of the three barriers per round), no list / overflow / multi-hit arms, PPT points per lane
+// in flight before the first dependent gather, one drain of the queue per tile.
+#ifndef GPK_LEAN_PPT
+#define GPK_LEAN_PPT 4
+#endif
+#ifndef GPK_LEAN_QCAP
+#define GPK_LEAN_QCAP 256
+#endif
+#ifndef GPK_LEAN_MINWAVES
+#define GPK_LEAN_MINWAVES 1
+#endif
+constexpr int LEAN_PPT = GPK_LEAN_PPT, LEAN_TILE = PIP_BLOCK * LEAN_PPT, LEAN_QCAP = GPK_LEAN_QCAP;
+static_assert(PIP_WTILE % LEAN_TILE == 0, "a writer tile is a whole number of lean tiles");
+__global__ __launch_bounds__(PIP_BLOCK, GPK_LEAN_MINWAVES) void pip_tile_lean_kernel(DevGeo pts, DevGeo polys, PipView pv,
+                                                                                    uint32_t* __restrict__ counts, uint32_t* __restrict__ code,
+                                                                                    unsigned long long* __restrict__ block_tot,
+                                                                                    unsigned long long* __restrict__ super_tot,
+                                                                                    unsigned long long* __restrict__ stats) {
+    constexpr int PPT = LEAN_PPT, S = PIP_SUB, FINE = PIP_SLAB_MUL << PIP_FINE_LOG2, FY_SUB = PIP_FINE_LOG2 - 2;
+    static_assert(FINE == S << FY_SUB, "fine rows per level-2 row");
+    __shared__ QEntry q[LEAN_QCAP];
+    __shared__ uint32_t q_n;
+    __shared__ unsigned long long s_tot;
+    const int tid = threadIdx.x, lane64 = tid & 63;
+    const int64_t base = (int64_t)blockIdx.x * LEAN_TILE;
+    const int64_t n = pts.n_geoms;
+    const uint32_t rem = (uint32_t)(n - base < (int64_t)LEAN_TILE ? n - base : (int64_t)LEAN_TILE);
+    const double2* __restrict__ tile_xy = pts.xy + base;
+
+    // stage A: every point of the lane is requested before anything waits (coalesced 16-byte loads)
+    double2 p[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const uint32_t t = (uint32_t)(k * PIP_BLOCK + tid);
+        const bool ok = t < rem && dev::valid_row(pts.validity, base + t);
+        p[k] = ok ? tile_xy[t] : make_double2(NAN, NAN);
+    }
+    if (tid == 0) {
+        q_n = 0;
+        s_tot = 0;
+    }
+    __syncthreads();  // the loads above are in flight while the work-group meets here
+
+    // stage B: level-1 words (one 4-byte gather per point; empty points read nothing)
+    uint32_t sx[PPT], fyf[PPT], word[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        sx[k] = (uint32_t)dev::cell_of(p[k].x, pv.rx0, pv.inv_fw * S, pv.R * S);
+        fyf[k] = (uint32_t)dev::cell_of(p[k].y, pv.ry0, pv.inv_fh * FINE, pv.R * FINE);
+        const uint32_t fy = fyf[k] >> FY_SUB;
+        word[k] = (p[k].x == p[k].x && p[k].y == p[k].y) ? pv.cell[(fy / S) * (uint32_t)pv.R + (sx[k] / S)] : 0u;
+    }
+    // stage C: level-2 records of the cells an edge crosses (32 bytes: two 16-byte gathers off one line)
+    uint4 ra[PPT], rb[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        ra[k] = rb[k] = make_uint4(0u, 0u, 0u, 0u);
+        if ((word[k] >> 30) == CELL_TAG_SUB) {
+            const uint4* __restrict__ r = reinterpret_cast<const uint4*>(pv.sub + (word[k] & 0x3FFFFFFFu));
+            ra[k] = r[0];  // part_flags, e0, e1, e2
+            rb[k] = r[1];  // labels
+        }
+    }
+    // stage D: decide, or mark for the exact walk
+    uint32_t res[PPT];   // part that contains the point, CODE_NONE, or (pending) PENDING | queue slot
+    uint32_t qpart[PPT], qe0[PPT], qcnt[PPT];
+    bool todo[PPT];
+    constexpr uint32_t PENDING = 0x80000000u;  // part ids stay below 2^30 (cell word payload)
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const uint32_t tag = word[k] >> 30, payload = word[k] & 0x3FFFFFFFu;
+        res[k] = CODE_NONE;
+        todo[k] = false;
+        qpart[k] = ra[k].x;  // part | (has holes) << 31
+        qe0[k] = qcnt[k] = 0;
+        if (tag == CELL_TAG_SINGLE) {
+            res[k] = payload >> 1;  // lean index: single entries are interiors (boundary cells carry records)
+        } else if (tag == CELL_TAG_SUB) {
+            const uint32_t fy = fyf[k] >> FY_SUB;
+            const int idx = (int)((fy % S) * S + (sx[k] % S));
+            const int wsel = idx >> 4;
+            const uint32_t lw = wsel == 0 ? rb[k].x : (wsel == 1 ? rb[k].y : (wsel == 2 ? rb[k].z : rb[k].w));
+            const uint32_t lab = (lw >> (2 * (idx & 15))) & 3u;
+            if (lab == 1u) res[k] = ra[k].x & 0x3FFFFFFFu;
+            if (lab == 2u) {
+                const bool upper = ((fyf[k] >> PIP_FINE_LOG2) & 1u) != 0;
+                qe0[k] = upper ? ra[k].z : ra[k].y;
+                qcnt[k] = (upper ? ra[k].w : ra[k].z) - qe0[k];
+                todo[k] = qcnt[k] > 0;  // an empty slab: p.y is outside the exterior's y-range
+            }
+        }
+    }
+    // Rounds of (queue the marked points -> PIP_GS lanes per queued pair walk the slab's edges -> owners collect the
+    // verdicts).  One round unless a tile holds more boundary points than the queue (then the rest goes next round).
+    unsigned long long edges_walked = 0, pairs_walked = 0;
+    const int glane = tid & (PIP_GS - 1);
+    for (;;) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const unsigned long long mask = __ballot(todo[k]);
+            if (mask) {
+                uint32_t wbase = 0;
+                const int leader = __ffsll((long long)mask) - 1;
+                if (lane64 == leader) wbase = atomicAdd(&q_n, (uint32_t)__popcll(mask));
+                wbase = __shfl(wbase, leader, 64);
+                const uint32_t slot = wbase + (uint32_t)__popcll(mask & ((1ull << lane64) - 1ull));
+                if (todo[k] && slot < (uint32_t)LEAN_QCAP) {
+                    q[slot] = QEntry{p[k].x, p[k].y, qpart[k] & 0x3FFFFFFFu, qe0[k], qcnt[k], qpart[k] & 0x80000000u};
+                    res[k] = PENDING | slot;
+                    todo[k] = false;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t queued = q_n;  // uniform: read after the barrier
+        const uint32_t nq = queued < (uint32_t)LEAN_QCAP ? queued : (uint32_t)LEAN_QCAP;
+        for (uint32_t e = tid / PIP_GS; e < nq; e += PIP_BLOCK / PIP_GS) {
+            const QEntry en = q[e];
+            const int pos = pip::part_pos_group_from_edges<PIP_GS>(pv, polys, (int)en.part, (en.li_flags >> 31) ? 2 : 1, (int)en.e0, (int)en.cnt,
+                                                                   en.px, en.py, glane);
+            if (glane == 0) {
+                q[e].part = pos == dev::POS_INSIDE ? en.part : CODE_NONE;  // the verdict travels back in the entry
+                edges_walked += en.cnt;
+                ++pairs_walked;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PPT; ++k)
+            if (res[k] != CODE_NONE && (res[k] & PENDING)) res[k] = q[res[k] & ~PENDING].part;
+        if (queued <= (uint32_t)LEAN_QCAP) break;  // uniform
+        __syncthreads();  // every owner has read its verdicts: the queue can be reused
+        if (tid == 0) q_n = 0;
+        __syncthreads();
+    }
+    if (stats && pairs_walked) {  // measurement runs only (gpk_join_stats_enable): uniform branch on the pointer
+        atomicAdd(&stats[0], pairs_walked);
+        atomicAdd(&stats[1], edges_walked);
+    }
+    // finalize: part -> geometry (null geometries dropped), count + code, tile total
+    uint32_t* __restrict__ tile_counts = counts ? counts + base : nullptr;
+    uint32_t* __restrict__ tile_code = code + base;
+    unsigned long long wave_hits = 0;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const uint32_t li = (uint32_t)(k * PIP_BLOCK + tid);
+        uint32_t r = res[k];
+        if (r != CODE_NONE) {
+            const uint32_t geom = pv.part_geom ? pv.part_geom[r] : r;
+            r = dev::valid_row(polys.validity, geom) ? geom : CODE_NONE;
+        }
+        const uint32_t cnt = r != CODE_NONE ? 1u : 0u;
+        if (li < rem) {
+            if (tile_counts) dev::store_stream(tile_counts + li, cnt);
+            dev::store_stream(tile_code + li, r);
+        }
+        wave_hits += (unsigned long long)__popcll(__ballot(li < rem && cnt));
+    }
+    if (lane64 == 0 && wave_hits) atomicAdd(&s_tot, wave_hits);
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long tot = s_tot;
+        block_tot[blockIdx.x] = tot;
+        if (tot) atomicAdd(&super_tot[blockIdx.x >> PIP_SUPER_SHIFT], tot);
+    }
+}
+
 // pip_write: turns the per-point codes into the sorted (l, r) pair list.  Reads 4 bytes per point, writes 8
 // bytes per hit; only CODE_MULTI rows touch geometry again.  There is no separate scan kernel: a work-group
 // gets its global offset from the two-level totals (<= 64 tile totals + the super-tile totals before them,
@@ -592,7 +766,7 @@ __global__ __launch_bounds__(WR_BLOCK) void pip_write_kernel(DevGeo pts, DevGeo 
                                                                const unsigned long long* __restrict__ block_tot,
                                                                const unsigned long long* __restrict__ super_tot,
                                                                const uint32_t* __restrict__ multi_pool,
-                                                               int64_t n_tiles, uint32_t left_base,
+                                                               int64_t n_tiles, int tile_points, uint32_t left_base,
                                                                uint2* __restrict__ pairs, int64_t capacity,
                                                                unsigned long long* __restrict__ grand,
                                                                unsigned long long* __restrict__ grand_host) {
@@ -600,7 +774,7 @@ __global__ __launch_bounds__(WR_BLOCK) void pip_write_kernel(DevGeo pts, DevGeo 
     __shared__ unsigned long long s_base;
     __shared__ uint2 s_pairs[WR_CAP];
     const int tid = threadIdx.x;
-    const int64_t first_tile = (int64_t)blockIdx.x * (PIP_WTILE / PIP_TILE);
+    const int64_t first_tile = (int64_t)blockIdx.x * (PIP_WTILE / tile_points);  // tiles of the kernel that produced the totals
     if (tid < 64) {
         const int64_t sb = first_tile >> PIP_SUPER_SHIFT;
         unsigned long long acc = 0;
@@ -676,6 +850,11 @@ __global__ __launch_bounds__(WR_BLOCK) void pip_write_kernel(DevGeo pts, DevGeo 
             if (out_base + t < capacity) pairs[out_base + t] = s_pairs[t];
     }
 }
+
+// ---- join statistics (bench.py's edge_tests/s; off unless enabled) ---------------------------------------------------
+static unsigned long long* g_join_stats = nullptr;  // device: {queued (point, part) pairs, slab edges walked by the exact phase, 0, 0}
+static bool g_join_stats_on = false;
+static unsigned long long* join_stats_buffer() { return g_join_stats_on ? g_join_stats : nullptr; }
 
 // ================================= polygonal x polygonal join ======================================
 // Candidate generation of spatial_index.rs:74-76 for bbox-shaped left rows: every directory cell the left
@@ -975,7 +1154,13 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
                                 unsigned long long* total_out, hipStream_t s, uint32_t** counts_dev_out, uint32_t** pairs_dev_out,
                                 unsigned long long** grand_out) {
     const int64_t n = left->d.n_geoms;
-    const int64_t n_blocks = (n + PIP_TILE - 1) / PIP_TILE;
+    static const bool no_lean = [] {  // GPK_NO_LEAN=1: A/B runs of the general tile kernel on a lean-eligible index
+        const char* e = getenv("GPK_NO_LEAN");
+        return e && *e && *e != '0';
+    }();
+    const bool lean = right_index->pip.R > 0 && right_index->pip_lean && !no_lean;
+    const int tile_points = lean ? LEAN_TILE : PIP_TILE;
+    const int64_t n_blocks = (n + tile_points - 1) / tile_points;
     const bool want_pairs = pair_capacity > 0;
     const size_t counts_bytes = sizeof(uint32_t) * (size_t)n;
     const size_t pairs_bytes = sizeof(uint32_t) * 2 * (size_t)pair_capacity;
@@ -1012,19 +1197,23 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         const hipError_t me = hipMemsetAsync(stot, 0, sizeof(unsigned long long) * (size_t)(n_super + 2), s);
         if (me != hipSuccess) return fail(GPK_ERR_DEVICE, "spatial_join: %s", hipGetErrorString(me));
     }
-    if (right_index->pip.R > 0)
+    unsigned long long* stats = join_stats_buffer();  // nullptr unless gpk_join_stats_enable(1)
+    if (lean)
+        J_LAUNCH("gpk_pip_tile", pip_tile_lean_kernel, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d, right_index->pip,
+                 counts_dev, code, btot, stot, stats);
+    else if (right_index->pip.R > 0)
         if (right_index->pip.sub2)
             J_LAUNCH("gpk_pip_tile", (pip_tile_kernel<true, true>), dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
-                     right_index->v, right_index->pip, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top);
+                     right_index->v, right_index->pip, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top, stats);
         else
             J_LAUNCH("gpk_pip_tile", (pip_tile_kernel<true, false>), dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
-                     right_index->v, right_index->pip, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top);
+                     right_index->v, right_index->pip, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top, stats);
     else
         J_LAUNCH("gpk_pip_tile_generic", (pip_tile_kernel<false, false>), dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
-                 right_index->v, right_index->pip, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top);
+                 right_index->v, right_index->pip, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top, stats);
     // the writer also produces the grand total; in count-only mode it runs without a pair buffer
     J_LAUNCH("gpk_pip_write", pip_write_kernel, dim3((unsigned)n_wblocks), dim3(WR_BLOCK), 0, s, left->d, right->d, right_index->v,
-             code, btot, stot, (const uint32_t*)multi_pool, n_blocks, left_row_base, (uint2*)pairs_dev, pair_capacity, grand, total_out);
+             code, btot, stot, (const uint32_t*)multi_pool, n_blocks, tile_points, left_row_base, (uint2*)pairs_dev, pair_capacity, grand, total_out);
 #undef J_LAUNCH
 
     *counts_dev_out = counts_dev;
@@ -1138,6 +1327,28 @@ static int32_t swapped_pip_join(const gpk_geoarray* polys, const gpk_geoarray* p
 using namespace gpk;
 
 extern "C" {
+
+int32_t gpk_join_stats_enable(int32_t on) {
+    if (on && !g_join_stats) {
+        GPK_TRY(require_device());
+        GPK_HIP(hipMalloc((void**)&g_join_stats, 4 * sizeof(unsigned long long)));
+        GPK_HIP(hipMemset(g_join_stats, 0, 4 * sizeof(unsigned long long)));
+    }
+    g_join_stats_on = on != 0;
+    return GPK_OK;
+}
+
+int32_t gpk_join_stats(int64_t out[4], int32_t reset) {
+    if (!out) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (!g_join_stats) return GPK_OK;
+    GPK_HIP(hipDeviceSynchronize());
+    unsigned long long h[4];
+    GPK_HIP(hipMemcpy(h, g_join_stats, sizeof h, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; ++i) out[i] = (int64_t)h[i];
+    if (reset) GPK_HIP(hipMemset(g_join_stats, 0, sizeof h));
+    return GPK_OK;
+}
 
 int32_t gpk_index_free(gpk_index* idx) {
     if (!idx) return GPK_OK;

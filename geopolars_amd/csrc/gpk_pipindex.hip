@@ -68,7 +68,7 @@ __global__ void part_info_kernel(DevGeo a, int64_t n_parts, const int32_t* __res
 // against a row — down to SLAB_TARGET edges.
 constexpr int SLAB_TARGET = 12;
 __global__ void ring_rows_kernel(const double4* __restrict__ ring_bbox, int64_t n_rings, const int32_t* __restrict__ ring_off, FineGrid f,
-                                 int max_shift, int32_t* __restrict__ row0, int32_t* __restrict__ nrows) {
+                                 int max_shift, int32_t* __restrict__ row0, int32_t* __restrict__ nrows, int32_t* __restrict__ n_refined) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rings) return;
     const double4 b = ring_bbox[r];
@@ -83,6 +83,7 @@ __global__ void ring_rows_kernel(const double4* __restrict__ ring_bbox, int64_t 
     int sh = 0;
     while (sh < max_shift && n_edges > (int64_t)SLAB_TARGET * (base_rows << sh)) ++sh;
     const int j0 = f0 >> (PIP_FINE_LOG2 - sh), j1 = f1 >> (PIP_FINE_LOG2 - sh);
+    if (sh > 0) atomicAdd(n_refined, 1);  // rare (rings of hundreds of vertices); the join picks its lean kernel when there are none
     row0[r] = j0 | (sh << 24);
     nrows[r] = j1 - j0 + 1;
 }
@@ -625,11 +626,15 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
     // refined rows assume short edges; a ring of many LONG edges (a comb) would register each of them in every refined
     // row, so a total far beyond the coordinate count sends the build back to the base rows
     const int slab_off_slot = slot++;  // owned by the index from the moment it exists (released with it on any error path)
+    int32_t n_refined = 0, *n_refined_dev;
+    GPK_TRY(t.alloc(&n_refined_dev, 64));
     for (int max_shift = PIP_FINE_LOG2;; max_shift = 0) {
+        GPK_HIP(hipMemsetAsync(n_refined_dev, 0, sizeof(int32_t), s));
         GPK_LAUNCH("gpk_pipidx_ring_rows", ring_rows_kernel, blocks_for(n_rings), dim3(256), 0, s, ring_bbox, n_rings, d.ring_off, gs, max_shift,
-                   row0, nrows);
+                   row0, nrows, n_refined_dev);
         GPK_TRY(exclusive_scan_i32(nrows, n_rings, slab_base, nullptr, btot, s));
         GPK_HIP(hipMemcpyAsync(&n_slabs, slab_base + n_rings, sizeof n_slabs, hipMemcpyDeviceToHost, s));
+        GPK_HIP(hipMemcpyAsync(&n_refined, n_refined_dev, sizeof n_refined, hipMemcpyDeviceToHost, s));
         GPK_HIP(hipStreamSynchronize(s));
         if ((int64_t)n_slabs > max_scan) {  // few-vertex rings spanning many slab rows: more slabs than coordinates
             max_scan = n_slabs;
@@ -745,6 +750,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
 
     // ---- level 2 ------------------------------------------------------------------------------------
     int32_t n_sub = 0, n_sub2 = 0;
+    bool sub_overflow = false;
     SubCell* sub = nullptr;
     SubCell2* sub2 = nullptr;
     static_assert(PIP_SLAB_MUL == 2, "SubCell stores exactly two adjacent slab ranges");
@@ -761,7 +767,10 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
         GPK_HIP(hipMemcpyAsync(&n_sub, spos + n_cells, sizeof n_sub, hipMemcpyDeviceToHost, s));
         GPK_HIP(hipMemcpyAsync(&n_sub2, spos2 + n_cells, sizeof n_sub2, hipMemcpyDeviceToHost, s));
         GPK_HIP(hipStreamSynchronize(s));
-        if ((unsigned)n_sub >= SUB2_BIT || (unsigned)n_sub2 >= SUB2_BIT) n_sub = n_sub2 = 0;  // would not fit the cell word: no level 2
+        if ((unsigned)n_sub >= SUB2_BIT || (unsigned)n_sub2 >= SUB2_BIT) {  // would not fit the cell word: no level 2
+            n_sub = n_sub2 = 0;
+            sub_overflow = true;
+        }
         // two-part records make the join kernel carry a second part per point and cost a second labelling pass: they pay off
         // when shared borders are THE boundary shape (a tessellation: 17 two-part cells per one-part cell); columns of
         // overlapping polygons have about as many of either kind, most of their sub-cells end up "test both", and the pass
@@ -822,6 +831,12 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
         }
     }
     pv.lrec = lrec;
+    // Every cell is empty / strictly inside one part / crossed by one part with an inline level-2 record: each point has at
+    // most one candidate part and the join runs its lean kernel (gpk_join.hip: pip_tile_lean_kernel).  Disjoint polygons
+    // (parcels, the C2 right side) look like this; overlaps, shared borders and refined rings keep the general kernel.
+    const bool boundary_cells_have_records = level2_ok && !sub_overflow && n_sub2 == 0;  // every `part << 1 | 1` cell became a record
+    ix->pip_lean = list_len == 0 && n_refined == 0 && boundary_cells_have_records ? 1 : 0;
+    if (getenv("GPK_DEBUG_INDEX")) fprintf(stderr, "[gpk] lean join kernel eligible: %d (list %d, refined rings %d, one-part records %d)\n", ix->pip_lean, list_len, n_refined, n_sub);
     ix->nbytes += (int64_t)(sizeof(SubCell) * (size_t)n_sub + sizeof(SubCell2) * (size_t)n_sub2 + sizeof(SubCell) * (size_t)n_lrec);
     ix->pip = pv;
     ix->nbytes += (int64_t)(sizeof(uint32_t) * (size_t)n_cells + sizeof(uint32_t) * (size_t)list_len + sizeof(double4) * (size_t)n_edges +

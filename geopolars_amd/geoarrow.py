@@ -193,6 +193,52 @@ class GeoArrowArray:
             validity = np.packbits(bits, bitorder="little")
         return GeoArrowArray.from_wkb(values, offsets, validity)
 
+    # ---- row surgery on the host (sampling for parity checks, assembling shards) -------------------------------
+    def take(self, idx) -> "GeoArrowArray":
+        """Rows `idx` (any order, repeats allowed) as a self-contained array: offsets rebuilt, coordinates gathered."""
+        idx = np.asarray(idx, dtype=np.int64)
+        validity = None
+        if self.validity is not None:
+            validity = np.packbits(self.is_valid()[idx].astype(np.uint8), bitorder="little")
+        if self.geom_type == GEOM_POINT:
+            return GeoArrowArray(GEOM_POINT, self.xy[idx], validity=validity)
+
+        def gather(off, rows):  # children of `rows` under `off`: (new offsets, child indices)
+            lo, hi = off[rows].astype(np.int64), off[rows + 1].astype(np.int64)
+            n = hi - lo
+            new = np.zeros(len(rows) + 1, dtype=np.int64)
+            new[1:] = np.cumsum(n)
+            child = np.repeat(lo - new[:-1], n) + np.arange(int(new[-1]), dtype=np.int64)
+            return new.astype(np.int32), child
+
+        levels = [o for o in (self.geom_offsets, self.part_offsets, self.ring_offsets) if o is not None]
+        rows, new_levels = idx, []
+        for off in levels:
+            new, rows = gather(off, rows)
+            new_levels.append(new)
+        names = [k for k, o in zip(("geom_offsets", "part_offsets", "ring_offsets"), (self.geom_offsets, self.part_offsets, self.ring_offsets)) if o is not None]
+        return GeoArrowArray(self.geom_type, self.xy[rows], validity=validity, **dict(zip(names, new_levels)))
+
+    @staticmethod
+    def concat(arrays: Sequence["GeoArrowArray"]) -> "GeoArrowArray":
+        """Row-wise concatenation of arrays of one geometry type (offsets of piece k rebased by the child lengths before it)."""
+        a0 = arrays[0]
+        xy = np.concatenate([a.xy for a in arrays])
+        kw = {}
+        for name in ("geom_offsets", "part_offsets", "ring_offsets"):
+            if getattr(a0, name) is None:
+                continue
+            pieces, base = [], 0
+            for k, a in enumerate(arrays):
+                o = getattr(a, name).astype(np.int64)
+                pieces.append((o if k == 0 else o[1:]) + base)
+                base += int(o[-1])
+            kw[name] = np.concatenate(pieces).astype(np.int32)
+        validity = None
+        if any(a.validity is not None for a in arrays):
+            validity = np.packbits(np.concatenate([a.is_valid() for a in arrays]).astype(np.uint8), bitorder="little")
+        return GeoArrowArray(a0.geom_type, xy, validity=validity, **kw)
+
     # ---- export --------------------------------------------------------------------------------
     def to_wkb(self) -> tuple[np.ndarray, np.ndarray]:
         """-> (values uint8, offsets int32) of the WKB BinaryArray<i32> (from_geom_vec, util.rs:11-24), encoded on

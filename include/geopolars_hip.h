@@ -265,6 +265,13 @@ int32_t gpk_take_binary(const uint8_t* values, const int32_t* offsets, const uin
                         const int64_t* idx, int64_t n_idx, int32_t* out_offsets, uint8_t* out_values,
                         int64_t capacity, int64_t* n_bytes, uint8_t* out_validity, int32_t space, void* stream);
 
+/* ---- join statistics (bench.py's edge_tests/s) ---------------------------------- */
+/* While enabled, the point x polygonal join kernels count what their exact phase does (a few atomics per tile:
+ * leave it off in timed regions).  out = {(point, part) pairs sent to the exact winding walk, slab edges walked
+ * for them, 0, 0}, accumulated over the joins since the last reset; gpk_join_stats waits for the device. */
+int32_t gpk_join_stats_enable(int32_t on);
+int32_t gpk_join_stats(int64_t out[4], int32_t reset);
+
 /* ---- profiling hooks (bench.py's roofline leg) -------------------------------------------- */
 /* When enabled every kernel launch is bracketed by hipEvents on its stream. */
 int32_t gpk_profile_enable(int32_t on);

@@ -1,0 +1,119 @@
+"""GPU parity at configuration scale (BASELINE.json configs C2-C5, >= 1M rows on the sharded side): the HIP path through
+the C ABI against the CPU oracle on a RANDOM sample of rows (not a prefix) — the same sampled check bench.py gates its
+numbers with.  Sizes are the smallest that exercise what the full configurations exercise (grouped-distance schedule,
+segmented candidate lists, multi-hit pools, the lean and the general tile kernel) while the oracle still finishes in
+seconds on a sample."""
+import numpy as np
+import pytest
+
+from geopolars_amd import synth
+from geopolars_amd.geoarrow import GeoArrowArray
+from geopolars_amd.geoseries import GeoSeries
+from geopolars_amd.spatial_index import SpatialIndex, join_pairs
+
+pytestmark = pytest.mark.gpu
+
+
+def _sample(n, k, seed):
+    return np.sort(np.random.default_rng(seed).choice(n, size=min(n, k), replace=False)).astype(np.int64)
+
+
+def _pairs_of_rows(pairs, rows):
+    lo = np.searchsorted(pairs[:, 0], rows, side="left")
+    hi = np.searchsorted(pairs[:, 0], rows, side="right")
+    cnt = hi - lo
+    idx = np.repeat(lo - np.concatenate([[0], np.cumsum(cnt)[:-1]]), cnt) + np.arange(int(cnt.sum()))
+    out = pairs[idx].copy()
+    out[:, 0] = np.repeat(np.arange(len(rows), dtype=pairs.dtype), cnt)
+    return out
+
+
+def _check_join_sample(oracle, left, right, predicate, pairs, counts, k, seed):
+    idx = _sample(len(left), k, seed)
+    ep, ec, _ = oracle.spatial_join(left.take(idx), right, predicate, mode=1)
+    assert np.array_equal(counts[idx], ec)
+    assert np.array_equal(_pairs_of_rows(pairs, idx.astype(np.uint32)), ep)
+    assert int(counts.sum()) == len(pairs)
+    assert np.all(np.diff(pairs[:, 0].astype(np.int64)) >= 0)  # sorted by l ...
+    same = pairs[1:, 0] == pairs[:-1, 0]
+    assert np.all(pairs[1:, 1][same] > pairs[:-1, 1][same])  # ... then strictly by r
+
+
+def test_c2_scale_sampled(gpk, oracle):
+    """C2 at 4M points x 1000 x 64 (lean tile kernel: disjoint polygons), 200k random rows against the oracle."""
+    polys, pts = synth.star_polygons(1000, 64), synth.uniform_points(4_000_000, seed=101)
+    ps, qs = GeoSeries(pts), GeoSeries(polys)
+    pairs, counts = join_pairs(ps, qs, "intersects", r_index=SpatialIndex(qs))
+    _check_join_sample(oracle, pts, polys, "intersects", pairs, counts, 200_000, 7)
+
+
+def test_c2_scale_general_kernel_equals_lean(gpk, oracle):
+    """the same join through the general tile kernel (GPK_NO_LEAN is read once per process: use a right side the lean
+    kernel does not take — two overlapping copies of the polygons) equals the union of the single-copy answers"""
+    polys = synth.star_polygons(400, 32)
+    both = GeoArrowArray.concat([polys, polys])
+    pts = synth.uniform_points(1_000_000, seed=102)
+    p1, c1 = join_pairs(GeoSeries(pts), GeoSeries(polys), "contains")
+    p2, c2 = join_pairs(GeoSeries(pts), GeoSeries(both), "contains")
+    assert np.array_equal(c2, 2 * c1)
+    exp = np.concatenate([p1, p1 + np.array([0, 400], dtype=np.uint32)])
+    exp = exp[np.lexsort((exp[:, 1], exp[:, 0]))]
+    assert np.array_equal(p2, exp)
+
+
+@pytest.mark.parametrize("shuffled", [False, True])
+def test_c3_scale_sampled(gpk, oracle, shuffled):
+    """C3 at 2M points x 20k linestrings (100 rows per target: the grouped schedule; shuffled map: the radix grouping)."""
+    n, L = 2_000_000, 20_000
+    ls, pts = synth.random_linestrings(L), synth.uniform_points(n, seed=103)
+    rows = (np.arange(n, dtype=np.uint32) % L).astype(np.uint32)
+    if shuffled:
+        rows = np.random.default_rng(3).permutation(rows)
+    got = GeoSeries(pts).distance(GeoSeries(ls), other_rows=rows)
+    idx = _sample(n, 200_000, 8)
+    exp = oracle.distance_rowwise(pts.take(idx), ls, rows[idx])
+    g = got[idx]
+    rel = np.abs(g - exp) / np.maximum(np.abs(exp), 1e-300)
+    assert np.all((rel <= 1e-9) | (g == exp))  # tolerance of the north star: 1e-9 relative
+    assert np.array_equal(g == 0.0, exp == 0.0)
+
+
+def test_c3_out_of_range_row_map_entries_are_null_rows(gpk):
+    """b_rows entries >= n_geoms(b) behave like null rows (NaN), on the grouped and on the row-major schedule"""
+    ls, pts = synth.random_linestrings(50), synth.uniform_points(5000, seed=104)
+    for rows in ((np.arange(5000) % 50).astype(np.uint32), np.arange(5000, dtype=np.uint32) % 50):
+        rows = rows.copy()
+        bad = np.array([0, 17, 4999, 2500])
+        rows[bad] = [50, 1 << 31, 0xFFFFFFFF, 51]
+        got = GeoSeries(pts).distance(GeoSeries(ls), other_rows=rows)
+        assert np.all(np.isnan(got[bad]))
+        ok = np.ones(5000, dtype=bool)
+        ok[bad] = False
+        assert not np.any(np.isnan(got[ok]))
+    few = GeoSeries(synth.uniform_points(100, seed=105))  # fewer than 8 rows per target: the row-major kernel
+    rows = np.arange(100, dtype=np.uint32) % 50
+    rows[3] = 50
+    got = few.distance(GeoSeries(ls), other_rows=rows)
+    assert np.isnan(got[3]) and not np.any(np.isnan(np.delete(got, 3)))
+
+
+def test_c4_scale_sampled(gpk, oracle):
+    """C4 at full size: 1M x 1M polygons, index without the point tables, 100k random left rows against the oracle."""
+    left = synth.clustered_polygons(1_000_000, seed=41, mean_neighbours=4.0)
+    right = synth.clustered_polygons(1_000_000, seed=42, mean_neighbours=4.0)
+    ls, rs = GeoSeries(left), GeoSeries(right)
+    pairs, counts = join_pairs(ls, rs, "intersects", r_index=SpatialIndex(rs, for_points=False))
+    assert len(pairs) > 2_000_000
+    _check_join_sample(oracle, left, right, "intersects", pairs, counts, 100_000, 9)
+
+
+def test_c5_scale_sampled(gpk, oracle):
+    """C5 shape: 2M points within 600k power-law multipolygons (overlaps, holes, multi-hit rows) + area of all of them."""
+    mp = synth.powerlaw_multipolygons(600_000, seed=51)
+    pts = synth.uniform_points(2_000_000, seed=52)
+    ms, ps = GeoSeries(mp), GeoSeries(pts)
+    pairs, counts = join_pairs(ps, ms, "within", r_index=SpatialIndex(ms))
+    assert counts.max() >= 2
+    _check_join_sample(oracle, pts, mp, "within", pairs, counts, 200_000, 10)
+    area, exp = ms.area(), oracle.area(mp)
+    assert np.all(np.abs(area - exp) <= 1e-9 * np.maximum(np.abs(exp), 1e-300))
