@@ -681,7 +681,7 @@ def cpu_baseline_polyjoin(left_host, right_host, gpu_counts, target_s: float) ->
 def c5_chunk(k: int, rows: int):
     from geopolars_amd import synth
 
-    return synth.powerlaw_multipolygons(rows, seed=51 + k)
+    return synth.powerlaw_multipolygons(rows, seed=51 + k, size_n=rows * C5_CHUNKS)  # sized as part of ONE 5M-row column
 
 
 def run_c5(ctx: Ctx) -> None:

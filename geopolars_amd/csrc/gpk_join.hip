@@ -601,9 +601,24 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
 #ifndef GPK_LEAN_MINWAVES
 #define GPK_LEAN_MINWAVES 1
 #endif
+#ifndef GPK_LEAN_NT
+#define GPK_LEAN_NT 0  // 1: non-temporal point loads
+#endif
 constexpr int LEAN_PPT = GPK_LEAN_PPT, LEAN_TILE = PIP_BLOCK * LEAN_PPT, LEAN_QCAP = GPK_LEAN_QCAP;
 static_assert(PIP_WTILE % LEAN_TILE == 0, "a writer tile is a whole number of lean tiles");
-__global__ __launch_bounds__(PIP_BLOCK, GPK_LEAN_MINWAVES) void pip_tile_lean_kernel(DevGeo pts, DevGeo polys, PipView pv,
+// GPK_TILE_TRACE (diagnosis builds only): lane 0 of every 64th tile stamps the wall clock at the stage boundaries of the lean
+// kernel (after forcing the stage's loads to land) into the statistics buffer; tools/tile_trace.py prints the stage times.
+#ifdef GPK_TILE_TRACE
+#define TILE_STAMP(i)                                                                                              \
+    do {                                                                                                           \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                \
+        if (stats && tid == 0 && (blockIdx.x & 63) == 0 && (blockIdx.x >> 6) < 8000) stats[8 + (blockIdx.x >> 6) * 8 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define TILE_STAMP(i) do {} while (0)
+#endif
+constexpr uint32_t LEAN_SLOW = 1u << 30;  // QEntry::li_flags: a point of a list cell — one lane runs the generic walk for it
+__global__ __launch_bounds__(PIP_BLOCK, GPK_LEAN_MINWAVES) void pip_tile_lean_kernel(DevGeo pts, DevGeo polys, IndexView ix, PipView pv,
                                                                                     uint32_t* __restrict__ counts, uint32_t* __restrict__ code,
                                                                                     unsigned long long* __restrict__ block_tot,
                                                                                     unsigned long long* __restrict__ super_tot,
@@ -618,6 +633,7 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_LEAN_MINWAVES) void pip_tile_lean_ke
     const int64_t n = pts.n_geoms;
     const uint32_t rem = (uint32_t)(n - base < (int64_t)LEAN_TILE ? n - base : (int64_t)LEAN_TILE);
     const double2* __restrict__ tile_xy = pts.xy + base;
+    TILE_STAMP(0);
 
     // stage A: every point of the lane is requested before anything waits (coalesced 16-byte loads)
     double2 p[PPT];
@@ -625,13 +641,14 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_LEAN_MINWAVES) void pip_tile_lean_ke
     for (int k = 0; k < PPT; ++k) {
         const uint32_t t = (uint32_t)(k * PIP_BLOCK + tid);
         const bool ok = t < rem && dev::valid_row(pts.validity, base + t);
-        p[k] = ok ? tile_xy[t] : make_double2(NAN, NAN);
+        p[k] = ok ? (GPK_LEAN_NT ? dev::load_stream(tile_xy + t) : tile_xy[t]) : make_double2(NAN, NAN);
     }
     if (tid == 0) {
         q_n = 0;
         s_tot = 0;
     }
     __syncthreads();  // the loads above are in flight while the work-group meets here
+    TILE_STAMP(1);
 
     // stage B: level-1 words (one 4-byte gather per point; empty points read nothing)
     uint32_t sx[PPT], fyf[PPT], word[PPT];
@@ -642,6 +659,7 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_LEAN_MINWAVES) void pip_tile_lean_ke
         const uint32_t fy = fyf[k] >> FY_SUB;
         word[k] = (p[k].x == p[k].x && p[k].y == p[k].y) ? pv.cell[(fy / S) * (uint32_t)pv.R + (sx[k] / S)] : 0u;
     }
+    TILE_STAMP(2);
     // stage C: level-2 records of the cells an edge crosses (32 bytes: two 16-byte gathers off one line)
     uint4 ra[PPT], rb[PPT];
 #pragma unroll
@@ -653,11 +671,11 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_LEAN_MINWAVES) void pip_tile_lean_ke
             rb[k] = r[1];  // labels
         }
     }
+    TILE_STAMP(3);
     // stage D: decide, or mark for the exact walk
-    uint32_t res[PPT];   // part that contains the point, CODE_NONE, or (pending) PENDING | queue slot
+    uint32_t res[PPT];   // part that contains the point / CODE_NONE — or, while bit k of `pending` is set, its queue slot
     uint32_t qpart[PPT], qe0[PPT], qcnt[PPT];
     bool todo[PPT];
-    constexpr uint32_t PENDING = 0x80000000u;  // part ids stay below 2^30 (cell word payload)
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         const uint32_t tag = word[k] >> 30, payload = word[k] & 0x3FFFFFFFu;
@@ -680,12 +698,19 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_LEAN_MINWAVES) void pip_tile_lean_ke
                 qcnt[k] = (upper ? ra[k].w : ra[k].z) - qe0[k];
                 todo[k] = qcnt[k] > 0;  // an empty slab: p.y is outside the exterior's y-range
             }
+        } else if (tag == CELL_TAG_LIST) {  // the few cells where parts meet (a lean index has next to none): generic walk
+            qpart[k] = LEAN_SLOW;
+            todo[k] = true;
         }
     }
+    uint32_t slow_cnt[PPT];  // hit count of a list-cell point (its code then names a geometry, CODE_NONE or CODE_MULTI)
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) slow_cnt[k] = 0;
     // Rounds of (queue the marked points -> PIP_GS lanes per queued pair walk the slab's edges -> owners collect the
     // verdicts).  One round unless a tile holds more boundary points than the queue (then the rest goes next round).
     unsigned long long edges_walked = 0, pairs_walked = 0;
     const int glane = tid & (PIP_GS - 1);
+    uint32_t pending = 0;  // bit k: res[k] holds a queue slot whose verdict is still to be collected
     for (;;) {
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
@@ -697,17 +722,28 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_LEAN_MINWAVES) void pip_tile_lean_ke
                 wbase = __shfl(wbase, leader, 64);
                 const uint32_t slot = wbase + (uint32_t)__popcll(mask & ((1ull << lane64) - 1ull));
                 if (todo[k] && slot < (uint32_t)LEAN_QCAP) {
-                    q[slot] = QEntry{p[k].x, p[k].y, qpart[k] & 0x3FFFFFFFu, qe0[k], qcnt[k], qpart[k] & 0x80000000u};
-                    res[k] = PENDING | slot;
+                    q[slot] = QEntry{p[k].x, p[k].y, qpart[k] & 0x3FFFFFFFu, qe0[k], qcnt[k], qpart[k] & (0x80000000u | LEAN_SLOW)};
+                    res[k] = slot;
+                    pending |= 1u << k;
                     todo[k] = false;
                 }
             }
         }
         __syncthreads();
+        TILE_STAMP(4);
         const uint32_t queued = q_n;  // uniform: read after the barrier
         const uint32_t nq = queued < (uint32_t)LEAN_QCAP ? queued : (uint32_t)LEAN_QCAP;
         for (uint32_t e = tid / PIP_GS; e < nq; e += PIP_BLOCK / PIP_GS) {
             const QEntry en = q[e];
+            if (en.li_flags & LEAN_SLOW) {  // uniform within the group (one entry per group)
+                if (glane == 0) {
+                    uint32_t cnt, first;
+                    generic_point(polys, ix, en.px, en.py, cnt, first);
+                    q[e].part = cnt == 0 ? CODE_NONE : (cnt == 1 ? first : CODE_MULTI);
+                    q[e].cnt = cnt;
+                }
+                continue;
+            }
             const int pos = pip::part_pos_group_from_edges<PIP_GS>(pv, polys, (int)en.part, (en.li_flags >> 31) ? 2 : 1, (int)en.e0, (int)en.cnt,
                                                                    en.px, en.py, glane);
             if (glane == 0) {
@@ -716,10 +752,17 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_LEAN_MINWAVES) void pip_tile_lean_ke
                 ++pairs_walked;
             }
         }
+        TILE_STAMP(5);
         __syncthreads();
+        TILE_STAMP(6);
 #pragma unroll
         for (int k = 0; k < PPT; ++k)
-            if (res[k] != CODE_NONE && (res[k] & PENDING)) res[k] = q[res[k] & ~PENDING].part;
+            if (pending & (1u << k)) {
+                const uint32_t slot = res[k];
+                res[k] = q[slot].part;
+                if (qpart[k] == LEAN_SLOW) slow_cnt[k] = q[slot].cnt | 0x80000000u;  // top bit: "this point went the slow way"
+            }
+        pending = 0;
         if (queued <= (uint32_t)LEAN_QCAP) break;  // uniform
         __syncthreads();  // every owner has read its verdicts: the queue can be reused
         if (tid == 0) q_n = 0;
@@ -736,24 +779,261 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_LEAN_MINWAVES) void pip_tile_lean_ke
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         const uint32_t li = (uint32_t)(k * PIP_BLOCK + tid);
-        uint32_t r = res[k];
-        if (r != CODE_NONE) {
-            const uint32_t geom = pv.part_geom ? pv.part_geom[r] : r;
-            r = dev::valid_row(polys.validity, geom) ? geom : CODE_NONE;
+        uint32_t r = res[k], cnt;
+        if (slow_cnt[k]) {  // list-cell point: the generic walk already speaks in geometries (validity included)
+            cnt = slow_cnt[k] & 0x7FFFFFFFu;
+        } else {
+            if (r != CODE_NONE) {
+                const uint32_t geom = pv.part_geom ? pv.part_geom[r] : r;
+                r = dev::valid_row(polys.validity, geom) ? geom : CODE_NONE;
+            }
+            cnt = r != CODE_NONE ? 1u : 0u;
         }
-        const uint32_t cnt = r != CODE_NONE ? 1u : 0u;
         if (li < rem) {
             if (tile_counts) dev::store_stream(tile_counts + li, cnt);
             dev::store_stream(tile_code + li, r);
         }
-        wave_hits += (unsigned long long)__popcll(__ballot(li < rem && cnt));
+        wave_hits += (unsigned long long)__popcll(__ballot(li < rem && cnt == 1u));
+        if (li < rem && cnt >= 2u) atomicAdd(&s_tot, (unsigned long long)cnt);
     }
     if (lane64 == 0 && wave_hits) atomicAdd(&s_tot, wave_hits);
+    TILE_STAMP(7);
     __syncthreads();
     if (tid == 0) {
         const unsigned long long tot = s_tot;
         block_tot[blockIdx.x] = tot;
         if (tot) atomicAdd(&super_tot[blockIdx.x >> PIP_SUPER_SHIFT], tot);
+    }
+}
+
+// ---- pip_tile_route: the lean tile step with the level-1 routing ON CHIP ------------------------------------------------
+// For small rasters (PipView::route: R <= 512, i.e. right sides up to ~65k coordinates — the 1k x 64-vertex headline) the
+// level-1 answer of a point is two bits: "nothing here" / "a record" / "something else".  Those bit planes (2 x 32 KB) and
+// the record ranks (18 KB) live in LDS, loaded once by a PERSISTENT work-group that then walks tiles of points:
+//   empty cell (about half of the points)  -> decided from LDS, no memory request at all;
+//   record cell                            -> the record's index is a rank computed from LDS (row base + word rank +
+//                                             popcount): ONE 32-byte gather instead of a 4-byte gather then the record;
+//   anything else (interiors, list cells)  -> the level-1 word from global memory, as before.
+// Every 4-byte gather costs a 64-byte L2 request, and the L2 -> L1 request rate is what bounds this join: this
+// removes ~45 % of the requests.  The next tile's points are requested before the exact phase of the current one starts.
+#ifndef GPK_ROUTE_BLOCK
+#define GPK_ROUTE_BLOCK 1024
+#endif
+#ifndef GPK_ROUTE_PPT
+#define GPK_ROUTE_PPT 2
+#endif
+#ifndef GPK_ROUTE_QCAP
+#define GPK_ROUTE_QCAP 128
+#endif
+#ifndef GPK_ROUTE_MINWAVES
+#define GPK_ROUTE_MINWAVES 8  // two 1024-lane work-groups per CU = 8 waves per SIMD: at most 64 VGPRs
+#endif
+#ifndef GPK_ROUTE_WGS_PER_CU
+#define GPK_ROUTE_WGS_PER_CU 2
+#endif
+constexpr int ROUTE_BLOCK = GPK_ROUTE_BLOCK, ROUTE_PPT = GPK_ROUTE_PPT, ROUTE_TILE = ROUTE_BLOCK * ROUTE_PPT, ROUTE_QCAP = GPK_ROUTE_QCAP;
+static_assert(PIP_WTILE % ROUTE_TILE == 0, "a writer tile is a whole number of route tiles");
+constexpr int ROUTE_LDS_WORDS = 2 * (PIP_ROUTE_RMAX * PIP_ROUTE_RMAX / 32) + PIP_ROUTE_RMAX + (PIP_ROUTE_RMAX * PIP_ROUTE_RMAX / 64 + 1) / 2;
+__global__ __launch_bounds__(ROUTE_BLOCK, GPK_ROUTE_MINWAVES) void pip_tile_route_kernel(DevGeo pts, DevGeo polys, IndexView ix, PipView pv, int64_t n_tiles,
+                                                                     uint32_t* __restrict__ counts, uint32_t* __restrict__ code,
+                                                                     unsigned long long* __restrict__ block_tot,
+                                                                     unsigned long long* __restrict__ super_tot,
+                                                                     unsigned long long* __restrict__ stats) {
+    constexpr int PPT = ROUTE_PPT, S = PIP_SUB, FINE = PIP_SLAB_MUL << PIP_FINE_LOG2, FY_SUB = PIP_FINE_LOG2 - 2;
+    __shared__ uint32_t s_route[ROUTE_LDS_WORDS];
+    __shared__ QEntry q[ROUTE_QCAP];
+    __shared__ uint32_t q_n;
+    __shared__ unsigned long long s_tot;
+    const int tid = threadIdx.x, lane64 = tid & 63;
+    const int R = pv.R, W = R * R / 32, wpr = R / 32;
+    const int64_t n = pts.n_geoms;
+    {  // routing tables -> LDS, once per work-group (coalesced 16-byte loads; the planes stay L2-resident for the other groups)
+        const int words = route_words(R);
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(pv.route);
+        uint4* dst = reinterpret_cast<uint4*>(s_route);
+        for (int i = tid; i < words / 4; i += ROUTE_BLOCK) dst[i] = src[i];
+        for (int i = (words / 4) * 4 + tid; i < words; i += ROUTE_BLOCK) s_route[i] = pv.route[i];
+    }
+    const uint32_t* sN = s_route;
+    const uint32_t* sS = s_route + W;
+    const uint32_t* sRow = s_route + 2 * W;
+    const uint16_t* sRank = reinterpret_cast<const uint16_t*>(s_route + 2 * W + R);
+    const int glane = tid & (PIP_GS - 1);
+
+    auto load_tile = [&](int64_t tile, double2 (&p)[PPT]) {
+        const int64_t base = tile * ROUTE_TILE;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int64_t i = base + k * ROUTE_BLOCK + tid;
+            const bool ok = tile < n_tiles && i < n && dev::valid_row(pts.validity, i);
+            p[k] = ok ? pts.xy[i] : make_double2(NAN, NAN);
+        }
+    };
+    double2 p[PPT], p_next[PPT];
+    load_tile((int64_t)blockIdx.x, p);
+    __syncthreads();  // tables in LDS
+
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t base = tile * ROUTE_TILE;
+        const uint32_t rem = (uint32_t)(n - base < (int64_t)ROUTE_TILE ? n - base : (int64_t)ROUTE_TILE);
+        if (tid == 0) {
+            q_n = 0;
+            s_tot = 0;
+        }
+        // stage B: route every point on chip; request what it needs next (a record, or the level-1 word)
+        uint32_t sx[PPT], fyf[PPT], word[PPT];
+        uint4 ra[PPT], rb[PPT];
+        bool has_rec[PPT];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            sx[k] = (uint32_t)dev::cell_of(p[k].x, pv.rx0, pv.inv_fw * S, R * S);
+            fyf[k] = (uint32_t)dev::cell_of(p[k].y, pv.ry0, pv.inv_fh * FINE, R * FINE);
+            const uint32_t cx = sx[k] / S, cy = (fyf[k] >> FY_SUB) / S;
+            const uint32_t w = cy * (uint32_t)wpr + (cx >> 5), bit = cx & 31u;
+            const bool here = (p[k].x == p[k].x && p[k].y == p[k].y) && ((sN[w] >> bit) & 1u);
+            const uint32_t sw = sS[w];
+            has_rec[k] = here && ((sw >> bit) & 1u);
+            word[k] = 0u;  // empty
+            ra[k] = rb[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (has_rec[k]) {
+                const uint32_t rec = sRow[cy] + (uint32_t)sRank[w >> 1] + ((w & 1u) ? (uint32_t)__popc(sS[w - 1]) : 0u) + (uint32_t)__popc(sw & ((1u << bit) - 1u));
+                const uint4* __restrict__ r = reinterpret_cast<const uint4*>(pv.sub + rec);
+                ra[k] = r[0];
+                rb[k] = r[1];
+            } else if (here) {
+                word[k] = pv.cell[cy * (uint32_t)R + cx];
+            }
+        }
+        // stage D: decide, or mark for the exact walk
+        uint32_t res[PPT], qpart[PPT], qe0[PPT], qcnt[PPT], slow_cnt[PPT];
+        bool todo[PPT];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const uint32_t tag = word[k] >> 30, payload = word[k] & 0x3FFFFFFFu;
+            res[k] = CODE_NONE;
+            todo[k] = false;
+            slow_cnt[k] = 0;
+            qpart[k] = ra[k].x;
+            qe0[k] = qcnt[k] = 0;
+            if (has_rec[k]) {
+                const uint32_t fy = fyf[k] >> FY_SUB;
+                const int idx = (int)((fy % S) * S + (sx[k] % S));
+                const int wsel = idx >> 4;
+                const uint32_t lw = wsel == 0 ? rb[k].x : (wsel == 1 ? rb[k].y : (wsel == 2 ? rb[k].z : rb[k].w));
+                const uint32_t lab = (lw >> (2 * (idx & 15))) & 3u;
+                if (lab == 1u) res[k] = ra[k].x & 0x3FFFFFFFu;
+                if (lab == 2u) {
+                    const bool upper = ((fyf[k] >> PIP_FINE_LOG2) & 1u) != 0;
+                    qe0[k] = upper ? ra[k].z : ra[k].y;
+                    qcnt[k] = (upper ? ra[k].w : ra[k].z) - qe0[k];
+                    todo[k] = qcnt[k] > 0;
+                }
+            } else if (tag == CELL_TAG_SINGLE && !(payload & 1u)) {
+                res[k] = payload >> 1;
+            } else if (word[k] != 0u) {  // list cells and anything unexpected: the generic walk decides
+                qpart[k] = LEAN_SLOW;
+                todo[k] = true;
+            }
+        }
+        __syncthreads();  // q_n = 0 visible; everybody is past the previous tile's finalize
+        unsigned long long edges_walked = 0, pairs_walked = 0;
+        bool first_round = true;
+        uint32_t pending = 0;  // bit k: res[k] holds a queue slot whose verdict is still to be collected
+        for (;;) {
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const unsigned long long mask = __ballot(todo[k]);
+                if (mask) {
+                    uint32_t wbase = 0;
+                    const int leader = __ffsll((long long)mask) - 1;
+                    if (lane64 == leader) wbase = atomicAdd(&q_n, (uint32_t)__popcll(mask));
+                    wbase = __shfl(wbase, leader, 64);
+                    const uint32_t slot = wbase + (uint32_t)__popcll(mask & ((1ull << lane64) - 1ull));
+                    if (todo[k] && slot < (uint32_t)ROUTE_QCAP) {
+                        q[slot] = QEntry{p[k].x, p[k].y, qpart[k] & 0x3FFFFFFFu, qe0[k], qcnt[k], qpart[k] & (0x80000000u | LEAN_SLOW)};
+                        res[k] = slot;
+                        pending |= 1u << k;
+                        todo[k] = false;
+                    }
+                }
+            }
+            if (first_round) {  // the next tile's points travel while this tile's exact phase runs
+                load_tile(tile + gridDim.x, p_next);
+                first_round = false;
+            }
+            __syncthreads();
+            const uint32_t queued = q_n;
+            const uint32_t nq = queued < (uint32_t)ROUTE_QCAP ? queued : (uint32_t)ROUTE_QCAP;
+            for (uint32_t e = tid / PIP_GS; e < nq; e += ROUTE_BLOCK / PIP_GS) {
+                const QEntry en = q[e];
+                if (en.li_flags & LEAN_SLOW) {
+                    if (glane == 0) {
+                        uint32_t cnt, first;
+                        generic_point(polys, ix, en.px, en.py, cnt, first);
+                        q[e].part = cnt == 0 ? CODE_NONE : (cnt == 1 ? first : CODE_MULTI);
+                        q[e].cnt = cnt;
+                    }
+                    continue;
+                }
+                const int pos = pip::part_pos_group_from_edges<PIP_GS>(pv, polys, (int)en.part, (en.li_flags >> 31) ? 2 : 1, (int)en.e0,
+                                                                       (int)en.cnt, en.px, en.py, glane);
+                if (glane == 0) {
+                    q[e].part = pos == dev::POS_INSIDE ? en.part : CODE_NONE;
+                    edges_walked += en.cnt;
+                    ++pairs_walked;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < PPT; ++k)
+                if (pending & (1u << k)) {
+                    const uint32_t slot = res[k];
+                    res[k] = q[slot].part;
+                    if (qpart[k] == LEAN_SLOW) slow_cnt[k] = q[slot].cnt | 0x80000000u;
+                }
+            pending = 0;
+            if (queued <= (uint32_t)ROUTE_QCAP) break;
+            __syncthreads();
+            if (tid == 0) q_n = 0;
+            __syncthreads();
+        }
+        if (stats && pairs_walked) {
+            atomicAdd(&stats[0], pairs_walked);
+            atomicAdd(&stats[1], edges_walked);
+        }
+        // finalize
+        uint32_t* __restrict__ tile_counts = counts ? counts + base : nullptr;
+        uint32_t* __restrict__ tile_code = code + base;
+        unsigned long long wave_hits = 0;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const uint32_t li = (uint32_t)(k * ROUTE_BLOCK + tid);
+            uint32_t r = res[k], cnt;
+            if (slow_cnt[k]) {
+                cnt = slow_cnt[k] & 0x7FFFFFFFu;
+            } else {
+                if (r != CODE_NONE) {
+                    const uint32_t geom = pv.part_geom ? pv.part_geom[r] : r;
+                    r = dev::valid_row(polys.validity, geom) ? geom : CODE_NONE;
+                }
+                cnt = r != CODE_NONE ? 1u : 0u;
+            }
+            if (li < rem) {
+                if (tile_counts) dev::store_stream(tile_counts + li, cnt);
+                dev::store_stream(tile_code + li, r);
+            }
+            wave_hits += (unsigned long long)__popcll(__ballot(li < rem && cnt == 1u));
+            if (li < rem && cnt >= 2u) atomicAdd(&s_tot, (unsigned long long)cnt);
+        }
+        if (lane64 == 0 && wave_hits) atomicAdd(&s_tot, wave_hits);
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned long long tot = s_tot;
+            block_tot[tile] = tot;
+            if (tot) atomicAdd(&super_tot[tile >> PIP_SUPER_SHIFT], tot);
+        }
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) p[k] = p_next[k];
     }
 }
 
@@ -852,6 +1132,11 @@ __global__ __launch_bounds__(WR_BLOCK) void pip_write_kernel(DevGeo pts, DevGeo 
 }
 
 // ---- join statistics (bench.py's edge_tests/s; off unless enabled) ---------------------------------------------------
+#ifdef GPK_TILE_TRACE
+constexpr size_t JOIN_STATS_WORDS = 8 + 8 * 8000;  // + the stage stamps of up to 8000 sampled tiles
+#else
+constexpr size_t JOIN_STATS_WORDS = 4;
+#endif
 static unsigned long long* g_join_stats = nullptr;  // device: {queued (point, part) pairs, slab edges walked by the exact phase, 0, 0}
 static bool g_join_stats_on = false;
 static unsigned long long* join_stats_buffer() { return g_join_stats_on ? g_join_stats : nullptr; }
@@ -1159,7 +1444,12 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         return e && *e && *e != '0';
     }();
     const bool lean = right_index->pip.R > 0 && right_index->pip_lean && !no_lean;
-    const int tile_points = lean ? LEAN_TILE : PIP_TILE;
+    static const bool no_route = [] {  // GPK_NO_ROUTE=1: A/B runs of the lean kernel on an index that has routing planes
+        const char* e = getenv("GPK_NO_ROUTE");
+        return e && *e && *e != '0';
+    }();
+    const bool route = lean && right_index->pip.route && !no_route;
+    const int tile_points = route ? ROUTE_TILE : (lean ? LEAN_TILE : PIP_TILE);
     const int64_t n_blocks = (n + tile_points - 1) / tile_points;
     const bool want_pairs = pair_capacity > 0;
     const size_t counts_bytes = sizeof(uint32_t) * (size_t)n;
@@ -1198,8 +1488,13 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         if (me != hipSuccess) return fail(GPK_ERR_DEVICE, "spatial_join: %s", hipGetErrorString(me));
     }
     unsigned long long* stats = join_stats_buffer();  // nullptr unless gpk_join_stats_enable(1)
-    if (lean)
-        J_LAUNCH("gpk_pip_tile", pip_tile_lean_kernel, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d, right_index->pip,
+    if (route) {  // persistent work-groups: one per CU (the routing planes take most of a CU's LDS)
+        int64_t wgs = (int64_t)cu_count() * GPK_ROUTE_WGS_PER_CU;
+        if (wgs > n_blocks) wgs = n_blocks;
+        J_LAUNCH("gpk_pip_tile", pip_tile_route_kernel, dim3((unsigned)wgs), dim3(ROUTE_BLOCK), 0, s, left->d, right->d, right_index->v,
+                 right_index->pip, n_blocks, counts_dev, code, btot, stot, stats);
+    } else if (lean)
+        J_LAUNCH("gpk_pip_tile", pip_tile_lean_kernel, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d, right_index->v, right_index->pip,
                  counts_dev, code, btot, stot, stats);
     else if (right_index->pip.R > 0)
         if (right_index->pip.sub2)
@@ -1331,8 +1626,8 @@ extern "C" {
 int32_t gpk_join_stats_enable(int32_t on) {
     if (on && !g_join_stats) {
         GPK_TRY(require_device());
-        GPK_HIP(hipMalloc((void**)&g_join_stats, 4 * sizeof(unsigned long long)));
-        GPK_HIP(hipMemset(g_join_stats, 0, 4 * sizeof(unsigned long long)));
+        GPK_HIP(hipMalloc((void**)&g_join_stats, JOIN_STATS_WORDS * sizeof(unsigned long long)));
+        GPK_HIP(hipMemset(g_join_stats, 0, JOIN_STATS_WORDS * sizeof(unsigned long long)));
     }
     g_join_stats_on = on != 0;
     return GPK_OK;
@@ -1350,9 +1645,19 @@ int32_t gpk_join_stats(int64_t out[4], int32_t reset) {
     return GPK_OK;
 }
 
+#ifdef GPK_TILE_TRACE
+int32_t gpk_join_trace(unsigned long long* out, int64_t n_words) {  // diagnosis builds only: the raw stage stamps
+    if (!g_join_stats || !out) return GPK_ERR_INVALID_ARGUMENT;
+    GPK_HIP(hipDeviceSynchronize());
+    GPK_HIP(hipMemcpy(out, g_join_stats + 8, sizeof(unsigned long long) * (size_t)(n_words < (int64_t)(JOIN_STATS_WORDS - 8) ? n_words : (int64_t)(JOIN_STATS_WORDS - 8)), hipMemcpyDeviceToHost));
+    GPK_HIP(hipMemset(g_join_stats, 0, JOIN_STATS_WORDS * sizeof(unsigned long long)));
+    return GPK_OK;
+}
+#endif
+
 int32_t gpk_index_free(gpk_index* idx) {
     if (!idx) return GPK_OK;
-    for (int i = 0; i < 16; ++i)
+    for (int i = 0; i < 24; ++i)
         if (idx->owned[i]) (void)hipFree(idx->owned[i]);
     delete idx;
     return GPK_OK;

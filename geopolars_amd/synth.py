@@ -114,9 +114,11 @@ def clustered_polygons(n: int, seed: int = SEED + 4, domain: float = DOMAIN, min
     return GeoArrowArray(GEOM_POLYGON, xy, geom_offsets=np.arange(n + 1, dtype=np.int32), ring_offsets=ring_off.astype(np.int32))
 
 
-def powerlaw_multipolygons(n: int, seed: int = SEED + 5, domain: float = DOMAIN, alpha: float = 1.5, min_verts: int = 4, cap: int = 100_000, max_parts: int = 3, hole_prob: float = 0.15) -> GeoArrowArray:
+def powerlaw_multipolygons(n: int, seed: int = SEED + 5, domain: float = DOMAIN, alpha: float = 1.5, min_verts: int = 4, cap: int = 100_000, max_parts: int = 3, hole_prob: float = 0.15, size_n: int | None = None) -> GeoArrowArray:
     """C5 right side: multipolygons whose ring vertex counts follow Pareto(alpha) (min 4, capped), 1-3
-    member polygons each, some with one hole (a scaled copy of the exterior, CW)."""
+    member polygons each, some with one hole (a scaled copy of the exterior, CW).  Member radii scale with
+    domain / sqrt(size_n) (default n): a column generated in chunks passes the column's total row count, so that the
+    chunks together cover the domain like one column of that size."""
     rng = np.random.default_rng(seed)
     n_parts = rng.integers(1, max_parts + 1, n)
     geom_off = np.zeros(n + 1, dtype=np.int64)
@@ -139,7 +141,7 @@ def powerlaw_multipolygons(n: int, seed: int = SEED + 5, domain: float = DOMAIN,
     gx, gy = rng.uniform(0.0, domain, n), rng.uniform(0.0, domain, n)
     # parts of one multipolygon sit side by side so they do not overlap
     k_in_geom = np.arange(P) - np.repeat(geom_off[:-1], n_parts)
-    base_r = rng.uniform(0.2, 1.0, P) * domain / np.sqrt(max(n, 1)) * 0.5
+    base_r = rng.uniform(0.2, 1.0, P) * domain / np.sqrt(max(size_n or n, 1)) * 0.5
     pcx = gx[gid_part] + k_in_geom * 2.2 * base_r
     pcy = gy[gid_part]
     rid = np.repeat(np.arange(R), nv_ring + 1)
