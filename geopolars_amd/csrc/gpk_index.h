@@ -89,18 +89,7 @@ struct PipView {
     const int32_t* ring_slab_base;   // n_rings + 1
     const int32_t* slab_off;         // n_slabs + 1
     const double4* slab_edges;
-    // Routing bit planes of a SMALL raster (R <= PIP_ROUTE_RMAX, lean indexes only; nullptr otherwise): what the
-    // LDS-resident tile kernel keeps on chip instead of gathering a level-1 word per point.  One buffer of 32-bit words:
-    //   [0, W)            plane N: bit c & 31 of word c >> 5 = cell c is not empty                      (W = R * R / 32)
-    //   [W, 2W)           plane S: cell c carries a one-part level-2 record (CELL_TAG_SUB without SUB2_BIT)
-    //   [2W, 2W + R)      row_base[cj]: records of the rows before cj
-    //   [2W + R, ...)     rank16[w / 2] (two per word): records of row cj before the PAIR of words that holds word w
-    // record index of an S cell = row_base[cj] + rank16[w / 2] + (w odd: popcount(S[w - 1])) + popcount(S[w] & bits below c):
-    // pv.sub is in cell order.
-    const uint32_t* route;
 };
-constexpr int PIP_ROUTE_RMAX = 512;  // 2 x 32 KB planes + 10 KB ranks: two work-groups per CU keep them in LDS next to their queues
-__host__ __device__ inline int route_words(int R) { return 2 * (R * R / 32) + R + (R * R / 64 + 1) / 2; }
 constexpr uint32_t CELL_TAG_EMPTY = 0u, CELL_TAG_SINGLE = 1u, CELL_TAG_LIST = 2u, CELL_TAG_SUB = 3u;
 
 namespace dev {

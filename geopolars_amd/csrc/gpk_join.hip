@@ -806,237 +806,6 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_LEAN_MINWAVES) void pip_tile_lean_ke
     }
 }
 
-// ---- pip_tile_route: the lean tile step with the level-1 routing ON CHIP ------------------------------------------------
-// For small rasters (PipView::route: R <= 512, i.e. right sides up to ~65k coordinates — the 1k x 64-vertex headline) the
-// level-1 answer of a point is two bits: "nothing here" / "a record" / "something else".  Those bit planes (2 x 32 KB) and
-// the record ranks (18 KB) live in LDS, loaded once by a PERSISTENT work-group that then walks tiles of points:
-//   empty cell (about half of the points)  -> decided from LDS, no memory request at all;
-//   record cell                            -> the record's index is a rank computed from LDS (row base + word rank +
-//                                             popcount): ONE 32-byte gather instead of a 4-byte gather then the record;
-//   anything else (interiors, list cells)  -> the level-1 word from global memory, as before.
-// Every 4-byte gather costs a 64-byte L2 request, and the L2 -> L1 request rate is what bounds this join: this
-// removes ~45 % of the requests.  The next tile's points are requested before the exact phase of the current one starts.
-#ifndef GPK_ROUTE_BLOCK
-#define GPK_ROUTE_BLOCK 1024
-#endif
-#ifndef GPK_ROUTE_PPT
-#define GPK_ROUTE_PPT 2
-#endif
-#ifndef GPK_ROUTE_QCAP
-#define GPK_ROUTE_QCAP 128
-#endif
-#ifndef GPK_ROUTE_MINWAVES
-#define GPK_ROUTE_MINWAVES 8  // two 1024-lane work-groups per CU = 8 waves per SIMD: at most 64 VGPRs
-#endif
-#ifndef GPK_ROUTE_WGS_PER_CU
-#define GPK_ROUTE_WGS_PER_CU 2
-#endif
-constexpr int ROUTE_BLOCK = GPK_ROUTE_BLOCK, ROUTE_PPT = GPK_ROUTE_PPT, ROUTE_TILE = ROUTE_BLOCK * ROUTE_PPT, ROUTE_QCAP = GPK_ROUTE_QCAP;
-static_assert(PIP_WTILE % ROUTE_TILE == 0, "a writer tile is a whole number of route tiles");
-constexpr int ROUTE_LDS_WORDS = 2 * (PIP_ROUTE_RMAX * PIP_ROUTE_RMAX / 32) + PIP_ROUTE_RMAX + (PIP_ROUTE_RMAX * PIP_ROUTE_RMAX / 64 + 1) / 2;
-__global__ __launch_bounds__(ROUTE_BLOCK, GPK_ROUTE_MINWAVES) void pip_tile_route_kernel(DevGeo pts, DevGeo polys, IndexView ix, PipView pv, int64_t n_tiles,
-                                                                     uint32_t* __restrict__ counts, uint32_t* __restrict__ code,
-                                                                     unsigned long long* __restrict__ block_tot,
-                                                                     unsigned long long* __restrict__ super_tot,
-                                                                     unsigned long long* __restrict__ stats) {
-    constexpr int PPT = ROUTE_PPT, S = PIP_SUB, FINE = PIP_SLAB_MUL << PIP_FINE_LOG2, FY_SUB = PIP_FINE_LOG2 - 2;
-    __shared__ uint32_t s_route[ROUTE_LDS_WORDS];
-    __shared__ QEntry q[ROUTE_QCAP];
-    __shared__ uint32_t q_n;
-    __shared__ unsigned long long s_tot;
-    const int tid = threadIdx.x, lane64 = tid & 63;
-    const int R = pv.R, W = R * R / 32, wpr = R / 32;
-    const int64_t n = pts.n_geoms;
-    {  // routing tables -> LDS, once per work-group (coalesced 16-byte loads; the planes stay L2-resident for the other groups)
-        const int words = route_words(R);
-        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(pv.route);
-        uint4* dst = reinterpret_cast<uint4*>(s_route);
-        for (int i = tid; i < words / 4; i += ROUTE_BLOCK) dst[i] = src[i];
-        for (int i = (words / 4) * 4 + tid; i < words; i += ROUTE_BLOCK) s_route[i] = pv.route[i];
-    }
-    const uint32_t* sN = s_route;
-    const uint32_t* sS = s_route + W;
-    const uint32_t* sRow = s_route + 2 * W;
-    const uint16_t* sRank = reinterpret_cast<const uint16_t*>(s_route + 2 * W + R);
-    const int glane = tid & (PIP_GS - 1);
-
-    auto load_tile = [&](int64_t tile, double2 (&p)[PPT]) {
-        const int64_t base = tile * ROUTE_TILE;
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int64_t i = base + k * ROUTE_BLOCK + tid;
-            const bool ok = tile < n_tiles && i < n && dev::valid_row(pts.validity, i);
-            p[k] = ok ? pts.xy[i] : make_double2(NAN, NAN);
-        }
-    };
-    double2 p[PPT], p_next[PPT];
-    load_tile((int64_t)blockIdx.x, p);
-    __syncthreads();  // tables in LDS
-
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t base = tile * ROUTE_TILE;
-        const uint32_t rem = (uint32_t)(n - base < (int64_t)ROUTE_TILE ? n - base : (int64_t)ROUTE_TILE);
-        if (tid == 0) {
-            q_n = 0;
-            s_tot = 0;
-        }
-        // stage B: route every point on chip; request what it needs next (a record, or the level-1 word)
-        uint32_t sx[PPT], fyf[PPT], word[PPT];
-        uint4 ra[PPT], rb[PPT];
-        bool has_rec[PPT];
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            sx[k] = (uint32_t)dev::cell_of(p[k].x, pv.rx0, pv.inv_fw * S, R * S);
-            fyf[k] = (uint32_t)dev::cell_of(p[k].y, pv.ry0, pv.inv_fh * FINE, R * FINE);
-            const uint32_t cx = sx[k] / S, cy = (fyf[k] >> FY_SUB) / S;
-            const uint32_t w = cy * (uint32_t)wpr + (cx >> 5), bit = cx & 31u;
-            const bool here = (p[k].x == p[k].x && p[k].y == p[k].y) && ((sN[w] >> bit) & 1u);
-            const uint32_t sw = sS[w];
-            has_rec[k] = here && ((sw >> bit) & 1u);
-            word[k] = 0u;  // empty
-            ra[k] = rb[k] = make_uint4(0u, 0u, 0u, 0u);
-            if (has_rec[k]) {
-                const uint32_t rec = sRow[cy] + (uint32_t)sRank[w >> 1] + ((w & 1u) ? (uint32_t)__popc(sS[w - 1]) : 0u) + (uint32_t)__popc(sw & ((1u << bit) - 1u));
-                const uint4* __restrict__ r = reinterpret_cast<const uint4*>(pv.sub + rec);
-                ra[k] = r[0];
-                rb[k] = r[1];
-            } else if (here) {
-                word[k] = pv.cell[cy * (uint32_t)R + cx];
-            }
-        }
-        // stage D: decide, or mark for the exact walk
-        uint32_t res[PPT], qpart[PPT], qe0[PPT], qcnt[PPT], slow_cnt[PPT];
-        bool todo[PPT];
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const uint32_t tag = word[k] >> 30, payload = word[k] & 0x3FFFFFFFu;
-            res[k] = CODE_NONE;
-            todo[k] = false;
-            slow_cnt[k] = 0;
-            qpart[k] = ra[k].x;
-            qe0[k] = qcnt[k] = 0;
-            if (has_rec[k]) {
-                const uint32_t fy = fyf[k] >> FY_SUB;
-                const int idx = (int)((fy % S) * S + (sx[k] % S));
-                const int wsel = idx >> 4;
-                const uint32_t lw = wsel == 0 ? rb[k].x : (wsel == 1 ? rb[k].y : (wsel == 2 ? rb[k].z : rb[k].w));
-                const uint32_t lab = (lw >> (2 * (idx & 15))) & 3u;
-                if (lab == 1u) res[k] = ra[k].x & 0x3FFFFFFFu;
-                if (lab == 2u) {
-                    const bool upper = ((fyf[k] >> PIP_FINE_LOG2) & 1u) != 0;
-                    qe0[k] = upper ? ra[k].z : ra[k].y;
-                    qcnt[k] = (upper ? ra[k].w : ra[k].z) - qe0[k];
-                    todo[k] = qcnt[k] > 0;
-                }
-            } else if (tag == CELL_TAG_SINGLE && !(payload & 1u)) {
-                res[k] = payload >> 1;
-            } else if (word[k] != 0u) {  // list cells and anything unexpected: the generic walk decides
-                qpart[k] = LEAN_SLOW;
-                todo[k] = true;
-            }
-        }
-        __syncthreads();  // q_n = 0 visible; everybody is past the previous tile's finalize
-        unsigned long long edges_walked = 0, pairs_walked = 0;
-        bool first_round = true;
-        uint32_t pending = 0;  // bit k: res[k] holds a queue slot whose verdict is still to be collected
-        for (;;) {
-#pragma unroll
-            for (int k = 0; k < PPT; ++k) {
-                const unsigned long long mask = __ballot(todo[k]);
-                if (mask) {
-                    uint32_t wbase = 0;
-                    const int leader = __ffsll((long long)mask) - 1;
-                    if (lane64 == leader) wbase = atomicAdd(&q_n, (uint32_t)__popcll(mask));
-                    wbase = __shfl(wbase, leader, 64);
-                    const uint32_t slot = wbase + (uint32_t)__popcll(mask & ((1ull << lane64) - 1ull));
-                    if (todo[k] && slot < (uint32_t)ROUTE_QCAP) {
-                        q[slot] = QEntry{p[k].x, p[k].y, qpart[k] & 0x3FFFFFFFu, qe0[k], qcnt[k], qpart[k] & (0x80000000u | LEAN_SLOW)};
-                        res[k] = slot;
-                        pending |= 1u << k;
-                        todo[k] = false;
-                    }
-                }
-            }
-            if (first_round) {  // the next tile's points travel while this tile's exact phase runs
-                load_tile(tile + gridDim.x, p_next);
-                first_round = false;
-            }
-            __syncthreads();
-            const uint32_t queued = q_n;
-            const uint32_t nq = queued < (uint32_t)ROUTE_QCAP ? queued : (uint32_t)ROUTE_QCAP;
-            for (uint32_t e = tid / PIP_GS; e < nq; e += ROUTE_BLOCK / PIP_GS) {
-                const QEntry en = q[e];
-                if (en.li_flags & LEAN_SLOW) {
-                    if (glane == 0) {
-                        uint32_t cnt, first;
-                        generic_point(polys, ix, en.px, en.py, cnt, first);
-                        q[e].part = cnt == 0 ? CODE_NONE : (cnt == 1 ? first : CODE_MULTI);
-                        q[e].cnt = cnt;
-                    }
-                    continue;
-                }
-                const int pos = pip::part_pos_group_from_edges<PIP_GS>(pv, polys, (int)en.part, (en.li_flags >> 31) ? 2 : 1, (int)en.e0,
-                                                                       (int)en.cnt, en.px, en.py, glane);
-                if (glane == 0) {
-                    q[e].part = pos == dev::POS_INSIDE ? en.part : CODE_NONE;
-                    edges_walked += en.cnt;
-                    ++pairs_walked;
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < PPT; ++k)
-                if (pending & (1u << k)) {
-                    const uint32_t slot = res[k];
-                    res[k] = q[slot].part;
-                    if (qpart[k] == LEAN_SLOW) slow_cnt[k] = q[slot].cnt | 0x80000000u;
-                }
-            pending = 0;
-            if (queued <= (uint32_t)ROUTE_QCAP) break;
-            __syncthreads();
-            if (tid == 0) q_n = 0;
-            __syncthreads();
-        }
-        if (stats && pairs_walked) {
-            atomicAdd(&stats[0], pairs_walked);
-            atomicAdd(&stats[1], edges_walked);
-        }
-        // finalize
-        uint32_t* __restrict__ tile_counts = counts ? counts + base : nullptr;
-        uint32_t* __restrict__ tile_code = code + base;
-        unsigned long long wave_hits = 0;
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const uint32_t li = (uint32_t)(k * ROUTE_BLOCK + tid);
-            uint32_t r = res[k], cnt;
-            if (slow_cnt[k]) {
-                cnt = slow_cnt[k] & 0x7FFFFFFFu;
-            } else {
-                if (r != CODE_NONE) {
-                    const uint32_t geom = pv.part_geom ? pv.part_geom[r] : r;
-                    r = dev::valid_row(polys.validity, geom) ? geom : CODE_NONE;
-                }
-                cnt = r != CODE_NONE ? 1u : 0u;
-            }
-            if (li < rem) {
-                if (tile_counts) dev::store_stream(tile_counts + li, cnt);
-                dev::store_stream(tile_code + li, r);
-            }
-            wave_hits += (unsigned long long)__popcll(__ballot(li < rem && cnt == 1u));
-            if (li < rem && cnt >= 2u) atomicAdd(&s_tot, (unsigned long long)cnt);
-        }
-        if (lane64 == 0 && wave_hits) atomicAdd(&s_tot, wave_hits);
-        __syncthreads();
-        if (tid == 0) {
-            const unsigned long long tot = s_tot;
-            block_tot[tile] = tot;
-            if (tot) atomicAdd(&super_tot[tile >> PIP_SUPER_SHIFT], tot);
-        }
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) p[k] = p_next[k];
-    }
-}
-
 // pip_write: turns the per-point codes into the sorted (l, r) pair list.  Reads 4 bytes per point, writes 8
 // bytes per hit; only CODE_MULTI rows touch geometry again.  There is no separate scan kernel: a work-group
 // gets its global offset from the two-level totals (<= 64 tile totals + the super-tile totals before them,
@@ -1444,12 +1213,7 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         return e && *e && *e != '0';
     }();
     const bool lean = right_index->pip.R > 0 && right_index->pip_lean && !no_lean;
-    static const bool no_route = [] {  // GPK_NO_ROUTE=1: A/B runs of the lean kernel on an index that has routing planes
-        const char* e = getenv("GPK_NO_ROUTE");
-        return e && *e && *e != '0';
-    }();
-    const bool route = lean && right_index->pip.route && !no_route;
-    const int tile_points = route ? ROUTE_TILE : (lean ? LEAN_TILE : PIP_TILE);
+    const int tile_points = lean ? LEAN_TILE : PIP_TILE;
     const int64_t n_blocks = (n + tile_points - 1) / tile_points;
     const bool want_pairs = pair_capacity > 0;
     const size_t counts_bytes = sizeof(uint32_t) * (size_t)n;
@@ -1488,12 +1252,7 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         if (me != hipSuccess) return fail(GPK_ERR_DEVICE, "spatial_join: %s", hipGetErrorString(me));
     }
     unsigned long long* stats = join_stats_buffer();  // nullptr unless gpk_join_stats_enable(1)
-    if (route) {  // persistent work-groups: one per CU (the routing planes take most of a CU's LDS)
-        int64_t wgs = (int64_t)cu_count() * GPK_ROUTE_WGS_PER_CU;
-        if (wgs > n_blocks) wgs = n_blocks;
-        J_LAUNCH("gpk_pip_tile", pip_tile_route_kernel, dim3((unsigned)wgs), dim3(ROUTE_BLOCK), 0, s, left->d, right->d, right_index->v,
-                 right_index->pip, n_blocks, counts_dev, code, btot, stot, stats);
-    } else if (lean)
+    if (lean)
         J_LAUNCH("gpk_pip_tile", pip_tile_lean_kernel, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d, right_index->v, right_index->pip,
                  counts_dev, code, btot, stot, stats);
     else if (right_index->pip.R > 0)

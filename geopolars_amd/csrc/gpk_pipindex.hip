@@ -515,46 +515,6 @@ __global__ void lrec_assign_kernel(const uint32_t* __restrict__ cell, uint32_t* 
     }
 }
 
-// ---- routing planes of a small raster (PipView::route) -----------------------------------------------------------------
-// one lane per 32-cell word: the N and S bits of its cells
-__global__ void route_planes_kernel(const uint32_t* __restrict__ cell, int R, uint32_t* __restrict__ route) {
-    const int W = R * R / 32;
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= W) return;
-    uint32_t nb = 0, sb = 0;
-    for (int b = 0; b < 32; ++b) {
-        const uint32_t c = cell[(size_t)w * 32 + b];
-        if (c != 0u) nb |= 1u << b;
-        if ((c >> 30) == CELL_TAG_SUB && !((c & 0x3FFFFFFFu) & SUB2_BIT)) sb |= 1u << b;
-    }
-    route[w] = nb;
-    route[W + w] = sb;
-}
-// one lane per raster row: record ranks of the row's words; row totals land in row_base[] and are scanned by the lane of row 0
-// after a grid-wide ordering is not available — so a second tiny kernel does the scan
-__global__ void route_row_rank_kernel(int R, uint32_t* __restrict__ route) {
-    const int W = R * R / 32, wpr = R / 32;
-    const int cj = blockIdx.x * blockDim.x + threadIdx.x;
-    if (cj >= R) return;
-    uint16_t* rank16 = reinterpret_cast<uint16_t*>(route + 2 * W + R);
-    uint32_t run = 0;
-    for (int k = 0; k < wpr; ++k) {
-        if (!(k & 1)) rank16[(cj * wpr + k) >> 1] = (uint16_t)run;  // wpr is even (R % 64 == 0)
-        run += (uint32_t)__popc(route[W + cj * wpr + k]);
-    }
-    route[2 * W + cj] = run;  // row total, turned into the exclusive prefix below
-}
-__global__ void route_row_base_kernel(int R, uint32_t* __restrict__ route) {
-    const int W = R * R / 32;
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    uint32_t run = 0;
-    for (int cj = 0; cj < R; ++cj) {
-        const uint32_t t = route[2 * W + cj];
-        route[2 * W + cj] = run;
-        run += t;
-    }
-}
-
 }  // namespace gpk
 
 using namespace gpk;
@@ -878,17 +838,6 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
     // (a few list cells are tolerated — polygons whose boxes touch share a cell here and there; the lean kernel sends
     // their points through the generic walk: at most 1 list word per 8 one-part records)
     ix->pip_lean = (int64_t)list_len * 8 <= (int64_t)n_sub && n_refined == 0 && boundary_cells_have_records ? 1 : 0;
-    if (ix->pip_lean && R <= PIP_ROUTE_RMAX && R % 64 == 0 && n_sub > 0) {
-        uint32_t* route = nullptr;
-        GPK_HIP(hipMalloc((void**)&route, sizeof(uint32_t) * (size_t)route_words(R)));
-        keep(route);
-        GPK_LAUNCH("gpk_pipidx_route_planes", route_planes_kernel, blocks_for(R * R / 32), dim3(256), 0, s, (const uint32_t*)cell, R, route);
-        GPK_LAUNCH("gpk_pipidx_route_rank", route_row_rank_kernel, blocks_for(R), dim3(256), 0, s, R, route);
-        GPK_LAUNCH("gpk_pipidx_route_base", route_row_base_kernel, dim3(1), dim3(64), 0, s, R, route);
-        GPK_HIP(hipStreamSynchronize(s));
-        pv.route = route;
-        ix->nbytes += (int64_t)sizeof(uint32_t) * route_words(R);
-    }
     if (getenv("GPK_DEBUG_INDEX")) fprintf(stderr, "[gpk] lean join kernel eligible: %d (list %d, refined rings %d, one-part records %d)\n", ix->pip_lean, list_len, n_refined, n_sub);
     ix->nbytes += (int64_t)(sizeof(SubCell) * (size_t)n_sub + sizeof(SubCell2) * (size_t)n_sub2 + sizeof(SubCell) * (size_t)n_lrec);
     ix->pip = pv;
