@@ -92,6 +92,10 @@ _PROTOS = {
     "gpk_affine_transform_rows": (C.c_int32, [_VP, _VP, _VP, C.c_int32, _VP]),
     "gpk_convex_hull": (C.c_int32, [_VP, _VP, _VP, C.c_int32, _VP]),
     "gpk_distance_rowwise": (C.c_int32, [_VP, _VP, _VP, _VP, C.c_int32, _VP]),
+    "gpk_rowmap_build": (C.c_int32, [_VP, _VP, C.c_int64, C.c_int32, _VP, C.POINTER(_VP)]),
+    "gpk_rowmap_free": (C.c_int32, [_VP]),
+    "gpk_rowmap_nbytes": (C.c_int32, [_VP, C.POINTER(C.c_int64)]),
+    "gpk_distance_rowmap": (C.c_int32, [_VP, _VP, _VP, _VP, C.c_int32, _VP]),
     "gpk_predicate_rowwise": (C.c_int32, [_VP, _VP, _VP, C.c_int32, _VP, C.c_int32, _VP]),
     "gpk_index_build": (C.c_int32, [_VP, _VP, C.POINTER(_VP)]),
     "gpk_index_build_ex": (C.c_int32, [_VP, C.c_int32, _VP, _VP, C.POINTER(_VP)]),

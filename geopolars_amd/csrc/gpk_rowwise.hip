@@ -325,53 +325,86 @@ __global__ __launch_bounds__(256) void distance_kernel(DevGeo pts, DevGeo other,
 // ---- distance, rows grouped by target (point x LINESTRING with a row map) ------------------------------
 // When many rows point at the same linestring (C3: 10M rows -> 100k linestrings) the row-major kernel above
 // re-reads every linestring ~100 times from L2/MALL (10 GB of gather traffic for 98 MB of coordinates) and
-// spends lanes on per-row reductions.  Grouped: a counting sort orders the rows by target; one WAVE owns one
-// target, stages its vertices in LDS once, and every lane walks the segments for its own point (LDS broadcast
-// reads, no cross-lane reduction).  Which lane handles which row depends on atomic order; the value written
-// for a row does not.
-// Both passes aggregate equal keys inside a wave before touching memory (clustered row maps put many rows of
-// one target in the same wave: 64 same-address atomics would serialise): up to two rounds of "lanes that share
-// the first remaining lane's key go together", the rest falls back to one atomic per lane.
-// Map entries >= L (no such target) are counted in the extra bucket L, which no work item covers; the scatter pass gives
-// those rows their result directly: NaN, the answer of a null row.
+// spends lanes on per-row reductions.  Grouped: the rows are ordered ONCE per row map (gpk_rowmap) by target, the
+// targets themselves by descending vertex count, and the ordered rows are cut into chunks of 64.  One WAVE owns one
+// chunk: its lanes' targets are a handful of neighbours in the length order (equally long linestrings, so every lane
+// walks about the same number of segments and no lane idles behind a short batch), the wave stages a window of each
+// of those linestrings in LDS once, and every lane walks the segments of ITS target for its own point with LDS reads
+// (lanes of one target read one address: a broadcast) — no cross-lane reduction.  The staged coordinates are the
+// "ring coordinates in LDS per work-group" of the north star.
+
+// Pass 1 / 3 of the map build: histogram of the map over targets, then the scatter of the rows into target order.  Both
+// passes aggregate equal keys inside a wave before touching memory (clustered row maps put many rows of one target in the
+// same wave: 64 same-address atomics would serialise): up to two rounds of "lanes that share the first remaining lane's key
+// go together", the rest falls back to one atomic per lane.  Map entries >= L (no such target) are counted in the extra
+// bucket L, which sorts behind every real target and is never visited: those rows get NaN, the answer of a null row.
+// SCATTER: counter[] holds the cursors of the targets IN LENGTH ORDER (cursor of target t at counter[rank[t]]).
 template <bool SCATTER>
-__global__ __launch_bounds__(256) void dist_sort_kernel(const uint32_t* __restrict__ rows, int64_t n, uint32_t L, int32_t* __restrict__ counter,
-                                                        uint32_t* __restrict__ perm, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void rowmap_sort_kernel(const uint32_t* __restrict__ rows, int64_t n, uint32_t L, const uint32_t* __restrict__ rank,
+                                                          int32_t* __restrict__ counter, uint32_t* __restrict__ perm, uint32_t* __restrict__ tsorted) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     bool todo = i < n;
     uint32_t key = todo ? rows[i] : 0u;
-    if (key >= L) {
-        key = L;
-        if (SCATTER && todo) out[i] = NAN;
-    }
+    if (key >= L) key = L;
+    const uint32_t slot_key = SCATTER ? (key < L ? rank[key] : L) : key;
 #pragma unroll
     for (int round = 0; round < 2; ++round) {
         const unsigned long long rest = __ballot(todo);
         if (!rest) break;
         const int leader = __ffsll((long long)rest) - 1;
-        const uint32_t lkey = __shfl(key, leader, 64);
-        const bool mine = todo && key == lkey;
+        const uint32_t lkey = __shfl(slot_key, leader, 64);
+        const bool mine = todo && slot_key == lkey;
         const unsigned long long same = __ballot(mine);
         int base = 0;
         if (lane == leader) base = atomicAdd(&counter[lkey], (int)__popcll(same));
         base = __shfl(base, leader, 64);
         if (mine) {
-            if (SCATTER) perm[base + (int)__popcll(same & ((1ull << lane) - 1ull))] = (uint32_t)i;
+            if (SCATTER) {
+                const int at = base + (int)__popcll(same & ((1ull << lane) - 1ull));
+                perm[at] = (uint32_t)i;
+                tsorted[at] = key;
+            }
             todo = false;
         }
     }
     if (todo) {
-        const int slot = atomicAdd(&counter[key], 1);
-        if (SCATTER) perm[slot] = (uint32_t)i;
+        const int at = atomicAdd(&counter[slot_key], 1);
+        if (SCATTER) {
+            perm[at] = (uint32_t)i;
+            tsorted[at] = key;
+        }
     }
+}
+// pass 2: sort keys of the targets — descending vertex count, ties by id (the key is unique, so the order is deterministic)
+__global__ void rowmap_keys_kernel(DevGeo ls, uint32_t L, unsigned long long* __restrict__ keys) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= L) return;
+    const uint32_t nv = (uint32_t)(ls.geom_off[t + 1] - ls.geom_off[t]);
+    keys[t] = ((unsigned long long)(0xFFFFFFFFu - nv) << 32) | t;
+}
+// rank[target] = position in the length order; cnt_sorted[r] = rows of the r-th target in that order
+__global__ void rowmap_rank_kernel(const unsigned long long* __restrict__ sorted, uint32_t L, const int32_t* __restrict__ cnt, uint32_t* __restrict__ rank,
+                                   int32_t* __restrict__ cnt_sorted) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > L) return;
+    if (r == L) {
+        cnt_sorted[L] = cnt[L];  // rows without a target
+        return;
+    }
+    const uint32_t t = (uint32_t)sorted[r];
+    rank[t] = r;
+    cnt_sorted[r] = cnt[t];
+}
+__global__ void rowmap_nan_kernel(const uint32_t* __restrict__ perm, int64_t from, int64_t n, double* __restrict__ out) {
+    const int64_t i = from + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[perm[i]] = NAN;
 }
 
 // How local is the row map?  Counts the lanes whose key is within one of their right neighbour's (ascending or equal
 // runs: `i mod L`, sorted maps, blocks of one target).  Local maps make the counting sort's atomics land on neighbouring
 // counters (one cache line per wave); a random map makes every lane's atomic its own line, and a radix sort wins.
-// A sample is enough: DIST_PROBE_BLOCKS chunks of 256 rows spread evenly over the map (one atomic per wave on a single
-// word — sampling every row would cost 1.9 ms in that atomic alone).
+// A sample is enough: DIST_PROBE_BLOCKS chunks of 256 rows spread evenly over the map.
 constexpr int DIST_PROBE_BLOCKS = 256;
 __global__ __launch_bounds__(256) void dist_probe_kernel(const uint32_t* __restrict__ rows, int64_t n, unsigned long long* __restrict__ local) {
     const int64_t i = (int64_t)blockIdx.x * (n / gridDim.x) + threadIdx.x;
@@ -379,138 +412,153 @@ __global__ __launch_bounds__(256) void dist_probe_kernel(const uint32_t* __restr
     const unsigned long long m = __ballot(i + 1 < n && (kn - k <= 1u));
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(local, (unsigned long long)__popcll(m));
 }
-// radix-sort grouping: row numbers, and the map clamped to L (entries without a target sort behind every real one and get NaN)
-__global__ void iota_clamp_kernel(const uint32_t* __restrict__ rows, uint32_t L, uint32_t* __restrict__ iota, uint32_t* __restrict__ keys,
-                                  double* __restrict__ out, int64_t n) {
+// radix path of the map build: sort keys = position of the row's target in the length order (L = no such target)
+__global__ void rowmap_radix_keys_kernel(const uint32_t* __restrict__ rows, uint32_t L, const uint32_t* __restrict__ rank, uint32_t* __restrict__ keys,
+                                         uint32_t* __restrict__ iota, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    iota[i] = (uint32_t)i;
     const uint32_t k = rows[i];
-    keys[i] = k < L ? k : L;
-    if (k >= L) out[i] = NAN;
+    keys[i] = k < L ? rank[k] : L;
+    iota[i] = (uint32_t)i;
 }
-// off[t] = first position of key t in the sorted keys (t = 0..L), cnt[t] = rows of target t
-__global__ void sorted_offsets_kernel(const uint32_t* __restrict__ keys, int64_t n, int64_t L, int32_t* __restrict__ off,
-                                      int32_t* __restrict__ cnt) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t > L) return;
-    auto lower = [&](uint32_t key) {
-        int64_t lo = 0, hi = n;
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (keys[mid] < key)
-                lo = mid + 1;
-            else
-                hi = mid;
-        }
-        return lo;
-    };
-    const int64_t a = lower((uint32_t)t);
-    off[t] = (int32_t)a;
-    if (t < L) cnt[t] = (int32_t)(lower((uint32_t)t + 1u) - a);
+// sorted rank -> target id (order[r] = the low word of the r-th sorted target key)
+__global__ void rowmap_targets_kernel(const uint32_t* __restrict__ keys_sorted, const unsigned long long* __restrict__ order, uint32_t L, int64_t n,
+                                      uint32_t* __restrict__ tsorted) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = keys_sorted[i];
+    tsorted[i] = r < L ? (uint32_t)order[r] : L;
 }
 
-__global__ void dist_batches_kernel(const int32_t* __restrict__ cnt, int64_t L, int32_t* __restrict__ nb) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < L) nb[t] = (cnt[t] + 63) >> 6;
-}
-
-// squared distance to one segment with the start-point terms carried from the previous segment (|p - a|^2 of
-// this segment is |p - b|^2 of the last one).  Explicit fma: this kernel's results only need the 1e-9 contract;
-// the zero / non-zero outcome is decided separately by the exact re-walk below.
+// One segment step of the grouped kernel.  The distance from p to a linestring is the smaller of (1) the distance to its
+// nearest VERTEX and (2) the distance to the nearest segment whose interior holds p's projection — the same minimum the
+// per-segment clamps of geo-types' line_segment_distance produce (an end point is never nearer than its segment), without
+// the clamp selects: vertices go through one v_min_f64, interiors through a fraction cross^2 / d2 compared by
+// cross-multiplication (no division, no sqrt per segment; one divide + sqrt per row at the end).  The start-point terms are
+// carried from the previous segment.  Explicit fma: this kernel's results only need the 1e-9 contract; the zero / non-zero
+// outcome is decided separately by the exact re-walk below.
 struct SegState {
-    double ax, ay, qx, qy, na2;  // vertex a, p - a, |p - a|^2
+    double ax, ay, qx, qy;  // vertex a, p - a
 };
-__device__ __forceinline__ void seg_step(SegState& st, double2 b, double px, double py, Frac& best, int& maybe) {
+__device__ __forceinline__ double vmin_f64(double a, double b) {  // one instruction (fmin() adds a canonicalising v_max per operand)
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void seg_step(SegState& st, double2 b, double px, double py, double& best_v, Frac& best_i, double& sum_d2) {
     const double rx = px - b.x, ry = py - b.y;
     const double nb2 = __builtin_fma(rx, rx, ry * ry);
     const double dx = b.x - st.ax, dy = b.y - st.ay;
     const double d2 = __builtin_fma(dx, dx, dy * dy);
     const double dot = __builtin_fma(st.qx, dx, st.qy * dy);
     const double cross = __builtin_fma(st.qx, dy, -(st.qy * dx));
-    Frac c;
-    const bool at_a = d2 == 0.0 || dot <= 0.0, at_b = dot >= d2;
-    c.num = at_a ? st.na2 : (at_b ? nb2 : cross * cross);
-    c.den = (at_a || at_b) ? 1.0 : d2;
-    if (frac_less(c, best)) best = c;
-    // candidates for upstream's "point is on the linestring" short-circuit: a vertex hit, or |tx - ty| within reach
-    // of f64::EPSILON (tx - ty == cross / (dx dy)); everything else is certainly not on the segment
-    maybe |= (int)(st.na2 == 0.0 || nb2 == 0.0 || fabs(cross) <= 1.7763568394002505e-15 * fabs(dx * dy));
+    best_v = vmin_f64(best_v, nb2);
+    sum_d2 += d2;  // >= the longest segment: bounds how close a point upstream calls "on the linestring" can be (below)
+    const double c2 = cross * cross;
+    if (dot > 0.0 && dot < d2 && c2 * best_i.den < best_i.num * d2) {  // projection inside the segment, and nearer
+        best_i.num = c2;
+        best_i.den = d2;
+    }
     st.ax = b.x;
     st.ay = b.y;
     st.qx = rx;
     st.qy = ry;
-    st.na2 = nb2;
 }
 
-constexpr int DG_CHUNK = 256;  // vertices staged per wave (4 KB: keeps ~10 work-groups per CU resident); longer linestrings are streamed in passes
-__global__ __launch_bounds__(256) void distance_grouped_kernel(DevGeo pts, DevGeo ls, const int32_t* __restrict__ off,
-                                                               const int32_t* __restrict__ item_off,
-                                                               const uint32_t* __restrict__ perm, double* __restrict__ out) {
-    __shared__ double2 s_xy[4][DG_CHUNK + 1];
+constexpr int DC_K = 31;      // segments per staged window of one linestring (32 vertices)
+constexpr int DC_SLOT = 33;   // LDS stride of a staged window in vertices (odd: windows of different targets sit on different banks)
+constexpr int DC_MAXD = 8;    // targets staged at once per wave (a chunk with more distinct targets goes in several groups)
+__global__ __launch_bounds__(256) void distance_grouped_kernel(DevGeo pts, DevGeo ls, const uint32_t* __restrict__ perm,
+                                                               const uint32_t* __restrict__ tsorted, int64_t n_valid, double* __restrict__ out) {
+    __shared__ double2 s_xy[4][DC_MAXD * DC_SLOT];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double2* sv = s_xy[wave];
-    const int64_t L = ls.n_geoms;
-    const int64_t n_items = item_off[L];
-    // one work item = (target, batch of 64 rows of that target)
-    for (int64_t it = (int64_t)blockIdx.x * 4 + wave; it < n_items; it += (int64_t)gridDim.x * 4) {
-        int64_t lo = 0, hi = L;  // largest t with item_off[t] <= it
-        while (hi - lo > 1) {
-            const int64_t mid = (lo + hi) >> 1;
-            if ((int64_t)item_off[mid] <= it)
-                lo = mid;
-            else
-                hi = mid;
-        }
-        const int64_t t = lo;
-        const int r = off[t] + (int)(it - item_off[t]) * 64 + lane;
-        const bool active = r < off[t + 1];
-        const int c0 = ls.geom_off[t], nv = ls.geom_off[t + 1] - c0;
-        const uint32_t i = active ? perm[r] : 0u;
+    const int64_t n_chunks = (n_valid + 63) >> 6;
+    for (int64_t ch = (int64_t)blockIdx.x * 4 + wave; ch < n_chunks; ch += (int64_t)gridDim.x * 4) {
+        const int64_t pos = (ch << 6) + lane;
+        const bool active = pos < n_valid;
+        const uint32_t t = active ? tsorted[pos] : 0xFFFFFFFFu;
+        const uint32_t i = active ? perm[pos] : 0u;
         double2 p = make_double2(NAN, NAN);
         if (active && dev::valid_row(pts.validity, i)) p = pts.xy[i];
-        Frac best{INFINITY, 1.0};
-        int maybe = 0;
-        SegState st{0, 0, 0, 0, 0};
-        for (int cb = 0; cb < nv; cb += DG_CHUNK) {  // one pass unless the linestring exceeds DG_CHUNK + 1 vertices
-            const int m = nv - cb < DG_CHUNK + 1 ? nv - cb : DG_CHUNK + 1;
-            __builtin_amdgcn_wave_barrier();
-            for (int k = lane; k < m; k += 64) sv[k] = ls.xy[c0 + cb + k];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (cb == 0) {
-                const double2 a = sv[0];
-                st.ax = a.x;
-                st.ay = a.y;
-                st.qx = p.x - a.x;
-                st.qy = p.y - a.y;
-                st.na2 = __builtin_fma(st.qx, st.qx, st.qy * st.qy);
-                if (nv == 1) maybe |= (int)(st.na2 == 0.0);
-            }
-#pragma unroll 4
-            for (int k = 1; k < m; ++k) seg_step(st, sv[k], p.x, p.y, best, maybe);
+        int c0 = 0, nv = 0;
+        if (active) {
+            c0 = ls.geom_off[t];
+            nv = ls.geom_off[t + 1] - c0;
         }
-        // exact replay of line_string_contains_point for the (rare) lanes that came close
-        int eps_hit = 0;
-        if (__any(maybe)) {
-            if (nv <= DG_CHUNK + 1) {
-                if (maybe) {
-                    if (nv == 1) eps_hit = (int)(sv[0].x == p.x && sv[0].y == p.y);
-                    for (int k = 0; k + 1 < nv && !eps_hit; ++k) {
-                        const double2 a = sv[k], b = sv[k + 1];
-                        const double cr = (p.x - a.x) * (b.y - a.y) - (p.y - a.y) * (b.x - a.x);
-                        eps_hit = (int)((a.x == p.x && a.y == p.y) || (b.x == p.x && b.y == p.y) ||
-                                        segment_contains_eps(p.x, p.y, a.x, a.y, b.x, b.y, cr, (b.x - a.x) * (b.y - a.y)));
+        // runs of equal targets: the k-th run of the wave is staged in LDS slot k (mod DC_MAXD)
+        const uint32_t t_prev = __shfl_up(t, 1, 64);
+        const unsigned long long heads = __ballot(active && (lane == 0 || t != t_prev));
+        const int my_run = (int)__popcll(heads & ((2ull << lane) - 1ull)) - 1;
+        const int n_runs = (int)__popcll(heads);
+        double best_v = INFINITY, sum_d2 = 0.0;  // nearest vertex (squared); sum of squared segment lengths
+        Frac best_i{INFINITY, 1.0};              // nearest interior projection (squared, as a fraction)
+        SegState st{0, 0, 0, 0};
+        for (int g0 = 0; g0 < n_runs; g0 += DC_MAXD) {
+            const bool mine = active && my_run >= g0 && my_run < g0 + DC_MAXD;
+            const int slot = (my_run - g0) * DC_SLOT;
+            int nv_max = mine ? nv : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const int w = __shfl_xor(nv_max, o, 64);
+                nv_max = w > nv_max ? w : nv_max;
+            }
+            // lane j of each half wave copies vertex j of a window: two targets per load instruction
+            for (int w0 = 0; w0 < (nv_max > 1 ? nv_max - 1 : 1); w0 += DC_K) {
+                __builtin_amdgcn_wave_barrier();
+                {
+                    unsigned long long m = heads;
+                    for (int q = 0; q < g0; ++q) m &= m - 1;  // skip the runs of earlier groups
+                    const int half = lane >> 5, j = lane & 31;
+                    for (int sl = 0; sl < DC_MAXD && m; sl += 2) {
+                        const int lead0 = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        int lead1 = lead0;
+                        bool two = false;
+                        if (m && sl + 1 < DC_MAXD) {
+                            lead1 = __ffsll((long long)m) - 1;
+                            m &= m - 1;
+                            two = true;
+                        }
+                        const int lead = half ? lead1 : lead0;
+                        const int s_c0 = __shfl(c0, lead, 64), s_nv = __shfl(nv, lead, 64);
+                        if ((half == 0 || two) && w0 + j < s_nv) sv[(sl + half) * DC_SLOT + j] = ls.xy[s_c0 + w0 + j];
                     }
                 }
-            } else if (maybe) {  // streamed linestring: replay from global memory
-                for (int k = 0; k + 1 < nv && !eps_hit; ++k) {
-                    const double2 a = ls.xy[c0 + k], b = ls.xy[c0 + k + 1];
-                    const double cr = (p.x - a.x) * (b.y - a.y) - (p.y - a.y) * (b.x - a.x);
-                    eps_hit = (int)((a.x == p.x && a.y == p.y) || (b.x == p.x && b.y == p.y) ||
-                                    segment_contains_eps(p.x, p.y, a.x, a.y, b.x, b.y, cr, (b.x - a.x) * (b.y - a.y)));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (mine && nv > 0) {
+                    if (w0 == 0) {
+                        const double2 a = sv[slot];
+                        st.ax = a.x;
+                        st.ay = a.y;
+                        st.qx = p.x - a.x;
+                        st.qy = p.y - a.y;
+                        // the first vertex; a one-vertex linestring is at f64::MAX unless the point IS the vertex (upstream's fold)
+                        const double na2 = __builtin_fma(st.qx, st.qx, st.qy * st.qy);
+                        if (nv > 1 || na2 == 0.0) best_v = na2;
+                    }
+                    const int kmax = nv - 1 - w0 < DC_K ? nv - 1 - w0 : DC_K;
+#pragma unroll 2
+                    for (int k = 1; k <= kmax; ++k) seg_step(st, sv[slot + k], p.x, p.y, best_v, best_i, sum_d2);
                 }
+            }
+        }
+        // Upstream short-circuits "the point is on the linestring => 0" with |tx - ty| <= f64::EPSILON per segment
+        // (tx - ty == cross / (dx dy)), which only a point within ~6 eps * |segment| of a segment can satisfy: squared,
+        // best <= 64 eps^2 * (longest segment)^2 <= 64 eps^2 * sum of the squared segment lengths.  Such lanes — and exact vertex hits, best == 0 — replay the upstream test
+        // verbatim from global memory, so the zero / non-zero outcome stays exact; everybody else skips it.
+        int eps_hit = 0;
+        const double best = vmin_f64(best_v, best_i.num == INFINITY ? INFINITY : best_i.num / best_i.den);  // squared distance (INFINITY: no segment)
+        const bool maybe = active && nv > 0 && best <= 3.1554436208840472e-30 * sum_d2;  // 64 * 2^-104
+        if (maybe) {
+            if (nv == 1) eps_hit = 1;  // best == 0 above: the point equals the vertex
+            for (int k = 0; k + 1 < nv && !eps_hit; ++k) {
+                const double2 a = ls.xy[c0 + k], b = ls.xy[c0 + k + 1];
+                const double cr = (p.x - a.x) * (b.y - a.y) - (p.y - a.y) * (b.x - a.x);
+                eps_hit = (int)((a.x == p.x && a.y == p.y) || (b.x == p.x && b.y == p.y) ||
+                                segment_contains_eps(p.x, p.y, a.x, a.y, b.x, b.y, cr, (b.x - a.x) * (b.y - a.y)));
             }
         }
         if (active) {
@@ -520,7 +568,7 @@ __global__ __launch_bounds__(256) void distance_grouped_kernel(DevGeo pts, DevGe
             else if (nv == 0 || eps_hit)
                 d = 0.0;
             else
-                d = frac_sqrt(best);
+                d = best == INFINITY ? DBL_MAX : sqrt(best);
             out[i] = d;
         }
     }
@@ -630,11 +678,186 @@ static dim3 coop_grid(int64_t n_rows, int G) {
     return dim3((unsigned)(blocks > 0 ? blocks : 1));
 }
 
+
+// ---- row map: the rows of a point column ordered for the grouped distance kernel ---------------------------------------
+}  // namespace gpk
+struct gpk_rowmap {
+    int device;
+    int64_t n, n_valid, n_targets;
+    uint32_t* perm;     // left rows in (target length order, target) order; rows without a target last
+    uint32_t* tsorted;  // their targets, same order
+    int64_t nbytes;
+};
+namespace gpk {
+
+// rows_dev: the map in device memory.  Synchronous (the build reads two counts back); buffers live until gpk_rowmap_free.
+static int32_t rowmap_build_dev(const gpk_geoarray* ls, const uint32_t* rows_dev, int64_t n, hipStream_t s, gpk_rowmap** out) {
+    *out = nullptr;
+    const int64_t L = ls->d.n_geoms;
+    if (n > (int64_t)INT32_MAX) return fail(GPK_ERR_INVALID_ARGUMENT, "row map: more than 2^31 - 1 rows (split the column)");
+    gpk_rowmap* m = new gpk_rowmap;
+    memset(m, 0, sizeof *m);
+    m->n = n;
+    m->n_targets = L;
+    (void)hipGetDevice(&m->device);
+    void* tmp = nullptr;
+    void* sort_tmp = nullptr;
+    auto fin = [&](int32_t rc) {
+        (void)hipStreamSynchronize(s);
+        if (tmp) (void)hipFree(tmp);
+        if (sort_tmp) (void)hipFree(sort_tmp);
+        if (rc != GPK_OK) {
+            gpk_rowmap_free(m);
+            m = nullptr;
+        }
+        *out = m;
+        return rc;
+    };
+    const size_t nb = align256(sizeof(uint32_t) * (size_t)(n > 0 ? n : 1));
+    {
+        const hipError_t e1 = hipMalloc((void**)&m->perm, nb), e2 = hipMalloc((void**)&m->tsorted, nb);
+        if (e1 != hipSuccess || e2 != hipSuccess) return fin(fail(GPK_ERR_OOM, "row map: hipMalloc failed"));
+    }
+    m->nbytes = (int64_t)(2 * nb);
+    // scratch: cnt | cnt_sorted | off | cursor (L+2 i32 each) | rank (L u32) | keys, sorted (L u64 each) | scan totals
+    const size_t ib = align256(sizeof(int32_t) * (size_t)(L + 2)), kb = align256(sizeof(unsigned long long) * (size_t)(L + 1));
+    size_t sort_bytes = 0;
+    {
+        const hipError_t e = rocprim::radix_sort_keys(nullptr, sort_bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (size_t)L, 0, 64, s);
+        if (e != hipSuccess) return fin(fail(GPK_ERR_DEVICE, "row map: %s", hipGetErrorString(e)));
+    }
+    const size_t total = 5 * ib + 2 * kb + align256(sort_bytes + 256) + align256(sizeof(unsigned long long) * (size_t)((L + 256) / 256 + 4));
+    if (hipMalloc(&tmp, total) != hipSuccess) return fin(fail(GPK_ERR_OOM, "row map: hipMalloc(%zu) failed", total));
+    char* base = (char*)tmp;
+    int32_t* cnt = (int32_t*)base;
+    int32_t* cnt_sorted = (int32_t*)(base + ib);
+    int32_t* off = (int32_t*)(base + 2 * ib);
+    int32_t* cursor = (int32_t*)(base + 3 * ib);
+    uint32_t* rank = (uint32_t*)(base + 4 * ib);
+    unsigned long long* keys = (unsigned long long*)(base + 5 * ib);
+    unsigned long long* sorted = (unsigned long long*)(base + 5 * ib + kb);
+    void* rp_tmp = base + 5 * ib + 2 * kb;
+    unsigned long long* btot = (unsigned long long*)(base + 5 * ib + 2 * kb + align256(sort_bytes + 256));
+    auto run = [&]() -> int32_t {
+        const dim3 rg((unsigned)((n + 255) / 256)), lg((unsigned)((L + 256) / 256));
+        // targets in descending vertex-count order
+        GPK_LAUNCH("gpk_rowmap_keys", rowmap_keys_kernel, lg, dim3(256), 0, s, ls->d, (uint32_t)L, keys);
+        GPK_HIP(rocprim::radix_sort_keys(rp_tmp, sort_bytes, (const unsigned long long*)keys, sorted, (size_t)L, 0, 64, s));
+        // how local is the map?  (decides counting sort vs radix sort of the rows)
+        unsigned long long h_local = 0, *d_local = btot;
+        GPK_HIP(hipMemsetAsync(d_local, 0, sizeof(unsigned long long), s));
+        const int probe_blocks = n >= 256 * DIST_PROBE_BLOCKS ? DIST_PROBE_BLOCKS : 1;
+        GPK_LAUNCH("gpk_dist_probe", dist_probe_kernel, dim3((unsigned)probe_blocks), dim3(256), 0, s, rows_dev, n, d_local);
+        GPK_HIP(hipMemcpyAsync(&h_local, d_local, sizeof h_local, hipMemcpyDeviceToHost, s));
+        GPK_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(L + 2), s));
+        GPK_LAUNCH("gpk_rowmap_hist", rowmap_sort_kernel<false>, rg, dim3(256), 0, s, rows_dev, n, (uint32_t)L, (const uint32_t*)nullptr, cnt, (uint32_t*)nullptr,
+                   (uint32_t*)nullptr);
+        GPK_LAUNCH("gpk_rowmap_rank", rowmap_rank_kernel, lg, dim3(256), 0, s, (const unsigned long long*)sorted, (uint32_t)L, (const int32_t*)cnt, rank, cnt_sorted);
+        GPK_TRY(exclusive_scan_i32(cnt_sorted, L + 1, off, cursor, btot, s));  // off[L] = rows with a target = start of the rest
+        int32_t n_valid = 0;
+        GPK_HIP(hipMemcpyAsync(&n_valid, off + L, sizeof n_valid, hipMemcpyDeviceToHost, s));
+        GPK_HIP(hipStreamSynchronize(s));
+        m->n_valid = n_valid;
+        const int64_t sampled = (int64_t)probe_blocks * 256 < n ? (int64_t)probe_blocks * 256 : n;
+        if (2 * (int64_t)h_local >= sampled) {
+            GPK_LAUNCH("gpk_rowmap_scatter", rowmap_sort_kernel<true>, rg, dim3(256), 0, s, rows_dev, n, (uint32_t)L, (const uint32_t*)rank, cursor, m->perm,
+                       m->tsorted);
+        } else {  // scattered map: every lane's atomic would be its own cache line; a radix sort of (length rank, row) pairs wins
+            int bits = 1;
+            while (bits < 32 && (1ll << bits) < L + 1) ++bits;  // keys 0..L (L = "no such target")
+            size_t tb = 0;
+            GPK_HIP(rocprim::radix_sort_pairs(nullptr, tb, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, m->perm, (size_t)n, 0, bits, s));
+            GPK_HIP(hipMalloc(&sort_tmp, 3 * nb + tb + 256));
+            uint32_t* iota = (uint32_t*)sort_tmp;
+            uint32_t* keys_in = (uint32_t*)((char*)sort_tmp + nb);
+            uint32_t* keys_sorted = (uint32_t*)((char*)sort_tmp + 2 * nb);
+            void* rp2 = (char*)sort_tmp + 3 * nb;
+            GPK_LAUNCH("gpk_rowmap_radix_keys", rowmap_radix_keys_kernel, rg, dim3(256), 0, s, rows_dev, (uint32_t)L, (const uint32_t*)rank, keys_in, iota, n);
+            GPK_HIP(rocprim::radix_sort_pairs(rp2, tb, (const uint32_t*)keys_in, keys_sorted, (const uint32_t*)iota, m->perm, (size_t)n, 0, bits, s));
+            GPK_LAUNCH("gpk_rowmap_targets", rowmap_targets_kernel, rg, dim3(256), 0, s, (const uint32_t*)keys_sorted, (const unsigned long long*)sorted, (uint32_t)L, n,
+                       m->tsorted);
+        }
+        return GPK_OK;
+    };
+    return fin(run());
+}
+
+static int32_t distance_rowmap_dev(const gpk_geoarray* pts, const gpk_geoarray* ls, const gpk_rowmap* map, double* out_dev, hipStream_t s) {
+    const int64_t n = map->n, nv = map->n_valid;
+    if (nv < n)  // map entries without a target: the answer of a null row
+        GPK_LAUNCH("gpk_rowmap_nan", rowmap_nan_kernel, dim3((unsigned)((n - nv + 255) / 256)), dim3(256), 0, s, (const uint32_t*)map->perm, nv, n, out_dev);
+    if (nv == 0) return GPK_OK;
+    int64_t blocks = ((nv + 63) / 64 + 3) / 4;  // one wave per chunk of 64 ordered rows
+    const int64_t cap = (int64_t)cu_count() * 16;
+    if (blocks > cap) blocks = cap;
+    GPK_LAUNCH("gpk_distance_grouped", distance_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pts->d, ls->d, (const uint32_t*)map->perm,
+               (const uint32_t*)map->tsorted, nv, out_dev);
+    return GPK_OK;
+}
+
 }  // namespace gpk
 
 using namespace gpk;
 
 extern "C" {
+
+int32_t gpk_rowmap_free(gpk_rowmap* m) {
+    if (!m) return GPK_OK;
+    if (m->perm) (void)hipFree(m->perm);
+    if (m->tsorted) (void)hipFree(m->tsorted);
+    delete m;
+    return GPK_OK;
+}
+
+int32_t gpk_rowmap_build(const gpk_geoarray* b, const uint32_t* b_rows, int64_t n_rows, int32_t rows_space, void* stream, gpk_rowmap** out) {
+    if (!b || !out || (!b_rows && n_rows > 0) || n_rows < 0) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = nullptr;
+    GPK_TRY(require_device());
+    if (b->d.type != GPK_GEOM_LINESTRING)
+        return fail(GPK_ERR_MISMATCHED_GEOMETRY, "row map: the grouped schedule serves LINESTRING right sides (found type %d)", b->d.type);
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t* rows_dev = b_rows;
+    void* staged = nullptr;
+    if (rows_space != GPK_MEM_DEVICE && n_rows > 0) {
+        GPK_HIP(hipMalloc(&staged, sizeof(uint32_t) * (size_t)n_rows));
+        const hipError_t e = hipMemcpyAsync(staged, b_rows, sizeof(uint32_t) * (size_t)n_rows, hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) {
+            (void)hipFree(staged);
+            return fail(GPK_ERR_DEVICE, "row map: %s", hipGetErrorString(e));
+        }
+        rows_dev = (const uint32_t*)staged;
+    }
+    const int32_t rc = rowmap_build_dev(b, rows_dev, n_rows, s, out);  // synchronises before it returns
+    if (staged) (void)hipFree(staged);
+    return rc;
+}
+
+int32_t gpk_rowmap_nbytes(const gpk_rowmap* m, int64_t* out_bytes) {
+    if (!m || !out_bytes) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out_bytes = m->nbytes;
+    return GPK_OK;
+}
+
+int32_t gpk_distance_rowmap(const gpk_geoarray* a, const gpk_geoarray* b, const gpk_rowmap* map, double* out, int32_t out_space, void* stream) {
+    if (!a || !b || !map || !out) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
+    GPK_TRY(require_device());
+    if (a->d.type != GPK_GEOM_POINT || b->d.type != GPK_GEOM_LINESTRING)
+        return fail(GPK_ERR_MISMATCHED_GEOMETRY, "distance with a row map: POINT x LINESTRING (found types %d, %d)", a->d.type, b->d.type);
+    if (map->n != a->d.n_geoms || map->n_targets != b->d.n_geoms)
+        return fail(GPK_ERR_INVALID_ARGUMENT, "row map was built for %lld rows x %lld targets, called with %lld x %lld", (long long)map->n,
+                    (long long)map->n_targets, (long long)a->d.n_geoms, (long long)b->d.n_geoms);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t n = a->d.n_geoms;
+    if (n == 0) return GPK_OK;
+    const size_t ob = sizeof(double) * (size_t)n;
+    double* out_dev = out;
+    if (out_space != GPK_MEM_DEVICE) {
+        GPK_TRY(workspace().begin(align256(ob) + 512));
+        out_dev = (double*)workspace().take(ob);
+    }
+    GPK_TRY(distance_rowmap_dev(a, b, map, out_dev, s));
+    return copy_out(out, out_space, out_dev, ob, s);
+}
 
 int32_t gpk_distance_rowwise(const gpk_geoarray* a, const gpk_geoarray* b, const uint32_t* b_rows, double* out,
                              int32_t out_space, void* stream) {
@@ -668,75 +891,15 @@ int32_t gpk_distance_rowwise(const gpk_geoarray* a, const gpk_geoarray* b, const
             rows_dev = r;
         }
     }
-    // many rows per linestring: group the rows by target and stage each linestring in LDS once
+    // many rows per linestring: order the rows by target once (the row map), stage each linestring in LDS per chunk
     if (b_rows && other->d.type == GPK_GEOM_LINESTRING && other->d.n_geoms > 0 && n >= 8 * other->d.n_geoms) {
-        const int64_t L = other->d.n_geoms;
-        void* tmp = nullptr;  // off | cursor | cnt | batches | item_off (L+1 each) | perm (n) | scan totals
-        const size_t ib = align256(sizeof(int32_t) * (size_t)(L + 1));
-        const size_t total = 5 * ib + align256(sizeof(uint32_t) * (size_t)n) + align256(sizeof(unsigned long long) * (size_t)((L + 255) / 256 + 4));
-        GPK_HIP(hipMalloc(&tmp, total));
-        void* sort_tmp_free = nullptr;
-        auto fin = [&](int32_t rc) {
-            (void)hipStreamSynchronize(s);
-            (void)hipFree(tmp);
-            if (sort_tmp_free) (void)hipFree(sort_tmp_free);
-            return rc;
-        };
-        char* base = (char*)tmp;
-        int32_t* g_off = (int32_t*)base;
-        int32_t* g_cur = (int32_t*)(base + ib);
-        int32_t* g_cnt = (int32_t*)(base + 2 * ib);
-        int32_t* g_nb = (int32_t*)(base + 3 * ib);
-        int32_t* g_item = (int32_t*)(base + 4 * ib);
-        uint32_t* perm = (uint32_t*)(base + 5 * ib);
-        unsigned long long* btot = (unsigned long long*)(base + 5 * ib + align256(sizeof(uint32_t) * (size_t)n));
-        void* sort_tmp = nullptr;  // radix-sort path only
-        auto run = [&]() -> int32_t {
-            const dim3 rg((unsigned)((n + 255) / 256));
-            // rows grouped by target: counting sort for local row maps, radix sort (rocPRIM) for scattered ones
-            unsigned long long h_local = 0, *d_local = btot;
-            GPK_HIP(hipMemsetAsync(d_local, 0, sizeof(unsigned long long), s));
-            const int probe_blocks = n >= 256 * DIST_PROBE_BLOCKS ? DIST_PROBE_BLOCKS : 1;
-            GPK_LAUNCH("gpk_dist_probe", dist_probe_kernel, dim3((unsigned)probe_blocks), dim3(256), 0, s, rows_dev, n, d_local);
-            GPK_HIP(hipMemcpyAsync(&h_local, d_local, sizeof h_local, hipMemcpyDeviceToHost, s));
-            GPK_HIP(hipStreamSynchronize(s));
-            const int64_t sampled = (int64_t)probe_blocks * 256 < n ? (int64_t)probe_blocks * 256 : n;
-            if (2 * (int64_t)h_local >= sampled) {
-                GPK_HIP(hipMemsetAsync(g_cnt, 0, sizeof(int32_t) * (size_t)(L + 1), s));
-                GPK_LAUNCH("gpk_dist_hist", dist_sort_kernel<false>, rg, dim3(256), 0, s, rows_dev, n, (uint32_t)L, g_cnt, (uint32_t*)nullptr, (double*)nullptr);
-                GPK_TRY(exclusive_scan_i32(g_cnt, L, g_off, g_cur, btot, s));  // g_cur[L] = g_off[L]: the bucket of map entries without a target
-                GPK_HIP(hipMemcpyAsync(g_cur + L, g_off + L, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-                GPK_LAUNCH("gpk_dist_scatter", dist_sort_kernel<true>, rg, dim3(256), 0, s, rows_dev, n, (uint32_t)L, g_cur, perm, out_dev);
-            } else {
-                int bits = 1;
-                while (bits < 32 && (1ll << bits) < L + 1) ++bits;  // keys 0..L (L = "no such target")
-                size_t tb = 0;
-                GPK_HIP(rocprim::radix_sort_pairs(nullptr, tb, rows_dev, (uint32_t*)nullptr, (const uint32_t*)nullptr, perm, (size_t)n, 0, bits, s));
-                const size_t nbytes = align256(sizeof(uint32_t) * (size_t)n);
-                GPK_HIP(hipMalloc(&sort_tmp, 3 * nbytes + tb + 256));
-                uint32_t* iota = (uint32_t*)sort_tmp;
-                uint32_t* keys_sorted = (uint32_t*)((char*)sort_tmp + nbytes);
-                uint32_t* keys_in = (uint32_t*)((char*)sort_tmp + 2 * nbytes);
-                void* rp_tmp = (char*)sort_tmp + 3 * nbytes;
-                GPK_LAUNCH("gpk_dist_iota", iota_clamp_kernel, rg, dim3(256), 0, s, rows_dev, (uint32_t)L, iota, keys_in, out_dev, n);
-                GPK_HIP(rocprim::radix_sort_pairs(rp_tmp, tb, (const uint32_t*)keys_in, keys_sorted, (const uint32_t*)iota, perm, (size_t)n, 0, bits, s));
-                GPK_LAUNCH("gpk_dist_offsets", sorted_offsets_kernel, dim3((unsigned)((L + 256) / 256)), dim3(256), 0, s, (const uint32_t*)keys_sorted, n,
-                           L, g_off, g_cnt);
-            }
-            GPK_LAUNCH("gpk_dist_batches", dist_batches_kernel, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, s, (const int32_t*)g_cnt, L, g_nb);
-            GPK_TRY(exclusive_scan_i32(g_nb, L, g_item, nullptr, btot, s));
-            int64_t blocks = (n / 64 + L + 3) / 4;  // upper bound on the number of (target, 64-row batch) items
-            const int64_t cap = (int64_t)cu_count() * 16;
-            if (blocks > cap) blocks = cap;
-            GPK_LAUNCH("gpk_distance_grouped", distance_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pts->d, other->d,
-                       (const int32_t*)g_off, (const int32_t*)g_item, (const uint32_t*)perm, out_dev);
-            return GPK_OK;
-        };
-        const int32_t rc = run();
-        sort_tmp_free = sort_tmp;
-        if (rc != GPK_OK) return fin(rc);
-        const int32_t rc2 = copy_out(out, out_space, out_dev, ob, s);
-        return fin(rc2);
+        gpk_rowmap* map = nullptr;
+        GPK_TRY(rowmap_build_dev(other, rows_dev, n, s, &map));
+        int32_t rc = distance_rowmap_dev(pts, other, map, out_dev, s);
+        if (rc == GPK_OK) rc = copy_out(out, out_space, out_dev, ob, s);
+        (void)hipStreamSynchronize(s);  // the map's buffers are released below
+        gpk_rowmap_free(map);
+        return rc;
     }
     int G = other->d.type == GPK_GEOM_POINT ? 1 : pick_group_rows(other->d);
     G = G <= 1 ? 1 : (G <= 8 ? 8 : 32);  // instantiated group sizes

@@ -282,9 +282,14 @@ class GeoSeries:
         return self._per_row_affine(mats)
 
     # ---- binary row-wise operators (HIP) ---------------------------------------------------------
-    def distance(self, other: "GeoSeries", other_rows: Optional[np.ndarray] = None) -> np.ndarray:
+    def distance(self, other: "GeoSeries", other_rows: Optional[np.ndarray] = None, row_map: Optional["RowMap"] = None) -> np.ndarray:
         """geoseries.rs:141-146: 1-to-1 row-wise Euclidean distance.  `other_rows` pairs row i with
-        other[other_rows[i]] (the take() a dataframe caller would have materialised)."""
+        other[other_rows[i]] (the take() a dataframe caller would have materialised); a `row_map` prepared once from
+        such a pairing (RowMap(other, other_rows)) skips the per-call ordering of the rows."""
+        if row_map is not None:
+            out = np.empty(len(self), dtype=np.float64)
+            _abi.check(_abi.lib().gpk_distance_rowmap(self.device().handle, other.device().handle, row_map.handle, out.ctypes.data, MEM_HOST, None))
+            return out
         n = len(self) if self.array.geom_type == GEOM_POINT or other_rows is not None else len(other)
         out = np.empty(n, dtype=np.float64)
         rows = None
@@ -315,6 +320,41 @@ class GeoSeries:
 
     def intersects(self, other: "GeoSeries", other_rows=None) -> np.ndarray:
         return self._predicate(other, "intersects", other_rows)
+
+
+class RowMap:
+    """A row pairing (left row i -> right row rows[i]) ordered once for the grouped distance kernel (gpk_rowmap_build):
+    reuse it for every batch of points that joins the same linestring column through the same foreign-key column."""
+
+    def __init__(self, right: GeoSeries, rows, stream: int = 0):
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        h = C.c_void_p()
+        _abi.check(_abi.lib().gpk_rowmap_build(right.device().handle, rows.ctypes.data if len(rows) else None, len(rows), MEM_HOST, stream, C.byref(h)))
+        self._h = h
+
+    @staticmethod
+    def from_device(right_dev: DeviceGeoArray, rows_tensor, stream: int = 0) -> "RowMap":
+        """rows_tensor: int32/uint32 CUDA tensor (the map already in HBM)"""
+        self = RowMap.__new__(RowMap)
+        h = C.c_void_p()
+        _abi.check(_abi.lib().gpk_rowmap_build(right_dev.handle, rows_tensor.data_ptr(), rows_tensor.shape[0], _abi.MEM_DEVICE, stream, C.byref(h)))
+        self._h = h
+        return self
+
+    @property
+    def handle(self) -> C.c_void_p:
+        return self._h
+
+    def free(self) -> None:
+        if self._h:
+            _abi.lib().gpk_rowmap_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def _abi_name(t: int) -> str:

@@ -178,6 +178,20 @@ int32_t gpk_convex_hull(const gpk_geoarray* a, double* out_xy, int32_t* out_ring
  * LINESTRING, POLYGON, MULTIPOLYGON, MULTILINESTRING, MULTIPOINT} and the mirrored pairs. */
 int32_t gpk_distance_rowwise(const gpk_geoarray* a, const gpk_geoarray* b, const uint32_t* b_rows,
                              double* out, int32_t out_space, void* stream);
+/* A row map that is used more than once (a dataframe's foreign-key column joined against the same geometry column for
+ * every batch of points) can be prepared ONCE: gpk_rowmap_build orders the left rows by target (targets by descending
+ * vertex count, so that the 64 rows one wave takes walk equally long linestrings) and keeps the order in HBM;
+ * gpk_distance_rowmap then runs the distance kernel alone, stream-ordered.  LINESTRING right sides (the grouped schedule);
+ * gpk_distance_rowwise with b_rows builds, uses and drops such a map internally when a target has 8 or more rows on
+ * average.  b_rows in `rows_space`; the build synchronises the stream. */
+typedef struct gpk_rowmap gpk_rowmap;
+int32_t gpk_rowmap_build(const gpk_geoarray* b, const uint32_t* b_rows, int64_t n_rows, int32_t rows_space,
+                         void* stream, gpk_rowmap** out);
+int32_t gpk_rowmap_free(gpk_rowmap* map);
+int32_t gpk_rowmap_nbytes(const gpk_rowmap* map, int64_t* out_bytes);
+/* out[n_geoms(a)] as gpk_distance_rowwise(a, b, b_rows, ...) would fill it; a POINT, b the LINESTRING array of the map */
+int32_t gpk_distance_rowmap(const gpk_geoarray* a, const gpk_geoarray* b, const gpk_rowmap* map, double* out,
+                            int32_t out_space, void* stream);
 /* contains / within / intersects row-wise (north-star additions to the trait; semantics from the
  * dispatch table spatial_index.rs:89-137, geo 0.27 traits).  out[n] bytes 0/1.  Pairs with an answer:
  * point x polygonal (all three), polygonal x polygonal (intersects; contains / within = "the contained side

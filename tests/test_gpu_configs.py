@@ -78,6 +78,62 @@ def test_c3_scale_sampled(gpk, oracle, shuffled):
     assert np.array_equal(g == 0.0, exp == 0.0)
 
 
+def test_c3_prepared_row_map_equals_one_shot(gpk, oracle):
+    """gpk_rowmap_build + gpk_distance_rowmap (the map ordered once) answers exactly what gpk_distance_rowwise answers, for
+    skewed maps too: many distinct targets per 64-row chunk, targets without rows, long linestrings (several LDS windows)."""
+    from geopolars_amd.geoseries import RowMap
+
+    rng = np.random.default_rng(5)
+    ls = synth.random_linestrings(3000, min_log2=0.0, max_log2=8.0)
+    pts = synth.uniform_points(400_000, seed=106)
+    gs, ps = GeoSeries(ls), GeoSeries(pts)
+    for rows in (
+        (np.arange(400_000) % 3000).astype(np.uint32),
+        rng.integers(0, 3000, 400_000).astype(np.uint32),
+        np.minimum(rng.zipf(1.3, 400_000) - 1, 2999).astype(np.uint32),  # a few targets own most rows, most targets own none
+        np.sort(rng.integers(0, 3000, 400_000)).astype(np.uint32),
+    ):
+        one = ps.distance(gs, other_rows=rows)
+        rm = RowMap(gs, rows)
+        two = ps.distance(gs, row_map=rm)
+        assert np.array_equal(one, two)
+        idx = _sample(400_000, 60_000, 11)
+        exp = oracle.distance_rowwise(pts.take(idx), ls, rows[idx])
+        g = two[idx]
+        rel = np.abs(g - exp) / np.maximum(np.abs(exp), 1e-300)
+        assert np.all((rel <= 1e-9) | (g == exp))
+        assert np.array_equal(g == 0.0, exp == 0.0)
+
+
+def test_c3_points_on_the_linestring_are_at_zero(gpk, oracle):
+    """vertices, points on axis-aligned segments and (as representable) segment midpoints: the zero / non-zero outcome of
+    upstream's line_string_contains_point short-circuit is replayed exactly by the grouped kernel"""
+    ls = synth.random_linestrings(500, min_log2=1.0, max_log2=6.0)
+    xy, off = ls.xy, ls.geom_offsets
+    rng = np.random.default_rng(6)
+    rows, pts = [], []
+    for t in range(500):
+        v = xy[off[t] : off[t + 1]]
+        for _ in range(20):  # >= 8 rows per target: the grouped schedule
+            k = rng.integers(0, len(v) - 1)
+            kind = rng.integers(0, 4)
+            a, b = v[k], v[k + 1]
+            pts.append(a if kind == 0 else ((a + b) / 2 if kind == 1 else (a + (b - a) * 0.25 if kind == 2 else a + np.array([1e-3, -1e-3]))))  # (1e-3: a point 1e-9 off a segment of a 1e3-sized coordinate frame has no 1e-9-relative distance in f64, upstream's formula included)
+            rows.append(t)
+    pts = GeoArrowArray.from_points(np.array(pts))
+    rows = np.array(rows, dtype=np.uint32)
+    got = GeoSeries(pts).distance(GeoSeries(ls), other_rows=rows)
+    exp = oracle.distance_rowwise(pts, ls, rows)
+    assert np.array_equal(got == 0.0, exp == 0.0)
+    assert (exp == 0.0).sum() > 2000
+    rel = np.abs(got - exp) / np.maximum(np.abs(exp), 1e-300)
+    # "as representable" mid points that upstream does not call on the segment sit ~1e-13 off it: the value of such a
+    # distance is rounding noise of the 1e3-sized coordinates in ANY evaluation order (upstream's included): both tiny
+    tiny = (exp < 1e-9) & (got < 1e-9)
+    assert np.all((rel <= 1e-9) | (got == exp) | tiny)
+    assert np.all(rel[exp > 1e-6] <= 1e-9)
+
+
 def test_c3_out_of_range_row_map_entries_are_null_rows(gpk):
     """b_rows entries >= n_geoms(b) behave like null rows (NaN), on the grouped and on the row-major schedule"""
     ls, pts = synth.random_linestrings(50), synth.uniform_points(5000, seed=104)
