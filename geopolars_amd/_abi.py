@@ -90,6 +90,16 @@ _PROTOS = {
     "gpk_euclidean_length": (C.c_int32, [_VP, _VP, C.c_int32, _VP]),
     "gpk_affine_transform": (C.c_int32, [_VP, C.POINTER(C.c_double), _VP, C.c_int32, _VP]),
     "gpk_affine_transform_rows": (C.c_int32, [_VP, _VP, _VP, C.c_int32, _VP]),
+    "gpk_affine_about_origin": (C.c_int32, [_VP, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_double, C.c_double, _VP, C.c_int32, _VP]),
+    "gpk_envelope": (C.c_int32, [_VP, _VP, _VP, C.c_int32, _VP]),
+    "gpk_exterior": (C.c_int32, [_VP, _VP, _VP, C.POINTER(C.c_int64), C.c_int32, _VP]),
+    "gpk_explode": (C.c_int32, [_VP, _VP, C.c_int32, _VP, C.POINTER(_VP)]),
+    "gpk_geoarray_validity": (C.c_int32, [_VP, _VP, C.POINTER(C.c_int32), _VP]),
+    "gpk_geoarray_len": (C.c_int32, [_VP, C.POINTER(C.c_int64)]),
+    "gpk_geom_type": (C.c_int32, [_VP, _VP, C.c_int32, _VP]),
+    "gpk_is_empty": (C.c_int32, [_VP, _VP, C.c_int32, _VP]),
+    "gpk_is_ring": (C.c_int32, [_VP, _VP, C.c_int32, _VP]),
+    "gpk_point_xy": (C.c_int32, [_VP, _VP, _VP, C.c_int32, _VP]),
     "gpk_convex_hull": (C.c_int32, [_VP, _VP, _VP, C.c_int32, _VP]),
     "gpk_distance_rowwise": (C.c_int32, [_VP, _VP, _VP, _VP, C.c_int32, _VP]),
     "gpk_rowmap_build": (C.c_int32, [_VP, _VP, C.c_int64, C.c_int32, _VP, C.POINTER(_VP)]),

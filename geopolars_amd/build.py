@@ -33,6 +33,7 @@ SOURCES = [
     "gpk_wkb_device.hip",
     "gpk_wkb_encode.hip",
     "gpk_take.hip",
+    "gpk_structural.hip",
 ]
 
 FLAGS = [

@@ -121,4 +121,6 @@ namespace gpk {
 int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s);
 // gpk_unary.hip: closed bbox of every coordinate sequence (ring) as AoS double4; NaN for empty ones
 int32_t ring_bboxes(const gpk_geoarray* a, double4* out_dev, hipStream_t s);
+// gpk_unary.hip: one affine matrix per geometry; matrices in `mat_space`, output in `out_space`
+int32_t affine_rows_impl(const gpk_geoarray* a, const double* matrices, int32_t mat_space, double* out_xy, int32_t out_space, hipStream_t s);
 }  // namespace gpk

@@ -334,6 +334,22 @@ int32_t gpk_geoarray_free(gpk_geoarray* a) {
     return GPK_OK;
 }
 
+int32_t gpk_geoarray_validity(const gpk_geoarray* a, uint8_t* out_bitmap, int32_t* out_has_validity, void* stream) {
+    if (!a || !out_has_validity) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out_has_validity = a->d.validity ? 1 : 0;
+    if (!a->d.validity || !out_bitmap || a->d.n_geoms == 0) return GPK_OK;
+    hipStream_t s = (hipStream_t)stream;
+    GPK_HIP(hipMemcpyAsync(out_bitmap, a->d.validity, (size_t)((a->d.n_geoms + 7) / 8), hipMemcpyDeviceToHost, s));
+    GPK_HIP(hipStreamSynchronize(s));
+    return GPK_OK;
+}
+
+int32_t gpk_geoarray_len(const gpk_geoarray* a, int64_t* out_n) {
+    if (!a || !out_n) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out_n = a->d.n_geoms;
+    return GPK_OK;
+}
+
 int32_t gpk_geoarray_nbytes(const gpk_geoarray* a, int64_t* out_bytes) {
     if (!a || !out_bytes) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
     *out_bytes = a->nbytes;

@@ -1234,20 +1234,28 @@ int32_t gpk_affine_transform(const gpk_geoarray* a, const double m[6], double* o
 }
 
 int32_t gpk_affine_transform_rows(const gpk_geoarray* a, const double* matrices, double* out_xy, int32_t out_space, void* stream) {
+    return gpk::affine_rows_impl(a, matrices, out_space, out_xy, out_space, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// matrices in `mat_space`, output in `out_space` (gpk_affine_about_origin builds its matrices on the device whatever the output space)
+int32_t gpk::affine_rows_impl(const gpk_geoarray* a, const double* matrices, int32_t mat_space, double* out_xy, int32_t out_space, hipStream_t s) {
     if (!a || !matrices || !out_xy) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
     GPK_TRY(require_device());
-    hipStream_t s = (hipStream_t)stream;
     const int64_t n = a->d.n_coords, ng = a->d.n_geoms;
     if (n == 0 || ng == 0) return GPK_OK;
     const size_t ob = sizeof(double) * 2 * (size_t)n, mb = sizeof(double) * 6 * (size_t)ng;
     void* out_dev = out_xy;
     const double* mats_dev = matrices;
-    if (out_space != GPK_MEM_DEVICE) {
+    if (out_space != GPK_MEM_DEVICE || mat_space != GPK_MEM_DEVICE) {
         GPK_TRY(workspace().begin(align256(ob) + align256(mb) + 512));
-        out_dev = workspace().take(ob);
-        double* m = (double*)workspace().take(mb);
-        GPK_HIP(hipMemcpyAsync(m, matrices, mb, hipMemcpyHostToDevice, s));
-        mats_dev = m;
+        if (out_space != GPK_MEM_DEVICE) out_dev = workspace().take(ob);
+        if (mat_space != GPK_MEM_DEVICE) {
+            double* m = (double*)workspace().take(mb);
+            GPK_HIP(hipMemcpyAsync(m, matrices, mb, hipMemcpyHostToDevice, s));
+            mats_dev = m;
+        }
     }
     const int G = pick_group(n, ng);
     const int64_t per_block = 256 / G;
@@ -1264,5 +1272,3 @@ int32_t gpk_affine_transform_rows(const gpk_geoarray* a, const double* matrices,
     }
     return copy_out(out_xy, out_space, out_dev, ob, s);
 }
-
-}  // extern "C"

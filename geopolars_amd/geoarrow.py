@@ -374,7 +374,13 @@ class DeviceGeoArray:
         po = np.empty(n_parts + 1, dtype=np.int32) if gt == GEOM_MULTIPOLYGON else None
         ro = np.empty(n_rings + 1, dtype=np.int32) if gt in (GEOM_POLYGON, GEOM_MULTILINESTRING, GEOM_MULTIPOLYGON) else None
         _abi.check(lib.gpk_geoarray_download(self.handle, sizes, xy.ctypes.data if n_coords else None, _ptr(go), _ptr(po), _ptr(ro), stream))
-        return GeoArrowArray(gt, xy, geom_offsets=go, part_offsets=po, ring_offsets=ro, validity=getattr(self, "_validity", None), n_geoms=n_geoms)
+        validity = getattr(self, "_validity", None)
+        if validity is None:  # the bitmap may exist on the device only (a decoded or exploded column)
+            has = C.c_int32(0)
+            bm = np.zeros((n_geoms + 7) // 8, dtype=np.uint8)
+            _abi.check(lib.gpk_geoarray_validity(self.handle, bm.ctypes.data if len(bm) else None, C.byref(has), stream))
+            validity = bm if has.value else None
+        return GeoArrowArray(gt, xy, geom_offsets=go, part_offsets=po, ring_offsets=ro, validity=validity, n_geoms=n_geoms)
 
     def nbytes(self) -> int:
         n = C.c_int64(0)

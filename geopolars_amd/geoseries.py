@@ -8,14 +8,12 @@ dead code (geopolars/src/spatial_index.rs:89-137).  polars is not available here
 single-chunk GeoArrow array (`GeoArrowArray`) instead of a `polars.Series` — exactly what
 ffi.rs:56 rechunks to before crossing into Rust.
 
-Every operator goes through the C ABI into HIP kernels; nothing here computes geometry on the CPU.
-Cheap structural accessors (`geom_type`, `is_empty`, `x`, `y`, `exterior`, `envelope` ring assembly)
-only slice offset buffers.
+Every operator — the structural ones (`geom_type`, `is_empty`, `x`, `y`, `exterior`, `explode`, `envelope`, `is_ring`)
+included — goes through the C ABI into HIP kernels; nothing here computes geometry on the CPU.
 """
 from __future__ import annotations
 
 import ctypes as C
-import math
 from typing import Optional, Sequence, Union
 
 import numpy as np
@@ -80,62 +78,60 @@ class GeoSeries:
             self._dev = DeviceGeoArray.upload(self.array)
         return self._dev
 
-    # ---- structural accessors (offset arithmetic only) -------------------------------------------
-    def geom_type(self) -> np.ndarray:
-        """geoseries.rs:60-73: -1 missing, 0 Point, 1 LineString, 3 Polygon, 4.., 6 MultiPolygon."""
-        out = np.full(len(self), self.array.geom_type, dtype=np.int8)
-        out[~self.array.is_valid()] = -1
+    # ---- structural operators (gpk_structural.hip: maps over rows / offset surgery on the device) ---------------
+    def _row_map(self, fn, dtype) -> np.ndarray:
+        out = np.empty(len(self), dtype=dtype)
+        _abi.check(fn(self.device().handle, out.ctypes.data if len(out) else None, MEM_HOST, None))
         return out
 
+    def geom_type(self) -> np.ndarray:
+        """geoseries.rs:60-73: -1 missing, 0 Point, 1 LineString, 3 Polygon, 4.., 6 MultiPolygon."""
+        return self._row_map(_abi.lib().gpk_geom_type, np.int8)
+
     def is_empty(self) -> np.ndarray:
-        a = self.array
-        if a.geom_type == GEOM_POINT:
-            return np.isnan(a.xy).any(axis=1)
-        return np.diff(a.geom_offsets) == 0
+        """geoseries.rs:75-76 (geo HasDimensions::is_empty)."""
+        return self._row_map(_abi.lib().gpk_is_empty, np.uint8).astype(bool)
 
     def x(self) -> np.ndarray:
         self._require(GEOM_POINT, "x")
-        return self.array.xy[:, 0].copy()
+        out = np.empty(len(self), dtype=np.float64)
+        _abi.check(_abi.lib().gpk_point_xy(self.device().handle, out.ctypes.data, None, MEM_HOST, None))
+        return out
 
     def y(self) -> np.ndarray:
         self._require(GEOM_POINT, "y")
-        return self.array.xy[:, 1].copy()
+        out = np.empty(len(self), dtype=np.float64)
+        _abi.check(_abi.lib().gpk_point_xy(self.device().handle, None, out.ctypes.data, MEM_HOST, None))
+        return out
 
     def exterior(self) -> "GeoSeries":
-        """Outer ring of each polygon as a LineString series (geoseries.rs:43-47)."""
+        """Outer ring of each polygon as a LineString series (geoseries.rs:43-47); null rows stay null."""
         self._require(GEOM_POLYGON, "exterior")
         a = self.array
-        first = a.geom_offsets[:-1]
-        has = np.diff(a.geom_offsets) > 0
-        starts = np.where(has, a.ring_offsets[np.minimum(first, a.n_rings - 1 if a.n_rings else 0)], 0)
-        ends = np.where(has, a.ring_offsets[np.minimum(first + 1, a.n_rings)], 0)
-        lens = ends - starts
+        xy = np.empty((max(a.n_coords, 1), 2), dtype=np.float64)
         off = np.zeros(len(self) + 1, dtype=np.int32)
-        off[1:] = np.cumsum(lens)
-        idx = np.concatenate([np.arange(s, e) for s, e in zip(starts, ends)]) if len(self) else np.zeros(0, int)
-        return GeoSeries(GeoArrowArray(GEOM_LINESTRING, a.xy[idx.astype(np.int64)], geom_offsets=off))
+        n_out = C.c_int64(0)
+        _abi.check(_abi.lib().gpk_exterior(self.device().handle, xy.ctypes.data, off.ctypes.data, C.byref(n_out), MEM_HOST, None))
+        return GeoSeries(GeoArrowArray(GEOM_LINESTRING, xy[: int(n_out.value)].copy(), geom_offsets=off, validity=a.validity, n_geoms=len(self)))
 
     def is_ring(self) -> np.ndarray:
-        """geoseries.rs:75-81: True for features that are closed (first coordinate == last); LineStrings only."""
+        """geoseries.rs:78-83: True for closed features (first coordinate == last; geo-types counts an empty linestring
+        as closed); LineStrings only."""
         self._require(GEOM_LINESTRING, "is_ring")
-        a = self.array
-        o = a.geom_offsets
-        n = np.diff(o)
-        first = a.xy[np.minimum(o[:-1], max(a.n_coords - 1, 0))] if a.n_coords else np.zeros((len(self), 2))
-        last = a.xy[np.maximum(o[1:] - 1, 0)] if a.n_coords else np.zeros((len(self), 2))
-        return (n > 0) & np.all(first == last, axis=1)
+        return self._row_map(_abi.lib().gpk_is_ring, np.uint8).astype(bool)
 
-    def explode(self) -> "GeoSeries":
-        """geoseries.rs:49-50: multi-part geometries -> one row per part (pure offset surgery: the coordinate
-        buffer is shared, benches/explode.rs explodes 45,000 two-point MultiPoints this way)."""
-        a = self.array
-        if a.geom_type == GEOM_MULTIPOINT:
-            return GeoSeries(GeoArrowArray.from_points(a.xy))
-        if a.geom_type == GEOM_MULTILINESTRING:
-            return GeoSeries(GeoArrowArray(GEOM_LINESTRING, a.xy, geom_offsets=a.ring_offsets))
-        if a.geom_type == GEOM_MULTIPOLYGON:
-            return GeoSeries(GeoArrowArray(GEOM_POLYGON, a.xy, geom_offsets=a.part_offsets, ring_offsets=a.ring_offsets))
-        return GeoSeries(a)
+    def explode(self, return_parents: bool = False):
+        """geoseries.rs:49-50: multi-part geometries -> one row per part.  Pure offset surgery on the device: the result
+        views this series' coordinate buffer (benches/explode.rs explodes 45,000 two-point MultiPoints this way).  With
+        `return_parents` also the row each member came from."""
+        h = C.c_void_p()
+        n_members = {GEOM_MULTIPOINT: self.array.n_coords, GEOM_MULTILINESTRING: self.array.n_rings, GEOM_MULTIPOLYGON: self.array.n_parts}.get(self.array.geom_type, len(self))
+        parents = np.empty(n_members, dtype=np.int32) if return_parents else None
+        _abi.check(_abi.lib().gpk_explode(self.device().handle, parents.ctypes.data if return_parents and n_members else None, MEM_HOST, None, C.byref(h)))
+        gt = {GEOM_MULTIPOINT: GEOM_POINT, GEOM_MULTILINESTRING: GEOM_LINESTRING, GEOM_MULTIPOLYGON: GEOM_POLYGON}.get(self.array.geom_type, self.array.geom_type)
+        view = DeviceGeoArray(h.value, gt, n_members, self.array.n_coords, keepalive=[self._dev])  # the view borrows our buffers
+        out = GeoSeries(None, device=view)
+        return (out, parents) if return_parents else out
 
     def _require(self, t: int, op: str) -> None:
         if self.array.geom_type != t:
@@ -169,29 +165,24 @@ class GeoSeries:
     def envelope(self) -> "GeoSeries":
         """geoseries.rs:28-33: the bounding rectangle as a geometry.  Points stay points; everything
         else becomes the closed 5-coordinate rectangle polygon (minx miny, maxx miny, maxx maxy,
-        minx maxy, minx miny) that geo's `Rect::to_polygon` produces."""
+        minx maxy, minx miny) that geo's `Rect::to_polygon` produces; null and empty rows give null."""
         if self.array.geom_type == GEOM_POINT:
             return GeoSeries(self.array)
-        b = self.bounds()
         n = len(self)
-        ok = ~np.isnan(b[:, 0])
-        xy = np.empty((n, 5, 2), dtype=np.float64)
-        xy[:, 0] = b[:, [0, 1]]
-        xy[:, 1] = b[:, [2, 1]]
-        xy[:, 2] = b[:, [2, 3]]
-        xy[:, 3] = b[:, [0, 3]]
-        xy[:, 4] = b[:, [0, 1]]
-        xy = xy[ok].reshape(-1, 2)
-        ring_off = np.arange(0, 5 * int(ok.sum()) + 1, 5, dtype=np.int32)
-        geom_off = np.zeros(n + 1, dtype=np.int32)
-        geom_off[1:] = np.cumsum(ok)
-        return GeoSeries(GeoArrowArray(GEOM_POLYGON, xy, geom_offsets=geom_off, ring_offsets=ring_off))
+        xy = np.empty((5 * n, 2), dtype=np.float64)
+        valid = np.empty(n, dtype=np.uint8)
+        _abi.check(_abi.lib().gpk_envelope(self.device().handle, xy.ctypes.data if n else None, valid.ctypes.data if n else None, MEM_HOST, None))
+        validity = None if valid.all() else np.packbits(valid.astype(bool), bitorder="little")
+        return GeoSeries(
+            GeoArrowArray(GEOM_POLYGON, xy, geom_offsets=np.arange(n + 1, dtype=np.int32), ring_offsets=np.arange(0, 5 * n + 1, 5, dtype=np.int32), validity=validity)
+        )
 
     def centroid(self) -> "GeoSeries":
         xy = np.empty((len(self), 2), dtype=np.float64)
         valid = np.empty(len(self), dtype=np.uint8)
         _abi.check(_abi.lib().gpk_centroid(self.device().handle, xy.ctypes.data, valid.ctypes.data, MEM_HOST, None))
-        return GeoSeries(GeoArrowArray.from_points(xy))
+        ok = valid.astype(bool) & self.array.is_valid()  # null in, null out; an empty geometry has no centroid
+        return GeoSeries(GeoArrowArray.from_points(xy, validity=None if ok.all() else np.packbits(ok, bitorder="little")))
 
     def convex_hull(self) -> "GeoSeries":
         a = self.array
@@ -200,7 +191,7 @@ class GeoSeries:
         _abi.check(_abi.lib().gpk_convex_hull(self.device().handle, xy.ctypes.data, ring_off.ctypes.data, MEM_HOST, None))
         xy = xy[: ring_off[-1]]
         return GeoSeries(
-            GeoArrowArray(GEOM_POLYGON, xy, geom_offsets=np.arange(len(self) + 1, dtype=np.int32), ring_offsets=ring_off)
+            GeoArrowArray(GEOM_POLYGON, xy, geom_offsets=np.arange(len(self) + 1, dtype=np.int32), ring_offsets=ring_off, validity=a.validity)
         )
 
     def affine_transform(self, matrix: Sequence[float]) -> "GeoSeries":
@@ -229,57 +220,34 @@ class GeoSeries:
     def to_crs(self, from_crs: str, to_crs: str) -> "GeoSeries":
         raise NotImplementedError("to_crs (geoseries.rs:148-151, PROJ) is not on the accelerated path: use the reference's CPU implementation")
 
-    def _origin(self, origin: TransformOrigin) -> np.ndarray:
-        """TransformOrigin (py-geopolars/src/utils.rs:5-27): 'centroid' | 'center' (of the bbox) |
-        (x, y).  Per-geometry origins -> one matrix per row."""
+    def _about_origin(self, kind: int, p0: float, p1: float, origin: TransformOrigin) -> "GeoSeries":
+        """rotate / scale / skew: the per-geometry origins (TransformOrigin, py-geopolars/src/utils.rs:5-27: 'centroid' |
+        'center' of the bbox | (x, y)) and matrices are computed on the device (gpk_affine_about_origin)."""
+        ox = oy = 0.0
         if isinstance(origin, str):
             o = origin.lower()
-            if o == "centroid":
-                return self.centroid().array.xy
-            if o == "center":
-                b = self.bounds()
-                return np.stack([(b[:, 0] + b[:, 2]) / 2.0, (b[:, 1] + b[:, 3]) / 2.0], axis=1)
-            raise ValueError("Invalid argument")  # PyGeopolarsError::Other("Invalid argument"), utils.rs:21
-        x, y = origin
-        return np.tile(np.array([[float(x), float(y)]]), (len(self), 1))
-
-    def _per_row_affine(self, mats: np.ndarray) -> "GeoSeries":
-        """One matrix per geometry (per-geometry origins): a single HIP launch, G lanes per geometry."""
-        if len(mats) == 0:
-            return self
+            if o not in ("centroid", "center"):
+                raise ValueError("Invalid argument")  # PyGeopolarsError::Other("Invalid argument"), utils.rs:21
+            ok = 0 if o == "centroid" else 1
+        else:
+            ok = 2
+            ox, oy = (float(v) for v in origin)
         a = self.array
-        mats = np.ascontiguousarray(mats, dtype=np.float64).reshape(len(self), 6)
         out = np.empty_like(a.xy)
-        _abi.check(_abi.lib().gpk_affine_transform_rows(self.device().handle, mats.ctypes.data, out.ctypes.data, MEM_HOST, None))
-        return GeoSeries(
-            GeoArrowArray(a.geom_type, out, a.geom_offsets, a.part_offsets, a.ring_offsets, a.validity, n_geoms=a.n_geoms)
-        )
+        _abi.check(_abi.lib().gpk_affine_about_origin(self.device().handle, kind, float(p0), float(p1), ok, ox, oy, out.ctypes.data if len(out) else None, MEM_HOST, None))
+        return GeoSeries(GeoArrowArray(a.geom_type, out, a.geom_offsets, a.part_offsets, a.ring_offsets, a.validity, n_geoms=a.n_geoms))
 
     def rotate(self, angle: float, origin: TransformOrigin = "center") -> "GeoSeries":
         """angle in degrees, counter-clockwise, about `origin` (geoseries.rs:85-93)."""
-        t = math.radians(angle)
-        c, s = math.cos(t), math.sin(t)
-        o = self._origin(origin)
-        mats = np.stack(
-            [np.full(len(o), c), np.full(len(o), -s), o[:, 0] - c * o[:, 0] + s * o[:, 1], np.full(len(o), s), np.full(len(o), c), o[:, 1] - s * o[:, 0] - c * o[:, 1]],
-            axis=1,
-        )
-        return self._per_row_affine(mats)
+        return self._about_origin(0, angle, 0.0, origin)
 
     def scale(self, xfact: float = 1.0, yfact: float = 1.0, origin: TransformOrigin = "center") -> "GeoSeries":
-        o = self._origin(origin)
-        z = np.zeros(len(o))
-        mats = np.stack([z + xfact, z, o[:, 0] * (1 - xfact), z, z + yfact, o[:, 1] * (1 - yfact)], axis=1)
-        return self._per_row_affine(mats)
+        return self._about_origin(1, xfact, yfact, origin)
 
     def skew(self, xs: float = 0.0, ys: float = 0.0, origin: TransformOrigin = "center") -> "GeoSeries":
         """geoseries.rs:118-139: [[1, tan(xs), xoff], [tan(ys), 1, yoff]], xoff = -origin.y*tan(xs),
         yoff = -origin.x*tan(ys); angles in degrees."""
-        tx, ty = math.tan(math.radians(xs)), math.tan(math.radians(ys))
-        o = self._origin(origin)
-        z = np.zeros(len(o))
-        mats = np.stack([z + 1.0, z + tx, -o[:, 1] * tx, z + ty, z + 1.0, -o[:, 0] * ty], axis=1)
-        return self._per_row_affine(mats)
+        return self._about_origin(2, xs, ys, origin)
 
     # ---- binary row-wise operators (HIP) ---------------------------------------------------------
     def distance(self, other: "GeoSeries", other_rows: Optional[np.ndarray] = None, row_map: Optional["RowMap"] = None) -> np.ndarray:

@@ -140,6 +140,10 @@ int32_t gpk_geoarray_to_wkb(const gpk_geoarray* a, int32_t* out_offsets, uint8_t
 int32_t gpk_geoarray_download(const gpk_geoarray* a, int64_t sizes[4], double* xy, int32_t* geom_offsets,
                               int32_t* part_offsets, int32_t* ring_offsets, void* stream);
 
+/* The Arrow validity bitmap of a handle, device -> host: *out_has_validity = 0 when every row is valid (nothing is
+ * written); out_bitmap[(n_geoms + 7) / 8] may be NULL to ask only that. */
+int32_t gpk_geoarray_validity(const gpk_geoarray* a, uint8_t* out_bitmap, int32_t* out_has_validity, void* stream);
+
 /* ---- unary operators: GeoSeries::{area, centroid, envelope/bounds, affine_transform, ...} --- */
 /* out arrays live in `out_space`; sizes are in elements.                                      */
 /* area: geoseries.rs:14-16,188-190.  out[n_geoms] */
@@ -165,6 +169,49 @@ int32_t gpk_affine_transform(const gpk_geoarray* a, const double m[6], double* o
  * matrices[6*n_geoms] in the same [a, b, xoff, d, e, yoff] order, living in `out_space`. */
 int32_t gpk_affine_transform_rows(const gpk_geoarray* a, const double* matrices, double* out_xy,
                                   int32_t out_space, void* stream);
+/* rotate / scale / skew about a per-geometry origin in ONE call (geoseries.rs:85-93,95-107,118-139): the origins
+ * (TransformOrigin of py-geopolars/src/utils.rs:5-27: centroid | centre of the bounding box | a point) and the per-row
+ * matrices are computed on the device, then applied like gpk_affine_transform_rows.
+ *   kind    GPK_AFFINE_ROTATE  p0 = angle in degrees, counter-clockwise                      [c, -s, ox - c ox + s oy, s, c, oy - s ox - c oy]
+ *           GPK_AFFINE_SCALE   p0 = xfact, p1 = yfact                                        [xf, 0, ox (1 - xf), 0, yf, oy (1 - yf)]
+ *           GPK_AFFINE_SKEW    p0 = xs, p1 = ys in degrees (matrix of geoseries.rs:129-138)   [1, tan xs, -oy tan xs, tan ys, 1, -ox tan ys]
+ *   origin  GPK_ORIGIN_CENTROID | GPK_ORIGIN_CENTER | GPK_ORIGIN_POINT (ox, oy)
+ * out_xy[2*n_coords]; offsets are unchanged and shared with the input. */
+#define GPK_AFFINE_ROTATE 0
+#define GPK_AFFINE_SCALE  1
+#define GPK_AFFINE_SKEW   2
+#define GPK_ORIGIN_CENTROID 0
+#define GPK_ORIGIN_CENTER   1
+#define GPK_ORIGIN_POINT    2
+int32_t gpk_affine_about_origin(const gpk_geoarray* a, int32_t kind, double p0, double p1, int32_t origin,
+                                double ox, double oy, double* out_xy, int32_t out_space, void* stream);
+/* envelope as a geometry (geoseries.rs:28-33; geo BoundingRect -> Rect::to_polygon): one closed 5-coordinate rectangle
+ * per row (minx miny, maxx miny, maxx maxy, minx maxy, minx miny) — a POLYGON column whose ring_offsets are 5 i.
+ * out_xy[10*n_geoms]; out_valid[n_geoms] bytes (0 = null or empty row: its rectangle is NaN).  The envelope of a point is
+ * the point: POINT columns are reported (GPK_ERR_MISMATCHED_GEOMETRY), pass them through unchanged. */
+int32_t gpk_envelope(const gpk_geoarray* a, double* out_xy, uint8_t* out_valid, int32_t out_space, void* stream);
+/* exterior (geoseries.rs:43-47): the outer ring of each polygon as a LINESTRING column.  POLYGON columns only
+ * (GeopolarsError::MismatchedGeometry otherwise).  out_geom_offsets[n_geoms+1]; out_xy capacity 2*n_coords(a) doubles
+ * (NULL = size query); *n_out_coords = coordinates written.  Null rows give empty linestrings. */
+int32_t gpk_exterior(const gpk_geoarray* a, double* out_xy, int32_t* out_geom_offsets, int64_t* n_out_coords,
+                     int32_t out_space, void* stream);
+/* explode (geoseries.rs:49-50; benches/explode.rs:10-24): one row per member of a multi-part geometry.  Pure offset
+ * surgery — MULTIPOINT -> POINT, MULTILINESTRING -> LINESTRING, MULTIPOLYGON -> POLYGON, single-part columns explode to
+ * themselves — so *out is a VIEW of `a` (coordinates and inner offsets are shared: `a` must outlive it; free it with
+ * gpk_geoarray_free).  Members of a null row are null.  out_parent (optional, n_members i32 in `parent_space`): the row
+ * each member came from — the index a dataframe repeats its other columns by. */
+int32_t gpk_explode(const gpk_geoarray* a, int32_t* out_parent, int32_t parent_space, void* stream, gpk_geoarray** out);
+/* rows of a handle (n_geoms) — e.g. of an exploded view */
+int32_t gpk_geoarray_len(const gpk_geoarray* a, int64_t* out_n);
+/* geom_type (geoseries.rs:60-73): the column's pygeos type id per row, -1 for null rows.  out[n_geoms] i8 */
+int32_t gpk_geom_type(const gpk_geoarray* a, int8_t* out, int32_t out_space, void* stream);
+/* is_empty (geoseries.rs:75-76; geo HasDimensions::is_empty): out[n_geoms] bytes 0/1, 0 for null rows */
+int32_t gpk_is_empty(const gpk_geoarray* a, uint8_t* out, int32_t out_space, void* stream);
+/* is_ring (geoseries.rs:78-83; geo-types LineString::is_closed: first == last, an empty linestring counts as closed).
+ * LINESTRING columns only.  out[n_geoms] bytes 0/1, 0 for null rows */
+int32_t gpk_is_ring(const gpk_geoarray* a, uint8_t* out, int32_t out_space, void* stream);
+/* x / y (geoseries.rs:177-180): POINT columns only; either output may be NULL; NaN for null rows */
+int32_t gpk_point_xy(const gpk_geoarray* a, double* out_x, double* out_y, int32_t out_space, void* stream);
 /* convex_hull: geoseries.rs:23-26,196-198.  Output = POLYGON array, one closed CCW ring per geometry.
  * out_ring_offsets[n_geoms+1]; out_xy capacity must be >= 2*(n_coords + n_geoms) doubles. */
 int32_t gpk_convex_hull(const gpk_geoarray* a, double* out_xy, int32_t* out_ring_offsets,

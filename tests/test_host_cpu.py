@@ -174,29 +174,10 @@ def test_lowres_contains_its_cities_oracle(oracle):
         assert hit
 
 
-def test_geoseries_structural_accessors():
+def test_geoarrow_to_pyarrow_layout():
     polys = GeoArrowArray.from_polygons([[[(0, 0), (4, 0), (4, 4), (0, 4)], [(1, 1), (1, 2), (2, 2), (2, 1)]], [], [[(5, 5), (6, 5), (6, 6)]]])
-    s = GeoSeries(polys)
-    assert s.geom_type().tolist() == [3, 3, 3]
-    assert s.is_empty().tolist() == [False, True, False]
-    ext = s.exterior().array
-    assert ext.geom_type == _abi.GEOM_LINESTRING and ext.geom_offsets.tolist() == [0, 5, 5, 9]
-    pts = GeoSeries(GeoArrowArray.from_points([[1.0, 2.0], [np.nan, np.nan]]))
-    assert pts.x().tolist()[0] == 1.0 and pts.y().tolist()[0] == 2.0 and pts.is_empty().tolist() == [False, True]
-    with pytest.raises(_abi.MismatchedGeometry):
-        s.x()
     arr = polys.to_pyarrow()
     assert len(arr) == 3 and arr[0].as_py()[0][0] == [0.0, 0.0]
-
-
-def test_explode_and_is_ring_structural():
-    mp = GeoArrowArray.from_multipolygons([[[[(0, 0), (1, 0), (0, 1)]], [[(5, 5), (6, 5), (5, 6)]]], [[[(2, 2), (3, 2), (2, 3)]]]])
-    ex = GeoSeries(mp).explode().array
-    assert ex.geom_type == _abi.GEOM_POLYGON and len(ex) == 3 and ex.ring_offsets.tolist() == [0, 4, 8, 12]
-    pts = GeoArrowArray(_abi.GEOM_MULTIPOINT, np.arange(8.0).reshape(4, 2), geom_offsets=np.array([0, 2, 4], np.int32))
-    assert len(GeoSeries(pts).explode()) == 4  # benches/explode.rs: two-point MultiPoints -> points
-    ls = GeoArrowArray.from_linestrings([[(0, 0), (1, 0), (1, 1), (0, 0)], [(0, 0), (1, 1)], [(2, 2)]])
-    assert GeoSeries(ls).is_ring().tolist() == [True, False, True]
 
 
 # ---- GeoArrow -> WKB, host encoder (from_geom_vec, util.rs:11-24) -------------------------------------
