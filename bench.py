@@ -99,6 +99,8 @@ class Ctx:
         if self.use_dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
+            if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
+                os.environ["NCCL_DEBUG"] = "WARN"  # no RCCL version banner on stdout: rank 0 prints ONE JSON line
             dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
         self.lib = _abi.lib()
         self.dev_name, self.cus = _abi.device_info()
@@ -349,8 +351,8 @@ def run_c2(ctx: Ctx) -> None:
     out["parity"] = parity_point_join(s_last["host"], polys_host, "intersects", s_last["counts"], s_last["pairs"], h, args.parity_rows)
     if ctx.world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_join(s_last["host"], polys_host, "intersects", s_last["counts"], args.cpu_seconds)
+    ctx.finish()  # (RCCL may print its banner while the group goes down: the JSON line stays the last line of stdout)
     print(json.dumps(out), flush=True)
-    ctx.finish()
 
 
 def parity_point_join(pts_host, right_host, predicate: str, gpu_counts, gpu_pairs, h: int, rows: int) -> dict:
@@ -510,8 +512,8 @@ def run_c3(ctx: Ctx) -> None:
     line["parity"] = main["parity"]
     if ctx.world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_distance(pts_host, ls_host, rows_mod, args.cpu_seconds)
+    ctx.finish()  # (RCCL may print its banner while the group goes down: the JSON line stays the last line of stdout)
     print(json.dumps(line), flush=True)
-    ctx.finish()
 
 
 def parity_distance(pts_host, ls_host, rows, gpu_out, k: int) -> dict:
@@ -662,8 +664,8 @@ def run_c4(ctx: Ctx) -> None:
     line["parity"] = parity
     if W == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_polyjoin(left_host, right_full, counts, args.cpu_seconds)
+    ctx.finish()  # (RCCL may print its banner while the group goes down: the JSON line stays the last line of stdout)
     print(json.dumps(line), flush=True)
-    ctx.finish()
 
 
 def parity_poly_join(left_host, right_host, gpu_counts, gpu_pairs, h: int, base: int, rows: int) -> dict:
@@ -821,8 +823,8 @@ def run_c5(ctx: Ctx) -> None:
     line["parity"]["area"] = parity_area(shard_host, area)
     if W == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_join(pts_host, right_host, "within", counts, args.cpu_seconds)
+    ctx.finish()  # (RCCL may print its banner while the group goes down: the JSON line stays the last line of stdout)
     print(json.dumps(line), flush=True)
-    ctx.finish()
 
 
 def parity_area(host, gpu_area) -> dict:

@@ -21,7 +21,7 @@ from tests.lattice import concentric_pair, nudged, random_pair  # noqa: E402
 from tests.test_oracle_rational import contains_bruteforce, intersects_bruteforce  # noqa: E402
 
 
-def main() -> None:
+def main(out_dir: str = HERE) -> None:
     rng = random.Random(20241008)
     pairs = []
     for _ in range(4000):
@@ -34,7 +34,7 @@ def main() -> None:
     meets = np.array([intersects_bruteforce(exact(p), exact(q)) for p, q in pairs], dtype=np.uint8)
     a = GeoArrowArray.from_polygons([p for p, _ in pairs])
     b = GeoArrowArray.from_polygons([q for _, q in pairs])
-    out = os.path.join(HERE, "contains_lattice.npz")
+    out = os.path.join(out_dir, "contains_lattice.npz")
     np.savez_compressed(
         out,
         a_xy=a.xy, a_geom_offsets=a.geom_offsets, a_ring_offsets=a.ring_offsets,
@@ -46,4 +46,4 @@ def main() -> None:
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else HERE)

@@ -20,7 +20,7 @@ from tests.lattice import star_with_hole  # noqa: E402
 from tests.test_oracle_rational import _poly_pos  # noqa: E402
 
 
-def main() -> None:
+def main(out_dir: str = HERE) -> None:
     rng = random.Random(404)
     polys = []
     for _ in range(150):
@@ -40,7 +40,7 @@ def main() -> None:
             if k > 0:
                 pairs.append((i, j))
     a = GeoArrowArray.from_polygons(polys)
-    out = os.path.join(HERE, "join_lattice.npz")
+    out = os.path.join(out_dir, "join_lattice.npz")
     np.savez_compressed(
         out, xy=a.xy, geom_offsets=a.geom_offsets, ring_offsets=a.ring_offsets,
         points=np.array([(float(x), float(y)) for x, y in pts]), pairs=np.array(pairs, dtype=np.uint32),
@@ -49,4 +49,4 @@ def main() -> None:
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else HERE)

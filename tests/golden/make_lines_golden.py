@@ -21,7 +21,7 @@ from geopolars_amd.geoarrow import GeoArrowArray  # noqa: E402
 from tests.test_oracle_rational import on_segment  # noqa: E402
 
 
-def main() -> None:
+def main(out_dir: str = HERE) -> None:
     rng = random.Random(55)
     lines, pts = [], []
     for _ in range(1500):
@@ -75,7 +75,7 @@ def main() -> None:
             best = q2 if best is None or q2 < best else best
         dist.append(math.sqrt(float(best)))
     a = GeoArrowArray.from_linestrings(lines)
-    out = os.path.join(HERE, "lines_lattice.npz")
+    out = os.path.join(out_dir, "lines_lattice.npz")
     np.savez_compressed(
         out, xy=a.xy, geom_offsets=a.geom_offsets, points=np.array(pts, dtype=np.float64), length=np.array(length), centroid=np.array(cen),
         centroid_valid=np.array(cen_ok), bounds=np.array(bounds, dtype=np.float64), contains=np.array(contains), distance=np.array(dist),
@@ -84,4 +84,4 @@ def main() -> None:
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else HERE)

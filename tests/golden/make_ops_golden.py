@@ -46,7 +46,7 @@ def int_hull(points):
     return h + [h[0]]
 
 
-def main() -> None:
+def main(out_dir: str = HERE) -> None:
     rng = random.Random(77)
     polys, pts = [], []
     for _ in range(1500):
@@ -86,7 +86,7 @@ def main() -> None:
                     best = d2 if best is None or d2 < best else best
             dist.append(math.sqrt(float(best)))
     a = GeoArrowArray.from_polygons(polys)
-    out = os.path.join(HERE, "ops_lattice.npz")
+    out = os.path.join(out_dir, "ops_lattice.npz")
     np.savez_compressed(
         out,
         xy=a.xy, geom_offsets=a.geom_offsets, ring_offsets=a.ring_offsets, points=np.array(pts, dtype=np.float64),
@@ -97,4 +97,4 @@ def main() -> None:
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else HERE)

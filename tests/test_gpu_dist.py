@@ -1,0 +1,125 @@
+"""GPU: the N-rank path of SURVEY.md section 8e on the one GPU a test box has — the RCCL ("nccl") process group at world size 1
+(every collective degenerates, but the exact code path of bench.py --config c4 / c5 --gpus N runs: device-resident all-gatherv
+of the right side, the leaves exchange, the index assembled from gathered leaves), and K-shard equivalence of the HIP join
+(K = 2, 4, 8 row ranges of the left side with left_row_base, concatenated == unsharded).  No 2/4/8-GPU number exists: the
+build environment hands out one GPU per call; the driver's SCALE run is the only multi-GPU measurement."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from geopolars_amd import _abi, synth
+from geopolars_amd.dist import GeoBuffers, all_gather_leaves, all_gatherv_buffers, shard_rows, slice_rows
+from geopolars_amd.geoseries import GeoSeries
+from geopolars_amd.spatial_index import SpatialIndex, join_pairs, join_pairs_device
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.fixture(scope="module")
+def nccl_world1(gpk):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+def test_device_resident_exchange_and_index_from_gathered_leaves(nccl_world1):
+    """what bench.py --config c4 does on every rank, at world 1 over RCCL: buffers stay in HBM end to end"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    left = synth.clustered_polygons(60_000, seed=41, mean_neighbours=4.0)
+    right = synth.clustered_polygons(60_000, seed=42, mean_neighbours=4.0)
+    shard = GeoBuffers.from_host(right, dev)
+    shard_arr = shard.to_device_geoarray(stream)
+    box = torch.empty((len(right), 4), dtype=torch.float64, device=dev)
+    _abi.check(_abi.lib().gpk_bounds(shard_arr.handle, box.data_ptr(), _abi.MEM_DEVICE, stream))
+    stats = {}
+    gathered = all_gatherv_buffers(shard, stats=stats)
+    leaves = all_gather_leaves(box)
+    assert gathered.xy.is_cuda and gathered.ring_offsets.is_cuda and leaves.is_cuda  # nothing was staged through the host
+    assert stats["gathered_bytes"] == right.xy.nbytes + right.geom_offsets.nbytes + right.ring_offsets.nbytes
+    assert torch.equal(gathered.xy, shard.xy) and torch.equal(gathered.ring_offsets, shard.ring_offsets) and torch.equal(leaves, box)
+    rdev = gathered.to_device_geoarray(stream)
+    index = SpatialIndex.from_device(rdev, stream=stream, for_points=False, bboxes=leaves)
+    ldev = GeoBuffers.from_host(left, dev).to_device_geoarray(stream)
+    counts = torch.empty(len(left), dtype=torch.int32, device=dev)
+    pairs = torch.empty((8 * len(left), 2), dtype=torch.int32, device=dev)
+    h = join_pairs_device(ldev, rdev, index, "intersects", counts, pairs, stream=stream)
+    exp_pairs, exp_counts = join_pairs(GeoSeries(left), GeoSeries(right), "intersects")
+    assert h == len(exp_pairs)
+    assert np.array_equal(pairs[:h].cpu().numpy().astype(np.uint32), exp_pairs)
+    assert np.array_equal(counts.cpu().numpy().astype(np.uint32), exp_counts)
+
+
+def test_exchange_with_nulls_on_the_device(nccl_world1):
+    import torch
+
+    dev = torch.device("cuda", 0)
+    a = synth.powerlaw_multipolygons(500)
+    keep = np.ones(len(a), dtype=bool)
+    keep[::7] = False
+    a.validity = np.packbits(keep, bitorder="little")
+    got = all_gatherv_buffers(GeoBuffers.from_host(a, dev)).to_host()
+    assert np.array_equal(got.is_valid(), keep) and np.array_equal(got.xy, a.xy) and np.array_equal(got.part_offsets, a.part_offsets)
+
+
+@pytest.mark.parametrize("k", [2, 4, 8])
+def test_row_sharded_hip_joins_equal_unsharded(gpk, k):
+    """outputs of row shards are disjoint: concat(HIP shard results with left_row_base) == the unsharded HIP join — for the
+    point join (C2 / C5 arms) and for the polygon join (C4), shards balanced by vertex weight"""
+    polys = synth.star_polygons(300, 24)
+    pts = synth.uniform_points(200_000, seed=31)
+    ps, qs = GeoSeries(pts), GeoSeries(polys)
+    idx = SpatialIndex(qs)
+    full_pairs, full_counts = join_pairs(ps, qs, "intersects", r_index=idx)
+    parts, counts = [], []
+    for r in range(k):
+        lo, hi = shard_rows(len(pts), k, r)
+        p, c = join_pairs(GeoSeries(slice_rows(pts, lo, hi)), qs, "intersects", r_index=idx, left_row_base=lo)
+        parts.append(p)
+        counts.append(c)
+    assert np.array_equal(np.concatenate(parts), full_pairs) and np.array_equal(np.concatenate(counts), full_counts)
+    left = synth.clustered_polygons(20_000, seed=5, mean_neighbours=6.0)
+    right = synth.clustered_polygons(20_000, seed=6, mean_neighbours=6.0)
+    rs = GeoSeries(right)
+    ridx = SpatialIndex(rs, for_points=False)
+    full_pairs, full_counts = join_pairs(GeoSeries(left), rs, "intersects", r_index=ridx)
+    w = np.diff(left.ring_offsets)[left.geom_offsets[:-1]]
+    parts, counts = [], []
+    for r in range(k):
+        lo, hi = shard_rows(len(left), k, r, weights=w)
+        p, c = join_pairs(GeoSeries(slice_rows(left, lo, hi)), rs, "intersects", r_index=ridx, left_row_base=lo)
+        parts.append(p)
+        counts.append(c)
+    assert np.array_equal(np.concatenate(parts), full_pairs) and np.array_equal(np.concatenate(counts), full_counts)
+
+
+@pytest.mark.parametrize("config,extra", [("c4", ["--polygons", "150000"]), ("c5", ["--multipolygons", "160000", "--points", "400000"])])
+def test_bench_n_rank_path_at_world_1(gpk, config, extra):
+    """bench.py --force-dist: RCCL initialised, the right side exchanged, parity-gated line printed"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--force-dist", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--parity-rows", "20000"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    assert line["n_gpus"] == 1 and line["parity"]["bit_exact"] and line["roofline"]["launch_ms"] > 0
+    assert line["config"]["right_side_exchange"]["bytes"] > 0

@@ -44,6 +44,10 @@ def test_polygon_measures_match_golden(gpk, name):
     assert env.n_coords == 5 * len(s) and np.array_equal(env.xy[0::5], z["oracle_bounds"][:, :2])
     if name == "nybb":
         assert np.allclose(s.area(), z["Shape_Area"], rtol=5e-6)
+        from tests.test_host_cpu import all_rings_as_multilinestring
+
+        # Shape_Leng (the fixture's own column) is the length of ALL rings of a borough: the HIP length of that MultiLineString
+        assert np.allclose(GeoSeries(all_rings_as_multilinestring(s.array)).euclidean_length(), z["Shape_Leng"], rtol=5e-5)
 
 
 def test_countries_contain_cities_join(gpk, oracle):

@@ -140,6 +140,12 @@ def test_oracle_reproduces_golden(oracle, name):
     assert np.array_equal(oracle.euclidean_length(a), z["oracle_length"])
 
 
+def all_rings_as_multilinestring(a: GeoArrowArray) -> GeoArrowArray:
+    """every ring (exteriors and holes of every member) of a polygonal row as the members of one MultiLineString row"""
+    go = a.geom_offsets if a.part_offsets is None else a.part_offsets[a.geom_offsets]
+    return GeoArrowArray(_abi.GEOM_MULTILINESTRING, a.xy, geom_offsets=go.astype(np.int32), ring_offsets=a.ring_offsets)
+
+
 def test_nybb_shape_area_and_length_known_answers(oracle):
     """nybb.arrow ships Shape_Area / Shape_Leng columns: a weak (1e-5) known-answer check of shoelace
     area and perimeter on real data."""
@@ -152,6 +158,10 @@ def test_nybb_shape_area_and_length_known_answers(oracle):
     length = oracle.euclidean_length(a)
     assert (length <= z["Shape_Leng"] * (1 + 1e-4)).all()
     assert np.allclose(length, z["Shape_Leng"], rtol=2e-2)
+    # the second reference-held pin for `length`: every ring of a borough as one MultiLineString -> its length IS Shape_Leng
+    # (the fixture's own column; agreement 7e-6 .. 3.3e-5, SURVEY.md 8c — the column was computed by other software)
+    rings = all_rings_as_multilinestring(a)
+    assert np.allclose(oracle.euclidean_length(rings), z["Shape_Leng"], rtol=5e-5)
 
 
 def test_lowres_contains_its_cities_oracle(oracle):
