@@ -100,6 +100,8 @@ _PROTOS = {
     "gpk_is_empty": (C.c_int32, [_VP, _VP, C.c_int32, _VP]),
     "gpk_is_ring": (C.c_int32, [_VP, _VP, C.c_int32, _VP]),
     "gpk_point_xy": (C.c_int32, [_VP, _VP, _VP, C.c_int32, _VP]),
+    "gpk_geodesic_length": (C.c_int32, [_VP, C.c_int32, _VP, C.c_int32, _VP]),
+    "gpk_simplify": (C.c_int32, [_VP, C.c_double, _VP, _VP, C.POINTER(C.c_int64), C.c_int32, _VP]),
     "gpk_convex_hull": (C.c_int32, [_VP, _VP, _VP, C.c_int32, _VP]),
     "gpk_distance_rowwise": (C.c_int32, [_VP, _VP, _VP, _VP, C.c_int32, _VP]),
     "gpk_rowmap_build": (C.c_int32, [_VP, _VP, C.c_int64, C.c_int32, _VP, C.POINTER(_VP)]),

@@ -34,6 +34,7 @@ SOURCES = [
     "gpk_wkb_encode.hip",
     "gpk_take.hip",
     "gpk_structural.hip",
+    "gpk_lineal_ops.hip",
 ]
 
 FLAGS = [

@@ -210,13 +210,35 @@ class GeoSeries:
         """geoseries.rs:163-174; parameter names of the Python surface (georust/geoseries.py:278)"""
         return self.affine_transform([1.0, 0.0, xoff, 0.0, 1.0, yoff])
 
-    # ---- operators of the reference surface that are off this backend's path (DESIGN.md §8) -------------------
+    GEODESIC_METHODS = {"geodesic": 0, "haversine": 1, "vincenty": 2}
+
     def geodesic_length(self, method: str = "geodesic") -> np.ndarray:
-        raise NotImplementedError("geodesic_length (geoseries.rs:52-58) is not on the accelerated path: use the reference's CPU implementation")
+        """geoseries.rs:52-58 / georust/geoseries.py: metres, coordinates in (lon, lat) degrees.  'haversine' and 'vincenty' run
+        on the GPU; 'geodesic' (Karney's algorithm) is not restated in this backend and is reported as such."""
+        m = self.GEODESIC_METHODS.get(method.lower())
+        if m is None:
+            raise ValueError("Geodesic calculation method not valid. Use one of geodesic, haversine or vincenty")  # geo.rs:68-71
+        out = np.empty(len(self), dtype=np.float64)
+        _abi.check(_abi.lib().gpk_geodesic_length(self.device().handle, m, out.ctypes.data if len(out) else None, MEM_HOST, None))
+        return out
 
     def simplify(self, tolerance: float) -> "GeoSeries":
-        raise NotImplementedError("simplify (geoseries.rs:108-116) is not on the accelerated path: use the reference's CPU implementation")
+        """geoseries.rs:108-116: Douglas-Peucker with geo 0.27's rules (gpk_simplify); the nesting above the coordinate
+        sequences is unchanged."""
+        a = self.array
+        if a.geom_type in (GEOM_POINT, GEOM_MULTIPOINT):
+            return GeoSeries(a)
+        n_seq = a.n_rings if a.ring_offsets is not None else len(self)
+        xy = np.empty((max(a.n_coords, 1), 2), dtype=np.float64)
+        off = np.zeros(n_seq + 1, dtype=np.int32)
+        n_out = C.c_int64(0)
+        _abi.check(_abi.lib().gpk_simplify(self.device().handle, float(tolerance), xy.ctypes.data, off.ctypes.data, C.byref(n_out), MEM_HOST, None))
+        xy = xy[: int(n_out.value)].copy()
+        if a.ring_offsets is not None:
+            return GeoSeries(GeoArrowArray(a.geom_type, xy, a.geom_offsets, a.part_offsets, off, a.validity, n_geoms=a.n_geoms))
+        return GeoSeries(GeoArrowArray(a.geom_type, xy, off, validity=a.validity, n_geoms=a.n_geoms))
 
+    # ---- the one operator of the reference surface that stays off this backend (DESIGN.md section 8) ---------------------
     def to_crs(self, from_crs: str, to_crs: str) -> "GeoSeries":
         raise NotImplementedError("to_crs (geoseries.rs:148-151, PROJ) is not on the accelerated path: use the reference's CPU implementation")
 

@@ -212,6 +212,28 @@ int32_t gpk_is_empty(const gpk_geoarray* a, uint8_t* out, int32_t out_space, voi
 int32_t gpk_is_ring(const gpk_geoarray* a, uint8_t* out, int32_t out_space, void* stream);
 /* x / y (geoseries.rs:177-180): POINT columns only; either output may be NULL; NaN for null rows */
 int32_t gpk_point_xy(const gpk_geoarray* a, double* out_x, double* out_y, int32_t out_space, void* stream);
+/* geodesic_length (geoseries.rs:52-58,216-218; methods of py-geopolars/src/geo.rs:61-78): metres along the ellipsoid /
+ * sphere, coordinates = (lon, lat) degrees; linestrings = their segments, polygons = exterior rings only, points = 0
+ * (the row rule of euclidean_length).  out[n_geoms]; null rows NaN.
+ *   GPK_GEODESIC_HAVERSINE  geo 0.27 HaversineLength: great circle on the mean-radius sphere (6371008.8 m)
+ *   GPK_GEODESIC_VINCENTY   geo 0.27 VincentyLength: Vincenty's inverse formula on WGS84; a row holding a segment upstream
+ *                           answers with Err(FailedToConverge) (nearly antipodal end points) is NaN
+ *   GPK_GEODESIC_KARNEY     ("geodesic", the Python default: Karney 2013 via geographiclib-rs) is NOT restated here:
+ *                           GPK_ERR_INVALID_ARGUMENT — keep the reference's CPU path for it */
+#define GPK_GEODESIC_KARNEY    0
+#define GPK_GEODESIC_HAVERSINE 1
+#define GPK_GEODESIC_VINCENTY  2
+int32_t gpk_geodesic_length(const gpk_geoarray* a, int32_t method, double* out, int32_t out_space, void* stream);
+/* simplify (geoseries.rs:108-116,240-242): Ramer-Douglas-Peucker as geo 0.27 runs it (algorithm/simplify.rs): per
+ * coordinate sequence (linestring / ring), the farthest point from the chord decides (the LAST one among equals), a
+ * range whose farthest point is within `epsilon` loses its interior unless the sequence would drop below 2 (linestrings)
+ * / 4 (polygon rings) coordinates; end points are always kept; epsilon <= 0 returns the input.  The nesting above the
+ * sequences does not change: the result has the input's geom / part offsets and
+ *   out_seq_offsets[n_seq + 1]   the new innermost offsets (ring_offsets, or geom_offsets of a LINESTRING column)
+ *   out_xy                       capacity 2 * n_coords(a) doubles (NULL = size query); *n_out_coords = coordinates kept.
+ * LINESTRING / MULTILINESTRING / POLYGON / MULTIPOLYGON columns (points: GPK_ERR_MISMATCHED_GEOMETRY, pass through). */
+int32_t gpk_simplify(const gpk_geoarray* a, double epsilon, double* out_xy, int32_t* out_seq_offsets,
+                     int64_t* n_out_coords, int32_t out_space, void* stream);
 /* convex_hull: geoseries.rs:23-26,196-198.  Output = POLYGON array, one closed CCW ring per geometry.
  * out_ring_offsets[n_geoms+1]; out_xy capacity must be >= 2*(n_coords + n_geoms) doubles. */
 int32_t gpk_convex_hull(const gpk_geoarray* a, double* out_xy, int32_t* out_ring_offsets,

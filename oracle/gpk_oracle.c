@@ -1358,3 +1358,175 @@ int32_t gpko_spatial_join(const gpk_geoarrow_desc* left, const gpk_geoarrow_desc
     free(G.items);
     return rc;
 }
+
+/* ================================================================================================
+ * geodesic_length (geoseries.rs:52-58) — geo 0.27 haversine_distance.rs / vincenty_distance.rs, summed over
+ * the segments of a row's sequences the way euclidean_length picks them.  Pinned by the values the crate's own docs state
+ * for New York -> London (haversine 5_570_230 m, vincenty 5_585_234 m, rounded) and by Vincenty's published
+ * Flinders Peak -> Buninyong line (54 972.271 m): tests/test_oracle_lineal_ops.py.  "geodesic" (Karney) is not restated.
+ * ================================================================================================ */
+static double o_haversine(double lon1, double lat1, double lon2, double lat2) {
+    const double rad = 0.017453292519943295;
+    const double t1 = lat1 * rad, t2 = lat2 * rad, dt = (lat2 - lat1) * rad, dl = (lon2 - lon1) * rad;
+    const double sh = sin(dt / 2.0), sl = sin(dl / 2.0);
+    const double a = sh * sh + cos(t1) * cos(t2) * (sl * sl);
+    return 6371008.8 * (2.0 * asin(sqrt(a)));
+}
+static double o_vincenty(double lon1, double lat1, double lon2, double lat2) {
+    const double rad = 0.017453292519943295, a = 6378137.0, b = 6356752.314245, f = 1.0 / 298.257223563;
+    const double L = (lon2 - lon1) * rad;
+    const double U1 = atan((1.0 - f) * tan(lat1 * rad)), U2 = atan((1.0 - f) * tan(lat2 * rad));
+    const double sU1 = sin(U1), cU1 = cos(U1), sU2 = sin(U2), cU2 = cos(U2);
+    double lam = L, lam_p, sS = 0, cS = 0, sig = 0, c2A = 0, c2SM = 0;
+    int it = 100;
+    for (;;) {
+        const double sl = sin(lam), cl = cos(lam);
+        const double t0 = cU2 * sl, t1 = cU1 * sU2 - sU1 * cU2 * cl;
+        sS = sqrt(t0 * t0 + t1 * t1);
+        if (sS == 0.0) return (lon1 == lon2 && lat1 == lat2) ? 0.0 : NAN;
+        cS = sU1 * sU2 + cU1 * cU2 * cl;
+        sig = atan2(sS, cS);
+        const double sA = cU1 * cU2 * sl / sS;
+        c2A = 1.0 - sA * sA;
+        c2SM = c2A == 0.0 ? 0.0 : cS - 2.0 * sU1 * sU2 / c2A;
+        const double C = f / 16.0 * c2A * (4.0 + f * (4.0 - 3.0 * c2A));
+        lam_p = lam;
+        lam = L + (1.0 - C) * f * sA * (sig + C * sS * (c2SM + C * cS * (-1.0 + 2.0 * c2SM * c2SM)));
+        if (fabs(lam - lam_p) <= 1e-12) break;
+        if (--it == 0) return NAN;
+    }
+    const double uSq = c2A * (a * a - b * b) / (b * b);
+    const double A = 1.0 + uSq / 16384.0 * (4096.0 + uSq * (-768.0 + uSq * (320.0 - 175.0 * uSq)));
+    const double B = uSq / 1024.0 * (256.0 + uSq * (-128.0 + uSq * (74.0 - 47.0 * uSq)));
+    const double dS = B * sS * (c2SM + B / 4.0 * (cS * (-1.0 + 2.0 * c2SM * c2SM) - B / 6.0 * c2SM * (-3.0 + 4.0 * sS * sS) * (-3.0 + 4.0 * c2SM * c2SM)));
+    return b * A * (sig - dS);
+}
+static double o_geodesic_seq(const double* xy, int64_t n, int32_t method) {
+    double v = 0.0;
+    for (int64_t i = 0; i + 1 < n; ++i)
+        v += method == GPK_GEODESIC_HAVERSINE ? o_haversine(xy[2 * i], xy[2 * i + 1], xy[2 * i + 2], xy[2 * i + 3])
+                                              : o_vincenty(xy[2 * i], xy[2 * i + 1], xy[2 * i + 2], xy[2 * i + 3]);
+    return v;
+}
+int32_t gpko_geodesic_length(const gpk_geoarrow_desc* a, int32_t method, double* out) {
+    if (method != GPK_GEODESIC_HAVERSINE && method != GPK_GEODESIC_VINCENTY) return GPK_ERR_INVALID_ARGUMENT;
+    for (int64_t g = 0; g < a->n_geoms; ++g) {
+        double v = 0.0;
+        if (!is_valid_row(a, g)) {
+            out[g] = NAN;
+            continue;
+        }
+        switch (a->geom_type) {
+        case GPK_GEOM_LINESTRING:
+            v = o_geodesic_seq(a->xy + 2 * (int64_t)a->geom_offsets[g], a->geom_offsets[g + 1] - a->geom_offsets[g], method);
+            break;
+        case GPK_GEOM_MULTILINESTRING:
+            for (int64_t l = a->geom_offsets[g]; l < a->geom_offsets[g + 1]; ++l) {
+                int64_t n;
+                const double* xy = ring_xy(a, l, &n);
+                v += o_geodesic_seq(xy, n, method);
+            }
+            break;
+        case GPK_GEOM_POLYGON:
+        case GPK_GEOM_MULTIPOLYGON: {
+            int64_t p0, p1;
+            geom_parts(a, g, &p0, &p1);
+            for (int64_t p = p0; p < p1; ++p) {
+                ring_span s = part_rings(a, p);
+                if (s.r1 > s.r0) {
+                    int64_t n;
+                    const double* xy = ring_xy(a, s.r0, &n);
+                    v += o_geodesic_seq(xy, n, method);
+                }
+            }
+            break;
+        }
+        default:
+            v = 0.0;
+        }
+        out[g] = v;
+    }
+    return GPK_OK;
+}
+
+/* ================================================================================================
+ * simplify (geoseries.rs:108-116) — geo 0.27 algorithm/simplify.rs, compute_rdp restated RECURSIVELY, as upstream
+ * writes it: the farthest interior point from the chord (fold with `>=`: the last one among equals), split when it is
+ * farther than epsilon (left part first; `simplified_len` is shared), otherwise cull the interior unless the sequence
+ * would drop below INITIAL_MIN (2 linestrings, 4 polygon rings).  The distance is line_segment_distance with a plain
+ * sqrt (upstream: hypot; at most an ulp apart).  The HIP kernel walks the same recursion with an explicit stack.
+ * ================================================================================================ */
+static double o_seg_dist(const double* p, const double* s, const double* e) {
+    const double dx = e[0] - s[0], dy = e[1] - s[1];
+    if (s[0] == e[0] && s[1] == e[1]) return sqrt((p[0] - s[0]) * (p[0] - s[0]) + (p[1] - s[1]) * (p[1] - s[1]));
+    const double d2 = dx * dx + dy * dy;
+    const double r = ((p[0] - s[0]) * dx + (p[1] - s[1]) * dy) / d2;
+    if (r <= 0.0) return sqrt((p[0] - s[0]) * (p[0] - s[0]) + (p[1] - s[1]) * (p[1] - s[1]));
+    if (r >= 1.0) return sqrt((p[0] - e[0]) * (p[0] - e[0]) + (p[1] - e[1]) * (p[1] - e[1]));
+    const double t = ((s[1] - p[1]) * dx - (s[0] - p[0]) * dy) / d2;
+    return fabs(t) * sqrt(d2);
+}
+static void o_rdp(const double* xy, int64_t i, int64_t j, double eps, int64_t min_pts, int64_t* len, uint8_t* keep) {
+    if (j - i < 2) return;
+    int64_t at = 0;
+    double best = 0.0;
+    for (int64_t k = i + 1; k < j; ++k) {
+        const double d = o_seg_dist(xy + 2 * k, xy + 2 * i, xy + 2 * j);
+        if (d >= best) {
+            best = d;
+            at = k;
+        }
+    }
+    if (best > eps) {
+        o_rdp(xy, i, at, eps, min_pts, len, keep);
+        o_rdp(xy, at, j, eps, min_pts, len, keep);
+        return;
+    }
+    const int64_t culled = j - i - 1;
+    if (*len - culled < min_pts) return;
+    *len -= culled;
+    for (int64_t k = i + 1; k < j; ++k) keep[k] = 0;
+}
+int32_t gpko_simplify(const gpk_geoarrow_desc* a, double eps, double* out_xy, int32_t* out_seq_offsets, int64_t* n_out) {
+    const int32_t* off;
+    int64_t n_seq;
+    int64_t min_pts = 2;
+    switch (a->geom_type) {
+    case GPK_GEOM_LINESTRING:
+        off = a->geom_offsets;
+        n_seq = a->n_geoms;
+        break;
+    case GPK_GEOM_MULTILINESTRING:
+        off = a->ring_offsets;
+        n_seq = a->n_rings;
+        break;
+    case GPK_GEOM_POLYGON:
+    case GPK_GEOM_MULTIPOLYGON:
+        off = a->ring_offsets;
+        n_seq = a->n_rings;
+        min_pts = 4;
+        break;
+    default:
+        return GPK_ERR_MISMATCHED_GEOMETRY;
+    }
+    int64_t w = 0;
+    out_seq_offsets[0] = 0;
+    for (int64_t s = 0; s < n_seq; ++s) {
+        const int64_t c0 = off[s], n = off[s + 1] - c0;
+        const double* xy = a->xy + 2 * c0;
+        uint8_t* keep = (uint8_t*)malloc((size_t)(n > 0 ? n : 1));
+        memset(keep, 1, (size_t)(n > 0 ? n : 1));
+        int64_t len = n;
+        if (n >= 3 && eps > 0.0) o_rdp(xy, 0, n - 1, eps, min_pts, &len, keep);
+        for (int64_t k = 0; k < n; ++k)
+            if (keep[k]) {
+                out_xy[2 * w] = xy[2 * k];
+                out_xy[2 * w + 1] = xy[2 * k + 1];
+                ++w;
+            }
+        free(keep);
+        out_seq_offsets[s + 1] = (int32_t)w;
+    }
+    *n_out = w;
+    return GPK_OK;
+}

@@ -12,8 +12,31 @@
  * by exact rational arithmetic (tests/test_oracle_exact.py).  For area / centroid / distance /
  * convex_hull / intersects the reference pins nothing: "parity unpinned" for those ops.
  *
- * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline / parity legs may load this library.
  * Nothing under geopolars_amd/ imports, links or calls it.
+ *
+ * BEHAVIOURS STILL MARKED [verify] IN SURVEY.md APPENDIX A (upstream source is not in the reference tree, so each is a
+ * reading of geo 0.27's published behaviour, not a checked fact), what this restatement does, and the test that fails if the
+ * choice is changed — i.e. what to re-run against real geo 0.27 outputs the day a Rust toolchain is available:
+ *   A.1  ring rule, even-odd crossing vs non-zero winding          winding number (agrees with even-odd on every simple ring;
+ *        differs only on self-intersecting rings)                  tests/test_oracle_exact.py::test_ring_rule_on_a_self_intersecting_ring
+ *   A.1  LineString.contains(Point): end points of an open line    boundary (end points) excluded, closed lines have none
+ *        are its boundary                                          tests/test_oracle_rational.py::test_linestring_contains_point_matches_integer_arithmetic,
+ *                                                                  tests/golden/lines_lattice.npz (`contains`)
+ *   A.1  MultiPolygon.contains(Point) = any member                 any member            tests/test_gpu_join.py::test_join_dispatch_arms_of_the_reference
+ *   A.3  bounding_rect of a polygon scans the exterior only        every coordinate of every ring (equal on valid input: holes lie
+ *                                                                  inside the exterior)  tests/test_oracle_rational.py::test_length_centroid_and_bounds_of_linestrings_and_multipoints
+ *   A.4  point-linestring distance of an EMPTY / one-vertex line   0 / f64::MAX (the fold's start value)   tests/golden/lines_lattice.npz (`distance`)
+ *   A.5  centroid accumulation order, weights                      |ring area| weights, first-vertex shift; order immaterial at 1e-9
+ *                                                                  tests/test_oracle_rational.py::test_area_and_centroid_of_polygons_with_holes_and_multipolygons
+ *   A.6  AffineTransform::from([f64; 6]) order                     [a, b, xoff, d, e, yoff]   tests/test_oracle_rational.py::test_affine_transform_with_integer_matrices_is_exact
+ *   A.6  convex hull: collinear boundary points                    DROPPED (strict left turns only), closed counter-clockwise ring from the
+ *                                                                  lexicographic minimum; fewer than three distinct points degrade to 2- / 3-coordinate
+ *                                                                  rings.  Upstream quickhull output is compared only after canonicalisation, so a
+ *                                                                  different collinear rule upstream would show as extra vertices:
+ *                                                                  tests/test_oracle_exact.py::test_convex_hull_square_with_interior_and_collinear,
+ *                                                                  tests/test_oracle_rational.py::test_convex_hull_matches_bruteforce
+ *   --   LineString::is_closed of an empty linestring              true (geo-types documents the JTS LinearRing rule)   tests/test_gpu_structural.py::test_explode_and_is_ring
  */
 #ifndef GPK_ORACLE_H
 #define GPK_ORACLE_H
@@ -54,6 +77,10 @@ int32_t gpko_bounds(const gpk_geoarrow_desc* a, double* out4);
 int32_t gpko_euclidean_length(const gpk_geoarrow_desc* a, double* out);
 int32_t gpko_affine_transform(const gpk_geoarrow_desc* a, const double m[6], double* out_xy);
 int32_t gpko_convex_hull(const gpk_geoarrow_desc* a, double* out_xy, int32_t* out_ring_offsets);
+
+/* geodesic_length (GPK_GEODESIC_HAVERSINE | GPK_GEODESIC_VINCENTY) and simplify (out_xy capacity 2 * n_coords doubles) */
+int32_t gpko_geodesic_length(const gpk_geoarrow_desc* a, int32_t method, double* out);
+int32_t gpko_simplify(const gpk_geoarrow_desc* a, double eps, double* out_xy, int32_t* out_seq_offsets, int64_t* n_out);
 
 /* row-wise binary */
 int32_t gpko_distance_rowwise(const gpk_geoarrow_desc* a, const gpk_geoarrow_desc* b,

@@ -59,6 +59,10 @@ def lib() -> C.CDLL:
         L.gpko_affine_transform.argtypes = [D, C.POINTER(C.c_double), VP]
         L.gpko_convex_hull.restype = C.c_int32
         L.gpko_convex_hull.argtypes = [D, VP, VP]
+        L.gpko_geodesic_length.restype = C.c_int32
+        L.gpko_geodesic_length.argtypes = [D, C.c_int32, VP]
+        L.gpko_simplify.restype = C.c_int32
+        L.gpko_simplify.argtypes = [D, C.c_double, VP, VP, C.POINTER(C.c_int64)]
         L.gpko_distance_rowwise.restype = C.c_int32
         L.gpko_distance_rowwise.argtypes = [D, D, VP, VP, C.c_int32]
         L.gpko_predicate_rowwise.restype = C.c_int32
@@ -136,6 +140,24 @@ def convex_hull(a: GeoArrowArray):
     d = a.desc()
     _ok(lib().gpko_convex_hull(C.byref(d), xy.ctypes.data, off.ctypes.data), "convex_hull")
     return xy[: off[-1]], off
+
+
+def geodesic_length(a: GeoArrowArray, method: str) -> np.ndarray:
+    out = np.empty(len(a), dtype=np.float64)
+    d = a.desc()
+    _ok(lib().gpko_geodesic_length(C.byref(d), {"haversine": 1, "vincenty": 2}[method], out.ctypes.data), "geodesic_length")
+    return out
+
+
+def simplify(a: GeoArrowArray, eps: float):
+    """-> (xy (k, 2), innermost offsets) of the simplified array (outer offsets are the input's)"""
+    n_seq = a.n_rings if a.ring_offsets is not None else len(a)
+    xy = np.empty((max(a.n_coords, 1), 2), dtype=np.float64)
+    off = np.zeros(n_seq + 1, dtype=np.int32)
+    n_out = C.c_int64(0)
+    d = a.desc()
+    _ok(lib().gpko_simplify(C.byref(d), float(eps), xy.ctypes.data, off.ctypes.data, C.byref(n_out)), "simplify")
+    return xy[: int(n_out.value)].copy(), off
 
 
 def distance_rowwise(a: GeoArrowArray, b: GeoArrowArray, b_rows=None, n_threads: int = 0) -> np.ndarray:

@@ -270,3 +270,18 @@ def test_one_row_with_tens_of_thousands_of_candidates(gpk, oracle):
             got_pairs, got_counts = join_pairs(GeoSeries(l), GeoSeries(r), pred)
             assert np.array_equal(got_counts, exp_counts) and np.array_equal(got_pairs, exp_pairs)
     assert len(exp_pairs) == 0  # a small square never contains the big star
+
+
+def test_self_intersecting_ring_follows_the_oracles_winding_rule(gpk, oracle):
+    """the {5/2} star winds twice around its core: the HIP join answers what the oracle answers (winding number != 0), whichever
+    kernel serves it (SURVEY Appendix A.1 [verify]; tests/test_oracle_exact.py pins the oracle's choice)"""
+    import math
+
+    star = [(50 + 40 * math.cos(2 * math.pi * (2 * k) / 5 + 0.3), 50 + 40 * math.sin(2 * math.pi * (2 * k) / 5 + 0.3)) for k in range(5)]
+    polys = GeoArrowArray.from_polygons([[star]])
+    pts = synth.uniform_points(20_000, seed=77, domain=100.0)
+    exp_pairs, exp_counts, _ = oracle.spatial_join(pts, polys, "contains", mode=0)
+    got_pairs, got_counts = join_pairs(GeoSeries(pts), GeoSeries(polys), "contains")
+    assert np.array_equal(got_counts, exp_counts) and np.array_equal(got_pairs, exp_pairs)
+    core = np.hypot(pts.xy[:, 0] - 50, pts.xy[:, 1] - 50) < 10  # well inside the doubly wound pentagon
+    assert got_counts[core].all()

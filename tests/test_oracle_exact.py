@@ -130,6 +130,22 @@ def test_coord_pos_ring_degenerate(oracle):
 KA_POINTS = [(0.0, 10.0), (1.0, 1.0), (10.0, 1.0), (1.0, -1.0), (0.0, -10.0), (-1.0, -1.0), (-10.0, 0.0), (-1.0, 1.0), (0.0, 10.0)]
 
 
+def test_ring_rule_on_a_self_intersecting_ring(oracle):
+    """SURVEY Appendix A.1 [verify]: geo 0.27's coord_pos_relative_to_ring is restated as a WINDING NUMBER test.  On simple rings
+    winding and even-odd agree (every other test); they part on self-intersecting rings.  This pins the choice on a ring that
+    winds twice around its core — points of the doubly wound core are Inside under winding (wn = 2), Outside under even-odd —
+    so a change of rule cannot go unnoticed (the HIP path is held to the oracle on the same ring in tests/test_gpu_join.py)."""
+    # a pentagram-like ring: the star polygon {5/2} winds twice around the central pentagon
+    import math
+
+    ring = [(math.cos(2 * math.pi * (2 * k) / 5 + 0.3), math.sin(2 * math.pi * (2 * k) / 5 + 0.3)) for k in range(5)]
+    ring.append(ring[0])
+    assert oracle.coord_pos_ring((0.0, 0.0), np.array(ring)) == 2  # INSIDE: winding number 2 (even-odd would say outside)
+    tip = (0.9 * ring[0][0], 0.9 * ring[0][1])
+    assert oracle.coord_pos_ring(tip, np.array(ring)) == 2  # a tip of the star: wound once, inside under both rules
+    assert oracle.coord_pos_ring((2.0, 2.0), np.array(ring)) == 0
+
+
 def test_ka1_spatial_join_boundary_not_contained(oracle):
     """spatial_index.rs:432-484: inner join shape (2, 4), left join 9 rows."""
     pts = GeoArrowArray.from_points(KA_POINTS)

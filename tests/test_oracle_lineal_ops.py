@@ -1,0 +1,116 @@
+"""CPU: the oracle's geodesic_length and simplify restatements (oracle/gpk_oracle.c) against what exists OUTSIDE this repository
+for them: the values geo's own documentation states, Vincenty's published test line, and — for Douglas-Peucker — an
+independent pure-Python recursion on exact rationals plus hand-checked cases of the rules that are particular to geo 0.27
+(last farthest point among equals, the INITIAL_MIN floor of 4 for rings)."""
+from fractions import Fraction as F
+
+import numpy as np
+import pytest
+
+from geopolars_amd import _abi
+from geopolars_amd.geoarrow import GeoArrowArray
+
+
+def _dms(d, m, s):
+    return d + m / 60.0 + s / 3600.0
+
+
+def test_geodesic_lengths_reproduce_published_values(oracle):
+    nyc_london = GeoArrowArray.from_linestrings([[(-74.006, 40.7128), (-0.1278, 51.5074)]])
+    # the examples of geo's HaversineLength / VincentyLength docs (New York City -> London), rounded to metres there
+    assert round(float(oracle.geodesic_length(nyc_london, "haversine")[0])) == 5_570_230
+    assert round(float(oracle.geodesic_length(nyc_london, "vincenty")[0])) == 5_585_234
+    # T. Vincenty (1975), the line Flinders Peak -> Buninyong: 54 972.271 m
+    fb = GeoArrowArray.from_linestrings([[(_dms(144, 25, 29.52440), -_dms(37, 57, 3.72030)), (_dms(143, 55, 35.38390), -_dms(37, 39, 10.15610))]])
+    assert abs(float(oracle.geodesic_length(fb, "vincenty")[0]) - 54972.271) < 1e-3
+    # coincident points: 0; antipodal points: upstream's FailedToConverge -> NaN; a polygon counts its exterior ring only
+    z = GeoArrowArray.from_linestrings([[(10.0, 20.0), (10.0, 20.0)], [(0.0, 0.0), (180.0, 0.0)], []])
+    v = oracle.geodesic_length(z, "vincenty")
+    assert v[0] == 0.0 and np.isnan(v[1]) and v[2] == 0.0
+    poly = GeoArrowArray.from_polygons([[[(0, 0), (1, 0), (1, 1), (0, 1)], [(0.2, 0.2), (0.2, 0.4), (0.4, 0.4), (0.4, 0.2)]]])
+    ring = GeoArrowArray.from_linestrings([[(0, 0), (1, 0), (1, 1), (0, 1), (0, 0)]])
+    assert oracle.geodesic_length(poly, "haversine")[0] == oracle.geodesic_length(ring, "haversine")[0]
+
+
+def _rdp_rational(pts, eps, min_pts):
+    """geo 0.27 compute_rdp on exact rationals (squared distances compared, so no rounding anywhere)"""
+    n = len(pts)
+    keep = [True] * n
+    state = {"len": n}
+
+    def d2(p, s, e):
+        dx, dy = e[0] - s[0], e[1] - s[1]
+        if dx == 0 and dy == 0:
+            return (p[0] - s[0]) ** 2 + (p[1] - s[1]) ** 2
+        dd = dx * dx + dy * dy
+        r = F((p[0] - s[0]) * dx + (p[1] - s[1]) * dy, dd)
+        if r <= 0:
+            return (p[0] - s[0]) ** 2 + (p[1] - s[1]) ** 2
+        if r >= 1:
+            return (p[0] - e[0]) ** 2 + (p[1] - e[1]) ** 2
+        c = (s[1] - p[1]) * dx - (s[0] - p[0]) * dy
+        return F(c * c, dd)
+
+    def rec(i, j):
+        if j - i < 2:
+            return
+        best, at = F(0), 0
+        for k in range(i + 1, j):
+            d = d2(pts[k], pts[i], pts[j])
+            if d >= best:
+                best, at = d, k
+        if best > eps * eps:
+            rec(i, at)
+            rec(at, j)
+            return
+        culled = j - i - 1
+        if state["len"] - culled < min_pts:
+            return
+        state["len"] -= culled
+        for k in range(i + 1, j):
+            keep[k] = False
+
+    if n >= 3 and eps > 0:
+        rec(0, n - 1)
+    return [p for p, k in zip(pts, keep) if k]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_simplify_matches_the_rational_recursion_on_lattice_lines(oracle, seed):
+    rng = np.random.default_rng(seed)
+    lines = []
+    for _ in range(40):
+        n = int(rng.integers(2, 60))
+        walk = np.cumsum(rng.integers(-4, 5, (n, 2)), axis=0)
+        lines.append([tuple(int(v) for v in p) for p in walk])
+    a = GeoArrowArray.from_linestrings(lines)
+    for eps in (F(1, 2), F(3), F(7)):  # distances of lattice data are never within an ulp of these: float == rational decisions
+        xy, off = oracle.simplify(a, float(eps))
+        for i, line in enumerate(lines):
+            exp = _rdp_rational(line, eps, 2)
+            assert xy[off[i] : off[i + 1]].tolist() == [[float(x), float(y)] for x, y in exp], (seed, i, eps)
+
+
+def test_simplify_rules_particular_to_geo(oracle):
+    # geo's doc example: [(0,0),(5,4),(11,5.5),(17.3,3.2),(27.8,0.1)] with epsilon 1.0 -> [(0,0),(5,4),(11,5.5),(27.8,0.1)]
+    ls = GeoArrowArray.from_linestrings([[(0.0, 0.0), (5.0, 4.0), (11.0, 5.5), (17.3, 3.2), (27.8, 0.1)]])
+    xy, off = oracle.simplify(ls, 1.0)
+    assert xy.tolist() == [[0.0, 0.0], [5.0, 4.0], [11.0, 5.5], [27.8, 0.1]] and off.tolist() == [0, 4]
+    # polygons: a ring never drops below 4 coordinates (INITIAL_MIN = 4) — a thin sliver keeps a closed triangle
+    poly = GeoArrowArray.from_polygons([[[(0, 0), (10, 0), (10, 0.1), (5, 0.2), (0, 0.1)]]])
+    xy, off = oracle.simplify(poly, 5.0)
+    assert off[-1] >= 4 and xy[0].tolist() == xy[-1].tolist()
+    # the doc example of Polygon::simplify: [(0,0),(0,10),(5,11),(10,10),(10,0),(0,0)] with epsilon 2 drops (5, 11)
+    poly = GeoArrowArray.from_polygons([[[(0, 0), (0, 10), (5, 11), (10, 10), (10, 0)]]])
+    xy, off = oracle.simplify(poly, 2.0)
+    assert xy.tolist() == [[0, 0], [0, 10], [10, 10], [10, 0], [0, 0]]
+    # ties: two interior points equally far from the chord -> the split happens at the LAST one
+    ls = GeoArrowArray.from_linestrings([[(0, 0), (2, 3), (4, 3), (6, 0)]])
+    xy, _ = oracle.simplify(ls, 1.0)
+    assert xy.tolist() == [[0, 0], [2, 3], [4, 3], [6, 0]]
+    # epsilon <= 0 and short sequences come back unchanged
+    xy, off = oracle.simplify(ls, 0.0)
+    assert len(xy) == 4
+    two = GeoArrowArray.from_linestrings([[(0, 0), (1, 1)], [(5, 5)], []])
+    xy, off = oracle.simplify(two, 10.0)
+    assert off.tolist() == [0, 2, 3, 3]
