@@ -259,17 +259,20 @@ def test_plain_c_client_links_and_fails_loudly_without_a_device(tmp_path):
 
 
 def test_off_path_operators_say_so():
-    """geodesic_length / simplify / to_crs belong to the reference surface but not to this backend: a clear
-    error instead of an AttributeError; translate takes the Python surface's parameter names"""
+    """to_crs (PROJ) belongs to the reference surface but not to this backend: a clear error instead of an
+    AttributeError; an unknown geodesic method is rejected with the reference's message before any device is touched;
+    translate takes the Python surface's parameter names"""
     import inspect
 
     from geopolars_amd.geoseries import GeoSeries
 
     s = GeoSeries(GeoArrowArray.from_points([(0.0, 0.0)]))
-    for call in (lambda: s.geodesic_length(), lambda: s.simplify(1.0), lambda: s.to_crs("EPSG:4326", "EPSG:3857")):
-        with pytest.raises(NotImplementedError, match="not on the accelerated path"):
-            call()
+    with pytest.raises(NotImplementedError, match="not on the accelerated path"):
+        s.to_crs("EPSG:4326", "EPSG:3857")
+    with pytest.raises(ValueError, match="Geodesic calculation method not valid"):
+        s.geodesic_length("rhumb")
     assert list(inspect.signature(GeoSeries.translate).parameters)[1:] == ["xoff", "yoff"]
+    assert list(inspect.signature(GeoSeries.simplify).parameters)[1:] == ["tolerance"]
 
 
 def test_wkb_host_codec_round_trip_on_random_structures():
