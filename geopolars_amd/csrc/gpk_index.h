@@ -118,7 +118,7 @@ struct gpk_index {
 
 namespace gpk {
 // gpk_pipindex.hip: builds ix->pip for a polygonal array (no-op otherwise).  ix->v must be complete.
-int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s);
+int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, bool list_records = true);
 // gpk_unary.hip: closed bbox of every coordinate sequence (ring) as AoS double4; NaN for empty ones
 int32_t ring_bboxes(const gpk_geoarray* a, double4* out_dev, hipStream_t s);
 // gpk_unary.hip: one affine matrix per geometry; matrices in `mat_space`, output in `out_space`

@@ -1536,7 +1536,7 @@ int32_t gpk_index_build_ex(const gpk_geoarray* a, int32_t parts, const double* b
     ix->nbytes = (int64_t)(sizeof(double4) * (size_t)n + sizeof(GridParams) + sizeof(int32_t) * (size_t)(n_cells + 1) +
                            sizeof(int32_t) * (size_t)total);
     if (parts & GPK_INDEX_PIP) {
-        const int32_t rc = build_pip_index(a, ix, s);  // raster + slabs for polygonal arrays
+        const int32_t rc = build_pip_index(a, ix, s, !(parts & GPK_INDEX_PIP_LIGHT));  // raster + slabs for polygonal arrays
         if (rc != GPK_OK) {
             gpk_index_free(ix);
             return rc;
@@ -1579,7 +1579,8 @@ int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right, co
 
     gpk_index* tmp_index = nullptr;
     if (!right_index) {  // built on the fly, like spatial_index.rs:60-71 — only the tables this arm reads
-        GPK_TRY(gpk_index_build_ex(right, GPK_INDEX_BBOX_GRID | (pip ? GPK_INDEX_PIP : 0), nullptr, stream, &tmp_index));
+        // (an index that serves ONE join skips the per-entry records of list cells: they cost more to build than one join saves)
+        GPK_TRY(gpk_index_build_ex(right, GPK_INDEX_BBOX_GRID | (pip ? GPK_INDEX_PIP | GPK_INDEX_PIP_LIGHT : 0), nullptr, stream, &tmp_index));
         right_index = tmp_index;
     } else if (right_index->n_geoms != right->d.n_geoms) {
         return fail(GPK_ERR_INVALID_ARGUMENT, "right_index was built over a different array");

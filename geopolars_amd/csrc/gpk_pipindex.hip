@@ -545,7 +545,7 @@ inline dim3 blocks_for(int64_t n) { return dim3((unsigned)((n + 255) / 256 > 0 ?
 
 namespace gpk {
 
-int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
+int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, bool list_records) {
     memset(&ix->pip, 0, sizeof ix->pip);
     const DevGeo& d = a->d;
     if (!is_polygonal(d.type) || d.n_geoms == 0 || d.n_coords == 0 || d.n_rings == 0) return GPK_OK;
@@ -802,7 +802,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s) {
     // records for the boundary entries of the cells that stayed lists (after the commit: two-part cells are gone)
     int32_t n_lrec = 0;
     SubCell* lrec = nullptr;
-    if (level2_ok && list_len > 0 && !getenv("GPK_NO_LIST_RECORDS")) {
+    if (level2_ok && list_len > 0 && list_records && !getenv("GPK_NO_LIST_RECORDS")) {
         int32_t *lcnt, *lpos;
         GPK_TRY(t.alloc(&lcnt, (size_t)n_cells + 1));
         GPK_TRY(t.alloc(&lpos, (size_t)n_cells + 1));
