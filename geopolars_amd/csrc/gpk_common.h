@@ -93,6 +93,8 @@ Workspace& workspace();
 // second and third per-thread arenas for calls whose scratch is sized in stages (the polygon x polygon join learns its
 // candidate count only after a first pass, and gpk_bounds inside it uses workspace() itself)
 Workspace& workspace_aux(int which);
+// one more arena per (calling thread, stream): scratch of stream-ordered calls that must survive until the stream gets there
+Workspace& workspace_for_stream(hipStream_t s);
 
 inline size_t align256(size_t n) { return (n + 255) & ~size_t(255); }
 

@@ -1225,16 +1225,19 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
                   align256(sizeof(uint32_t) * (size_t)multi_cap) + 1024;
     if (host_out && out_counts) need += align256(counts_bytes);
     if (host_out && want_pairs) need += align256(pairs_bytes);
-    int32_t rc = workspace().begin(need);
+    // scratch of the stream-ordered join: one arena per (calling thread, stream), so that joins a thread enqueues on
+    // DIFFERENT streams never share code / totals buffers (they used to: the header asked callers not to)
+    Workspace& ws = workspace_for_stream(s);
+    int32_t rc = ws.begin(need);
     if (rc != GPK_OK) return rc;
-    uint32_t* code = (uint32_t*)workspace().take(counts_bytes + 64);
-    unsigned long long* btot = (unsigned long long*)workspace().take(sizeof(unsigned long long) * (size_t)(n_blocks + n_super + 3));
+    uint32_t* code = (uint32_t*)ws.take(counts_bytes + 64);
+    unsigned long long* btot = (unsigned long long*)ws.take(sizeof(unsigned long long) * (size_t)(n_blocks + n_super + 3));
     unsigned long long* stot = btot + n_blocks;     // n_super super-tile totals
     unsigned long long* grand = stot + n_super;     // total hits
     uint32_t* multi_top = (uint32_t*)(grand + 1);   // words used in the multi-hit pool (zeroed with the totals)
-    uint32_t* multi_pool = (uint32_t*)workspace().take(sizeof(uint32_t) * (size_t)multi_cap);
-    uint32_t* counts_dev = out_counts ? (host_out ? (uint32_t*)workspace().take(counts_bytes) : out_counts) : nullptr;
-    uint32_t* pairs_dev = want_pairs ? (host_out ? (uint32_t*)workspace().take(pairs_bytes) : out_pairs) : nullptr;
+    uint32_t* multi_pool = (uint32_t*)ws.take(sizeof(uint32_t) * (size_t)multi_cap);
+    uint32_t* counts_dev = out_counts ? (host_out ? (uint32_t*)ws.take(counts_bytes) : out_counts) : nullptr;
+    uint32_t* pairs_dev = want_pairs ? (host_out ? (uint32_t*)ws.take(pairs_bytes) : out_pairs) : nullptr;
 
 
 #define J_LAUNCH(...)                          \

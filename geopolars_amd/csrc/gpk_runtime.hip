@@ -74,6 +74,13 @@ Workspace& workspace() {
     static thread_local Workspace ws;
     return ws;
 }
+Workspace& workspace_for_stream(hipStream_t s) {
+    static thread_local std::vector<std::pair<hipStream_t, Workspace*>> arenas;  // a handful of streams per thread: linear search
+    for (auto& kv : arenas)
+        if (kv.first == s) return *kv.second;
+    arenas.emplace_back(s, new Workspace);  // lives as long as the thread (like the other arenas: never freed at teardown)
+    return *arenas.back().second;
+}
 Workspace& workspace_aux(int which) {
     static thread_local Workspace aux[2];
     return aux[which & 1];

@@ -319,8 +319,8 @@ int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right,
  *   - out_counts / out_pairs are device buffers (either may be NULL as above);
  *   - *n_pairs_dev (device or device-mapped host memory, may be NULL) receives the total number of hits when the
  *     stream reaches that point; pairs beyond pair_capacity are dropped, so compare the two after synchronising.
- * Scratch comes from the calling thread's workspace: stream-ordered calls of one thread must use one stream (or
- * be separated by a synchronisation).
+ * Scratch comes from an arena owned by (calling thread, stream): calls enqueued on different streams do not share
+ * buffers; calls on ONE stream reuse them in stream order.
  */
 int32_t gpk_spatial_join_async(const gpk_geoarray* left, const gpk_geoarray* right,
                                const gpk_index* right_index, int32_t predicate, uint32_t left_row_base,

@@ -285,3 +285,36 @@ def test_self_intersecting_ring_follows_the_oracles_winding_rule(gpk, oracle):
     assert np.array_equal(got_counts, exp_counts) and np.array_equal(got_pairs, exp_pairs)
     core = np.hypot(pts.xy[:, 0] - 50, pts.xy[:, 1] - 50) < 10  # well inside the doubly wound pentagon
     assert got_counts[core].all()
+
+
+def test_stream_ordered_joins_on_two_streams_of_one_thread_do_not_share_scratch(gpk):
+    """gpk_spatial_join_async keeps its scratch per (thread, stream): joins enqueued alternately on two streams, nothing
+    synchronised in between, answer what the blocking join answers"""
+    import torch
+
+    from geopolars_amd.geoarrow import DeviceGeoArray
+    from geopolars_amd.spatial_index import join_pairs_device, join_pairs_enqueue
+
+    dev = torch.device("cuda", 0)
+    polys_host = synth.star_polygons(500, 32)
+    s0 = torch.cuda.current_stream().cuda_stream
+    polys = DeviceGeoArray.upload(polys_host, stream=s0)
+    index = SpatialIndex.from_device(polys, stream=s0)
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    jobs = []
+    for k in range(6):
+        n = 300_000 + 50_000 * k
+        xy = torch.from_numpy(synth.uniform_points(n, seed=200 + k).xy).to(dev)
+        jobs.append({"pts": DeviceGeoArray.from_device_buffers(_abi.GEOM_POINT, xy, stream=s0), "n": n, "counts": torch.empty(n, dtype=torch.int32, device=dev),
+                     "pairs": torch.empty((n, 2), dtype=torch.int32, device=dev), "total": torch.zeros(1, dtype=torch.int64, device=dev)})
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for k, j in enumerate(jobs):
+            join_pairs_enqueue(j["pts"], polys, index, "intersects", j["counts"], j["pairs"], j["total"], stream=streams[k % 2].cuda_stream)
+    torch.cuda.synchronize()
+    for j in jobs:
+        counts = torch.empty(j["n"], dtype=torch.int32, device=dev)
+        pairs = torch.empty((j["n"], 2), dtype=torch.int32, device=dev)
+        h = join_pairs_device(j["pts"], polys, index, "intersects", counts, pairs, stream=s0)
+        assert int(j["total"].item()) == h
+        assert torch.equal(j["counts"], counts) and torch.equal(j["pairs"][:h], pairs[:h])
