@@ -101,6 +101,7 @@ class Ctx:
             os.environ.setdefault("MASTER_PORT", "29511")
             if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
                 os.environ["NCCL_DEBUG"] = "WARN"  # no RCCL version banner on stdout: rank 0 prints ONE JSON line
+            os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")  # RCCL's warnings do not belong on stdout either
             dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
         self.lib = _abi.lib()
         self.dev_name, self.cus = _abi.device_info()
@@ -175,6 +176,17 @@ class Ctx:
     def finish(self):
         if self.use_dist:
             self.dist.destroy_process_group()
+
+
+def emit_line(line: dict) -> None:
+    """Rank 0's ONE JSON line, on a line of its own: RCCL writes its warnings to the C stdout buffer, which is flushed in
+    4 KiB pieces that end mid-line — so the C buffer is flushed first and the JSON starts after a newline."""
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.write("\n" + json.dumps(line) + "\n")
+    sys.stdout.flush()
 
 
 def dev_array(torch, a, dev, stream):
@@ -352,7 +364,7 @@ def run_c2(ctx: Ctx) -> None:
     if ctx.world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_join(s_last["host"], polys_host, "intersects", s_last["counts"], args.cpu_seconds)
     ctx.finish()  # (RCCL may print its banner while the group goes down: the JSON line stays the last line of stdout)
-    print(json.dumps(out), flush=True)
+    emit_line(out)
 
 
 def parity_point_join(pts_host, right_host, predicate: str, gpu_counts, gpu_pairs, h: int, rows: int) -> dict:
@@ -513,7 +525,7 @@ def run_c3(ctx: Ctx) -> None:
     if ctx.world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_distance(pts_host, ls_host, rows_mod, args.cpu_seconds)
     ctx.finish()  # (RCCL may print its banner while the group goes down: the JSON line stays the last line of stdout)
-    print(json.dumps(line), flush=True)
+    emit_line(line)
 
 
 def parity_distance(pts_host, ls_host, rows, gpu_out, k: int) -> dict:
@@ -665,7 +677,7 @@ def run_c4(ctx: Ctx) -> None:
     if W == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_polyjoin(left_host, right_full, counts, args.cpu_seconds)
     ctx.finish()  # (RCCL may print its banner while the group goes down: the JSON line stays the last line of stdout)
-    print(json.dumps(line), flush=True)
+    emit_line(line)
 
 
 def parity_poly_join(left_host, right_host, gpu_counts, gpu_pairs, h: int, base: int, rows: int) -> dict:
@@ -824,7 +836,7 @@ def run_c5(ctx: Ctx) -> None:
     if W == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline_join(pts_host, right_host, "within", counts, args.cpu_seconds)
     ctx.finish()  # (RCCL may print its banner while the group goes down: the JSON line stays the last line of stdout)
-    print(json.dumps(line), flush=True)
+    emit_line(line)
 
 
 def parity_area(host, gpu_area) -> dict:
