@@ -2,10 +2,11 @@
 // closed counter-clockwise exterior, collinear vertices dropped).
 //
 // The hull of a point set is unique, so any exact algorithm returns the same ring up to its start
-// vertex; this kernel emits it starting at the lexicographically smallest vertex.  One lane per
-// geometry for the chain, 16 lanes per geometry for the sort (bitonic network in LDS; a work-group per geometry beyond 128
-// points), then a monotone chain driven by the exact
-// orientation kernel.  Irregular per-row output sizes go through size -> scan -> compact.
+// vertex; this kernel emits it starting at the lexicographically smallest vertex.  Geometries of up to 128 points — the
+// common case — are solved whole by 16 cooperating lanes in LDS (bitonic network, then parallel left-turn filtering of
+// the candidate cycle to its fixed point: hull_small_kernel); larger ones get a work-group each for the sort and one lane
+// for a monotone chain.  Every orientation is the exact kernel's.  Irregular per-row output sizes go through
+// size -> scan -> compact.
 // This is the lowest-traffic operator of the surface; the sort's working set sits in LDS.
 #include "gpk_device.h"
 #include "gpk_scan.h"
@@ -118,10 +119,26 @@ __device__ __forceinline__ int hull_points(const DevGeo& a, int64_t g, int& c0) 
     }
     return n;
 }
-__global__ __launch_bounds__(256) void hull_sort_kernel(DevGeo a, double2* __restrict__ sorted, int32_t* __restrict__ n_pts,
-                                                        int32_t* __restrict__ big_list, int32_t* __restrict__ big_count) {
+// hull_small_kernel: the whole hull of a geometry of at most HULL_CAP points by HULL_GS cooperating lanes, in LDS:
+//   1. bitonic network over the points (coalesced loads, no data-dependent addressing);
+//   2. the candidate cycle L, points strictly below the chord L -> R ascending, R, points strictly above it descending
+//      (L / R = lexicographic extremes; duplicates and points on the chord never enter);
+//   3. rounds of parallel filtering: every candidate whose triple (predecessor, itself, successor) in the current cycle is
+//      not a strict left turn leaves, the survivors are compacted in order (group ballot + prefix popcount), until a round
+//      removes nothing.  A removed point lies on or above (below) a chord of points of its own half, so it is no hull
+//      vertex whatever else leaves in the same round; a cycle of strict left turns through L and R with every other point
+//      proven inside is THE hull — the ring the monotone chain (chain_of) writes, vertex for vertex, because both start at
+//      the smallest point, run counter-clockwise and drop collinear points.  Orientations are exact (dev::orient2d).
+// The hull goes to the geometry's slice of `stack` (coalesced), its size to sizes[g]; rows beyond HULL_CAP points are
+// listed for hull_sort_big_kernel + hull_chain_big_kernel.  The lane-per-geometry chain this replaces walked 2 x 64 points
+// with dependent LDS stack accesses while 63 of 64 memory lanes idled: 4.8 of the 7.4 ms of 2M x 64-vertex polygons.
+__global__ __launch_bounds__(256) void hull_small_kernel(DevGeo a, double2* __restrict__ sorted, int32_t* __restrict__ n_pts,
+                                                         int32_t* __restrict__ big_list, int32_t* __restrict__ big_count,
+                                                         double2* __restrict__ stack, int32_t* __restrict__ sizes) {
     __shared__ double2 lds[(256 / HULL_GS) * HULL_CAP];
-    const int lane = threadIdx.x & (HULL_GS - 1);
+    __shared__ uint8_t s_idx[256 / HULL_GS][2][HULL_CAP + 8];
+    const int lane = threadIdx.x & (HULL_GS - 1), grp = threadIdx.x / HULL_GS;
+    const int gshift = (threadIdx.x & 63) & ~(HULL_GS - 1);  // bit position of this group's lanes in a wave ballot
     const int64_t g = ((int64_t)blockIdx.x * 256 + threadIdx.x) / HULL_GS;
     if (g >= a.n_geoms) return;
     int c0;
@@ -129,9 +146,10 @@ __global__ __launch_bounds__(256) void hull_sort_kernel(DevGeo a, double2* __res
     if (lane == 0) {
         n_pts[g] = n;
         if (n > HULL_CAP) big_list[atomicAdd(big_count, 1)] = (int32_t)g;  // order is irrelevant: one work-group each
+        if (n <= 0) sizes[g] = 0;
     }
-    if (n <= 0 || n > HULL_CAP) return;  // empty, or left to hull_sort_big_kernel
-    double2* __restrict__ v = lds + (threadIdx.x / HULL_GS) * HULL_CAP;
+    if (n <= 0 || n > HULL_CAP) return;
+    double2* __restrict__ v = lds + grp * HULL_CAP;
     int P = 2;
     while (P < n) P <<= 1;
     for (int i = lane; i < P; i += HULL_GS) v[i] = i < n ? a.xy[c0 + i] : make_double2(INFINITY, INFINITY);  // sentinels sort last
@@ -154,7 +172,79 @@ __global__ __launch_bounds__(256) void hull_sort_kernel(DevGeo a, double2* __res
             }
         }
     sync();
-    for (int i = lane; i < n; i += HULL_GS) sorted[c0 + i] = v[i];
+    double2* __restrict__ h = stack + 2 * (int64_t)c0 + 2 * g;
+    const double2 L = v[0], R = v[n - 1];
+    if (L.x == R.x && L.y == R.y) {  // one distinct point
+        if (lane == 0) {
+            h[0] = L;
+            h[1] = L;
+            sizes[g] = 2;
+        }
+        return;
+    }
+    auto gballot = [&](bool c) -> uint32_t { return (uint32_t)(__ballot(c) >> gshift) & ((1u << HULL_GS) - 1u); };
+    const uint32_t below = (1u << lane) - 1u;
+    uint8_t* cur = s_idx[grp][0];
+    uint8_t* nxt = s_idx[grp][1];
+    // candidate cycle: interior points i = 1 .. n-2 in chunks of HULL_GS, lane = point; side[] keeps the chord test
+    constexpr int CH = (HULL_CAP + HULL_GS - 1) / HULL_GS;
+    int side[CH];
+    int cnt = 1;
+    if (lane == 0) cur[0] = 0;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        const int i = 1 + c * HULL_GS + lane;
+        side[c] = 0;
+        if (i < n - 1) {
+            const double2 p = v[i], q = v[i - 1];
+            if (!(p.x == q.x && p.y == q.y)) side[c] = dev::orient2d(L.x, L.y, R.x, R.y, p.x, p.y);
+        }
+        const uint32_t m = gballot(side[c] < 0);
+        if (side[c] < 0) cur[cnt + __popc(m & below)] = (uint8_t)i;
+        cnt += __popc(m);
+    }
+    if (lane == 0) cur[cnt] = (uint8_t)(n - 1);
+    ++cnt;
+#pragma unroll
+    for (int c = CH - 1; c >= 0; --c) {
+        const int i = 1 + c * HULL_GS + lane;
+        const uint32_t m = gballot(side[c] > 0);
+        if (side[c] > 0) cur[cnt + __popc(m >> (lane + 1))] = (uint8_t)i;  // descending within the chunk
+        cnt += __popc(m);
+    }
+    for (;;) {
+        sync();
+        int kept = 0;
+        for (int b = 0; b < cnt; b += HULL_GS) {
+            const int t = b + lane;
+            bool keep = false;
+            int i = 0;
+            if (t < cnt) {
+                i = cur[t];
+                if (i == 0 || i == n - 1) {
+                    keep = true;
+                } else {
+                    const double2 pa = v[cur[t - 1]], pb = v[i], pc = v[cur[t + 1 == cnt ? 0 : t + 1]];
+                    keep = dev::orient2d(pa.x, pa.y, pb.x, pb.y, pc.x, pc.y) > 0;
+                }
+            }
+            const uint32_t m = gballot(keep);
+            if (keep) nxt[kept + __popc(m & below)] = (uint8_t)i;
+            kept += __popc(m);
+        }
+        uint8_t* t = cur;
+        cur = nxt;
+        nxt = t;
+        const bool done = kept == cnt;  // uniform within the group
+        cnt = kept;
+        if (done) break;
+    }
+    sync();
+    for (int j = lane; j < cnt; j += HULL_GS) h[j] = v[cur[j]];
+    if (lane == 0) {
+        h[cnt] = L;  // close the ring
+        sizes[g] = cnt + 1;
+    }
 }
 // One work-group per geometry beyond HULL_CAP points (their ids were appended to big_list by hull_sort_kernel): the
 // normalised bitonic network — every comparator ascending, so a partner index beyond n is simply skipped, which is the
@@ -198,43 +288,36 @@ __global__ __launch_bounds__(256) void hull_sort_big_kernel(DevGeo a, double2* _
         __syncthreads();  // the LDS tile is reused by the next geometry of this work-group
     }
 }
-// one wave per work-group: when every geometry of the wave has at most HULL_STACK points the index stacks sit in an LDS
-// tile, interleaved by lane (entry k of lane l at [k * 64 + l]); otherwise the wave keeps them in global scratch
-constexpr int HULL_STACK = 129;  // stack depth: up to n + 1 entries for n points
-__global__ __launch_bounds__(64) void hull_chain_kernel(DevGeo a, const double2* __restrict__ sorted, const int32_t* __restrict__ n_pts,
-                                                         double2* __restrict__ stack, int32_t* __restrict__ idx_scratch,
-                                                         int32_t* __restrict__ sizes) {
-    __shared__ uint16_t s_idx[(HULL_STACK + 1) * 64];
-    const int lane = threadIdx.x;
-    const int64_t g = (int64_t)blockIdx.x * 64 + lane;
-    const int n = g < a.n_geoms ? n_pts[g] : 0;
-    const bool all_fit = __all(n <= HULL_STACK - 1);  // wave-uniform
-    if (n <= 0) {
-        if (g < a.n_geoms) sizes[g] = 0;
-        return;
-    }
-    int c0, c1;
-    geom_coord_range(a, g, c0, c1);
-    const double2* __restrict__ p = sorted + c0;
-    double2* __restrict__ h = stack + 2 * (int64_t)c0 + 2 * g;
-    auto ld = [&](int i) { return p[i]; };
-    if (all_fit) {
-        sizes[g] = chain_of(ld, n, [&](int k, int i) { s_idx[k * 64 + lane] = (uint16_t)i; }, [&](int k) { return (int)s_idx[k * 64 + lane]; }, h);
-    } else {
+// geometries beyond HULL_CAP points (sorted by hull_sort_big_kernel): one lane per listed geometry runs the monotone
+// chain with its index stack in the global scratch
+__global__ __launch_bounds__(64) void hull_chain_big_kernel(DevGeo a, const double2* __restrict__ sorted, const int32_t* __restrict__ n_pts,
+                                                             const int32_t* __restrict__ big_list, const int32_t* __restrict__ big_count,
+                                                             double2* __restrict__ stack, int32_t* __restrict__ idx_scratch,
+                                                             int32_t* __restrict__ sizes) {
+    const int n_big = *big_count;
+    for (int b = blockIdx.x * 64 + threadIdx.x; b < n_big; b += gridDim.x * 64) {
+        const int64_t g = big_list[b];
+        const int n = n_pts[g];
+        int c0, c1;
+        geom_coord_range(a, g, c0, c1);
+        const double2* __restrict__ p = sorted + c0;
+        double2* __restrict__ h = stack + 2 * (int64_t)c0 + 2 * g;
         int32_t* __restrict__ st = idx_scratch + 2 * (int64_t)c0 + 2 * g;
-        sizes[g] = chain_of(ld, n, [&](int k, int i) { st[k] = i; }, [&](int k) { return (int)st[k]; }, h);
+        sizes[g] = chain_of([&](int i) { return p[i]; }, n, [&](int k, int i) { st[k] = i; }, [&](int k) { return (int)st[k]; }, h);
     }
 }
 
-__global__ void hull_compact_kernel(DevGeo a, const double2* __restrict__ stack, const int32_t* __restrict__ off,
-                                    double2* __restrict__ out) {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// HULL_GS lanes per geometry copy its hull from the scratch slice to its place in the output (coalesced both ways)
+__global__ __launch_bounds__(256) void hull_compact_kernel(DevGeo a, const double2* __restrict__ stack, const int32_t* __restrict__ off,
+                                                           double2* __restrict__ out) {
+    const int lane = threadIdx.x & (HULL_GS - 1);
+    const int64_t g = ((int64_t)blockIdx.x * 256 + threadIdx.x) / HULL_GS;
     if (g >= a.n_geoms) return;
     int c0, c1;
     geom_coord_range(a, g, c0, c1);
-    const double2* h = stack + 2 * (int64_t)c0 + 2 * g;
+    const double2* __restrict__ h = stack + 2 * (int64_t)c0 + 2 * g;
     const int o = off[g], n = off[g + 1] - o;
-    for (int i = 0; i < n; ++i) out[o + i] = h[i];
+    for (int i = lane; i < n; i += HULL_GS) out[o + i] = h[i];
 }
 
 }  // namespace gpk
@@ -271,17 +354,18 @@ extern "C" int32_t gpk_convex_hull(const gpk_geoarray* a, double* out_xy, int32_
     }
     const dim3 grid((unsigned)nb), block(256);
     GPK_HIP(hipMemsetAsync(big_list + n, 0, sizeof(int32_t), s));
-    GPK_LAUNCH("gpk_hull_sort", hull_sort_kernel, dim3((unsigned)((n * HULL_GS + 255) / 256)), dim3(256), 0, s, a->d, sorted, n_pts, big_list,
-               big_list + n);
+    const dim3 ggrid((unsigned)((n * HULL_GS + 255) / 256));
+    GPK_LAUNCH("gpk_hull_small", hull_small_kernel, ggrid, block, 0, s, a->d, sorted, n_pts, big_list, big_list + n, stack, sizes);
     {
         const int64_t big_blocks = n < (int64_t)cu_count() * 8 ? n : (int64_t)cu_count() * 8;
         GPK_LAUNCH("gpk_hull_sort_big", hull_sort_big_kernel, dim3((unsigned)big_blocks), block, 0, s, a->d, sorted, (const int32_t*)n_pts,
                    (const int32_t*)big_list, (const int32_t*)(big_list + n));
+        const int64_t chain_blocks = (n + 63) / 64 < (int64_t)cu_count() * 16 ? (n + 63) / 64 : (int64_t)cu_count() * 16;
+        GPK_LAUNCH("gpk_hull_chain_big", hull_chain_big_kernel, dim3((unsigned)chain_blocks), dim3(64), 0, s, a->d, (const double2*)sorted,
+                   (const int32_t*)n_pts, (const int32_t*)big_list, (const int32_t*)(big_list + n), stack, idx_scratch, sizes);
     }
-    GPK_LAUNCH("gpk_hull_chain", hull_chain_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, a->d, (const double2*)sorted, (const int32_t*)n_pts, stack,
-               idx_scratch, sizes);
     GPK_TRY(exclusive_scan_i32(sizes, n, off_dev, nullptr, btot, s));
-    GPK_LAUNCH("gpk_hull_compact", hull_compact_kernel, grid, block, 0, s, a->d, stack, off_dev, out_dev);
+    GPK_LAUNCH("gpk_hull_compact", hull_compact_kernel, ggrid, block, 0, s, a->d, stack, off_dev, out_dev);
     if (host_out) {
         GPK_TRY(copy_out(out_ring_offsets, out_space, off_dev, off_bytes, s));
         const int32_t total = out_ring_offsets[n];

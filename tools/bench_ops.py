@@ -29,7 +29,7 @@ def dev_array(a, dev):
     )
 
 
-def timed(lib, fn, reps=10):
+def timed_impl(lib, fn, reps=10):
     stream = torch.cuda.current_stream().cuda_stream
     for _ in range(2):
         fn(stream)
@@ -65,14 +65,21 @@ def timed(lib, fn, reps=10):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--ops", default="", help="comma-separated subset of operators (default: all)")
     args = ap.parse_args()
+    only = set(x for x in args.ops.split(",") if x)
     lib = _abi.lib()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     name, cus = _abi.device_info()
     MEM_DEVICE = _abi.MEM_DEVICE
 
+    def timed(lib_, fn, reps=10, _t=timed_impl):  # an operator that was not asked for is not run
+        return _t(lib_, fn, reps) if (not only or timed.op in only) else (None, None)
+
     def report(op, workload, ms, kernels, nbytes):
+        if ms is None:
+            return
         gbs = nbytes / (ms * 1e-3) / 1e9
         print(json.dumps({"op": op, "workload": workload, "ms": ms, "kernels_ms": kernels, "algorithmic_bytes": nbytes, "GBps": gbs, "frac_of_8TBps": gbs / PEAK, "device": name}), flush=True)
 
@@ -92,19 +99,25 @@ def main():
         outv = torch.empty(n, dtype=torch.uint8, device=dev)
         outxy = torch.empty((v, 2), dtype=torch.float64, device=dev)
         m6 = (C.c_double * 6)(0.5, -0.25, 3.0, 0.25, 0.5, -7.0)
+        timed.op = "area"
         ms, k = timed(lib, lambda s: _abi.check(lib.gpk_area(d.handle, out1.data_ptr(), MEM_DEVICE, s)))
         report("area", wname, ms, k, 16 * v + off_bytes + 8 * n)
+        timed.op = "bounds"
         ms, k = timed(lib, lambda s: _abi.check(lib.gpk_bounds(d.handle, out4.data_ptr(), MEM_DEVICE, s)))
         report("bounds", wname, ms, k, 16 * v + off_bytes + 32 * n)
+        timed.op = "centroid"
         ms, k = timed(lib, lambda s: _abi.check(lib.gpk_centroid(d.handle, out2.data_ptr(), outv.data_ptr(), MEM_DEVICE, s)))
         report("centroid", wname, ms, k, 16 * v + off_bytes + 17 * n)
+        timed.op = "affine_transform"
         ms, k = timed(lib, lambda s: _abi.check(lib.gpk_affine_transform(d.handle, m6, outxy.data_ptr(), MEM_DEVICE, s)))
         report("affine_transform", wname, ms, k, 32 * v)
+        timed.op = "euclidean_length"
         ms, k = timed(lib, lambda s: _abi.check(lib.gpk_euclidean_length(d.handle, out1.data_ptr(), MEM_DEVICE, s)))
         report("euclidean_length", wname, ms, k, 16 * v + off_bytes + 8 * n)
         if wname.startswith("2M"):
             hxy = torch.empty((v + n, 2), dtype=torch.float64, device=dev)
             hoff = torch.empty(n + 1, dtype=torch.int32, device=dev)
+            timed.op = "convex_hull"
             ms, k = timed(lib, lambda s: _abi.check(lib.gpk_convex_hull(d.handle, hxy.data_ptr(), hoff.data_ptr(), MEM_DEVICE, s)), reps=3)
             report("convex_hull", wname, ms, k, 32 * v + off_bytes)
             del hxy, hoff
@@ -113,6 +126,7 @@ def main():
         _abi.check(lib.gpk_geoarray_to_wkb(d.handle, None, None, 0, C.byref(nb), MEM_DEVICE, None))
         wkb = torch.empty(int(nb.value), dtype=torch.uint8, device=dev)
         woff = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        timed.op = "to_wkb"
         ms, k = timed(lib, lambda s: _abi.check(lib.gpk_geoarray_to_wkb(d.handle, woff.data_ptr(), wkb.data_ptr(), int(nb.value), C.byref(nb), MEM_DEVICE, s)), reps=5)
         report("to_wkb", wname, ms, k, 16 * v + off_bytes + int(nb.value) + 4 * n)
         # WKB -> GeoArrow on the device (the bytes are already in HBM)
@@ -120,6 +134,7 @@ def main():
             out, gt = C.c_void_p(), C.c_int32(-1)
             _abi.check(lib.gpk_geoarray_from_wkb(wkb.data_ptr(), woff.data_ptr(), n, None, MEM_DEVICE, s, C.byref(out), C.byref(gt)))
             lib.gpk_geoarray_free(out)
+        timed.op = "from_wkb"
         ms, k = timed(lib, decode, reps=3)
         report("from_wkb", wname, ms, k, int(nb.value) + 4 * n + 16 * v + off_bytes)
         del d, out1, out2, out4, outv, outxy, wkb, woff
@@ -133,6 +148,7 @@ def main():
     out = torch.empty(npts, dtype=torch.float64, device=dev)
     for label, rows in (("rows = i mod L", np.arange(npts, dtype=np.uint32) % nls), ("rows shuffled", np.random.default_rng(1).permutation(np.arange(npts, dtype=np.uint32) % nls))):
         r = torch.from_numpy(rows.astype(np.int32)).to(dev)
+        timed.op = "distance"
         ms, k = timed(lib, lambda s: _abi.check(lib.gpk_distance_rowwise(dp.handle, dl.handle, r.data_ptr(), out.data_ptr(), MEM_DEVICE, s)), reps=5)
         # 16N + 4N + 16*V_ls + 4(L+1) + 8N (each distinct byte once)
         report("distance", f"C3: {npts} points x {nls} linestrings ({ls.n_coords} coords), {label}", ms, k, 16 * npts + 4 * npts + 16 * ls.n_coords + 4 * (nls + 1) + 8 * npts)
