@@ -16,6 +16,8 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <chrono>
+
 #include "gpk_device.h"
 #include "gpk_index.h"
 #include "gpk_pip.h"
@@ -27,6 +29,42 @@
 namespace gpk {
 
 // ================================= index build ==================================================
+// stage 1 of the extent: one closed box per work-group (NaN = nothing but empty geometries), in the boxes' own format, so
+// that extent_kernel folds them like boxes (min / max are exact: the result does not depend on the split)
+__global__ __launch_bounds__(256) void extent_partial_kernel(const double4* __restrict__ bbox, int64_t n, double4* __restrict__ part) {
+    __shared__ double red[4][4];
+    double mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double4 b = bbox[i];
+        if (b.x == b.x) {
+            mnx = fmin(mnx, b.x);
+            mny = fmin(mny, b.y);
+            mxx = fmax(mxx, b.z);
+            mxy = fmax(mxy, b.w);
+        }
+    }
+    mnx = dev::wave_min(mnx);
+    mny = dev::wave_min(mny);
+    mxx = dev::wave_max(mxx);
+    mxy = dev::wave_max(mxy);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[0][wave] = mnx;
+        red[1][wave] = mny;
+        red[2][wave] = mxx;
+        red[3][wave] = mxy;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            mnx = fmin(mnx, red[0][w]);
+            mny = fmin(mny, red[1][w]);
+            mxx = fmax(mxx, red[2][w]);
+            mxy = fmax(mxy, red[3][w]);
+        }
+        part[blockIdx.x] = mnx <= mxx ? make_double4(mnx, mny, mxx, mxy) : make_double4(NAN, NAN, NAN, NAN);
+    }
+}
 __global__ __launch_bounds__(1024) void extent_kernel(const double4* __restrict__ bbox, int64_t n,
                                                       int gx, int gy, GridParams* __restrict__ out) {
     __shared__ double red[4][16];
@@ -1481,6 +1519,15 @@ int32_t gpk_index_build_ex(const gpk_geoarray* a, int32_t parts, const double* b
         if (_rc != GPK_OK) return cleanup(_rc);  \
     } while (0)
 
+    const bool dbg_time = getenv("GPK_DEBUG_INDEX") != nullptr;  // wall time of the directory phases (the stream is drained per stamp)
+    auto t_last = std::chrono::steady_clock::now();
+    auto stamp = [&](const char* what) {
+        if (!dbg_time) return;
+        (void)hipStreamSynchronize(s);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[gpk] index build: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     double4* bbox = nullptr;
     GridParams* grid = nullptr;
     int32_t* cell_off = nullptr;
@@ -1498,16 +1545,25 @@ int32_t gpk_index_build_ex(const gpk_geoarray* a, int32_t parts, const double* b
     else
         IX_TRY(gpk_bounds(a, (double*)bbox, GPK_MEM_DEVICE, stream));
 
-    // 2. extent + grid parameters, all on device
-    IX_LAUNCH("gpk_index_extent", extent_kernel, dim3(1), dim3(1024), 0, s, bbox, n, gdim, gdim, grid);
-
-    // 3. count, scan, fill, sort
+    stamp("boxes (gpk_bounds)");
+    // 2. extent + grid parameters, all on device (two stages beyond a few thousand boxes: one work-group walked 5M of them in 4.7 ms)
     const int64_t n_blocks = (n_cells + 255) / 256;
+    const int64_t ext_blocks = n > 65536 ? 1024 : 0;
     IX_TRY(workspace().begin(align256(sizeof(int32_t) * (size_t)(n_cells + 1)) * 2 +
-                             align256(sizeof(unsigned long long) * (size_t)(n_blocks + 1)) + 1024));
+                             align256(sizeof(unsigned long long) * (size_t)(n_blocks + 1)) + align256(sizeof(double4) * 1024) + 1024));
     int32_t* cell_cnt = (int32_t*)workspace().take(sizeof(int32_t) * (size_t)(n_cells + 1));
     int32_t* cursor = (int32_t*)workspace().take(sizeof(int32_t) * (size_t)(n_cells + 1));
     unsigned long long* btot = (unsigned long long*)workspace().take(sizeof(unsigned long long) * (size_t)(n_blocks + 1));
+    double4* ext_part = (double4*)workspace().take(sizeof(double4) * 1024);
+    if (ext_blocks) {
+        IX_LAUNCH("gpk_index_extent_partial", extent_partial_kernel, dim3((unsigned)ext_blocks), dim3(256), 0, s, bbox, n, ext_part);
+        IX_LAUNCH("gpk_index_extent", extent_kernel, dim3(1), dim3(1024), 0, s, (const double4*)ext_part, ext_blocks, gdim, gdim, grid);
+    } else {
+        IX_LAUNCH("gpk_index_extent", extent_kernel, dim3(1), dim3(1024), 0, s, bbox, n, gdim, gdim, grid);
+    }
+
+    stamp("extent");
+    // 3. count, scan, fill, sort
     IX_HIP(hipMemsetAsync(cell_cnt, 0, sizeof(int32_t) * (size_t)(n_cells + 1), s));
     if (n > 0)
         IX_LAUNCH("gpk_index_count", grid_register_kernel<false>, grid_for(n, 256), dim3(256), 0, s, bbox, n, grid, cell_cnt, (int32_t*)nullptr);
@@ -1526,6 +1582,7 @@ int32_t gpk_index_build_ex(const gpk_geoarray* a, int32_t parts, const double* b
         IX_LAUNCH("gpk_index_sort", cell_sort_kernel, grid_for(n_cells, 256), dim3(256), 0, s, cell_off, n_cells, items);
     }
     IX_HIP(hipStreamSynchronize(s));  // the workspace may be recycled by the next call on another stream
+    stamp("directory");
 #undef IX_HIP
 #undef IX_TRY
 #undef IX_LAUNCH

@@ -21,6 +21,8 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <chrono>
+
 #include "gpk_device.h"
 #include "gpk_index.h"
 #include "gpk_pip.h"
@@ -361,6 +363,7 @@ __global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, Fi
     const double cyl = g.ry0 + (double)(S * cj) * fh2 - py2, cyh = g.ry0 + (double)(S * cj + S) * fh2 + py2;
     int n_list = 0;         // wave-uniform
     bool list_ok = true;    // false: more than SUB_EDGE_CAP edges meet the cell -> every lane walks the slabs itself
+
     for (int q = 0; q < NP && list_ok; ++q) {
         if (!crosses[q]) continue;
         int r0, r1;
@@ -468,7 +471,19 @@ __global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, Fi
             slabs_of(part[1], r2->b_part_flags, r2->b_e0, r2->b_e1, r2->b_e2);
         }
     }
-    atomicOr(&rec->labels[k >> 4], label << (2 * (k & 15)));
+    // the 64 labels of the record: two ballots (low / high label bit), lanes 0..3 interleave their 16 sub-cells' bits into one
+    // word each and store it — 64 global atomics on four addresses per record were most of this kernel's time
+    const unsigned long long lo = __ballot((label & 1u) != 0), hi = __ballot((label & 2u) != 0);
+    if (k < 4) {
+        auto spread16 = [](uint32_t x) {
+            x = (x | (x << 8)) & 0x00FF00FFu;
+            x = (x | (x << 4)) & 0x0F0F0F0Fu;
+            x = (x | (x << 2)) & 0x33333333u;
+            x = (x | (x << 1)) & 0x55555555u;
+            return x;
+        };
+        rec->labels[k] = spread16((uint32_t)(lo >> (16 * k)) & 0xFFFFu) | (spread16((uint32_t)(hi >> (16 * k)) & 0xFFFFu) << 1);
+    }
 }
 __global__ void sub_commit_kernel(const int32_t* __restrict__ flag, const int32_t* __restrict__ pos, const int32_t* __restrict__ flag2,
                                   const int32_t* __restrict__ pos2, int64_t n_cells, uint32_t* __restrict__ cell) {
@@ -524,12 +539,17 @@ struct Temps {  // scratch of the build: carved from the thread's auxiliary aren
                 // exit path) only when the arena's estimate was too small
     void* p[48] = {nullptr};
     int n = 0;
+    double malloc_ms = 0.0;  // GPK_DEBUG_INDEX: time spent in hipMalloc for temporaries the arena could not hold
+    size_t malloc_bytes = 0;
     template <typename T>
     int32_t alloc(T** out, size_t count) {
         const size_t bytes = sizeof(T) * (count ? count : 1);
         void* q = gpk::workspace_aux(1).take(bytes);
         if (!q) {
+            const auto t0 = std::chrono::steady_clock::now();
             hipError_t e = hipMalloc(&q, bytes);
+            malloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            malloc_bytes += bytes;
             if (e != hipSuccess) return fail(GPK_ERR_OOM, "index build: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
             if (n < 48) p[n++] = q;
         }
@@ -537,7 +557,11 @@ struct Temps {  // scratch of the build: carved from the thread's auxiliary aren
         return GPK_OK;
     }
     ~Temps() {
+        const auto t0 = std::chrono::steady_clock::now();
         for (int i = 0; i < n; ++i) (void)hipFree(p[i]);
+        if (getenv("GPK_DEBUG_INDEX"))
+            fprintf(stderr, "[gpk] index build: %d temporaries beyond the arena (%.2f GB): hipMalloc %.3f ms, hipFree %.3f ms\n", n, (double)malloc_bytes / 1e9,
+                    malloc_ms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     }
 };
 inline dim3 blocks_for(int64_t n) { return dim3((unsigned)((n + 255) / 256 > 0 ? (n + 255) / 256 : 1)); }
@@ -584,6 +608,16 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, boo
         (void)workspace_aux(1).begin(est);
     }
     Temps t;
+    // GPK_DEBUG_INDEX=1: wall time of every phase of the build (the stream is drained at each stamp)
+    const bool dbg_time = getenv("GPK_DEBUG_INDEX") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto stamp = [&](const char* what) {
+        if (!dbg_time) return;
+        (void)hipStreamSynchronize(s);
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[gpk] index build: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     int slot = 4;  // ix->owned[0..3] belong to the coarse directory
     auto keep = [&](void* p) {
         if (slot < 24) ix->owned[slot++] = p;
@@ -604,6 +638,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, boo
     double4* ring_bbox;
     GPK_TRY(t.alloc(&ring_bbox, (size_t)n_rings));
     GPK_TRY(ring_bboxes(a, ring_bbox, s));
+    stamp("ring maps + ring boxes");
     int32_t *row0 = nullptr, *nrows, *slab_base = nullptr;
     GPK_HIP(hipMalloc((void**)&row0, sizeof(int32_t) * (size_t)n_rings));
     keep(row0);
@@ -658,12 +693,14 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, boo
         }
         if (max_shift == 0 || (int64_t)n_edges <= 8 * d.n_coords + (1 << 20)) break;
     }
+    stamp("slab rows + counts");
     double4* edges = nullptr;
     GPK_HIP(hipMalloc((void**)&edges, sizeof(double4) * (size_t)(n_edges ? n_edges : 1)));
     keep(edges);
     GPK_LAUNCH("gpk_pipidx_slab_fill", slab_register_kernel<true>, blocks_for(d.n_coords), dim3(256), 0, s, d, gs, row0, slab_base,
                cursor, edges);
 
+    stamp("slab fill (+ edges malloc)");
     PartInfo* part_info = nullptr;
     GPK_HIP(hipMalloc((void**)&part_info, sizeof(PartInfo) * (size_t)(n_parts ? n_parts : 1)));
     keep(part_info);
@@ -685,6 +722,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, boo
     pv.slab_off = slab_off;
     pv.slab_edges = edges;
 
+    stamp("part info");
     // ---- boundary marks: (cell, part) keys, sorted + unique ---------------------------------------
     int32_t *mark_cnt, *mark_off;
     GPK_TRY(t.alloc(&mark_cnt, (size_t)d.n_coords + 1));
@@ -697,6 +735,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, boo
     GPK_HIP(hipStreamSynchronize(s));
     if (n_marks_raw >= (1ull << 31))
         return GPK_OK;  // pathological (huge edges over a fine raster): leave the accelerator off
+    stamp("mark count + scan");
     unsigned long long *keys, *sorted, *marks;
     GPK_TRY(t.alloc(&keys, (size_t)n_marks_raw));
     GPK_TRY(t.alloc(&sorted, (size_t)n_marks_raw));
@@ -725,6 +764,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, boo
         n_marks = nu;
     }
 
+    stamp("mark fill + sort + unique");
     // ---- cells ----------------------------------------------------------------------------------
     uint32_t* cell = nullptr;
     GPK_HIP(hipMalloc((void**)&cell, sizeof(uint32_t) * (size_t)n_cells));
@@ -748,6 +788,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, boo
     pv.cell = cell;
     pv.list = list;
 
+    stamp("cells");
     // ---- level 2 ------------------------------------------------------------------------------------
     int32_t n_sub = 0, n_sub2 = 0;
     bool sub_overflow = false;
@@ -797,6 +838,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, boo
             GPK_HIP(hipStreamSynchronize(s));
         }
     }
+    stamp("level-2 records");
     pv.sub = sub;
     pv.sub2 = sub2;
     // records for the boundary entries of the cells that stayed lists (after the commit: two-part cells are gone)
@@ -830,6 +872,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, boo
             n_lrec = 0;
         }
     }
+    stamp("list-cell records");
     pv.lrec = lrec;
     // (Nearly) every cell is empty / strictly inside one part / crossed by one part with an inline level-2 record: a point has
     // one candidate part and the join runs its lean kernel (gpk_join.hip: pip_tile_lean_kernel).  Disjoint polygons

@@ -37,6 +37,19 @@ def test_library_exports_every_header_symbol():
     assert b"gfx950" in lib.gpk_version()
 
 
+def test_integration_doc_names_every_symbol():
+    """INTEGRATION.md's table and Rust shim cover the whole ABI: every entry point of the header appears as an extern line"""
+    hdr = open(os.path.join(ROOT, "include", "geopolars_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(gpk_[a-z0-9_]+)\s*\(", hdr))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    shim = doc[doc.index("extern \"C\" {") : doc.index("fn check(rc: i32)")]
+    missing = sorted(n for n in declared if not re.search(r"fn %s\(" % n, shim))
+    assert not missing, missing
+    table = doc[: doc.index("## 2. The Rust shim")]
+    assert not sorted(n for n in declared if n not in table)
+
+
 def test_no_cpu_fallback_without_device():
     """The product path must fail loudly when no gfx950 is present (this container has no GPU)."""
     if _abi.device_count() > 0:
