@@ -739,7 +739,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, boo
     unsigned long long *keys, *sorted, *marks;
     GPK_TRY(t.alloc(&keys, (size_t)n_marks_raw));
     GPK_TRY(t.alloc(&sorted, (size_t)n_marks_raw));
-    GPK_TRY(t.alloc(&marks, (size_t)n_marks_raw));
+    marks = keys;  // the unsorted keys are dead once the sort has run: the unique marks are compacted into their buffer
     int64_t n_marks = 0;
     if (n_marks_raw > 0) {
         GPK_LAUNCH("gpk_pipidx_mark_fill", mark_kernel<true>, blocks_for(d.n_coords), dim3(256), 0, s, d, g, ring_part, mark_off, keys);

@@ -348,26 +348,42 @@ __device__ __forceinline__ void seq_stats_group_body(const double2* __restrict__
     for (int64_t k = (int64_t)block * (256 / G) + threadIdx.x / G; k < n_list; k += groups_per_grid) {
         const int64_t s = list ? (int64_t)list[k] : k;
         if ((MASK & M_DEGEN) && stats[ST_AREA2 * n_seq + s] != 0.0) continue;  // group-uniform
-        const int c0 = seq_off[s], c1 = seq_off[s + 1];
+        // Two-lane groups walk sequences of a handful of coordinates: the two offsets and the two end points were four of
+        // their ~nine load instructions.  PAIR: each lane loads one offset and they swap (DPP); the first vertex is lane 0's
+        // first load; whether the ring is closed is decided at the end from the last vertex a lane held (the terms are
+        // accumulated as if it were and dropped when it is not — the same sum, since an open sequence added nothing before).
+        constexpr bool PAIR = G == 2;
+        int c0, c1;
+        if (PAIR) {
+            const int mine = seq_off[s + lane], other = dev::dpp_mov<0xB1>(mine);  // quad_perm [1,0,3,2]
+            c0 = lane == 0 ? mine : other;
+            c1 = lane == 0 ? other : mine;
+        } else {
+            c0 = seq_off[s];
+            c1 = seq_off[s + 1];
+        }
         const int n = c1 - c0;
         double a2 = 0, acx = 0, acy = 0, len = 0, lmx = 0, lmy = 0, sx_ = 0, sy_ = 0;
         double mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
         double2 first = make_double2(0, 0), last = make_double2(0, 0);
-        if (n > 0) {
+        if (!PAIR && n > 0) {
             first = xy[c0];
             last = xy[c1 - 1];
         }
         // twice_signed_ring_area: < 3 coords or open -> 0 (area.rs); centroid's add_ring uses the same
-        const bool closed_ring = n >= 3 && first.x == last.x && first.y == last.y;
+        bool closed_ring = PAIR ? n >= 3 : (n >= 3 && first.x == last.x && first.y == last.y);
         // ONE load per vertex: lane l holds vertex c0 + t*G + l in round t; the edge's other end is the neighbour lane's
         // vertex (DPP row shift), and for the group's last lane the first lane's vertex of the NEXT round, which is
         // prefetched one round ahead anyway.  Trip count is uniform within the group (all its lanes stay active for DPP).
         constexpr bool EDGES = (MASK & (M_AREA | M_CENT | M_LEN | M_LENC)) != 0;
         int i = c0 + lane;
         double2 cur = i < c1 ? xy[i] : make_double2(0.0, 0.0);
+        double2 held = cur;  // PAIR: the last vertex this lane loaded
+        if (PAIR) first = make_double2(dev::dpp_mov<0xA0>(cur.x), dev::dpp_mov<0xA0>(cur.y));  // quad_perm [0,0,2,2]: lane 0's vertex
         for (int base = c0; base < c1; base += G, i += G) {
             const double2 nxt = i + G < c1 ? xy[i + G] : make_double2(0.0, 0.0);
             const double2 p = cur;
+            if (PAIR && i < c1) held = p;
             double2 q = make_double2(0.0, 0.0);
             if (EDGES) {
                 const double ax = dev::dpp_mov<0x101>(cur.x), ay = dev::dpp_mov<0x101>(cur.y);                  // row_shl:1
@@ -406,6 +422,12 @@ __device__ __forceinline__ void seq_stats_group_body(const double2* __restrict__
                     }
                 }
             }
+        }
+        if (PAIR && (MASK & (M_AREA | M_CENT))) {  // closed? the last vertex sits with lane (n - 1) & 1
+            const double ox = dev::dpp_mov<0xB1>(held.x), oy = dev::dpp_mov<0xB1>(held.y);
+            const double2 lastv = ((n - 1) & 1) == lane ? held : make_double2(ox, oy);
+            closed_ring = closed_ring && first.x == lastv.x && first.y == lastv.y;
+            if (!closed_ring) a2 = acx = acy = 0.0;
         }
         if (MASK & (M_AREA | M_CENT)) a2 = group_sum<G>(a2);
         if (MASK & M_CENT) {
