@@ -174,7 +174,10 @@ constexpr int PIP_OVF = 256;                   // per-tile overflow list for poi
 #endif
 constexpr int PIP_QCAP = GPK_PIP_QCAP;             // LDS queue capacity (overflow is resolved inline, still exact)
 constexpr int PIP_SUPER_SHIFT = 6;             // 64 tiles per super-tile (two-level prefix of the tile totals)
-constexpr int PIP_WPT = 8;                     // writer: consecutive points per thread
+#ifndef GPK_WR_WPT
+#define GPK_WR_WPT 8
+#endif
+constexpr int PIP_WPT = GPK_WR_WPT;            // writer: consecutive points per thread (a multiple of 4: 16-byte code loads)
 constexpr int PIP_WTILE = WR_BLOCK * PIP_WPT;  // writer: points per work-group (a multiple of PIP_TILE)
 constexpr int WR_CAP = PIP_WTILE;              // writer: pairs of one tile compacted in LDS (16 KB) before the coalesced copy-out
 static_assert(PIP_WTILE % PIP_TILE == 0, "a writer tile is a whole number of pip_tile tiles");
@@ -640,7 +643,7 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
 #define GPK_LEAN_MINWAVES 1
 #endif
 #ifndef GPK_LEAN_NT
-#define GPK_LEAN_NT 0  // 1: non-temporal point loads
+#define GPK_LEAN_NT 1  // 1: non-temporal point loads (cold inputs, the bench protocol: 148 -> 143 us; inputs resident in the Infinity Cache lose ~7 us)
 #endif
 constexpr int LEAN_PPT = GPK_LEAN_PPT, LEAN_TILE = PIP_BLOCK * LEAN_PPT, LEAN_QCAP = GPK_LEAN_QCAP;
 static_assert(PIP_WTILE % LEAN_TILE == 0, "a writer tile is a whole number of lean tiles");
@@ -873,9 +876,13 @@ __global__ __launch_bounds__(WR_BLOCK) void pip_write_kernel(DevGeo pts, DevGeo 
     }
     const int64_t i0 = (int64_t)blockIdx.x * PIP_WTILE + (int64_t)tid * PIP_WPT;
     uint32_t c[PIP_WPT];
+    static_assert(PIP_WPT % 4 == 0, "16-byte code loads");
     if (i0 + PIP_WPT <= pts.n_geoms) {
-        const uint4 a = *reinterpret_cast<const uint4*>(code + i0), b = *reinterpret_cast<const uint4*>(code + i0 + 4);
-        c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+#pragma unroll
+        for (int q = 0; q < PIP_WPT / 4; ++q) {
+            const uint4 a = *reinterpret_cast<const uint4*>(code + i0 + 4 * q);
+            c[4 * q] = a.x; c[4 * q + 1] = a.y; c[4 * q + 2] = a.z; c[4 * q + 3] = a.w;
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < PIP_WPT; ++k) c[k] = i0 + k < pts.n_geoms ? code[i0 + k] : CODE_NONE;
