@@ -132,24 +132,32 @@ __device__ __forceinline__ int hull_points(const DevGeo& a, int64_t g, int& c0) 
 // The hull goes to the geometry's slice of `stack` (coalesced), its size to sizes[g]; rows beyond HULL_CAP points are
 // listed for hull_sort_big_kernel + hull_chain_big_kernel.  The lane-per-geometry chain this replaces walked 2 x 64 points
 // with dependent LDS stack accesses while 63 of 64 memory lanes idled: 4.8 of the 7.4 ms of 2M x 64-vertex polygons.
-__global__ __launch_bounds__(256) void hull_small_kernel(DevGeo a, double2* __restrict__ sorted, int32_t* __restrict__ n_pts,
-                                                         int32_t* __restrict__ big_list, int32_t* __restrict__ big_count,
-                                                         double2* __restrict__ stack, int32_t* __restrict__ sizes) {
-    __shared__ double2 lds[(256 / HULL_GS) * HULL_CAP];
-    __shared__ uint8_t s_idx[256 / HULL_GS][2][HULL_CAP + 8];
+// CAP = 64 first (half the LDS per work-group: eight work-groups per CU instead of four — the kernel is bound by the
+// latency of its barrier-free but strictly sequential LDS steps, so occupancy is what it buys), rows of 65 .. 128 points are
+// listed and taken by the CAP = 128 instantiation (LISTED: the work-groups stride over the list).
+template <int CAP, bool LISTED>
+__global__ __launch_bounds__(256) void hull_small_kernel(DevGeo a, int32_t* __restrict__ n_pts, const int32_t* __restrict__ in_list,
+                                                         const int32_t* __restrict__ in_count, int32_t* __restrict__ mid_list,
+                                                         int32_t* __restrict__ mid_count, int32_t* __restrict__ big_list,
+                                                         int32_t* __restrict__ big_count, double2* __restrict__ stack,
+                                                         int32_t* __restrict__ sizes) {
+    __shared__ double2 lds[(256 / HULL_GS) * CAP];
+    __shared__ uint8_t s_idx[256 / HULL_GS][2][CAP + 8];
     const int lane = threadIdx.x & (HULL_GS - 1), grp = threadIdx.x / HULL_GS;
     const int gshift = (threadIdx.x & 63) & ~(HULL_GS - 1);  // bit position of this group's lanes in a wave ballot
-    const int64_t g = ((int64_t)blockIdx.x * 256 + threadIdx.x) / HULL_GS;
-    if (g >= a.n_geoms) return;
+    const int64_t n_items = LISTED ? (int64_t)*in_count : a.n_geoms;
+    for (int64_t item = (int64_t)blockIdx.x * (256 / HULL_GS) + grp; item < n_items; item += (int64_t)gridDim.x * (256 / HULL_GS)) {
+    const int64_t g = LISTED ? (int64_t)in_list[item] : item;
     int c0;
     const int n = hull_points(a, g, c0);
-    if (lane == 0) {
+    if (!LISTED && lane == 0) {
         n_pts[g] = n;
         if (n > HULL_CAP) big_list[atomicAdd(big_count, 1)] = (int32_t)g;  // order is irrelevant: one work-group each
+        else if (n > CAP) mid_list[atomicAdd(mid_count, 1)] = (int32_t)g;
         if (n <= 0) sizes[g] = 0;
     }
-    if (n <= 0 || n > HULL_CAP) return;
-    double2* __restrict__ v = lds + grp * HULL_CAP;
+    if (n <= 0 || n > CAP) continue;
+    double2* __restrict__ v = lds + grp * CAP;
     int P = 2;
     while (P < n) P <<= 1;
     for (int i = lane; i < P; i += HULL_GS) v[i] = i < n ? a.xy[c0 + i] : make_double2(INFINITY, INFINITY);  // sentinels sort last
@@ -180,14 +188,14 @@ __global__ __launch_bounds__(256) void hull_small_kernel(DevGeo a, double2* __re
             h[1] = L;
             sizes[g] = 2;
         }
-        return;
+        continue;
     }
     auto gballot = [&](bool c) -> uint32_t { return (uint32_t)(__ballot(c) >> gshift) & ((1u << HULL_GS) - 1u); };
     const uint32_t below = (1u << lane) - 1u;
     uint8_t* cur = s_idx[grp][0];
     uint8_t* nxt = s_idx[grp][1];
     // candidate cycle: interior points i = 1 .. n-2 in chunks of HULL_GS, lane = point; side[] keeps the chord test
-    constexpr int CH = (HULL_CAP + HULL_GS - 1) / HULL_GS;
+    constexpr int CH = (CAP + HULL_GS - 1) / HULL_GS;
     int side[CH];
     int cnt = 1;
     if (lane == 0) cur[0] = 0;
@@ -244,6 +252,8 @@ __global__ __launch_bounds__(256) void hull_small_kernel(DevGeo a, double2* __re
     if (lane == 0) {
         h[cnt] = L;  // close the ring
         sizes[g] = cnt + 1;
+    }
+    sync();  // the group's LDS slices are rewritten by its next item
     }
 }
 // One work-group per geometry beyond HULL_CAP points (their ids were appended to big_list by hull_sort_kernel): the
@@ -336,7 +346,7 @@ extern "C" int32_t gpk_convex_hull(const gpk_geoarray* a, double* out_xy, int32_
     const bool host_out = out_space != GPK_MEM_DEVICE;
     size_t need = align256(sizeof(double2) * (size_t)(nc + 1)) + align256(sizeof(double2) * (2 * (size_t)nc + 2 * (size_t)n + 2)) +
                   2 * align256(off_bytes) + align256(sizeof(unsigned long long) * (size_t)(nb + 2)) +
-                  align256(sizeof(int32_t) * (2 * (size_t)nc + 2 * (size_t)n + 2)) + align256(off_bytes) + 1024;
+                  align256(sizeof(int32_t) * (2 * (size_t)nc + 2 * (size_t)n + 2)) + 2 * align256(off_bytes) + 1024;
     if (host_out) need += align256(sizeof(double2) * cap_coords) + align256(off_bytes);
     GPK_TRY(workspace().begin(need));
     double2* sorted = (double2*)workspace().take(sizeof(double2) * (size_t)(nc + 1));
@@ -346,6 +356,7 @@ extern "C" int32_t gpk_convex_hull(const gpk_geoarray* a, double* out_xy, int32_
     int32_t* idx_scratch = (int32_t*)workspace().take(sizeof(int32_t) * (2 * (size_t)nc + 2 * (size_t)n + 2));
     unsigned long long* btot = (unsigned long long*)workspace().take(sizeof(unsigned long long) * (size_t)(nb + 2));
     int32_t* big_list = (int32_t*)workspace().take(off_bytes);  // [0, n): ids of the geometries beyond HULL_CAP points, [n]: their number
+    int32_t* mid_list = (int32_t*)workspace().take(off_bytes);  // the same for 65 .. HULL_CAP points
     double2* out_dev = host_out ? (double2*)workspace().take(sizeof(double2) * cap_coords) : (double2*)out_xy;
     int32_t* off_dev = host_out ? (int32_t*)workspace().take(off_bytes) : out_ring_offsets;
     if (n == 0) {
@@ -354,8 +365,15 @@ extern "C" int32_t gpk_convex_hull(const gpk_geoarray* a, double* out_xy, int32_
     }
     const dim3 grid((unsigned)nb), block(256);
     GPK_HIP(hipMemsetAsync(big_list + n, 0, sizeof(int32_t), s));
+    GPK_HIP(hipMemsetAsync(mid_list + n, 0, sizeof(int32_t), s));
     const dim3 ggrid((unsigned)((n * HULL_GS + 255) / 256));
-    GPK_LAUNCH("gpk_hull_small", hull_small_kernel, ggrid, block, 0, s, a->d, sorted, n_pts, big_list, big_list + n, stack, sizes);
+    GPK_LAUNCH("gpk_hull_small", (hull_small_kernel<64, false>), ggrid, block, 0, s, a->d, n_pts, (const int32_t*)nullptr, (const int32_t*)nullptr, mid_list,
+               mid_list + n, big_list, big_list + n, stack, sizes);
+    {  // rows of 65 .. 128 points (listed by the launch above)
+        const int64_t mid_blocks = (n + 15) / 16 < (int64_t)cu_count() * 8 ? (n + 15) / 16 : (int64_t)cu_count() * 8;
+        GPK_LAUNCH("gpk_hull_small_mid", (hull_small_kernel<HULL_CAP, true>), dim3((unsigned)mid_blocks), block, 0, s, a->d, n_pts, (const int32_t*)mid_list,
+                   (const int32_t*)(mid_list + n), (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, stack, sizes);
+    }
     {
         const int64_t big_blocks = n < (int64_t)cu_count() * 8 ? n : (int64_t)cu_count() * 8;
         GPK_LAUNCH("gpk_hull_sort_big", hull_sort_big_kernel, dim3((unsigned)big_blocks), block, 0, s, a->d, sorted, (const int32_t*)n_pts,

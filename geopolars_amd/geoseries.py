@@ -125,11 +125,15 @@ class GeoSeries:
         views this series' coordinate buffer (benches/explode.rs explodes 45,000 two-point MultiPoints this way).  With
         `return_parents` also the row each member came from."""
         h = C.c_void_p()
-        n_members = {GEOM_MULTIPOINT: self.array.n_coords, GEOM_MULTILINESTRING: self.array.n_rings, GEOM_MULTIPOLYGON: self.array.n_parts}.get(self.array.geom_type, len(self))
+        dev = self.device()
+        sizes = (C.c_int64 * 4)()  # n_coords, n_parts, n_rings, n_geoms of the handle: no host copy of a series decoded on the GPU
+        _abi.check(_abi.lib().gpk_geoarray_download(dev.handle, sizes, None, None, None, None, None))
+        src_type = dev.geom_type
+        n_members = {GEOM_MULTIPOINT: int(sizes[0]), GEOM_MULTILINESTRING: int(sizes[2]), GEOM_MULTIPOLYGON: int(sizes[1])}.get(src_type, len(self))
         parents = np.empty(n_members, dtype=np.int32) if return_parents else None
-        _abi.check(_abi.lib().gpk_explode(self.device().handle, parents.ctypes.data if return_parents and n_members else None, MEM_HOST, None, C.byref(h)))
-        gt = {GEOM_MULTIPOINT: GEOM_POINT, GEOM_MULTILINESTRING: GEOM_LINESTRING, GEOM_MULTIPOLYGON: GEOM_POLYGON}.get(self.array.geom_type, self.array.geom_type)
-        view = DeviceGeoArray(h.value, gt, n_members, self.array.n_coords, keepalive=[self._dev])  # the view borrows our buffers
+        _abi.check(_abi.lib().gpk_explode(dev.handle, parents.ctypes.data if return_parents and n_members else None, MEM_HOST, None, C.byref(h)))
+        gt = {GEOM_MULTIPOINT: GEOM_POINT, GEOM_MULTILINESTRING: GEOM_LINESTRING, GEOM_MULTIPOLYGON: GEOM_POLYGON}.get(src_type, src_type)
+        view = DeviceGeoArray(h.value, gt, n_members, int(sizes[0]), keepalive=[self._dev])  # the view borrows our buffers
         out = GeoSeries(None, device=view)
         return (out, parents) if return_parents else out
 
