@@ -154,6 +154,8 @@ struct FinalOut {
     double* out;              // result column (bounds: 4 doubles per row, centroid: 2)
     const uint8_t* validity;  // of the geometries (= sequences)
     uint8_t* out_valid;       // centroid: "has a centroid" flags (may be nullptr)
+    int32_t* degen_flag;      // centroid: set by the area-weighted pass when some ring has zero area; the degenerate-only pass
+                              // leaves at once while it is 0 (nearly every column: the pass then costs a launch, not a walk)
 };
 // centroid of a row that contributes as a linestring (Centroid::add_line_string, centroid.rs): length-weighted
 // midpoints, or the start point when every segment is degenerate; same arithmetic as wc_add_linestring + the final divide
@@ -165,6 +167,7 @@ __device__ __forceinline__ double2 line_centroid(const SeqPartial& a, double2 fi
 template <unsigned MASK, int FIN>
 __device__ __forceinline__ void seq_store_any(const SeqPartial& a, double* __restrict__ stats, int64_t n_seq, int64_t s, int c0, int c1,
                                               const double2* __restrict__ xy, const FinalOut& f) {
+    if ((MASK & M_CENT) && !(MASK & M_DEGEN) && f.degen_flag && c1 > c0 && a.a2 / 2.0 == 0.0) *f.degen_flag = 1;  // (benign race: every writer stores 1)
     if (FIN == FIN_NONE) {
         seq_store<MASK>(a, stats, n_seq, s);
         return;
@@ -862,6 +865,7 @@ struct SeqPlan {
 template <unsigned MASK, int FIN>
 __global__ __launch_bounds__(256) void seq_stats_kernel(const double2* __restrict__ xy, const int32_t* __restrict__ seq_off, int64_t n_seq,
                                                         double* __restrict__ stats, SeqPlan p, FinalOut fin) {
+    if ((MASK & M_DEGEN) && fin.degen_flag && *fin.degen_flag == 0) return;  // no zero-area ring anywhere: nothing to redo
     int b = blockIdx.x;
     if (b < p.blocks[3]) {
         seq_stats_long_body<MASK, FIN>(xy, seq_off, n_seq, p.list[3], p.count[3], p.chunk_begin, p.n_chunks, p.long_part, stats, b, p.blocks[3], fin);
@@ -1008,7 +1012,7 @@ static int32_t seq_classes_of(const gpk_geoarray* a, hipStream_t s, const gpk_se
 
 template <unsigned MASK, int FIN = FIN_NONE>
 static int32_t launch_seq_stats(const gpk_geoarray* arr, double* stats, double* long_part, hipStream_t s, const char* name,
-                                FinalOut fin = FinalOut{nullptr, nullptr, nullptr}) {
+                                FinalOut fin = FinalOut{nullptr, nullptr, nullptr, nullptr}) {
     const DevGeo& a = arr->d;
     const int32_t* seq_off;
     int64_t n_seq;
@@ -1058,6 +1062,7 @@ struct UnaryCtx {
     void* out_dev = nullptr;
     void* out2_dev = nullptr;
     int64_t n_seq = 0;
+    int32_t* flag = nullptr;  // one device word for the operator (centroid: "some ring has zero area")
 };
 static int32_t unary_begin(const gpk_geoarray* a, size_t out_bytes, size_t out2_bytes, void* out,
                            void* out2, int32_t out_space, UnaryCtx* c) {
@@ -1079,6 +1084,7 @@ static int32_t unary_begin(const gpk_geoarray* a, size_t out_bytes, size_t out2_
     c->long_part = part_bytes ? (double*)workspace().take(part_bytes) : nullptr;
     c->out_dev = stage ? workspace().take(out_bytes ? out_bytes : 8) : out;
     c->out2_dev = out2 ? (stage ? workspace().take(out2_bytes ? out2_bytes : 8) : out2) : nullptr;
+    c->flag = (int32_t*)workspace().take(64);
     return GPK_OK;
 }
 
@@ -1164,7 +1170,7 @@ int32_t gpk_euclidean_length(const gpk_geoarray* a, double* out, int32_t out_spa
         const gpk_seq_classes* cl = nullptr;
         if (a->d.type != GPK_GEOM_MULTIPOINT) GPK_TRY(seq_classes_of(a, s, &cl));
         if (cl && cl->one_to_one) {
-            GPK_TRY((launch_seq_stats<M_LEN, FIN_LENGTH>(a, c.stats, c.long_part, s, "gpk_seq_length", FinalOut{(double*)c.out_dev, a->d.validity, nullptr})));
+            GPK_TRY((launch_seq_stats<M_LEN, FIN_LENGTH>(a, c.stats, c.long_part, s, "gpk_seq_length", FinalOut{(double*)c.out_dev, a->d.validity, nullptr, nullptr})));
             return copy_out(out, out_space, c.out_dev, ob, s);
         }
         if (a->d.type != GPK_GEOM_MULTIPOINT) GPK_TRY(launch_seq_stats<M_LEN>(a, c.stats, c.long_part, s, "gpk_seq_length"));
@@ -1186,7 +1192,7 @@ int32_t gpk_bounds(const gpk_geoarray* a, double* out4, int32_t out_space, void*
         const gpk_seq_classes* cl;
         GPK_TRY(seq_classes_of(a, s, &cl));
         if (cl->one_to_one) {  // stage 1 writes the boxes, no combine pass
-            GPK_TRY((launch_seq_stats<M_BBOX, FIN_BOUNDS>(a, c.stats, c.long_part, s, "gpk_seq_bbox", FinalOut{(double*)c.out_dev, a->d.validity, nullptr})));
+            GPK_TRY((launch_seq_stats<M_BBOX, FIN_BOUNDS>(a, c.stats, c.long_part, s, "gpk_seq_bbox", FinalOut{(double*)c.out_dev, a->d.validity, nullptr, nullptr})));
         } else {
             GPK_TRY(launch_seq_stats<M_BBOX>(a, c.stats, c.long_part, s, "gpk_seq_bbox"));
             GPK_LAUNCH("gpk_bounds_combine", bounds_combine_kernel, grid_for(n), dim3(256), 0, s, a->d, c.stats, c.n_seq, (double*)c.out_dev);
@@ -1208,8 +1214,9 @@ int32_t gpk_centroid(const gpk_geoarray* a, double* out_xy, uint8_t* out_valid, 
     } else {
         const gpk_seq_classes* cl;
         GPK_TRY(seq_classes_of(a, s, &cl));
+        GPK_HIP(hipMemsetAsync(c.flag, 0, sizeof(int32_t), s));
         if (cl->one_to_one) {  // stage 1 writes the centroids: no stats round trip, no combine pass
-            const FinalOut fin{(double*)c.out_dev, a->d.validity, (uint8_t*)c.out2_dev};
+            const FinalOut fin{(double*)c.out_dev, a->d.validity, (uint8_t*)c.out2_dev, c.flag};
             if (a->d.type == GPK_GEOM_MULTIPOINT) {
                 GPK_TRY((launch_seq_stats<M_SUM, FIN_CENT_MPOINT>(a, c.stats, c.long_part, s, "gpk_seq_sum", fin)));
             } else if (a->d.type == GPK_GEOM_POLYGON) {
@@ -1224,9 +1231,11 @@ int32_t gpk_centroid(const gpk_geoarray* a, double* out_xy, uint8_t* out_valid, 
         if (a->d.type == GPK_GEOM_MULTIPOINT)
             GPK_TRY(launch_seq_stats<M_SUM>(a, c.stats, c.long_part, s, "gpk_seq_sum"));
         else if (is_polygonal(a->d.type)) {
-            GPK_TRY(launch_seq_stats<M_CENT>(a, c.stats, c.long_part, s, "gpk_ring_centroid"));
-            // zero-area rings degrade to their linestring centroid: a second pass that skips everything else
-            GPK_TRY(launch_seq_stats<M_LENC | M_DEGEN>(a, c.stats, c.long_part, s, "gpk_ring_centroid_degenerate"));
+            const FinalOut flag_only{nullptr, nullptr, nullptr, c.flag};
+            GPK_TRY(launch_seq_stats<M_CENT>(a, c.stats, c.long_part, s, "gpk_ring_centroid", flag_only));
+            // zero-area rings degrade to their linestring centroid: a second pass that skips everything else (and leaves at
+            // once when the first pass saw no such ring)
+            GPK_TRY(launch_seq_stats<M_LENC | M_DEGEN>(a, c.stats, c.long_part, s, "gpk_ring_centroid_degenerate", flag_only));
         } else {
             GPK_TRY(launch_seq_stats<M_LENC>(a, c.stats, c.long_part, s, "gpk_line_centroid"));
         }
