@@ -1,9 +1,16 @@
-# One GPU-box call that produces the round's evidence: GPU tests, the four bench lines, the headline profile.
-#   bash tools/gpu_round.sh <tag>     (run through gpurun; everything lands under gpurun_out/)
+# One GPU-box call that produces the round's evidence: GPU tests, the four bench lines, the headline profile (kernel stats +
+# PMC passes + calibrated traffic record), kernel stats of the other three configurations and of the operator bench.
+#   bash tools/gpu_round.sh <tag>     (run through gpurun; everything lands under gpurun_out/, profiles/<tag>_pmc_traffic.json is
+#   written by tools/profile_headline.sh and copied to gpurun_out/ as well)
 TAG=${1:-rXX}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd $R
-( time timeout 900 python -m pytest tests -m gpu -x -q ) > $O/${TAG}_gputests.log 2>&1; tail -3 $O/${TAG}_gputests.log
-for c in c2 c3 c4 c5; do
-  timeout 400 python bench.py --config $c > $O/${TAG}_bench_$c.log 2>&1; grep -h '"metric"' $O/${TAG}_bench_$c.log | cut -c1-400 || tail -5 $O/${TAG}_bench_$c.log
-done
+( time timeout 900 python -m pytest tests -m gpu -q ) > $O/${TAG}_gputests.log 2>&1; tail -3 $O/${TAG}_gputests.log
 bash tools/profile_headline.sh $TAG
+for c in c2 c3 c4 c5; do
+  timeout 400 python bench.py --config $c > $O/${TAG}_bench_$c.log 2>&1; grep -h '"metric"' $O/${TAG}_bench_$c.log | cut -c1-300 || tail -5 $O/${TAG}_bench_$c.log
+done
+for c in c3 c4 c5; do
+  bash tools/prof_stats.sh ${TAG}_$c python $R/bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --parity-rows 20000
+done
+bash tools/prof_stats.sh ${TAG}_ops python $R/tools/bench_ops.py; grep -h '"op"' $O/${TAG}_ops.log > $O/${TAG}_ops.jsonl
+python tools/bench_reference_benches.py > $O/${TAG}_reference_benches.jsonl 2>/dev/null
