@@ -321,6 +321,8 @@ def run_c2(ctx: Ctx) -> None:
         if rec is not None:
             traffic, valu_busy = rec.get("traffic_bytes_per_launch"), rec.get("valu_busy")
             traffic_note = rec.get("calibration")
+            if rec.get("traffic_bytes_split_estimate"):
+                traffic_note += f"; upper bound — with the read factor applied to the point stream only: {rec['traffic_bytes_split_estimate']} B"
     k_write = warm.get("gpk_pip_write", 0.0)
     queued, edges = int(st[0]), int(st[1])
     step_s = ms_per_step * 1e-3

@@ -77,6 +77,13 @@ def main():
     write = vals.get("WRITE_SIZE", 0.0) * 1024.0
     rec["fetch_bytes_raw"], rec["write_bytes_raw"] = fetch, write
     rec["traffic_bytes_per_launch"] = int(fetch * (f_read or 1.0) + write * (f_write or 1.0))
+    # The read factor is exact only for the coalesced 16-byte point stream (what the probe reads).  Split estimate: the 160 MB
+    # of points account for 160e6 / factor of the raw counter; whatever else was fetched — index gathers that missed the
+    # XCD L2 — is taken at the counter's own 64 bytes per request.  The truth lies between this and the figure above.
+    if f_read:
+        pts_raw = 160e6 / f_read
+        rec["traffic_bytes_split_estimate"] = int(160e6 + max(fetch - pts_raw, 0.0) + write * (f_write or 1.0))
+        rec["traffic_note"] = "traffic_bytes_per_launch applies the probe's read factor to every fetched byte (upper bound); traffic_bytes_split_estimate applies it to the point stream only and counts the remaining requests at 64 bytes"
     rec["calibration"] = (
         f"FETCH_SIZE x {f_read:.3f}, WRITE_SIZE x {f_write:.3f}: factors that make tools/micro/tile_probe mode 0 (160 MB of 16-byte coalesced loads in, 40 MB of 4-byte stores out, known byte counts) read its true size"
         if f_read and f_write
@@ -87,11 +94,12 @@ def main():
     dur = durations_us(os.path.join(root, "stats"), KERNEL) or [x for d in glob.glob(os.path.join(root, "pmc_*")) for x in durations_us(d, KERNEL)]
     if dur:
         rec["kernel_us_rocprof_mean"] = sum(dur) / len(dur)
+        rec["kernel_us_rocprof_median"] = sorted(dur)[len(dur) // 2]  # (the first launch of a process runs several times longer)
     if vals.get("SQ_INSTS_VALU") and dur:
         # every vector instruction occupies its SIMD for 4 cycles (wave64 on 16 lanes); 256 CUs x 4 SIMDs at 2.4 GHz
-        cycles = (sum(dur) / len(dur)) * 1e-6 * 2.4e9
+        cycles = sorted(dur)[len(dur) // 2] * 1e-6 * 2.4e9
         rec["valu_busy"] = vals["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cycles)
-        rec["valu_busy_note"] = "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel cycles at 2.4 GHz)"
+        rec["valu_busy_note"] = "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel cycles at 2.4 GHz, median launch)"
         if vals.get("SQ_WAVES"):
             rec["instr_per_wave"] = {k: vals[k] / vals["SQ_WAVES"] for k in vals if k.startswith("SQ_INSTS_")}
     json.dump(rec, open(out, "w"), indent=1)
