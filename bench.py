@@ -294,12 +294,13 @@ def run_c2(ctx: Ctx) -> None:
 
     elapsed, k_tile, n_tile, warm = ctx.timed(step, "gpk_pip_tile", args.steps, args.warmup, profile=not args.no_profile)
     # what the exact phase did, measured on one extra untimed step (a few atomics per tile: never inside the timed region)
-    lib.gpk_join_stats_enable(1)
     st = (C.c_int64 * 4)()
-    lib.gpk_join_stats(st, 1)
-    step(args.warmup + args.steps)  # same set the next timed step would have used
-    lib.gpk_join_stats(st, 1)
-    lib.gpk_join_stats_enable(0)
+    if not args.no_join_stats:
+        lib.gpk_join_stats_enable(1)
+        lib.gpk_join_stats(st, 1)
+        step(args.warmup + args.steps)  # same set the next timed step would have used
+        lib.gpk_join_stats(st, 1)
+        lib.gpk_join_stats_enable(0)
     torch.cuda.synchronize()
     s_last = sets[last["set"]]
     h = join_pairs_device(s_last["pts"], polys, index, "intersects", s_last["counts"], s_last["pairs"], left_row_base=0, stream=stream)
@@ -872,6 +873,7 @@ def main() -> None:
     ap.add_argument("--index-per-step", action="store_true", help="c2: rebuild the right-side index inside every step")
     ap.add_argument("--sync-steps", action="store_true", help="c2: use the synchronous gpk_spatial_join (host waits for every step)")
     ap.add_argument("--no-profile", action="store_true", help="tuning only: no HIP events around the kernels (the roofline leg reads zero)")
+    ap.add_argument("--no-join-stats", action="store_true", help="c2: skip the extra untimed step that counts the exact phase's work (its atomics make that one launch ~7x longer: kernel-trace averages of a profiler run stay clean without it)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the exchange even at world size 1 (path test)")
     args = ap.parse_args()
     if args.steps is None:
