@@ -298,3 +298,39 @@ def test_one_to_one_columns_skip_the_combine_pass_and_keep_nulls_and_empties(gpk
     exp_c, exp_v = oracle.centroid(degenerate)
     got = GeoSeries(degenerate).centroid()
     _close(got.array.xy, exp_c)
+
+
+def test_convex_hull_adversarial_point_sets(gpk, oracle):
+    """the cooperative hull (sort + parallel left-turn filtering, 64- and 128-point instantiations, the chain beyond): point
+    sets built to stress the filtering — everything collinear, everything identical, many duplicates, points ON the chord
+    between the extremes, a convex polygon (nothing leaves), a spiral (the filter needs many rounds), lattice blocks full of
+    collinear triples — at every size around the instantiation limits"""
+    rng = np.random.default_rng(5)
+    sets = []
+    for n in (1, 2, 3, 4, 5, 16, 17, 63, 64, 65, 66, 127, 128, 129, 130, 300):
+        t = np.linspace(0.0, 1.0, n)
+        sets.append(np.stack([t * 7.0 - 3.0, t * 14.0 + 1.0], axis=1))  # collinear
+        sets.append(np.tile([[2.5, -1.25]], (n, 1)))  # one point, n times
+        k = np.arange(n)
+        ang = 2 * np.pi * k / max(n, 1)
+        sets.append(np.stack([np.cos(ang), np.sin(ang)], axis=1) * 10.0)  # convex position
+        sets.append(np.stack([np.cos(6 * ang), np.sin(6 * ang)], axis=1) * (1.0 + k[:, None] / max(n, 1)))  # spiral
+        sets.append(rng.integers(0, 4, (n, 2)).astype(np.float64))  # tiny lattice: duplicates and collinear triples everywhere
+        half = rng.integers(-5, 6, (n, 2)).astype(np.float64)
+        half[::2, 1] = half[::2, 0] * 2.0  # every other point on the line y = 2x (through the likely extremes)
+        sets.append(half)
+        sets.append(rng.permutation(np.concatenate([rng.normal(size=(n, 2)), rng.normal(size=(n, 2))])[: max(n, 1)]))
+    a = GeoArrowArray(_abi.GEOM_MULTIPOINT, np.concatenate(sets), geom_offsets=np.concatenate([[0], np.cumsum([len(s) for s in sets])]).astype(np.int32))
+    exp_xy, exp_off = oracle.convex_hull(a)
+    h = GeoSeries(a).convex_hull().array
+    assert np.array_equal(h.ring_offsets, exp_off)
+    for g in range(len(a)):
+        got = _canon(h.xy[h.ring_offsets[g] : h.ring_offsets[g + 1]])
+        exp = _canon(exp_xy[exp_off[g] : exp_off[g + 1]])
+        assert np.array_equal(got, exp), (g, len(sets[g]))
+    # without canonicalisation: the ring starts at the lexicographically smallest vertex and is closed
+    for g in range(len(a)):
+        ring = h.xy[h.ring_offsets[g] : h.ring_offsets[g + 1]]
+        if len(ring) >= 2:
+            assert np.array_equal(ring[0], ring[-1])
+            assert tuple(ring[0]) == min(map(tuple, ring))
