@@ -149,7 +149,7 @@ __global__ void cell_sort_kernel(const int32_t* __restrict__ cell_off, int64_t n
 #ifndef GPK_PIP_PPT
 #define GPK_PIP_PPT 2
 #endif
-// GPK_ABLATE (tuning builds only, tools/pmc_ablate.sh): 1 = no exact phase, 2 = every cell empty, 3 = level-1 interiors only,
+// GPK_ABLATE (tuning builds only, tools/pmc_ablate.sh, tools/ablate_time.py): 1 = no exact phase, 2 = every cell empty, 3 = level-1 interiors only,
 // 5 = level-2 labels without queue pushes.  0 in the shipped library.
 #ifndef GPK_ABLATE
 #define GPK_ABLATE 0
@@ -699,6 +699,10 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_LEAN_MINWAVES) void pip_tile_lean_ke
         fyf[k] = (uint32_t)dev::cell_of(p[k].y, pv.ry0, pv.inv_fh * FINE, pv.R * FINE);
         const uint32_t fy = fyf[k] >> FY_SUB;
         word[k] = (p[k].x == p[k].x && p[k].y == p[k].y) ? pv.cell[(fy / S) * (uint32_t)pv.R + (sx[k] / S)] : 0u;
+        // tuning builds only (tools/ablate_time.py; the answers are wrong on purpose)
+        if (GPK_ABLATE == 2) word[k] = 0u;                                                  // no gather at all: the streaming floor
+        if (GPK_ABLATE == 3) word[k] = (word[k] >> 30) == CELL_TAG_SINGLE ? word[k] : 0u;  // level-1 interiors only
+        if (GPK_ABLATE == 6) word[k] = (word[k] >> 30) == CELL_TAG_SUB ? ((CELL_TAG_SINGLE << 30) | (word[k] & 0x3FFFFFu)) : word[k];  // records never read
     }
     TILE_STAMP(2);
     // stage C: level-2 records of the cells an edge crosses (32 bytes: two 16-byte gathers off one line)
@@ -737,7 +741,7 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_LEAN_MINWAVES) void pip_tile_lean_ke
                 const bool upper = ((fyf[k] >> PIP_FINE_LOG2) & 1u) != 0;
                 qe0[k] = upper ? ra[k].z : ra[k].y;
                 qcnt[k] = (upper ? ra[k].w : ra[k].z) - qe0[k];
-                todo[k] = qcnt[k] > 0;  // an empty slab: p.y is outside the exterior's y-range
+                todo[k] = qcnt[k] > 0 && GPK_ABLATE != 1;  // an empty slab: p.y is outside the exterior's y-range (ablation 1: no exact phase)
             }
         } else if (tag == CELL_TAG_LIST) {  // the few cells where parts meet (a lean index has next to none): generic walk
             qpart[k] = LEAN_SLOW;
