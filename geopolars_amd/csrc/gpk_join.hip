@@ -636,16 +636,14 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
 #ifndef GPK_LEAN_PPT
 #define GPK_LEAN_PPT 4
 #endif
-#ifndef GPK_LEAN_QCAP
-#define GPK_LEAN_QCAP 256
-#endif
 #ifndef GPK_LEAN_MINWAVES
 #define GPK_LEAN_MINWAVES 1
 #endif
 #ifndef GPK_LEAN_NT
-#define GPK_LEAN_NT 1  // 1: non-temporal point loads (cold inputs, the bench protocol: 148 -> 143 us; inputs resident in the Infinity Cache lose ~7 us)
+#define GPK_LEAN_NT 0  // 1: non-temporal point loads — a gain of 3 % while a queued pair carried its point in the entry; now the lane groups read the
+                       // point again from the tile, and that second read wants the line still in L2 (136.5 vs 138.7 us)
 #endif
-constexpr int LEAN_PPT = GPK_LEAN_PPT, LEAN_TILE = PIP_BLOCK * LEAN_PPT, LEAN_QCAP = GPK_LEAN_QCAP;
+constexpr int LEAN_PPT = GPK_LEAN_PPT, LEAN_TILE = PIP_BLOCK * LEAN_PPT;  // (the queue holds a whole tile)
 static_assert(PIP_WTILE % LEAN_TILE == 0, "a writer tile is a whole number of lean tiles");
 // GPK_TILE_TRACE (diagnosis builds only): lane 0 of every 64th tile stamps the wall clock at the stage boundaries of the lean
 // kernel (after forcing the stage's loads to land) into the statistics buffer; tools/tile_trace.py prints the stage times.
@@ -658,7 +656,16 @@ static_assert(PIP_WTILE % LEAN_TILE == 0, "a writer tile is a whole number of le
 #else
 #define TILE_STAMP(i) do {} while (0)
 #endif
-constexpr uint32_t LEAN_SLOW = 1u << 30;  // QEntry::li_flags: a point of a list cell — one lane runs the generic walk for it
+constexpr uint32_t LEAN_SLOW = 1u << 30;  // LeanEntry::li_flags: a point of a list cell — one lane runs the generic walk for it
+// A queued (point, part) pair of the lean kernel: 16 bytes.  The point itself is NOT in the entry — the lane group reads it
+// from the tile (its address is known from `li`, so the load goes out together with the edge loads) — which lets the
+// queue hold a whole tile (no overflow rounds: nothing of phase 1 has to stay in registers across the exact phase) in
+// 16 KB of LDS.
+struct LeanEntry {
+    uint32_t li_flags;  // point index within the tile | LEAN_SLOW | (part has holes) << 31
+    uint32_t part;      // in: the part; out: the part when the point is inside it, CODE_NONE otherwise (slow path: the result code)
+    uint32_t e0, cnt;   // in: the exterior slab's edge range; out (slow path): cnt = hits
+};
 __global__ __launch_bounds__(PIP_BLOCK, GPK_LEAN_MINWAVES) void pip_tile_lean_kernel(DevGeo pts, DevGeo polys, IndexView ix, PipView pv,
                                                                                     uint32_t* __restrict__ counts, uint32_t* __restrict__ code,
                                                                                     unsigned long long* __restrict__ block_tot,
@@ -666,7 +673,7 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_LEAN_MINWAVES) void pip_tile_lean_ke
                                                                                     unsigned long long* __restrict__ stats) {
     constexpr int PPT = LEAN_PPT, S = PIP_SUB, FINE = PIP_SLAB_MUL << PIP_FINE_LOG2, FY_SUB = PIP_FINE_LOG2 - 2;
     static_assert(FINE == S << FY_SUB, "fine rows per level-2 row");
-    __shared__ QEntry q[LEAN_QCAP];
+    __shared__ LeanEntry q[LEAN_TILE];
     __shared__ uint32_t q_n;
     __shared__ unsigned long long s_tot;
     const int tid = threadIdx.x, lane64 = tid & 63;
@@ -751,68 +758,60 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_LEAN_MINWAVES) void pip_tile_lean_ke
     uint32_t slow_cnt[PPT];  // hit count of a list-cell point (its code then names a geometry, CODE_NONE or CODE_MULTI)
 #pragma unroll
     for (int k = 0; k < PPT; ++k) slow_cnt[k] = 0;
-    // Rounds of (queue the marked points -> PIP_GS lanes per queued pair walk the slab's edges -> owners collect the
-    // verdicts).  One round unless a tile holds more boundary points than the queue (then the rest goes next round).
+    // Queue the marked points (the queue holds a whole tile: one round) -> PIP_GS lanes per queued pair walk the slab's edges ->
+    // owners collect the verdicts.  From here on a lane keeps only res[] / the pending mask of its points.
     unsigned long long edges_walked = 0, pairs_walked = 0;
     const int glane = tid & (PIP_GS - 1);
-    uint32_t pending = 0;  // bit k: res[k] holds a queue slot whose verdict is still to be collected
-    for (;;) {
+    uint32_t pending = 0;  // bit k: res[k] holds a queue slot whose verdict is still to be collected; bit 8 + k: a slow-path point
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const unsigned long long mask = __ballot(todo[k]);
-            if (mask) {
-                uint32_t wbase = 0;
-                const int leader = __ffsll((long long)mask) - 1;
-                if (lane64 == leader) wbase = atomicAdd(&q_n, (uint32_t)__popcll(mask));
-                wbase = __shfl(wbase, leader, 64);
-                const uint32_t slot = wbase + (uint32_t)__popcll(mask & ((1ull << lane64) - 1ull));
-                if (todo[k] && slot < (uint32_t)LEAN_QCAP) {
-                    q[slot] = QEntry{p[k].x, p[k].y, qpart[k] & 0x3FFFFFFFu, qe0[k], qcnt[k], qpart[k] & (0x80000000u | LEAN_SLOW)};
-                    res[k] = slot;
-                    pending |= 1u << k;
-                    todo[k] = false;
-                }
+    for (int k = 0; k < PPT; ++k) {
+        const unsigned long long mask = __ballot(todo[k]);
+        if (mask) {
+            uint32_t wbase = 0;
+            const int leader = __ffsll((long long)mask) - 1;
+            if (lane64 == leader) wbase = atomicAdd(&q_n, (uint32_t)__popcll(mask));
+            wbase = __shfl(wbase, leader, 64);
+            const uint32_t slot = wbase + (uint32_t)__popcll(mask & ((1ull << lane64) - 1ull));
+            if (todo[k]) {
+                q[slot] = LeanEntry{(uint32_t)(k * PIP_BLOCK + tid) | (qpart[k] & (0x80000000u | LEAN_SLOW)), qpart[k] & 0x3FFFFFFFu, qe0[k], qcnt[k]};
+                res[k] = slot;
+                pending |= (1u << k) | (qpart[k] == LEAN_SLOW ? 0x100u << k : 0u);
             }
         }
-        __syncthreads();
-        TILE_STAMP(4);
-        const uint32_t queued = q_n;  // uniform: read after the barrier
-        const uint32_t nq = queued < (uint32_t)LEAN_QCAP ? queued : (uint32_t)LEAN_QCAP;
-        for (uint32_t e = tid / PIP_GS; e < nq; e += PIP_BLOCK / PIP_GS) {
-            const QEntry en = q[e];
-            if (en.li_flags & LEAN_SLOW) {  // uniform within the group (one entry per group)
-                if (glane == 0) {
-                    uint32_t cnt, first;
-                    generic_point(polys, ix, en.px, en.py, cnt, first);
-                    q[e].part = cnt == 0 ? CODE_NONE : (cnt == 1 ? first : CODE_MULTI);
-                    q[e].cnt = cnt;
-                }
-                continue;
-            }
-            const int pos = pip::part_pos_group_from_edges<PIP_GS>(pv, polys, (int)en.part, (en.li_flags >> 31) ? 2 : 1, (int)en.e0, (int)en.cnt,
-                                                                   en.px, en.py, glane);
-            if (glane == 0) {
-                q[e].part = pos == dev::POS_INSIDE ? en.part : CODE_NONE;  // the verdict travels back in the entry
-                edges_walked += en.cnt;
-                ++pairs_walked;
-            }
-        }
-        TILE_STAMP(5);
-        __syncthreads();
-        TILE_STAMP(6);
-#pragma unroll
-        for (int k = 0; k < PPT; ++k)
-            if (pending & (1u << k)) {
-                const uint32_t slot = res[k];
-                res[k] = q[slot].part;
-                if (qpart[k] == LEAN_SLOW) slow_cnt[k] = q[slot].cnt | 0x80000000u;  // top bit: "this point went the slow way"
-            }
-        pending = 0;
-        if (queued <= (uint32_t)LEAN_QCAP) break;  // uniform
-        __syncthreads();  // every owner has read its verdicts: the queue can be reused
-        if (tid == 0) q_n = 0;
-        __syncthreads();
     }
+    __syncthreads();
+    TILE_STAMP(4);
+    const uint32_t nq = q_n;  // uniform: read after the barrier (<= LEAN_TILE: one entry per point at most)
+    for (uint32_t e = tid / PIP_GS; e < nq; e += PIP_BLOCK / PIP_GS) {
+        const LeanEntry en = q[e];
+        const double2 pt = tile_xy[en.li_flags & 0x3FFFFFFFu];  // (requested together with the edges below; an L2 hit: the tile was just read)
+        if (en.li_flags & LEAN_SLOW) {  // uniform within the group (one entry per group)
+            if (glane == 0) {
+                uint32_t cnt, first;
+                generic_point(polys, ix, pt.x, pt.y, cnt, first);
+                q[e].part = cnt == 0 ? CODE_NONE : (cnt == 1 ? first : CODE_MULTI);
+                q[e].cnt = cnt;
+            }
+            continue;
+        }
+        const int pos = pip::part_pos_group_from_edges<PIP_GS>(pv, polys, (int)en.part, (en.li_flags >> 31) ? 2 : 1, (int)en.e0, (int)en.cnt, pt.x,
+                                                               pt.y, glane);
+        if (glane == 0) {
+            q[e].part = pos == dev::POS_INSIDE ? en.part : CODE_NONE;  // the verdict travels back in the entry
+            edges_walked += en.cnt;
+            ++pairs_walked;
+        }
+    }
+    TILE_STAMP(5);
+    __syncthreads();
+    TILE_STAMP(6);
+#pragma unroll
+    for (int k = 0; k < PPT; ++k)
+        if (pending & (1u << k)) {
+            const uint32_t slot = res[k];
+            res[k] = q[slot].part;
+            if (pending & (0x100u << k)) slow_cnt[k] = q[slot].cnt | 0x80000000u;  // top bit: "this point went the slow way"
+        }
     if (stats && pairs_walked) {  // measurement runs only (gpk_join_stats_enable): uniform branch on the pointer
         atomicAdd(&stats[0], pairs_walked);
         atomicAdd(&stats[1], edges_walked);
