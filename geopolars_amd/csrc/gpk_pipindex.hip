@@ -512,6 +512,16 @@ __global__ void lrec_count_kernel(const uint32_t* __restrict__ cell, const uint3
     }
     cnt[c] = n;
 }
+// one-part records: the flagged cells as a work list (cell, part), record pos[c] — the build then launches one wave per
+// RECORD instead of one per raster cell (two thirds of the cells of the C2 raster, nineteen in twenty of a 2048 x 2048 one,
+// carry no record)
+__global__ void sub_work_kernel(const uint32_t* __restrict__ cell, const int32_t* __restrict__ flag, const int32_t* __restrict__ pos,
+                                int64_t n_cells, int32_t* __restrict__ work_cell, uint32_t* __restrict__ work_part) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cells || !flag[c]) return;
+    work_cell[pos[c]] = (int32_t)c;
+    work_part[pos[c]] = (cell[c] & 0x3FFFFFFFu) >> 1;
+}
 __global__ void lrec_assign_kernel(const uint32_t* __restrict__ cell, uint32_t* __restrict__ list, int64_t n_cells,
                                    const int32_t* __restrict__ pos, int32_t* __restrict__ work_cell, uint32_t* __restrict__ work_part) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -822,8 +832,15 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, boo
             GPK_HIP(hipMalloc((void**)&sub, sizeof(SubCell) * (size_t)n_sub));
             keep(sub);
             GPK_HIP(hipMemsetAsync(sub, 0, sizeof(SubCell) * (size_t)n_sub, s));
-            GPK_LAUNCH("gpk_pipidx_sub_build", sub_build_kernel<1>, blocks_for(n_cells * PIP_SUB * PIP_SUB), dim3(256), 0, s, d, pv, g, sflag, spos,
-                       n_cells, (const uint32_t*)cell, (const uint32_t*)list, sub, (SubCell2*)nullptr);
+            int32_t* swork_cell;
+            uint32_t* swork_part;
+            GPK_TRY(t.alloc(&swork_cell, (size_t)n_sub));
+            GPK_TRY(t.alloc(&swork_part, (size_t)n_sub));
+            GPK_LAUNCH("gpk_pipidx_sub_work", sub_work_kernel, blocks_for(n_cells), dim3(256), 0, s, (const uint32_t*)cell, (const int32_t*)sflag,
+                       (const int32_t*)spos, n_cells, swork_cell, swork_part);
+            GPK_LAUNCH("gpk_pipidx_sub_build", (sub_build_kernel<1, true>), blocks_for((int64_t)n_sub * PIP_SUB * PIP_SUB), dim3(256), 0, s, d, pv, g,
+                       (const int32_t*)nullptr, (const int32_t*)nullptr, n_cells, (const uint32_t*)cell, (const uint32_t*)list, sub, (SubCell2*)nullptr,
+                       (const int32_t*)swork_cell, (const uint32_t*)swork_part, (int64_t)n_sub);
         }
         if (n_sub2 > 0) {
             GPK_HIP(hipMalloc((void**)&sub2, sizeof(SubCell2) * (size_t)n_sub2));
