@@ -72,6 +72,33 @@ def pmc_record(kernel: str):
     return None, "no PMC record for this kernel under profiles/"
 
 
+def pmc_config_record(config: str):
+    """Raw / factor-corrected PMC traffic of a configuration's dominant kernel from the latest committed
+    profiles/r*_pmc_traffic_configs.json whose source hash matches this tree (else None + reason)."""
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_configs.json")))
+    cur = source_hash()
+    for fn in reversed(cands):
+        try:
+            with open(fn) as f:
+                t = json.load(f)
+        except Exception:
+            continue
+        if t.get("source_hash") != cur:
+            return None, f"stale: {os.path.basename(fn)} was measured at source hash {t.get('source_hash')}, this tree is {cur} (re-run tools/profile_configs.sh)"
+        r = t.get("configs", {}).get(config)
+        if r is None:
+            return None, f"{os.path.basename(fn)} holds no record for {config}"
+        return r, f"raw FETCH_SIZE + WRITE_SIZE of {r['kernel']} per launch; with the 16-byte-stream read factor {t.get('read_factor_of_the_16_byte_stream')}: {r['traffic_bytes_with_read_factor']} B (gathers are tallied at 64 B per request: the truth lies between)"
+    return None, "no PMC record for this configuration under profiles/"
+
+
+def roofline_traffic(roofline: dict, config: str) -> dict:
+    r, note = pmc_config_record(config)
+    roofline["traffic"] = r["traffic_bytes_raw"] if r else None
+    roofline["traffic_note"] = note
+    return roofline
+
+
 class Ctx:
     """torch / torch.distributed plumbing shared by every configuration."""
 
@@ -523,6 +550,8 @@ def run_c3(ctx: Ctx) -> None:
         "valu": {"note": "the kernel is bound by f64 vector issue, not HBM", "achieved": valu, "peak": F64_VALU_PEAK, "unit": "f64 instr/s", "frac": valu / F64_VALU_PEAK, "instr_per_segment": instr_per_seg},
         "source_hash": source_hash(),
     }
+    if n == 10_000_000 and args.lines == 100_000:
+        roofline_traffic(roofline, "c3")
     line = base_line(ctx, "row-wise point-linestring distances/sec (10M pts x 100k linestrings)", ctx.world * n * args.steps / main["elapsed"], "rows/s", ms_per_step, "weak", config, roofline)
     line["parity"] = main["parity"]
     if ctx.world == 1 and not args.no_cpu_baseline:
@@ -675,6 +704,8 @@ def run_c4(ctx: Ctx) -> None:
         "note": "candidate refine is VALU-bound (exact segment-pair tests), the candidate passes are gather-bound; the HBM fraction is reported as the contract asks",
         "source_hash": source_hash(),
     }
+    if args.polygons == 1_000_000 and W == 1:
+        roofline_traffic(roofline, "c4")
     line = base_line(ctx, "polygon-pair intersects() join rows/sec (1M x 1M polygons)", n * args.steps / elapsed, "left rows/s", ms_per_step, "strong", config, roofline)
     line["parity"] = parity
     if W == 1 and not args.no_cpu_baseline:
@@ -833,6 +864,8 @@ def run_c5(ctx: Ctx) -> None:
         "note": "latency-bound gathers into a multi-gigabyte index (raster words, level-2 records, edge slabs), not a streaming kernel; the streaming part of the step is area()",
         "source_hash": source_hash(),
     }
+    if n == 6_250_000 and args.multipolygons == 5_000_000:
+        roofline_traffic(roofline, "c5")
     line = base_line(ctx, "predicate evals/sec (points within power-law multipolygons, + area)", float(W) * n * right_host.n_geoms * args.steps / elapsed, "evals/s", ms_per_step, "weak", config, roofline)
     line["parity"] = parity_point_join(pts_host, right_host, "within", counts, pairs, h, args.parity_rows)
     line["parity"]["area"] = parity_area(shard_host, area)

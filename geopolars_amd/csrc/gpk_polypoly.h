@@ -170,13 +170,15 @@ __device__ inline int polygon_pos_group(const DevGeo& a, int r0, int r1, double 
 }
 
 // bboxes of a polygon's exterior (.x.. of `ext`) and of all its rings (`all`), G lanes, same value on every lane
-// `known` (optional): the exterior's box when the caller already has it (bounds of a Polygon row)
+// `known` (when have_known): the exterior's box the caller already has (bounds of a Polygon row).  By VALUE: a pointer to the
+// caller's local put that local into scratch memory — 64 bytes stored per lane and candidate pair, 4 GB of HBM writes per
+// 1M x 1M join (profiles/r02e_pmc_traffic_configs.json: WRITE_SIZE of gpk_pair_refine against 4 MB of results).
 template <int G>
-__device__ inline void polygon_bboxes_group(const DevGeo& a, int r0, int r1, int lane, const double4* known, double4& ext, double4& all) {
+__device__ inline void polygon_bboxes_group(const DevGeo& a, int r0, int r1, int lane, bool have_known, double4 known, double4& ext, double4& all) {
     double mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
     const int c0 = a.ring_off[r0], ce = a.ring_off[r0 + 1], c1 = a.ring_off[r1];
-    if (known) {
-        mnx = known->x; mny = known->y; mxx = known->z; mxy = known->w;
+    if (have_known) {
+        mnx = known.x; mny = known.y; mxx = known.z; mxy = known.w;
     } else {
         for (int i = c0 + lane; i < ce; i += G) {
             const double2 p = a.xy[i];
@@ -212,16 +214,17 @@ constexpr int PP_VOTE = 4;   // list entries between two group votes in the cros
 constexpr int PP_LIST = GPK_PP_LIST;  // per list; a group owns two lists (2 * PP_LIST double4 = 2 KB)
 template <int G>
 __device__ inline bool polygon_intersects_polygon_group(const DevGeo& a, int ar0, int ar1, const DevGeo& b, int br0, int br1, int lane,
-                                                        double4* __restrict__ seg_list, const double4* a_box = nullptr,
-                                                        const double4* b_box = nullptr) {
+                                                        double4* __restrict__ seg_list, bool have_a_box = false,
+                                                        double4 a_box = double4{0, 0, 0, 0}, bool have_b_box = false,
+                                                        double4 b_box = double4{0, 0, 0, 0}) {
     static_assert(G <= 64 && (G & (G - 1)) == 0 && PP_LIST >= G, "group size");
     if (ar1 <= ar0 || br1 <= br0) return false;
     const int a_c0 = a.ring_off[ar0], a_c1 = a.ring_off[ar1];
     const int b_c0 = b.ring_off[br0], b_c1 = b.ring_off[br1];
     if (a.ring_off[ar0 + 1] == a_c0 || b.ring_off[br0 + 1] == b_c0) return false;  // empty exterior
     double4 ea, fa, eb, fb;
-    polygon_bboxes_group<G>(a, ar0, ar1, lane, a_box, ea, fa);
-    polygon_bboxes_group<G>(b, br0, br1, lane, b_box, eb, fb);
+    polygon_bboxes_group<G>(a, ar0, ar1, lane, have_a_box, a_box, ea, fa);
+    polygon_bboxes_group<G>(b, br0, br1, lane, have_b_box, b_box, eb, fb);
     if (ea.z < eb.x || ea.w < eb.y || eb.z < ea.x || eb.w < ea.y) return false;  // has_disjoint_bboxes (exteriors)
 
     const int gbase = (int)(threadIdx.x & 63) & ~(G - 1);  // first lane of this group within its wave
@@ -322,8 +325,7 @@ __device__ inline bool polygonal_intersects_polygonal_group(const DevGeo& a, int
                                                             double4* __restrict__ seg_list, const double4* a_boxes = nullptr,
                                                             const double4* b_boxes = nullptr) {
     const double4 abox = a_boxes ? a_boxes[ia] : make_double4(0, 0, 0, 0), bbox = b_boxes ? b_boxes[ib] : make_double4(0, 0, 0, 0);
-    const double4* ah = a_boxes && a.type == GPK_GEOM_POLYGON ? &abox : nullptr;
-    const double4* bh = b_boxes && b.type == GPK_GEOM_POLYGON ? &bbox : nullptr;
+    const bool ah = a_boxes && a.type == GPK_GEOM_POLYGON, bh = b_boxes && b.type == GPK_GEOM_POLYGON;
     int a0, a1, b0, b1;
     dev::geom_parts(a, ia, a0, a1);
     dev::geom_parts(b, ib, b0, b1);
@@ -333,7 +335,7 @@ __device__ inline bool polygonal_intersects_polygonal_group(const DevGeo& a, int
         for (int q = b0; q < b1; ++q) {
             int br0, br1;
             dev::part_rings(b, q, br0, br1);
-            if (polygon_intersects_polygon_group<G>(a, ar0, ar1, b, br0, br1, lane, seg_list, ah, bh)) return true;
+            if (polygon_intersects_polygon_group<G>(a, ar0, ar1, b, br0, br1, lane, seg_list, ah, abox, bh, bbox)) return true;
         }
     }
     return false;
