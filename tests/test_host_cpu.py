@@ -317,3 +317,32 @@ def test_wkb_host_codec_round_trip_on_random_structures():
                 assert (x is None) == (y is None) and (x is None or np.array_equal(x, y)), name
 
     run()
+
+
+def test_bench_helpers_sampling_and_traffic_records(tmp_path, monkeypatch):
+    """bench.py's host-side helpers: the parity sample, the pair extraction the sampled check relies on, and the rule that a PMC
+    traffic record is reported only for the sources it was measured at"""
+    import importlib
+    import json as _json
+
+    bench = importlib.import_module("bench")
+    rows = bench.sample_rows(1000, 50, seed=1)
+    assert len(rows) == 50 and len(set(rows.tolist())) == 50 and np.all(np.diff(rows) > 0) and rows.max() < 1000
+    assert len(bench.sample_rows(10, 50, seed=1)) == 10  # never more rows than there are
+    pairs = np.array([[0, 5], [2, 1], [2, 7], [3, 3], [9, 0], [9, 4]], dtype=np.uint32)
+    got = bench.pairs_of_rows(pairs, np.array([2, 4, 9], dtype=np.int64))
+    assert got.tolist() == [[0, 1], [0, 7], [2, 0], [2, 4]]  # l renumbered to the position in the sample; row 4 has no pair
+    assert bench.pairs_of_rows(np.zeros((0, 2), dtype=np.uint32), np.array([1, 2])).shape == (0, 2)
+    # traffic records: the committed one matches this tree ...
+    rec, why = bench.pmc_record("gpk_pip_tile")
+    assert (rec is not None and why is None and rec["source_hash"] == bench.source_hash()) or (rec is None and "stale" in why)
+    # ... and a record measured at other sources is refused with the reason
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "r99_pmc_traffic.json").write_text(_json.dumps({"kernel": "gpk_pip_tile", "source_hash": "0" * 16, "traffic_bytes_per_launch": 1}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "source_hash", lambda: "f" * 16)
+    rec, why = bench.pmc_record("gpk_pip_tile")
+    assert rec is None and "stale" in why and "0000" in why
+    rec, why = bench.pmc_config_record("c4")
+    assert rec is None and "no PMC record" in why
