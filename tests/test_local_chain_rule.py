@@ -1,0 +1,17 @@
+"""The decision rule DESIGN.md section 7 proposes for "test" sub-cells (tools/proto_local_chain.py): winding number of a
+point of a padded sub-cell = a per-sub-cell constant + the contributions of the LOCAL CHAIN of ring edges.  Checked against
+the full ring walk on random and on-edge points; CPU only, a few seconds."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("workload", ["c2", "small", "c4"])
+def test_local_chain_rule_agrees_with_the_full_ring_walk(workload):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "proto_local_chain.py"), workload], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "disagreements: 0" in r.stdout
