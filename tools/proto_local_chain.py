@@ -135,5 +135,52 @@ def main():
     return 1 if bad else 0
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "census"):
     sys.exit(main())
+
+
+def census():
+    """python tools/proto_local_chain.py census: every test sub-cell of the C2 right side — how many there are, how long their
+    chains get, what the per-sub-cell table would weigh (8 bytes: first coordinate, edge count, base winding)"""
+    polys = synth.star_polygons(1000, 64)
+    ro, xy = polys.ring_offsets, polys.xy
+    R, S = 512, 8
+    x0, y0 = xy.min(0)
+    x1, y1 = xy.max(0)
+    fw, fh = (x1 - x0) / (R - 3), (y1 - y0) / (R - 3)
+    rx0, ry0 = x0 - 1.5 * fw, y0 - 1.5 * fh
+    sw, sh = fw / S, fh / S
+    pad_x, pad_y = fw / 65536.0 / S, fh / 65536.0 / S
+    hist = {}
+    n_cells = 0
+    for g in range(0, 1000, 10):  # every tenth polygon: the right side is statistically uniform
+        ring = [(float(p[0]), float(p[1])) for p in xy[ro[g] : ro[g + 1]]]
+        n = len(ring) - 1
+        touched = set()
+        for i in range(n):
+            (ax, ay), (bx, by) = ring[i], ring[i + 1]
+            i0, i1 = int((min(ax, bx) - pad_x - rx0) / sw), int((max(ax, bx) + pad_x - rx0) / sw)
+            j0, j1 = int((min(ay, by) - pad_y - ry0) / sh), int((max(ay, by) + pad_y - ry0) / sh)
+            for si in range(i0, i1 + 1):
+                for sj in range(j0, j1 + 1):
+                    if (si, sj) in touched:
+                        continue
+                    xl, xh = rx0 + si * sw - pad_x, rx0 + (si + 1) * sw + pad_x
+                    yl, yh = ry0 + sj * sh - pad_y, ry0 + (sj + 1) * sh + pad_y
+                    if seg_meets_rect(ax, ay, bx, by, xl, yl, xh, yh):
+                        touched.add((si, sj))
+        for (si, sj) in touched:
+            xl, xh = rx0 + si * sw - pad_x, rx0 + (si + 1) * sw + pad_x
+            yl, yh = ry0 + sj * sh - pad_y, ry0 + (sj + 1) * sh + pad_y
+            k = len(local_chain(ring, xl, yl, xh, yh))
+            hist[k] = hist.get(k, 0) + 1
+            n_cells += 1
+    total = n_cells * 10
+    print(f"test sub-cells of the C2 right side: ~{total} ({total / (R * S) ** 2:.3%} of the {R * S} x {R * S} sub-cell grid) -> 8-byte table: {total * 8 / 1e6:.1f} MB")
+    tot = sum(hist.values())
+    print("chain length histogram:", {k: f"{v / tot:.1%}" for k, v in sorted(hist.items())})
+    print(f"mean {sum(k * v for k, v in hist.items()) / tot:.2f} edges per test sub-cell")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "census":
+    census()
