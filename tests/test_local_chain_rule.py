@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("workload", ["c2", "small", "c4"])
-def test_local_chain_rule_agrees_with_the_full_ring_walk(workload):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "proto_local_chain.py"), workload], capture_output=True, text=True, timeout=300)
+@pytest.mark.parametrize("mode", [[], ["--as-kernel"]])  # the rule itself / the single-arc form tools/next_round/local_chain.patch builds
+def test_local_chain_rule_agrees_with_the_full_ring_walk(workload, mode):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "proto_local_chain.py"), workload] + mode, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "disagreements: 0" in r.stdout

@@ -72,8 +72,37 @@ def local_chain(ring, xl, yl, xh, yh):
     return sorted(C)
 
 
+CHAIN_MAX = 7
+
+
+def local_arc(ring, xl, yl, xh, yh):
+    """the chain as the BUILD KERNEL forms it (chain_aux_kernel): one arc [lo, hi] of edge indices spanning every touching edge,
+    grown by the y-rule, never across the ring's first / last coordinate, at most CHAIN_MAX edges; None = fallback"""
+    n = len(ring) - 1  # edges 0 .. n - 1, vertices 0 .. n (vertex n closes the ring)
+    T = [i for i in range(n) if seg_meets_rect(*ring[i], *ring[i + 1], xl, yl, xh, yh)]
+    if not T:
+        return None
+    lo, hi = min(T), max(T)
+    while hi - lo + 1 <= CHAIN_MAX:
+        if not (yl <= ring[hi + 1][1] <= yh):
+            break
+        if hi + 1 >= n:
+            return None
+        hi += 1
+    while hi - lo + 1 <= CHAIN_MAX:
+        if not (yl <= ring[lo][1] <= yh):
+            break
+        if lo <= 0:
+            return None
+        lo -= 1
+    if hi - lo + 1 > CHAIN_MAX:
+        return None
+    return list(range(lo, hi + 1))
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "c2"
+    as_kernel = "--as-kernel" in sys.argv
     rng = np.random.default_rng(7)
     if which == "c2":
         polys, R = synth.star_polygons(1000, 64), 512
@@ -90,7 +119,7 @@ def main():
     rx0, ry0 = x0 - 1.5 * fw, y0 - 1.5 * fh
     sw, sh = fw / S, fh / S
     pad_x, pad_y = fw / 65536.0 / S, fh / 65536.0 / S
-    chain_len, bad, checked, cells = [], 0, 0, 0
+    chain_len, bad, checked, cells, fallbacks = [], 0, 0, 0, 0
     print(f"workload {which}: {len(polys)} polygons, raster {R}")
     for g in rng.choice(len(polys), 60, replace=False):
         ring = [(float(p[0]), float(p[1])) for p in xy[ro[g] : ro[g + 1]]]
@@ -105,7 +134,10 @@ def main():
         for (si, sj) in list(seen)[:120]:
             xl, xh = rx0 + si * sw - pad_x, rx0 + (si + 1) * sw + pad_x
             yl, yh = ry0 + sj * sh - pad_y, ry0 + (sj + 1) * sh + pad_y
-            C = local_chain(ring, xl, yl, xh, yh)
+            C = local_arc(ring, xl, yl, xh, yh) if as_kernel else local_chain(ring, xl, yl, xh, yh)
+            if C is None:
+                fallbacks += 1
+                continue
             if not C:
                 continue
             cells += 1
@@ -130,7 +162,7 @@ def main():
                 if on_full != on_loc or (not on_full and (wn_full != 0) != (wn_loc != 0)) or (not on_full and wn_full != wn_loc):
                     bad += 1
     cl = np.array(chain_len)
-    print(f"sub-cells with a chain: {cells}; points checked: {checked}; disagreements: {bad}")
+    print(f"sub-cells with a chain: {cells}; points checked: {checked}; disagreements: {bad}" + (f"; fallbacks (no single short arc): {fallbacks}" if as_kernel else ""))
     print(f"chain length: mean {cl.mean():.2f}, median {np.median(cl):.0f}, p90 {np.percentile(cl, 90):.0f}, max {cl.max()}  (C2 rings have 64 edges; a slab row of the current index holds ~7.7 of them)")
     return 1 if bad else 0
 
