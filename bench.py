@@ -112,17 +112,15 @@ class Ctx:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        if self.world != args.gpus:
+        if self.world != args.gpus:  # (main() launches the ranks itself when there is no launcher: this is a launcher that disagrees)
             if self.rank == 0:
-                print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}; launch with torch.distributed.run", file=sys.stderr)
-            if self.world == 1 and args.gpus > 1:
-                sys.exit(2)
+                print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}: the line reports n_gpus = {self.world}", file=sys.stderr)
         if not torch.cuda.is_available():
             print("bench.py: no GPU visible — libgeopolars_hip has no CPU fallback", file=sys.stderr)
             sys.exit(3)
         torch.cuda.set_device(self.local_rank)
         self.dev = torch.device("cuda", self.local_rank)
-        self.use_dist = self.world > 1 or args.force_dist
+        self.use_dist = self.world > 1 or args.force_dist or (args.spawn and "WORLD_SIZE" in os.environ)
         if self.use_dist:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
@@ -145,6 +143,14 @@ class Ctx:
         t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
+
+    def all_ranks(self, v: float) -> list:
+        if not self.use_dist:
+            return [v]
+        t = self.torch.zeros(self.world, dtype=self.torch.float64, device=self.dev)
+        t[self.rank] = v
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [float(x) for x in t.tolist()]
 
     def sum_over_ranks(self, v: float) -> float:
         if not self.use_dist:
@@ -184,6 +190,7 @@ class Ctx:
         lib.gpk_profile_filter(b"")
         k_ms, k_n = self.kernel_ms(dominant)
         lib.gpk_profile_reset()
+        self.rank_seconds = self.all_ranks(t1 - t0)  # every rank's own clock around the same K steps (the line carries them)
         return self.max_over_ranks(t1 - t0), k_ms, k_n, warm
 
     # substring queries: no name here is a substring of another one that can run in the same step
@@ -258,6 +265,11 @@ def base_line(ctx: Ctx, metric: str, value: float, unit: str, ms_per_step: float
         "data": "synthetic",
         "config": dict(config, device=ctx.dev_name, cus=ctx.cus),
         "roofline": roofline,
+        "ranks": {
+            "world": ctx.world,
+            "backend": ("nccl (RCCL)" if ctx.use_dist else None),
+            "ms_per_step_per_rank": [t / a.steps * 1e3 for t in getattr(ctx, "rank_seconds", [])],
+        },
     }
 
 
@@ -887,6 +899,25 @@ def parity_area(host, gpu_area) -> dict:
 
 
 # ------------------------------------------------------------------------------------------------------
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: re-run this very command line as N ranks of one node under
+    torch.distributed.run (one process per GPU, RCCL over xGMI, rendezvous on 127.0.0.1 at a free port).  Rank 0's JSON line
+    comes through on stdout unchanged; the exit status is the launcher's."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it across processes)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    print(f"bench.py: --gpus {n} without WORLD_SIZE: launching {n} ranks under torch.distributed.run (port {port})", file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2")
@@ -908,11 +939,14 @@ def main() -> None:
     ap.add_argument("--no-profile", action="store_true", help="tuning only: no HIP events around the kernels (the roofline leg reads zero)")
     ap.add_argument("--no-join-stats", action="store_true", help="c2: skip the extra untimed step that counts the exact phase's work (its atomics make that one launch ~7x longer: kernel-trace averages of a profiler run stay clean without it)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the exchange even at world size 1 (path test)")
+    ap.add_argument("--spawn", action="store_true", help="launch the rank(s) under torch.distributed.run even for --gpus 1 (what --gpus N > 1 does by itself when there is no launcher)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = {"c2": 20, "c3": 10, "c4": 10, "c5": 10}[args.config]
     if args.points is None:
         args.points = {"c2": 10_000_000, "c3": 10_000_000, "c4": 0, "c5": 6_250_000}[args.config]
+    if (args.gpus > 1 or args.spawn) and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     ctx = Ctx(args)
     {"c2": run_c2, "c3": run_c3, "c4": run_c4, "c5": run_c5}[args.config](ctx)
 

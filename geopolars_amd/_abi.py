@@ -114,6 +114,7 @@ _PROTOS = {
     "gpk_index_build_ex": (C.c_int32, [_VP, C.c_int32, _VP, _VP, C.POINTER(_VP)]),
     "gpk_index_free": (C.c_int32, [_VP]),
     "gpk_index_nbytes": (C.c_int32, [_VP, C.POINTER(C.c_int64)]),
+    "gpk_index_describe": (C.c_int32, [_VP, C.POINTER(C.c_int64)]),
     "gpk_spatial_join": (
         C.c_int32,
         [_VP, _VP, _VP, C.c_int32, C.c_uint32, _VP, _VP, C.c_int64, C.POINTER(C.c_int64), C.c_int32, _VP],

@@ -137,6 +137,38 @@ __device__ __forceinline__ bool ring_edge(double sx, double sy, double ex, doubl
     return false;
 }
 
+// ring_edge for kernels that keep the expansion arithmetic out of their code (pip_tile_chain, gpk_join.hip): the same arms, but an
+// orientation that Shewchuk's stage-A bound cannot certify is not recomputed here — `unsure` is set and the caller hands the
+// point to the exact walk.  (wn and the return value are then meaningless for this edge.)
+__device__ __forceinline__ bool ring_edge_filtered(double sx, double sy, double ex, double ey, double cx, double cy, int& wn, bool& unsure) {
+    const bool up = sy <= cy && ey >= cy;
+    const bool down = sy > cy && ey <= cy;
+    if (!(up || down)) return false;
+    const double lo = fmin(sx, ex), hi = fmax(sx, ex);
+    if (cx < lo) {
+        wn += up ? (ey != cy ? 1 : 0) : -1;
+        return false;
+    }
+    if (!(cx <= hi)) return false;
+    const double detleft = (sx - cx) * (ey - cy);
+    const double detright = (sy - cy) * (ex - cx);
+    const double det = detleft - detright;
+    const double detsum = fabs(detleft) + fabs(detright);
+    const double errbound = 3.3306690738754716e-16 * detsum;
+    const bool opposite = (detleft > 0.0 && detright <= 0.0) || (detleft < 0.0 && detright >= 0.0) || detleft == 0.0;
+    if (!(opposite || fabs(det) >= errbound)) {
+        unsure = true;
+        return false;
+    }
+    const int o = (det > 0.0) - (det < 0.0);
+    if (o == 0) return true;
+    if (up)
+        wn += (o > 0 && ey != cy) ? 1 : 0;
+    else
+        wn -= (o < 0) ? 1 : 0;
+    return false;
+}
+
 // coord_pos_relative_to_ring over a closed ring in global memory.
 __device__ inline int coord_pos_ring(const double2* __restrict__ ring, int n, double cx, double cy) {
     if (n == 0) return POS_OUTSIDE;

@@ -74,6 +74,32 @@ struct SubCell2 {
     uint32_t pad[4];
 };
 constexpr uint32_t SUB2_BIT = 1u << 29;         // in a CELL_TAG_SUB payload: the index refers to PipView::sub2
+// "test" sub-cells of a lean index (one part per cell), decided in the owning lane: for the padded sub-cell Q the LOCAL CHAIN is
+// the run of ring edges that covers every edge meeting Q, grown at both ends while the end vertex's y lies in Q's y-interval;
+// then winding(p) = base + sum of the chain edges' contributions for every p of Q (the rule is checked on
+// the CPU by tools/proto_local_chain.py / tests/test_local_chain_rule.py).  count == 0: no single short chain (several runs,
+// more than CHAIN_MAX edges, a wrap over the ring's end, a part with holes): the lane walks the part's slabs instead.
+// An index that carries chains (PipView::sub_aux) stores, in every one-part record, the position of the record's first chain
+// entry in SubCell::e0 (the slab ranges e0 / e1 / e2 are what the queue kernel reads; the chain kernel never does): the entry
+// of a `test` sub-cell is sub_aux[e0 + rank of its label among the record's `test` labels].
+constexpr int CHAIN_MAX = 7;
+struct ChainAux {
+    uint32_t first;  // coordinate index (into the array's xy) of the chain's first vertex; the chain is edges first .. first + count - 1
+    uint8_t count;   // 1 .. CHAIN_MAX, or 0 = walk the part
+    int8_t base;     // summed winding contribution of every edge outside the chain: constant over the padded sub-cell
+    uint16_t pad;
+};
+// Level-1 routing of a small raster (R <= PIP_ROUTE_RMAX) as an LDS image: one 16-byte word per 32 consecutive cells of a
+// raster row.  A persistent work-group keeps the whole image in LDS (128 KB at R = 512) and a point learns from ONE LDS
+// read whether its cell is empty (nothing to fetch), carries a one-part record (its index = rec0 + rank of the cell's bit:
+// records are numbered in cell order) or needs the level-1 word from memory (interiors, the few list cells).
+constexpr int PIP_ROUTE_RMAX = 512;
+struct RouteWord {
+    uint32_t bmask;  // bit i: cell 32 * w + i carries a one-part level-2 record
+    uint32_t gmask;  // bit i: the cell's level-1 word must be read (interior of a part, list cell, anything else non-empty)
+    uint32_t rec0;   // record index of the first cell set in bmask
+    uint32_t pad;
+};
 struct PipView {
     int32_t R;  // 0 = accelerator not built (degenerate extent): kernels use the generic walk
     double rx0, ry0, fw, fh, inv_fw, inv_fh;
@@ -81,6 +107,8 @@ struct PipView {
     const uint32_t* list;
     const SubCell* sub;              // level-2 records (cell tag 3)
     const SubCell2* sub2;            // two-part level-2 records (cell tag 3, payload & SUB2_BIT)
+    const ChainAux* sub_aux;         // lean indexes with chains (see ChainAux); else nullptr
+    const RouteWord* route;          // LDS image of the level-1 routing (chains + R <= PIP_ROUTE_RMAX); else nullptr
     const SubCell* lrec;             // level-2 records of the BOUNDARY entries of list cells: when set, such an entry is
                                      // `record index << 1 | 1` (the record names the part), else `part << 1 | 1`
     const uint32_t* part_geom;       // nullptr for POLYGON arrays (part == geometry)

@@ -717,7 +717,7 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_LEAN_MINWAVES) void pip_tile_lean_ke
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         ra[k] = rb[k] = make_uint4(0u, 0u, 0u, 0u);
-        if ((word[k] >> 30) == CELL_TAG_SUB) {
+        if ((word[k] >> 30) == CELL_TAG_SUB && !(word[k] & SUB2_BIT)) {
             const uint4* __restrict__ r = reinterpret_cast<const uint4*>(pv.sub + (word[k] & 0x3FFFFFFFu));
             ra[k] = r[0];  // part_flags, e0, e1, e2
             rb[k] = r[1];  // labels
@@ -735,9 +735,11 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_LEAN_MINWAVES) void pip_tile_lean_ke
         todo[k] = false;
         qpart[k] = ra[k].x;  // part | (has holes) << 31
         qe0[k] = qcnt[k] = 0;
-        if (tag == CELL_TAG_SINGLE) {
+        // (what the host-side gate of a lean index rules out — boundary entries without a record, two-part records, records
+        // that reach their slabs through PartInfo — takes the generic walk here instead of being trusted not to occur)
+        if (tag == CELL_TAG_SINGLE && !(payload & 1u)) {
             res[k] = payload >> 1;  // lean index: single entries are interiors (boundary cells carry records)
-        } else if (tag == CELL_TAG_SUB) {
+        } else if (tag == CELL_TAG_SUB && !(payload & SUB2_BIT) && !(ra[k].x & SUB_INDIRECT)) {
             const uint32_t fy = fyf[k] >> FY_SUB;
             const int idx = (int)((fy % S) * S + (sx[k] % S));
             const int wsel = idx >> 4;
@@ -750,7 +752,7 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_LEAN_MINWAVES) void pip_tile_lean_ke
                 qcnt[k] = (upper ? ra[k].w : ra[k].z) - qe0[k];
                 todo[k] = qcnt[k] > 0 && GPK_ABLATE != 1;  // an empty slab: p.y is outside the exterior's y-range (ablation 1: no exact phase)
             }
-        } else if (tag == CELL_TAG_LIST) {  // the few cells where parts meet (a lean index has next to none): generic walk
+        } else if (tag != CELL_TAG_EMPTY) {  // the few cells where parts meet (a lean index has next to none): generic walk
             qpart[k] = LEAN_SLOW;
             todo[k] = true;
         }
@@ -847,6 +849,281 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_LEAN_MINWAVES) void pip_tile_lean_ke
         const unsigned long long tot = s_tot;
         block_tot[blockIdx.x] = tot;
         if (tot) atomicAdd(&super_tot[blockIdx.x >> PIP_SUPER_SHIFT], tot);
+    }
+}
+
+// ---- pip_tile_chain: the lean tile step with `test` sub-cells decided in the owning lane ---------------------------------
+// (gpk_index::pip_lean with PipView::sub_aux: ChainAux tables, gpk_index.h.)  One WAVE owns a tile of 64 * PPT points and
+// never meets another wave: no queue, no lane groups, no LDS traffic between lanes, no barrier.  A point reads its level-1
+// word, then — in a cell an edge crosses — the cell's level-2 record; a `test` label sends it to its chain entry (the rank of
+// the label among the record's `test` labels locates it) and the lane sums the contributions of the chain's one or two ring
+// edges (1.26 on the C2 right side) on top of the stored base winding.
+//
+// ROUTE = true (PipView::route, R <= PIP_ROUTE_RMAX): persistent work-groups keep the level-1 routing in LDS (RouteWord); a
+// point then needs no memory request at all in an empty cell, ONE gather (the record, its index computed from the LDS word)
+// in a cell an edge crosses, and the level-1 word only in interiors: 0.65 dependent gathers per point instead of 1.5.
+//
+// The kernels' arguments hold only what the hot path reads (the full views — two DevGeo, IndexView, PipView: 100 dwords — do
+// not fit the scalar register file next to the kernel's own state; the compiler then parks them in vector-register lanes and
+// pays a v_readlane per use).  Everything that needs those views is NOT done here: a point of a list cell, a `test` point
+// whose sub-cell has no chain entry, a point whose orientation against a chain edge Shewchuk's stage-A bound cannot certify
+// — a handful per launch on real data — is appended to a deferred list and decided by pip_fixup_kernel with the generic
+// (always exact) walk.  The tile kernels therefore contain no call, no expansion arithmetic and no scratch memory.
+#ifndef GPK_CHAIN_PPT
+#define GPK_CHAIN_PPT 4
+#endif
+#ifndef GPK_CHAIN_NT
+#define GPK_CHAIN_NT 1  // non-temporal point loads: a point is read exactly once by this kernel
+#endif
+#ifndef GPK_CHAIN_ABLATE
+#define GPK_CHAIN_ABLATE 0  // tuning builds only (answers wrong on purpose): 1 = `test` points count as outside
+#endif
+#ifndef GPK_ROUTE_BLOCK
+#define GPK_ROUTE_BLOCK 1024
+#endif
+#ifndef GPK_ROUTE_PPT
+#define GPK_ROUTE_PPT 4
+#endif
+constexpr int CHAIN_PPT = GPK_CHAIN_PPT, ROUTE_PPT = GPK_ROUTE_PPT, ROUTE_BLOCK = GPK_ROUTE_BLOCK;
+static_assert(PIP_WTILE % (64 * CHAIN_PPT) == 0 && PIP_WTILE % (64 * ROUTE_PPT) == 0, "a writer tile is a whole number of chain tiles");
+
+struct ChainHot {
+    const double2* pts_xy;
+    const uint8_t* pts_validity;
+    int64_t n_points, n_tiles;
+    const double2* polys_xy;
+    const uint8_t* polys_validity;
+    int32_t R;
+    double rx0, ry0, inv_fw, inv_fh;
+    const uint32_t* cell;
+    const SubCell* sub;
+    const ChainAux* sub_aux;
+    const uint32_t* part_geom;
+    const RouteWord* route;
+    uint32_t* counts;
+    uint32_t* code;
+    unsigned long long* block_tot;
+    unsigned long long* super_tot;
+    unsigned long long* stats;
+    uint32_t* defer_count;  // zeroed with the totals
+    uint32_t* defer_list;   // left-row indices (one slot per point: a hostile point set can defer every row)
+};
+
+template <int PPT>
+__device__ __forceinline__ void chain_load_points(const ChainHot& h, int64_t tile, int lane, double2 (&p)[PPT]) {
+    const int64_t base = tile * (64 * PPT);
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int64_t i = base + k * 64 + lane;
+        const bool ok = tile < h.n_tiles && i < h.n_points && dev::valid_row(h.pts_validity, i);
+        p[k] = ok ? (GPK_CHAIN_NT ? dev::load_stream(h.pts_xy + i) : h.pts_xy[i]) : make_double2(NAN, NAN);
+    }
+}
+
+template <int PPT, bool ROUTE>
+__device__ __forceinline__ void chain_tile(const double2 (&p)[PPT], const ChainHot& h, const uint4* s_route, int64_t tile, int lane) {
+    constexpr int S = PIP_SUB, CHAIN_TILE = 64 * PPT;
+    const int64_t base = tile * CHAIN_TILE;
+    const uint32_t rem = (uint32_t)(h.n_points - base < (int64_t)CHAIN_TILE ? h.n_points - base : (int64_t)CHAIN_TILE);
+    const uint32_t R = (uint32_t)h.R;
+
+    // level 1: the cell's word (ROUTE: from the LDS image where that answers)
+    uint32_t sidx[PPT], word[PPT];  // sidx: the point's sub-cell within its cell (label index, x fastest)
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const uint32_t sx = (uint32_t)dev::cell_of(p[k].x, h.rx0, h.inv_fw * S, (int)(R * S));
+        const uint32_t sy = (uint32_t)dev::cell_of(p[k].y, h.ry0, h.inv_fh * S, (int)(R * S));
+        const bool real = p[k].x == p[k].x && p[k].y == p[k].y;
+        const uint32_t cx = sx / S, cy = sy / S;
+        sidx[k] = (sy % S) * S + (sx % S);
+        if (ROUTE) {
+            const uint4 rw = s_route[cy * (R >> 5) + (cx >> 5)];  // RouteWord: bmask, gmask, rec0
+            const uint32_t bit = cx & 31u;
+            word[k] = 0u;
+            if (real && ((rw.x >> bit) & 1u))
+                word[k] = (CELL_TAG_SUB << 30) | (rw.z + (uint32_t)__popc(rw.x & ((1u << bit) - 1u)));
+            else if (real && ((rw.y >> bit) & 1u))
+                word[k] = h.cell[cy * R + cx];
+        } else {
+            word[k] = real ? h.cell[cy * R + cx] : 0u;
+        }
+    }
+    // level 2: records of the cells an edge crosses — the head (part | flags, first chain entry, `test` labels per label word)
+    // and the ONE label word that holds the point's sub-cell (both off the record's 32-byte line)
+    uint4 ra[PPT];
+    uint32_t lw[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        ra[k] = make_uint4(0u, 0u, 0u, 0u);
+        lw[k] = 0u;
+        if ((word[k] >> 30) == CELL_TAG_SUB && !(word[k] & SUB2_BIT)) {
+            const SubCell* __restrict__ r = h.sub + (word[k] & 0x3FFFFFFFu);
+            ra[k] = *reinterpret_cast<const uint4*>(r);
+            lw[k] = r->labels[sidx[k] >> 4];
+        }
+    }
+    // decide; `test` points name their chain entry, anything a lean index should not hold is deferred
+    uint32_t res[PPT], aux_at[PPT];
+    uint32_t tmask = 0u, dmask = 0u;  // bit k: point k is a `test` point / is deferred to the generic walk
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const uint32_t tag = word[k] >> 30, payload = word[k] & 0x3FFFFFFFu;
+        res[k] = CODE_NONE;
+        aux_at[k] = 0u;
+        if (tag == CELL_TAG_SINGLE && !(payload & 1u)) {
+            res[k] = payload >> 1;
+        } else if (tag == CELL_TAG_SUB && !(payload & SUB2_BIT)) {
+            const uint32_t sh = 2u * (sidx[k] & 15u), wsel = sidx[k] >> 4;
+            const uint32_t lab = (lw[k] >> sh) & 3u;
+            if (lab == 1u) res[k] = ra[k].x & 0x3FFFFFFFu;
+            if (lab >= 2u && GPK_CHAIN_ABLATE != 1) {
+                // rank of this `test` label among the record's: the label words before it (counted at build time, one byte
+                // per word in the head), then the fields below it in its own word
+                const uint32_t before = wsel == 0 ? 0u : ((ra[k].z >> (8u * (wsel - 1u))) & 0xFFu);
+                const uint32_t tl = (lw[k] >> 1) & ~lw[k] & 0x55555555u;
+                aux_at[k] = ra[k].y + before + (uint32_t)__popc(tl & ((1u << sh) - 1u));
+                tmask |= 1u << k;
+            }
+        } else if (word[k] != 0u) {  // list cells (a lean index has next to none), and whatever a lean index should not hold
+            dmask |= 1u << k;
+        }
+    }
+    uint2 ca[PPT];  // ChainAux: first | count, base
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        ca[k] = make_uint2(0u, 0u);
+        if (tmask & (1u << k)) ca[k] = *reinterpret_cast<const uint2*>(h.sub_aux + aux_at[k]);
+    }
+    // the exact step, one point per lane and round: a lane holds 0.2 `test` points on average, so one or two rounds decide the
+    // wave (a loop per k would run PPT times)
+    unsigned long long edges_walked = 0, pairs_walked = 0;
+    while (__any(tmask != 0u)) {
+        if (tmask != 0u) {
+            const int k = __ffs((int)tmask) - 1;
+            tmask &= tmask - 1u;
+            double px = p[0].x, py = p[0].y;
+            uint2 c = ca[0];
+            uint32_t part = ra[0].x;
+#pragma unroll
+            for (int kk = 1; kk < PPT; ++kk)
+                if (k == kk) {
+                    px = p[kk].x;
+                    py = p[kk].y;
+                    c = ca[kk];
+                    part = ra[kk].x;
+                }
+            part &= 0x3FFFFFFFu;
+            const int count = (int)(c.y & 0xFFu);
+            bool inside = false, defer = count == 0;  // no chain entry for this sub-cell: the generic walk decides
+            if (count > 0) {
+                const double2* __restrict__ v = h.polys_xy + c.x;
+                int wn = (int)(int8_t)((c.y >> 8) & 0xFFu);
+                const double2 v0 = v[0], v1 = v[1], v2 = v[count >= 2 ? 2 : 1];
+                bool on = dev::ring_edge_filtered(v0.x, v0.y, v1.x, v1.y, px, py, wn, defer);
+                if (count >= 2) on |= dev::ring_edge_filtered(v1.x, v1.y, v2.x, v2.y, px, py, wn, defer);
+                double2 a = v2;
+                for (int j = 2; j < count; ++j) {
+                    const double2 b = v[j + 1];
+                    on |= dev::ring_edge_filtered(a.x, a.y, b.x, b.y, px, py, wn, defer);
+                    a = b;
+                }
+                inside = !on && wn != 0;
+                edges_walked += (unsigned long long)count;
+            }
+            if (defer) dmask |= 1u << k;
+            ++pairs_walked;
+#pragma unroll
+            for (int kk = 0; kk < PPT; ++kk)
+                if (k == kk) res[kk] = inside ? part : CODE_NONE;
+        }
+    }
+    // deferred points: provisional "no hit" here, the real answer (count, code, totals) from pip_fixup_kernel
+#pragma unroll
+    for (int k = 0; k < PPT; ++k)
+        if (dmask & (1u << k)) {
+            res[k] = CODE_NONE;
+            if ((uint32_t)(k * 64 + lane) < rem) h.defer_list[atomicAdd(h.defer_count, 1u)] = (uint32_t)(base + k * 64 + lane);
+        }
+    if (h.stats && pairs_walked) {  // measurement runs only (gpk_join_stats_enable): uniform branch on the pointer
+        atomicAdd(&h.stats[0], pairs_walked);
+        atomicAdd(&h.stats[1], edges_walked);
+    }
+    // finalize: part -> geometry (null geometries dropped), count + code, the tile's total
+    uint32_t* __restrict__ tile_counts = h.counts ? h.counts + base : nullptr;
+    uint32_t* __restrict__ tile_code = h.code + base;
+    unsigned long long hits = 0;  // wave-uniform
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const uint32_t li = (uint32_t)(k * 64 + lane);
+        uint32_t r = res[k];
+        if (r != CODE_NONE) {
+            const uint32_t geom = h.part_geom ? h.part_geom[r] : r;
+            r = dev::valid_row(h.polys_validity, geom) ? geom : CODE_NONE;
+        }
+        const uint32_t cnt = r != CODE_NONE ? 1u : 0u;
+        if (li < rem) {
+            if (tile_counts) dev::store_stream(tile_counts + li, cnt);
+            dev::store_stream(tile_code + li, r);
+        }
+        hits += (unsigned long long)__popcll(__ballot(li < rem && cnt == 1u));
+    }
+    if (lane == 0) {
+        h.block_tot[tile] = hits;
+        if (hits) atomicAdd(&h.super_tot[tile >> PIP_SUPER_SHIFT], hits);  // integer adds: order-independent
+    }
+}
+
+__global__ __launch_bounds__(PIP_BLOCK) void pip_tile_chain_kernel(ChainHot h) {
+    const int64_t tile = (int64_t)blockIdx.x * (PIP_BLOCK / 64) + (threadIdx.x >> 6);
+    if (tile >= h.n_tiles) return;  // (whole waves)
+    const int lane = threadIdx.x & 63;
+    double2 p[CHAIN_PPT];
+    chain_load_points<CHAIN_PPT>(h, tile, lane, p);
+    chain_tile<CHAIN_PPT, false>(p, h, nullptr, tile, lane);
+}
+
+// persistent work-groups (one per CU: the routing image takes most of its LDS), a wave walks tiles wave, wave + W, ...
+__global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_route_kernel(ChainHot h) {
+    __shared__ uint4 s_route[PIP_ROUTE_RMAX * PIP_ROUTE_RMAX / 32];
+    {
+        const int words = h.R * h.R / 32;
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(h.route);
+        for (int i = threadIdx.x; i < words; i += ROUTE_BLOCK) s_route[i] = src[i];
+    }
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * (ROUTE_BLOCK / 64);
+    int64_t tile = (int64_t)blockIdx.x * (ROUTE_BLOCK / 64) + (threadIdx.x >> 6);
+    __syncthreads();
+    // (no software prefetch of the next tile: vector loads return in order, so the first dependent gather of this tile would
+    // wait for the next tile's points as well — the other fifteen waves of the CU are what hides a wave's load latency)
+    for (; tile < h.n_tiles; tile += stride) {
+        double2 p[ROUTE_PPT];
+        chain_load_points<ROUTE_PPT>(h, tile, lane, p);
+        chain_tile<ROUTE_PPT, true>(p, h, s_route, tile, lane);
+    }
+}
+
+// The deferred points of a chain / route launch, decided by the generic walk (directory candidates -> full ring walks with the
+// exact orientation kernel): count, code and the two levels of totals are corrected before pip_write reads them.  Real data
+// defers a handful of points; the launch exists so that the tile kernels need none of this code.
+__global__ __launch_bounds__(256) void pip_fixup_kernel(DevGeo pts, DevGeo polys, IndexView ix, const uint32_t* __restrict__ defer_count,
+                                                        const uint32_t* __restrict__ defer_list, int tile_points, uint32_t* __restrict__ counts,
+                                                        uint32_t* __restrict__ code, unsigned long long* __restrict__ block_tot,
+                                                        unsigned long long* __restrict__ super_tot, unsigned long long* __restrict__ stats) {
+    const uint32_t nd = *defer_count;
+    if (stats && nd && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[2], (unsigned long long)nd);
+    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < nd; e += gridDim.x * 256u) {
+        const uint32_t g = defer_list[e];
+        const double2 p = pts.xy[g];
+        uint32_t cnt, first;
+        generic_point(polys, ix, p.x, p.y, cnt, first);
+        if (counts) counts[g] = cnt;
+        code[g] = cnt == 0 ? CODE_NONE : (cnt == 1 ? first : CODE_MULTI);
+        if (cnt) {
+            const uint32_t tile = g / (uint32_t)tile_points;
+            atomicAdd(&block_tot[tile], (unsigned long long)cnt);
+            atomicAdd(&super_tot[tile >> PIP_SUPER_SHIFT], (unsigned long long)cnt);
+        }
     }
 }
 
@@ -1261,14 +1538,24 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         return e && *e && *e != '0';
     }();
     const bool lean = right_index->pip.R > 0 && right_index->pip_lean && !no_lean;
-    const int tile_points = lean ? LEAN_TILE : PIP_TILE;
+    // an index with chains (ChainAux, gpk_index.h) is served by the chain kernels only: its records carry chain positions where
+    // the queue kernel expects slab ranges.  GPK_NO_ROUTE=1: A/B runs without the LDS routing image.
+    static const bool no_route = [] {
+        const char* e = getenv("GPK_NO_ROUTE");
+        return e && *e && *e != '0';
+    }();
+    const bool has_chains = right_index->pip.R > 0 && right_index->pip.sub_aux != nullptr;
+    const bool chain = has_chains;  // (the deferred list lives in the multi-hit pool: one word per left row, see multi_cap)
+    const bool route = chain && right_index->pip.route != nullptr && right_index->pip.R <= PIP_ROUTE_RMAX && !no_route;
+    const int tile_points = chain ? 64 * (route ? ROUTE_PPT : CHAIN_PPT) : (lean ? LEAN_TILE : PIP_TILE);
     const int64_t n_blocks = (n + tile_points - 1) / tile_points;
     const bool want_pairs = pair_capacity > 0;
     const size_t counts_bytes = sizeof(uint32_t) * (size_t)n;
     const size_t pairs_bytes = sizeof(uint32_t) * 2 * (size_t)pair_capacity;
     const int64_t n_super = (n_blocks >> PIP_SUPER_SHIFT) + 1;
     const int64_t n_wblocks = (n + PIP_WTILE - 1) / PIP_WTILE;
-    const uint32_t multi_cap = (uint32_t)(n < (int64_t)0x18000000 ? 2 * n + 1024 : (int64_t)0x30000000);  // words in the multi-hit pool
+    // words in the multi-hit pool — or, for a chain launch (which has no multi-hit rows), in the deferred list: one per left row
+    const uint32_t multi_cap = chain ? (uint32_t)(n > 1024 ? n : 1024) : (uint32_t)(n < (int64_t)0x18000000 ? 2 * n + 1024 : (int64_t)0x30000000);
     size_t need = align256(counts_bytes + 64) /*code*/ + align256(sizeof(unsigned long long) * (size_t)(n_blocks + n_super + 3)) +
                   align256(sizeof(uint32_t) * (size_t)multi_cap) + 1024;
     if (host_out && out_counts) need += align256(counts_bytes);
@@ -1298,12 +1585,47 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         if (_rc != GPK_OK) return _rc;         \
     } while (0)
 
+    unsigned long long* stats = join_stats_buffer();  // nullptr unless gpk_join_stats_enable(1)
     {
-        const hipError_t me = hipMemsetAsync(stot, 0, sizeof(unsigned long long) * (size_t)(n_super + 2), s);
+        const hipError_t me = hipMemsetAsync(stot, 0, sizeof(unsigned long long) * (size_t)(n_super + 2), s);  // (+ grand, multi_top / the deferred count)
         if (me != hipSuccess) return fail(GPK_ERR_DEVICE, "spatial_join: %s", hipGetErrorString(me));
     }
-    unsigned long long* stats = join_stats_buffer();  // nullptr unless gpk_join_stats_enable(1)
-    if (lean)
+    ChainHot hot;
+    memset(&hot, 0, sizeof hot);
+    if (chain) {
+        const PipView& pv = right_index->pip;
+        hot.pts_xy = left->d.xy;
+        hot.pts_validity = left->d.validity;
+        hot.n_points = n;
+        hot.n_tiles = n_blocks;
+        hot.polys_xy = right->d.xy;
+        hot.polys_validity = right->d.validity;
+        hot.R = pv.R;
+        hot.rx0 = pv.rx0;
+        hot.ry0 = pv.ry0;
+        hot.inv_fw = pv.inv_fw;
+        hot.inv_fh = pv.inv_fh;
+        hot.cell = pv.cell;
+        hot.sub = pv.sub;
+        hot.sub_aux = pv.sub_aux;
+        hot.part_geom = pv.part_geom;
+        hot.route = pv.route;
+        hot.counts = counts_dev;
+        hot.code = code;
+        hot.block_tot = btot;
+        hot.super_tot = stot;
+        hot.stats = stats;
+        hot.defer_count = multi_top;   // (a chain launch has no multi-hit pool: its words and its cursor hold the deferred rows)
+        hot.defer_list = multi_pool;
+    }
+    if (chain && route) {  // persistent work-groups, one per CU
+        int64_t wgs = (int64_t)cu_count();
+        const int64_t want = (n_blocks + ROUTE_BLOCK / 64 - 1) / (ROUTE_BLOCK / 64);
+        if (wgs > want) wgs = want;
+        J_LAUNCH("gpk_pip_tile", pip_tile_route_kernel, dim3((unsigned)wgs), dim3(ROUTE_BLOCK), 0, s, hot);
+    } else if (chain)
+        J_LAUNCH("gpk_pip_tile", pip_tile_chain_kernel, dim3((unsigned)((n_blocks + PIP_BLOCK / 64 - 1) / (PIP_BLOCK / 64))), dim3(PIP_BLOCK), 0, s, hot);
+    else if (lean)
         J_LAUNCH("gpk_pip_tile", pip_tile_lean_kernel, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d, right_index->v, right_index->pip,
                  counts_dev, code, btot, stot, stats);
     else if (right_index->pip.R > 0)
@@ -1316,6 +1638,9 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
     else
         J_LAUNCH("gpk_pip_tile_generic", (pip_tile_kernel<false, false>), dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
                  right_index->v, right_index->pip, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top, stats);
+    if (chain)  // the deferred rows (gpk_join.hip: ChainHot) before the writer reads codes and totals
+        J_LAUNCH("gpk_pip_fixup", pip_fixup_kernel, dim3(128), dim3(256), 0, s, left->d, right->d, right_index->v, (const uint32_t*)multi_top,
+                 (const uint32_t*)multi_pool, tile_points, counts_dev, code, btot, stot, stats);
     // the writer also produces the grand total; in count-only mode it runs without a pair buffer
     J_LAUNCH("gpk_pip_write", pip_write_kernel, dim3((unsigned)n_wblocks), dim3(WR_BLOCK), 0, s, left->d, right->d, right_index->v,
              code, btot, stot, (const uint32_t*)multi_pool, n_blocks, tile_points, left_row_base, (uint2*)pairs_dev, pair_capacity, grand, total_out);
@@ -1470,6 +1795,16 @@ int32_t gpk_index_free(gpk_index* idx) {
     for (int i = 0; i < 24; ++i)
         if (idx->owned[i]) (void)hipFree(idx->owned[i]);
     delete idx;
+    return GPK_OK;
+}
+
+int32_t gpk_index_describe(const gpk_index* idx, int64_t out[8]) {
+    if (!idx || !out) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
+    for (int i = 0; i < 8; ++i) out[i] = 0;
+    out[0] = idx->pip.R;
+    out[1] = idx->pip_lean;
+    out[2] = idx->pip.sub_aux != nullptr;
+    out[3] = idx->pip.route != nullptr;
     return GPK_OK;
 }
 

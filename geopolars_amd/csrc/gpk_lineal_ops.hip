@@ -151,6 +151,10 @@ __global__ __launch_bounds__(256) void rdp_kernel(const double2* __restrict__ xy
         uint8_t* __restrict__ kp = keep + c0;
         int2* __restrict__ st = stack + c0;
         for (int i = lane; i < n; i += G) kp[i] = 1;
+        // the group's lanes overwrite each other's marks below (lane (k - ri - 1) % G culls what lane k % G marked): order them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         int len = n, top = 0;  // simplified_len; stack depth (identical on every lane of the group)
         int ri = 0, rj = n - 1;
         bool have = n >= 3 && eps > 0.0;  // fewer than three points, or a non-positive epsilon: unchanged (geo's rdp wrapper)
@@ -235,7 +239,7 @@ using namespace gpk;
 extern "C" {
 
 int32_t gpk_geodesic_length(const gpk_geoarray* a, int32_t method, double* out, int32_t out_space, void* stream) {
-    if (!a || !out) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!a || (!out && a->d.n_geoms > 0)) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
     if (method == GPK_GEODESIC_KARNEY)
         return fail(GPK_ERR_INVALID_ARGUMENT,
                     "geodesic_length: method 'geodesic' (Karney's algorithm, geographiclib) is not restated in this backend; use 'haversine' or "

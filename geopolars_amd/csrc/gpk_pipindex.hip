@@ -123,7 +123,8 @@ __device__ __forceinline__ bool edge_at(const DevGeo& a, int i, int& r, double2&
 template <bool FILL>
 __global__ void slab_register_kernel(DevGeo a, FineGrid f, const int32_t* __restrict__ row0,
                                      const int32_t* __restrict__ slab_base, int32_t* __restrict__ cnt_or_cursor,
-                                     double4* __restrict__ edges) {
+                                     double4* __restrict__ edges, int32_t* __restrict__ vidx = nullptr) {
+    // vidx (optional, FILL only): the coordinate index every slab entry's edge starts at (build-time only: chain_aux_kernel)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_coords) return;
     int r;
@@ -138,7 +139,10 @@ __global__ void slab_register_kernel(DevGeo a, FineGrid f, const int32_t* __rest
     for (int j = j0; j <= j1; ++j) {
         const int sl = slab_base[r] + (j - slab_row0_of(rr));
         const int slot = atomicAdd(&cnt_or_cursor[sl], 1);
-        if (FILL) edges[slot] = make_double4(s.x, s.y, e.x, e.y);
+        if (FILL) {
+            edges[slot] = make_double4(s.x, s.y, e.x, e.y);
+            if (vidx) vidx[slot] = (int32_t)i;
+        }
     }
 }
 
@@ -512,6 +516,179 @@ __global__ void lrec_count_kernel(const uint32_t* __restrict__ cell, const uint3
     }
     cnt[c] = n;
 }
+// ---- local chains of the `test` sub-cells of a lean index (gpk_index.h: ChainAux) ------------------------------------------
+__device__ __forceinline__ int test_labels_of(uint32_t w) { return __popc((w >> 1) & ~w & 0x55555555u); }  // 2-bit fields equal to 2
+__global__ void chain_count_kernel(const SubCell* __restrict__ sub, int64_t n_sub, int32_t* __restrict__ cnt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_sub) return;
+    const SubCell rc = sub[i];
+    cnt[i] = test_labels_of(rc.labels[0]) + test_labels_of(rc.labels[1]) + test_labels_of(rc.labels[2]) + test_labels_of(rc.labels[3]);
+}
+// One wave per record (work item = (cell, part) of sub_work_kernel), lane = sub-cell.  The wave lists the edges of the part's
+// slab rows in this raster row that meet the padded cell (with the coordinate index each starts at), every `test` lane then
+//   1. takes the listed edges that meet ITS padded sub-cell (exact: the test that labelled it) and the arc [lo, hi] of ring
+//      edges spanning them,
+//   2. grows the arc at both ends while the end vertex's y lies in the sub-cell's closed y-interval,
+//   3. sums the contributions, at the sub-cell centre, of the edges of the centre's slab row that are NOT in the arc: `base`.
+// An arc that would pass the ring's first / last coordinate, exceed CHAIN_MAX edges, a part with holes, or a cell whose edge
+// list overflowed gets count = 0 (the join walks the part's slab for such points).
+__global__ __launch_bounds__(256) void chain_aux_kernel(DevGeo a, PipView pv, FineGrid g, const int32_t* __restrict__ work_cell,
+                                                        const uint32_t* __restrict__ work_part, int64_t n_work,
+                                                        const int32_t* __restrict__ slab_vidx, const SubCell* __restrict__ sub,
+                                                        const int32_t* __restrict__ aux_base, ChainAux* __restrict__ aux) {
+    constexpr int S = PIP_SUB, SS = PIP_SUB * PIP_SUB;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t item = t / SS;
+    const int k = (int)(t % SS);
+    if (item >= n_work) return;  // (whole waves: SS == 64)
+    const int64_t c = work_cell[item];
+    const int part = (int)work_part[item];
+    const SubCell rc = sub[item];
+    const uint32_t lw = rc.labels[k >> 4];
+    const bool test = ((lw >> (2 * (k & 15))) & 3u) == 2u;
+    const unsigned long long tm = __ballot(test);
+    if (tm == 0ull) return;  // uniform
+    const int ci = (int)(c % g.R), cj = (int)(c / g.R);
+    const int si = S * ci + (k % S), sj = S * cj + (k / S);
+    const double fw2 = g.fw / S, fh2 = g.fh / S, px2 = g.pad_x / S, py2 = g.pad_y / S;
+    const double xl = g.rx0 + (double)si * fw2 - px2, xh = g.rx0 + (double)(si + 1) * fw2 + px2;
+    const double yl = g.ry0 + (double)sj * fh2 - py2, yh = g.ry0 + (double)(sj + 1) * fh2 + py2;
+    const double cxl = g.rx0 + (double)(S * ci) * fw2 - px2, cxh = g.rx0 + (double)(S * ci + S) * fw2 + px2;
+    const double cyl = g.ry0 + (double)(S * cj) * fh2 - py2, cyh = g.ry0 + (double)(S * cj + S) * fh2 + py2;
+    __shared__ double4 s_edges[256 / 64][SUB_EDGE_CAP];
+    __shared__ int32_t s_vidx[256 / 64][SUB_EDGE_CAP];
+    const int wave = threadIdx.x >> 6, lane64 = threadIdx.x & 63;
+    int r0, r1;
+    dev::part_rings(a, part, r0, r1);
+    bool list_ok = r1 - r0 == 1;  // a part with holes: no chains (uniform)
+    int n_list = 0;
+    if (list_ok) {
+        int e0, e1;
+        if (pip::slab_span_of_raster_row(pv, r0, cj, e0, e1)) {
+            for (int eb = e0; eb < e1 && list_ok; eb += 64) {
+                const int e = eb + lane64;
+                bool keep = false;
+                double4 ed = make_double4(0, 0, 0, 0);
+                if (e < e1) {
+                    ed = pv.slab_edges[e];
+                    keep = !(fmax(ed.x, ed.z) < cxl || fmin(ed.x, ed.z) > cxh || fmax(ed.y, ed.w) < cyl || fmin(ed.y, ed.w) > cyh);
+                }
+                const unsigned long long m = __ballot(keep);
+                const int add = __popcll(m);
+                if (n_list + add > SUB_EDGE_CAP) {
+                    list_ok = false;
+                    break;
+                }
+                if (keep) {
+                    const int at = n_list + __popcll(m & ((1ull << lane64) - 1ull));
+                    s_edges[wave][at] = ed;
+                    s_vidx[wave][at] = slab_vidx[e];
+                }
+                n_list += add;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (!test) return;
+    ChainAux out;
+    out.first = 0u;
+    out.count = 0;
+    out.base = 0;
+    out.pad = 0;
+    const int rank = __popcll(tm & ((1ull << lane64) - 1ull));
+    ChainAux* __restrict__ dst = aux + aux_base[item] + rank;
+    if (list_ok) {
+        const int c0 = a.ring_off[r0], c1 = a.ring_off[r0 + 1];  // the ring's coordinates: edges c0 .. c1 - 2
+        int lo = 0x7FFFFFFF, hi = -1;
+        for (int e = 0; e < n_list; ++e) {
+            const double4 ed = s_edges[wave][e];
+            if (fmax(ed.x, ed.z) < xl || fmin(ed.x, ed.z) > xh || fmax(ed.y, ed.w) < yl || fmin(ed.y, ed.w) > yh) continue;
+            const int o1 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yl), o2 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yl);
+            const int o3 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yh), o4 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yh);
+            if ((o1 > 0 && o2 > 0 && o3 > 0 && o4 > 0) || (o1 < 0 && o2 < 0 && o3 < 0 && o4 < 0)) continue;
+            const int v = s_vidx[wave][e];  // (an edge listed for both slab rows of the cell appears twice: same index)
+            lo = v < lo ? v : lo;
+            hi = v > hi ? v : hi;
+        }
+        bool ok = hi >= lo;
+        // grow: edge hi ends at vertex hi + 1, edge lo starts at vertex lo; stop at the ring's ends (a chain does not wrap)
+        while (ok && hi - lo + 1 <= CHAIN_MAX) {
+            const double y = a.xy[hi + 1].y;  // edge hi ends at vertex hi + 1 (<= c1 - 1, the closing coordinate)
+            if (!(y >= yl && y <= yh)) break;
+            if (hi + 1 >= c1 - 1) {  // the chain would continue with the ring's first edge: no wrapping chains
+                ok = false;
+                break;
+            }
+            ++hi;
+        }
+        while (ok && hi - lo + 1 <= CHAIN_MAX) {
+            const double y = a.xy[lo].y;  // edge lo starts at vertex lo (>= c0)
+            if (!(y >= yl && y <= yh)) break;
+            if (lo <= c0) {  // the chain would continue with the ring's last edge
+                ok = false;
+                break;
+            }
+            --lo;
+        }
+        ok = ok && hi - lo + 1 <= CHAIN_MAX;
+        if (ok) {
+            // base: the other edges' winding at the centre — they all sit in the centre's slab row
+            const double cx = g.rx0 + ((double)si + 0.5) * fw2, cy = g.ry0 + ((double)sj + 0.5) * fh2;
+            int e0, e1, wn = 0;
+            bool on = false;
+            if (pip::slab_range(pv, r0, pip::row_of(pv, cy), e0, e1)) {
+                for (int e = e0; e < e1; ++e) {
+                    const int v = slab_vidx[e];
+                    if (v >= lo && v <= hi) continue;
+                    const double4 ed = pv.slab_edges[e];
+                    on |= dev::ring_edge(ed.x, ed.y, ed.z, ed.w, cx, cy, wn);
+                }
+            }
+            if (!on && wn >= -127 && wn <= 127) {  // (an edge outside the chain cannot pass through the centre; guard anyway)
+                out.first = (uint32_t)lo;
+                out.count = (uint8_t)(hi - lo + 1);
+                out.base = (int8_t)wn;
+            }
+        }
+    }
+    *dst = out;
+}
+
+// an index with chains: every one-part record names its first chain entry in e0 and carries, in e1, the number of `test` labels in
+// label words 0, 0..1, 0..2 (one byte each) — the chain kernel then finds a label's rank from its own word alone (ChainAux)
+__global__ void chain_commit_kernel(SubCell* __restrict__ sub, int64_t n_sub, const int32_t* __restrict__ aux_base) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_sub) return;
+    const uint32_t c0 = (uint32_t)test_labels_of(sub[i].labels[0]), c1 = c0 + (uint32_t)test_labels_of(sub[i].labels[1]),
+                   c2 = c1 + (uint32_t)test_labels_of(sub[i].labels[2]);
+    sub[i].e0 = (uint32_t)aux_base[i];
+    sub[i].e1 = c0 | (c1 << 8) | (c2 << 16);
+    sub[i].e2 = 0u;
+}
+// LDS image of the level-1 routing (gpk_index.h: RouteWord): one thread per 32 cells of a raster row, after sub_commit_kernel
+__global__ void route_build_kernel(const uint32_t* __restrict__ cell, int64_t n_words, RouteWord* __restrict__ route) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    RouteWord rw{0u, 0u, 0u, 0u};
+    bool have = false;
+    for (int i = 0; i < 32; ++i) {
+        const uint32_t cw = cell[32 * w + i];
+        const uint32_t tag = cw >> 30, payload = cw & 0x3FFFFFFFu;
+        if (tag == CELL_TAG_SUB && !(payload & SUB2_BIT)) {
+            rw.bmask |= 1u << i;
+            if (!have) {
+                rw.rec0 = payload;
+                have = true;
+            }
+        } else if (cw != 0u) {
+            rw.gmask |= 1u << i;
+        }
+    }
+    route[w] = rw;
+}
+
 // one-part records: the flagged cells as a work list (cell, part), record pos[c] — the build then launches one wave per
 // RECORD instead of one per raster cell (two thirds of the cells of the C2 raster, nineteen in twenty of a 2048 x 2048 one,
 // carry no record)
@@ -707,8 +884,10 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, boo
     double4* edges = nullptr;
     GPK_HIP(hipMalloc((void**)&edges, sizeof(double4) * (size_t)(n_edges ? n_edges : 1)));
     keep(edges);
+    int32_t* slab_vidx = nullptr;  // build-time only: where every slab entry's edge starts (chains of lean indexes)
+    if ((int64_t)n_edges <= ((int64_t)64 << 20)) GPK_TRY(t.alloc(&slab_vidx, (size_t)(n_edges ? n_edges : 1)));
     GPK_LAUNCH("gpk_pipidx_slab_fill", slab_register_kernel<true>, blocks_for(d.n_coords), dim3(256), 0, s, d, gs, row0, slab_base,
-               cursor, edges);
+               cursor, edges, slab_vidx);
 
     stamp("slab fill (+ edges malloc)");
     PartInfo* part_info = nullptr;
@@ -802,6 +981,8 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, boo
     // ---- level 2 ------------------------------------------------------------------------------------
     int32_t n_sub = 0, n_sub2 = 0;
     bool sub_overflow = false;
+    int32_t* swork_cell = nullptr;   // the one-part records' (cell, part) work list: reused by the chain pass below
+    uint32_t* swork_part = nullptr;
     SubCell* sub = nullptr;
     SubCell2* sub2 = nullptr;
     static_assert(PIP_SLAB_MUL == 2, "SubCell stores exactly two adjacent slab ranges");
@@ -832,8 +1013,6 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, boo
             GPK_HIP(hipMalloc((void**)&sub, sizeof(SubCell) * (size_t)n_sub));
             keep(sub);
             GPK_HIP(hipMemsetAsync(sub, 0, sizeof(SubCell) * (size_t)n_sub, s));
-            int32_t* swork_cell;
-            uint32_t* swork_part;
             GPK_TRY(t.alloc(&swork_cell, (size_t)n_sub));
             GPK_TRY(t.alloc(&swork_part, (size_t)n_sub));
             GPK_LAUNCH("gpk_pipidx_sub_work", sub_work_kernel, blocks_for(n_cells), dim3(256), 0, s, (const uint32_t*)cell, (const int32_t*)sflag,
@@ -899,6 +1078,42 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, boo
     // their points through the generic walk: at most 1 list word per 8 one-part records)
     ix->pip_lean = (int64_t)list_len * 8 <= (int64_t)n_sub && n_refined == 0 && boundary_cells_have_records ? 1 : 0;
     if (getenv("GPK_DEBUG_INDEX")) fprintf(stderr, "[gpk] lean join kernel eligible: %d (list %d, refined rings %d, one-part records %d)\n", ix->pip_lean, list_len, n_refined, n_sub);
+    // local chains for the `test` sub-cells of a lean index (gpk_index.h: ChainAux): the join then decides them in the owning lane
+    if (ix->pip_lean && slab_vidx && n_sub > 0 && swork_cell && !getenv("GPK_NO_CHAINS")) {
+        int32_t *ccnt, *cbase_tmp;
+        GPK_TRY(t.alloc(&ccnt, (size_t)n_sub + 1));
+        GPK_TRY(t.alloc(&cbase_tmp, (size_t)n_sub + 1));
+        pv.sub = sub;
+        GPK_LAUNCH("gpk_pipidx_chain_count", chain_count_kernel, blocks_for(n_sub), dim3(256), 0, s, (const SubCell*)sub, (int64_t)n_sub, ccnt);
+        GPK_TRY(exclusive_scan_i32(ccnt, n_sub, cbase_tmp, nullptr, btot, s));
+        int32_t n_aux = 0;
+        GPK_HIP(hipMemcpyAsync(&n_aux, cbase_tmp + n_sub, sizeof n_aux, hipMemcpyDeviceToHost, s));
+        GPK_HIP(hipStreamSynchronize(s));
+        if (n_aux > 0) {
+            ChainAux* aux = nullptr;
+            GPK_HIP(hipMalloc((void**)&aux, sizeof(ChainAux) * (size_t)n_aux));
+            keep(aux);
+            GPK_LAUNCH("gpk_pipidx_chain_aux", chain_aux_kernel, blocks_for((int64_t)n_sub * PIP_SUB * PIP_SUB), dim3(256), 0, s, d, pv, g,
+                       (const int32_t*)swork_cell, (const uint32_t*)swork_part, (int64_t)n_sub, (const int32_t*)slab_vidx, (const SubCell*)sub,
+                       (const int32_t*)cbase_tmp, aux);
+            // (after chain_aux_kernel, which still reads the records' labels only: e0 now names the record's first chain entry)
+            GPK_LAUNCH("gpk_pipidx_chain_commit", chain_commit_kernel, blocks_for(n_sub), dim3(256), 0, s, sub, (int64_t)n_sub, (const int32_t*)cbase_tmp);
+            pv.sub_aux = aux;
+            ix->nbytes += (int64_t)(sizeof(ChainAux) * (size_t)n_aux);
+            if (R <= PIP_ROUTE_RMAX && !getenv("GPK_NO_ROUTE_IMAGE")) {
+                RouteWord* route = nullptr;
+                const int64_t n_words = n_cells / 32;
+                GPK_HIP(hipMalloc((void**)&route, sizeof(RouteWord) * (size_t)n_words));
+                keep(route);
+                GPK_LAUNCH("gpk_pipidx_route", route_build_kernel, blocks_for(n_words), dim3(256), 0, s, (const uint32_t*)cell, n_words, route);
+                pv.route = route;
+                ix->nbytes += (int64_t)(sizeof(RouteWord) * (size_t)n_words);
+            }
+            GPK_HIP(hipStreamSynchronize(s));
+            if (getenv("GPK_DEBUG_INDEX")) fprintf(stderr, "[gpk] local chains: %d test sub-cells in %d records%s\n", n_aux, n_sub, pv.route ? ", routing image" : "");
+        }
+        stamp("local chains");
+    }
     ix->nbytes += (int64_t)(sizeof(SubCell) * (size_t)n_sub + sizeof(SubCell2) * (size_t)n_sub2 + sizeof(SubCell) * (size_t)n_lrec);
     ix->pip = pv;
     ix->nbytes += (int64_t)(sizeof(uint32_t) * (size_t)n_cells + sizeof(uint32_t) * (size_t)list_len + sizeof(double4) * (size_t)n_edges +

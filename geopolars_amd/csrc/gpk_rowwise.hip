@@ -719,6 +719,7 @@ static int32_t rowmap_build_dev(const gpk_geoarray* ls, const uint32_t* rows_dev
         if (e1 != hipSuccess || e2 != hipSuccess) return fin(fail(GPK_ERR_OOM, "row map: hipMalloc failed"));
     }
     m->nbytes = (int64_t)(2 * nb);
+    if (n == 0) return fin(GPK_OK);  // an empty batch: an empty map (n_valid = 0), no launch (a grid of zero blocks is an error)
     // scratch: cnt | cnt_sorted | off | cursor (L+2 i32 each) | rank (L u32) | keys, sorted (L u64 each) | scan totals
     const size_t ib = align256(sizeof(int32_t) * (size_t)(L + 2)), kb = align256(sizeof(unsigned long long) * (size_t)(L + 1));
     size_t sort_bytes = 0;

@@ -75,10 +75,25 @@ Workspace& workspace() {
     return ws;
 }
 Workspace& workspace_for_stream(hipStream_t s) {
-    static thread_local std::vector<std::pair<hipStream_t, Workspace*>> arenas;  // a handful of streams per thread: linear search
-    for (auto& kv : arenas)
-        if (kv.first == s) return *kv.second;
-    arenas.emplace_back(s, new Workspace);  // lives as long as the thread (like the other arenas: never freed at teardown)
+    // A thread keeps at most STREAM_ARENAS of these (least recently used goes): callers that create and destroy a stream per
+    // batch would otherwise leave one join-sized arena (> 12 bytes per left row) behind per dead stream handle.  The evicted
+    // arena may still be in use by work queued on its stream, so it is released only after the device has drained.
+    constexpr size_t STREAM_ARENAS = 8;
+    static thread_local std::vector<std::pair<hipStream_t, Workspace*>> arenas;  // most recently used last; a handful: linear search
+    for (size_t i = 0; i < arenas.size(); ++i)
+        if (arenas[i].first == s) {
+            auto kv = arenas[i];
+            arenas.erase(arenas.begin() + (long)i);
+            arenas.push_back(kv);
+            return *kv.second;
+        }
+    if (arenas.size() >= STREAM_ARENAS) {
+        Workspace* old = arenas.front().second;
+        arenas.erase(arenas.begin());
+        old->trim(0);  // synchronises the device, then frees
+        delete old;
+    }
+    arenas.emplace_back(s, new Workspace);
     return *arenas.back().second;
 }
 Workspace& workspace_aux(int which) {

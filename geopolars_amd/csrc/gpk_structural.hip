@@ -218,7 +218,7 @@ using namespace gpk;
 extern "C" {
 
 int32_t gpk_envelope(const gpk_geoarray* a, double* out_xy, uint8_t* out_valid, int32_t out_space, void* stream) {
-    if (!a || !out_xy) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!a || (!out_xy && a->d.n_geoms > 0)) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");  // (an empty column has no output to point at)
     GPK_TRY(require_device());
     if (a->d.type == GPK_GEOM_POINT)
         return fail(GPK_ERR_MISMATCHED_GEOMETRY, "envelope: the envelope of a point is the point itself — pass a POINT column through unchanged");
@@ -360,7 +360,7 @@ int32_t gpk_explode(const gpk_geoarray* a, int32_t* out_parent, int32_t parent_s
 }
 
 int32_t gpk_geom_type(const gpk_geoarray* a, int8_t* out, int32_t out_space, void* stream) {
-    if (!a || !out) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!a || (!out && a->d.n_geoms > 0)) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
     GPK_TRY(require_device());
     hipStream_t s = (hipStream_t)stream;
     const int64_t n = a->d.n_geoms;
@@ -371,7 +371,7 @@ int32_t gpk_geom_type(const gpk_geoarray* a, int8_t* out, int32_t out_space, voi
 }
 
 int32_t gpk_is_empty(const gpk_geoarray* a, uint8_t* out, int32_t out_space, void* stream) {
-    if (!a || !out) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!a || (!out && a->d.n_geoms > 0)) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
     GPK_TRY(require_device());
     hipStream_t s = (hipStream_t)stream;
     const int64_t n = a->d.n_geoms;
@@ -382,7 +382,7 @@ int32_t gpk_is_empty(const gpk_geoarray* a, uint8_t* out, int32_t out_space, voi
 }
 
 int32_t gpk_is_ring(const gpk_geoarray* a, uint8_t* out, int32_t out_space, void* stream) {
-    if (!a || !out) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!a || (!out && a->d.n_geoms > 0)) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
     GPK_TRY(require_device());
     if (a->d.type != GPK_GEOM_LINESTRING)
         return fail(GPK_ERR_MISMATCHED_GEOMETRY, "is_ring: expected a LINESTRING column (found type %d)", a->d.type);
@@ -417,7 +417,7 @@ int32_t gpk_point_xy(const gpk_geoarray* a, double* out_x, double* out_y, int32_
 
 int32_t gpk_affine_about_origin(const gpk_geoarray* a, int32_t kind, double p0, double p1, int32_t origin, double ox, double oy, double* out_xy,
                                 int32_t out_space, void* stream) {
-    if (!a || !out_xy) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!a || (!out_xy && a->d.n_coords > 0)) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
     if (kind < GPK_AFFINE_ROTATE || kind > GPK_AFFINE_SKEW) return fail(GPK_ERR_INVALID_ARGUMENT, "unknown transform kind %d", kind);
     if (origin < GPK_ORIGIN_CENTROID || origin > GPK_ORIGIN_POINT) return fail(GPK_ERR_INVALID_ARGUMENT, "unknown origin %d", origin);  // "Invalid argument", utils.rs:21
     GPK_TRY(require_device());

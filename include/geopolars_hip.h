@@ -291,6 +291,10 @@ int32_t gpk_index_build_ex(const gpk_geoarray* a, int32_t parts, const double* b
                            gpk_index** out);
 int32_t gpk_index_free(gpk_index* idx);
 int32_t gpk_index_nbytes(const gpk_index* idx, int64_t* out_bytes);
+/* What the index holds (tests and bench.py report it; nothing in a join depends on the caller knowing):
+ *   out = {raster side R (0: no point-in-polygon tables), one-part-per-cell ("lean") 0/1, local chains 0/1 (`test` sub-cells
+ *          decided from one or two ring edges in the owning lane), LDS routing image 0/1 (R <= 512), 0, 0, 0, 0} */
+int32_t gpk_index_describe(const gpk_index* idx, int64_t out[8]);
 
 /*
  * spatial_join refine (spatial_index.rs:74-143): all (l, r) with predicate(left[l], right[r]) true,
@@ -353,8 +357,10 @@ int32_t gpk_take_binary(const uint8_t* values, const int32_t* offsets, const uin
 
 /* ---- join statistics (bench.py's edge_tests/s) ---------------------------------- */
 /* While enabled, the point x polygonal join kernels count what their exact phase does (a few atomics per tile:
- * leave it off in timed regions).  out = {(point, part) pairs sent to the exact winding walk, slab edges walked
- * for them, 0, 0}, accumulated over the joins since the last reset; gpk_join_stats waits for the device. */
+ * leave it off in timed regions).  out = {(point, part) pairs sent to the exact winding walk, edges walked for them,
+ * left rows a chain-kernel join deferred to the generic walk (list cells, sub-cells without a chain entry, orientations
+ * the floating-point filter could not certify), 0}, accumulated over the joins since the last reset; gpk_join_stats waits
+ * for the device. */
 int32_t gpk_join_stats_enable(int32_t on);
 int32_t gpk_join_stats(int64_t out[4], int32_t reset);
 

@@ -133,3 +133,17 @@ def test_bench_n_rank_path_at_world_1(gpk, config, extra):
     assert line["parity"].get("bit_exact", True) and line["parity"].get("max_rel_err", 0.0) <= 1e-9
     if config in ("c4", "c5"):
         assert line["config"]["right_side_exchange"]["bytes"] > 0
+
+
+def test_bench_launches_its_own_ranks(gpk):
+    """`python bench.py --gpus N` with no launcher re-runs itself under torch.distributed.run (exercised here at N = 1 with
+    --spawn: the same code path, RCCL initialised by the spawned rank); the line carries every rank's own step time"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn", "--points", "2000000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+           "--parity-rows", "20000"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "launching 1 ranks under torch.distributed.run" in r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    assert line["n_gpus"] == 1 and line["ranks"]["world"] == 1 and line["ranks"]["backend"] == "nccl (RCCL)"
+    assert len(line["ranks"]["ms_per_step_per_rank"]) == 1 and line["parity"]["bit_exact"]

@@ -146,3 +146,24 @@ def test_translate_of_the_reference_bench(gpk):
     """benches/affine.rs:23-26: translate(10, 10)"""
     pts = synth.uniform_points(202)
     assert np.array_equal(GeoSeries(pts).translate(10.0, 10.0).array.xy, pts.xy + 10.0)
+
+
+def test_zero_row_columns_and_columns_of_empty_geometries(gpk):
+    """a zero-length series returns zero-length results (the C entry points accept a NULL output when there is nothing to write);
+    rotate / scale / skew over rows that hold no coordinate leave them as they are"""
+    from geopolars_amd.geoseries import RowMap
+
+    for empty in (GeoArrowArray.from_polygons([]), GeoArrowArray.from_linestrings([])):
+        s = GeoSeries(empty)
+        assert len(s.geom_type()) == 0 and len(s.is_empty()) == 0 and len(s.envelope()) == 0
+        assert len(s.rotate(30.0)) == 0 and len(s.scale(2.0, 3.0)) == 0 and len(s.skew(10.0, 5.0, origin="centroid")) == 0
+    ls = GeoSeries(GeoArrowArray.from_linestrings([]))
+    assert len(ls.is_ring()) == 0 and len(ls.geodesic_length("haversine")) == 0 and len(ls.euclidean_length()) == 0
+    hollow = GeoSeries(GeoArrowArray.from_polygons([[], [], []]))  # three rows, no ring, no coordinate
+    assert hollow.is_empty().tolist() == [True, True, True]
+    for t in (hollow.rotate(45.0), hollow.scale(2.0, 2.0, origin="centroid"), hollow.skew(1.0, 2.0, origin=(0.0, 0.0))):
+        assert len(t) == 3 and t.array.n_coords == 0
+    lines = GeoSeries(synth.random_linestrings(50))
+    m = RowMap(lines, np.zeros(0, dtype=np.uint32))  # an empty batch builds an empty map
+    pts = GeoSeries(GeoArrowArray.from_points(np.zeros((0, 2))))
+    assert len(pts.distance(lines, row_map=m)) == 0

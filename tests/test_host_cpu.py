@@ -346,3 +346,18 @@ def test_bench_helpers_sampling_and_traffic_records(tmp_path, monkeypatch):
     assert rec is None and "stale" in why and "0000" in why
     rec, why = bench.pmc_config_record("c4")
     assert rec is None and "no PMC record" in why
+
+
+def test_bench_gpus_n_without_a_launcher_spawns_n_ranks():
+    """`python bench.py --gpus 2` must not exit asking for a launcher: it re-runs itself as 2 ranks under torch.distributed.run.
+    There is no GPU here, so each rank stops at "no GPU visible" — which shows that both were started."""
+    import subprocess, sys as _sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([_sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env)
+    assert "launching 2 ranks under torch.distributed.run" in r.stderr
+    import torch
+
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and r.stderr.count("no GPU visible") == 2
