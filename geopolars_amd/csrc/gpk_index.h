@@ -78,17 +78,29 @@ constexpr uint32_t SUB2_BIT = 1u << 29;         // in a CELL_TAG_SUB payload: th
 // the run of ring edges that covers every edge meeting Q, grown at both ends while the end vertex's y lies in Q's y-interval;
 // then winding(p) = base + sum of the chain edges' contributions for every p of Q (the rule is checked on
 // the CPU by tools/proto_local_chain.py / tests/test_local_chain_rule.py).  count == 0: no single short chain (several runs,
-// more than CHAIN_MAX edges, a wrap over the ring's end, a part with holes): the lane walks the part's slabs instead.
-// An index that carries chains (PipView::sub_aux) stores, in every one-part record, the position of the record's first chain
-// entry in SubCell::e0 (the slab ranges e0 / e1 / e2 are what the queue kernel reads; the chain kernel never does): the entry
-// of a `test` sub-cell is sub_aux[e0 + rank of its label among the record's `test` labels].
-constexpr int CHAIN_MAX = 7;
+// more than CHAIN_MAX edges, a part with holes): the row is decided by the generic walk (pip_fixup_kernel).
+constexpr int CHAIN_MAX = 12;
+// chain entry i of an index = chain_head[i] (count, base, where vertices 4 .. are) + sub_aux[i] (the first four vertices, one cache
+// line): a `test` point reads both with independent requests and needs nothing else — 99.8 % of the chains of the C2 right side
+// have at most three edges.
+constexpr uint32_t CHAIN_COUNT_MASK = 0xFu;  // bits 0-3: edges in the chain, 1 .. CHAIN_MAX (0 = no chain entry: the generic walk decides)
+constexpr int CHAIN_BASE_SHIFT = 4;          // bits 4-11: summed winding contribution of every ring edge outside the chain (signed):
+                                             // constant over the padded sub-cell
+constexpr int CHAIN_EXT_SHIFT = 12;          // bits 12-31: count > 3: PipView::chain_ext[ext .. ext + count - 3) are vertices 4 .. count
 struct ChainAux {
-    uint32_t first;  // coordinate index (into the array's xy) of the chain's first vertex; the chain is edges first .. first + count - 1
-    uint8_t count;   // 1 .. CHAIN_MAX, or 0 = walk the part
-    int8_t base;     // summed winding contribution of every edge outside the chain: constant over the padded sub-cell
-    uint16_t pad;
+    double2 v[4];  // the chain's first four vertices, copied (a chain may run over the ring's closing vertex)
 };
+// An index with chains keeps its one-part level-2 records (PipView::sub, 32 bytes per raster cell) as TWO half-cell records: the
+// labels of four sub-cell rows, the part, and where the half's chain entries start — everything a point needs, in one 16-byte
+// request.  (The queue kernels read the SubCell form; an index has one or the other: pip_join_enqueue picks the kernel.)
+struct HalfCell {
+    uint32_t lw[2];       // 2 x 16 labels (label words 2 * half and 2 * half + 1 of the cell)
+    uint32_t part_flags;  // part | (part has holes) << 31
+    uint32_t aux_base;    // chain entry of the half's first `test` label (label order)
+};
+static_assert(sizeof(HalfCell) * 2 == sizeof(SubCell), "two half-cell records overlay one SubCell");
+static_assert(sizeof(ChainAux) == 64, "one chain entry per cache line");
+static_assert(CHAIN_MAX <= (int)CHAIN_COUNT_MASK, "the edge count of a chain is a 4-bit field");
 // Level-1 routing of a small raster (R <= PIP_ROUTE_RMAX) as an LDS image: one 16-byte word per 32 consecutive cells of a
 // raster row.  A persistent work-group keeps the whole image in LDS (128 KB at R = 512) and a point learns from ONE LDS
 // read whether its cell is empty (nothing to fetch), carries a one-part record (its index = rec0 + rank of the cell's bit:
@@ -108,6 +120,8 @@ struct PipView {
     const SubCell* sub;              // level-2 records (cell tag 3)
     const SubCell2* sub2;            // two-part level-2 records (cell tag 3, payload & SUB2_BIT)
     const ChainAux* sub_aux;         // lean indexes with chains (see ChainAux); else nullptr
+    const uint32_t* chain_head;      // count | base | ext per chain entry
+    const double2* chain_ext;        // vertices 4 .. of the chains longer than three edges
     const RouteWord* route;          // LDS image of the level-1 routing (chains + R <= PIP_ROUTE_RMAX); else nullptr
     const SubCell* lrec;             // level-2 records of the BOUNDARY entries of list cells: when set, such an entry is
                                      // `record index << 1 | 1` (the record names the part), else `part << 1 | 1`

@@ -13,6 +13,7 @@
 // (A single-pass variant with decoupled look-back was measured and was slower on MI355X: the in-order
 // commit makes finished work-groups hold their LDS/wave slots while they wait — see DESIGN.md.)
 #include <cstring>
+#include <type_traits>
 
 #include <rocprim/rocprim.hpp>
 
@@ -852,16 +853,24 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_LEAN_MINWAVES) void pip_tile_lean_ke
     }
 }
 
-// ---- pip_tile_chain: the lean tile step with `test` sub-cells decided in the owning lane ---------------------------------
-// (gpk_index::pip_lean with PipView::sub_aux: ChainAux tables, gpk_index.h.)  One WAVE owns a tile of 64 * PPT points and
-// never meets another wave: no queue, no lane groups, no LDS traffic between lanes, no barrier.  A point reads its level-1
-// word, then — in a cell an edge crosses — the cell's level-2 record; a `test` label sends it to its chain entry (the rank of
-// the label among the record's `test` labels locates it) and the lane sums the contributions of the chain's one or two ring
-// edges (1.26 on the C2 right side) on top of the stored base winding.
-//
-// ROUTE = true (PipView::route, R <= PIP_ROUTE_RMAX): persistent work-groups keep the level-1 routing in LDS (RouteWord); a
-// point then needs no memory request at all in an empty cell, ONE gather (the record, its index computed from the LDS word)
-// in a cell an edge crosses, and the level-1 word only in interiors: 0.65 dependent gathers per point instead of 1.5.
+// ---- pip_tile_chain / pip_tile_route: the lean tile step with `test` sub-cells decided from their local chains -----------------
+// (gpk_index::pip_lean with PipView::sub_aux: chain tables, gpk_index.h.)  One WAVE owns a tile of 64 * P points and never meets
+// another wave: no work-group queue, no barrier.  A point's way through the tables, one dependent memory round trip per step:
+//   1. the point itself (coalesced 16-byte loads, non-temporal: read once);
+//   2. its raster cell: empty -> done; strictly inside a part -> the level-1 word names it; an edge crosses the cell -> the half-cell
+//      record of the point's sub-cell (ONE 16-byte request: 32 labels, the part, where the half's chain entries start);
+//   3. the label: outside / inside -> done; `test` -> the sub-cell's chain entry (the rank of the label among the half's `test`
+//      labels locates it): a head word (edge count, base winding) + one 64-byte line with the chain's vertices;
+//   4. base + the contributions of the chain's one or two edges (1.26 on the C2 right side); count + code + tile total.
+// Step 3 / 4 concern one point in twenty, scattered over the lanes: the wave packs those points into a list in its own slice of
+// LDS (no other wave sees it: wave-level ordering is enough) and lanes 0 .. T - 1 take one each — one round trip and one pass of
+// the orientation code for all of the tile's `test` points, in dense lanes.
+//   pip_tile_chain   level 1 from memory (any raster size);
+//   pip_tile_route   level 1 from an LDS image (PipView::route, R <= PIP_ROUTE_RMAX) kept by persistent work-groups: an empty cell
+//                    costs no request at all, a record's index comes straight from the LDS word (one round trip less), and
+//                    only interiors read their level-1 word.
+// What bounds them (measured): the L2's request rate — every divergent gather is one request whatever its size —
+// and the vector ALU (each point costs ~100 instructions); hence one request per table level and no per-lane loops.
 //
 // The kernels' arguments hold only what the hot path reads (the full views — two DevGeo, IndexView, PipView: 100 dwords — do
 // not fit the scalar register file next to the kernel's own state; the compiler then parks them in vector-register lanes and
@@ -872,8 +881,18 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_LEAN_MINWAVES) void pip_tile_lean_ke
 #ifndef GPK_CHAIN_PPT
 #define GPK_CHAIN_PPT 4
 #endif
+#define GPK_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// a loop over 0 .. N - 1 whose index is a compile-time constant in the body: per-point state lives in small arrays, and only constant
+// indices from the start keep the compiler from turning such an array into one wide register tuple (or leaving it in scratch memory)
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
 #ifndef GPK_CHAIN_NT
-#define GPK_CHAIN_NT 1  // non-temporal point loads: a point is read exactly once by this kernel
+#define GPK_CHAIN_NT 1  // non-temporal point loads: a point is read exactly once by these kernels
 #endif
 #ifndef GPK_CHAIN_ABLATE
 #define GPK_CHAIN_ABLATE 0  // tuning builds only (answers wrong on purpose): 1 = `test` points count as outside
@@ -882,7 +901,7 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_LEAN_MINWAVES) void pip_tile_lean_ke
 #define GPK_ROUTE_BLOCK 1024
 #endif
 #ifndef GPK_ROUTE_PPT
-#define GPK_ROUTE_PPT 4
+#define GPK_ROUTE_PPT 8
 #endif
 constexpr int CHAIN_PPT = GPK_CHAIN_PPT, ROUTE_PPT = GPK_ROUTE_PPT, ROUTE_BLOCK = GPK_ROUTE_BLOCK;
 static_assert(PIP_WTILE % (64 * CHAIN_PPT) == 0 && PIP_WTILE % (64 * ROUTE_PPT) == 0, "a writer tile is a whole number of chain tiles");
@@ -891,13 +910,14 @@ struct ChainHot {
     const double2* pts_xy;
     const uint8_t* pts_validity;
     int64_t n_points, n_tiles;
-    const double2* polys_xy;
     const uint8_t* polys_validity;
-    int32_t R;
+    int32_t R, logR;  // the raster side is a power of two
     double rx0, ry0, inv_fw, inv_fh;
     const uint32_t* cell;
-    const SubCell* sub;
+    const HalfCell* half;
     const ChainAux* sub_aux;
+    const uint32_t* chain_head;
+    const double2* chain_ext;
     const uint32_t* part_geom;
     const RouteWord* route;
     uint32_t* counts;
@@ -909,151 +929,212 @@ struct ChainHot {
     uint32_t* defer_list;   // left-row indices (one slot per point: a hostile point set can defer every row)
 };
 
-template <int PPT>
-__device__ __forceinline__ void chain_load_points(const ChainHot& h, int64_t tile, int lane, double2 (&p)[PPT]) {
-    const int64_t base = tile * (64 * PPT);
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        const int64_t i = base + k * 64 + lane;
-        const bool ok = tile < h.n_tiles && i < h.n_points && dev::valid_row(h.pts_validity, i);
-        p[k] = ok ? (GPK_CHAIN_NT ? dev::load_stream(h.pts_xy + i) : h.pts_xy[i]) : make_double2(NAN, NAN);
-    }
-}
+// one `test` point of a tile, in the wave's LDS list (24 bytes; reading the point again from memory instead was measured: the
+// tile's lines are streamed with the non-temporal hint and are gone from the L2 — 20 us more per launch)
+struct ChainItem {
+    double px, py;
+    uint32_t aux_at;  // in: the point's chain entry; out: the verdict (bit 0 inside, bit 1 defer)
+    uint32_t pad;
+};
+// list slots per wave = one pass of the exact step: a quarter of the tile's points.  A tile with more `test` points than that (the
+// raster is far too coarse for such a right side) hands the surplus to the generic walk like any other deferred row.
+template <int P>
+constexpr int chain_items() { return 16 * P; }
 
-template <int PPT, bool ROUTE>
-__device__ __forceinline__ void chain_tile(const double2 (&p)[PPT], const ChainHot& h, const uint4* s_route, int64_t tile, int lane) {
-    constexpr int S = PIP_SUB, CHAIN_TILE = 64 * PPT;
+// FULL: the tile holds 64 * P points and the left column has no validity bitmap (wave-uniform, true for all tiles but the last
+// of a plain column): no per-point guards on loads and stores
+template <int P, bool ROUTE, bool FULL>
+__device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mask, const uint32_t* s_rec0, ChainItem* s_items, int64_t tile, int lane) {
+    constexpr int S = PIP_SUB, CHAIN_TILE = 64 * P, ITEMS = chain_items<P>();
     const int64_t base = tile * CHAIN_TILE;
-    const uint32_t rem = (uint32_t)(h.n_points - base < (int64_t)CHAIN_TILE ? h.n_points - base : (int64_t)CHAIN_TILE);
-    const uint32_t R = (uint32_t)h.R;
-
-    // level 1: the cell's word (ROUTE: from the LDS image where that answers)
-    uint32_t sidx[PPT], word[PPT];  // sidx: the point's sub-cell within its cell (label index, x fastest)
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        const uint32_t sx = (uint32_t)dev::cell_of(p[k].x, h.rx0, h.inv_fw * S, (int)(R * S));
-        const uint32_t sy = (uint32_t)dev::cell_of(p[k].y, h.ry0, h.inv_fh * S, (int)(R * S));
-        const bool real = p[k].x == p[k].x && p[k].y == p[k].y;
+    const uint32_t rem = FULL ? (uint32_t)CHAIN_TILE : (uint32_t)(h.n_points - base < (int64_t)CHAIN_TILE ? h.n_points - base : (int64_t)CHAIN_TILE);
+    const int logR = h.logR;
+    // 1. the points
+    const double2* __restrict__ tile_xy = h.pts_xy + base;
+    double px[P], py[P];
+    static_for<P>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        double2 v = make_double2(NAN, NAN);
+        if (FULL || ((uint32_t)(k * 64 + lane) < rem && dev::valid_row(h.pts_validity, base + k * 64 + lane)))
+            v = GPK_CHAIN_NT ? dev::load_stream(tile_xy + (k * 64 + lane)) : tile_xy[k * 64 + lane];
+        px[k] = v.x;
+        py[k] = v.y;
+    });
+    // (GPK_SCHED_FENCE: nothing is moved across — left to itself the scheduler interleaves the steps of different points until it
+    // runs out of registers, then spills; the source order below IS the intended schedule: requests of a step back to back, their
+    // uses in the next step)
+    GPK_SCHED_FENCE();
+    // 2. level 1 (ROUTE: from the LDS image where that answers), then the half-cell records
+    uint32_t sidx[P], w[P], gw[P];  // sub-cell within the cell (label index, x fastest); record index known from LDS (recmask); level-1
+                                    // word requested (its own register: a register with a request pending for SOME lanes cannot be
+                                    // read by the others without waiting for it)
+    uint32_t recmask = 0u;          // bit k: point k's cell carries a one-part record and w[k] is its index (ROUTE only)
+    const double sub_max = (double)(((uint32_t)S << logR) - 1u);
+    static_for<P>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        // dev::cell_of at sub-cell resolution (negative / NaN products clamp to 0, large ones to the last sub-cell)
+        const uint32_t sx = (uint32_t)fmin(fmax((px[k] - h.rx0) * (h.inv_fw * S), 0.0), sub_max);
+        const uint32_t sy = (uint32_t)fmin(fmax((py[k] - h.ry0) * (h.inv_fh * S), 0.0), sub_max);
+        const bool real = px[k] == px[k] && py[k] == py[k];
         const uint32_t cx = sx / S, cy = sy / S;
         sidx[k] = (sy % S) * S + (sx % S);
+        w[k] = gw[k] = 0u;
+        bool want = false;
         if (ROUTE) {
-            const uint4 rw = s_route[cy * (R >> 5) + (cx >> 5)];  // RouteWord: bmask, gmask, rec0
-            const uint32_t bit = cx & 31u;
-            word[k] = 0u;
-            if (real && ((rw.x >> bit) & 1u))
-                word[k] = (CELL_TAG_SUB << 30) | (rw.z + (uint32_t)__popc(rw.x & ((1u << bit) - 1u)));
-            else if (real && ((rw.y >> bit) & 1u))
-                word[k] = h.cell[cy * R + cx];
-        } else {
-            word[k] = real ? h.cell[cy * R + cx] : 0u;
-        }
-    }
-    // level 2: records of the cells an edge crosses — the head (part | flags, first chain entry, `test` labels per label word)
-    // and the ONE label word that holds the point's sub-cell (both off the record's 32-byte line)
-    uint4 ra[PPT];
-    uint32_t lw[PPT];
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        ra[k] = make_uint4(0u, 0u, 0u, 0u);
-        lw[k] = 0u;
-        if ((word[k] >> 30) == CELL_TAG_SUB && !(word[k] & SUB2_BIT)) {
-            const SubCell* __restrict__ r = h.sub + (word[k] & 0x3FFFFFFFu);
-            ra[k] = *reinterpret_cast<const uint4*>(r);
-            lw[k] = r->labels[sidx[k] >> 4];
-        }
-    }
-    // decide; `test` points name their chain entry, anything a lean index should not hold is deferred
-    uint32_t res[PPT], aux_at[PPT];
-    uint32_t tmask = 0u, dmask = 0u;  // bit k: point k is a `test` point / is deferred to the generic walk
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        const uint32_t tag = word[k] >> 30, payload = word[k] & 0x3FFFFFFFu;
-        res[k] = CODE_NONE;
-        aux_at[k] = 0u;
-        if (tag == CELL_TAG_SINGLE && !(payload & 1u)) {
-            res[k] = payload >> 1;
-        } else if (tag == CELL_TAG_SUB && !(payload & SUB2_BIT)) {
-            const uint32_t sh = 2u * (sidx[k] & 15u), wsel = sidx[k] >> 4;
-            const uint32_t lab = (lw[k] >> sh) & 3u;
-            if (lab == 1u) res[k] = ra[k].x & 0x3FFFFFFFu;
-            if (lab >= 2u && GPK_CHAIN_ABLATE != 1) {
-                // rank of this `test` label among the record's: the label words before it (counted at build time, one byte
-                // per word in the head), then the fields below it in its own word
-                const uint32_t before = wsel == 0 ? 0u : ((ra[k].z >> (8u * (wsel - 1u))) & 0xFFu);
-                const uint32_t tl = (lw[k] >> 1) & ~lw[k] & 0x55555555u;
-                aux_at[k] = ra[k].y + before + (uint32_t)__popc(tl & ((1u << sh) - 1u));
-                tmask |= 1u << k;
+            const uint32_t at = (cy << (logR - 5)) + (cx >> 5), bit = cx & 31u;
+            const uint2 m = s_mask[at];  // RouteWord: bmask, gmask
+            if (real && ((m.x >> bit) & 1u)) {
+                w[k] = s_rec0[at] + (uint32_t)__popc(m.x & ((1u << bit) - 1u));
+                recmask |= 1u << k;
+            } else {
+                want = real && ((m.y >> bit) & 1u);
             }
-        } else if (word[k] != 0u) {  // list cells (a lean index has next to none), and whatever a lean index should not hold
+        } else {
+            want = real;
+        }
+        if (want) gw[k] = h.cell[(cy << logR) + cx];
+        GPK_SCHED_FENCE();
+    });
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 rec[P];  // HalfCell: lw[0], lw[1], part, aux_base  (kept as the 16-byte tuple the request fills: copies out of it would sit
+                   // in the requesting branch and wait for the request on the spot — P round trips one after the other)
+    static_for<P>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        rec[k] = u32x4{0u, 0u, 0u, 0u};
+        if (!ROUTE) {  // the record's index is in the word just read: this wait is the chain kernel's extra round trip
+            if ((gw[k] >> 30) == CELL_TAG_SUB && !(gw[k] & SUB2_BIT)) {
+                w[k] = gw[k] & 0x3FFFFFFFu;
+                recmask |= 1u << k;
+            }
+        }
+        if ((recmask >> k) & 1u) rec[k] = *reinterpret_cast<const u32x4*>(h.half + 2u * w[k] + (sidx[k] >> 5));
+    });
+    GPK_SCHED_FENCE();
+    // 3. labels; a `test` point goes into the wave's LDS list with its chain entry; anything a lean index should not hold is deferred
+    static_assert(ITEMS <= 256, "a list slot is an 8-bit field");
+    uint32_t res[P], slots[(P + 3) / 4];  // slots: the list slot of point k in byte k % 4 of word k / 4
+    static_for<(P + 3) / 4>([&](auto J) { slots[decltype(J)::value] = 0u; });
+    uint32_t tmask = 0u, dmask = 0u;  // bit k: point k is in the list / is deferred to the generic walk
+    uint32_t n_items = 0;             // wave-uniform
+    static_for<P>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        const bool has = ((recmask >> k) & 1u) != 0u;
+        const uint32_t tag = gw[k] >> 30, payload = gw[k] & 0x3FFFFFFFu;
+        res[k] = CODE_NONE;
+        bool test = false;
+        uint32_t aux_at = 0u;
+        if (has) {
+            const uint32_t sh = 2u * (sidx[k] & 15u), upper = (sidx[k] >> 4) & 1u;
+            const uint32_t lw = upper ? rec[k].y : rec[k].x;
+            const uint32_t lab = (lw >> sh) & 3u;
+            if (lab >= 1u) res[k] = rec[k].z & 0x3FFFFFFFu;
+            if (lab >= 2u) {
+                // rank of this `test` label among the half's: the lower label word (if the label sits in the upper one), then
+                // the fields below it in its own word
+                const uint32_t tl = (lw >> 1) & ~lw & 0x55555555u, tl0 = (rec[k].x >> 1) & ~rec[k].x & 0x55555555u;
+                aux_at = rec[k].w + (upper ? (uint32_t)__popc(tl0) : 0u) + (uint32_t)__popc(tl & ((1u << sh) - 1u));
+                if (GPK_CHAIN_ABLATE == 1)
+                    res[k] = CODE_NONE;
+                else
+                    test = true;
+            }
+        } else if (tag == CELL_TAG_SINGLE && !(payload & 1u)) {
+            res[k] = payload >> 1;
+        } else if (gw[k] != 0u) {  // list cells (a lean index has next to none), and whatever a lean index should not hold
             dmask |= 1u << k;
         }
-    }
-    uint2 ca[PPT];  // ChainAux: first | count, base
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        ca[k] = make_uint2(0u, 0u);
-        if (tmask & (1u << k)) ca[k] = *reinterpret_cast<const uint2*>(h.sub_aux + aux_at[k]);
-    }
-    // the exact step, one point per lane and round: a lane holds 0.2 `test` points on average, so one or two rounds decide the
-    // wave (a loop per k would run PPT times)
-    unsigned long long edges_walked = 0, pairs_walked = 0;
-    while (__any(tmask != 0u)) {
-        if (tmask != 0u) {
-            const int k = __ffs((int)tmask) - 1;
-            tmask &= tmask - 1u;
-            double px = p[0].x, py = p[0].y;
-            uint2 c = ca[0];
-            uint32_t part = ra[0].x;
-#pragma unroll
-            for (int kk = 1; kk < PPT; ++kk)
-                if (k == kk) {
-                    px = p[kk].x;
-                    py = p[kk].y;
-                    c = ca[kk];
-                    part = ra[kk].x;
+        const unsigned long long m = __ballot(test);
+        if (m) {  // (wave-uniform)
+            const uint32_t at = n_items + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            n_items += (uint32_t)__popcll(m);
+            if (test) {
+                if (at < (uint32_t)ITEMS) {
+                    slots[k / 4] |= at << (8 * (k % 4));
+                    tmask |= 1u << k;
+                    ChainItem* it = s_items + at;
+                    it->px = px[k];
+                    it->py = py[k];
+                    it->aux_at = aux_at;
+                } else {
+                    dmask |= 1u << k;  // the list is full
                 }
-            part &= 0x3FFFFFFFu;
-            const int count = (int)(c.y & 0xFFu);
+            }
+        }
+        GPK_SCHED_FENCE();
+    });
+    // 4. the exact step: one listed point per lane and pass
+    n_items = n_items < (uint32_t)ITEMS ? n_items : (uint32_t)ITEMS;
+    unsigned long long edges_walked = 0;
+    if (n_items) {  // (wave-uniform)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t i = (uint32_t)lane; i < n_items; i += 64u) {
+            const uint32_t at = s_items[i].aux_at;
+            const ChainAux* __restrict__ e = h.sub_aux + at;
+            double2 q = make_double2(s_items[i].px, s_items[i].py);
+            uint32_t hd = h.chain_head[at];
+            double2 a0 = e->v[0], a1 = e->v[1], a2 = e->v[2], a3 = e->v[3];
+            // (all five requests go out before the head is looked at: the compiler would otherwise sink the vertex requests
+            // under `count > 0` — a second round trip)
+            asm volatile("" : "+v"(hd), "+v"(a0.x), "+v"(a0.y), "+v"(a1.x), "+v"(a1.y), "+v"(a2.x), "+v"(a2.y), "+v"(a3.x), "+v"(a3.y));
+            const double qx = q.x, qy = q.y;
+            const int count = (int)(hd & CHAIN_COUNT_MASK);
             bool inside = false, defer = count == 0;  // no chain entry for this sub-cell: the generic walk decides
             if (count > 0) {
-                const double2* __restrict__ v = h.polys_xy + c.x;
-                int wn = (int)(int8_t)((c.y >> 8) & 0xFFu);
-                const double2 v0 = v[0], v1 = v[1], v2 = v[count >= 2 ? 2 : 1];
-                bool on = dev::ring_edge_filtered(v0.x, v0.y, v1.x, v1.y, px, py, wn, defer);
-                if (count >= 2) on |= dev::ring_edge_filtered(v1.x, v1.y, v2.x, v2.y, px, py, wn, defer);
-                double2 a = v2;
-                for (int j = 2; j < count; ++j) {
-                    const double2 b = v[j + 1];
-                    on |= dev::ring_edge_filtered(a.x, a.y, b.x, b.y, px, py, wn, defer);
-                    a = b;
+                int wn = (int)(int8_t)((hd >> CHAIN_BASE_SHIFT) & 0xFFu);
+                bool on = dev::ring_edge_filtered(a0.x, a0.y, a1.x, a1.y, qx, qy, wn, defer);
+                if (count >= 2) on |= dev::ring_edge_filtered(a1.x, a1.y, a2.x, a2.y, qx, qy, wn, defer);
+                if (count >= 3) on |= dev::ring_edge_filtered(a2.x, a2.y, a3.x, a3.y, qx, qy, wn, defer);
+                if (count > 3) {  // 0.2 % of the chains: the further vertices follow in chain_ext
+                    const double2* __restrict__ ev = h.chain_ext + (hd >> CHAIN_EXT_SHIFT);
+                    double ax = a3.x, ay = a3.y;
+                    for (int j = 3; j < count; ++j) {
+                        const double2 b = ev[j - 3];
+                        on |= dev::ring_edge_filtered(ax, ay, b.x, b.y, qx, qy, wn, defer);
+                        ax = b.x;
+                        ay = b.y;
+                    }
                 }
                 inside = !on && wn != 0;
                 edges_walked += (unsigned long long)count;
             }
-            if (defer) dmask |= 1u << k;
-            ++pairs_walked;
-#pragma unroll
-            for (int kk = 0; kk < PPT; ++kk)
-                if (k == kk) res[kk] = inside ? part : CODE_NONE;
+            s_items[i].aux_at = (inside && !defer ? 1u : 0u) | (defer ? 2u : 0u);
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        static_for<P>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            if ((tmask >> k) & 1u) {
+                const uint32_t v = s_items[(slots[k / 4] >> (8 * (k % 4))) & 0xFFu].aux_at;
+                if (!(v & 1u)) res[k] = CODE_NONE;
+                if (v & 2u) dmask |= 1u << k;
+            }
+        });
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next tile overwrites the list)
+        __builtin_amdgcn_wave_barrier();
     }
     // deferred points: provisional "no hit" here, the real answer (count, code, totals) from pip_fixup_kernel
-#pragma unroll
-    for (int k = 0; k < PPT; ++k)
-        if (dmask & (1u << k)) {
-            res[k] = CODE_NONE;
-            if ((uint32_t)(k * 64 + lane) < rem) h.defer_list[atomicAdd(h.defer_count, 1u)] = (uint32_t)(base + k * 64 + lane);
-        }
-    if (h.stats && pairs_walked) {  // measurement runs only (gpk_join_stats_enable): uniform branch on the pointer
-        atomicAdd(&h.stats[0], pairs_walked);
-        atomicAdd(&h.stats[1], edges_walked);
+    if (__any(dmask != 0u)) {
+        static_for<P>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            if (dmask & (1u << k)) {
+                res[k] = CODE_NONE;
+                if (FULL || (uint32_t)(k * 64 + lane) < rem) h.defer_list[atomicAdd(h.defer_count, 1u)] = (uint32_t)(base + k * 64 + lane);
+            }
+        });
     }
-    // finalize: part -> geometry (null geometries dropped), count + code, the tile's total
+    if (h.stats && n_items) {  // measurement runs only (gpk_join_stats_enable): uniform branch on the pointer
+        if (lane == 0) atomicAdd(&h.stats[0], (unsigned long long)n_items);
+        if (edges_walked) atomicAdd(&h.stats[1], edges_walked);
+    }
+    // part -> geometry (null geometries dropped), count + code, the tile's total
     uint32_t* __restrict__ tile_counts = h.counts ? h.counts + base : nullptr;
     uint32_t* __restrict__ tile_code = h.code + base;
     unsigned long long hits = 0;  // wave-uniform
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
+    static_for<P>([&](auto K) {
+        constexpr int k = decltype(K)::value;
         const uint32_t li = (uint32_t)(k * 64 + lane);
         uint32_t r = res[k];
         if (r != CODE_NONE) {
@@ -1061,68 +1142,125 @@ __device__ __forceinline__ void chain_tile(const double2 (&p)[PPT], const ChainH
             r = dev::valid_row(h.polys_validity, geom) ? geom : CODE_NONE;
         }
         const uint32_t cnt = r != CODE_NONE ? 1u : 0u;
-        if (li < rem) {
+        if (FULL || li < rem) {
             if (tile_counts) dev::store_stream(tile_counts + li, cnt);
             dev::store_stream(tile_code + li, r);
         }
-        hits += (unsigned long long)__popcll(__ballot(li < rem && cnt == 1u));
-    }
+        hits += (unsigned long long)__popcll(__ballot((FULL || li < rem) && cnt == 1u));
+    });
     if (lane == 0) {
         h.block_tot[tile] = hits;
         if (hits) atomicAdd(&h.super_tot[tile >> PIP_SUPER_SHIFT], hits);  // integer adds: order-independent
     }
 }
+template <int P, bool ROUTE>
+__device__ __forceinline__ void chain_tile_any(const ChainHot& h, const uint2* s_mask, const uint32_t* s_rec0, ChainItem* s_items, int64_t tile, int lane) {
+    if (h.pts_validity == nullptr && (tile + 1) * (int64_t)(64 * P) <= h.n_points)  // (wave-uniform)
+        chain_tile<P, ROUTE, true>(h, s_mask, s_rec0, s_items, tile, lane);
+    else
+        chain_tile<P, ROUTE, false>(h, s_mask, s_rec0, s_items, tile, lane);
+}
 
 __global__ __launch_bounds__(PIP_BLOCK) void pip_tile_chain_kernel(ChainHot h) {
+    __shared__ ChainItem s_items[PIP_BLOCK / 64][chain_items<CHAIN_PPT>()];
     const int64_t tile = (int64_t)blockIdx.x * (PIP_BLOCK / 64) + (threadIdx.x >> 6);
     if (tile >= h.n_tiles) return;  // (whole waves)
-    const int lane = threadIdx.x & 63;
-    double2 p[CHAIN_PPT];
-    chain_load_points<CHAIN_PPT>(h, tile, lane, p);
-    chain_tile<CHAIN_PPT, false>(p, h, nullptr, tile, lane);
+    chain_tile_any<CHAIN_PPT, false>(h, nullptr, nullptr, s_items[threadIdx.x >> 6], tile, threadIdx.x & 63);
 }
 
 // persistent work-groups (one per CU: the routing image takes most of its LDS), a wave walks tiles wave, wave + W, ...
 __global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_route_kernel(ChainHot h) {
-    __shared__ uint4 s_route[PIP_ROUTE_RMAX * PIP_ROUTE_RMAX / 32];
+    constexpr int WORDS = PIP_ROUTE_RMAX * PIP_ROUTE_RMAX / 32;
+    __shared__ uint2 s_mask[WORDS];     // RouteWord::bmask, gmask
+    __shared__ uint32_t s_rec0[WORDS];  // RouteWord::rec0
+    __shared__ ChainItem s_items[ROUTE_BLOCK / 64][chain_items<ROUTE_PPT>()];
     {
         const int words = h.R * h.R / 32;
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(h.route);
-        for (int i = threadIdx.x; i < words; i += ROUTE_BLOCK) s_route[i] = src[i];
+        for (int i = threadIdx.x; i < words; i += ROUTE_BLOCK) {
+            const uint4 rw = src[i];
+            s_mask[i] = make_uint2(rw.x, rw.y);
+            s_rec0[i] = rw.z;
+        }
     }
     const int lane = threadIdx.x & 63;
     const int64_t stride = (int64_t)gridDim.x * (ROUTE_BLOCK / 64);
-    int64_t tile = (int64_t)blockIdx.x * (ROUTE_BLOCK / 64) + (threadIdx.x >> 6);
     __syncthreads();
-    // (no software prefetch of the next tile: vector loads return in order, so the first dependent gather of this tile would
-    // wait for the next tile's points as well — the other fifteen waves of the CU are what hides a wave's load latency)
-    for (; tile < h.n_tiles; tile += stride) {
-        double2 p[ROUTE_PPT];
-        chain_load_points<ROUTE_PPT>(h, tile, lane, p);
-        chain_tile<ROUTE_PPT, true>(p, h, s_route, tile, lane);
-    }
+    for (int64_t tile = (int64_t)blockIdx.x * (ROUTE_BLOCK / 64) + (threadIdx.x >> 6); tile < h.n_tiles; tile += stride)
+        chain_tile_any<ROUTE_PPT, true>(h, s_mask, s_rec0, s_items[threadIdx.x >> 6], tile, lane);
 }
 
-// The deferred points of a chain / route launch, decided by the generic walk (directory candidates -> full ring walks with the
-// exact orientation kernel): count, code and the two levels of totals are corrected before pip_write reads them.  Real data
-// defers a handful of points; the launch exists so that the tile kernels need none of this code.
+// The deferred points of a chain / route launch, decided by the generic walk (directory candidates -> full ring walks with
+// the exact orientation kernel): count, code and the two levels of totals are corrected before pip_write reads them.  One WAVE
+// per deferred row, its lanes striding over the candidate's ring edges (a row then costs a handful of dependent loads, not one
+// per edge): real data defers a handful of rows, and the launch exists so that the tile kernels need none of this code.
 __global__ __launch_bounds__(256) void pip_fixup_kernel(DevGeo pts, DevGeo polys, IndexView ix, const uint32_t* __restrict__ defer_count,
                                                         const uint32_t* __restrict__ defer_list, int tile_points, uint32_t* __restrict__ counts,
                                                         uint32_t* __restrict__ code, unsigned long long* __restrict__ block_tot,
                                                         unsigned long long* __restrict__ super_tot, unsigned long long* __restrict__ stats) {
     const uint32_t nd = *defer_count;
-    if (stats && nd && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[2], (unsigned long long)nd);
-    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < nd; e += gridDim.x * 256u) {
-        const uint32_t g = defer_list[e];
-        const double2 p = pts.xy[g];
-        uint32_t cnt, first;
-        generic_point(polys, ix, p.x, p.y, cnt, first);
-        if (counts) counts[g] = cnt;
-        code[g] = cnt == 0 ? CODE_NONE : (cnt == 1 ? first : CODE_MULTI);
-        if (cnt) {
-            const uint32_t tile = g / (uint32_t)tile_points;
-            atomicAdd(&block_tot[tile], (unsigned long long)cnt);
-            atomicAdd(&super_tot[tile >> PIP_SUPER_SHIFT], (unsigned long long)cnt);
+    if (nd == 0u) return;
+    if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[2], (unsigned long long)nd);
+    const int lane = threadIdx.x & 63;
+    const GridParams g = *ix.grid;
+    for (uint32_t e = blockIdx.x * 4u + (threadIdx.x >> 6); e < nd; e += gridDim.x * 4u) {
+        const uint32_t row = defer_list[e];
+        const double2 p = pts.xy[row];
+        uint32_t cnt = 0, first = CODE_NONE;
+        if (p.x == p.x && p.y == p.y) {
+            const int cx = dev::cell_of(p.x, g.x0, g.inv_w, g.gx), cy = dev::cell_of(p.y, g.y0, g.inv_h, g.gy);
+            const int cc = cy * g.gx + cx;
+            for (int q = ix.cell_off[cc]; q < ix.cell_off[cc + 1]; ++q) {  // candidates in ascending id order (uniform across the wave)
+                const int j = ix.items[q];
+                const double4 bb = ix.bbox[j];
+                if (!(p.x >= bb.x && p.x <= bb.z && p.y >= bb.y && p.y <= bb.w) || !dev::valid_row(polys.validity, j)) continue;
+                int p0, p1;
+                dev::geom_parts(polys, j, p0, p1);
+                bool hit = false;
+                for (int part = p0; part < p1 && !hit; ++part) {  // Contains<Point>: strictly inside some member polygon
+                    int r0, r1;
+                    dev::part_rings(polys, part, r0, r1);
+                    int pos = dev::POS_INSIDE;  // position w.r.t. the polygon: exterior first, then the holes
+                    for (int r = r0; r < r1 && pos == dev::POS_INSIDE; ++r) {
+                        const int c0 = polys.ring_off[r], n = polys.ring_off[r + 1] - c0;
+                        int wn = 0, on = 0;
+                        if (n == 1) {
+                            const double2 s0 = polys.xy[c0];
+                            on = (p.x == s0.x && p.y == s0.y) ? 1 : 0;
+                        }
+                        for (int i = lane; i + 1 < n; i += 64) {
+                            const double2 s0 = polys.xy[c0 + i], s1 = polys.xy[c0 + i + 1];
+                            on |= (int)dev::ring_edge(s0.x, s0.y, s1.x, s1.y, p.x, p.y, wn);
+                        }
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) {
+                            wn += __shfl_xor(wn, o, 64);
+                            on |= __shfl_xor(on, o, 64);
+                        }
+                        const int rp = n == 0 ? dev::POS_OUTSIDE : (on ? dev::POS_BOUNDARY : (wn != 0 ? dev::POS_INSIDE : dev::POS_OUTSIDE));
+                        if (r == r0)
+                            pos = rp;  // Outside / OnBoundary of the exterior ends it
+                        else if (rp == dev::POS_BOUNDARY)
+                            pos = dev::POS_BOUNDARY;
+                        else if (rp == dev::POS_INSIDE)
+                            pos = dev::POS_OUTSIDE;  // inside a hole
+                    }
+                    hit = r1 > r0 && pos == dev::POS_INSIDE;
+                }
+                if (hit) {
+                    if (cnt == 0) first = (uint32_t)j;
+                    ++cnt;
+                }
+            }
+        }
+        if (lane == 0) {
+            if (counts) counts[row] = cnt;
+            code[row] = cnt == 0 ? CODE_NONE : (cnt == 1 ? first : CODE_MULTI);
+            if (cnt) {
+                const uint32_t tile = row / (uint32_t)tile_points;
+                atomicAdd(&block_tot[tile], (unsigned long long)cnt);
+                atomicAdd(&super_tot[tile >> PIP_SUPER_SHIFT], (unsigned long long)cnt);
+            }
         }
     }
 }
@@ -1540,13 +1678,13 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
     const bool lean = right_index->pip.R > 0 && right_index->pip_lean && !no_lean;
     // an index with chains (ChainAux, gpk_index.h) is served by the chain kernels only: its records carry chain positions where
     // the queue kernel expects slab ranges.  GPK_NO_ROUTE=1: A/B runs without the LDS routing image.
+    // GPK_TILE_KERNEL=chain: A/B runs of the chain kernel on an index that has the LDS routing image
     static const bool no_route = [] {
-        const char* e = getenv("GPK_NO_ROUTE");
-        return e && *e && *e != '0';
+        const char* e = getenv("GPK_TILE_KERNEL");
+        return e && !strcmp(e, "chain");
     }();
-    const bool has_chains = right_index->pip.R > 0 && right_index->pip.sub_aux != nullptr;
-    const bool chain = has_chains;  // (the deferred list lives in the multi-hit pool: one word per left row, see multi_cap)
-    const bool route = chain && right_index->pip.route != nullptr && right_index->pip.R <= PIP_ROUTE_RMAX && !no_route;
+    const bool chain = right_index->pip.R > 0 && right_index->pip.sub_aux != nullptr;  // (the deferred list lives in the multi-hit pool, see multi_cap)
+    const bool route = chain && !no_route && right_index->pip.route != nullptr && right_index->pip.R <= PIP_ROUTE_RMAX;
     const int tile_points = chain ? 64 * (route ? ROUTE_PPT : CHAIN_PPT) : (lean ? LEAN_TILE : PIP_TILE);
     const int64_t n_blocks = (n + tile_points - 1) / tile_points;
     const bool want_pairs = pair_capacity > 0;
@@ -1598,16 +1736,19 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         hot.pts_validity = left->d.validity;
         hot.n_points = n;
         hot.n_tiles = n_blocks;
-        hot.polys_xy = right->d.xy;
         hot.polys_validity = right->d.validity;
         hot.R = pv.R;
+        hot.logR = 0;
+        while ((1 << hot.logR) < pv.R) ++hot.logR;
         hot.rx0 = pv.rx0;
         hot.ry0 = pv.ry0;
         hot.inv_fw = pv.inv_fw;
         hot.inv_fh = pv.inv_fh;
         hot.cell = pv.cell;
-        hot.sub = pv.sub;
+        hot.half = reinterpret_cast<const HalfCell*>(pv.sub);  // (an index with chains keeps its one-part records in half-cell form)
         hot.sub_aux = pv.sub_aux;
+        hot.chain_head = pv.chain_head;
+        hot.chain_ext = pv.chain_ext;
         hot.part_geom = pv.part_geom;
         hot.route = pv.route;
         hot.counts = counts_dev;
@@ -1619,8 +1760,9 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         hot.defer_list = multi_pool;
     }
     if (chain && route) {  // persistent work-groups, one per CU
+        const int tiles_per_wg = ROUTE_BLOCK / 64;
         int64_t wgs = (int64_t)cu_count();
-        const int64_t want = (n_blocks + ROUTE_BLOCK / 64 - 1) / (ROUTE_BLOCK / 64);
+        const int64_t want = (n_blocks + tiles_per_wg - 1) / tiles_per_wg;
         if (wgs > want) wgs = want;
         J_LAUNCH("gpk_pip_tile", pip_tile_route_kernel, dim3((unsigned)wgs), dim3(ROUTE_BLOCK), 0, s, hot);
     } else if (chain)
@@ -1639,7 +1781,7 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         J_LAUNCH("gpk_pip_tile_generic", (pip_tile_kernel<false, false>), dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
                  right_index->v, right_index->pip, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top, stats);
     if (chain)  // the deferred rows (gpk_join.hip: ChainHot) before the writer reads codes and totals
-        J_LAUNCH("gpk_pip_fixup", pip_fixup_kernel, dim3(128), dim3(256), 0, s, left->d, right->d, right_index->v, (const uint32_t*)multi_top,
+        J_LAUNCH("gpk_pip_fixup", pip_fixup_kernel, dim3(512), dim3(256), 0, s, left->d, right->d, right_index->v, (const uint32_t*)multi_top,
                  (const uint32_t*)multi_pool, tile_points, counts_dev, code, btot, stot, stats);
     // the writer also produces the grand total; in count-only mode it runs without a pair buffer
     J_LAUNCH("gpk_pip_write", pip_write_kernel, dim3((unsigned)n_wblocks), dim3(WR_BLOCK), 0, s, left->d, right->d, right_index->v,

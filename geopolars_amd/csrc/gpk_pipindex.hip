@@ -526,17 +526,21 @@ __global__ void chain_count_kernel(const SubCell* __restrict__ sub, int64_t n_su
 }
 // One wave per record (work item = (cell, part) of sub_work_kernel), lane = sub-cell.  The wave lists the edges of the part's
 // slab rows in this raster row that meet the padded cell (with the coordinate index each starts at), every `test` lane then
-//   1. takes the listed edges that meet ITS padded sub-cell (exact: the test that labelled it) and the arc [lo, hi] of ring
-//      edges spanning them,
+//   1. takes the listed edges that meet ITS padded sub-cell (exact: the test that labelled it) and the shortest arc of the
+//      ring — a ring is a cycle: the arc may run over the closing vertex — that covers them,
 //   2. grows the arc at both ends while the end vertex's y lies in the sub-cell's closed y-interval,
-//   3. sums the contributions, at the sub-cell centre, of the edges of the centre's slab row that are NOT in the arc: `base`.
-// An arc that would pass the ring's first / last coordinate, exceed CHAIN_MAX edges, a part with holes, or a cell whose edge
-// list overflowed gets count = 0 (the join walks the part's slab for such points).
+//   3. sums the contributions, at the sub-cell centre, of the edges of the centre's slab row that are NOT in the arc: `base`,
+//   4. copies the arc's first four vertices into the entry (vertices 4 .. follow in chain_ext: chain_ext_kernel).
+// An arc of more than CHAIN_MAX edges, a part with holes, or a cell whose edge list overflowed gets count = 0 (such rows are
+// decided by the generic walk).
 __global__ __launch_bounds__(256) void chain_aux_kernel(DevGeo a, PipView pv, FineGrid g, const int32_t* __restrict__ work_cell,
                                                         const uint32_t* __restrict__ work_part, int64_t n_work,
                                                         const int32_t* __restrict__ slab_vidx, const SubCell* __restrict__ sub,
-                                                        const int32_t* __restrict__ aux_base, ChainAux* __restrict__ aux) {
+                                                        const int32_t* __restrict__ aux_base, ChainAux* __restrict__ aux,
+                                                        uint32_t* __restrict__ head, uint32_t* __restrict__ first_at,
+                                                        int32_t* __restrict__ ext_need) {
     constexpr int S = PIP_SUB, SS = PIP_SUB * PIP_SUB;
+    static_assert(SUB_EDGE_CAP <= 64, "the touched edges of a sub-cell are a 64-bit mask over the cell's list");
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t item = t / SS;
     const int k = (int)(t % SS);
@@ -592,80 +596,124 @@ __global__ __launch_bounds__(256) void chain_aux_kernel(DevGeo a, PipView pv, Fi
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (!test) return;
-    ChainAux out;
-    out.first = 0u;
-    out.count = 0;
-    out.base = 0;
-    out.pad = 0;
     const int rank = __popcll(tm & ((1ull << lane64) - 1ull));
-    ChainAux* __restrict__ dst = aux + aux_base[item] + rank;
-    if (list_ok) {
-        const int c0 = a.ring_off[r0], c1 = a.ring_off[r0 + 1];  // the ring's coordinates: edges c0 .. c1 - 2
-        int lo = 0x7FFFFFFF, hi = -1;
+    const int64_t slot = (int64_t)aux_base[item] + rank;
+    ChainAux out;
+    out.v[0] = out.v[1] = out.v[2] = out.v[3] = make_double2(0.0, 0.0);
+    uint32_t out_head = 0u, out_first = 0u;
+    int need = 0;
+    const int c0 = list_ok ? a.ring_off[r0] : 0, ne = list_ok ? a.ring_off[r0 + 1] - c0 - 1 : 0;  // the ring's edges: 0 .. ne - 1 (closed ring)
+    if (list_ok && ne >= 1) {
+        // 1. the listed edges that meet this padded sub-cell (an edge listed for both slab rows of the cell appears twice: harmless)
+        unsigned long long touched = 0ull;
         for (int e = 0; e < n_list; ++e) {
             const double4 ed = s_edges[wave][e];
             if (fmax(ed.x, ed.z) < xl || fmin(ed.x, ed.z) > xh || fmax(ed.y, ed.w) < yl || fmin(ed.y, ed.w) > yh) continue;
             const int o1 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yl), o2 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yl);
             const int o3 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yh), o4 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yh);
             if ((o1 > 0 && o2 > 0 && o3 > 0 && o4 > 0) || (o1 < 0 && o2 < 0 && o3 < 0 && o4 < 0)) continue;
-            const int v = s_vidx[wave][e];  // (an edge listed for both slab rows of the cell appears twice: same index)
-            lo = v < lo ? v : lo;
-            hi = v > hi ? v : hi;
+            touched |= 1ull << e;
         }
-        bool ok = hi >= lo;
-        // grow: edge hi ends at vertex hi + 1, edge lo starts at vertex lo; stop at the ring's ends (a chain does not wrap)
-        while (ok && hi - lo + 1 <= CHAIN_MAX) {
-            const double y = a.xy[hi + 1].y;  // edge hi ends at vertex hi + 1 (<= c1 - 1, the closing coordinate)
-            if (!(y >= yl && y <= yh)) break;
-            if (hi + 1 >= c1 - 1) {  // the chain would continue with the ring's first edge: no wrapping chains
-                ok = false;
-                break;
+        // the shortest arc [lo, lo + len) of the cycle 0 .. ne - 1 that covers the touched edges: the complement of the widest
+        // gap between one touched edge and the next one after it
+        int lo = 0, len = 0;
+        if (touched) {
+            int best_gap = -1, best_a = 0, best_next = 0;
+            for (unsigned long long ma = touched; ma; ma &= ma - 1ull) {
+                const int ea = s_vidx[wave][__ffsll((long long)ma) - 1] - c0;
+                int nd = ne, nb = ea;  // distance to / index of the next touched edge after ea, cyclically (ne: ea is the only one)
+                for (unsigned long long mb = touched; mb; mb &= mb - 1ull) {
+                    const int eb = s_vidx[wave][__ffsll((long long)mb) - 1] - c0;
+                    int d = eb - ea;
+                    if (d < 0) d += ne;
+                    if (d > 0 && d < nd) {
+                        nd = d;
+                        nb = eb;
+                    }
+                }
+                if (nd > best_gap) {
+                    best_gap = nd;
+                    best_a = ea;
+                    best_next = nb;
+                }
             }
-            ++hi;
+            lo = best_next;                    // the arc starts right after the widest gap ...
+            len = ne - best_gap + 1;           // ... and ends at the edge before it (one touched edge: best_gap = ne, len = 1)
         }
-        while (ok && hi - lo + 1 <= CHAIN_MAX) {
-            const double y = a.xy[lo].y;  // edge lo starts at vertex lo (>= c0)
+        bool ok = len >= 1 && len <= CHAIN_MAX;
+        // 2. grow: the arc's last edge ends at vertex lo + len, its first edge starts at vertex lo (indices modulo ne)
+        while (ok && len < ne) {
+            int hv = lo + len;
+            if (hv >= ne) hv -= ne;
+            const double y = a.xy[c0 + hv].y;
             if (!(y >= yl && y <= yh)) break;
-            if (lo <= c0) {  // the chain would continue with the ring's last edge
-                ok = false;
-                break;
-            }
-            --lo;
+            ++len;
+            ok = len <= CHAIN_MAX;
         }
-        ok = ok && hi - lo + 1 <= CHAIN_MAX;
+        while (ok && len < ne) {
+            const double y = a.xy[c0 + lo].y;
+            if (!(y >= yl && y <= yh)) break;
+            lo = lo == 0 ? ne - 1 : lo - 1;
+            ++len;
+            ok = len <= CHAIN_MAX;
+        }
         if (ok) {
-            // base: the other edges' winding at the centre — they all sit in the centre's slab row
+            // 3. base: the other edges' winding at the centre — they all sit in the centre's slab row
             const double cx = g.rx0 + ((double)si + 0.5) * fw2, cy = g.ry0 + ((double)sj + 0.5) * fh2;
             int e0, e1, wn = 0;
             bool on = false;
             if (pip::slab_range(pv, r0, pip::row_of(pv, cy), e0, e1)) {
                 for (int e = e0; e < e1; ++e) {
-                    const int v = slab_vidx[e];
-                    if (v >= lo && v <= hi) continue;
+                    int d = slab_vidx[e] - c0 - lo;
+                    if (d < 0) d += ne;
+                    if (d < len) continue;  // an edge of the arc
                     const double4 ed = pv.slab_edges[e];
                     on |= dev::ring_edge(ed.x, ed.y, ed.z, ed.w, cx, cy, wn);
                 }
             }
-            if (!on && wn >= -127 && wn <= 127) {  // (an edge outside the chain cannot pass through the centre; guard anyway)
-                out.first = (uint32_t)lo;
-                out.count = (uint8_t)(hi - lo + 1);
-                out.base = (int8_t)wn;
+            if (!on && wn >= -127 && wn <= 127) {  // (an edge outside the arc cannot pass through the centre; guard anyway)
+                out_head = (uint32_t)len | ((uint32_t)(uint8_t)(int8_t)wn << CHAIN_BASE_SHIFT);
+                out_first = (uint32_t)(c0 + lo);
+                for (int j = 0; j < 4; ++j) {  // 4. vertices 0 .. 3 (a shorter chain repeats its last vertex)
+                    const int v = (lo + (j <= len ? j : len)) % ne;
+                    out.v[j] = a.xy[c0 + v];
+                }
+                need = len > 3 ? len - 3 : 0;
             }
         }
     }
-    *dst = out;
+    aux[slot] = out;
+    head[slot] = out_head;
+    first_at[slot] = out_first;
+    ext_need[slot] = need;
 }
-
-// an index with chains: every one-part record names its first chain entry in e0 and carries, in e1, the number of `test` labels in
-// label words 0, 0..1, 0..2 (one byte each) — the chain kernel then finds a label's rank from its own word alone (ChainAux)
+// vertices 4 .. count of the chains longer than three edges (one thread per chain entry), and where they are in the entry's head
+__global__ void chain_ext_kernel(DevGeo a, uint32_t* __restrict__ head, const uint32_t* __restrict__ first_at, int64_t n_aux,
+                                 const int32_t* __restrict__ ext_off, double2* __restrict__ ext) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_aux) return;
+    const int len = (int)(head[i] & CHAIN_COUNT_MASK);
+    if (len <= 3) return;
+    if ((uint32_t)ext_off[i] >= (1u << (32 - CHAIN_EXT_SHIFT))) {  // the offset does not fit the head word: no chain entry (the generic walk decides)
+        head[i] = 0u;
+        return;
+    }
+    const int r = ring_of_coord(a.ring_off, (int)a.n_rings, (int)first_at[i]);
+    const int c0 = a.ring_off[r], ne = a.ring_off[r + 1] - c0 - 1;
+    const int lo = (int)first_at[i] - c0;
+    head[i] |= (uint32_t)ext_off[i] << CHAIN_EXT_SHIFT;
+    for (int j = 4; j <= len; ++j) ext[ext_off[i] + (j - 4)] = a.xy[c0 + (lo + j) % ne];
+}
+// an index with chains: every one-part record is rewritten as two half-cell records (gpk_index.h: HalfCell) — after chain_aux_kernel,
+// which reads the SubCell form
 __global__ void chain_commit_kernel(SubCell* __restrict__ sub, int64_t n_sub, const int32_t* __restrict__ aux_base) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_sub) return;
-    const uint32_t c0 = (uint32_t)test_labels_of(sub[i].labels[0]), c1 = c0 + (uint32_t)test_labels_of(sub[i].labels[1]),
-                   c2 = c1 + (uint32_t)test_labels_of(sub[i].labels[2]);
-    sub[i].e0 = (uint32_t)aux_base[i];
-    sub[i].e1 = c0 | (c1 << 8) | (c2 << 16);
-    sub[i].e2 = 0u;
+    const SubCell rc = sub[i];
+    const uint32_t lower_tests = (uint32_t)(test_labels_of(rc.labels[0]) + test_labels_of(rc.labels[1]));
+    HalfCell* h = reinterpret_cast<HalfCell*>(sub + i);
+    h[0] = HalfCell{{rc.labels[0], rc.labels[1]}, rc.part_flags & ~SUB_INDIRECT, (uint32_t)aux_base[i]};
+    h[1] = HalfCell{{rc.labels[2], rc.labels[3]}, rc.part_flags & ~SUB_INDIRECT, (uint32_t)aux_base[i] + lower_tests};
 }
 // LDS image of the level-1 routing (gpk_index.h: RouteWord): one thread per 32 cells of a raster row, after sub_commit_kernel
 __global__ void route_build_kernel(const uint32_t* __restrict__ cell, int64_t n_words, RouteWord* __restrict__ route) {
@@ -1093,9 +1141,32 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, boo
             ChainAux* aux = nullptr;
             GPK_HIP(hipMalloc((void**)&aux, sizeof(ChainAux) * (size_t)n_aux));
             keep(aux);
+            uint32_t* chead = nullptr;
+            GPK_HIP(hipMalloc((void**)&chead, sizeof(uint32_t) * (size_t)n_aux));
+            keep(chead);
+            int32_t *ext_need, *ext_off;
+            uint32_t* first_at;
+            GPK_TRY(t.alloc(&ext_need, (size_t)n_aux + 1));
+            GPK_TRY(t.alloc(&ext_off, (size_t)n_aux + 1));
+            GPK_TRY(t.alloc(&first_at, (size_t)n_aux + 1));
+            unsigned long long* btot3;
+            GPK_TRY(t.alloc(&btot3, (size_t)((n_aux + 255) / 256 + 4)));
             GPK_LAUNCH("gpk_pipidx_chain_aux", chain_aux_kernel, blocks_for((int64_t)n_sub * PIP_SUB * PIP_SUB), dim3(256), 0, s, d, pv, g,
                        (const int32_t*)swork_cell, (const uint32_t*)swork_part, (int64_t)n_sub, (const int32_t*)slab_vidx, (const SubCell*)sub,
-                       (const int32_t*)cbase_tmp, aux);
+                       (const int32_t*)cbase_tmp, aux, chead, first_at, ext_need);
+            GPK_TRY(exclusive_scan_i32(ext_need, n_aux, ext_off, nullptr, btot3, s));
+            int32_t n_ext = 0;
+            GPK_HIP(hipMemcpyAsync(&n_ext, ext_off + n_aux, sizeof n_ext, hipMemcpyDeviceToHost, s));
+            GPK_HIP(hipStreamSynchronize(s));
+            double2* ext = nullptr;
+            GPK_HIP(hipMalloc((void**)&ext, sizeof(double2) * (size_t)(n_ext > 0 ? n_ext : 1)));
+            keep(ext);
+            if (n_ext > 0)
+                GPK_LAUNCH("gpk_pipidx_chain_ext", chain_ext_kernel, blocks_for(n_aux), dim3(256), 0, s, d, chead, (const uint32_t*)first_at, (int64_t)n_aux,
+                           (const int32_t*)ext_off, ext);
+            pv.chain_head = chead;
+            pv.chain_ext = ext;
+            ix->nbytes += (int64_t)(sizeof(double2) * (size_t)n_ext + sizeof(uint32_t) * (size_t)n_aux);
             // (after chain_aux_kernel, which still reads the records' labels only: e0 now names the record's first chain entry)
             GPK_LAUNCH("gpk_pipidx_chain_commit", chain_commit_kernel, blocks_for(n_sub), dim3(256), 0, s, sub, (int64_t)n_sub, (const int32_t*)cbase_tmp);
             pv.sub_aux = aux;

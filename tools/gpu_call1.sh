@@ -1,0 +1,5 @@
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd $R
+( time timeout 400 python -m pytest tests/test_gpu_chains.py -x -q ) > $O/r03a_chains.log 2>&1; tail -15 $O/r03a_chains.log
+bash tools/sweep_tile.sh > $O/r03a_sweep.log 2>&1; cat $O/r03a_sweep.log
+( time timeout 600 python -m pytest tests -m gpu -q -x ) > $O/r03a_gputests.log 2>&1; tail -8 $O/r03a_gputests.log
+timeout 300 python bench.py > $O/r03a_bench_c2.log 2>&1; tail -3 $O/r03a_bench_c2.log | cut -c1-1500

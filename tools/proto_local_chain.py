@@ -72,32 +72,43 @@ def local_chain(ring, xl, yl, xh, yh):
     return sorted(C)
 
 
-CHAIN_MAX = 7
+CHAIN_MAX = 12
 
 
 def local_arc(ring, xl, yl, xh, yh):
-    """the chain as the BUILD KERNEL forms it (chain_aux_kernel): one arc [lo, hi] of edge indices spanning every touching edge,
-    grown by the y-rule, never across the ring's first / last coordinate, at most CHAIN_MAX edges; None = fallback"""
-    n = len(ring) - 1  # edges 0 .. n - 1, vertices 0 .. n (vertex n closes the ring)
-    T = [i for i in range(n) if seg_meets_rect(*ring[i], *ring[i + 1], xl, yl, xh, yh)]
+    """the chain as the BUILD KERNEL forms it (chain_aux_kernel, gpk_pipindex.hip): the shortest arc of the CYCLE of ring edges
+    that covers every touching edge (the complement of the widest gap between one touched edge and the next), grown at both
+    ends by the y-rule, at most CHAIN_MAX edges; None = no chain entry (the generic walk decides such points)"""
+    n = len(ring) - 1  # edges 0 .. n - 1 (vertex n closes the ring: ring[n] == ring[0])
+    T = sorted({i for i in range(n) if seg_meets_rect(*ring[i], *ring[i + 1], xl, yl, xh, yh)})
     if not T:
         return None
-    lo, hi = min(T), max(T)
-    while hi - lo + 1 <= CHAIN_MAX:
-        if not (yl <= ring[hi + 1][1] <= yh):
+    best_gap, lo = -1, T[0]
+    for a in T:
+        nd, nb = n, a
+        for b in T:
+            d = (b - a) % n
+            if 0 < d < nd:
+                nd, nb = d, b
+        if nd > best_gap:
+            best_gap, lo = nd, nb
+    length = n - best_gap + 1
+    if length > CHAIN_MAX:
+        return None
+    while length < n:
+        if not (yl <= ring[(lo + length) % n][1] <= yh):
             break
-        if hi + 1 >= n:
+        length += 1
+        if length > CHAIN_MAX:
             return None
-        hi += 1
-    while hi - lo + 1 <= CHAIN_MAX:
+    while length < n:
         if not (yl <= ring[lo][1] <= yh):
             break
-        if lo <= 0:
+        lo = (lo - 1) % n
+        length += 1
+        if length > CHAIN_MAX:
             return None
-        lo -= 1
-    if hi - lo + 1 > CHAIN_MAX:
-        return None
-    return list(range(lo, hi + 1))
+    return [(lo + j) % n for j in range(length)]
 
 
 def main():
