@@ -194,7 +194,7 @@ class Ctx:
         return self.max_over_ranks(t1 - t0), k_ms, k_n, warm
 
     # substring queries: no name here is a substring of another one that can run in the same step
-    KERNELS = ("gpk_pip_tile", "gpk_pip_write", "gpk_distance_grouped", "gpk_dist_hist", "gpk_dist_scatter", "gpk_dist_probe", "gpk_dist_batches", "gpk_dist_iota",
+    KERNELS = ("gpk_pip_tile", "gpk_pip_write", "gpk_pip_fixup", "gpk_distance_grouped", "gpk_dist_hist", "gpk_dist_scatter", "gpk_dist_probe", "gpk_dist_batches", "gpk_dist_iota",
                "gpk_dist_offsets", "gpk_rowmap", "gpk_bbox_cand_count", "gpk_bbox_cand_fill", "gpk_pair_refine", "gpk_pair_count", "gpk_pair_emit", "gpk_counts_copy",
                "gpk_ring_area", "gpk_area_combine", "gpk_seq_long", "gpk_scan", "gpk_seq_bbox", "gpk_bounds_combine", "gpk_stats_to_bbox")
 
@@ -372,15 +372,16 @@ def run_c2(ctx: Ctx) -> None:
         "polygons": m,
         "vertices_per_polygon": args.verts,
         "hits_per_step": h,
-        "algorithm": "uniform-grid bbox directory + two-level exact raster routing -> exact winding walk over edge slabs, sorted (l,r) pairs + counts; N x M logical pairs counted, raster-rejected pairs included",
+        "algorithm": "two-level exact raster routing (level 1 from an LDS image in persistent work-groups, level 2 = one 16-byte half-cell record) -> `test` sub-cells decided from their local chain (base winding + one or two ring edges, exact orientation filter; uncertifiable rows go through the generic exact walk), sorted (l,r) pairs + counts; N x M logical pairs counted, raster-rejected pairs included",
+        "index_tables": index.describe(),
         "index": "rebuilt per step" if args.index_per_step else "prebuilt r_index (spatial_index.rs:20-21)",
         "call": "gpk_spatial_join (blocking)" if sync_steps else "gpk_spatial_join_async (stream-ordered; the timed region ends synchronised)",
         "parallelism": f"row-sharded x{ctx.world}, right side replicated",
         "input_rotation": f"{R} distinct 10M-point inputs and output sets ({R * (16 * n + 4 * n + 8 * n) / 2**20:.0f} MiB): inputs come from HBM, not from the 256 MiB Infinity Cache",
         "join_bytes_per_step": bytes_join,
         "join_GBps_end_to_end": bytes_join / step_s / 1e9,
-        "kernel_ms": {"gpk_pip_tile": k_tile, "gpk_pip_write (warm-up steps)": k_write},
-        "exact_phase": {"queued_point_part_pairs_per_step": queued, "edge_tests_per_step": edges},
+        "kernel_ms": {"gpk_pip_tile": k_tile, "gpk_pip_write (warm-up steps)": k_write, "gpk_pip_fixup (warm-up steps)": warm.get("gpk_pip_fixup", 0.0)},
+        "exact_phase": {"test_points_per_step": queued, "edge_tests_per_step": edges, "rows_deferred_to_the_generic_walk_per_step": int(st[2])},
         "edge_tests_per_s": edges / step_s if step_s > 0 else None,
         "valu_busy": valu_busy,
         "pcie_inclusive": None
