@@ -125,6 +125,12 @@ _PROTOS = {
     "gpk_join_indices": (C.c_int32, [_VP, _VP, C.c_int64, C.c_int64, C.c_uint32, C.c_int32, _VP, _VP, C.c_int64, C.POINTER(C.c_int64), C.c_int32, _VP]),
     "gpk_take_fixed": (C.c_int32, [_VP, C.c_int32, _VP, C.c_int64, _VP, C.c_int64, _VP, _VP, C.c_int32, _VP]),
     "gpk_take_binary": (C.c_int32, [_VP, _VP, _VP, C.c_int64, _VP, C.c_int64, _VP, _VP, C.c_int64, C.POINTER(C.c_int64), _VP, C.c_int32, _VP]),
+    "gpk_comm_unique_id": (C.c_int32, [C.POINTER(C.c_uint8)]),
+    "gpk_comm_init": (C.c_int32, [C.c_int32, C.c_int32, C.POINTER(C.c_uint8), C.POINTER(_VP)]),
+    "gpk_comm_free": (C.c_int32, [_VP]),
+    "gpk_comm_info": (C.c_int32, [_VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "gpk_allgatherv_geoarray": (C.c_int32, [_VP, _VP, _VP, C.POINTER(_VP), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "gpk_allgatherv_rows_f64": (C.c_int32, [_VP, _VP, C.c_int64, C.c_int32, _VP, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _VP]),
     "gpk_join_stats_enable": (C.c_int32, [C.c_int32]),
     "gpk_join_stats": (C.c_int32, [C.POINTER(C.c_int64), C.c_int32]),
     "gpk_profile_enable": (C.c_int32, [C.c_int32]),

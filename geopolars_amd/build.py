@@ -35,6 +35,7 @@ SOURCES = [
     "gpk_take.hip",
     "gpk_structural.hip",
     "gpk_lineal_ops.hip",
+    "gpk_comm.hip",
 ]
 
 FLAGS = [

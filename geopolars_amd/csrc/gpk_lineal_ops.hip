@@ -1,6 +1,6 @@
 // gpk_lineal_ops.hip — the two remaining operators of `trait GeoSeries` that walk coordinate sequences:
-//   geodesic_length   geoseries.rs:52-58,216-218   (methods of py-geopolars/src/geo.rs:61-78: haversine | vincenty;
-//                                                   "geodesic" = Karney's algorithm is NOT restated: see the entry point)
+//   geodesic_length   geoseries.rs:52-58,216-218   (methods of py-geopolars/src/geo.rs:61-78: geodesic (Karney, gpk_karney.h) |
+//                                                   haversine | vincenty)
 //   simplify          geoseries.rs:108-116,240-242  Ramer-Douglas-Peucker, geo 0.27 algorithm/simplify.rs
 // Both follow the upstream crate's published behaviour (the bodies in the reference are todo!()); what each restates is said
 // at the function.  Coordinates are (lon, lat) degrees for the geodesic lengths, like geo's HaversineLength / VincentyLength.
@@ -8,6 +8,7 @@
 #include <cmath>
 
 #include "gpk_device.h"
+#include "gpk_karney.h"
 #include "gpk_index.h"
 #include "gpk_scan.h"
 
@@ -87,7 +88,9 @@ __global__ __launch_bounds__(256) void geodesic_seq_kernel(const double2* __rest
         double v = 0.0;
         for (int i = c0 + lane; i + 1 < c1; i += G) {
             const double2 p = xy[i], q = xy[i + 1];
-            v += METHOD == GPK_GEODESIC_HAVERSINE ? haversine_m(p.x, p.y, q.x, q.y) : vincenty_m(p.x, p.y, q.x, q.y);
+            v += METHOD == GPK_GEODESIC_HAVERSINE ? haversine_m(p.x, p.y, q.x, q.y)
+                 : METHOD == GPK_GEODESIC_VINCENTY ? vincenty_m(p.x, p.y, q.x, q.y)
+                                                   : karney::k_geodesic_m(p.x, p.y, q.x, q.y);
         }
         v = dev::group_sum<G>(v);
         if (lane == 0) seq_len[s] = v;
@@ -240,11 +243,7 @@ extern "C" {
 
 int32_t gpk_geodesic_length(const gpk_geoarray* a, int32_t method, double* out, int32_t out_space, void* stream) {
     if (!a || (!out && a->d.n_geoms > 0)) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (method == GPK_GEODESIC_KARNEY)
-        return fail(GPK_ERR_INVALID_ARGUMENT,
-                    "geodesic_length: method 'geodesic' (Karney's algorithm, geographiclib) is not restated in this backend; use 'haversine' or "
-                    "'vincenty', or the reference's CPU implementation");
-    if (method != GPK_GEODESIC_HAVERSINE && method != GPK_GEODESIC_VINCENTY)
+    if (method != GPK_GEODESIC_KARNEY && method != GPK_GEODESIC_HAVERSINE && method != GPK_GEODESIC_VINCENTY)
         return fail(GPK_ERR_INVALID_ARGUMENT, "Geodesic calculation method not valid. Use one of geodesic, haversine or vincenty");  // geo.rs:68-71
     GPK_TRY(require_device());
     hipStream_t s = (hipStream_t)stream;
@@ -261,7 +260,10 @@ int32_t gpk_geodesic_length(const gpk_geoarray* a, int32_t method, double* out, 
     double* out_dev = host ? (double*)workspace_aux(0).take(ob) : out;
     if (n_seq > 0) {
         const double mean = (double)a->d.n_coords / (double)n_seq;
-        if (mean <= 24.0) {
+        // (Karney's method is a few hundred f64 operations per segment with a data-dependent Newton loop: always the wide groups)
+        if (method == GPK_GEODESIC_KARNEY)
+            GPK_LAUNCH("gpk_geodesic_seq", (geodesic_seq_kernel<16, GPK_GEODESIC_KARNEY>), group_grid(n_seq, 16), dim3(256), 0, s, a->d.xy, seq_off, n_seq, seq_len);
+        else if (mean <= 24.0) {
             if (method == GPK_GEODESIC_HAVERSINE)
                 GPK_LAUNCH("gpk_geodesic_seq", (geodesic_seq_kernel<4, GPK_GEODESIC_HAVERSINE>), group_grid(n_seq, 4), dim3(256), 0, s, a->d.xy, seq_off, n_seq, seq_len);
             else

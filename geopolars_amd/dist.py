@@ -221,3 +221,87 @@ def broadcast_geoarray(a: Optional[GeoArrowArray], src: int = 0, device: Optiona
     ro = bc(a.ring_offsets if rank == src else None, n_rings + 1, torch.int32) if n_rings >= 0 else None
     validity = bc(a.validity if rank == src else None, (n_geoms + 7) // 8, torch.uint8) if has_valid else None
     return GeoArrowArray(gt, xy, geom_offsets=go, part_offsets=po, ring_offsets=ro, validity=validity, n_geoms=n_geoms)
+
+
+# ---- the same exchange behind the C ABI (gpk_comm_*, gpk_allgatherv_*: RCCL opened by the library itself) ---------------------
+class Comm:
+    """A communicator of libgeopolars_hip (include/geopolars_hip.h, "multi-GPU"): what a Rust / Polars caller of the C ABI uses
+    where this module's torch.distributed helpers serve the Python mirror.  `Comm.from_torch()` draws the unique id on rank 0
+    and hands it to the other ranks over the already initialised torch.distributed group (any side channel would do)."""
+
+    def __init__(self, rank: int, world: int, unique_id: bytes):
+        import ctypes as C
+
+        from . import _abi
+
+        h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        _abi.check(_abi.lib().gpk_comm_init(rank, world, buf, C.byref(h)))
+        self._h, self.rank, self.world = h, rank, world
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+
+        from . import _abi
+
+        buf = (C.c_uint8 * 128)()
+        _abi.check(_abi.lib().gpk_comm_unique_id(buf))
+        return bytes(buf)
+
+    @staticmethod
+    def from_torch(device: torch.device, group=None) -> "Comm":
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        t = torch.zeros(128, dtype=torch.uint8, device=device)
+        if rank == 0:
+            t = torch.frombuffer(bytearray(Comm.unique_id()), dtype=torch.uint8).to(device)
+        dist.broadcast(t, 0, group=group)
+        return Comm(rank, world, bytes(t.cpu().numpy().tobytes()))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def all_gatherv(self, shard, stream: int = 0):
+        """DeviceGeoArray shard -> (the whole column as a DeviceGeoArray that owns its buffers, first row of this rank's shard,
+        bytes gathered)"""
+        import ctypes as C
+
+        from . import _abi
+        from .geoarrow import DeviceGeoArray
+
+        out, base, nbytes = C.c_void_p(), C.c_int64(0), C.c_int64(0)
+        _abi.check(_abi.lib().gpk_allgatherv_geoarray(self._h, shard.handle, stream, C.byref(out), C.byref(base), C.byref(nbytes)))
+        n = C.c_int64(0)
+        _abi.check(_abi.lib().gpk_geoarray_len(out, C.byref(n)))
+        return DeviceGeoArray(out.value, shard.geom_type, int(n.value), -1), int(base.value), int(nbytes.value)
+
+    def all_gather_rows(self, local: torch.Tensor, stream: int = 0) -> torch.Tensor:
+        """(n_local, width) float64 CUDA tensor of every rank -> (n_total, width) in rank order (the leaves of the right side's
+        index: gpk_bounds of each shard)"""
+        import ctypes as C
+
+        from . import _abi
+
+        local = local.contiguous()
+        width = int(local.shape[1]) if local.dim() == 2 else 1
+        total = C.c_int64(0)
+        counts = (C.c_int64 * self.world)()
+        lib = _abi.lib()
+        _abi.check(lib.gpk_allgatherv_rows_f64(self._h, local.data_ptr(), int(local.shape[0]), width, None, 0, C.byref(total), counts, stream))
+        out = torch.empty((int(total.value), width), dtype=torch.float64, device=local.device)
+        _abi.check(lib.gpk_allgatherv_rows_f64(self._h, local.data_ptr(), int(local.shape[0]), width, out.data_ptr(), int(total.value), C.byref(total), counts, stream))
+        return out
+
+    def free(self) -> None:
+        from . import _abi
+
+        if self._h:
+            _abi.lib().gpk_comm_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -217,8 +217,8 @@ class GeoSeries:
     GEODESIC_METHODS = {"geodesic": 0, "haversine": 1, "vincenty": 2}
 
     def geodesic_length(self, method: str = "geodesic") -> np.ndarray:
-        """geoseries.rs:52-58 / georust/geoseries.py: metres, coordinates in (lon, lat) degrees.  'haversine' and 'vincenty' run
-        on the GPU; 'geodesic' (Karney's algorithm) is not restated in this backend and is reported as such."""
+        """geoseries.rs:52-58 / georust/geoseries.py: metres, coordinates in (lon, lat) degrees; all three methods run on the
+        GPU — 'geodesic' (the default) is Karney's algorithm (csrc/gpk_karney.h), as in geo's GeodesicLength."""
         m = self.GEODESIC_METHODS.get(method.lower())
         if m is None:
             raise ValueError("Geodesic calculation method not valid. Use one of geodesic, haversine or vincenty")  # geo.rs:68-71

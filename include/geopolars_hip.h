@@ -218,8 +218,8 @@ int32_t gpk_point_xy(const gpk_geoarray* a, double* out_x, double* out_y, int32_
  *   GPK_GEODESIC_HAVERSINE  geo 0.27 HaversineLength: great circle on the mean-radius sphere (6371008.8 m)
  *   GPK_GEODESIC_VINCENTY   geo 0.27 VincentyLength: Vincenty's inverse formula on WGS84; a row holding a segment upstream
  *                           answers with Err(FailedToConverge) (nearly antipodal end points) is NaN
- *   GPK_GEODESIC_KARNEY     ("geodesic", the Python default: Karney 2013 via geographiclib-rs) is NOT restated here:
- *                           GPK_ERR_INVALID_ARGUMENT — keep the reference's CPU path for it */
+ *   GPK_GEODESIC_KARNEY     "geodesic", the Python default: geo 0.27 GeodesicLength = Karney's algorithm (J. Geodesy 87, 2013,
+ *                           through geographiclib-rs) on WGS84 — order-6 series, Newton's method with bisection fallback */
 #define GPK_GEODESIC_KARNEY    0
 #define GPK_GEODESIC_HAVERSINE 1
 #define GPK_GEODESIC_VINCENTY  2
@@ -354,6 +354,31 @@ int32_t gpk_take_fixed(const void* values, int32_t elem_bits, const uint8_t* val
 int32_t gpk_take_binary(const uint8_t* values, const int32_t* offsets, const uint8_t* validity, int64_t n_values,
                         const int64_t* idx, int64_t n_idx, int32_t* out_offsets, uint8_t* out_values,
                         int64_t capacity, int64_t* n_bytes, uint8_t* out_validity, int32_t space, void* stream);
+
+/* ---- multi-GPU: the one collective of the path ------------------------------------ */
+/* One process per GPU; the LEFT series is sharded by rows and needs no collective (disjoint output rows, pairs carry
+ * `left_row_base`).  A RIGHT side that is itself produced sharded is exchanged once — where `spatial_join` receives its right
+ * side and its index, spatial_index.rs:37-76 — with an all-gatherv of its GeoArrow buffers over RCCL / xGMI, and the leaves of
+ * its index (per-geometry boxes: the NodeEnvelopes of spatial_index.rs:206-312, gpk_bounds of the shard) travel the same way,
+ * so that gpk_index_build_ex assembles the gathered index from them.  Device-resident end to end: lengths first (one small
+ * all-gather, the only host read), then one grouped round of broadcasts per buffer with every piece landing at its final
+ * offset; offsets are rebased and validity repacked on the device.  RCCL is opened at run time (GPK_RCCL_PATH, else the
+ * copy the process already holds, else the system's): there is no link-time dependency.
+ *   gpk_comm_unique_id   rank 0 draws the 128-byte id (ncclUniqueId) and hands it to the other ranks by any side channel
+ *   gpk_comm_init        every rank, same id: a communicator on the current device (collective call)
+ *   gpk_allgatherv_geoarray   shard -> the whole column in rank order (a new handle, gpk_geoarray_free); *out_row_base = first
+ *                        row of this rank's shard in it; every rank passes the same geometry type (GPK_ERR_MISMATCHED_GEOMETRY)
+ *   gpk_allgatherv_rows_f64   n_local rows of `width` doubles (device) -> all rows in rank order; out_dev NULL = total only
+ *                        (still a collective: every rank must make the same call); out_counts[world] host, may be NULL */
+typedef struct gpk_comm gpk_comm;
+int32_t gpk_comm_unique_id(uint8_t out_id[128]);
+int32_t gpk_comm_init(int32_t rank, int32_t world, const uint8_t id[128], gpk_comm** out);
+int32_t gpk_comm_free(gpk_comm* comm);
+int32_t gpk_comm_info(const gpk_comm* comm, int32_t* out_rank, int32_t* out_world);
+int32_t gpk_allgatherv_geoarray(gpk_comm* comm, const gpk_geoarray* shard, void* stream, gpk_geoarray** out,
+                                int64_t* out_row_base, int64_t* out_bytes);
+int32_t gpk_allgatherv_rows_f64(gpk_comm* comm, const double* local_dev, int64_t n_local, int32_t width, double* out_dev,
+                                int64_t out_capacity_rows, int64_t* out_total_rows, int64_t* out_counts, void* stream);
 
 /* ---- join statistics (bench.py's edge_tests/s) ---------------------------------- */
 /* While enabled, the point x polygonal join kernels count what their exact phase does (a few atomics per tile:

@@ -145,7 +145,7 @@ def convex_hull(a: GeoArrowArray):
 def geodesic_length(a: GeoArrowArray, method: str) -> np.ndarray:
     out = np.empty(len(a), dtype=np.float64)
     d = a.desc()
-    _ok(lib().gpko_geodesic_length(C.byref(d), {"haversine": 1, "vincenty": 2}[method], out.ctypes.data), "geodesic_length")
+    _ok(lib().gpko_geodesic_length(C.byref(d), {"geodesic": 0, "haversine": 1, "vincenty": 2}[method], out.ctypes.data), "geodesic_length")
     return out
 
 

@@ -14,6 +14,7 @@ import pytest
 
 from geopolars_amd import _abi, synth
 from geopolars_amd.dist import GeoBuffers, all_gather_leaves, all_gatherv_buffers, shard_rows, slice_rows
+from geopolars_amd.geoarrow import GeoArrowArray
 from geopolars_amd.geoseries import GeoSeries
 from geopolars_amd.spatial_index import SpatialIndex, join_pairs, join_pairs_device
 
@@ -147,3 +148,61 @@ def test_bench_launches_its_own_ranks(gpk):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
     assert line["n_gpus"] == 1 and line["ranks"]["world"] == 1 and line["ranks"]["backend"] == "nccl (RCCL)"
     assert len(line["ranks"]["ms_per_step_per_rank"]) == 1 and line["parity"]["bit_exact"]
+
+
+def _roundtrip(comm, host):
+    from geopolars_amd.geoarrow import DeviceGeoArray
+
+    shard = DeviceGeoArray.upload(host)
+    full, base, nbytes = comm.all_gatherv(shard)
+    got = full.download()
+    assert base == 0 and nbytes > 0 or len(host) == 0
+    assert got.geom_type == host.geom_type and len(got) == len(host)
+    assert np.array_equal(got.xy, host.xy)
+    for name in ("geom_offsets", "part_offsets", "ring_offsets"):
+        a, b = getattr(got, name), getattr(host, name)
+        assert (a is None) == (b is None) and (a is None or np.array_equal(a, b)), name
+    if host.validity is None:
+        assert got.validity is None or got.is_valid().all()
+    else:
+        assert np.array_equal(got.is_valid(), host.is_valid())
+    return full
+
+
+def test_c_abi_communicator_at_world_1(gpk, oracle):
+    """gpk_comm_* / gpk_allgatherv_*: RCCL opened by the library itself (no torch.distributed), a one-rank communicator; the
+    gathered column equals the shard for every GeoArrow nesting, nulls included, and serves a join like the original"""
+    import torch
+
+    from geopolars_amd.dist import Comm
+    from geopolars_amd.geoarrow import DeviceGeoArray
+
+    comm = Comm(0, 1, Comm.unique_id())
+    rng = np.random.default_rng(3)
+    pts = synth.uniform_points(10_001)
+    keep = rng.uniform(size=len(pts)) > 0.1
+    pts_nulls = GeoArrowArray.from_points(pts.xy, validity=np.packbits(keep, bitorder="little"))
+    polys = synth.clustered_polygons(3_000, seed=7)
+    mps = synth.powerlaw_multipolygons(500, seed=8)
+    lines = synth.random_linestrings(700, seed=9)
+    for host in (pts, pts_nulls, polys, mps, lines, GeoArrowArray.from_polygons([])):
+        _roundtrip(comm, host)
+    # the leaves: boxes of the shard, gathered; the gathered index serves the join like one built from scratch
+    right = synth.star_polygons(300, 24)
+    shard = DeviceGeoArray.upload(right)
+    full, _, _ = comm.all_gatherv(shard)
+    boxes = torch.from_numpy(GeoSeries(right).bounds()).cuda()
+    leaves = comm.all_gather_rows(boxes)
+    assert torch.equal(leaves, boxes)
+    index = SpatialIndex.from_device(full, bboxes=leaves)
+    left = synth.uniform_points(50_000, seed=4)
+    exp_pairs, exp_counts, _ = oracle.spatial_join(left, right, "intersects", mode=0)
+    dl = DeviceGeoArray.upload(left)
+    counts = torch.empty(len(left), dtype=torch.int32, device="cuda")
+    pairs = torch.empty((len(left), 2), dtype=torch.int32, device="cuda")
+    from geopolars_amd.spatial_index import join_pairs_device
+
+    h = join_pairs_device(dl, full, index, "intersects", counts, pairs)
+    assert np.array_equal(counts.cpu().numpy().astype(np.uint32), exp_counts)
+    assert np.array_equal(pairs[:h].cpu().numpy().astype(np.uint32), exp_pairs)
+    comm.free()

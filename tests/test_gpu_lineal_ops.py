@@ -25,7 +25,7 @@ def _lonlat_lines(n, seed, lo=2, hi=200):
     return GeoArrowArray(_abi.GEOM_LINESTRING, xy, geom_offsets=off)
 
 
-@pytest.mark.parametrize("method", ["haversine", "vincenty"])
+@pytest.mark.parametrize("method", ["geodesic", "haversine", "vincenty"])
 def test_geodesic_length_parity(gpk, oracle, method):
     lines = _lonlat_lines(20_000, 3)
     got, exp = GeoSeries(lines).geodesic_length(method), oracle.geodesic_length(lines, method)
@@ -46,8 +46,13 @@ def test_geodesic_published_values_and_methods(gpk):
     nyc_london = GeoSeries(GeoArrowArray.from_linestrings([[(-74.006, 40.7128), (-0.1278, 51.5074)]]))
     assert round(float(nyc_london.geodesic_length("haversine")[0])) == 5_570_230  # geo's HaversineLength doc example
     assert round(float(nyc_london.geodesic_length("vincenty")[0])) == 5_585_234  # geo's VincentyLength doc example
-    with pytest.raises(_abi.GeopolarsHipError):
-        nyc_london.geodesic_length("geodesic")  # Karney's algorithm is not restated in this backend: reported, not approximated
+    assert round(float(nyc_london.geodesic_length("geodesic")[0])) == 5_585_234  # geo's GeodesicDistance doc example
+    assert round(float(nyc_london.geodesic_length()[0])) == 5_585_234  # ("geodesic" is the default: georust/geoseries.py:128)
+    three = GeoSeries(GeoArrowArray.from_linestrings([[(-74.006, 40.7128), (-0.1278, 51.5074), (135.5244559, 34.687455)]]))
+    assert round(float(three.geodesic_length("geodesic")[0])) == 15_109_158  # geo's GeodesicLength doc example
+    published = GeoSeries(GeoArrowArray.from_linestrings([[(174.81, -41.32), (-5.50, 40.96)], [(-73.8, 40.6), (-0.5, 51.6)], [(0.0, 0.0), (179.5, 0.5)], [(0.0, 0.0), (180.0, 0.0)]]))
+    got = published.geodesic_length("geodesic")  # GeographicLib: Wellington -> Salamanca, JFK -> LHR; Karney 2013's antipodal pair
+    assert np.allclose(got, [19959679.26735382, 5551759.4003186841, 19936288.578965, 20003931.458625], rtol=0, atol=2e-3)
     with pytest.raises(ValueError):
         nyc_london.geodesic_length("rhumb")
 

@@ -32,6 +32,43 @@ def test_geodesic_lengths_reproduce_published_values(oracle):
     assert oracle.geodesic_length(poly, "haversine")[0] == oracle.geodesic_length(ring, "haversine")[0]
 
 
+def test_karney_geodesic_reproduces_published_lines(oracle):
+    """"geodesic" = geo 0.27 GeodesicLength = Karney's inverse problem (geographiclib-rs): the values geo's documentation and
+    GeographicLib publish.  (lon, lat) order, like every geodesic method of the surface."""
+
+    def line(*pts):
+        return float(oracle.geodesic_length(GeoArrowArray.from_linestrings([list(pts)]), "geodesic")[0])
+
+    # geo's GeodesicDistance / GeodesicLength doc examples (rounded to metres there)
+    assert round(line((-74.006, 40.7128), (-0.1278, 51.5074))) == 5_585_234
+    assert round(line((-74.006, 40.7128), (-0.1278, 51.5074), (135.5244559, 34.687455))) == 15_109_158
+    # GeographicLib's documentation: Wellington (41.32S 174.81E) -> Salamanca (40.96N 5.50W), s12 = 19959679.267 m
+    assert abs(line((174.81, -41.32), (-5.50, 40.96)) - 19959679.26735382) < 1e-5
+    # GeodSolve's example: JFK (40.6N 73.8W) -> LHR (51.6N 0.5W), 5551759.400 m
+    assert abs(line((-73.8, 40.6), (-0.5, 51.6)) - 5551759.4003186841) < 1e-5
+    # the first line of GeographicLib's GeodTest set
+    assert abs(line((-139.44815, 35.60777), (-69.95921, -11.17491)) - 8935244.5604818305) < 1e-6
+    # Karney 2013, the nearly antipodal example: (0, 0) -> (0.5N, 179.5E), 19936288.579 m
+    assert abs(line((0.0, 0.0), (179.5, 0.5)) - 19936288.578965) < 1e-3
+    # closed forms on WGS84: a quarter of the equator, a quarter meridian (10001965.729 m), antipodes over the pole
+    a = 6378137.0
+    assert abs(line((0.0, 0.0), (90.0, 0.0)) - a * np.pi / 2) < 1e-6
+    assert abs(line((0.0, 0.0), (0.0, 90.0)) - 10001965.729313) < 1e-4
+    assert abs(line((0.0, 0.0), (180.0, 0.0)) - 2 * 10001965.729313) < 1e-3  # (Vincenty's iteration fails here)
+    assert line((10.0, 20.0), (10.0, 20.0)) == 0.0
+    # symmetric, and in step with Vincenty's formula where that converges (sub-millimetre on 20 000 random lines)
+    rng = np.random.default_rng(2)
+    p = np.stack([rng.uniform(-180, 180, 20_000), rng.uniform(-89, 89, 20_000)], axis=1)
+    q = np.stack([rng.uniform(-180, 180, 20_000), rng.uniform(-89, 89, 20_000)], axis=1)
+    off = np.arange(0, 40_001, 2, dtype=np.int32)
+    fwd = GeoArrowArray(_abi.GEOM_LINESTRING, np.stack([p, q], axis=1).reshape(-1, 2), geom_offsets=off)
+    bwd = GeoArrowArray(_abi.GEOM_LINESTRING, np.stack([q, p], axis=1).reshape(-1, 2), geom_offsets=off)
+    kf, kb, vf = oracle.geodesic_length(fwd, "geodesic"), oracle.geodesic_length(bwd, "geodesic"), oracle.geodesic_length(fwd, "vincenty")
+    assert np.all(np.abs(kf - kb) <= 1e-8)
+    ok = ~np.isnan(vf) & (kf < 1.9e7)  # (Vincenty's series loses accuracy towards the antipode)
+    assert ok.sum() > 15_000 and np.all(np.abs(kf[ok] - vf[ok]) < 1e-3)
+
+
 def _rdp_rational(pts, eps, min_pts):
     """geo 0.27 compute_rdp on exact rationals (squared distances compared, so no rounding anywhere)"""
     n = len(pts)
