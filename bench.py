@@ -96,6 +96,12 @@ def roofline_traffic(roofline: dict, config: str) -> dict:
     r, note = pmc_config_record(config)
     roofline["traffic"] = r["traffic_bytes_raw"] if r else None
     roofline["traffic_note"] = note
+    if r and r.get("valu_wave_instructions_per_launch") and roofline.get("launch_ms") and "valu" not in roofline:
+        # a second roofline for kernels that are not bandwidth-bound: vector instructions issued (SQ_INSTS_VALU, one per wave of 64
+        # lanes) against the f64 issue rate — an upper bound on what arithmetic could explain
+        lane_rate = r["valu_wave_instructions_per_launch"] * 64.0 / (roofline["launch_ms"] * 1e-3)
+        roofline["valu"] = {"wave_instructions_per_launch": r["valu_wave_instructions_per_launch"], "achieved_lane_instr_per_s": lane_rate, "peak": F64_VALU_PEAK,
+                            "frac": lane_rate / F64_VALU_PEAK, "salu_wave_instructions_per_launch": r.get("salu_wave_instructions_per_launch")}
     return roofline
 
 
@@ -626,7 +632,7 @@ def cpu_baseline_distance(pts_host, ls_host, rows, target_s: float) -> dict:
 def run_c4(ctx: Ctx) -> None:
     torch, args, lib = ctx.torch, ctx.args, ctx.lib
     from geopolars_amd import _abi, synth
-    from geopolars_amd.dist import GeoBuffers, all_gather_leaves, all_gatherv_buffers, shard_rows, slice_rows
+    from geopolars_amd.dist import Comm, GeoBuffers, all_gather_leaves, all_gatherv_buffers, shard_rows, slice_rows
     from geopolars_amd.spatial_index import SpatialIndex, join_pairs_device
 
     n, dev, stream, W = args.polygons, ctx.dev, ctx.stream, ctx.world
@@ -645,16 +651,23 @@ def run_c4(ctx: Ctx) -> None:
         shard_arr = right_shard.to_device_geoarray(stream)
         box = torch.empty((rhi - rlo, 4), dtype=torch.float64, device=dev)
         _abi.check(lib.gpk_bounds(shard_arr.handle, box.data_ptr(), _abi.MEM_DEVICE, stream))
+        comm = Comm.from_torch(dev) if args.comm == "abi" else None  # (the unique id travels over the torch group: any side channel would do)
         ctx.barrier()
         t0 = time.perf_counter()
         stats = {}
-        right_buf = all_gatherv_buffers(right_shard, stats=stats)
-        leaves = all_gather_leaves(box)
+        if comm is not None:  # the exchange through the C ABI: gpk_allgatherv_geoarray / gpk_allgatherv_rows_f64 (RCCL opened by the library)
+            right, _, gathered = comm.all_gatherv(shard_arr, stream=stream)
+            leaves = comm.all_gather_rows(box, stream=stream)
+            stats["gathered_bytes"] = gathered
+        else:
+            right_buf = all_gatherv_buffers(right_shard, stats=stats)
+            leaves = all_gather_leaves(box)
+            right = right_buf.to_device_geoarray(stream)
         ctx.barrier()
-        exchange = {"ms": ctx.max_over_ranks(time.perf_counter() - t0) * 1e3, "bytes": stats["gathered_bytes"] + leaves.numel() * 8}
+        exchange = {"ms": ctx.max_over_ranks(time.perf_counter() - t0) * 1e3, "bytes": stats["gathered_bytes"] + leaves.numel() * 8,
+                    "through": "C ABI (gpk_allgatherv_*)" if comm is not None else "torch.distributed (geopolars_amd.dist)"}
     else:
-        right_buf, leaves = right_shard, None
-    right = right_buf.to_device_geoarray(stream)
+        right, leaves = right_shard.to_device_geoarray(stream), None
     left = dev_array(torch, left_host, dev, stream)
     nl = hi - lo
     build_ms = []
@@ -698,7 +711,7 @@ def run_c4(ctx: Ctx) -> None:
         "join_ms": ms_per_step,
         "build_plus_join_ms": min(build_ms) + ms_per_step,
         "note_build": "spatial_join without r_index pays build + join (spatial_index.rs:47-71); `value` is the join with a prebuilt r_index (spatial_index.rs:558-624)",
-        "right_side_exchange": {"ms": exchange["ms"], "bytes": exchange["bytes"], "what": "all-gatherv of the right GeoArrow buffers + the per-geometry boxes, device-resident, outside the timed region"},
+        "right_side_exchange": {"ms": exchange["ms"], "bytes": exchange["bytes"], "through": exchange.get("through"), "what": "all-gatherv of the right GeoArrow buffers + the per-geometry boxes, device-resident, outside the timed region"},
         "kernel_ms_per_step": warm,
         "parallelism": f"left row-sharded x{W} (strong scaling: the 1M x 1M problem is fixed), right side all-gathered",
     }
@@ -940,6 +953,7 @@ def main() -> None:
     ap.add_argument("--no-profile", action="store_true", help="tuning only: no HIP events around the kernels (the roofline leg reads zero)")
     ap.add_argument("--no-join-stats", action="store_true", help="c2: skip the extra untimed step that counts the exact phase's work (its atomics make that one launch ~7x longer: kernel-trace averages of a profiler run stay clean without it)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the exchange even at world size 1 (path test)")
+    ap.add_argument("--comm", choices=["torch", "abi"], default="torch", help="c4: the right-side exchange through torch.distributed (geopolars_amd.dist) or through the library's own RCCL entry points (gpk_allgatherv_*)")
     ap.add_argument("--spawn", action="store_true", help="launch the rank(s) under torch.distributed.run even for --gpus 1 (what --gpus N > 1 does by itself when there is no launcher)")
     args = ap.parse_args()
     if args.steps is None:

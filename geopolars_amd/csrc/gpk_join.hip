@@ -1456,14 +1456,42 @@ __device__ __forceinline__ int64_t row_of_candidate(const int32_t* __restrict__ 
 __global__ __launch_bounds__(256) void pair_refine_kernel(DevGeo left, DevGeo right, const uint32_t* __restrict__ cand_l,
                                                            const uint32_t* __restrict__ cand_r, int64_t n_cand,
                                                            const double4* __restrict__ lbbox, const double4* __restrict__ rbbox,
-                                                           uint8_t* __restrict__ hit) {
-    __shared__ double4 seg_lists[(256 / JOIN_GS) * 2 * PP_LIST];  // one in-window segment list per group (gpk_polypoly.h)
+                                                           uint8_t* __restrict__ hit, bool l_one_ring, bool r_one_ring) {
+    // (l_one_ring / r_one_ring: every polygon of that POLYGON column is known to have exactly one ring — ring r is geometry r)
+    // per group: the staging slice of the small-pair path, which doubles as the two in-window segment lists of the general one
+    static_assert(sizeof(PairSmallLds) >= 2 * PP_LIST * sizeof(double4), "the general routine's lists fit the small-pair slice");
+    __shared__ PairSmallLds slices[256 / JOIN_GS];
     const int lane = threadIdx.x & (JOIN_GS - 1);
-    double4* seg_list = seg_lists + (threadIdx.x / JOIN_GS) * 2 * PP_LIST;
+    PairSmallLds* slice = slices + threadIdx.x / JOIN_GS;
+    const bool plain = left.type == GPK_GEOM_POLYGON && right.type == GPK_GEOM_POLYGON && lbbox && rbbox;  // (uniform)
     const int64_t groups = (int64_t)gridDim.x * (256 / JOIN_GS);
     for (int64_t c = (int64_t)blockIdx.x * (256 / JOIN_GS) + threadIdx.x / JOIN_GS; c < n_cand; c += groups) {
-        const int64_t i = (int64_t)cand_l[c];
-        const bool h = polygonal_intersects_polygonal_group<JOIN_GS>(left, i, right, (int64_t)cand_r[c], lane, seg_list, lbbox, rbbox);
+        const int64_t i = (int64_t)cand_l[c], j = (int64_t)cand_r[c];
+        bool h;
+        bool small = false;
+        int ca = 0, na = 0, cb = 0, nb = 0;
+        if (plain) {  // two single-ring polygons of at most PP_SMALL coordinates: the staged path (gpk_polypoly.h)
+            int ra0 = (int)i, ra1 = (int)i + 1, rb0 = (int)j, rb1 = (int)j + 1;
+            if (!l_one_ring) {
+                ra0 = left.geom_off[i];
+                ra1 = left.geom_off[i + 1];
+            }
+            if (!r_one_ring) {
+                rb0 = right.geom_off[j];
+                rb1 = right.geom_off[j + 1];
+            }
+            if (ra1 - ra0 == 1 && rb1 - rb0 == 1) {
+                ca = left.ring_off[ra0];
+                na = left.ring_off[ra0 + 1] - ca;
+                cb = right.ring_off[rb0];
+                nb = right.ring_off[rb0 + 1] - cb;
+                small = na >= 1 && nb >= 1 && na <= PP_SMALL && nb <= PP_SMALL;
+            }
+        }
+        if (small)
+            h = polygon_pair_small<JOIN_GS>(left.xy + ca, na, right.xy + cb, nb, lbbox[i], rbbox[j], lane, slice);
+        else
+            h = polygonal_intersects_polygonal_group<JOIN_GS>(left, i, right, j, lane, reinterpret_cast<double4*>(slice), lbbox, rbbox);
         if (lane == 0) hit[c] = h;
     }
 }
@@ -1627,7 +1655,8 @@ static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, co
             else
                 GPK_LAUNCH("gpk_pair_refine", pair_refine_kernel, dim3((unsigned)blocks), dim3(256), 0, s, left->d, right->d,
                            (const uint32_t*)cand_l, (const uint32_t*)cand_r, (int64_t)n_cand, (const double4*)lbbox,
-                           right_index->v.bbox, hit);
+                           right_index->v.bbox, hit, left->d.type == GPK_GEOM_POLYGON && left->classes && left->classes->one_to_one,
+                           right->d.type == GPK_GEOM_POLYGON && right->classes && right->classes->one_to_one);
         }
         GPK_LAUNCH("gpk_pair_count", pair_emit_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, n, (const int32_t*)cand_off,
                    (const uint32_t*)cand_r, (const uint8_t*)hit, counts, (const int32_t*)nullptr, left_row_base, (uint2*)nullptr, (int64_t)0);

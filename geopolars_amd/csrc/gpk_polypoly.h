@@ -318,6 +318,86 @@ __device__ inline bool polygon_intersects_polygon_group(const DevGeo& a, int ar0
     return polygon_pos_group<G>(b, br0, br1, p.x, p.y, lane) != dev::POS_OUTSIDE;
 }
 
+// ---- the common case of a polygon x polygon join: two single-ring polygons of at most PP_SMALL coordinates -------------------
+// Same boolean as polygon_intersects_polygon_group, but both rings are staged ONCE in the group's LDS slice (coalesced requests,
+// the two rings' requests in flight together) and everything after that — window clipping, the segment cross test, the two
+// containment tests — reads LDS.  The general routine walks global memory at every step (ring offsets per lane and round, the
+// coordinates again for the containment test): eight dependent round trips per candidate pair against two here, and the refine
+// of a 1M x 1M join is a latency chain, not arithmetic.
+constexpr int PP_SMALL = 66;  // coordinates per ring (closed: 65 edges) the small-pair path stages: 36 KB per work-group, four per CU
+struct PairSmallLds {
+    double2 a[PP_SMALL], b[PP_SMALL];
+    uint8_t la[PP_SMALL], lb[PP_SMALL];  // in-window segments (their first coordinate's index)
+};
+template <int G>
+__device__ inline bool polygon_pair_small(const double2* __restrict__ axy, int na, const double2* __restrict__ bxy, int nb, double4 ea, double4 eb, int lane,
+                                          PairSmallLds* __restrict__ t) {
+    // (the caller has checked: 1 <= na, nb <= PP_SMALL; ea / eb = the rings' boxes)
+    if (ea.z < eb.x || ea.w < eb.y || eb.z < ea.x || eb.w < ea.y) return false;  // has_disjoint_bboxes
+    for (int i = lane; i < na; i += G) t->a[i] = axy[i];
+    for (int i = lane; i < nb; i += G) t->b[i] = bxy[i];
+    const int gbase = (int)(threadIdx.x & 63) & ~(G - 1);
+    const unsigned long long gmask_all = G == 64 ? ~0ull : ((1ull << G) - 1ull);
+    auto lds_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    lds_sync();
+    // window clipping: a segment of one ring can only meet the other ring inside the other ring's box
+    auto clip = [&](const double2* ring, int n, const double4& box, uint8_t* list) {
+        int m = 0;
+        for (int i0 = 0; i0 + 1 < n; i0 += G) {
+            const int i = i0 + lane;
+            bool keep = false;
+            if (i + 1 < n) {
+                const double2 q0 = ring[i], q1 = ring[i + 1];
+                keep = !(fmax(q0.x, q1.x) < box.x || fmin(q0.x, q1.x) > box.z || fmax(q0.y, q1.y) < box.y || fmin(q0.y, q1.y) > box.w);
+            }
+            const unsigned long long mine = (__ballot(keep) >> gbase) & gmask_all;
+            if (keep) list[m + __popcll(mine & ((1ull << lane) - 1ull))] = (uint8_t)i;
+            m += __popcll(mine);
+        }
+        return m;
+    };
+    const int ma = clip(t->a, na, eb, t->la), mb = clip(t->b, nb, ea, t->lb);
+    lds_sync();
+    bool hit = false;
+    for (int i0 = 0; i0 < ma && !hit; i0 += G) {
+        const bool active = i0 + lane < ma;
+        const int ia = active ? (int)t->la[i0 + lane] : 0;
+        const double2 p0 = t->a[ia], p1 = t->a[active ? ia + 1 : 0];
+        const double plx = fmin(p0.x, p1.x), phx = fmax(p0.x, p1.x), ply = fmin(p0.y, p1.y), phy = fmax(p0.y, p1.y);
+        for (int e0 = 0; e0 < mb && !hit; e0 += PP_VOTE) {
+            bool found = false;
+            if (active) {
+                const int e1 = e0 + PP_VOTE < mb ? e0 + PP_VOTE : mb;
+                for (int e = e0; e < e1; ++e) {
+                    const int ib = (int)t->lb[e];
+                    const double2 q0 = t->b[ib], q1 = t->b[ib + 1];
+                    if (fmax(q0.x, q1.x) < plx || fmin(q0.x, q1.x) > phx || fmax(q0.y, q1.y) < ply || fmin(q0.y, q1.y) > phy) continue;
+                    if (line_intersects_line(p0, p1, q0, q1)) {
+                        found = true;
+                        break;
+                    }
+                }
+            }
+            hit = group_any<G>(found);
+        }
+    }
+    if (!hit) {
+        // no boundary pair touches: one vertex per ring decides containment (see polygon_intersects_polygon_group)
+        const double2 q = t->b[0];
+        hit = coord_pos_ring_group<G>(t->a, na, q.x, q.y, lane) != dev::POS_OUTSIDE;
+        if (!hit) {
+            const double2 p = t->a[0];
+            hit = coord_pos_ring_group<G>(t->b, nb, p.x, p.y, lane) != dev::POS_OUTSIDE;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();  // the slice may be overwritten after this point
+    return hit;
+}
+
 template <int G>
 // a_boxes / b_boxes (optional): per-geometry exterior bounds (gpk_bounds layout); used for Polygon rows, where the
 // geometry's bounds ARE its one exterior's box

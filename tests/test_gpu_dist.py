@@ -120,6 +120,7 @@ def test_row_sharded_hip_joins_equal_unsharded(gpk, k):
         ("c2", ["--points", "2000000"]),  # the configuration the driver's scaling run launches with --gpus N
         ("c3", ["--points", "1000000", "--lines", "20000"]),
         ("c4", ["--polygons", "150000"]),
+        ("c4", ["--polygons", "150000", "--comm", "abi"]),  # the same exchange through gpk_allgatherv_* (RCCL opened by the library)
         ("c5", ["--multipolygons", "160000", "--points", "400000"]),
     ],
 )

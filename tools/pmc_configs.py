@@ -38,6 +38,11 @@ def main():
             "traffic_bytes_raw": int((f + w) * 1024.0),
             "traffic_bytes_with_read_factor": int((f * READ_FACTOR + w) * 1024.0),
         }
+        v, nv = mean_counter(os.path.join(root, f"{c}_SQ_INSTS_VALU"), pat, "SQ_INSTS_VALU")
+        sa, _ = mean_counter(os.path.join(root, f"{c}_SQ_INSTS_VALU"), pat, "SQ_INSTS_SALU")
+        if v is not None:
+            rec["configs"][c]["valu_wave_instructions_per_launch"] = v
+            rec["configs"][c]["salu_wave_instructions_per_launch"] = sa
     json.dump(rec, open(out, "w"), indent=1)
     print(json.dumps(rec)[:900])
 
