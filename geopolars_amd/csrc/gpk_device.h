@@ -137,6 +137,67 @@ __device__ __forceinline__ bool ring_edge(double sx, double sy, double ex, doubl
     return false;
 }
 
+// orient2d_exact without a call and without scratch memory (every loop unrolled: the two expansions live in registers), for
+// code that must not contain a call (the tile kernels of gpk_join.hip settle their rare rows in place)
+__device__ __forceinline__ int orient2d_exact_unrolled(double ax, double ay, double bx, double by, double cx, double cy) {
+    double t[12];
+    two_prod(ax, by, t[0], t[1]);
+    two_prod(-ax, cy, t[2], t[3]);
+    two_prod(-cx, by, t[4], t[5]);
+    two_prod(-ay, bx, t[6], t[7]);
+    two_prod(ay, cx, t[8], t[9]);
+    two_prod(cy, bx, t[10], t[11]);
+    double e[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        double q = t[i];
+#pragma unroll
+        for (int j = 0; j < i; ++j) {
+            double s, err;
+            two_sum(q, e[j], s, err);
+            e[j] = err;
+            q = s;
+        }
+        e[i] = q;
+    }
+    int sign = 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {  // most significant non-zero component is the last one
+        if (e[i] > 0.0) sign = 1;
+        if (e[i] < 0.0) sign = -1;
+    }
+    return sign;
+}
+// dev::ring_edge with the exact arm inlined (same arms, same results)
+__device__ __forceinline__ bool ring_edge_inline(double sx, double sy, double ex, double ey, double cx, double cy, int& wn) {
+    const bool up = sy <= cy && ey >= cy;
+    const bool down = sy > cy && ey <= cy;
+    if (!(up || down)) return false;
+    const double lo = fmin(sx, ex), hi = fmax(sx, ex);
+    if (cx < lo) {
+        wn += up ? (ey != cy ? 1 : 0) : -1;
+        return false;
+    }
+    if (!(cx <= hi)) return false;
+    const double detleft = (sx - cx) * (ey - cy);
+    const double detright = (sy - cy) * (ex - cx);
+    const double det = detleft - detright;
+    const double detsum = fabs(detleft) + fabs(detright);
+    const double errbound = 3.3306690738754716e-16 * detsum;
+    const bool opposite = (detleft > 0.0 && detright <= 0.0) || (detleft < 0.0 && detright >= 0.0) || detleft == 0.0;
+    int o;
+    if (opposite || fabs(det) >= errbound)
+        o = (det > 0.0) - (det < 0.0);
+    else
+        o = orient2d_exact_unrolled(sx, sy, ex, ey, cx, cy);
+    if (o == 0) return true;
+    if (up)
+        wn += (o > 0 && ey != cy) ? 1 : 0;
+    else
+        wn -= (o < 0) ? 1 : 0;
+    return false;
+}
+
 // ring_edge for kernels that keep the expansion arithmetic out of their code (pip_tile_chain, gpk_join.hip): the same arms, but an
 // orientation that Shewchuk's stage-A bound cannot certify is not recomputed here — `unsure` is set and the caller hands the
 // point to the exact walk.  (wn and the return value are then meaningless for this edge.)

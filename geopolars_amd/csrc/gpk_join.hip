@@ -874,10 +874,11 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_LEAN_MINWAVES) void pip_tile_lean_ke
 //
 // The kernels' arguments hold only what the hot path reads (the full views — two DevGeo, IndexView, PipView: 100 dwords — do
 // not fit the scalar register file next to the kernel's own state; the compiler then parks them in vector-register lanes and
-// pays a v_readlane per use).  Everything that needs those views is NOT done here: a point of a list cell, a `test` point
-// whose sub-cell has no chain entry, a point whose orientation against a chain edge Shewchuk's stage-A bound cannot certify
-// — a handful per launch on real data — is appended to a deferred list and decided by pip_fixup_kernel with the generic
-// (always exact) walk.  The tile kernels therefore contain no call, no expansion arithmetic and no scratch memory.
+// pays a v_readlane per use).  What needs those views is rare — a point of a list cell, a `test` point whose sub-cell has no
+// chain entry, a point whose orientation against a chain edge Shewchuk's stage-A bound cannot certify: a handful per launch
+// on real data — and is settled at the end of the tile by the whole wave with the generic (always exact) walk, its arguments
+// read from device memory (ChainCold) at that point.  The kernels contain no call and no scratch memory: the expansion
+// arithmetic of the exact orientation is unrolled into registers that are free there (dev::orient2d_exact_unrolled).
 #ifndef GPK_CHAIN_PPT
 #define GPK_CHAIN_PPT 4
 #endif
@@ -925,9 +926,85 @@ struct ChainHot {
     unsigned long long* block_tot;
     unsigned long long* super_tot;
     unsigned long long* stats;
-    uint32_t* defer_count;  // zeroed with the totals
-    uint32_t* defer_list;   // left-row indices (one slot per point: a hostile point set can defer every row)
+    const struct ChainCold* cold;  // what the generic walk of a rare row reads (written by join_prep_kernel)
 };
+// the arguments of the rare arm, in device memory: loaded where they are used — as kernel arguments they would be held in scalar
+// registers across the hot loop (and spilled)
+struct ChainCold {
+    DevGeo polys;
+    IndexView ix;
+    GridParams grid;
+};
+// one small launch in place of the memset of a join's totals: zeroes them and writes the rare arm's arguments
+__global__ __launch_bounds__(256) void join_prep_kernel(unsigned long long* __restrict__ zero, int64_t n_zero, ChainCold* __restrict__ cold_out, DevGeo polys,
+                                                        IndexView ix) {
+    for (int64_t i = threadIdx.x; i < n_zero; i += 256) zero[i] = 0ull;
+    if (threadIdx.x == 0) {
+        cold_out->polys = polys;
+        cold_out->ix = ix;
+        cold_out->grid = *ix.grid;
+    }
+}
+// The generic (always exact) walk for ONE point, by a whole wave: directory candidates in ascending id order, each candidate's
+// rings with the lanes striding over the edges (a row costs a handful of dependent loads, not one per edge), the exact
+// orientation kernel inlined.  Returns the hit count; *first = the first hit.  Same answers as generic_point.
+// INLINE_EXACT: the expansion arithmetic of the exact orientation unrolled into registers (no call, no scratch memory: what the
+// persistent route kernel wants, which owns 128 registers per lane anyway) or reached by a call (the chain kernel: 84 registers
+// instead of 113, i.e. one more wave per SIMD, for a 208-byte stack).
+template <bool INLINE_EXACT>
+__device__ __forceinline__ uint32_t chain_generic_row(const ChainCold* __restrict__ cold, double px, double py, int lane, uint32_t* first) {
+    const DevGeo polys = cold->polys;
+    const IndexView ix = cold->ix;
+    const GridParams g = cold->grid;
+    uint32_t cnt = 0;
+    *first = CODE_NONE;
+    if (!(px == px && py == py)) return 0u;
+    const int cx = dev::cell_of(px, g.x0, g.inv_w, g.gx), cy = dev::cell_of(py, g.y0, g.inv_h, g.gy);
+    const int cc = cy * g.gx + cx;
+    for (int q = ix.cell_off[cc]; q < ix.cell_off[cc + 1]; ++q) {
+        const int j = ix.items[q];
+        const double4 bb = ix.bbox[j];
+        if (!(px >= bb.x && px <= bb.z && py >= bb.y && py <= bb.w) || !dev::valid_row(polys.validity, j)) continue;
+        int p0, p1;
+        dev::geom_parts(polys, j, p0, p1);
+        bool hit = false;
+        for (int part = p0; part < p1 && !hit; ++part) {  // Contains<Point>: strictly inside some member polygon
+            int r0, r1;
+            dev::part_rings(polys, part, r0, r1);
+            int pos = dev::POS_INSIDE;  // position w.r.t. the polygon: exterior first, then the holes
+            for (int r = r0; r < r1 && pos == dev::POS_INSIDE; ++r) {
+                const int c0 = polys.ring_off[r], n = polys.ring_off[r + 1] - c0;
+                int wn = 0, on = 0;
+                if (n == 1) {
+                    const double2 s0 = polys.xy[c0];
+                    on = (px == s0.x && py == s0.y) ? 1 : 0;
+                }
+                for (int i = lane; i + 1 < n; i += 64) {
+                    const double2 s0 = polys.xy[c0 + i], s1 = polys.xy[c0 + i + 1];
+                    on |= (int)(INLINE_EXACT ? dev::ring_edge_inline(s0.x, s0.y, s1.x, s1.y, px, py, wn) : dev::ring_edge(s0.x, s0.y, s1.x, s1.y, px, py, wn));
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    wn += __shfl_xor(wn, o, 64);
+                    on |= __shfl_xor(on, o, 64);
+                }
+                const int rp = n == 0 ? dev::POS_OUTSIDE : (on ? dev::POS_BOUNDARY : (wn != 0 ? dev::POS_INSIDE : dev::POS_OUTSIDE));
+                if (r == r0)
+                    pos = rp;  // Outside / OnBoundary of the exterior ends it
+                else if (rp == dev::POS_BOUNDARY)
+                    pos = dev::POS_BOUNDARY;
+                else if (rp == dev::POS_INSIDE)
+                    pos = dev::POS_OUTSIDE;  // inside a hole
+            }
+            hit = r1 > r0 && pos == dev::POS_INSIDE;
+        }
+        if (hit) {
+            if (cnt == 0) *first = (uint32_t)j;
+            ++cnt;
+        }
+    }
+    return cnt;
+}
 
 // one `test` point of a tile, in the wave's LDS list (24 bytes; reading the point again from memory instead was measured: the
 // tile's lines are streamed with the non-temporal hint and are gone from the L2 — 20 us more per launch)
@@ -1062,6 +1139,8 @@ __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mas
         }
         GPK_SCHED_FENCE();
     });
+    uint32_t* __restrict__ tile_counts = h.counts ? h.counts + base : nullptr;
+    uint32_t* __restrict__ tile_code = h.code + base;
     // 4. the exact step: one listed point per lane and pass
     n_items = n_items < (uint32_t)ITEMS ? n_items : (uint32_t)ITEMS;
     unsigned long long edges_walked = 0;
@@ -1115,14 +1194,19 @@ __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mas
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next tile overwrites the list)
         __builtin_amdgcn_wave_barrier();
     }
-    // deferred points: provisional "no hit" here, the real answer (count, code, totals) from pip_fixup_kernel
+    // the rare rows (list-cell points, sub-cells without a chain entry, orientations the filter could not certify) are listed now —
+    // the point's index within the tile, in the wave's LDS list, which holds a whole tile of them — and settled at the very end of
+    // the tile, when nothing of the tile's state is live any more
+    uint32_t n_rare = 0;  // wave-uniform
+    uint32_t* s_rare = reinterpret_cast<uint32_t*>(s_items);
+    static_assert(sizeof(ChainItem) * chain_items<P>() >= sizeof(uint32_t) * 64 * P, "the list holds a tile of rare rows");
     if (__any(dmask != 0u)) {
         static_for<P>([&](auto K) {
             constexpr int k = decltype(K)::value;
-            if (dmask & (1u << k)) {
-                res[k] = CODE_NONE;
-                if (FULL || (uint32_t)(k * 64 + lane) < rem) h.defer_list[atomicAdd(h.defer_count, 1u)] = (uint32_t)(base + k * 64 + lane);
-            }
+            const bool want = ((dmask >> k) & 1u) != 0u;
+            const unsigned long long m = __ballot(want);
+            if (want) s_rare[n_rare + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)(k * 64 + lane);
+            n_rare += (uint32_t)__popcll(m);
         });
     }
     if (h.stats && n_items) {  // measurement runs only (gpk_join_stats_enable): uniform branch on the pointer
@@ -1130,8 +1214,6 @@ __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mas
         if (edges_walked) atomicAdd(&h.stats[1], edges_walked);
     }
     // part -> geometry (null geometries dropped), count + code, the tile's total
-    uint32_t* __restrict__ tile_counts = h.counts ? h.counts + base : nullptr;
-    uint32_t* __restrict__ tile_code = h.code + base;
     unsigned long long hits = 0;  // wave-uniform
     static_for<P>([&](auto K) {
         constexpr int k = decltype(K)::value;
@@ -1142,12 +1224,34 @@ __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mas
             r = dev::valid_row(h.polys_validity, geom) ? geom : CODE_NONE;
         }
         const uint32_t cnt = r != CODE_NONE ? 1u : 0u;
-        if (FULL || li < rem) {
+        const bool mine = (FULL || li < rem) && !((dmask >> k) & 1u);  // (a rare row's count and code were written by its walk)
+        if (mine) {
             if (tile_counts) dev::store_stream(tile_counts + li, cnt);
             dev::store_stream(tile_code + li, r);
         }
-        hits += (unsigned long long)__popcll(__ballot((FULL || li < rem) && cnt == 1u));
+        hits += (unsigned long long)__popcll(__ballot(mine && cnt == 1u));
     });
+    // the rare rows: the whole wave walks one row after the other with the generic walk; the walk's arguments come from device
+    // memory (ChainCold).  Their counts and codes are written here (the owning lanes skipped their stores).
+    if (n_rare) {  // (wave-uniform)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t i = 0; i < n_rare; ++i) {
+            const uint32_t li = s_rare[i];
+            const double2 q = tile_xy[li];
+            uint32_t first;
+            const uint32_t cnt = chain_generic_row<ROUTE>(h.cold, q.x, q.y, lane, &first);
+            if (lane == 0) {
+                if (tile_counts) tile_counts[li] = cnt;
+                tile_code[li] = cnt == 0 ? CODE_NONE : (cnt == 1 ? first : CODE_MULTI);
+            }
+            hits += cnt;
+        }
+        if (h.stats && lane == 0) atomicAdd(&h.stats[2], (unsigned long long)n_rare);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next tile overwrites the list)
+        __builtin_amdgcn_wave_barrier();
+    }
     if (lane == 0) {
         h.block_tot[tile] = hits;
         if (hits) atomicAdd(&h.super_tot[tile >> PIP_SUPER_SHIFT], hits);  // integer adds: order-independent
@@ -1188,81 +1292,6 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_route_kernel(ChainHot h)
     __syncthreads();
     for (int64_t tile = (int64_t)blockIdx.x * (ROUTE_BLOCK / 64) + (threadIdx.x >> 6); tile < h.n_tiles; tile += stride)
         chain_tile_any<ROUTE_PPT, true>(h, s_mask, s_rec0, s_items[threadIdx.x >> 6], tile, lane);
-}
-
-// The deferred points of a chain / route launch, decided by the generic walk (directory candidates -> full ring walks with
-// the exact orientation kernel): count, code and the two levels of totals are corrected before pip_write reads them.  One WAVE
-// per deferred row, its lanes striding over the candidate's ring edges (a row then costs a handful of dependent loads, not one
-// per edge): real data defers a handful of rows, and the launch exists so that the tile kernels need none of this code.
-__global__ __launch_bounds__(256) void pip_fixup_kernel(DevGeo pts, DevGeo polys, IndexView ix, const uint32_t* __restrict__ defer_count,
-                                                        const uint32_t* __restrict__ defer_list, int tile_points, uint32_t* __restrict__ counts,
-                                                        uint32_t* __restrict__ code, unsigned long long* __restrict__ block_tot,
-                                                        unsigned long long* __restrict__ super_tot, unsigned long long* __restrict__ stats) {
-    const uint32_t nd = *defer_count;
-    if (nd == 0u) return;
-    if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[2], (unsigned long long)nd);
-    const int lane = threadIdx.x & 63;
-    const GridParams g = *ix.grid;
-    for (uint32_t e = blockIdx.x * 4u + (threadIdx.x >> 6); e < nd; e += gridDim.x * 4u) {
-        const uint32_t row = defer_list[e];
-        const double2 p = pts.xy[row];
-        uint32_t cnt = 0, first = CODE_NONE;
-        if (p.x == p.x && p.y == p.y) {
-            const int cx = dev::cell_of(p.x, g.x0, g.inv_w, g.gx), cy = dev::cell_of(p.y, g.y0, g.inv_h, g.gy);
-            const int cc = cy * g.gx + cx;
-            for (int q = ix.cell_off[cc]; q < ix.cell_off[cc + 1]; ++q) {  // candidates in ascending id order (uniform across the wave)
-                const int j = ix.items[q];
-                const double4 bb = ix.bbox[j];
-                if (!(p.x >= bb.x && p.x <= bb.z && p.y >= bb.y && p.y <= bb.w) || !dev::valid_row(polys.validity, j)) continue;
-                int p0, p1;
-                dev::geom_parts(polys, j, p0, p1);
-                bool hit = false;
-                for (int part = p0; part < p1 && !hit; ++part) {  // Contains<Point>: strictly inside some member polygon
-                    int r0, r1;
-                    dev::part_rings(polys, part, r0, r1);
-                    int pos = dev::POS_INSIDE;  // position w.r.t. the polygon: exterior first, then the holes
-                    for (int r = r0; r < r1 && pos == dev::POS_INSIDE; ++r) {
-                        const int c0 = polys.ring_off[r], n = polys.ring_off[r + 1] - c0;
-                        int wn = 0, on = 0;
-                        if (n == 1) {
-                            const double2 s0 = polys.xy[c0];
-                            on = (p.x == s0.x && p.y == s0.y) ? 1 : 0;
-                        }
-                        for (int i = lane; i + 1 < n; i += 64) {
-                            const double2 s0 = polys.xy[c0 + i], s1 = polys.xy[c0 + i + 1];
-                            on |= (int)dev::ring_edge(s0.x, s0.y, s1.x, s1.y, p.x, p.y, wn);
-                        }
-#pragma unroll
-                        for (int o = 32; o > 0; o >>= 1) {
-                            wn += __shfl_xor(wn, o, 64);
-                            on |= __shfl_xor(on, o, 64);
-                        }
-                        const int rp = n == 0 ? dev::POS_OUTSIDE : (on ? dev::POS_BOUNDARY : (wn != 0 ? dev::POS_INSIDE : dev::POS_OUTSIDE));
-                        if (r == r0)
-                            pos = rp;  // Outside / OnBoundary of the exterior ends it
-                        else if (rp == dev::POS_BOUNDARY)
-                            pos = dev::POS_BOUNDARY;
-                        else if (rp == dev::POS_INSIDE)
-                            pos = dev::POS_OUTSIDE;  // inside a hole
-                    }
-                    hit = r1 > r0 && pos == dev::POS_INSIDE;
-                }
-                if (hit) {
-                    if (cnt == 0) first = (uint32_t)j;
-                    ++cnt;
-                }
-            }
-        }
-        if (lane == 0) {
-            if (counts) counts[row] = cnt;
-            code[row] = cnt == 0 ? CODE_NONE : (cnt == 1 ? first : CODE_MULTI);
-            if (cnt) {
-                const uint32_t tile = row / (uint32_t)tile_points;
-                atomicAdd(&block_tot[tile], (unsigned long long)cnt);
-                atomicAdd(&super_tot[tile >> PIP_SUPER_SHIFT], (unsigned long long)cnt);
-            }
-        }
-    }
 }
 
 // pip_write: turns the per-point codes into the sorted (l, r) pair list.  Reads 4 bytes per point, writes 8
@@ -1712,7 +1741,7 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         const char* e = getenv("GPK_TILE_KERNEL");
         return e && !strcmp(e, "chain");
     }();
-    const bool chain = right_index->pip.R > 0 && right_index->pip.sub_aux != nullptr;  // (the deferred list lives in the multi-hit pool, see multi_cap)
+    const bool chain = right_index->pip.R > 0 && right_index->pip.sub_aux != nullptr;
     const bool route = chain && !no_route && right_index->pip.route != nullptr && right_index->pip.R <= PIP_ROUTE_RMAX;
     const int tile_points = chain ? 64 * (route ? ROUTE_PPT : CHAIN_PPT) : (lean ? LEAN_TILE : PIP_TILE);
     const int64_t n_blocks = (n + tile_points - 1) / tile_points;
@@ -1721,10 +1750,10 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
     const size_t pairs_bytes = sizeof(uint32_t) * 2 * (size_t)pair_capacity;
     const int64_t n_super = (n_blocks >> PIP_SUPER_SHIFT) + 1;
     const int64_t n_wblocks = (n + PIP_WTILE - 1) / PIP_WTILE;
-    // words in the multi-hit pool — or, for a chain launch (which has no multi-hit rows), in the deferred list: one per left row
-    const uint32_t multi_cap = chain ? (uint32_t)(n > 1024 ? n : 1024) : (uint32_t)(n < (int64_t)0x18000000 ? 2 * n + 1024 : (int64_t)0x30000000);
+    // words in the multi-hit pool (a chain launch has no multi-hit rows in it: a rare row with several hits is CODE_MULTI)
+    const uint32_t multi_cap = chain ? 1024u : (uint32_t)(n < (int64_t)0x18000000 ? 2 * n + 1024 : (int64_t)0x30000000);
     size_t need = align256(counts_bytes + 64) /*code*/ + align256(sizeof(unsigned long long) * (size_t)(n_blocks + n_super + 3)) +
-                  align256(sizeof(uint32_t) * (size_t)multi_cap) + 1024;
+                  align256(sizeof(uint32_t) * (size_t)multi_cap) + align256(sizeof(ChainCold)) + 1024;
     if (host_out && out_counts) need += align256(counts_bytes);
     if (host_out && want_pairs) need += align256(pairs_bytes);
     // scratch of the stream-ordered join: one arena per (calling thread, stream), so that joins a thread enqueues on
@@ -1738,6 +1767,7 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
     unsigned long long* grand = stot + n_super;     // total hits
     uint32_t* multi_top = (uint32_t*)(grand + 1);   // words used in the multi-hit pool (zeroed with the totals)
     uint32_t* multi_pool = (uint32_t*)ws.take(sizeof(uint32_t) * (size_t)multi_cap);
+    ChainCold* cold = (ChainCold*)ws.take(sizeof(ChainCold));
     uint32_t* counts_dev = out_counts ? (host_out ? (uint32_t*)ws.take(counts_bytes) : out_counts) : nullptr;
     uint32_t* pairs_dev = want_pairs ? (host_out ? (uint32_t*)ws.take(pairs_bytes) : out_pairs) : nullptr;
 
@@ -1753,8 +1783,10 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
     } while (0)
 
     unsigned long long* stats = join_stats_buffer();  // nullptr unless gpk_join_stats_enable(1)
-    {
-        const hipError_t me = hipMemsetAsync(stot, 0, sizeof(unsigned long long) * (size_t)(n_super + 2), s);  // (+ grand, multi_top / the deferred count)
+    if (chain) {  // totals zeroed and the rare arm's arguments written by one small launch
+        J_LAUNCH("gpk_join_prep", join_prep_kernel, dim3(1), dim3(256), 0, s, stot, n_super + 2, cold, right->d, right_index->v);
+    } else {
+        const hipError_t me = hipMemsetAsync(stot, 0, sizeof(unsigned long long) * (size_t)(n_super + 2), s);  // (+ grand, multi_top)
         if (me != hipSuccess) return fail(GPK_ERR_DEVICE, "spatial_join: %s", hipGetErrorString(me));
     }
     ChainHot hot;
@@ -1785,8 +1817,7 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         hot.block_tot = btot;
         hot.super_tot = stot;
         hot.stats = stats;
-        hot.defer_count = multi_top;   // (a chain launch has no multi-hit pool: its words and its cursor hold the deferred rows)
-        hot.defer_list = multi_pool;
+        hot.cold = cold;
     }
     if (chain && route) {  // persistent work-groups, one per CU
         const int tiles_per_wg = ROUTE_BLOCK / 64;
@@ -1809,9 +1840,6 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
     else
         J_LAUNCH("gpk_pip_tile_generic", (pip_tile_kernel<false, false>), dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
                  right_index->v, right_index->pip, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top, stats);
-    if (chain)  // the deferred rows (gpk_join.hip: ChainHot) before the writer reads codes and totals
-        J_LAUNCH("gpk_pip_fixup", pip_fixup_kernel, dim3(512), dim3(256), 0, s, left->d, right->d, right_index->v, (const uint32_t*)multi_top,
-                 (const uint32_t*)multi_pool, tile_points, counts_dev, code, btot, stot, stats);
     // the writer also produces the grand total; in count-only mode it runs without a pair buffer
     J_LAUNCH("gpk_pip_write", pip_write_kernel, dim3((unsigned)n_wblocks), dim3(WR_BLOCK), 0, s, left->d, right->d, right_index->v,
              code, btot, stot, (const uint32_t*)multi_pool, n_blocks, tile_points, left_row_base, (uint2*)pairs_dev, pair_capacity, grand, total_out);
