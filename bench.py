@@ -839,6 +839,14 @@ def run_c5(ctx: Ctx) -> None:
     h = int(total.item())
     if h > pairs.shape[0]:
         raise SystemExit(f"bench.py --config c5: {h} pairs exceed the pair buffer")
+    st = (C.c_int64 * 4)()  # what the exact phase did, on one extra untimed join
+    if not args.no_join_stats:
+        lib.gpk_join_stats_enable(1)
+        lib.gpk_join_stats(st, 1)
+        join_pairs_enqueue(pts, right, index, "within", counts, pairs, total, left_row_base=0, stream=stream)
+        lib.gpk_join_stats(st, 1)
+        lib.gpk_join_stats_enable(0)
+        torch.cuda.synchronize()
     # area over ALL multipolygons of the gathered right side, once (what one GPU would do alone)
     area_all = torch.empty(right_buf.n_geoms, dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
@@ -847,6 +855,24 @@ def run_c5(ctx: Ctx) -> None:
         _abi.check(lib.gpk_area(right.handle, area_all.data_ptr(), _abi.MEM_DEVICE, stream))
     torch.cuda.synchronize()
     area_all_ms = (time.perf_counter() - t0) * 1e3 / 3
+    # the same join against an index WITH the per-entry records of its list cells (GPK_INDEX_PIP_FULL): reported, not the headline
+    index_full = None
+    if W == 1 and not args.no_index_variants:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        full = SpatialIndex.from_device(right, stream=stream, full=True)
+        torch.cuda.synchronize()
+        full_build_ms = (time.perf_counter() - t0) * 1e3
+        for _ in range(2):
+            join_pairs_enqueue(pts, right, full, "within", counts, pairs, total, left_row_base=0, stream=stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            join_pairs_enqueue(pts, right, full, "within", counts, pairs, total, left_row_base=0, stream=stream)
+        torch.cuda.synchronize()
+        index_full = {"parts": "GPK_INDEX_BBOX_GRID | GPK_INDEX_PIP | GPK_INDEX_PIP_FULL", "build_ms": full_build_ms, "bytes": full.nbytes(),
+                      "join_ms": (time.perf_counter() - t0) * 1e3 / 5, "pairs_equal_the_default_index": int(total.item()) == h}
+        full.free()
     if ctx.rank != 0:
         ctx.finish()
         return
@@ -863,9 +889,12 @@ def run_c5(ctx: Ctx) -> None:
         "multipolygons": right_host.n_geoms,
         "coordinates": right_host.n_coords,
         "hits_per_step": h,
+        "exact_phase": {"queued_point_part_pairs_per_step": int(st[0]), "edge_tests_per_step": int(st[1])},
         "call": "gpk_spatial_join_async(within) + gpk_area, one stream",
         "index_build_ms": build_ms,
         "index_bytes": index.nbytes(),
+        "index_describe": index.describe(),
+        "index_full_variant": index_full,
         "join_ms_per_step": sum(v for k, v in warm.items() if "pip_" in k),
         "area_ms_per_step": area_ms,
         "area_GBps": area_bytes / (area_ms * 1e-3) / 1e9 if area_ms > 0 else None,
@@ -945,6 +974,7 @@ def main() -> None:
     ap.add_argument("--polygons", type=int, default=1_000_000, help="c4: polygons per side")
     ap.add_argument("--multipolygons", type=int, default=5_000_000, help="c5: right-side multipolygons (all of them on every GPU)")
     ap.add_argument("--rotate", type=int, default=3, help="c2: distinct input/output sets cycled through by the steps (cold inputs)")
+    ap.add_argument("--no-index-variants", action="store_true", help="c5: skip the extra build + joins of the GPK_INDEX_PIP_FULL index")
     ap.add_argument("--parity-rows", type=int, default=300_000, help="random sample of left rows compared with the oracle")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -40,6 +40,7 @@ PRED_WITHIN = 2
 INDEX_BBOX_GRID = 1
 INDEX_PIP = 2
 INDEX_PIP_LIGHT = 4
+INDEX_PIP_FULL = 8
 PREDICATES = {"intersects": PRED_INTERSECTS, "contains": PRED_CONTAINS, "within": PRED_WITHIN}
 
 

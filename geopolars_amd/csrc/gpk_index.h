@@ -127,10 +127,17 @@ struct PipView {
                                      // `record index << 1 | 1` (the record names the part), else `part << 1 | 1`
     const uint32_t* part_geom;       // nullptr for POLYGON arrays (part == geometry)
     const PartInfo* part_info;       // n_parts
+    const float4* part_box;          // per part: its exterior ring's box rounded OUTWARD to f32 (minx, miny, maxx, maxy), or nullptr.
+                                     // Built for indexes whose list cells carry no per-entry records: a point outside the box skips
+                                     // the entry before PartInfo, the slab offsets and the exact walk are touched
     const int32_t* ring_row0;        // row0 | shift << 24 per ring
     const int32_t* ring_slab_base;   // n_rings + 1
     const int32_t* slab_off;         // n_slabs + 1
-    const double4* slab_edges;
+    const double4* slab_edges;       // slab entries as edge copies (32 B each) — small right sides; or nullptr:
+    const int32_t* slab_vidx;        // slab entries as coordinate indices (4 B each): the edge is (slab_xy[v], slab_xy[v + 1]); ~v for the
+                                     // degenerate edge of a one-coordinate ring.  Large right sides: an eighth of the bytes, and consecutive
+                                     // edges of a ring share their vertices' cache lines (pip::slab_edge reads either form)
+    const double2* slab_xy;          // the indexed array's coordinates (slab_vidx form)
 };
 constexpr uint32_t CELL_TAG_EMPTY = 0u, CELL_TAG_SINGLE = 1u, CELL_TAG_LIST = 2u, CELL_TAG_SUB = 3u;
 
@@ -160,7 +167,8 @@ struct gpk_index {
 
 namespace gpk {
 // gpk_pipindex.hip: builds ix->pip for a polygonal array (no-op otherwise).  ix->v must be complete.
-int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, bool list_records = true);
+// list_records_mode: 0 never (GPK_INDEX_PIP_LIGHT), 1 where they pay for themselves (default), 2 always (GPK_INDEX_PIP_FULL)
+int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int list_records_mode = 1);
 // gpk_unary.hip: closed bbox of every coordinate sequence (ring) as AoS double4; NaN for empty ones
 int32_t ring_bboxes(const gpk_geoarray* a, double4* out_dev, hipStream_t s);
 // gpk_unary.hip: one affine matrix per geometry; matrices in `mat_space`, output in `out_space`

@@ -474,6 +474,10 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
                                 continue;
                             }
                         } else {
+                            if (pv.part_box) {  // (closed box of the exterior, rounded outward: outside it = outside the part)
+                                const float4 bb = pv.part_box[part];
+                                if (!(p[k].x >= (double)bb.x && p[k].x <= (double)bb.z && p[k].y >= (double)bb.y && p[k].y <= (double)bb.w)) continue;
+                            }
                             const PartInfo pq = pv.part_info[part];
                             if (!part_slab(pq, fyf[k], a0, a1)) continue;
                             holes = pq.n_rings > 1 ? 0x80000000u : 0u;
@@ -1741,6 +1745,10 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         const char* e = getenv("GPK_TILE_KERNEL");
         return e && !strcmp(e, "chain");
     }();
+    // slabs kept as coordinate indices read the coordinates of the array THIS call names (an index built over another upload of the
+    // same column — SpatialIndex(series) next to the series itself — stays valid after that upload is gone)
+    PipView pvj = right_index->pip;
+    pvj.slab_xy = right->d.xy;
     const bool chain = right_index->pip.R > 0 && right_index->pip.sub_aux != nullptr;
     const bool route = chain && !no_route && right_index->pip.route != nullptr && right_index->pip.R <= PIP_ROUTE_RMAX;
     const int tile_points = chain ? 64 * (route ? ROUTE_PPT : CHAIN_PPT) : (lean ? LEAN_TILE : PIP_TILE);
@@ -1828,18 +1836,18 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
     } else if (chain)
         J_LAUNCH("gpk_pip_tile", pip_tile_chain_kernel, dim3((unsigned)((n_blocks + PIP_BLOCK / 64 - 1) / (PIP_BLOCK / 64))), dim3(PIP_BLOCK), 0, s, hot);
     else if (lean)
-        J_LAUNCH("gpk_pip_tile", pip_tile_lean_kernel, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d, right_index->v, right_index->pip,
+        J_LAUNCH("gpk_pip_tile", pip_tile_lean_kernel, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d, right_index->v, pvj,
                  counts_dev, code, btot, stot, stats);
     else if (right_index->pip.R > 0)
         if (right_index->pip.sub2)
             J_LAUNCH("gpk_pip_tile", (pip_tile_kernel<true, true>), dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
-                     right_index->v, right_index->pip, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top, stats);
+                     right_index->v, pvj, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top, stats);
         else
             J_LAUNCH("gpk_pip_tile", (pip_tile_kernel<true, false>), dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
-                     right_index->v, right_index->pip, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top, stats);
+                     right_index->v, pvj, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top, stats);
     else
         J_LAUNCH("gpk_pip_tile_generic", (pip_tile_kernel<false, false>), dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
-                 right_index->v, right_index->pip, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top, stats);
+                 right_index->v, pvj, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top, stats);
     // the writer also produces the grand total; in count-only mode it runs without a pair buffer
     J_LAUNCH("gpk_pip_write", pip_write_kernel, dim3((unsigned)n_wblocks), dim3(WR_BLOCK), 0, s, left->d, right->d, right_index->v,
              code, btot, stot, (const uint32_t*)multi_pool, n_blocks, tile_points, left_row_base, (uint2*)pairs_dev, pair_capacity, grand, total_out);
@@ -2140,7 +2148,7 @@ int32_t gpk_index_build_ex(const gpk_geoarray* a, int32_t parts, const double* b
     ix->nbytes = (int64_t)(sizeof(double4) * (size_t)n + sizeof(GridParams) + sizeof(int32_t) * (size_t)(n_cells + 1) +
                            sizeof(int32_t) * (size_t)total);
     if (parts & GPK_INDEX_PIP) {
-        const int32_t rc = build_pip_index(a, ix, s, !(parts & GPK_INDEX_PIP_LIGHT));  // raster + slabs for polygonal arrays
+        const int32_t rc = build_pip_index(a, ix, s, (parts & GPK_INDEX_PIP_LIGHT) ? 0 : ((parts & GPK_INDEX_PIP_FULL) ? 2 : 1));  // raster + slabs for polygonal arrays
         if (rc != GPK_OK) {
             gpk_index_free(ix);
             return rc;

@@ -44,6 +44,15 @@ __device__ __forceinline__ bool slab_span_of_raster_row(const PipView& pv, int r
     return e1 > e0;
 }
 
+__device__ __forceinline__ int slab_vertex(int v) { return v < 0 ? ~v : v; }  // coordinate index a slab_vidx entry names
+// slab entry k as an edge (x0, y0, x1, y1): a stored copy, or the two coordinates its index names (PipView::slab_vidx)
+__device__ __forceinline__ double4 slab_edge(const PipView& pv, int k) {
+    if (pv.slab_edges) return pv.slab_edges[k];
+    const int v = pv.slab_vidx[k];
+    const double2 a = pv.slab_xy[v < 0 ? ~v : v], b = pv.slab_xy[v < 0 ? ~v : v + 1];
+    return make_double4(a.x, a.y, b.x, b.y);
+}
+
 // ---- one lane --------------------------------------------------------------------------------
 __device__ inline int ring_pos_single(const PipView& pv, int r, double px, double py, int row) {
     int e0, e1;
@@ -51,7 +60,7 @@ __device__ inline int ring_pos_single(const PipView& pv, int r, double px, doubl
     int wn = 0;
     bool on = false;
     for (int k = e0; k < e1; ++k) {
-        const double4 ed = pv.slab_edges[k];
+        const double4 ed = slab_edge(pv, k);
         on |= dev::ring_edge(ed.x, ed.y, ed.z, ed.w, px, py, wn);
     }
     if (on) return dev::POS_BOUNDARY;
@@ -83,7 +92,7 @@ __device__ __forceinline__ int ring_pos_group(const PipView& pv, int r, double p
     if (!slab_range(pv, r, row, e0, e1)) return dev::POS_OUTSIDE;
     int wn = 0, on = 0;
     for (int k = e0 + lane; k < e1; k += GS) {
-        const double4 ed = pv.slab_edges[k];
+        const double4 ed = slab_edge(pv, k);
         on |= (int)dev::ring_edge(ed.x, ed.y, ed.z, ed.w, px, py, wn);
     }
     {  // one packed reduction: winding sum in the high half, on-boundary count in the low half
@@ -101,7 +110,7 @@ __device__ __forceinline__ int part_pos_group_from_edges(const PipView& pv, cons
                                                          double px, double py, int lane) {
     int wn = 0, on = 0;
     for (int k = lane; k < cnt; k += GS) {
-        const double4 ed = pv.slab_edges[e0 + k];
+        const double4 ed = slab_edge(pv, e0 + k);
         on |= (int)dev::ring_edge(ed.x, ed.y, ed.z, ed.w, px, py, wn);
     }
     {  // one packed reduction: winding sum in the high half, on-boundary count in the low half

@@ -65,6 +65,28 @@ __global__ void part_info_kernel(DevGeo a, int64_t n_parts, const int32_t* __res
     info[p] = pi;
 }
 
+__global__ void part_box_kernel(DevGeo a, int64_t n_parts, const double4* __restrict__ ring_bbox, float4* __restrict__ box) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_parts) return;
+    int r0, r1;
+    dev::part_rings(a, (int)p, r0, r1);
+    const float nan = __builtin_nanf("");
+    float4 b = make_float4(nan, nan, nan, nan);  // no exterior / empty exterior: no point is inside
+    if (r1 > r0) {
+        const double4 d = ring_bbox[r0];
+        auto down = [](double v) {
+            float f = (float)v;
+            return (double)f > v ? nextafterf(f, -INFINITY) : f;
+        };
+        auto up = [](double v) {
+            float f = (float)v;
+            return (double)f < v ? nextafterf(f, INFINITY) : f;
+        };
+        b = make_float4(down(d.x), down(d.y), up(d.z), up(d.w));
+    }
+    box[p] = b;
+}
+
 // Slab rows of every ring.  f = the FINEST row grid (R * PIP_SLAB_MUL << PIP_FINE_LOG2 rows).  The ring's shift is the
 // smallest one (up to max_shift) that brings the expected slab — edges / rows, exact for a ring whose edges are short
 // against a row — down to SLAB_TARGET edges.
@@ -124,7 +146,8 @@ template <bool FILL>
 __global__ void slab_register_kernel(DevGeo a, FineGrid f, const int32_t* __restrict__ row0,
                                      const int32_t* __restrict__ slab_base, int32_t* __restrict__ cnt_or_cursor,
                                      double4* __restrict__ edges, int32_t* __restrict__ vidx = nullptr) {
-    // vidx (optional, FILL only): the coordinate index every slab entry's edge starts at (build-time only: chain_aux_kernel)
+    // vidx (optional, FILL only): the coordinate index every slab entry's edge starts at (chain_aux_kernel; PipView::slab_vidx when the
+    // index keeps no edge copies: `edges` is nullptr then)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n_coords) return;
     int r;
@@ -136,12 +159,13 @@ __global__ void slab_register_kernel(DevGeo a, FineGrid f, const int32_t* __rest
     const int rr = row0[r];
     const int down = PIP_FINE_LOG2 - slab_shift_of(rr);  // f is the finest row grid
     const int j0 = frow(f, ylo) >> down, j1 = frow(f, yhi) >> down;
+    const bool degenerate = FILL && a.ring_off[r + 1] - a.ring_off[r] == 1;  // edge_at: (s, s) of a one-coordinate ring
     for (int j = j0; j <= j1; ++j) {
         const int sl = slab_base[r] + (j - slab_row0_of(rr));
         const int slot = atomicAdd(&cnt_or_cursor[sl], 1);
         if (FILL) {
-            edges[slot] = make_double4(s.x, s.y, e.x, e.y);
-            if (vidx) vidx[slot] = (int32_t)i;
+            if (edges) edges[slot] = make_double4(s.x, s.y, e.x, e.y);
+            if (vidx) vidx[slot] = degenerate ? ~(int32_t)i : (int32_t)i;
         }
     }
 }
@@ -318,6 +342,41 @@ __global__ void sub_flag_kernel(const uint32_t* __restrict__ cell, const uint32_
     flag2[c] = f2;
 }
 
+// exterior slabs of a cell's PIP_SLAB_MUL (= 2) base slab rows are adjacent in slab_off: [e0,e1) and [e1,e2); a part
+// whose exterior has refined rows has more than two per cell: its record says SUB_INDIRECT and the join kernel goes
+// through PartInfo for it.  (cj = raster row of the cell)
+__device__ __forceinline__ void record_slabs(const PipView& pv, int p, int cj, uint32_t& flags, uint32_t& e0, uint32_t& e1, uint32_t& e2) {
+    const PartInfo pi = pv.part_info[p];
+    e0 = e1 = e2 = 0;
+    flags = (uint32_t)p | (pi.n_rings > 1 ? 0x80000000u : 0u);
+    if (slab_shift_of(pi.row0) != 0) {
+        flags |= SUB_INDIRECT;
+        return;
+    }
+    const int j0 = PIP_SLAB_MUL * cj - slab_row0_of(pi.row0), j1 = j0 + 1;
+    const bool lo_ok = j0 >= 0 && j0 < pi.nrows, hi_ok = j1 >= 0 && j1 < pi.nrows;
+    if (lo_ok) {
+        e0 = (uint32_t)pv.slab_off[pi.slab_base + j0];
+        e1 = (uint32_t)pv.slab_off[pi.slab_base + j0 + 1];
+        e2 = e1;
+    }
+    if (hi_ok) {
+        if (!lo_ok) e0 = e1 = (uint32_t)pv.slab_off[pi.slab_base + j1];
+        e2 = (uint32_t)pv.slab_off[pi.slab_base + j1 + 1];
+    }
+}
+// The head of every work item's record (part word + the exterior's slab ranges in the cell's raster row), one LANE per item: the
+// five dependent gathers behind it (part -> PartInfo -> slab offsets) run 64 to a wave here instead of one to a wave at the top of
+// sub_build_kernel, whose waves then start from their record head (see its fast path).
+__global__ void sub_head_kernel(PipView pv, FineGrid g, const int32_t* __restrict__ work_cell, const uint32_t* __restrict__ work_part,
+                                int64_t n_work, SubCell* __restrict__ sub) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_work) return;
+    uint32_t flags, e0, e1, e2;
+    record_slabs(pv, (int)work_part[i], (int)(work_cell[i] / g.R), flags, e0, e1, e2);
+    *reinterpret_cast<uint4*>(&sub[i].part_flags) = make_uint4(flags, e0, e1, e2);
+}
+
 // PIP_SUB^2 lanes per flagged cell: lane k labels sub-cell (k % PIP_SUB, k / PIP_SUB).  A sub-cell is "test
 // exactly" when any edge of ANY ring of a part that crosses the cell (taken from the rings' slabs of this raster row)
 // is not strictly on one side of the sub-cell's padded rectangle; otherwise it inherits the exact position of its
@@ -361,10 +420,71 @@ __global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, Fi
     // LDS list — then every lane tests only those few against its own sub-cell (a slab row holds every edge of the ring
     // that crosses the row anywhere in x; a cell sees one to three of them).
     __shared__ double4 s_edges[256 / 64][SUB_EDGE_CAP];
+    __shared__ double4 s_edges_all[WORK ? 256 / 64 : 1][WORK ? 64 : 1];  // fast path: every edge of the part in this raster row
     const int wave = threadIdx.x >> 6, lane64 = threadIdx.x & 63;
     // the cell = the union of its padded sub-cells, written with the very expressions the corner lanes use below
     const double cxl = g.rx0 + (double)(S * ci) * fw2 - px2, cxh = g.rx0 + (double)(S * ci + S) * fw2 + px2;
     const double cyl = g.ry0 + (double)(S * cj) * fh2 - py2, cyh = g.ry0 + (double)(S * cj + S) * fh2 + py2;
+    auto edge_touches = [&](const double4 ed) {
+        // cheap reject: edge bbox vs padded rectangle (closed)
+        if (fmax(ed.x, ed.z) < xl || fmin(ed.x, ed.z) > xh || fmax(ed.y, ed.w) < yl || fmin(ed.y, ed.w) > yh) return false;
+        const int o1 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yl);
+        const int o2 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yl);
+        const int o3 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yh);
+        const int o4 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yh);
+        const bool all_pos = o1 > 0 && o2 > 0 && o3 > 0 && o4 > 0;
+        const bool all_neg = o1 < 0 && o2 < 0 && o3 < 0 && o4 < 0;
+        return !(all_pos || all_neg);
+    };
+    // the record's labels from the two ballots (low / high label bit): lanes 0..3 interleave their 16 sub-cells' bits into one word
+    // each and store it — 64 global atomics on four addresses per record were most of this kernel's time
+    auto store_labels = [&](SubCell* rec, uint32_t label) {
+        const unsigned long long lo = __ballot((label & 1u) != 0), hi = __ballot((label & 2u) != 0);
+        if (k < 4) {
+            auto spread16 = [](uint32_t x) {
+                x = (x | (x << 8)) & 0x00FF00FFu;
+                x = (x | (x << 4)) & 0x0F0F0F0Fu;
+                x = (x | (x << 2)) & 0x33333333u;
+                x = (x | (x << 1)) & 0x55555555u;
+                return x;
+            };
+            rec->labels[k] = spread16((uint32_t)(lo >> (16 * k)) & 0xFFFFu) | (spread16((uint32_t)(hi >> (16 * k)) & 0xFFFFu) << 1);
+        }
+    };
+    if (WORK) {
+        // Fast path (sub_head_kernel wrote the record head): a one-ring part without refined rows has ALL its edges of this raster row
+        // in [e0, e2) — lower base slab row [e0, e1), upper [e1, e2).  One load per lane stages them in LDS; the touch test and the
+        // centre's winding walk (its slab row is the lower or the upper one: sub-rows 0..3 / 4..7, as the join kernel picks it) both
+        // run from there.  Two dependent loads per record instead of nine.
+        const uint4 head = *reinterpret_cast<const uint4*>(&sub[item].part_flags);
+        const uint32_t n_all = head.w - head.y;
+        if (!(head.x & (SUB_INDIRECT | 0x80000000u)) && n_all <= 64u) {
+            if ((uint32_t)lane64 < n_all) s_edges_all[wave][lane64] = pip::slab_edge(pv, (int)(head.y + (uint32_t)lane64));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            bool touched = false;
+            for (uint32_t e = 0; e < n_all && !touched; ++e) touched = edge_touches(s_edges_all[wave][e]);
+            uint32_t label = 2u;
+            if (!touched) {
+                const double cx = g.rx0 + ((double)si + 0.5) * fw2, cy = g.ry0 + ((double)sj + 0.5) * fh2;
+                const bool ok = dev::cell_of(cx, g.rx0, g.inv_fw * S, g.R * S) == si && dev::cell_of(cy, g.ry0, g.inv_fh * S, g.R * S) == sj;
+                if (ok) {
+                    const uint32_t mid = head.z - head.y;
+                    const uint32_t a0 = (k / S) >= S / 2 ? mid : 0u, a1 = (k / S) >= S / 2 ? n_all : mid;
+                    int wn = 0;
+                    bool on = false;
+                    for (uint32_t e = a0; e < a1; ++e) {
+                        const double4 ed = s_edges_all[wave][e];
+                        on |= dev::ring_edge(ed.x, ed.y, ed.z, ed.w, cx, cy, wn);
+                    }
+                    label = on ? 2u : (wn != 0 ? 1u : 0u);
+                }
+            }
+            store_labels(sub + item, label);
+            return;
+        }
+    }
     int n_list = 0;         // wave-uniform
     bool list_ok = true;    // false: more than SUB_EDGE_CAP edges meet the cell -> every lane walks the slabs itself
 
@@ -380,7 +500,7 @@ __global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, Fi
                 bool keep = false;
                 double4 ed = make_double4(0, 0, 0, 0);
                 if (e < e1) {
-                    ed = pv.slab_edges[e];
+                    ed = pip::slab_edge(pv, e);
                     keep = !(fmax(ed.x, ed.z) < cxl || fmin(ed.x, ed.z) > cxh || fmax(ed.y, ed.w) < cyl || fmin(ed.y, ed.w) > cyh);
                 }
                 const unsigned long long m = __ballot(keep);
@@ -397,17 +517,6 @@ __global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, Fi
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    auto edge_touches = [&](const double4 ed) {
-        // cheap reject: edge bbox vs padded rectangle (closed)
-        if (fmax(ed.x, ed.z) < xl || fmin(ed.x, ed.z) > xh || fmax(ed.y, ed.w) < yl || fmin(ed.y, ed.w) > yh) return false;
-        const int o1 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yl);
-        const int o2 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yl);
-        const int o3 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yh);
-        const int o4 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yh);
-        const bool all_pos = o1 > 0 && o2 > 0 && o3 > 0 && o4 > 0;
-        const bool all_neg = o1 < 0 && o2 < 0 && o3 < 0 && o4 < 0;
-        return !(all_pos || all_neg);
-    };
     bool touched = false;
     if (list_ok) {
         for (int e = 0; e < n_list && !touched; ++e) touched = edge_touches(s_edges[wave][e]);
@@ -419,7 +528,7 @@ __global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, Fi
             for (int r = r0; r < r1 && !touched; ++r) {
                 int e0, e1;
                 if (!pip::slab_span_of_raster_row(pv, r, cj, e0, e1)) continue;
-                for (int e = e0; e < e1 && !touched; ++e) touched = edge_touches(pv.slab_edges[e]);
+                for (int e = e0; e < e1 && !touched; ++e) touched = edge_touches(pip::slab_edge(pv, e));
             }
         }
     }
@@ -444,29 +553,7 @@ __global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, Fi
             }
         }
     }
-    // exterior slabs of the cell's PIP_SLAB_MUL (= 2) base slab rows are adjacent in slab_off: [e0,e1) and [e1,e2); a part
-    // whose exterior has refined rows has more than two per cell: its record says SUB_INDIRECT and the join kernel goes
-    // through PartInfo for it
-    auto slabs_of = [&](int p, uint32_t& flags, uint32_t& e0, uint32_t& e1, uint32_t& e2) {
-        const PartInfo pi = pv.part_info[p];
-        e0 = e1 = e2 = 0;
-        flags = (uint32_t)p | (pi.n_rings > 1 ? 0x80000000u : 0u);
-        if (slab_shift_of(pi.row0) != 0) {
-            flags |= SUB_INDIRECT;
-            return;
-        }
-        const int j0 = PIP_SLAB_MUL * cj - slab_row0_of(pi.row0), j1 = j0 + 1;
-        const bool lo_ok = j0 >= 0 && j0 < pi.nrows, hi_ok = j1 >= 0 && j1 < pi.nrows;
-        if (lo_ok) {
-            e0 = (uint32_t)pv.slab_off[pi.slab_base + j0];
-            e1 = (uint32_t)pv.slab_off[pi.slab_base + j0 + 1];
-            e2 = e1;
-        }
-        if (hi_ok) {
-            if (!lo_ok) e0 = e1 = (uint32_t)pv.slab_off[pi.slab_base + j1];
-            e2 = (uint32_t)pv.slab_off[pi.slab_base + j1 + 1];
-        }
-    };
+    auto slabs_of = [&](int p, uint32_t& flags, uint32_t& e0, uint32_t& e1, uint32_t& e2) { record_slabs(pv, p, cj, flags, e0, e1, e2); };
     SubCell* rec = WORK ? sub + item : (NP == 1 ? sub + pos[c] : &sub2[pos[c]].a);
     if (k == 0) {
         slabs_of(part[0], rec->part_flags, rec->e0, rec->e1, rec->e2);
@@ -475,19 +562,7 @@ __global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, Fi
             slabs_of(part[1], r2->b_part_flags, r2->b_e0, r2->b_e1, r2->b_e2);
         }
     }
-    // the 64 labels of the record: two ballots (low / high label bit), lanes 0..3 interleave their 16 sub-cells' bits into one
-    // word each and store it — 64 global atomics on four addresses per record were most of this kernel's time
-    const unsigned long long lo = __ballot((label & 1u) != 0), hi = __ballot((label & 2u) != 0);
-    if (k < 4) {
-        auto spread16 = [](uint32_t x) {
-            x = (x | (x << 8)) & 0x00FF00FFu;
-            x = (x | (x << 4)) & 0x0F0F0F0Fu;
-            x = (x | (x << 2)) & 0x33333333u;
-            x = (x | (x << 1)) & 0x55555555u;
-            return x;
-        };
-        rec->labels[k] = spread16((uint32_t)(lo >> (16 * k)) & 0xFFFFu) | (spread16((uint32_t)(hi >> (16 * k)) & 0xFFFFu) << 1);
-    }
+    store_labels(rec, label);
 }
 __global__ void sub_commit_kernel(const int32_t* __restrict__ flag, const int32_t* __restrict__ pos, const int32_t* __restrict__ flag2,
                                   const int32_t* __restrict__ pos2, int64_t n_cells, uint32_t* __restrict__ cell) {
@@ -574,7 +649,7 @@ __global__ __launch_bounds__(256) void chain_aux_kernel(DevGeo a, PipView pv, Fi
                 bool keep = false;
                 double4 ed = make_double4(0, 0, 0, 0);
                 if (e < e1) {
-                    ed = pv.slab_edges[e];
+                    ed = pip::slab_edge(pv, e);
                     keep = !(fmax(ed.x, ed.z) < cxl || fmin(ed.x, ed.z) > cxh || fmax(ed.y, ed.w) < cyl || fmin(ed.y, ed.w) > cyh);
                 }
                 const unsigned long long m = __ballot(keep);
@@ -586,7 +661,7 @@ __global__ __launch_bounds__(256) void chain_aux_kernel(DevGeo a, PipView pv, Fi
                 if (keep) {
                     const int at = n_list + __popcll(m & ((1ull << lane64) - 1ull));
                     s_edges[wave][at] = ed;
-                    s_vidx[wave][at] = slab_vidx[e];
+                    s_vidx[wave][at] = pip::slab_vertex(slab_vidx[e]);
                 }
                 n_list += add;
             }
@@ -664,10 +739,10 @@ __global__ __launch_bounds__(256) void chain_aux_kernel(DevGeo a, PipView pv, Fi
             bool on = false;
             if (pip::slab_range(pv, r0, pip::row_of(pv, cy), e0, e1)) {
                 for (int e = e0; e < e1; ++e) {
-                    int d = slab_vidx[e] - c0 - lo;
+                    int d = pip::slab_vertex(slab_vidx[e]) - c0 - lo;
                     if (d < 0) d += ne;
                     if (d < len) continue;  // an edge of the arc
-                    const double4 ed = pv.slab_edges[e];
+                    const double4 ed = pip::slab_edge(pv, e);
                     on |= dev::ring_edge(ed.x, ed.y, ed.z, ed.w, cx, cy, wn);
                 }
             }
@@ -804,7 +879,7 @@ inline dim3 blocks_for(int64_t n) { return dim3((unsigned)((n + 255) / 256 > 0 ?
 
 namespace gpk {
 
-int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, bool list_records) {
+int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int list_records_mode) {
     memset(&ix->pip, 0, sizeof ix->pip);
     const DevGeo& d = a->d;
     if (!is_polygonal(d.type) || d.n_geoms == 0 || d.n_coords == 0 || d.n_rings == 0) return GPK_OK;
@@ -818,6 +893,17 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, boo
         if (v >= 64 && v <= 4096 && (v & (v - 1)) == 0) r_max = v;
     }
     while (R < r_max && (double)R < 2.0 * sqrt((double)d.n_coords)) R <<= 1;
+    // a column of MANY small parts (C5: 6.5M parts of 5M multipolygons) puts 1.5 parts into every cell of the 2048 raster and every
+    // point walks an entry list; one more doubling: tile 1.91 -> 1.54 ms, level-1 words 16 -> 64 MB
+    // At that resolution the per-entry records of the remaining list cells (29M of them for C5) cost 97 ms of a 215 ms build to
+    // take 2.03 -> 1.57 ms per 6.25M-point join: they are built on request only (GPK_INDEX_PIP_FULL), the entry lists get part boxes
+    bool many_parts = false;
+    if (!getenv("GPK_PIP_RMAX") && R == 2048 && d.n_parts > (int64_t)R * R / 2) {
+        R = 4096;
+        many_parts = true;
+    }
+    bool list_records = list_records_mode == 2 || (list_records_mode == 1 && !many_parts);
+    if (const char* e = getenv("GPK_LIST_RECORDS")) list_records = atoi(e) != 0;  // tuning knob
     FineGrid g;
     g.R = R;
     g.fw = w / (double)(R - 3);
@@ -929,11 +1015,21 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, boo
         if (max_shift == 0 || (int64_t)n_edges <= 8 * d.n_coords + (1 << 20)) break;
     }
     stamp("slab rows + counts");
+    // slab entries: 32-byte edge copies for small right sides (one load level in the exact walk), 4-byte coordinate indices beyond
+    // GPK_SLAB_COPY_MAX_MB (default 256) of copies — the copies of a 144M-coordinate column were 5 of its index's 6.4 GB
     double4* edges = nullptr;
-    GPK_HIP(hipMalloc((void**)&edges, sizeof(double4) * (size_t)(n_edges ? n_edges : 1)));
-    keep(edges);
-    int32_t* slab_vidx = nullptr;  // build-time only: where every slab entry's edge starts (chains of lean indexes)
-    if ((int64_t)n_edges <= ((int64_t)64 << 20)) GPK_TRY(t.alloc(&slab_vidx, (size_t)(n_edges ? n_edges : 1)));
+    int32_t* slab_vidx = nullptr;  // also read by the chain build of lean indexes
+    size_t copy_max = size_t(256) << 20;
+    if (const char* e = getenv("GPK_SLAB_COPY_MAX_MB")) copy_max = (size_t)atoll(e) << 20;
+    const bool edge_copies = sizeof(double4) * (size_t)n_edges <= copy_max;
+    if (edge_copies) {
+        GPK_HIP(hipMalloc((void**)&edges, sizeof(double4) * (size_t)(n_edges ? n_edges : 1)));
+        keep(edges);
+        if ((int64_t)n_edges <= ((int64_t)64 << 20)) GPK_TRY(t.alloc(&slab_vidx, (size_t)(n_edges ? n_edges : 1)));
+    } else {
+        GPK_HIP(hipMalloc((void**)&slab_vidx, sizeof(int32_t) * (size_t)n_edges));
+        keep(slab_vidx);
+    }
     GPK_LAUNCH("gpk_pipidx_slab_fill", slab_register_kernel<true>, blocks_for(d.n_coords), dim3(256), 0, s, d, gs, row0, slab_base,
                cursor, edges, slab_vidx);
 
@@ -958,6 +1054,8 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, boo
     pv.ring_slab_base = slab_base;
     pv.slab_off = slab_off;
     pv.slab_edges = edges;
+    pv.slab_vidx = edge_copies ? nullptr : slab_vidx;
+    pv.slab_xy = d.xy;
 
     stamp("part info");
     // ---- boundary marks: (cell, part) keys, sorted + unique ---------------------------------------
@@ -1065,6 +1163,8 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, boo
             GPK_TRY(t.alloc(&swork_part, (size_t)n_sub));
             GPK_LAUNCH("gpk_pipidx_sub_work", sub_work_kernel, blocks_for(n_cells), dim3(256), 0, s, (const uint32_t*)cell, (const int32_t*)sflag,
                        (const int32_t*)spos, n_cells, swork_cell, swork_part);
+            GPK_LAUNCH("gpk_pipidx_sub_head", sub_head_kernel, blocks_for(n_sub), dim3(256), 0, s, pv, g, (const int32_t*)swork_cell,
+                       (const uint32_t*)swork_part, (int64_t)n_sub, sub);
             GPK_LAUNCH("gpk_pipidx_sub_build", (sub_build_kernel<1, true>), blocks_for((int64_t)n_sub * PIP_SUB * PIP_SUB), dim3(256), 0, s, d, pv, g,
                        (const int32_t*)nullptr, (const int32_t*)nullptr, n_cells, (const uint32_t*)cell, (const uint32_t*)list, sub, (SubCell2*)nullptr,
                        (const int32_t*)swork_cell, (const uint32_t*)swork_part, (int64_t)n_sub);
@@ -1108,6 +1208,8 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, boo
             GPK_HIP(hipMemsetAsync(lrec, 0, sizeof(SubCell) * (size_t)n_lrec, s));
             GPK_LAUNCH("gpk_pipidx_lrec_assign", lrec_assign_kernel, blocks_for(n_cells), dim3(256), 0, s, (const uint32_t*)cell, list, n_cells,
                        (const int32_t*)lpos, work_cell, work_part);
+            GPK_LAUNCH("gpk_pipidx_lrec_head", sub_head_kernel, blocks_for(n_lrec), dim3(256), 0, s, pv, g, (const int32_t*)work_cell,
+                       (const uint32_t*)work_part, (int64_t)n_lrec, lrec);
             GPK_LAUNCH("gpk_pipidx_lrec_build", (sub_build_kernel<1, true>), blocks_for((int64_t)n_lrec * PIP_SUB * PIP_SUB), dim3(256), 0, s, d, pv, g,
                        (const int32_t*)nullptr, (const int32_t*)nullptr, n_cells, (const uint32_t*)cell, (const uint32_t*)list, lrec, (SubCell2*)nullptr,
                        (const int32_t*)work_cell, (const uint32_t*)work_part, (int64_t)n_lrec);
@@ -1118,6 +1220,14 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, boo
     }
     stamp("list-cell records");
     pv.lrec = lrec;
+    if (list_len > 0 && !lrec && !getenv("GPK_NO_PART_BOX")) {  // plain entry lists: a box per part rejects most (point, entry) pairs early
+        float4* part_box = nullptr;
+        GPK_HIP(hipMalloc((void**)&part_box, sizeof(float4) * (size_t)(n_parts ? n_parts : 1)));
+        keep(part_box);
+        GPK_LAUNCH("gpk_pipidx_part_box", part_box_kernel, blocks_for(n_parts), dim3(256), 0, s, d, n_parts, (const double4*)ring_bbox, part_box);
+        pv.part_box = part_box;
+        ix->nbytes += (int64_t)(sizeof(float4) * (size_t)n_parts);
+    }
     // (Nearly) every cell is empty / strictly inside one part / crossed by one part with an inline level-2 record: a point has
     // one candidate part and the join runs its lean kernel (gpk_join.hip: pip_tile_lean_kernel).  Disjoint polygons
     // (parcels, the C2 right side) look like this; overlaps, shared borders and refined rings keep the general kernel.
@@ -1187,7 +1297,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, boo
     }
     ix->nbytes += (int64_t)(sizeof(SubCell) * (size_t)n_sub + sizeof(SubCell2) * (size_t)n_sub2 + sizeof(SubCell) * (size_t)n_lrec);
     ix->pip = pv;
-    ix->nbytes += (int64_t)(sizeof(uint32_t) * (size_t)n_cells + sizeof(uint32_t) * (size_t)list_len + sizeof(double4) * (size_t)n_edges +
+    ix->nbytes += (int64_t)(sizeof(uint32_t) * (size_t)n_cells + sizeof(uint32_t) * (size_t)list_len + (pv.slab_edges ? sizeof(double4) : sizeof(int32_t)) * (size_t)n_edges +
                             sizeof(int32_t) * (size_t)(n_slabs + 1) + sizeof(int32_t) * (size_t)(2 * n_rings + 1) +
                             (part_geom ? sizeof(uint32_t) * (size_t)n_parts : 0) + sizeof(PartInfo) * (size_t)n_parts);
     return GPK_OK;

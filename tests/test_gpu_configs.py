@@ -173,3 +173,50 @@ def test_c5_scale_sampled(gpk, oracle):
     _check_join_sample(oracle, pts, mp, "within", pairs, counts, 200_000, 10)
     area, exp = ms.area(), oracle.area(mp)
     assert np.all(np.abs(area - exp) <= 1e-9 * np.maximum(np.abs(exp), 1e-300))
+
+
+# ---- BASELINE.json's FULL sizes, every row against the oracle (OpenMP over rows on the box's host cores) ------------
+def test_c2_full_size_every_row(gpk, oracle):
+    """C2 as quoted: 10M points x 1000 x 64-vertex polygons — counts and pairs of ALL rows equal the oracle's."""
+    polys, pts = synth.star_polygons(1000, 64), synth.uniform_points(10_000_000, seed=12345)
+    ps, qs = GeoSeries(pts), GeoSeries(polys)
+    ix = SpatialIndex(qs)
+    assert ix.describe()["route"] == 1  # the headline path: the routed tile kernel
+    pairs, counts = join_pairs(ps, qs, "intersects", r_index=ix)
+    ep, ec, _ = oracle.spatial_join(pts, polys, "intersects", mode=1)
+    assert np.array_equal(counts, ec)
+    assert np.array_equal(pairs, ep)
+    # size-independent properties: counts sum to the pairs, rows sorted, the answer does not depend on the point order
+    assert int(counts.sum()) == len(pairs) and np.all(np.diff(pairs[:, 0].astype(np.int64)) >= 0)
+    perm = np.random.default_rng(4).permutation(len(pts))
+    p2, c2 = join_pairs(GeoSeries(pts.take(perm)), qs, "intersects", r_index=ix)
+    assert np.array_equal(c2, counts[perm])
+
+
+def test_c3_full_size_every_row(gpk, oracle):
+    """C3 as quoted: 10M points x 100k linestrings (row map i % 100k), all 10M distances within 1e-9 relative."""
+    n, L = 10_000_000, 100_000
+    ls, pts = synth.random_linestrings(L), synth.uniform_points(n, seed=777)
+    rows = (np.arange(n, dtype=np.uint32) % L).astype(np.uint32)
+    got = GeoSeries(pts).distance(GeoSeries(ls), other_rows=rows)
+    exp = oracle.distance_rowwise(pts, ls, rows)
+    rel = np.abs(got - exp) / np.maximum(np.abs(exp), 1e-300)
+    assert np.all((rel <= 1e-9) | (got == exp))  # tolerance of the north star: 1e-9 relative
+    assert np.array_equal(got == 0.0, exp == 0.0)
+
+
+def test_many_small_parts_index_variants(gpk, oracle):
+    """more than two parts per cell of the 2048 raster (2.4M parts): the index takes a 4096 raster, plain entry lists and part
+    boxes; GPK_INDEX_PIP_FULL adds the per-entry records — both answer like the oracle"""
+    mp = synth.powerlaw_multipolygons(1_200_000, seed=61)
+    pts = synth.uniform_points(1_000_000, seed=62)
+    ms, ps = GeoSeries(mp), GeoSeries(pts)
+    ix = SpatialIndex(ms)
+    assert ix.describe()["R"] == 4096
+    pairs, counts = join_pairs(ps, ms, "within", r_index=ix)
+    assert counts.max() >= 2
+    _check_join_sample(oracle, pts, mp, "within", pairs, counts, 100_000, 12)
+    full = SpatialIndex(ms, full=True)
+    p2, c2 = join_pairs(ps, ms, "within", r_index=full)
+    assert np.array_equal(p2, pairs) and np.array_equal(c2, counts)
+    assert full.nbytes() > ix.nbytes()
