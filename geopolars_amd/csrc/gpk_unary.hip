@@ -221,23 +221,49 @@ constexpr int SEQ_LANES[3] = {2, 8, 16};
 constexpr int SEQ_MAXLEN[3] = {16, 128, SEQ_LONG};  // class k takes lengths <= SEQ_MAXLEN[k] (and > SEQ_MAXLEN[k-1])
 __device__ __forceinline__ int seq_class_of(int n) { return n <= SEQ_MAXLEN[0] ? 0 : (n <= SEQ_MAXLEN[1] ? 1 : (n <= SEQ_MAXLEN[2] ? 2 : 3)); }
 
-// FILL = false: counts per class (one atomic per wave and class); FILL = true: ids appended at the class cursors
+// FILL = false: counts per class; FILL = true: ids appended at the class cursors.  A work-group classifies SEQ_CLS_ROUNDS x 256
+// consecutive sequences and touches each class cursor ONCE (one atomic per wave and class put 700k atomics on four addresses for
+// C5's 15M rings: 4.6 ms per pass); inside the group the ids keep their order (round, wave, lane).
+constexpr int SEQ_CLS_ROUNDS = 8;
 template <bool FILL>
 __global__ __launch_bounds__(256) void seq_classify_kernel(const int32_t* __restrict__ seq_off, int64_t n_seq, int32_t* __restrict__ cursor,
                                                             int32_t* __restrict__ lists) {
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int c = s < n_seq ? seq_class_of(seq_off[s + 1] - seq_off[s]) : -1;
-    const int lane = threadIdx.x & 63;
+    __shared__ int32_t s_cnt[SEQ_CLS_ROUNDS * 4][4];  // [round * 4 + wave][class]; after the prefix: the slot's first position
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * (256 * SEQ_CLS_ROUNDS);
+    int cls[SEQ_CLS_ROUNDS];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const unsigned long long m = __ballot(c == k);
-        if (!m) continue;
-        const int leader = __ffsll((long long)m) - 1;
-        int base = 0;
-        if (lane == leader) base = atomicAdd(&cursor[k], __popcll(m));
-        if (FILL) {
-            base = __shfl(base, leader, 64);
-            if (c == k) lists[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)s;
+    for (int r = 0; r < SEQ_CLS_ROUNDS; ++r) {
+        const int64_t s = base + r * 256 + threadIdx.x;
+        cls[r] = s < n_seq ? seq_class_of(seq_off[s + 1] - seq_off[s]) : -1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned long long m = __ballot(cls[r] == k);
+            if (lane == 0) s_cnt[r * 4 + wave][k] = __popcll(m);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {  // class k: exclusive prefix over the (round, wave) slots, one atomic for the group's total
+        const int k = threadIdx.x;
+        int total = 0;
+        for (int i = 0; i < SEQ_CLS_ROUNDS * 4; ++i) {
+            const int c = s_cnt[i][k];
+            s_cnt[i][k] = total;
+            total += c;
+        }
+        const int at = total ? atomicAdd(&cursor[k], total) : 0;
+        if (FILL)
+            for (int i = 0; i < SEQ_CLS_ROUNDS * 4; ++i) s_cnt[i][k] += at;
+    }
+    if (!FILL) return;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SEQ_CLS_ROUNDS; ++r) {
+        const int c = cls[r];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned long long mk = __ballot(c == k);
+            if (c == k) lists[s_cnt[r * 4 + wave][k] + __popcll(mk & ((1ull << lane) - 1ull))] = (int32_t)(base + r * 256 + threadIdx.x);
         }
     }
 }
@@ -942,7 +968,8 @@ static int32_t seq_classes_of(const gpk_geoarray* a, hipStream_t s, const gpk_se
         int32_t h[4] = {0, 0, 0, 0};
         auto run = [&]() -> int32_t {
             GPK_HIP(hipMemsetAsync(cursor, 0, 4 * sizeof(int32_t), s));
-            GPK_LAUNCH("gpk_seq_classify", seq_classify_kernel<false>, dim3((unsigned)((n_seq + 255) / 256)), dim3(256), 0, s, seq_off, n_seq, cursor,
+            const unsigned cls_blocks = (unsigned)((n_seq + 256 * SEQ_CLS_ROUNDS - 1) / (256 * SEQ_CLS_ROUNDS));
+            GPK_LAUNCH("gpk_seq_classify", seq_classify_kernel<false>, dim3(cls_blocks), dim3(256), 0, s, seq_off, n_seq, cursor,
                        (int32_t*)nullptr);
             GPK_HIP(hipMemcpyAsync(h, cursor, sizeof h, hipMemcpyDeviceToHost, s));
             GPK_HIP(hipStreamSynchronize(s));
@@ -958,7 +985,7 @@ static int32_t seq_classes_of(const gpk_geoarray* a, hipStream_t s, const gpk_se
             GPK_HIP(hipMalloc((void**)&c->lists, sizeof(int32_t) * (size_t)n_seq));
             int32_t b32[4] = {(int32_t)c->begin[0], (int32_t)c->begin[1], (int32_t)c->begin[2], (int32_t)c->begin[3]};
             GPK_HIP(hipMemcpyAsync(cursor, b32, sizeof b32, hipMemcpyHostToDevice, s));
-            GPK_LAUNCH("gpk_seq_classify", seq_classify_kernel<true>, dim3((unsigned)((n_seq + 255) / 256)), dim3(256), 0, s, seq_off, n_seq, cursor,
+            GPK_LAUNCH("gpk_seq_classify", seq_classify_kernel<true>, dim3(cls_blocks), dim3(256), 0, s, seq_off, n_seq, cursor,
                        c->lists);
             GPK_HIP(hipStreamSynchronize(s));
             return GPK_OK;
