@@ -1469,6 +1469,49 @@ __global__ __launch_bounds__(256) void bbox_cand_kernel(DevGeo left, DevGeo righ
     for (int a = 0; a < cnt; ++a) cand_l[o0 + a] = (uint32_t)i;  // left row of every candidate: the refine reads it directly
 }
 
+// One search instead of two for ordinary rows: the count pass also leaves each row's first CAND_STAGE candidates (sorted) in a padded
+// staging slice; when no row has more (nearly every join: rows have a handful), cand_compact_kernel moves the slices to their scanned
+// offsets and the second directory walk (bbox_cand_kernel<true>: 0.90 ms of the 6.1 ms C4 join) does not run.
+constexpr int CAND_STAGE = 16;
+static_assert(CAND_STAGE <= CAND_INLINE_SORT, "a staged row is one that the fill pass would have sorted inline");
+__global__ __launch_bounds__(256) void bbox_cand_stage_kernel(DevGeo left, DevGeo right, IndexView ix, const double4* __restrict__ lbbox,
+                                                               int32_t* __restrict__ cand_cnt, uint32_t* __restrict__ stage,
+                                                               int32_t* __restrict__ flags /* [0]: big rows, [1]: rows beyond CAND_STAGE */) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= left.n_geoms) return;
+    int cnt = 0;
+    uint32_t* mine = stage + i * CAND_STAGE;
+    if (dev::valid_row(left.validity, i)) {
+        const GridParams g = *ix.grid;
+        for_each_bbox_candidate(ix, g, lbbox[i], [&](int j) {
+            if (!dev::valid_row(right.validity, j)) return;
+            if (cnt < CAND_STAGE) {  // insertion into the ascending prefix (a handful of entries in the thread's own 64-byte line)
+                int b = cnt - 1;
+                while (b >= 0 && mine[b] > (uint32_t)j) {
+                    mine[b + 1] = mine[b];
+                    --b;
+                }
+                mine[b + 1] = (uint32_t)j;
+            }
+            ++cnt;
+        });
+    }
+    cand_cnt[i] = cnt;
+    if (cnt > CAND_STAGE) flags[1] = 1;
+    if (cnt > CAND_INLINE_SORT) flags[0] = 1;
+}
+__global__ __launch_bounds__(256) void cand_compact_kernel(int64_t n_rows, const int32_t* __restrict__ cand_cnt, const int32_t* __restrict__ cand_off,
+                                                            const uint32_t* __restrict__ stage, uint32_t* __restrict__ cand_r,
+                                                            uint32_t* __restrict__ cand_l) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = t / CAND_STAGE;
+    const int j = (int)(t % CAND_STAGE);
+    if (i >= n_rows || j >= cand_cnt[i]) return;
+    const int64_t at = (int64_t)cand_off[i] + j;
+    cand_r[at] = stage[t];
+    cand_l[at] = (uint32_t)i;
+}
+
 // Stage 2: exact refine, JOIN_GS lanes per candidate pair (pairs are independent: the unit of parallelism is the
 // pair, not the row, so ragged candidate lists do not unbalance waves).
 #ifndef GPK_JOIN_GS
@@ -1486,7 +1529,12 @@ __device__ __forceinline__ int64_t row_of_candidate(const int32_t* __restrict__ 
     }
     return lo;
 }
-__global__ __launch_bounds__(256) void pair_refine_kernel(DevGeo left, DevGeo right, const uint32_t* __restrict__ cand_l,
+// (four waves per SIMD: 128 registers — a 16-dword spill in the rare exact-arithmetic arm — instead of 141 and three waves; the kernel
+// waits on gathers of polygon coordinates most of the time)
+#ifndef GPK_REFINE_MINWAVES
+#define GPK_REFINE_MINWAVES 4
+#endif
+__global__ __launch_bounds__(256, GPK_REFINE_MINWAVES) void pair_refine_kernel(DevGeo left, DevGeo right, const uint32_t* __restrict__ cand_l,
                                                            const uint32_t* __restrict__ cand_r, int64_t n_cand,
                                                            const double4* __restrict__ lbbox, const double4* __restrict__ rbbox,
                                                            uint8_t* __restrict__ hit, bool l_one_ring, bool r_one_ring) {
@@ -1614,6 +1662,11 @@ static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, co
     size_t need = 4 * i32n + align256(sizeof(unsigned long long) * (size_t)(nb + 2)) + 256 + 1024;
     if (host_out && out_counts) need += align256(sizeof(uint32_t) * (size_t)n);
     if (host_out && want_pairs) need += align256(pairs_bytes);
+    // (padded staging of the candidates: up to 512 MB — 8M left rows; beyond that the two-search path)
+    const size_t stage_bytes = sizeof(uint32_t) * CAND_STAGE * (size_t)(n > 0 ? n : 1);
+    static const bool no_stage = getenv("GPK_NO_CAND_STAGE") != nullptr;  // A/B runs
+    const bool staged = !no_stage && stage_bytes <= (size_t(512) << 20);
+    if (staged) need += align256(stage_bytes);
     rc = workspace().begin(need);
     if (rc != GPK_OK) return done(rc);
     int32_t* cand_cnt = (int32_t*)workspace().take(sizeof(int32_t) * (size_t)(n + 1));
@@ -1624,17 +1677,25 @@ static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, co
     int32_t* big_rows = (int32_t*)workspace().take(256);
     uint32_t* counts_out = out_counts ? (host_out ? (uint32_t*)workspace().take(sizeof(uint32_t) * (size_t)n) : out_counts) : nullptr;
     uint32_t* pairs_dev = want_pairs ? (host_out ? (uint32_t*)workspace().take(pairs_bytes) : out_pairs) : nullptr;
+    uint32_t* stage = staged ? (uint32_t*)workspace().take(stage_bytes) : nullptr;
 
-    int32_t n_cand = 0, has_big_rows = 0;
+    int32_t n_cand = 0, has_big_rows = 0, has_long_rows = 0;
     unsigned long long cand_total = 0;  // the 64-bit grand total of the scan: cand_off[n] is its truncation to i32
     auto stage1 = [&]() -> int32_t {
-        GPK_HIP(hipMemsetAsync(big_rows, 0, sizeof(int32_t), s));
-        GPK_LAUNCH("gpk_bbox_cand_count", bbox_cand_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, left->d, right->d, right_index->v,
-                   lbbox, cand_cnt, (const int32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, big_rows);
+        GPK_HIP(hipMemsetAsync(big_rows, 0, 2 * sizeof(int32_t), s));
+        if (staged)
+            GPK_LAUNCH("gpk_bbox_cand_count", bbox_cand_stage_kernel, dim3((unsigned)nb), dim3(256), 0, s, left->d, right->d, right_index->v,
+                       lbbox, cand_cnt, stage, big_rows);
+        else
+            GPK_LAUNCH("gpk_bbox_cand_count", bbox_cand_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, left->d, right->d, right_index->v,
+                       lbbox, cand_cnt, (const int32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, big_rows);
         GPK_TRY(exclusive_scan_i32(cand_cnt, n, cand_off, nullptr, btot, s));
+        int32_t fl[2] = {0, 0};
         GPK_HIP(hipMemcpyAsync(&cand_total, btot + nb, sizeof cand_total, hipMemcpyDeviceToHost, s));
-        GPK_HIP(hipMemcpyAsync(&has_big_rows, big_rows, sizeof has_big_rows, hipMemcpyDeviceToHost, s));
+        GPK_HIP(hipMemcpyAsync(fl, big_rows, sizeof fl, hipMemcpyDeviceToHost, s));
         GPK_HIP(hipStreamSynchronize(s));
+        has_big_rows = fl[0];
+        has_long_rows = fl[1];
         return GPK_OK;
     };
     rc = stage1();
@@ -1667,8 +1728,12 @@ static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, co
         }
     }
     auto stage23 = [&]() -> int32_t {
-        GPK_LAUNCH("gpk_bbox_cand_fill", bbox_cand_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, left->d, right->d, right_index->v,
-                   lbbox, cand_cnt, (const int32_t*)cand_off, cand_r, cand_l, big_rows);
+        if (staged && !has_long_rows && !has_big_rows)
+            GPK_LAUNCH("gpk_cand_compact", cand_compact_kernel, dim3((unsigned)((n * CAND_STAGE + 255) / 256)), dim3(256), 0, s, n,
+                       (const int32_t*)cand_cnt, (const int32_t*)cand_off, (const uint32_t*)stage, cand_r, cand_l);
+        else
+            GPK_LAUNCH("gpk_bbox_cand_fill", bbox_cand_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, left->d, right->d, right_index->v,
+                       lbbox, cand_cnt, (const int32_t*)cand_off, cand_r, cand_l, big_rows);
         if (has_big_rows && n_cand > 0) {  // some slice is long: sort every slice by right id, segment = left row
             GPK_HIP(rocprim::segmented_radix_sort_keys(seg_tmp, seg_bytes, (const uint32_t*)cand_r, cand_sorted, (unsigned)n_cand, (unsigned)n,
                                                        (const int32_t*)cand_off, (const int32_t*)cand_off + 1, 0, seg_bits, s));
