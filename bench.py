@@ -200,8 +200,8 @@ class Ctx:
         return self.max_over_ranks(t1 - t0), k_ms, k_n, warm
 
     # substring queries: no name here is a substring of another one that can run in the same step
-    KERNELS = ("gpk_pip_tile", "gpk_pip_write", "gpk_pip_fixup", "gpk_distance_grouped", "gpk_dist_hist", "gpk_dist_scatter", "gpk_dist_probe", "gpk_dist_batches", "gpk_dist_iota",
-               "gpk_dist_offsets", "gpk_rowmap", "gpk_bbox_cand_count", "gpk_bbox_cand_fill", "gpk_pair_refine", "gpk_pair_count", "gpk_pair_emit", "gpk_counts_copy",
+    KERNELS = ("gpk_pip_tile", "gpk_pip_write", "gpk_join_prep", "gpk_distance_grouped", "gpk_dist_hist", "gpk_dist_scatter", "gpk_dist_probe", "gpk_dist_batches", "gpk_dist_iota",
+               "gpk_dist_offsets", "gpk_rowmap", "gpk_bbox_cand_count", "gpk_bbox_cand_fill", "gpk_cand_compact", "gpk_pair_refine", "gpk_pair_count", "gpk_pair_emit", "gpk_counts_copy",
                "gpk_ring_area", "gpk_area_combine", "gpk_seq_long", "gpk_scan", "gpk_seq_bbox", "gpk_bounds_combine", "gpk_stats_to_bbox")
 
     def _all_kernels(self, calls: int) -> dict:
@@ -386,7 +386,7 @@ def run_c2(ctx: Ctx) -> None:
         "input_rotation": f"{R} distinct 10M-point inputs and output sets ({R * (16 * n + 4 * n + 8 * n) / 2**20:.0f} MiB): inputs come from HBM, not from the 256 MiB Infinity Cache",
         "join_bytes_per_step": bytes_join,
         "join_GBps_end_to_end": bytes_join / step_s / 1e9,
-        "kernel_ms": {"gpk_pip_tile": k_tile, "gpk_pip_write (warm-up steps)": k_write, "gpk_pip_fixup (warm-up steps)": warm.get("gpk_pip_fixup", 0.0)},
+        "kernel_ms": {"gpk_pip_tile": k_tile, "gpk_pip_write (warm-up steps)": k_write, "gpk_join_prep (warm-up steps)": warm.get("gpk_join_prep", 0.0)},
         "exact_phase": {"test_points_per_step": queued, "edge_tests_per_step": edges, "rows_deferred_to_the_generic_walk_per_step": int(st[2])},
         "edge_tests_per_s": edges / step_s if step_s > 0 else None,
         "valu_busy": valu_busy,

@@ -1500,16 +1500,39 @@ __global__ __launch_bounds__(256) void bbox_cand_stage_kernel(DevGeo left, DevGe
     if (cnt > CAND_STAGE) flags[1] = 1;
     if (cnt > CAND_INLINE_SORT) flags[0] = 1;
 }
-__global__ __launch_bounds__(256) void cand_compact_kernel(int64_t n_rows, const int32_t* __restrict__ cand_cnt, const int32_t* __restrict__ cand_off,
+// (a row with more than CAND_STAGE candidates — a dense cluster — walks the directory again, like bbox_cand_kernel<true>: one lane of
+// its CAND_STAGE; rows beyond CAND_INLINE_SORT send the whole join down the two-search path with its segmented sort)
+__global__ __launch_bounds__(256) void cand_compact_kernel(DevGeo left, DevGeo right, IndexView ix, const double4* __restrict__ lbbox,
+                                                            const int32_t* __restrict__ cand_cnt, const int32_t* __restrict__ cand_off,
                                                             const uint32_t* __restrict__ stage, uint32_t* __restrict__ cand_r,
                                                             uint32_t* __restrict__ cand_l) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t i = t / CAND_STAGE;
     const int j = (int)(t % CAND_STAGE);
-    if (i >= n_rows || j >= cand_cnt[i]) return;
-    const int64_t at = (int64_t)cand_off[i] + j;
-    cand_r[at] = stage[t];
-    cand_l[at] = (uint32_t)i;
+    if (i >= left.n_geoms) return;
+    const int cnt = cand_cnt[i];
+    const int64_t o0 = (int64_t)cand_off[i];
+    if (cnt <= CAND_STAGE) {
+        if (j < cnt) {
+            cand_r[o0 + j] = stage[t];
+            cand_l[o0 + j] = (uint32_t)i;
+        }
+        return;
+    }
+    if (j != 0) return;
+    int m = 0;
+    const GridParams g = *ix.grid;
+    for_each_bbox_candidate(ix, g, lbbox[i], [&](int r) {
+        if (!dev::valid_row(right.validity, r)) return;
+        int b = m - 1;  // insertion into the ascending prefix
+        while (b >= 0 && cand_r[o0 + b] > (uint32_t)r) {
+            cand_r[o0 + b + 1] = cand_r[o0 + b];
+            --b;
+        }
+        cand_r[o0 + b + 1] = (uint32_t)r;
+        ++m;
+    });
+    for (int a = 0; a < m; ++a) cand_l[o0 + a] = (uint32_t)i;
 }
 
 // Stage 2: exact refine, JOIN_GS lanes per candidate pair (pairs are independent: the unit of parallelism is the
@@ -1728,9 +1751,9 @@ static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, co
         }
     }
     auto stage23 = [&]() -> int32_t {
-        if (staged && !has_long_rows && !has_big_rows)
-            GPK_LAUNCH("gpk_cand_compact", cand_compact_kernel, dim3((unsigned)((n * CAND_STAGE + 255) / 256)), dim3(256), 0, s, n,
-                       (const int32_t*)cand_cnt, (const int32_t*)cand_off, (const uint32_t*)stage, cand_r, cand_l);
+        if (staged && !has_big_rows)
+            GPK_LAUNCH("gpk_cand_compact", cand_compact_kernel, dim3((unsigned)((n * CAND_STAGE + 255) / 256)), dim3(256), 0, s, left->d, right->d,
+                       right_index->v, (const double4*)lbbox, (const int32_t*)cand_cnt, (const int32_t*)cand_off, (const uint32_t*)stage, cand_r, cand_l);
         else
             GPK_LAUNCH("gpk_bbox_cand_fill", bbox_cand_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, left->d, right->d, right_index->v,
                        lbbox, cand_cnt, (const int32_t*)cand_off, cand_r, cand_l, big_rows);
