@@ -823,6 +823,12 @@ def run_c5(ctx: Ctx) -> None:
     index = SpatialIndex.from_device(right, stream=stream)
     torch.cuda.synchronize()
     build_ms = (time.perf_counter() - t0) * 1e3
+    # the same build once more: the first one also grows the library's scratch arenas and size-classifies the column (one-off per process / column)
+    t0 = time.perf_counter()
+    again = SpatialIndex.from_device(right, stream=stream)
+    torch.cuda.synchronize()
+    build_again_ms = (time.perf_counter() - t0) * 1e3
+    again.free()
     pts_host = synth.uniform_points(n, seed=52 + ctx.rank)
     pts = dev_array(torch, pts_host, dev, stream)
     counts = torch.empty(n, dtype=torch.int32, device=dev)
@@ -892,6 +898,7 @@ def run_c5(ctx: Ctx) -> None:
         "exact_phase": {"queued_point_part_pairs_per_step": int(st[0]), "edge_tests_per_step": int(st[1])},
         "call": "gpk_spatial_join_async(within) + gpk_area, one stream",
         "index_build_ms": build_ms,
+        "index_build_again_ms": build_again_ms,
         "index_bytes": index.nbytes(),
         "index_describe": index.describe(),
         "index_full_variant": index_full,

@@ -256,6 +256,7 @@ __global__ void cell_build_kernel(DevGeo a, IndexView ix, PipView pv, FineGrid g
                                   uint32_t* __restrict__ cell, uint32_t* __restrict__ list) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= (int64_t)g.R * g.R) return;
+    if (FILL && need[c] == 0) return;  // empty and one-entry cells got their word from the count pass: only list cells walk again
     const int ci = (int)(c % g.R), cj = (int)(c / g.R);
     const double cx = g.rx0 + ((double)ci + 0.5) * g.fw, cy = g.ry0 + ((double)cj + 0.5) * g.fh;
     const bool border = ci == 0 || cj == 0 || ci == g.R - 1 || cj == g.R - 1;
@@ -313,14 +314,10 @@ __global__ void cell_build_kernel(DevGeo a, IndexView ix, PipView pv, FineGrid g
 
     if (!FILL) {
         need[c] = n >= 2 ? n + 1 : 0;
+        if (n <= 1) cell[c] = n == 1 ? ((CELL_TAG_SINGLE << 30) | first_entry) : 0u;
         return;
     }
-    uint32_t word = 0;
-    if (n == 1)
-        word = (CELL_TAG_SINGLE << 30) | first_entry;
-    else if (n >= 2)
-        word = (CELL_TAG_LIST << 30) | (uint32_t)list_off[c];
-    cell[c] = word;
+    cell[c] = (CELL_TAG_LIST << 30) | (uint32_t)list_off[c];
 }
 
 // ---- level 2: cells crossed by exactly one part -----------------------------------------------------
@@ -924,7 +921,9 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
     // keys x 3 copies + flags); anything beyond it falls back to hipMalloc inside Temps
     // (capped: a multi-gigabyte arena costs more to map than the individual allocations it replaces)
     {
-        size_t est = (size_t)n_rings * 64 + (size_t)n_cells * 24 + (size_t)d.n_coords * 120 + (1u << 20);
+        // (nine per-cell arrays, the mark keys x 3, the sort's scratch, the chain pass: a temporary that misses the arena costs a
+        // hipMalloc + a hipFree — 0.2 ms each on this runtime, a third of the whole build of a 1000-polygon right side)
+        size_t est = (size_t)n_rings * 64 + (size_t)n_cells * 48 + (size_t)d.n_coords * 160 + (8u << 20);
         if (est > (size_t(256) << 20)) est = size_t(256) << 20;
         (void)workspace_aux(1).begin(est);
     }
@@ -1108,7 +1107,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
     GPK_TRY(t.alloc(&need, (size_t)n_cells + 1));
     GPK_TRY(t.alloc(&list_off, (size_t)n_cells + 1));
     GPK_LAUNCH("gpk_pipidx_cell_count", cell_build_kernel<false>, blocks_for(n_cells), dim3(256), 0, s, d, ix->v, pv, g, marks, n_marks,
-               need, (const int32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+               need, (const int32_t*)nullptr, cell, (uint32_t*)nullptr);
     GPK_TRY(exclusive_scan_i32(need, n_cells, list_off, nullptr, btot, s));
     int32_t list_len = 0;
     GPK_HIP(hipMemcpyAsync(&list_len, list_off + n_cells, sizeof list_len, hipMemcpyDeviceToHost, s));
