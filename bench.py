@@ -830,6 +830,10 @@ def run_c5(ctx: Ctx) -> None:
     build_again_ms = (time.perf_counter() - t0) * 1e3
     again.free()
     pts_host = synth.uniform_points(n, seed=52 + ctx.rank)
+    if args.diag_sorted_points:  # diagnosis only (never the reported configuration): the same points in raster order
+        xy = pts_host.xy
+        key = (np.floor(xy[:, 1] / synth.DOMAIN * 4096).astype(np.int64) << 12) | np.floor(xy[:, 0] / synth.DOMAIN * 4096).astype(np.int64)
+        pts_host = pts_host.take(np.argsort(key, kind="stable"))
     pts = dev_array(torch, pts_host, dev, stream)
     counts = torch.empty(n, dtype=torch.int32, device=dev)
     pairs = torch.empty((4 * n, 2), dtype=torch.int32, device=dev)
@@ -890,7 +894,7 @@ def run_c5(ctx: Ctx) -> None:
     area_bytes = 16 * shard_host.n_coords + 4 * (shard_host.n_geoms + shard_host.n_parts + shard_host.n_rings + 3) + 8 * n_share
     area_ms = sum(v for k, v in warm.items() if "area" in k or "seq_long" in k)
     config = {
-        "workload": f"C5: {n} points (one rank's share of 50M) within() all {right_host.n_geoms} power-law multipolygons ({right_host.n_coords} coordinates) + area() of {n_share} of them, per GPU",
+        "workload": ("DIAGNOSIS (points in raster order) " if args.diag_sorted_points else "") + f"C5: {n} points (one rank's share of 50M) within() all {right_host.n_geoms} power-law multipolygons ({right_host.n_coords} coordinates) + area() of {n_share} of them, per GPU",
         "points_per_gpu": n,
         "multipolygons": right_host.n_geoms,
         "coordinates": right_host.n_coords,
@@ -981,6 +985,7 @@ def main() -> None:
     ap.add_argument("--polygons", type=int, default=1_000_000, help="c4: polygons per side")
     ap.add_argument("--multipolygons", type=int, default=5_000_000, help="c5: right-side multipolygons (all of them on every GPU)")
     ap.add_argument("--rotate", type=int, default=3, help="c2: distinct input/output sets cycled through by the steps (cold inputs)")
+    ap.add_argument("--diag-sorted-points", action="store_true", help="c5, diagnosis: feed the points in raster order (how much of the tile kernel is locality)")
     ap.add_argument("--no-index-variants", action="store_true", help="c5: skip the extra build + joins of the GPK_INDEX_PIP_FULL index")
     ap.add_argument("--parity-rows", type=int, default=300_000, help="random sample of left rows compared with the oracle")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the cpu_baseline sample")

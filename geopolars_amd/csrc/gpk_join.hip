@@ -148,10 +148,12 @@ __global__ void cell_sort_kernel(const int32_t* __restrict__ cell_off, int64_t n
 
 // ================================= point-in-polygon join =========================================
 #ifndef GPK_PIP_PPT
-#define GPK_PIP_PPT 2
+#define GPK_PIP_PPT 2  // points per lane of pip_tile_kernel on ordinary indexes; list-heavy ones (gpk_index::pip_list_heavy) run the
+                       // PPT = 1 instance: the flattened passes carry the memory-level parallelism there, and a 256-point tile keeps 84
+                       // registers and 19 KB of LDS per work-group (C5 1.41 -> 1.31 ms); a tessellation, which streams, loses 20 % with it
 #endif
 // GPK_ABLATE (tuning builds only, tools/pmc_ablate.sh, tools/ablate_time.py): 1 = no exact phase, 2 = every cell empty, 3 = level-1 interiors only,
-// 5 = level-2 labels without queue pushes.  0 in the shipped library.
+// 5 = level-2 labels without queue pushes, 6 = list cells skipped, 7 = list entries end after the box test, 8 = no hole rings.  0 in the shipped library.
 #ifndef GPK_ABLATE
 #define GPK_ABLATE 0
 #endif
@@ -246,9 +248,29 @@ struct QEntry {  // 32 bytes: one queued (point, part) pair with its exterior sl
 #ifndef GPK_PIP_NT
 #define GPK_PIP_NT 2  // bit 0: non-temporal point loads (measured slower), bit 1: non-temporal result stores
 #endif
+#ifndef GPK_FLAT_B
+#define GPK_FLAT_B 2  // entries / edges a lane of the flattened passes keeps in flight (4: 123 registers instead of 92, no faster)
+#endif
 #define PIP_SYNC() __syncthreads()
+// GPK_TILE_TRACE (diagnosis builds only; tools/c5_stage_clocks.py): thread 0 of every work-group adds the wall-clock ticks (100 MHz) it
+// spent in each stage of pip_tile_kernel — barrier waits included, so a stage's total is the work-groups' critical path through it — to
+// the statistics buffer's words 8 + stage.
+#ifdef GPK_TILE_TRACE
+#define PIP_STAGE_CLK(idx)                                                   \
+    do {                                                                     \
+        if (stats && tid == 0) {                                             \
+            const unsigned long long _now = wall_clock64();                  \
+            atomicAdd(&stats[8 + (idx)], _now - t_stage);                    \
+            t_stage = _now;                                                  \
+        }                                                                    \
+    } while (0)
+#else
+#define PIP_STAGE_CLK(idx) \
+    do {                   \
+    } while (0)
+#endif
 // SUB2: the index holds two-part level-2 records (PipView::sub2); the variant without them stays as lean as it was
-template <bool RASTER, bool SUB2>
+template <bool RASTER, bool SUB2, int PPT = GPK_PIP_PPT>
 __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(DevGeo pts, DevGeo polys, IndexView ix, PipView pv,
                                                               uint32_t* __restrict__ counts,
                                                               uint32_t* __restrict__ code,
@@ -256,7 +278,20 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
                                                               unsigned long long* __restrict__ super_tot,
                                                               uint32_t* __restrict__ multi_pool, uint32_t multi_cap,
                                                               uint32_t* __restrict__ multi_top, unsigned long long* __restrict__ stats) {
+    constexpr int PIP_PPT = PPT, PIP_TILE = PIP_BLOCK * PPT, PIP_QCAP = PIP_BLOCK * PPT;  // (this instance's: they shadow the defaults)
     __shared__ QEntry q[RASTER ? PIP_QCAP : 1];
+    __shared__ uint32_t s_pre[RASTER ? PIP_QCAP + 1 : 1];  // phase 2: first flattened edge of every queued pair (+ the total)
+    constexpr int ACC_WORDS = PIP_QCAP > 2 * PIP_BLOCK ? PIP_QCAP : 2 * PIP_BLOCK;  // (the round's job list — two words per lane — shares it)
+    __shared__ int s_acc[RASTER ? ACC_WORDS : 1];          // phase 2: the pair's winding sum << 16 | on-boundary count
+    __shared__ uint32_t s_scan[PIP_BLOCK / 64 + 1];
+    __shared__ uint32_t lj_n[PIP_PPT];  // (point, list) jobs registered in round k
+    constexpr int PIP_HQCAP = 128;      // hole rings queued per drain of the pair queue (beyond it: the owning lane walks the hole)
+    __shared__ uint4 s_hq[RASTER ? PIP_HQCAP : 1];  // (owning pair, first slab entry, entries, -)
+    __shared__ int s_hacc[RASTER ? PIP_HQCAP : 1];
+    __shared__ uint32_t hq_n;
+    // a job = (list offset, point slot); the job list lives in s_acc's storage (phase 2 starts after the list pass)
+    static_assert(sizeof(uint2) * PIP_BLOCK <= sizeof(int) * ACC_WORDS, "the job list fits s_acc");
+    uint2* s_lj = reinterpret_cast<uint2*>(s_acc);
     __shared__ uint32_t s_cnt[PIP_TILE], s_hit[PIP_TILE * PIP_KHIT];
     __shared__ uint32_t q_n, ovf_n;
     __shared__ uint2 s_ovf[RASTER ? PIP_OVF : 1];  // (point slot, part) hits beyond a point's PIP_KHIT inline slots
@@ -267,11 +302,15 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
     const uint32_t rem = (uint32_t)(n - base < (int64_t)PIP_TILE ? n - base : (int64_t)PIP_TILE);  // points in this tile
     const double2* __restrict__ tile_xy = pts.xy + base;
     if (tid == 0) s_tot = 0;
+#ifdef GPK_TILE_TRACE
+    unsigned long long t_stage = wall_clock64();
+#endif
 
     if (RASTER) {
 #pragma unroll
         for (int k = 0; k < PIP_PPT; ++k) s_cnt[k * PIP_BLOCK + tid] = 0;
-        if (tid == 0) q_n = 0, ovf_n = 0;
+        if (tid == 0) q_n = 0, ovf_n = 0, hq_n = 0;
+        if (tid < PIP_PPT) lj_n[tid] = 0;
         __syncthreads();
 
         const int lane64 = tid & 63;
@@ -393,6 +432,15 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
         // stage E, one round per k: queue pushes (wave-aggregated), then — when the queue is filling up, and after
         // the last round — phase 2 drains it.  Boundary-dominated right sides (small overlapping polygons) queue more
         // than one pair per point; draining between rounds keeps them on the cooperative path.
+        auto record_any = [&](uint32_t li, uint32_t part) {  // any lane, any point of the tile (the flattened passes)
+            const uint32_t sl = atomicAdd(&s_cnt[li], 1u);
+            if (sl < (uint32_t)PIP_KHIT) {
+                s_hit[li * PIP_KHIT + sl] = part;
+            } else {
+                const uint32_t o = atomicAdd(&ovf_n, 1u);
+                if (o < (uint32_t)PIP_OVF) s_ovf[o] = make_uint2(li, part);
+            }
+        };
         auto record = [&](int li, uint32_t part) {  // phase 1: only this lane touches s_cnt[li] between barriers
             const uint32_t sl = s_cnt[li]++;
             if (sl < (uint32_t)PIP_KHIT) {
@@ -402,7 +450,7 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
                 if (o < (uint32_t)PIP_OVF) s_ovf[o] = make_uint2((uint32_t)li, part);
             }
         };
-        const int glane = tid & (PIP_GS - 1);
+        PIP_STAGE_CLK(0);
 #pragma unroll
         for (int k = 0; k < PIP_PPT; ++k) {
             const int li = k * PIP_BLOCK + tid;
@@ -441,70 +489,218 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
                         record(li, bpart);
                 }
             }
-            // cells where several parts meet (three or more, or two that both cover it): per-lane walk of the entry list
-            if ((word[k] >> 30) == CELL_TAG_LIST) {
-                const uint32_t off = word[k] & 0x3FFFFFFFu;
-                const uint32_t m = pv.list[off];
-                for (uint32_t t = 0; t < m; ++t) {
-                    const uint32_t e = pv.list[off + 1 + t];
-                    uint32_t part = e >> 1;
-                    if (e & 1u) {
-                        int a0, a1;
-                        uint32_t holes;
-                        if (pv.lrec) {  // the entry names a level-2 record: most points finish on its label
-                            const SubCell rc = pv.lrec[e >> 1];
-                            part = rc.part_flags & 0x3FFFFFFFu;
-                            const int idx = (fy[k] % S) * S + (sx[k] % S);
-                            const int wsel = idx >> 4;
-                            const uint32_t lw = wsel == 0 ? rc.labels[0] : (wsel == 1 ? rc.labels[1] : (wsel == 2 ? rc.labels[2] : rc.labels[3]));
-                            const uint32_t lab = (lw >> (2 * (idx & 15))) & 3u;
-                            if (lab == 0u) continue;
-                            if (lab == 2u) {
-                                holes = rc.part_flags & 0x80000000u;
-                                if (rc.part_flags & SUB_INDIRECT) {
-                                    if (!part_slab(pv.part_info[part], fyf[k], a0, a1)) continue;
-                                } else {
-                                    const bool upper = ((fyf[k] >> PIP_FINE_LOG2) & 1u) != 0;
-                                    a0 = (int)(upper ? rc.e1 : rc.e0);
-                                    a1 = (int)(upper ? rc.e2 : rc.e1);
-                                }
-                            }
-                            if (lab == 1u) {
-                                record(li, part);
-                                continue;
-                            }
-                        } else {
-                            if (pv.part_box) {  // (closed box of the exterior, rounded outward: outside it = outside the part)
-                                const float4 bb = pv.part_box[part];
-                                if (!(p[k].x >= (double)bb.x && p[k].x <= (double)bb.z && p[k].y >= (double)bb.y && p[k].y <= (double)bb.w)) continue;
-                            }
-                            const PartInfo pq = pv.part_info[part];
-                            if (!part_slab(pq, fyf[k], a0, a1)) continue;
-                            holes = pq.n_rings > 1 ? 0x80000000u : 0u;
-                        }
-                        if (a1 <= a0) continue;
-                        const uint32_t slot = atomicAdd(&q_n, 1u);
-                        if (slot < (uint32_t)PIP_QCAP) {
-                            q[slot] = QEntry{p[k].x, p[k].y, part, (uint32_t)a0, (uint32_t)(a1 - a0), (uint32_t)li | holes};
-                            continue;
-                        }
-                        if (pip::part_pos_single(pv, polys, (int)part, p[k].x, p[k].y) != dev::POS_INSIDE) continue;
-                    }
-                    record(li, part);
+            // cells where several parts meet (three or more, or two that both cover it): the (point, entry) pairs of the round, FLATTENED.
+            // A lane used to walk its own cell's list — five entries on average for C5, each a chain of dependent gathers (entry -> box
+            // -> PartInfo -> slab offsets), the whole work-group waiting at the barrier for the lane with the longest list: 72 of the
+            // 151 us a work-group lived.  Now the lanes register (point, list) jobs, and every lane takes a run of consecutive entries
+            // of the flattened job list, four at a time with their gathers in flight together.
+            {
+                const bool has_list = (word[k] >> 30) == CELL_TAG_LIST && GPK_ABLATE != 6;
+                const unsigned long long lm = __ballot(has_list);
+                if (lm) {  // (wave-uniform)
+                    const uint32_t off = word[k] & 0x3FFFFFFFu;
+                    const int leader = __ffsll((long long)lm) - 1;
+                    uint32_t wb = 0;
+                    if (lane64 == leader) wb = atomicAdd(&lj_n[k], (uint32_t)__popcll(lm));
+                    wb = __shfl(wb, leader, 64);
+                    if (has_list) s_lj[wb + (uint32_t)__popcll(lm & ((1ull << lane64) - 1ull))] = make_uint2(off, (uint32_t)li);
                 }
             }
             PIP_SYNC();
+            const uint32_t nl = lj_n[k];  // (uniform; at most one job per lane and round)
+            if (nl) {
+                const uint32_t my_m = (uint32_t)tid < nl ? pv.list[s_lj[tid].x] : 0u;  // entries of the job's list
+                uint32_t n_items;
+                const uint32_t pre = dev::block_exclusive_scan<uint32_t, PIP_BLOCK>(my_m, s_scan, &n_items);
+                if ((uint32_t)tid < nl) s_pre[tid] = pre;
+                if (tid == 0) s_pre[nl] = n_items;
+                __syncthreads();
+                const uint32_t chunk = (n_items + PIP_BLOCK - 1) / PIP_BLOCK;
+                const uint32_t j0 = (uint32_t)tid * chunk, j1 = j0 + chunk < n_items ? j0 + chunk : n_items;
+                // (one instance per index kind: the records of the one and the boxes of the other never share registers)
+                auto list_items = [&](auto LREC_T) {
+                    constexpr bool LREC = decltype(LREC_T)::value;
+                    if (j0 >= j1) return;
+                    uint32_t jb = 0;  // largest job with s_pre[jb] <= j0
+                    {
+                        uint32_t lo = 0, hi = nl;
+                        while (hi - lo > 1) {
+                            const uint32_t mid = (lo + hi) >> 1;
+                            if (s_pre[mid] <= j0)
+                                lo = mid;
+                            else
+                                hi = mid;
+                        }
+                        jb = lo;
+                    }
+                    constexpr int B = GPK_FLAT_B;
+                    for (uint32_t j = j0; j < j1; j += B) {
+                        bool ok[B];
+                        uint32_t jli[B], ew[B];
+                        double2 jp[B];
+#pragma unroll
+                        for (int u = 0; u < B; ++u) {
+                            const uint32_t jj = j + u;
+                            ok[u] = jj < j1;
+                            if (ok[u])
+                                while (jj >= s_pre[jb + 1]) ++jb;  // (a job with no entries is stepped over)
+                            const uint2 job = s_lj[jb];
+                            jli[u] = job.y;
+                            ew[u] = pv.list[job.x + 1u + (ok[u] ? jj - s_pre[jb] : 0u)];  // (a lane past its run re-reads a valid entry and drops it)
+                            jp[u] = tile_xy[jli[u]];
+                        }
+                        // second level, all four in flight: the entry's record (indexes with per-entry records) or its part's box
+                        SubCell rc[LREC ? B : 1];
+                        float4 bb[LREC ? 1 : B];
+#pragma unroll
+                        for (int u = 0; u < B; ++u) {
+                            if constexpr (LREC)
+                                rc[u] = pv.lrec[(ew[u] & 1u) ? ew[u] >> 1 : 0u];
+                            else if (pv.part_box)
+                                bb[u] = pv.part_box[ew[u] >> 1];
+                        }
+#pragma unroll
+                        for (int u = 0; u < B; ++u) {
+                            if (!ok[u]) continue;
+                            const uint32_t e = ew[u], jl = jli[u];
+                            const double jx = jp[u].x, jy = jp[u].y;
+                            uint32_t part = e >> 1;
+                            if (e & 1u) {
+                                int a0 = 0, a1 = 0;
+                                uint32_t holes = 0;
+                                const uint32_t jfyf = (uint32_t)dev::cell_of(jy, pv.ry0, pv.inv_fh * FINE, pv.R * FINE);
+                                if constexpr (LREC) {  // the entry names a level-2 record: most points finish on its label
+                                    const uint32_t jsx = (uint32_t)dev::cell_of(jx, pv.rx0, pv.inv_fw * S, pv.R * S), jfy = jfyf >> FY_SUB;
+                                    part = rc[u].part_flags & 0x3FFFFFFFu;
+                                    const int idx = (jfy % S) * S + (jsx % S);
+                                    const int wsel = idx >> 4;
+                                    const uint32_t lw = wsel == 0 ? rc[u].labels[0] : (wsel == 1 ? rc[u].labels[1] : (wsel == 2 ? rc[u].labels[2] : rc[u].labels[3]));
+                                    const uint32_t lab = (lw >> (2 * (idx & 15))) & 3u;
+                                    if (lab == 0u) continue;
+                                    if (lab == 1u) {
+                                        record_any(jl, part);
+                                        continue;
+                                    }
+                                    holes = rc[u].part_flags & 0x80000000u;
+                                    if (rc[u].part_flags & SUB_INDIRECT) {
+                                        if (!part_slab(pv.part_info[part], jfyf, a0, a1)) continue;
+                                    } else {
+                                        const bool upper = ((jfyf >> PIP_FINE_LOG2) & 1u) != 0;
+                                        a0 = (int)(upper ? rc[u].e1 : rc[u].e0);
+                                        a1 = (int)(upper ? rc[u].e2 : rc[u].e1);
+                                    }
+                                } else {
+                                    // (closed box of the exterior, rounded outward: outside it = outside the part)
+                                    if (pv.part_box && !(jx >= (double)bb[u].x && jx <= (double)bb[u].z && jy >= (double)bb[u].y && jy <= (double)bb[u].w)) continue;
+                                    if (GPK_ABLATE == 7) continue;  // tuning builds only
+                                    const PartInfo pq = pv.part_info[part];
+                                    if (!part_slab(pq, jfyf, a0, a1)) continue;
+                                    holes = pq.n_rings > 1 ? 0x80000000u : 0u;
+                                }
+                                if (a1 <= a0) continue;
+                                const uint32_t slot = atomicAdd(&q_n, 1u);
+                                if (slot < (uint32_t)PIP_QCAP) {
+                                    q[slot] = QEntry{jx, jy, part, (uint32_t)a0, (uint32_t)(a1 - a0), jl | holes};
+                                    continue;
+                                }
+                                if (pip::part_pos_single(pv, polys, (int)part, jx, jy) != dev::POS_INSIDE) continue;
+                            }
+                            record_any(jl, part);
+                        }
+                    }
+                };
+                if (pv.lrec)
+                    list_items(std::true_type{});
+                else
+                    list_items(std::false_type{});
+            }
+            PIP_SYNC();
+            PIP_STAGE_CLK(1);
             const uint32_t queued = q_n;  // uniform: read after the barrier
             if (k + 1 < PIP_PPT && queued <= (uint32_t)PIP_QCAP / 2) continue;
-            // phase 2
+            // phase 2: the queued pairs' slab edges, FLATTENED — lane = edge, not 8 lanes = pair.  A pair has 7 edges on average and its
+            // walk is three dependent gathers (queue entry -> slab entry -> coordinates): with 32 pairs per pass a tile needed eight
+            // such passes back to back, and that chain — not the arithmetic — was 1.1 ms of the 1.8 ms C5 join.  Here every lane takes a
+            // run of consecutive edges of the flattened list, four at a time with all their gathers in flight together, and adds the
+            // edge's winding / on-boundary contribution to its pair's LDS accumulator; one more pass decides the pairs.
             const uint32_t nq = GPK_ABLATE == 1 ? 0u : (queued < (uint32_t)PIP_QCAP ? queued : (uint32_t)PIP_QCAP);
             if (stats && tid == 0 && queued) atomicAdd(&stats[0], (unsigned long long)queued);  // measurement runs only
-            for (uint32_t e = tid / PIP_GS; e < nq; e += PIP_BLOCK / PIP_GS) {
-                const QEntry en = q[e];
-                if (stats && glane == 0) atomicAdd(&stats[1], (unsigned long long)en.cnt);
-                const int pos = pip::part_pos_group_from_edges<PIP_GS>(pv, polys, (int)en.part, (en.li_flags >> 31) ? 2 : 1, (int)en.e0,
-                                                                       (int)en.cnt, en.px, en.py, glane);
-                if (glane == 0 && pos == dev::POS_INSIDE) {
+            if (nq) {  // (uniform)
+                uint32_t mine = 0, c_of[PIP_PPT];
+#pragma unroll
+                for (int u = 0; u < PIP_PPT; ++u) {
+                    const uint32_t e = (uint32_t)tid * PIP_PPT + u;
+                    c_of[u] = e < nq ? q[e].cnt : 0u;
+                    mine += c_of[u];
+                    if (e < nq) s_acc[e] = 0;
+                }
+                uint32_t n_flat;
+                uint32_t run = dev::block_exclusive_scan<uint32_t, PIP_BLOCK>(mine, s_scan, &n_flat);
+#pragma unroll
+                for (int u = 0; u < PIP_PPT; ++u) {
+                    const uint32_t e = (uint32_t)tid * PIP_PPT + u;
+                    if (e <= nq) s_pre[e] = run;  // (entry nq: the total — written by the thread that owns slot nq, or below)
+                    run += c_of[u];
+                }
+                if (tid == 0) s_pre[nq] = n_flat;  // (same value if already written: entries past nq count zero)
+                __syncthreads();
+                PIP_STAGE_CLK(2);
+                if (stats && tid == 0) atomicAdd(&stats[1], (unsigned long long)n_flat);
+                // the flattened pass over `n_ent` entries whose first edges are s_pre[0 .. n_ent]: ent(i) -> (first slab entry, point)
+                auto flat_edges = [&](uint32_t n_ent, uint32_t n_edges, auto&& ent, int* acc) {
+                    const uint32_t chunk = (n_edges + PIP_BLOCK - 1) / PIP_BLOCK;
+                    const uint32_t j0 = (uint32_t)tid * chunk, j1 = j0 + chunk < n_edges ? j0 + chunk : n_edges;
+                    if (j0 >= j1) return;
+                    uint32_t e = 0;  // largest entry with s_pre[e] <= j0
+                    {
+                        uint32_t lo = 0, hi = n_ent;
+                        while (hi - lo > 1) {
+                            const uint32_t mid = (lo + hi) >> 1;
+                            if (s_pre[mid] <= j0)
+                                lo = mid;
+                            else
+                                hi = mid;
+                        }
+                        e = lo;
+                    }
+                    constexpr int B = GPK_FLAT_B;
+                    for (uint32_t j = j0; j < j1; j += B) {
+                        uint32_t ee[B], at[B];
+                        double2 pt[B];
+                        bool ok[B];
+#pragma unroll
+                        for (int u = 0; u < B; ++u) {
+                            const uint32_t jj = j + u;
+                            ok[u] = jj < j1;
+                            if (ok[u])
+                                while (jj >= s_pre[e + 1]) ++e;  // (entries have at least one edge)
+                            ee[u] = e;
+                            uint32_t first;
+                            ent(e, first, pt[u]);
+                            at[u] = first + (ok[u] ? jj - s_pre[e] : 0u);  // (a lane past its run re-reads a valid entry and drops the result)
+                        }
+                        double4 ed[B];
+#pragma unroll
+                        for (int u = 0; u < B; ++u) ed[u] = pip::slab_edge(pv, (int)at[u]);
+#pragma unroll
+                        for (int u = 0; u < B; ++u) {
+                            if (!ok[u]) continue;
+                            int wn = 0;
+                            const int on = (int)dev::ring_edge(ed[u].x, ed[u].y, ed[u].z, ed[u].w, pt[u].x, pt[u].y, wn);
+                            if (wn != 0 || on) atomicAdd(&acc[ee[u]], wn * 65536 + on);
+                        }
+                    }
+                };
+                flat_edges(nq, n_flat, [&](uint32_t e, uint32_t& first, double2& pt) {
+                    first = q[e].e0;
+                    pt = make_double2(q[e].px, q[e].py);
+                }, s_acc);
+                __syncthreads();
+                PIP_STAGE_CLK(3);
+                // decide.  A pair inside the exterior of a part WITH holes queues one entry per hole ring whose rows reach the point
+                // (three gathers per hole) and waits: the holes' slab edges go through the same flattened pass — a lane walking a hole
+                // edge by edge (a dozen dependent gathers) kept its whole work-group at the barrier.
+                auto hit = [&](const QEntry& en) {
                     const uint32_t li2 = en.li_flags & 0x7FFFFFFFu;
                     const uint32_t sl = atomicAdd(&s_cnt[li2], 1u);
                     if (sl < (uint32_t)PIP_KHIT) {
@@ -513,9 +709,66 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
                         const uint32_t o = atomicAdd(&ovf_n, 1u);
                         if (o < (uint32_t)PIP_OVF) s_ovf[o] = make_uint2(li2, en.part);
                     }
+                };
+                constexpr int PENDING = 0x7FFFFFFF;
+                for (uint32_t e = (uint32_t)tid; e < nq; e += PIP_BLOCK) {
+                    const int packed = s_acc[e];  // winding sum in the high half, on-boundary count in the low half
+                    s_acc[e] = 0;
+                    if ((packed & 0xFFFF) != 0 || (packed >> 16) == 0) continue;  // on the exterior ring, or outside it
+                    const QEntry en = q[e];
+                    if ((en.li_flags >> 31) && GPK_ABLATE != 8) {  // the part has holes: inside one (or on it) = not inside the part
+                        int r0, r1;
+                        dev::part_rings(polys, (int)en.part, r0, r1);
+                        const int row = pip::row_of(pv, en.py);
+                        bool out_of_part = false, pending = false;
+                        for (int r = r0 + 1; r < r1 && !out_of_part; ++r) {
+                            int a0, a1;
+                            if (!pip::slab_range(pv, r, row, a0, a1) || a1 <= a0) continue;  // no edge of this hole reaches the point's row: outside it
+                            const uint32_t slot = atomicAdd(&hq_n, 1u);
+                            if (slot < (uint32_t)PIP_HQCAP) {
+                                s_hq[slot] = make_uint4(e, (uint32_t)a0, (uint32_t)(a1 - a0), 0u);
+                                pending = true;
+                            } else {
+                                out_of_part = pip::ring_pos_single(pv, r, en.px, en.py, row) != dev::POS_OUTSIDE;
+                            }
+                        }
+                        if (out_of_part) continue;
+                        if (pending) {
+                            s_acc[e] = PENDING;
+                            continue;
+                        }
+                    }
+                    hit(en);
+                }
+                __syncthreads();
+                const uint32_t nh = hq_n < (uint32_t)PIP_HQCAP ? hq_n : (uint32_t)PIP_HQCAP;  // (uniform)
+                if (nh) {
+                    static_assert(PIP_HQCAP <= PIP_BLOCK, "one hole entry per lane in the scan");
+                    const uint32_t hc = (uint32_t)tid < nh ? s_hq[tid].z : 0u;
+                    uint32_t n_hedges;
+                    const uint32_t hpre = dev::block_exclusive_scan<uint32_t, PIP_BLOCK>(hc, s_scan, &n_hedges);
+                    if ((uint32_t)tid < nh) {
+                        s_pre[tid] = hpre;
+                        s_hacc[tid] = 0;
+                    }
+                    if (tid == 0) s_pre[nh] = n_hedges;
+                    __syncthreads();
+                    if (stats && tid == 0) atomicAdd(&stats[1], (unsigned long long)n_hedges);
+                    flat_edges(nh, n_hedges, [&](uint32_t h, uint32_t& first, double2& pt) {
+                        const uint4 he = s_hq[h];
+                        first = he.y;
+                        pt = make_double2(q[he.x].px, q[he.x].py);
+                    }, s_hacc);
+                    __syncthreads();
+                    if ((uint32_t)tid < nh && s_hacc[tid] != 0) s_acc[s_hq[tid].x] = 0;  // inside that hole, or on it (every writer stores 0)
+                    __syncthreads();
+                    for (uint32_t e = (uint32_t)tid; e < nq; e += PIP_BLOCK)
+                        if (s_acc[e] == PENDING) hit(q[e]);
+                    if (tid == 0) hq_n = 0;
                 }
             }
             PIP_SYNC();
+            PIP_STAGE_CLK(4);
             if (tid == 0) q_n = 0;
             PIP_SYNC();
         }
@@ -525,20 +778,40 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
     uint32_t* __restrict__ tile_counts = counts ? counts + base : nullptr;
     uint32_t* __restrict__ tile_code = code + base;
     unsigned long long wave_hits = 0;  // rows with exactly one hit, counted by ballot (uniform per wave)
+    // space in the multi-hit pool is reserved once per WAVE (a scan over the lanes' needs + one atomic): one atomic per multi-hit row on
+    // the single pool cursor was 1.1 ms of the 1.8 ms C5 join (300k rows in two or more overlapping multipolygons per 6.25M points)
+    auto pool_reserve = [&](uint32_t need) -> uint32_t {
+        const unsigned long long wants = __ballot(need != 0u);
+        if (!wants) return 0u;  // (uniform)
+        const int lane = tid & 63;
+        uint32_t incl = need;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t w = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += w;
+        }
+        const int last = 63 - __builtin_clzll(__ballot(true));  // highest active lane: holds the wave's total
+        uint32_t wbase = 0;
+        if (lane == last) wbase = atomicAdd(multi_top, incl);
+        wbase = __shfl(wbase, last, 64);
+        return wbase + incl - need;
+    };
 #pragma unroll
     for (int k = 0; k < PIP_PPT; ++k) {
         const int li = k * PIP_BLOCK + tid;
         const int64_t i = base + li;
-        if ((uint32_t)li >= rem) continue;
+        const bool in_tile = (uint32_t)li < rem;
         uint32_t cnt = 0, first = CODE_NONE, pool_code = CODE_MULTI;
         bool generic = !RASTER;
-        if (RASTER) {
+        uint32_t g0 = CODE_NONE, g1 = CODE_NONE, need = 0, novf = 0;
+        int mode = 0;  // 1: two geometries (a 3-word pool segment), 2: more part hits than inline slots (collected from the overflow list)
+        if (RASTER && in_tile) {
             cnt = s_cnt[li];
             if (cnt >= 1 && cnt <= (uint32_t)PIP_KHIT) {
                 // part hits -> geometry hits: ascending, each geometry once, null geometries dropped (written out
                 // for PIP_KHIT == 2 so that nothing is a runtime-indexed register array)
                 static_assert(PIP_KHIT == 2, "the finalize step is written for two remembered hits");
-                uint32_t g0 = CODE_NONE, g1 = CODE_NONE, m = 0;
+                uint32_t m = 0;
                 {
                     const uint32_t part = s_hit[li * PIP_KHIT];
                     const uint32_t geom = pv.part_geom ? pv.part_geom[part] : part;
@@ -564,46 +837,56 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
                 cnt = m;
                 if (m >= 1) first = g0;
                 if (m == 2) {
-                    const uint32_t at = atomicAdd(multi_top, 3u);
-                    if (at + 3u <= multi_cap) {
-                        multi_pool[at] = 2u;
-                        multi_pool[at + 1] = g0;
-                        multi_pool[at + 2] = g1;
-                        pool_code = CODE_POOL | at;
-                    }
+                    need = 3u;
+                    mode = 1;
                 }
             } else if (cnt > (uint32_t)PIP_KHIT) {
                 // more hits than inline slots: the rest sit in the tile's overflow list.  Collect all of them into a
                 // pool segment, then sort + dedup there (a handful of words, one lane).
-                const uint32_t novf = ovf_n;
-                const uint32_t at = novf <= (uint32_t)PIP_OVF ? atomicAdd(multi_top, cnt + 1u) : 0xFFFFFFFFu;
-                if (novf > (uint32_t)PIP_OVF || at + cnt + 1u > multi_cap) {
-                    generic = true;
+                novf = ovf_n;
+                if (novf <= (uint32_t)PIP_OVF) {
+                    need = cnt + 1u;
+                    mode = 2;
                 } else {
-                    uint32_t* seg = multi_pool + at + 1;
-                    uint32_t m = 0;
-                    auto put = [&](uint32_t part) {
-                        const uint32_t geom = pv.part_geom ? pv.part_geom[part] : part;
-                        if (!dev::valid_row(polys.validity, geom)) return;
-                        uint32_t j = m;  // insertion into the ascending prefix; equal geometry: drop
-                        while (j > 0 && seg[j - 1] > geom) --j;
-                        if (j > 0 && seg[j - 1] == geom) return;
-                        for (uint32_t t = m; t > j; --t) seg[t] = seg[t - 1];
-                        seg[j] = geom;
-                        ++m;
-                    };
-                    for (int h = 0; h < PIP_KHIT; ++h) put(s_hit[li * PIP_KHIT + h]);
-                    for (uint32_t o = 0; o < novf; ++o) {
-                        const uint2 e = s_ovf[o];
-                        if (e.x == (uint32_t)li) put(e.y);
-                    }
-                    multi_pool[at] = m;
-                    cnt = m;
-                    if (m >= 1) first = seg[0];
-                    if (m >= 2) pool_code = CODE_POOL | at;
+                    generic = true;
                 }
             }
         }
+        const uint32_t at = pool_reserve(need);  // (lanes past the end of the tile take part with need = 0)
+        if (mode == 1 && at + 3u <= multi_cap) {
+            multi_pool[at] = 2u;
+            multi_pool[at + 1] = g0;
+            multi_pool[at + 2] = g1;
+            pool_code = CODE_POOL | at;
+        }
+        if (mode == 2) {
+            if (at + cnt + 1u > multi_cap) {
+                generic = true;
+            } else {
+                uint32_t* seg = multi_pool + at + 1;
+                uint32_t m = 0;
+                auto put = [&](uint32_t part) {
+                    const uint32_t geom = pv.part_geom ? pv.part_geom[part] : part;
+                    if (!dev::valid_row(polys.validity, geom)) return;
+                    uint32_t j = m;  // insertion into the ascending prefix; equal geometry: drop
+                    while (j > 0 && seg[j - 1] > geom) --j;
+                    if (j > 0 && seg[j - 1] == geom) return;
+                    for (uint32_t t = m; t > j; --t) seg[t] = seg[t - 1];
+                    seg[j] = geom;
+                    ++m;
+                };
+                for (int h = 0; h < PIP_KHIT; ++h) put(s_hit[li * PIP_KHIT + h]);
+                for (uint32_t o = 0; o < novf; ++o) {
+                    const uint2 e = s_ovf[o];
+                    if (e.x == (uint32_t)li) put(e.y);
+                }
+                multi_pool[at] = m;
+                cnt = m;
+                if (m >= 1) first = seg[0];
+                if (m >= 2) pool_code = CODE_POOL | at;
+            }
+        }
+        if (!in_tile) continue;
         if (generic) {
             cnt = 0;
             if (dev::valid_row(pts.validity, i)) {
@@ -624,6 +907,7 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_PIP_MINWAVES) void pip_tile_kernel(D
     }
     if ((tid & 63) == 0 && wave_hits) atomicAdd(&s_tot, wave_hits);
     __syncthreads();
+    PIP_STAGE_CLK(5);
     if (tid == 0) {
         const unsigned long long tot = s_tot;
         block_tot[blockIdx.x] = tot;
@@ -1839,7 +2123,8 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
     pvj.slab_xy = right->d.xy;
     const bool chain = right_index->pip.R > 0 && right_index->pip.sub_aux != nullptr;
     const bool route = chain && !no_route && right_index->pip.route != nullptr && right_index->pip.R <= PIP_ROUTE_RMAX;
-    const int tile_points = chain ? 64 * (route ? ROUTE_PPT : CHAIN_PPT) : (lean ? LEAN_TILE : PIP_TILE);
+    const bool one_per_lane = !chain && !lean && right_index->pip.R > 0 && right_index->pip_list_heavy;  // (pip_tile_kernel<., ., 1>)
+    const int tile_points = chain ? 64 * (route ? ROUTE_PPT : CHAIN_PPT) : (lean ? LEAN_TILE : (one_per_lane ? PIP_BLOCK : PIP_TILE));
     const int64_t n_blocks = (n + tile_points - 1) / tile_points;
     const bool want_pairs = pair_capacity > 0;
     const size_t counts_bytes = sizeof(uint32_t) * (size_t)n;
@@ -1927,8 +2212,14 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         J_LAUNCH("gpk_pip_tile", pip_tile_lean_kernel, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d, right_index->v, pvj,
                  counts_dev, code, btot, stot, stats);
     else if (right_index->pip.R > 0)
-        if (right_index->pip.sub2)
+        if (right_index->pip.sub2 && one_per_lane)
+            J_LAUNCH("gpk_pip_tile", (pip_tile_kernel<true, true, 1>), dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
+                     right_index->v, pvj, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top, stats);
+        else if (right_index->pip.sub2)
             J_LAUNCH("gpk_pip_tile", (pip_tile_kernel<true, true>), dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
+                     right_index->v, pvj, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top, stats);
+        else if (one_per_lane)
+            J_LAUNCH("gpk_pip_tile", (pip_tile_kernel<true, false, 1>), dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
                      right_index->v, pvj, counts_dev, code, btot, stot, multi_pool, multi_cap, multi_top, stats);
         else
             J_LAUNCH("gpk_pip_tile", (pip_tile_kernel<true, false>), dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d,
@@ -2100,6 +2391,7 @@ int32_t gpk_index_describe(const gpk_index* idx, int64_t out[8]) {
     out[1] = idx->pip_lean;
     out[2] = idx->pip.sub_aux != nullptr;
     out[3] = idx->pip.route != nullptr;
+    out[4] = idx->pip_list_heavy;
     return GPK_OK;
 }
 

@@ -1121,6 +1121,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
     GPK_HIP(hipStreamSynchronize(s));
     pv.cell = cell;
     pv.list = list;
+    ix->pip_list_heavy = (int64_t)list_len * 4 > n_cells ? 1 : 0;
 
     stamp("cells");
     // ---- level 2 ------------------------------------------------------------------------------------

@@ -61,7 +61,7 @@ class SpatialIndex:
         """gpk_index_describe: which point-in-polygon tables the index carries (raster side, lean, chains, routing image)."""
         out = (C.c_int64 * 8)()
         _abi.check(_abi.lib().gpk_index_describe(self._h, out))
-        return {"R": int(out[0]), "lean": bool(out[1]), "chains": bool(out[2]), "route": bool(out[3])}
+        return {"R": int(out[0]), "lean": bool(out[1]), "chains": bool(out[2]), "route": bool(out[3]), "list_heavy": bool(out[4])}
 
     def free(self) -> None:
         if self._h:

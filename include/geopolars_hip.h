@@ -297,7 +297,8 @@ int32_t gpk_index_free(gpk_index* idx);
 int32_t gpk_index_nbytes(const gpk_index* idx, int64_t* out_bytes);
 /* What the index holds (tests and bench.py report it; nothing in a join depends on the caller knowing):
  *   out = {raster side R (0: no point-in-polygon tables), one-part-per-cell ("lean") 0/1, local chains 0/1 (`test` sub-cells
- *          decided from one or two ring edges in the owning lane), LDS routing image 0/1 (R <= 512), 0, 0, 0, 0} */
+ *          decided from one or two ring edges in the owning lane), LDS routing image 0/1 (R <= 512), entry lists dominate 0/1 (overlapping parts,
+ *          very many small parts: the general tile kernel runs one point per lane), 0, 0, 0} */
 int32_t gpk_index_describe(const gpk_index* idx, int64_t out[8]);
 
 /*

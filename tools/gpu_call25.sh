@@ -1,0 +1,17 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+T=r03zf
+( timeout 900 python -m pytest tests -m gpu -x -q -k "join or chain or config or index or pip or assembly or contains or edge or mixed or propert or fixture" ) > gpurun_out/${T}_tests.log 2>&1
+grep -a "passed\|failed" gpurun_out/${T}_tests.log | tail -3
+( GPK_NO_LEAN=1 GPK_NO_CHAINS=1 timeout 900 python -m pytest tests -m gpu -x -q -k "(join or config or pip or contains or edge or propert or mixed or assembly) and not chain and not full_size" ) > gpurun_out/${T}_tests_general.log 2>&1
+grep -a "passed\|failed" gpurun_out/${T}_tests_general.log | tail -3
+( GPK_NO_LEAN=1 GPK_NO_CHAINS=1 GPK_LIST_RECORDS=0 timeout 900 python -m pytest tests -m gpu -x -q -k "(join or config or pip or contains or edge or propert or mixed or assembly) and not chain and not full_size and not many_small" ) > gpurun_out/${T}_tests_general_nolrec.log 2>&1
+grep -a "passed\|failed" gpurun_out/${T}_tests_general_nolrec.log | tail -3
+timeout 400 python bench.py --config c5 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${T}_c5.log 2>&1
+grep -a '^{' gpurun_out/${T}_c5.log | python -c "
+import sys,json
+for l in sys.stdin:
+    d=json.loads(l); c=d['config']
+    print('c5 step', round(d['ms_per_step'],3), 'tile', c['kernel_ms_per_step']['gpk_pip_tile'], d['parity']['bit_exact'], c['index_full_variant'])
+"
+timeout 300 python tests/perf_configs.py --only tess 2>&1 | tail -1 | cut -c1-400
+GPK_NO_LEAN=1 GPK_NO_CHAINS=1 timeout 300 python tools/tile_time.py 2>&1 | tail -2
