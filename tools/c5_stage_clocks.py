@@ -35,7 +35,8 @@ assert lib.gpk_join_trace(buf, 16) == 0
 t = np.frombuffer(buf, dtype=np.uint64).astype(np.float64)[:6] * 10.0  # 100 MHz ticks -> ns
 names = ["points + level-1 words + records (stages A-D)", "pushes + entry lists (+ barrier)", "phase 2: scan of the queue", "phase 2: flattened edge pass",
          "phase 2: decide + holes (+ barrier)", "finalize (codes, pool, stores)"]
-tiles = (n + 511) // 512
+tile_points = 256 if index.describe()["list_heavy"] else 512
+tiles = (n + tile_points - 1) // tile_points
 print(f"{tiles} work-groups; summed critical path {t.sum() / 1e6:.1f} ms = {t.sum() / tiles / 1e3:.1f} us per work-group")
 for nm, v in zip(names, t):
     print(f"  {nm:50s} {v / tiles / 1e3:7.2f} us per work-group   {100 * v / t.sum():5.1f} %")
