@@ -56,9 +56,10 @@ def source_hash() -> str:
 
 def pmc_record(kernel: str):
     """Latest committed PMC traffic record for `kernel` whose source hash matches this tree (else None + reason)."""
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")))
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), key=os.path.getmtime)
     cur = source_hash()
-    for fn in reversed(cands):
+    stale = None
+    for fn in reversed(cands):  # any record measured at THIS tree's hash counts; otherwise name the newest one
         try:
             with open(fn) as f:
                 t = json.load(f)
@@ -68,15 +69,17 @@ def pmc_record(kernel: str):
             continue
         if t.get("source_hash") == cur:
             return t, None
-        return None, f"stale: {os.path.basename(fn)} was measured at source hash {t.get('source_hash')}, this tree is {cur} (re-run tools/profile_headline.sh)"
-    return None, "no PMC record for this kernel under profiles/"
+        if stale is None:
+            stale = f"stale: {os.path.basename(fn)} was measured at source hash {t.get('source_hash')}, this tree is {cur} (re-run tools/profile_headline.sh)"
+    return None, stale or "no PMC record for this kernel under profiles/"
 
 
 def pmc_config_record(config: str):
     """Raw / factor-corrected PMC traffic of a configuration's dominant kernel from the latest committed
     profiles/r*_pmc_traffic_configs.json whose source hash matches this tree (else None + reason)."""
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_configs.json")))
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_configs.json")), key=os.path.getmtime)
     cur = source_hash()
+    stale = None
     for fn in reversed(cands):
         try:
             with open(fn) as f:
@@ -84,12 +87,14 @@ def pmc_config_record(config: str):
         except Exception:
             continue
         if t.get("source_hash") != cur:
-            return None, f"stale: {os.path.basename(fn)} was measured at source hash {t.get('source_hash')}, this tree is {cur} (re-run tools/profile_configs.sh)"
+            if stale is None:
+                stale = f"stale: {os.path.basename(fn)} was measured at source hash {t.get('source_hash')}, this tree is {cur} (re-run tools/profile_configs.sh)"
+            continue
         r = t.get("configs", {}).get(config)
         if r is None:
             return None, f"{os.path.basename(fn)} holds no record for {config}"
         return r, f"raw FETCH_SIZE + WRITE_SIZE of {r['kernel']} per launch; with the 16-byte-stream read factor {t.get('read_factor_of_the_16_byte_stream')}: {r['traffic_bytes_with_read_factor']} B (gathers are tallied at 64 B per request: the truth lies between)"
-    return None, "no PMC record for this configuration under profiles/"
+    return None, stale or "no PMC record for this configuration under profiles/"
 
 
 def roofline_traffic(roofline: dict, config: str) -> dict:

@@ -1836,10 +1836,10 @@ __device__ __forceinline__ int64_t row_of_candidate(const int32_t* __restrict__ 
     }
     return lo;
 }
-// (four waves per SIMD: 128 registers — a 16-dword spill in the rare exact-arithmetic arm — instead of 141 and three waves; the kernel
-// waits on gathers of polygon coordinates most of the time)
+// (GPK_REFINE_MINWAVES=4 — 128 registers instead of 141, four waves per SIMD instead of three — was 4 % faster, 4.06 -> 3.90 ms, and wrote
+// 1.1 GB of spilled registers per launch to scratch memory, WRITE_SIZE 9.7 MB -> 1.14 GB: not taken)
 #ifndef GPK_REFINE_MINWAVES
-#define GPK_REFINE_MINWAVES 4
+#define GPK_REFINE_MINWAVES 1
 #endif
 __global__ __launch_bounds__(256, GPK_REFINE_MINWAVES) void pair_refine_kernel(DevGeo left, DevGeo right, const uint32_t* __restrict__ cand_l,
                                                            const uint32_t* __restrict__ cand_r, int64_t n_cand,
