@@ -2378,8 +2378,9 @@ int32_t gpk_join_trace(unsigned long long* out, int64_t n_words) {  // diagnosis
 
 int32_t gpk_index_free(gpk_index* idx) {
     if (!idx) return GPK_OK;
+    (void)hipDeviceSynchronize();  // (hipFree's implicit wait, once: a join enqueued against this index may still be running)
     for (int i = 0; i < 24; ++i)
-        if (idx->owned[i]) (void)hipFree(idx->owned[i]);
+        if (idx->owned[i]) cached_free(idx->owned[i]);
     delete idx;
     return GPK_OK;
 }
@@ -2463,11 +2464,11 @@ int32_t gpk_index_build_ex(const gpk_geoarray* a, int32_t parts, const double* b
     double4* bbox = nullptr;
     GridParams* grid = nullptr;
     int32_t* cell_off = nullptr;
-    IX_HIP(hipMalloc((void**)&bbox, sizeof(double4) * (size_t)(n > 0 ? n : 1)));
+    IX_HIP(cached_malloc((void**)&bbox, sizeof(double4) * (size_t)(n > 0 ? n : 1)));
     ix->owned[0] = bbox;
-    IX_HIP(hipMalloc((void**)&grid, sizeof(GridParams)));
+    IX_HIP(cached_malloc((void**)&grid, sizeof(GridParams)));
     ix->owned[1] = grid;
-    IX_HIP(hipMalloc((void**)&cell_off, sizeof(int32_t) * (size_t)(n_cells + 1)));
+    IX_HIP(cached_malloc((void**)&cell_off, sizeof(int32_t) * (size_t)(n_cells + 1)));
     ix->owned[2] = cell_off;
 
     // 1. bounding boxes (NodeEnvelope, spatial_index.rs:212-312) — or the caller's (the leaves another rank built and
@@ -2507,7 +2508,7 @@ int32_t gpk_index_build_ex(const gpk_geoarray* a, int32_t parts, const double* b
     if (total > (unsigned long long)INT32_MAX)
         return cleanup(fail(GPK_ERR_INVALID_OFFSETS, "spatial index directory overflows i32 (%llu entries)", total));
     int32_t* items = nullptr;
-    IX_HIP(hipMalloc((void**)&items, sizeof(int32_t) * (size_t)(total > 0 ? total : 1)));
+    IX_HIP(cached_malloc((void**)&items, sizeof(int32_t) * (size_t)(total > 0 ? total : 1)));
     ix->owned[3] = items;
     if (n > 0) {
         IX_LAUNCH("gpk_index_fill", grid_register_kernel<true>, grid_for(n, 256), dim3(256), 0, s, bbox, n, grid, cursor, items);

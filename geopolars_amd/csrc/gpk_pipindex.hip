@@ -854,7 +854,7 @@ struct Temps {  // scratch of the build: carved from the thread's auxiliary aren
         void* q = gpk::workspace_aux(1).take(bytes);
         if (!q) {
             const auto t0 = std::chrono::steady_clock::now();
-            hipError_t e = hipMalloc(&q, bytes);
+            hipError_t e = cached_malloc(&q, bytes);
             malloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             malloc_bytes += bytes;
             if (e != hipSuccess) return fail(GPK_ERR_OOM, "index build: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
@@ -865,7 +865,8 @@ struct Temps {  // scratch of the build: carved from the thread's auxiliary aren
     }
     ~Temps() {
         const auto t0 = std::chrono::steady_clock::now();
-        for (int i = 0; i < n; ++i) (void)hipFree(p[i]);
+        if (n) (void)hipDeviceSynchronize();  // (what hipFree did implicitly: no kernel of the build still reads a temporary)
+        for (int i = 0; i < n; ++i) cached_free(p[i]);
         if (getenv("GPK_DEBUG_INDEX"))
             fprintf(stderr, "[gpk] index build: %d temporaries beyond the arena (%.2f GB): hipMalloc %.3f ms, hipFree %.3f ms\n", n, (double)malloc_bytes / 1e9,
                     malloc_ms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
@@ -946,7 +947,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
     // ---- part / ring maps ----------------------------------------------------------------------
     uint32_t* part_geom = nullptr;
     if (d.type == GPK_GEOM_MULTIPOLYGON) {
-        GPK_HIP(hipMalloc((void**)&part_geom, sizeof(uint32_t) * (size_t)(n_parts ? n_parts : 1)));
+        GPK_HIP(cached_malloc((void**)&part_geom, sizeof(uint32_t) * (size_t)(n_parts ? n_parts : 1)));
         keep(part_geom);
         GPK_LAUNCH("gpk_pipidx_part_geom", part_geom_kernel, blocks_for(d.n_geoms), dim3(256), 0, s, d, part_geom);
     }
@@ -960,9 +961,9 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
     GPK_TRY(ring_bboxes(a, ring_bbox, s));
     stamp("ring maps + ring boxes");
     int32_t *row0 = nullptr, *nrows, *slab_base = nullptr;
-    GPK_HIP(hipMalloc((void**)&row0, sizeof(int32_t) * (size_t)n_rings));
+    GPK_HIP(cached_malloc((void**)&row0, sizeof(int32_t) * (size_t)n_rings));
     keep(row0);
-    GPK_HIP(hipMalloc((void**)&slab_base, sizeof(int32_t) * (size_t)(n_rings + 1)));
+    GPK_HIP(cached_malloc((void**)&slab_base, sizeof(int32_t) * (size_t)(n_rings + 1)));
     keep(slab_base);
     GPK_TRY(t.alloc(&nrows, (size_t)n_rings));
     unsigned long long* btot;
@@ -997,9 +998,9 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
         }
         GPK_TRY(t.alloc(&slab_cnt, (size_t)n_slabs + 1));
         GPK_TRY(t.alloc(&cursor, (size_t)n_slabs + 1));
-        if (slab_off) (void)hipFree(slab_off);
+        if (slab_off) cached_free(slab_off);  // (the stream was drained just above)
         ix->owned[slab_off_slot] = slab_off = nullptr;
-        GPK_HIP(hipMalloc((void**)&slab_off, sizeof(int32_t) * (size_t)(n_slabs + 1)));
+        GPK_HIP(cached_malloc((void**)&slab_off, sizeof(int32_t) * (size_t)(n_slabs + 1)));
         ix->owned[slab_off_slot] = slab_off;
         GPK_HIP(hipMemsetAsync(slab_cnt, 0, sizeof(int32_t) * (size_t)(n_slabs + 1), s));
         GPK_HIP(hipMemsetAsync(slab_off, 0, sizeof(int32_t) * (size_t)(n_slabs + 1), s));
@@ -1022,11 +1023,11 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
     if (const char* e = getenv("GPK_SLAB_COPY_MAX_MB")) copy_max = (size_t)atoll(e) << 20;
     const bool edge_copies = sizeof(double4) * (size_t)n_edges <= copy_max;
     if (edge_copies) {
-        GPK_HIP(hipMalloc((void**)&edges, sizeof(double4) * (size_t)(n_edges ? n_edges : 1)));
+        GPK_HIP(cached_malloc((void**)&edges, sizeof(double4) * (size_t)(n_edges ? n_edges : 1)));
         keep(edges);
         if ((int64_t)n_edges <= ((int64_t)64 << 20)) GPK_TRY(t.alloc(&slab_vidx, (size_t)(n_edges ? n_edges : 1)));
     } else {
-        GPK_HIP(hipMalloc((void**)&slab_vidx, sizeof(int32_t) * (size_t)n_edges));
+        GPK_HIP(cached_malloc((void**)&slab_vidx, sizeof(int32_t) * (size_t)n_edges));
         keep(slab_vidx);
     }
     GPK_LAUNCH("gpk_pipidx_slab_fill", slab_register_kernel<true>, blocks_for(d.n_coords), dim3(256), 0, s, d, gs, row0, slab_base,
@@ -1034,7 +1035,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
 
     stamp("slab fill (+ edges malloc)");
     PartInfo* part_info = nullptr;
-    GPK_HIP(hipMalloc((void**)&part_info, sizeof(PartInfo) * (size_t)(n_parts ? n_parts : 1)));
+    GPK_HIP(cached_malloc((void**)&part_info, sizeof(PartInfo) * (size_t)(n_parts ? n_parts : 1)));
     keep(part_info);
     GPK_LAUNCH("gpk_pipidx_part_info", part_info_kernel, blocks_for(n_parts), dim3(256), 0, s, d, n_parts, row0, slab_base, part_info);
 
@@ -1101,7 +1102,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
     stamp("mark fill + sort + unique");
     // ---- cells ----------------------------------------------------------------------------------
     uint32_t* cell = nullptr;
-    GPK_HIP(hipMalloc((void**)&cell, sizeof(uint32_t) * (size_t)n_cells));
+    GPK_HIP(cached_malloc((void**)&cell, sizeof(uint32_t) * (size_t)n_cells));
     keep(cell);
     int32_t *need, *list_off;
     GPK_TRY(t.alloc(&need, (size_t)n_cells + 1));
@@ -1114,7 +1115,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
     GPK_HIP(hipStreamSynchronize(s));
     if ((unsigned)list_len >= (1u << 30)) return GPK_OK;
     uint32_t* list = nullptr;
-    GPK_HIP(hipMalloc((void**)&list, sizeof(uint32_t) * (size_t)(list_len ? list_len : 1)));
+    GPK_HIP(cached_malloc((void**)&list, sizeof(uint32_t) * (size_t)(list_len ? list_len : 1)));
     keep(list);
     GPK_LAUNCH("gpk_pipidx_cell_fill", cell_build_kernel<true>, blocks_for(n_cells), dim3(256), 0, s, d, ix->v, pv, g, marks, n_marks,
                need, list_off, cell, list);
@@ -1156,7 +1157,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
         if (getenv("GPK_DEBUG_INDEX")) fprintf(stderr, "[gpk] level 2: %d one-part cells, %d two-part cells of %lld\n", n_sub, n_sub2, (long long)n_cells);
         if ((int64_t)n_sub2 < 4 * (int64_t)n_sub) n_sub2 = 0;
         if (n_sub > 0) {
-            GPK_HIP(hipMalloc((void**)&sub, sizeof(SubCell) * (size_t)n_sub));
+            GPK_HIP(cached_malloc((void**)&sub, sizeof(SubCell) * (size_t)n_sub));
             keep(sub);
             GPK_HIP(hipMemsetAsync(sub, 0, sizeof(SubCell) * (size_t)n_sub, s));
             GPK_TRY(t.alloc(&swork_cell, (size_t)n_sub));
@@ -1170,7 +1171,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
                        (const int32_t*)swork_cell, (const uint32_t*)swork_part, (int64_t)n_sub);
         }
         if (n_sub2 > 0) {
-            GPK_HIP(hipMalloc((void**)&sub2, sizeof(SubCell2) * (size_t)n_sub2));
+            GPK_HIP(cached_malloc((void**)&sub2, sizeof(SubCell2) * (size_t)n_sub2));
             keep(sub2);
             GPK_HIP(hipMemsetAsync(sub2, 0, sizeof(SubCell2) * (size_t)n_sub2, s));
             GPK_LAUNCH("gpk_pipidx_sub2_build", sub_build_kernel<2>, blocks_for(n_cells * PIP_SUB * PIP_SUB), dim3(256), 0, s, d, pv, g, sflag2, spos2,
@@ -1203,7 +1204,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
             uint32_t* work_part;
             GPK_TRY(t.alloc(&work_cell, (size_t)n_lrec));
             GPK_TRY(t.alloc(&work_part, (size_t)n_lrec));
-            GPK_HIP(hipMalloc((void**)&lrec, sizeof(SubCell) * (size_t)n_lrec));
+            GPK_HIP(cached_malloc((void**)&lrec, sizeof(SubCell) * (size_t)n_lrec));
             keep(lrec);
             GPK_HIP(hipMemsetAsync(lrec, 0, sizeof(SubCell) * (size_t)n_lrec, s));
             GPK_LAUNCH("gpk_pipidx_lrec_assign", lrec_assign_kernel, blocks_for(n_cells), dim3(256), 0, s, (const uint32_t*)cell, list, n_cells,
@@ -1222,7 +1223,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
     pv.lrec = lrec;
     if (list_len > 0 && !lrec && !getenv("GPK_NO_PART_BOX")) {  // plain entry lists: a box per part rejects most (point, entry) pairs early
         float4* part_box = nullptr;
-        GPK_HIP(hipMalloc((void**)&part_box, sizeof(float4) * (size_t)(n_parts ? n_parts : 1)));
+        GPK_HIP(cached_malloc((void**)&part_box, sizeof(float4) * (size_t)(n_parts ? n_parts : 1)));
         keep(part_box);
         GPK_LAUNCH("gpk_pipidx_part_box", part_box_kernel, blocks_for(n_parts), dim3(256), 0, s, d, n_parts, (const double4*)ring_bbox, part_box);
         pv.part_box = part_box;
@@ -1249,10 +1250,10 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
         GPK_HIP(hipStreamSynchronize(s));
         if (n_aux > 0) {
             ChainAux* aux = nullptr;
-            GPK_HIP(hipMalloc((void**)&aux, sizeof(ChainAux) * (size_t)n_aux));
+            GPK_HIP(cached_malloc((void**)&aux, sizeof(ChainAux) * (size_t)n_aux));
             keep(aux);
             uint32_t* chead = nullptr;
-            GPK_HIP(hipMalloc((void**)&chead, sizeof(uint32_t) * (size_t)n_aux));
+            GPK_HIP(cached_malloc((void**)&chead, sizeof(uint32_t) * (size_t)n_aux));
             keep(chead);
             int32_t *ext_need, *ext_off;
             uint32_t* first_at;
@@ -1269,7 +1270,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
             GPK_HIP(hipMemcpyAsync(&n_ext, ext_off + n_aux, sizeof n_ext, hipMemcpyDeviceToHost, s));
             GPK_HIP(hipStreamSynchronize(s));
             double2* ext = nullptr;
-            GPK_HIP(hipMalloc((void**)&ext, sizeof(double2) * (size_t)(n_ext > 0 ? n_ext : 1)));
+            GPK_HIP(cached_malloc((void**)&ext, sizeof(double2) * (size_t)(n_ext > 0 ? n_ext : 1)));
             keep(ext);
             if (n_ext > 0)
                 GPK_LAUNCH("gpk_pipidx_chain_ext", chain_ext_kernel, blocks_for(n_aux), dim3(256), 0, s, d, chead, (const uint32_t*)first_at, (int64_t)n_aux,
@@ -1284,7 +1285,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
             if (R <= PIP_ROUTE_RMAX && !getenv("GPK_NO_ROUTE_IMAGE")) {
                 RouteWord* route = nullptr;
                 const int64_t n_words = n_cells / 32;
-                GPK_HIP(hipMalloc((void**)&route, sizeof(RouteWord) * (size_t)n_words));
+                GPK_HIP(cached_malloc((void**)&route, sizeof(RouteWord) * (size_t)n_words));
                 keep(route);
                 GPK_LAUNCH("gpk_pipidx_route", route_build_kernel, blocks_for(n_words), dim3(256), 0, s, (const uint32_t*)cell, n_words, route);
                 pv.route = route;

@@ -2,7 +2,9 @@
 // scratch arena, HIP-event profiling of every launch, device checks and the "copy once to HBM"
 // upload (include/geopolars_hip.h: gpk_geoarray_upload replaces the per-op row decode of
 // geopolars/geopolars-geo/src/util.rs:27-37).
+#include <map>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "gpk_common.h"
@@ -23,6 +25,99 @@ int32_t fail(int32_t code, const char* fmt, ...) {
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
     return code;
+}
+
+// ---- cached device blocks -------------------------------------------------------------------------
+namespace {
+struct BlockCache {
+    std::mutex mu;
+    std::unordered_map<void*, std::pair<size_t, int>> live;  // block -> (bytes, device), for blocks handed out by cached_malloc
+    std::multimap<size_t, std::pair<void*, int>> idle;       // bytes -> (block, device)
+    size_t idle_bytes = 0;
+    size_t budget() {
+        static const size_t b = [] {
+            if (const char* e = getenv("GPK_DEVICE_CACHE_MB")) return (size_t)atoll(e) << 20;
+            size_t free_b = 0, total_b = 0;  // default: a sixteenth of the device's memory, 16 GB at most
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = size_t(64) << 30;
+            const size_t cap = size_t(16) << 30;
+            return total_b / 16 < cap ? total_b / 16 : cap;
+        }();
+        return b;
+    }
+    void release_all_locked() {
+        for (auto& kv : idle) (void)hipFree(kv.second.first);
+        idle.clear();
+        idle_bytes = 0;
+    }
+};
+BlockCache& block_cache() {
+    static BlockCache* c = new BlockCache;  // (never destroyed: blocks may be released during process teardown)
+    return *c;
+}
+}  // namespace
+
+hipError_t cached_malloc(void** p, size_t bytes) {
+    BlockCache& c = block_cache();
+    if (bytes == 0) bytes = 1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> g(c.mu);
+        for (auto it = c.idle.lower_bound(bytes); it != c.idle.end() && it->first <= bytes + bytes / 4 + 4096; ++it) {
+            if (it->second.second != dev) continue;
+            *p = it->second.first;
+            c.live[*p] = {it->first, dev};
+            c.idle_bytes -= it->first;
+            c.idle.erase(it);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {  // give the idle blocks back and try once more
+        (void)hipGetLastError();
+        {
+            std::lock_guard<std::mutex> g(c.mu);
+            c.release_all_locked();
+        }
+        e = hipMalloc(p, bytes);
+    }
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> g(c.mu);
+        c.live[*p] = {bytes, dev};
+    }
+    return e;
+}
+void cached_free(void* p) {
+    if (!p) return;
+    BlockCache& c = block_cache();
+    std::unique_lock<std::mutex> g(c.mu);
+    auto it = c.live.find(p);
+    if (it == c.live.end()) {  // not one of ours
+        g.unlock();
+        (void)hipFree(p);
+        return;
+    }
+    const size_t bytes = it->second.first;
+    const int dev = it->second.second;
+    c.live.erase(it);
+    if (bytes > c.budget()) {
+        g.unlock();
+        (void)hipFree(p);
+        return;
+    }
+    while (c.idle_bytes + bytes > c.budget() && !c.idle.empty()) {  // make room: the largest idle block goes first
+        auto last = std::prev(c.idle.end());
+        (void)hipFree(last->second.first);
+        c.idle_bytes -= last->first;
+        c.idle.erase(last);
+    }
+    c.idle.emplace(bytes, std::make_pair(p, dev));
+    c.idle_bytes += bytes;
+}
+void cached_release_all() {
+    BlockCache& c = block_cache();
+    std::lock_guard<std::mutex> g(c.mu);
+    c.release_all_locked();
 }
 
 // ---- workspace ---------------------------------------------------------------------------------
@@ -195,6 +290,12 @@ int32_t gpk_last_error(char* buf, size_t cap) {
     if (!buf || cap == 0) return GPK_ERR_INVALID_ARGUMENT;
     strncpy(buf, g_err, cap - 1);
     buf[cap - 1] = 0;
+    return GPK_OK;
+}
+
+int32_t gpk_device_cache_release(void) {
+    (void)hipDeviceSynchronize();
+    gpk::cached_release_all();
     return GPK_OK;
 }
 

@@ -99,6 +99,11 @@ int32_t gpk_last_error(char* buf, size_t cap);
 int32_t gpk_device_count(int32_t* out_n);
 /* name + CU count of the current HIP device; fails with GPK_ERR_DEVICE when it is not gfx950 */
 int32_t gpk_device_info(char* name_buf, size_t cap, int32_t* out_cus);
+/* Index tables and build temporaries are recycled through a cache of device blocks inside the library (a freed index's tables serve
+ * the next build: SpatialIndex values come and go with the dataframe pipeline, spatial_index.rs:37-71, and hipMalloc / hipFree of
+ * gigabytes cost up to hundreds of milliseconds).  The cache holds at most GPK_DEVICE_CACHE_MB (default: a sixteenth of the device's
+ * memory, 16 GB at most; 0 = no cache); this call hands every idle block back to the driver now. */
+int32_t gpk_device_cache_release(void);
 
 /* ---- "copied once to HBM as SoA" ---------------------------------------------------------- */
 /* replaces the per-op row decode of util.rs:27-37 (iter_geom) */

@@ -318,3 +318,25 @@ def test_stream_ordered_joins_on_two_streams_of_one_thread_do_not_share_scratch(
         h = join_pairs_device(j["pts"], polys, index, "intersects", counts, pairs, stream=s0)
         assert int(j["total"].item()) == h
         assert torch.equal(j["counts"], counts) and torch.equal(j["pairs"][:h], pairs[:h])
+
+
+def test_index_tables_are_recycled_and_released(gpk, oracle):
+    """gpk_index_free keeps an index's device blocks for the next build (no hipMalloc / hipFree per table); the joins answer the same
+    before and after, with the cache switched through gpk_device_cache_release in between"""
+    from geopolars_amd import _abi
+
+    polys, pts = synth.star_polygons(300, 32), synth.uniform_points(50_000, seed=9)
+    ps, qs = GeoSeries(pts), GeoSeries(polys)
+    ep, ec, _ = oracle.spatial_join(pts, polys, "intersects", mode=1)
+    for rep in range(4):
+        ix = SpatialIndex(qs)
+        pairs, counts = join_pairs(ps, qs, "intersects", r_index=ix)
+        assert np.array_equal(counts, ec) and np.array_equal(pairs, ep)
+        ix.free()
+        if rep == 1:
+            _abi.check(_abi.lib().gpk_device_cache_release())
+    # two live indexes never share a block
+    a, b = SpatialIndex(qs), SpatialIndex(qs)
+    pa, ca = join_pairs(ps, qs, "intersects", r_index=a)
+    pb, cb = join_pairs(ps, qs, "intersects", r_index=b)
+    assert np.array_equal(pa, ep) and np.array_equal(pb, ep) and np.array_equal(ca, ec) and np.array_equal(cb, ec)
