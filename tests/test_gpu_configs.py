@@ -220,3 +220,19 @@ def test_many_small_parts_index_variants(gpk, oracle):
     p2, c2 = join_pairs(ps, ms, "within", r_index=full)
     assert np.array_equal(p2, pairs) and np.array_equal(c2, counts)
     assert full.nbytes() > ix.nbytes()
+
+
+def test_c5_full_size_sampled(gpk, oracle):
+    """C5 as quoted per GPU: 6.25M points within ALL 5M power-law multipolygons (8 chunks of 625k, as bench.py builds them) — 200k
+    random rows against the oracle, the size-independent properties of the pair list on all of it, area() of all 5M rows."""
+    mp = GeoArrowArray.concat([synth.powerlaw_multipolygons(625_000, seed=51 + k, size_n=5_000_000) for k in range(8)])
+    pts = synth.uniform_points(6_250_000, seed=52)
+    ms, ps = GeoSeries(mp), GeoSeries(pts)
+    ix = SpatialIndex(ms)
+    d = ix.describe()
+    assert d["R"] == 4096 and d["list_heavy"] and not d["lean"]
+    pairs, counts = join_pairs(ps, ms, "within", r_index=ix)
+    assert counts.max() >= 2 and len(pairs) > 1_500_000
+    _check_join_sample(oracle, pts, mp, "within", pairs, counts, 200_000, 13)
+    area, exp = ms.area(), oracle.area(mp)
+    assert np.all(np.abs(area - exp) <= 1e-9 * np.maximum(np.abs(exp), 1e-300))
