@@ -101,12 +101,16 @@ def roofline_traffic(roofline: dict, config: str) -> dict:
     r, note = pmc_config_record(config)
     roofline["traffic"] = r["traffic_bytes_raw"] if r else None
     roofline["traffic_note"] = note
-    if r and r.get("valu_wave_instructions_per_launch") and roofline.get("launch_ms") and "valu" not in roofline:
+    if r and r.get("valu_wave_instructions_per_launch") and roofline.get("launch_ms"):
         # a second roofline for kernels that are not bandwidth-bound: vector instructions issued (SQ_INSTS_VALU, one per wave of 64
         # lanes) against the f64 issue rate — an upper bound on what arithmetic could explain
         lane_rate = r["valu_wave_instructions_per_launch"] * 64.0 / (roofline["launch_ms"] * 1e-3)
-        roofline["valu"] = {"wave_instructions_per_launch": r["valu_wave_instructions_per_launch"], "achieved_lane_instr_per_s": lane_rate, "peak": F64_VALU_PEAK,
-                            "frac": lane_rate / F64_VALU_PEAK, "salu_wave_instructions_per_launch": r.get("salu_wave_instructions_per_launch")}
+        issued = {"wave_instructions_per_launch": r["valu_wave_instructions_per_launch"], "achieved_lane_instr_per_s": lane_rate, "peak": F64_VALU_PEAK,
+                  "frac": lane_rate / F64_VALU_PEAK, "salu_wave_instructions_per_launch": r.get("salu_wave_instructions_per_launch")}
+        if "valu" not in roofline:
+            roofline["valu"] = issued
+        else:  # the configuration states its own arithmetic roofline (useful instructions): the issued ones go next to it
+            roofline["valu"]["issued"] = issued
     return roofline
 
 

@@ -139,9 +139,12 @@ __device__ inline int coord_pos_ring_group(const double2* __restrict__ ring, int
         return (cx == s.x && cy == s.y) ? dev::POS_BOUNDARY : dev::POS_OUTSIDE;
     }
     int wn = 0, on = 0;
-    for (int i = lane; i + 1 < n; i += G) {
-        const double2 s = ring[i], e = ring[i + 1];
+    for (int i = lane; i + 1 < n; i += 2 * G) {  // two edges per trip, both requested before either is evaluated
+        const int i2 = i + G;
+        const bool two = i2 + 1 < n;
+        const double2 s = ring[i], e = ring[i + 1], s2 = ring[two ? i2 : i], e2 = ring[two ? i2 + 1 : i + 1];
         on |= dev::ring_edge(s.x, s.y, e.x, e.y, cx, cy, wn) ? 1 : 0;
+        if (two) on |= dev::ring_edge(s2.x, s2.y, e2.x, e2.y, cx, cy, wn) ? 1 : 0;
     }
     {  // one packed reduction: winding sum in the high half, on-boundary count in the low half
         const int packed = dev::group_sum<G>(wn * 65536 + on);
@@ -334,6 +337,7 @@ __device__ inline bool polygon_pair_small(const double2* __restrict__ axy, int n
                                           PairSmallLds* __restrict__ t) {
     // (the caller has checked: 1 <= na, nb <= PP_SMALL; ea / eb = the rings' boxes)
     if (ea.z < eb.x || ea.w < eb.y || eb.z < ea.x || eb.w < ea.y) return false;  // has_disjoint_bboxes
+    // (all rounds of both rings requested up front — five fixed rounds of clamped loads — was slower: 3.74 against 3.67 ms)
     for (int i = lane; i < na; i += G) t->a[i] = axy[i];
     for (int i = lane; i < nb; i += G) t->b[i] = bxy[i];
     const int gbase = (int)(threadIdx.x & 63) & ~(G - 1);
@@ -347,16 +351,18 @@ __device__ inline bool polygon_pair_small(const double2* __restrict__ axy, int n
     // window clipping: a segment of one ring can only meet the other ring inside the other ring's box
     auto clip = [&](const double2* ring, int n, const double4& box, uint8_t* list) {
         int m = 0;
-        for (int i0 = 0; i0 + 1 < n; i0 += G) {
-            const int i = i0 + lane;
-            bool keep = false;
-            if (i + 1 < n) {
-                const double2 q0 = ring[i], q1 = ring[i + 1];
-                keep = !(fmax(q0.x, q1.x) < box.x || fmin(q0.x, q1.x) > box.z || fmax(q0.y, q1.y) < box.y || fmin(q0.y, q1.y) > box.w);
-            }
+        for (int i0 = 0; i0 + 1 < n; i0 += 2 * G) {  // two rounds per trip: four LDS reads in flight instead of two
+            const int i = i0 + lane, i2 = i + G;
+            const bool in1 = i + 1 < n, in2 = i2 + 1 < n;
+            const double2 q0 = ring[in1 ? i : 0], q1 = ring[in1 ? i + 1 : 0], r0 = ring[in2 ? i2 : 0], r1 = ring[in2 ? i2 + 1 : 0];
+            const bool keep = in1 && !(fmax(q0.x, q1.x) < box.x || fmin(q0.x, q1.x) > box.z || fmax(q0.y, q1.y) < box.y || fmin(q0.y, q1.y) > box.w);
+            const bool keep2 = in2 && !(fmax(r0.x, r1.x) < box.x || fmin(r0.x, r1.x) > box.z || fmax(r0.y, r1.y) < box.y || fmin(r0.y, r1.y) > box.w);
             const unsigned long long mine = (__ballot(keep) >> gbase) & gmask_all;
             if (keep) list[m + __popcll(mine & ((1ull << lane) - 1ull))] = (uint8_t)i;
             m += __popcll(mine);
+            const unsigned long long mine2 = (__ballot(keep2) >> gbase) & gmask_all;
+            if (keep2) list[m + __popcll(mine2 & ((1ull << lane) - 1ull))] = (uint8_t)i2;
+            m += __popcll(mine2);
         }
         return m;
     };
@@ -372,15 +378,19 @@ __device__ inline bool polygon_pair_small(const double2* __restrict__ axy, int n
             bool found = false;
             if (active) {
                 const int e1 = e0 + PP_VOTE < mb ? e0 + PP_VOTE : mb;
-                for (int e = e0; e < e1; ++e) {
-                    const int ib = (int)t->lb[e];
-                    const double2 q0 = t->b[ib], q1 = t->b[ib + 1];
-                    if (fmax(q0.x, q1.x) < plx || fmin(q0.x, q1.x) > phx || fmax(q0.y, q1.y) < ply || fmin(q0.y, q1.y) > phy) continue;
-                    if (line_intersects_line(p0, p1, q0, q1)) {
-                        found = true;
-                        break;
-                    }
-                }
+                // the PP_VOTE entries of a trip are requested together before any is tested (an entry is two dependent LDS reads — index,
+                // then coordinates — and three waves per SIMD do not hide them: one entry per trip 4.07 ms, two 3.76 ms)
+                static_assert(PP_VOTE == 4, "the cross test is written for four entries per vote");
+                const int last = e1 - 1;
+                const int i0 = (int)t->lb[e0], i1 = (int)t->lb[e0 + 1 < last ? e0 + 1 : last], i2 = (int)t->lb[e0 + 2 < last ? e0 + 2 : last], i3 = (int)t->lb[last];
+                const double2 qa0 = t->b[i0], qa1 = t->b[i0 + 1], qb0 = t->b[i1], qb1 = t->b[i1 + 1];
+                const double2 qc0 = t->b[i2], qc1 = t->b[i2 + 1], qd0 = t->b[i3], qd1 = t->b[i3 + 1];
+                auto meets = [&](const double2 q0, const double2 q1) {
+                    if (fmax(q0.x, q1.x) < plx || fmin(q0.x, q1.x) > phx || fmax(q0.y, q1.y) < ply || fmin(q0.y, q1.y) > phy) return false;
+                    return line_intersects_line(p0, p1, q0, q1);
+                };
+                // (entries past the list's end repeat its last one: the same answer again)
+                found = meets(qa0, qa1) || meets(qb0, qb1) || meets(qc0, qc1) || meets(qd0, qd1);
             }
             hit = group_any<G>(found);
         }

@@ -455,6 +455,8 @@ __device__ __forceinline__ void seg_step(SegState& st, double2 b, double px, dou
     best_v = vmin_f64(best_v, nb2);
     sum_d2 += d2;  // >= the longest segment: bounds how close a point upstream calls "on the linestring" can be (below)
     const double c2 = cross * cross;
+    // (as a branch: written with selects — no exec-mask bookkeeping — the kernel is 28 % SLOWER: whole waves skip the update on most
+    // segments once the nearest one has been met)
     if (dot > 0.0 && dot < d2 && c2 * best_i.den < best_i.num * d2) {  // projection inside the segment, and nearer
         best_i.num = c2;
         best_i.den = d2;
@@ -540,8 +542,19 @@ __global__ __launch_bounds__(256) void distance_grouped_kernel(DevGeo pts, DevGe
                         if (nv > 1 || na2 == 0.0) best_v = na2;
                     }
                     const int kmax = nv - 1 - w0 < DC_K ? nv - 1 - w0 : DC_K;
-#pragma unroll 2
-                    for (int k = 1; k <= kmax; ++k) seg_step(st, sv[slot + k], p.x, p.y, best_v, best_i, sum_d2);
+                    // two segments per trip, the next trip's first vertex requested before this trip's arithmetic (the loop used to wait
+                    // for its ds_read at the top of every segment and rotate its state through four 64-bit moves); the read past the last
+                    // vertex stays inside the window's slot (DC_SLOT = DC_K + 2 entries)
+                    int k = 1;
+                    double2 b0 = sv[slot + 1];
+                    for (; k + 1 <= kmax; k += 2) {
+                        const double2 b1 = sv[slot + k + 1];
+                        const double2 n0 = sv[slot + k + 2];
+                        seg_step(st, b0, p.x, p.y, best_v, best_i, sum_d2);
+                        seg_step(st, b1, p.x, p.y, best_v, best_i, sum_d2);
+                        b0 = n0;
+                    }
+                    if (k <= kmax) seg_step(st, b0, p.x, p.y, best_v, best_i, sum_d2);
                 }
             }
         }
