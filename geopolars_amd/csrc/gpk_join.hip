@@ -1703,13 +1703,19 @@ __device__ __forceinline__ void for_each_bbox_candidate(const IndexView& ix, con
     for (int cy = cy0; cy <= cy1; ++cy)
         for (int cx = cx0; cx <= cx1; ++cx) {
             const int c = cy * g.gx + cx;
-            for (int k = ix.cell_off[c]; k < ix.cell_off[c + 1]; ++k) {
-                const int j = ix.items[k];
-                const double4 rb = ix.bbox[j];
-                if (lb.z < rb.x || lb.w < rb.y || rb.z < lb.x || rb.w < lb.y) continue;  // closed-interval overlap test
+            auto visit = [&](int j, const double4 rb) {
+                if (lb.z < rb.x || lb.w < rb.y || rb.z < lb.x || rb.w < lb.y) return;  // closed-interval overlap test
                 const double rx = lb.x > rb.x ? lb.x : rb.x, ry = lb.y > rb.y ? lb.y : rb.y;
-                if (dev::cell_of(rx, g.x0, g.inv_w, g.gx) != cx || dev::cell_of(ry, g.y0, g.inv_h, g.gy) != cy) continue;
+                if (dev::cell_of(rx, g.x0, g.inv_w, g.gx) != cx || dev::cell_of(ry, g.y0, g.inv_h, g.gy) != cy) return;
                 f(j);
+            };
+            const int k1 = ix.cell_off[c + 1];
+            for (int k = ix.cell_off[c]; k < k1; k += 2) {  // two items per trip: both ids, then both boxes, in flight together
+                const bool two = k + 1 < k1;
+                const int j0 = ix.items[k], j1 = ix.items[two ? k + 1 : k];
+                const double4 b0 = ix.bbox[j0], b1 = ix.bbox[j1];
+                visit(j0, b0);
+                if (two) visit(j1, b1);
             }
         }
 }
@@ -1769,14 +1775,7 @@ __global__ __launch_bounds__(256) void bbox_cand_stage_kernel(DevGeo left, DevGe
         const GridParams g = *ix.grid;
         for_each_bbox_candidate(ix, g, lbbox[i], [&](int j) {
             if (!dev::valid_row(right.validity, j)) return;
-            if (cnt < CAND_STAGE) {  // insertion into the ascending prefix (a handful of entries in the thread's own 64-byte line)
-                int b = cnt - 1;
-                while (b >= 0 && mine[b] > (uint32_t)j) {
-                    mine[b + 1] = mine[b];
-                    --b;
-                }
-                mine[b + 1] = (uint32_t)j;
-            }
+            if (cnt < CAND_STAGE) mine[cnt] = (uint32_t)j;  // (in directory order: cand_compact_kernel sorts the slice across its 16 lanes)
             ++cnt;
         });
     }
@@ -1797,8 +1796,21 @@ __global__ __launch_bounds__(256) void cand_compact_kernel(DevGeo left, DevGeo r
     const int cnt = cand_cnt[i];
     const int64_t o0 = (int64_t)cand_off[i];
     if (cnt <= CAND_STAGE) {
+        // the row's slice, sorted by right id across the row's CAND_STAGE lanes: a bitonic network of ten shuffle steps (the count
+        // pass used to keep the slice sorted by insertion — a chain of dependent global loads per candidate)
+        static_assert(CAND_STAGE == 16, "the sorting network below is written for 16 lanes per row");
+        uint32_t v = j < cnt ? stage[t] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 2; k <= CAND_STAGE; k <<= 1) {
+#pragma unroll
+            for (int d = k >> 1; d > 0; d >>= 1) {
+                const uint32_t w = __shfl_xor(v, d, CAND_STAGE);
+                const bool keep_min = ((j & d) == 0) == ((j & k) == 0);
+                v = keep_min ? (v < w ? v : w) : (v > w ? v : w);
+            }
+        }
         if (j < cnt) {
-            cand_r[o0 + j] = stage[t];
+            cand_r[o0 + j] = v;
             cand_l[o0 + j] = (uint32_t)i;
         }
         return;

@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-T=r03u6
+T=r03u8
 ( timeout 900 python -m pytest tests -m gpu -x -q -k "(join or contains or config or propert or edge or mixed) and not full_size and not c5 and not c3 and not c2" ) > gpurun_out/${T}_tests.log 2>&1
 grep -a "passed\|failed" gpurun_out/${T}_tests.log | tail -3
 for v in staged; do

@@ -5,6 +5,7 @@
 TAG=${1:-rXX}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 cd $R
 ( time timeout 900 python -m pytest tests -m gpu -q ) > $O/${TAG}_gputests.log 2>&1; tail -3 $O/${TAG}_gputests.log
+( time timeout 600 python tests/stress_sweep.py ) > $O/${TAG}_stress_sweep.log 2>&1; tail -2 $O/${TAG}_stress_sweep.log
 bash tools/profile_headline.sh $TAG
 bash tools/profile_configs.sh $TAG; cd $R   # traffic + instruction counts of the dominant kernels of C3 / C4 / C5 -> profiles/<tag>_pmc_traffic_configs.json
 for c in c2 c3 c4 c5; do
