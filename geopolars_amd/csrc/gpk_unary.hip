@@ -405,12 +405,26 @@ __device__ __forceinline__ void seq_stats_group_body(const double2* __restrict__
         // vertex (DPP row shift), and for the group's last lane the first lane's vertex of the NEXT round, which is
         // prefetched one round ahead anyway.  Trip count is uniform within the group (all its lanes stay active for DPP).
         constexpr bool EDGES = (MASK & (M_AREA | M_CENT | M_LEN | M_LENC)) != 0;
+        // Two-lane groups (sequences of at most 16 coordinates: eight rounds at most) request ALL their vertices before the first round:
+        // with one round of look-ahead every round still waited a full memory round trip for a few flops — the class ran at 2.3 TB/s
+        // against 4.9 for the 8- and 16-lane ones.
+        // (four rounds in flight, not all nine: the classes share one kernel, and nine held vertices took its register count from 52 to
+        // 72 — the 8- and 16-lane classes lost a wave of occupancy and 8 % of their speed)
+        constexpr int PRE = PAIR ? SEQ_MAXLEN[0] / G + 1 : 1, AHEAD = 4;
+        double2 pre[PRE];
+        auto vertex_of_round = [&](int t) {
+            const int idx = c0 + lane + t * G;
+            return idx < c1 ? xy[idx] : make_double2(0.0, 0.0);
+        };
+        if (PAIR) {
+#pragma unroll
+            for (int t = 0; t < PRE; ++t) pre[t] = t < AHEAD ? vertex_of_round(t) : make_double2(0.0, 0.0);
+        }
         int i = c0 + lane;
-        double2 cur = i < c1 ? xy[i] : make_double2(0.0, 0.0);
+        double2 cur = PAIR ? pre[0] : (i < c1 ? xy[i] : make_double2(0.0, 0.0));
         double2 held = cur;  // PAIR: the last vertex this lane loaded
         if (PAIR) first = make_double2(dev::dpp_mov<0xA0>(cur.x), dev::dpp_mov<0xA0>(cur.y));  // quad_perm [0,0,2,2]: lane 0's vertex
-        for (int base = c0; base < c1; base += G, i += G) {
-            const double2 nxt = i + G < c1 ? xy[i + G] : make_double2(0.0, 0.0);
+        auto round = [&](const double2 nxt) {
             const double2 p = cur;
             if (PAIR && i < c1) held = p;
             double2 q = make_double2(0.0, 0.0);
@@ -420,7 +434,7 @@ __device__ __forceinline__ void seq_stats_group_body(const double2* __restrict__
                 q = lane == G - 1 ? make_double2(bx, by) : make_double2(ax, ay);
             }
             cur = nxt;
-            if (i >= c1) continue;
+            if (i >= c1) return;
             if (MASK & M_BBOX) {
                 mnx = p.x < mnx ? p.x : mnx;
                 mny = p.y < mny ? p.y : mny;
@@ -448,6 +462,62 @@ __device__ __forceinline__ void seq_stats_group_body(const double2* __restrict__
                     if (MASK & M_LENC) {
                         lmx += (p.x + q.x) / 2.0 * l;
                         lmy += (p.y + q.y) / 2.0 * l;
+                    }
+                }
+            }
+        };
+        if constexpr (PAIR) {
+#pragma unroll
+            for (int t = 0; t < PRE - 1; ++t) {
+                if (c0 + t * G >= c1) break;
+                if (t + AHEAD < PRE) pre[t + AHEAD] = vertex_of_round(t + AHEAD);
+                round(pre[t + 1]);
+                i += G;
+            }
+        } else {  // (the loop as it was: the same body through the lambda cost the 8- and 16-lane classes 5 - 9 %)
+            double2 n1 = i + G < c1 ? xy[i + G] : make_double2(0.0, 0.0);  // (two rounds ahead: one more vertex in flight per lane; a third: no gain)
+            for (int base = c0; base < c1; base += G, i += G) {
+                const double2 n2 = i + 2 * G < c1 ? xy[i + 2 * G] : make_double2(0.0, 0.0);
+                const double2 nxt = n1;
+                n1 = n2;
+                const double2 p = cur;
+                if (PAIR && i < c1) held = p;
+                double2 q = make_double2(0.0, 0.0);
+                if (EDGES) {
+                    const double ax = dev::dpp_mov<0x101>(cur.x), ay = dev::dpp_mov<0x101>(cur.y);                  // row_shl:1
+                    const double bx = dev::dpp_mov<0x110 + G - 1>(nxt.x), by = dev::dpp_mov<0x110 + G - 1>(nxt.y);  // row_shr:G-1
+                    q = lane == G - 1 ? make_double2(bx, by) : make_double2(ax, ay);
+                }
+                cur = nxt;
+                if (i >= c1) continue;
+                if (MASK & M_BBOX) {
+                    mnx = p.x < mnx ? p.x : mnx;
+                    mny = p.y < mny ? p.y : mny;
+                    mxx = p.x > mxx ? p.x : mxx;
+                    mxy = p.y > mxy ? p.y : mxy;
+                }
+                if (MASK & M_SUM) {
+                    sx_ += p.x;
+                    sy_ += p.y;
+                }
+                if (EDGES && i + 1 < c1) {
+                    if ((MASK & (M_AREA | M_CENT)) && closed_ring) {
+                        const double sx = p.x - first.x, sy = p.y - first.y;
+                        const double ex = q.x - first.x, ey = q.y - first.y;
+                        const double cr = sx * ey - sy * ex;
+                        a2 += cr;
+                        if (MASK & M_CENT) {
+                            acx += (ex + sx) * cr;
+                            acy += (ey + sy) * cr;
+                        }
+                    }
+                    if (MASK & (M_LEN | M_LENC)) {
+                        const double l = hypot(q.x - p.x, q.y - p.y);
+                        len += l;
+                        if (MASK & M_LENC) {
+                            lmx += (p.x + q.x) / 2.0 * l;
+                            lmy += (p.y + q.y) / 2.0 * l;
+                        }
                     }
                 }
             }
