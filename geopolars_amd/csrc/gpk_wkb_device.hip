@@ -166,18 +166,23 @@ __device__ inline bool parse_row(WkbCursor& r, RowCount& rc, double2* __restrict
 __global__ void wkb_scan_kernel(const uint8_t* __restrict__ values, const int32_t* __restrict__ offsets, int64_t n_rows,
                                 const uint8_t* __restrict__ validity, RowCount* __restrict__ rows, uint32_t* __restrict__ flags) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rows) return;
     RowCount rc{0, 0, 0, 0};
-    if (dev::valid_row(validity, i)) {
+    uint32_t bits = 0;
+    if (i < n_rows && dev::valid_row(validity, i)) {
         WkbCursor r{values + offsets[i], values + offsets[i + 1], true};
         if (!parse_row<false>(r, rc, nullptr, 0, nullptr, 0, nullptr, 0, false)) {
-            atomicOr(flags, 0x80000000u);  // malformed / unsupported
+            bits = 0x80000000u;  // malformed / unsupported
             rc = RowCount{0, 0, 0, 0};
         } else {
-            atomicOr(flags, 1u << rc.type);
+            bits = 1u << rc.type;
         }
     }
-    rows[i] = rc;
+    if (i < n_rows) rows[i] = rc;
+    // the column's type flags: OR-ed across the wave, and only a wave that brings a NEW bit touches the word (one atomicOr per row on
+    // one address was 8M serialised atomics for a column of 8M small polygons — most of this kernel's 0.73 ms)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bits |= (uint32_t)__shfl_xor((int)bits, o, 64);
+    if ((threadIdx.x & 63) == 0 && bits && (bits & ~__atomic_load_n(flags, __ATOMIC_RELAXED)) != 0u) atomicOr(flags, bits);
 }
 
 // per-row output extents for the chosen column type
