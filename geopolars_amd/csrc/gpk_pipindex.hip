@@ -107,7 +107,11 @@ __global__ void ring_rows_kernel(const double4* __restrict__ ring_bbox, int64_t 
     int sh = 0;
     while (sh < max_shift && n_edges > (int64_t)SLAB_TARGET * (base_rows << sh)) ++sh;
     const int j0 = f0 >> (PIP_FINE_LOG2 - sh), j1 = f1 >> (PIP_FINE_LOG2 - sh);
-    if (sh > 0) atomicAdd(n_refined, 1);  // rare (rings of hundreds of vertices); the join picks its lean kernel when there are none
+    {  // refined rings, counted per wave (a column of big rings — C5: a million of them — put one atomic per ring on this one word);
+       // the join picks its lean kernel when there are none
+        const unsigned long long m = __ballot(sh > 0);
+        if (m && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(n_refined, (int)__popcll(m));
+    }
     row0[r] = j0 | (sh << 24);
     nrows[r] = j1 - j0 + 1;
 }
