@@ -78,7 +78,7 @@ constexpr uint32_t SUB2_BIT = 1u << 29;         // in a CELL_TAG_SUB payload: th
 // the run of ring edges that covers every edge meeting Q, grown at both ends while the end vertex's y lies in Q's y-interval;
 // then winding(p) = base + sum of the chain edges' contributions for every p of Q (the rule is checked on
 // the CPU by tools/proto_local_chain.py / tests/test_local_chain_rule.py).  count == 0: no single short chain (several runs,
-// more than CHAIN_MAX edges, a part with holes): the row is decided by the generic walk (pip_fixup_kernel).
+// more than CHAIN_MAX edges, a part with holes): the row is decided by the generic walk, by the whole wave at the end of its tile.
 constexpr int CHAIN_MAX = 12;
 // chain entry i of an index = chain_head[i] (count, base, where vertices 4 .. are) + sub_aux[i] (the first four vertices, one cache
 // line): a `test` point reads both with independent requests and needs nothing else — 99.8 % of the chains of the C2 right side

@@ -229,19 +229,22 @@ struct QEntry {  // 32 bytes: one queued (point, part) pair with its exterior sl
     uint32_t li_flags;  // local point index | (part has holes) << 31
 };
 
-// pip_tile: one work-group classifies PIP_TILE points.
+// pip_tile: one work-group classifies PIP_TILE points (the GENERAL tile kernel: entry lists, two-part records, refined rings, holes,
+// rows in several geometries; disjoint right sides run pip_tile_route / pip_tile_chain, further down).
 //   phase 1 (lane = point): ONE 4-byte gather from the raster answers most points outright (no polygon
-//            here / strictly inside part p).  A point whose cell an edge may cross chases two more small
-//            gathers (PartInfo, slab offsets) — all lanes of all resident waves do this concurrently, so the
-//            latency of the dependent loads is hidden here — and is pushed to an LDS queue with a
-//            wave-aggregated slot grab (ballot + one LDS atomic per wave).  Loads are issued in stages
-//            (all points, then all cells, then all PartInfos, ...) to keep PIP_PPT requests per lane in flight.
-//   phase 2 (PIP_GS lanes = one queued pair): the group reads the slab as consecutive 32-byte edge records
-//            (one dependent load level) and runs the exact winding walk, folding the winding number and the
-//            on-boundary flag with xor-shuffles.  Compacting the undecided points this way keeps the lanes
-//            dense in the only expensive part of the kernel.
-//   finalize: rows with exactly one part hit map part -> geometry; rows with several hits (overlapping
-//            polygons / multipolygon parts) are recomputed by the generic walk so that counts are per geometry.
+//            here / strictly inside part p).  A point whose cell one part crosses reads that cell's level-2 record (or PartInfo + slab
+//            offsets) and is pushed to an LDS queue with a wave-aggregated slot grab (ballot + one LDS atomic per wave).  Loads are
+//            issued in stages (all points, then all cells, then all records, ...) to keep PPT requests per lane in flight.
+//   entry lists (round 3): the lanes whose cell is a LIST register (point, list) jobs; the jobs' entries are then one flat work
+//            list — every lane takes a run of consecutive (point, entry) items, GPK_FLAT_B at a time with their gathers in flight
+//            together (entry word + point, then the entry's record or its part's box), and pushes what survives.
+//   phase 2 (round 3: lane = slab EDGE): the queued pairs' slabs, flattened the same way; an edge's winding / on-boundary contribution
+//            goes to its pair's LDS accumulator (one atomicAdd of wn << 16 | on); a pair inside the exterior of a part with holes
+//            queues its hole rings, which go through the same pass.  (Round 2 walked a pair with PIP_GS = 8 lanes, eight passes per
+//            tile back to back, and lists / holes one lane each: DESIGN.md section 4.4 "Round 3, C5".)
+//   finalize: rows with exactly one part hit map part -> geometry; rows in several geometries (overlapping polygons / multipolygon
+//            parts) get a sorted segment of the multi-hit pool (its space reserved once per wave); only a tile that overflows its
+//            lists falls back to the generic walk.
 #ifndef GPK_PIP_MINWAVES
 #define GPK_PIP_MINWAVES 1
 #endif
@@ -1998,7 +2001,7 @@ static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, co
     uint32_t* pairs_dev = want_pairs ? (host_out ? (uint32_t*)workspace().take(pairs_bytes) : out_pairs) : nullptr;
     uint32_t* stage = staged ? (uint32_t*)workspace().take(stage_bytes) : nullptr;
 
-    int32_t n_cand = 0, has_big_rows = 0, has_long_rows = 0;
+    int32_t n_cand = 0, has_big_rows = 0;
     unsigned long long cand_total = 0;  // the 64-bit grand total of the scan: cand_off[n] is its truncation to i32
     auto stage1 = [&]() -> int32_t {
         GPK_HIP(hipMemsetAsync(big_rows, 0, 2 * sizeof(int32_t), s));
@@ -2014,7 +2017,6 @@ static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, co
         GPK_HIP(hipMemcpyAsync(fl, big_rows, sizeof fl, hipMemcpyDeviceToHost, s));
         GPK_HIP(hipStreamSynchronize(s));
         has_big_rows = fl[0];
-        has_long_rows = fl[1];
         return GPK_OK;
     };
     rc = stage1();

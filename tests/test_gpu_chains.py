@@ -1,4 +1,4 @@
-"""GPU parity of the chain tile kernels (gpk_join.hip: pip_tile_chain_kernel, pip_tile_route_kernel, pip_tile_pipe_kernel, pip_fixup_kernel)
+"""GPU parity of the chain tile kernels (gpk_join.hip: pip_tile_chain_kernel, pip_tile_route_kernel — rare rows settled inside them)
 through the C ABI vs the CPU oracle, bit-exact on counts and sorted (l, r) pairs (`Contains<Point>`, spatial_index.rs:91-96).
 
 Right sides here are DISJOINT polygons — what makes an index "lean" and gives it local chains — shaped to reach every arm:

@@ -1,4 +1,4 @@
-"""The decision rule of the chain kernels for "test" sub-cells (gpk_join.hip: pip_tile_chain / route / pipe; CPU mirror: tools/proto_local_chain.py): winding number of a
+"""The decision rule of the chain kernels for "test" sub-cells (gpk_join.hip: pip_tile_chain / pip_tile_route; CPU mirror: tools/proto_local_chain.py): winding number of a
 point of a padded sub-cell = a per-sub-cell constant + the contributions of the LOCAL CHAIN of ring edges.  Checked against
 the full ring walk on random and on-edge points; CPU only, a few seconds."""
 import os

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Tuning: HIP-event time of the kernels of the C2 join (gpk_pip_tile / gpk_pip_fixup / gpk_pip_write) on cold rotating inputs,
+"""Tuning: HIP-event time of the kernels of the C2 join (gpk_join_prep / gpk_pip_tile / gpk_pip_write) on cold rotating inputs,
 plus the wall time of a queued step, for the build named by GPK_LIB_PATH (default: the in-tree library).  No parity, no bench line
 (bench.py is the measurement of record); environment switches of the library apply (GPK_NO_CHAINS=1: queue kernel on an index
-without chains, GPK_TILE_KERNEL=chain|route|pipe: which of the chain kernels serves an index with chains).
+without chains, GPK_TILE_KERNEL=chain: the chain kernel instead of the routed one serves an index with chains).
     GPK_LIB_PATH=geopolars_amd/variants/r2.so python tools/tile_time.py [--polys 1000] [--points 10000000]"""
 import argparse, ctypes as C, os, sys, time
 import torch
@@ -46,10 +46,10 @@ for i in range(a.steps):
 torch.cuda.synchronize()
 lib.gpk_profile_enable(0)
 out = []
-for name in (b"gpk_pip_tile", b"gpk_pip_fixup", b"gpk_pip_write"):
+for name in (b"gpk_pip_tile", b"gpk_join_prep", b"gpk_pip_write"):
     ms, cnt = C.c_double(0), C.c_int64(0)
     lib.gpk_profile_query(name, C.byref(ms), C.byref(cnt))
-    out.append(f"{name.decode()[8:]} {1e3 * ms.value / max(cnt.value, 1):.1f}")
+    out.append(f"{name.decode()[4:]} {1e3 * ms.value / max(cnt.value, 1):.1f}")
 st = (C.c_int64 * 4)()
 lib.gpk_join_stats_enable(1); lib.gpk_join_stats(st, 1); step(0); lib.gpk_join_stats(st, 1); lib.gpk_join_stats_enable(0)
 d = index.describe()
