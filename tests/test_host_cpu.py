@@ -346,6 +346,15 @@ def test_bench_helpers_sampling_and_traffic_records(tmp_path, monkeypatch):
     assert rec is None and "stale" in why and "0000" in why
     rec, why = bench.pmc_config_record("c4")
     assert rec is None and "no PMC record" in why
+    # the record of THIS tree is found by its hash, whatever the files are called (tags do not sort by time: r03t < r03zz)
+    (prof / "r03a_pmc_traffic.json").write_text(_json.dumps({"kernel": "gpk_pip_tile", "source_hash": "f" * 16, "traffic_bytes_per_launch": 7}))
+    (prof / "r03a_pmc_traffic_configs.json").write_text(_json.dumps({"source_hash": "f" * 16, "read_factor_of_the_16_byte_stream": 1.9,
+                                                                      "configs": {"c4": {"kernel": "pair_refine", "traffic_bytes_raw": 5, "traffic_bytes_with_read_factor": 9}}}))
+    (prof / "r99_pmc_traffic_configs.json").write_text(_json.dumps({"source_hash": "0" * 16, "configs": {"c4": {"kernel": "pair_refine", "traffic_bytes_raw": 1}}}))
+    rec, why = bench.pmc_record("gpk_pip_tile")
+    assert rec is not None and why is None and rec["traffic_bytes_per_launch"] == 7
+    rec, why = bench.pmc_config_record("c4")
+    assert rec is not None and rec["traffic_bytes_raw"] == 5
 
 
 def test_bench_gpus_n_without_a_launcher_spawns_n_ranks():
