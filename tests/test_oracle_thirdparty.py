@@ -1,0 +1,59 @@
+"""The oracle against a THIRD-PARTY implementation where one is importable here: scipy.spatial.ConvexHull (Qhull — quickhull, the
+algorithm family of geo 0.27's `convex_hull/qhull.rs` that `oracle/gpk_oracle.c` restates).  Random clouds in general position: the
+hull is unique, so the vertex SETS must agree exactly and the oracle's ring must be closed and counter-clockwise.  CPU only."""
+import numpy as np
+import pytest
+
+from geopolars_amd.geoarrow import GeoArrowArray
+
+scipy_spatial = pytest.importorskip("scipy.spatial")
+
+
+def _shoelace2(ring):
+    x, y = ring[:, 0], ring[:, 1]
+    return float(np.sum(x[:-1] * y[1:] - x[1:] * y[:-1]))
+
+
+@pytest.mark.parametrize("seed, n_rows", [(1, 200), (2, 60)])
+def test_hull_vertices_equal_qhull(oracle, seed, n_rows):
+    rng = np.random.default_rng(seed)
+    rows = []
+    for _ in range(n_rows):
+        n = int(rng.integers(3, 200))
+        kind = rng.integers(0, 3)
+        if kind == 0:
+            pts = rng.uniform(-1000.0, 1000.0, (n, 2))
+        elif kind == 1:  # points near a circle: almost every point is a hull vertex
+            t = rng.uniform(0.0, 2.0 * np.pi, n)
+            pts = np.stack([np.cos(t), np.sin(t)], axis=1) * rng.uniform(50.0, 60.0, (n, 1)) + rng.uniform(-5.0, 5.0, 2)
+        else:  # a cloud with heavy interior: few hull vertices
+            pts = rng.normal(0.0, 1.0, (n, 2)) * rng.uniform(0.1, 100.0)
+        rows.append(pts)
+    a = GeoArrowArray.from_linestrings([p.tolist() for p in rows])  # (convex_hull only looks at the coordinates of a row)
+    xy, off = oracle.convex_hull(a)
+    for k, pts in enumerate(rows):
+        ring = xy[off[k] : off[k + 1]]
+        assert len(ring) >= 4 and np.array_equal(ring[0], ring[-1])  # closed
+        assert _shoelace2(ring) > 0.0  # counter-clockwise
+        want = {tuple(p) for p in pts[scipy_spatial.ConvexHull(pts).vertices]}
+        got = {tuple(p) for p in ring[:-1]}
+        assert got == want, (k, len(got), len(want))
+
+
+def test_area_and_perimeter_of_convex_polygons_equal_qhull(oracle):
+    """Qhull reports a 2-D hull's area (`volume`) and perimeter (`area`) from its own facet arithmetic: oracle.area and
+    oracle.euclidean_length of the same convex polygons agree to 1e-9 relative (the north star's tolerance)."""
+    rng = np.random.default_rng(7)
+    polys, want_area, want_len = [], [], []
+    for _ in range(300):
+        n = int(rng.integers(3, 120))
+        pts = rng.uniform(-500.0, 500.0, (n, 2)) * rng.uniform(0.01, 10.0)
+        h = scipy_spatial.ConvexHull(pts)
+        ring = pts[h.vertices]  # counter-clockwise in 2-D
+        polys.append([ring.tolist()])
+        want_area.append(h.volume)
+        want_len.append(h.area)
+    a = GeoArrowArray.from_polygons(polys)  # (closes the rings)
+    got_area, got_len = oracle.area(a), oracle.euclidean_length(a)
+    assert np.all(np.abs(got_area - np.array(want_area)) <= 1e-9 * np.array(want_area))
+    assert np.all(np.abs(got_len - np.array(want_len)) <= 1e-9 * np.array(want_len))
