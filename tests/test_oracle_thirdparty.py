@@ -57,3 +57,32 @@ def test_area_and_perimeter_of_convex_polygons_equal_qhull(oracle):
     got_area, got_len = oracle.area(a), oracle.euclidean_length(a)
     assert np.all(np.abs(got_area - np.array(want_area)) <= 1e-9 * np.array(want_area))
     assert np.all(np.abs(got_len - np.array(want_len)) <= 1e-9 * np.array(want_len))
+
+
+def test_point_in_convex_polygon_equals_qhull_delaunay(oracle):
+    """`within(point, polygon)` for convex polygons against scipy.spatial.Delaunay.find_simplex (Qhull's triangulation of the same
+    vertices): equal for every point that is not within 1e-7 of the boundary (Delaunay's own test is tolerance-based there)."""
+    rng = np.random.default_rng(11)
+    polys, pts, rows, want = [], [], [], []
+    for k in range(120):
+        cloud = rng.uniform(-100.0, 100.0, (int(rng.integers(3, 40)), 2))
+        h = scipy_spatial.ConvexHull(cloud)
+        ring = cloud[h.vertices]
+        polys.append([ring.tolist()])
+        tri = scipy_spatial.Delaunay(ring)
+        q = rng.uniform(-120.0, 120.0, (150, 2))
+        inside = tri.find_simplex(q) >= 0
+        # distance to the boundary (plain numpy): points too close to it are left out of the comparison
+        a, b = ring, np.roll(ring, -1, axis=0)
+        ab = b - a
+        t = np.clip(np.einsum("qed,ed->qe", q[:, None, :] - a[None, :, :], ab) / np.einsum("ed,ed->e", ab, ab), 0.0, 1.0)
+        d = np.min(np.linalg.norm(q[:, None, :] - (a[None, :, :] + t[:, :, None] * ab[None, :, :]), axis=2), axis=1)
+        keep = d > 1e-7
+        pts.append(q[keep])
+        rows.append(np.full(int(keep.sum()), k, dtype=np.uint32))
+        want.append(inside[keep])
+    pa = GeoArrowArray.from_points(np.concatenate(pts))
+    qa = GeoArrowArray.from_polygons(polys)
+    got = oracle.predicate_rowwise(pa, qa, "within", b_rows=np.concatenate(rows))
+    assert np.array_equal(got, np.concatenate(want))
+    assert got.sum() > 1000 and (~got).sum() > 1000
