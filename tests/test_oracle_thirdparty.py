@@ -86,3 +86,21 @@ def test_point_in_convex_polygon_equals_qhull_delaunay(oracle):
     got = oracle.predicate_rowwise(pa, qa, "within", b_rows=np.concatenate(rows))
     assert np.array_equal(got, np.concatenate(want))
     assert got.sum() > 1000 and (~got).sum() > 1000
+
+
+def test_haversine_length_equals_sklearn(oracle):
+    """geodesic_length(method="haversine") of two-point linestrings against sklearn.metrics.pairwise.haversine_distances (great-circle
+    angle) times geo's mean earth radius 6371008.8 m (HaversineLength, geo 0.27): 1e-9 relative away from the antipode / zero ends."""
+    pairwise = pytest.importorskip("sklearn.metrics.pairwise")
+    rng = np.random.default_rng(5)
+    lon = rng.uniform(-180.0, 180.0, (4000, 2))
+    lat = rng.uniform(-89.0, 89.0, (4000, 2))
+    lines = [[[lon[i, 0], lat[i, 0]], [lon[i, 1], lat[i, 1]]] for i in range(4000)]
+    got = oracle.geodesic_length(GeoArrowArray.from_linestrings(lines), "haversine")
+    a = np.radians(np.stack([lat[:, 0], lon[:, 0]], axis=1))
+    b = np.radians(np.stack([lat[:, 1], lon[:, 1]], axis=1))
+    ang = np.array([pairwise.haversine_distances(a[i : i + 1], b[i : i + 1])[0, 0] for i in range(4000)])
+    want = ang * 6371008.8
+    ok = (ang > 1e-3) & (ang < np.pi - 1e-3)  # (the formula's conditioning at the ends is the implementations' own business)
+    assert ok.sum() > 3900
+    assert np.all(np.abs(got[ok] - want[ok]) <= 1e-9 * want[ok])
