@@ -104,3 +104,58 @@ def test_haversine_length_equals_sklearn(oracle):
     ok = (ang > 1e-3) & (ang < np.pi - 1e-3)  # (the formula's conditioning at the ends is the implementations' own business)
     assert ok.sum() > 3900
     assert np.all(np.abs(got[ok] - want[ok]) <= 1e-9 * want[ok])
+
+
+def _near_boundary(q, ring, eps):
+    a, b = ring[:-1], ring[1:]
+    ab = b - a
+    den = np.einsum("ed,ed->e", ab, ab)
+    den = np.where(den > 0.0, den, 1.0)
+    t = np.clip(np.einsum("qed,ed->qe", q[:, None, :] - a[None, :, :], ab) / den, 0.0, 1.0)
+    d = np.min(np.linalg.norm(q[:, None, :] - (a[None, :, :] + t[:, :, None] * ab[None, :, :]), axis=2), axis=1)
+    return d <= eps
+
+
+def test_point_in_polygon_equals_matplotlib_on_the_headline_shapes(oracle):
+    """The C2 right side (64-vertex star polygons, non-convex) and multipolygons with holes against matplotlib.path.Path
+    (Anti-Grain's crossing test per ring; a polygon = inside its exterior and inside none of its holes): the oracle's join counts
+    equal matplotlib's on every point that is not within 1e-6 of a ring."""
+    mpath = pytest.importorskip("matplotlib.path")
+    from geopolars_amd import synth
+
+    def check(right, pts):
+        _, counts, _ = oracle.spatial_join(pts, right, "intersects", mode=1)
+        q = pts.xy
+        want = np.zeros(len(q), dtype=np.int64)
+        near = np.zeros(len(q), dtype=bool)
+        go, po, ro = right.geom_offsets, right.part_offsets, right.ring_offsets
+        for g in range(len(right)):
+            p0, p1 = (int(go[g]), int(go[g + 1])) if po is not None else (g, g + 1)
+            in_geom = np.zeros(len(q), dtype=bool)
+            for p in range(p0, p1):
+                r0, r1 = (int(po[p]), int(po[p + 1])) if po is not None else (int(go[p]), int(go[p + 1]))
+                rings = [right.xy[int(ro[r]) : int(ro[r + 1])] for r in range(r0, r1)]
+                lo, hi = rings[0].min(axis=0), rings[0].max(axis=0)
+                sel = np.nonzero(np.all((q >= lo - 1e-3) & (q <= hi + 1e-3), axis=1))[0]
+                if len(sel) == 0:
+                    continue
+                def ring_test(r):  # (one Path per ring: a compound path's contains_points does not treat inner subpaths as holes)
+                    return mpath.Path(r, [mpath.Path.MOVETO] + [mpath.Path.LINETO] * (len(r) - 2) + [mpath.Path.CLOSEPOLY]).contains_points(q[sel])
+
+                inside = ring_test(rings[0])
+                for hole in rings[1:]:
+                    inside &= ~ring_test(hole)
+                in_geom[sel] |= inside
+                for r in rings:
+                    near[sel] |= _near_boundary(q[sel], r, 1e-6)
+            want += in_geom
+        ok = ~near
+        assert ok.sum() > 0.98 * len(q)
+        assert np.array_equal(counts[ok].astype(np.int64), want[ok])
+        return int(want[ok].sum())
+
+    hits = check(synth.star_polygons(1000, 64), synth.uniform_points(30_000, seed=3))
+    assert hits > 8_000
+    mp = synth.powerlaw_multipolygons(400, seed=9)
+    hits = check(mp, synth.uniform_points(30_000, seed=4))
+    assert hits > 500
