@@ -159,3 +159,81 @@ def test_point_in_polygon_equals_matplotlib_on_the_headline_shapes(oracle):
     mp = synth.powerlaw_multipolygons(400, seed=9)
     hits = check(mp, synth.uniform_points(30_000, seed=4))
     assert hits > 500
+
+
+def test_area_centroid_distance_equal_sympy_geometry(oracle):
+    """sympy.geometry (exact rational arithmetic, an independent code base): area and centroid of random simple polygons on an
+    integer lattice, and the point-to-linestring distance, agree with the oracle to 1e-12."""
+    sg = pytest.importorskip("sympy.geometry")
+    import sympy
+
+    rng = np.random.default_rng(21)
+    polys, areas, cents = [], [], []
+    for _ in range(40):
+        n = int(rng.integers(3, 12))
+        ang = np.sort(rng.uniform(0.0, 2.0 * np.pi, n))
+        rad = rng.integers(5, 60, n)
+        v = np.unique(np.stack([np.rint(rad * np.cos(ang)), np.rint(rad * np.sin(ang))], axis=1).astype(np.int64), axis=0)
+        if len(v) < 3:
+            continue
+        v = v[np.argsort(np.arctan2(v[:, 1], v[:, 0]))]  # star-shaped about the origin: simple
+        sp = sg.Polygon(*[sg.Point(int(x), int(y)) for x, y in v])
+        if not isinstance(sp, sg.Polygon) or sp.area == 0:
+            continue
+        polys.append([v.astype(np.float64).tolist()])
+        areas.append(float(abs(sp.area)))
+        cents.append((float(sp.centroid.x), float(sp.centroid.y)))
+    a = GeoArrowArray.from_polygons(polys)
+    assert len(polys) >= 30
+    assert np.allclose(oracle.area(a), np.array(areas), rtol=1e-12, atol=0.0)
+    c = oracle.centroid(a)
+    cxy = c[0] if isinstance(c, tuple) else c
+    assert np.allclose(np.asarray(cxy).reshape(-1, 2), np.array(cents), rtol=1e-12, atol=1e-12)
+    # point -> linestring: min over sympy Segment.distance
+    lines, pts, want = [], [], []
+    for _ in range(40):
+        m = int(rng.integers(2, 7))
+        lv = rng.integers(-50, 50, (m, 2))
+        if np.any(np.all(lv[1:] == lv[:-1], axis=1)):
+            continue
+        p = rng.integers(-60, 60, 2)
+        segs = [sg.Segment(sg.Point(int(lv[k, 0]), int(lv[k, 1])), sg.Point(int(lv[k + 1, 0]), int(lv[k + 1, 1]))) for k in range(m - 1)]
+        d = min(float(sympy.N(s.distance(sg.Point(int(p[0]), int(p[1]))), 30)) for s in segs)
+        lines.append(lv.astype(np.float64).tolist())
+        pts.append(p.astype(np.float64))
+        want.append(d)
+    got = oracle.distance_rowwise(GeoArrowArray.from_points(np.array(pts)), GeoArrowArray.from_linestrings(lines))
+    assert np.allclose(got, np.array(want), rtol=1e-12, atol=1e-12)
+
+
+def test_polygon_intersects_polygon_equals_sympy_geometry(oracle):
+    """`intersects(polygon, polygon)` on small lattice polygons (shared vertices and touching edges happen by construction) against
+    sympy.geometry: the boundaries meet (exact `Polygon.intersection`) or one polygon strictly encloses a vertex of the other."""
+    sg = pytest.importorskip("sympy.geometry")
+    rng = np.random.default_rng(31)
+
+    def lattice_polygon(cx, cy):
+        n = int(rng.integers(3, 8))
+        ang = np.sort(rng.uniform(0.0, 2.0 * np.pi, n))
+        rad = rng.integers(2, 9, n)
+        v = np.unique(np.stack([cx + np.rint(rad * np.cos(ang)), cy + np.rint(rad * np.sin(ang))], axis=1).astype(np.int64), axis=0)
+        if len(v) < 3:
+            return None
+        v = v[np.argsort(np.arctan2(v[:, 1] - cy, v[:, 0] - cx))]
+        sp = sg.Polygon(*[sg.Point(int(x), int(y)) for x, y in v])
+        return (v, sp) if isinstance(sp, sg.Polygon) and sp.area != 0 else None
+
+    left, right, want = [], [], []
+    while len(want) < 60:
+        a = lattice_polygon(0, 0)
+        b = lattice_polygon(int(rng.integers(-12, 13)), int(rng.integers(-12, 13)))
+        if a is None or b is None:
+            continue
+        (va, pa), (vb, pb) = a, b
+        hit = bool(pa.intersection(pb)) or pa.encloses_point(pb.vertices[0]) or pb.encloses_point(pa.vertices[0])
+        left.append([va.astype(np.float64).tolist()])
+        right.append([vb.astype(np.float64).tolist()])
+        want.append(bool(hit))
+    got = oracle.predicate_rowwise(GeoArrowArray.from_polygons(left), GeoArrowArray.from_polygons(right), "intersects")
+    assert np.array_equal(got, np.array(want))
+    assert 10 < sum(want) < 55
