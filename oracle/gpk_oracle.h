@@ -10,7 +10,11 @@
  * PARITY PINNING: pinned only by the reference's in-tree known-answer vectors
  * (geopolars/src/spatial_index.rs:361-484: KA-1 boundary-not-contained, KA-2 closed bbox, KA-3) and
  * by exact rational arithmetic (tests/test_oracle_exact.py).  For area / centroid / distance /
- * convex_hull / intersects the reference pins nothing: "parity unpinned" for those ops.
+ * convex_hull / intersects the reference pins nothing: "parity unpinned" BY THE REFERENCE for those ops.
+ * Independent implementations that are importable in this environment agree with this restatement
+ * (tests/test_oracle_thirdparty.py): Qhull (scipy.spatial: hull vertex sets, area, perimeter, point location in convex
+ * polygons), matplotlib.path (point in polygon on the headline's star polygons and on multipolygons with holes),
+ * scikit-learn (haversine), sympy.geometry (exact area, centroid, point-linestring distance, polygon x polygon intersects).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline / parity legs may load this library.
  * Nothing under geopolars_amd/ imports, links or calls it.
