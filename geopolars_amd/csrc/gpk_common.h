@@ -83,11 +83,20 @@ class Workspace {
     void* take(size_t bytes);
     void trim(size_t keep_max);  // give the arena back when it has grown beyond keep_max bytes (after a device sync)
     ~Workspace();
+    // A caller that leaves the same small record at the same place of the arena call after call (the rare arm's arguments of the
+    // fused point join) tags it: tag_matches() is true when the PREVIOUS begin() .. begin() span ended with set_tag / a match of
+    // these very bytes at this very place and the arena has not been re-allocated since — then the record need not be written again.
+    bool tag_matches(const void* where, const void* bytes, size_t n);
+    void set_tag(const void* where, const void* bytes, size_t n);
 
   private:
     char* base_ = nullptr;
     size_t cap_ = 0, used_ = 0;
     int device_ = -1;
+    const void* tag_where_ = nullptr;
+    unsigned char tag_[192];
+    size_t tag_n_ = 0;
+    bool tag_prev_ = false, tag_cur_ = false;
 };
 Workspace& workspace();
 // second and third per-thread arenas for calls whose scratch is sized in stages (the polygon x polygon join learns its

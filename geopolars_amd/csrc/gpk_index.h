@@ -163,6 +163,7 @@ struct gpk_index {
     void* owned[24];  // bbox, grid, cell_off, items, then the PipView tables
     int64_t nbytes;
     int32_t pip_lean;  // 1: every raster cell names at most one part and boundary cells carry inline records (build_pip_index)
+    uint64_t serial;  // unique per built index (never reused): what a cached copy of an index's pointers is keyed with
     int32_t pip_list_heavy;  // 1: more than a list word per four raster cells (overlapping parts, very many small parts): the general tile
                              // kernel runs its one-point-per-lane instance
 };

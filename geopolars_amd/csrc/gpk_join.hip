@@ -12,7 +12,9 @@
 //                work-group totals (no scan kernel).
 // (A single-pass variant with decoupled look-back was measured and was slower on MI355X: the in-order
 // commit makes finished work-groups hold their LDS/wave slots while they wait — see DESIGN.md.)
+#include <atomic>
 #include <cstring>
+#include <mutex>
 #include <type_traits>
 
 #include <rocprim/rocprim.hpp>
@@ -1189,13 +1191,19 @@ __device__ __forceinline__ void static_for(F&& f) {
 #ifndef GPK_CHAIN_ABLATE
 #define GPK_CHAIN_ABLATE 0  // tuning builds only (answers wrong on purpose): 1 = `test` points count as outside
 #endif
+#ifndef GPK_FUSED_PREFETCH
+#define GPK_FUSED_PREFETCH 1
+#endif
 #ifndef GPK_ROUTE_BLOCK
 #define GPK_ROUTE_BLOCK 1024
 #endif
 #ifndef GPK_ROUTE_PPT
 #define GPK_ROUTE_PPT 8
 #endif
-constexpr int CHAIN_PPT = GPK_CHAIN_PPT, ROUTE_PPT = GPK_ROUTE_PPT, ROUTE_BLOCK = GPK_ROUTE_BLOCK;
+#ifndef GPK_FUSED_PPT
+#define GPK_FUSED_PPT 8
+#endif
+constexpr int CHAIN_PPT = GPK_CHAIN_PPT, ROUTE_PPT = GPK_ROUTE_PPT, ROUTE_BLOCK = GPK_ROUTE_BLOCK, FUSED_PPT = GPK_FUSED_PPT;
 static_assert(PIP_WTILE % (64 * CHAIN_PPT) == 0 && PIP_WTILE % (64 * ROUTE_PPT) == 0, "a writer tile is a whole number of chain tiles");
 
 struct ChainHot {
@@ -1218,6 +1226,9 @@ struct ChainHot {
     unsigned long long* super_tot;
     unsigned long long* stats;
     const struct ChainCold* cold;  // what the generic walk of a rare row reads (written by join_prep_kernel)
+    uint2* stage;                  // pip_tile_fused_kernel: one pair slot per left row, a wave's hits at the start of its rows' slots
+    int32_t n_full_tiles, pad;     // pip_tile_fused_kernel: tiles 0 .. n_full_tiles - 1 need no guards (whole tiles of a column without a validity bitmap)
+    double inv_fw_s, inv_fh_s, sub_max;  // pip_tile_fused_kernel: inv_fw * PIP_SUB, inv_fh * PIP_SUB (exact: a power of two), (PIP_SUB << logR) - 1
 };
 // the arguments of the rare arm, in device memory: loaded where they are used — as kernel arguments they would be held in scalar
 // registers across the hot loop (and spilled)
@@ -1242,8 +1253,10 @@ __global__ __launch_bounds__(256) void join_prep_kernel(unsigned long long* __re
 // INLINE_EXACT: the expansion arithmetic of the exact orientation unrolled into registers (no call, no scratch memory: what the
 // persistent route kernel wants, which owns 128 registers per lane anyway) or reached by a call (the chain kernel: 84 registers
 // instead of 113, i.e. one more wave per SIMD, for a 208-byte stack).
+// emit != nullptr: hit number t of the row (ascending geometry id) is stored as (l, id) in emit[t] while t < emit_room
 template <bool INLINE_EXACT>
-__device__ __forceinline__ uint32_t chain_generic_row(const ChainCold* __restrict__ cold, double px, double py, int lane, uint32_t* first) {
+__device__ __forceinline__ uint32_t chain_generic_row(const ChainCold* __restrict__ cold, double px, double py, int lane, uint32_t* first,
+                                                      uint2* emit = nullptr, uint32_t emit_room = 0u, uint32_t l = 0u) {
     const DevGeo polys = cold->polys;
     const IndexView ix = cold->ix;
     const GridParams g = cold->grid;
@@ -1291,12 +1304,35 @@ __device__ __forceinline__ uint32_t chain_generic_row(const ChainCold* __restric
         }
         if (hit) {
             if (cnt == 0) *first = (uint32_t)j;
+            if (emit != nullptr && lane == 0 && cnt < emit_room) emit[cnt] = make_uint2(l, (uint32_t)j);
             ++cnt;
         }
     }
     return cnt;
 }
 
+// set bits of a wave mask below this lane (v_mbcnt: no lane-mask register pair to keep)
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+// What the fused kernel's tile loop reads once per tile (or hardly ever) is read from the kernel-argument segment where it is used
+// — a scalar load that hits the scalar cache — instead of living in scalar registers across the loop, which has none to spare: every
+// spilled scalar costs v_writelane / v_readlane pairs, and past 64 of them a second vector register.  (The pointer is made opaque:
+// named directly the compiler loads every argument at the top of the kernel.)
+template <typename T>
+__device__ __forceinline__ T kernel_arg_at(uint32_t offset) {
+    const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    return *(const T __attribute__((address_space(4)))*)(ka + offset);
+}
+#define HOT_ARG(field) (FUSED ? kernel_arg_at<decltype(ChainHot::field)>((uint32_t)offsetof(ChainHot, field)) : h.field)
+// The same walk as a CALL (pip_tile_fused_kernel): the fused tile loop keeps the next tile's points in registers across the rare arm;
+// inlined, the walk's register needs are the loop's (everything live across it is spilled, on every path); called, only the call
+// site saves what it must.
+__device__ __noinline__ uint32_t chain_generic_row_call(const ChainCold* cold, double px, double py, int lane, uint2* emit, uint32_t emit_room, uint32_t l) {
+    uint32_t first;
+    return chain_generic_row<false>(cold, px, py, lane, &first, emit, emit_room, l);
+}
 // one `test` point of a tile, in the wave's LDS list (24 bytes; reading the point again from memory instead was measured: the
 // tile's lines are streamed with the non-temporal hint and are gone from the L2 — 20 us more per launch)
 struct ChainItem {
@@ -1309,43 +1345,100 @@ struct ChainItem {
 template <int P>
 constexpr int chain_items() { return 16 * P; }
 
-// FULL: the tile holds 64 * P points and the left column has no validity bitmap (wave-uniform, true for all tiles but the last
-// of a plain column): no per-point guards on loads and stores
-template <int P, bool ROUTE, bool FULL>
-__device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mask, const uint32_t* s_rec0, ChainItem* s_items, int64_t tile, int lane) {
-    constexpr int S = PIP_SUB, CHAIN_TILE = 64 * P, ITEMS = chain_items<P>();
+// The P points a lane holds, as 2 * P separately named doubles: a `double[P]` that lives across loop iterations (the fused kernel
+// requests a tile's points one tile ahead) is promoted to ONE 2 * P-register vector value — every use then drags the whole tuple
+// through the register allocator, and through scratch memory when it does not fit.  Nested structs are split into their fields.
+template <int P>
+struct PointRegs {
+    double x, y;
+    PointRegs<P - 1> rest;
+};
+template <>
+struct PointRegs<0> {};
+template <int K, int P>
+__device__ __forceinline__ double& point_x(PointRegs<P>& r) {
+    if constexpr (K == 0)
+        return r.x;
+    else
+        return point_x<K - 1>(r.rest);
+}
+template <int K, int P>
+__device__ __forceinline__ double& point_y(PointRegs<P>& r) {
+    if constexpr (K == 0)
+        return r.y;
+    else
+        return point_y<K - 1>(r.rest);
+}
+// a tile's points into registers (NaN for rows past the end and null rows).  FULL: see chain_tile
+template <int P, bool FULL, bool FUSED>
+__device__ __forceinline__ void chain_load_points(const ChainHot& h, int64_t tile, int lane, PointRegs<P>& pr) {
+    constexpr int CHAIN_TILE = 64 * P;
     const int64_t base = tile * CHAIN_TILE;
-    const uint32_t rem = FULL ? (uint32_t)CHAIN_TILE : (uint32_t)(h.n_points - base < (int64_t)CHAIN_TILE ? h.n_points - base : (int64_t)CHAIN_TILE);
-    const int logR = h.logR;
-    // 1. the points
-    const double2* __restrict__ tile_xy = h.pts_xy + base;
-    double px[P], py[P];
+    const int64_t n_points = FULL ? 0 : (HOT_ARG(n_points));
+    const uint32_t rem = FULL ? (uint32_t)CHAIN_TILE : (uint32_t)(n_points - base < (int64_t)CHAIN_TILE ? n_points - base : (int64_t)CHAIN_TILE);
+    const double2* __restrict__ tile_xy = (HOT_ARG(pts_xy)) + base;
     static_for<P>([&](auto K) {
         constexpr int k = decltype(K)::value;
         double2 v = make_double2(NAN, NAN);
-        if (FULL || ((uint32_t)(k * 64 + lane) < rem && dev::valid_row(h.pts_validity, base + k * 64 + lane)))
+        if (FULL || ((uint32_t)(k * 64 + lane) < rem && dev::valid_row(HOT_ARG(pts_validity), base + k * 64 + lane)))
             v = GPK_CHAIN_NT ? dev::load_stream(tile_xy + (k * 64 + lane)) : tile_xy[k * 64 + lane];
-        px[k] = v.x;
-        py[k] = v.y;
+        point_x<k>(pr) = v.x;
+        point_y<k>(pr) = v.y;
     });
+}
+template <int P, bool FUSED>
+__device__ __forceinline__ void chain_load_points_any(const ChainHot& h, int64_t tile, int lane, PointRegs<P>& pr) {
+    const bool full = FUSED ? tile < (int64_t)h.n_full_tiles : (h.pts_validity == nullptr && (tile + 1) * (int64_t)(64 * P) <= h.n_points);
+    if (full)  // (wave-uniform)
+        chain_load_points<P, true, FUSED>(h, tile, lane, pr);
+    else
+        chain_load_points<P, false, FUSED>(h, tile, lane, pr);
+}
+// FULL: the tile holds 64 * P points and the left column has no validity bitmap (wave-uniform, true for all tiles but the last
+// of a plain column): no per-point guards on loads and stores
+// FUSED (pip_tile_fused_kernel): no result codes and tile totals — the tile's hits go, in row order, to out[run ...] (slots below
+// out_cap only) as (l_add + row, geometry) and `run` moves on by their number; the rare rows are settled BEFORE the others are
+// ranked (their hit counts shift the ranks) and store their hits themselves
+template <int P, bool ROUTE, bool FULL, bool FUSED = false>
+__device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mask, const uint32_t* s_rec0, ChainItem* s_items, int64_t tile, int lane,
+                                           uint2* out, uint32_t out_cap, uint32_t* run_io, PointRegs<P>& pr, int64_t next_tile) {
+    constexpr int S = PIP_SUB, CHAIN_TILE = 64 * P, ITEMS = chain_items<P>();
+    const int64_t base = tile * CHAIN_TILE;
+    const int64_t n_points = FULL ? 0 : (HOT_ARG(n_points));
+    const uint32_t rem = FULL ? (uint32_t)CHAIN_TILE : (uint32_t)(n_points - base < (int64_t)CHAIN_TILE ? n_points - base : (int64_t)CHAIN_TILE);
+    const int logR = h.logR;
+    // 1. the points (PREFETCH: the caller's registers hold them already — requested during the previous tile's exact step — and
+    // receive the next tile's below)
+    constexpr bool PREFETCH = FUSED && GPK_FUSED_PREFETCH;
+    const double2* __restrict__ tile_xy = (HOT_ARG(pts_xy)) + base;
+    // (only guard-free tiles are requested ahead: next_tile < 0 on entry means "this tile's points are not here yet")
+    if (!PREFETCH || !FULL) chain_load_points<P, FULL, FUSED>(h, tile, lane, pr);
     // (GPK_SCHED_FENCE: nothing is moved across — left to itself the scheduler interleaves the steps of different points until it
     // runs out of registers, then spills; the source order below IS the intended schedule: requests of a step back to back, their
     // uses in the next step)
     GPK_SCHED_FENCE();
     // 2. level 1 (ROUTE: from the LDS image where that answers), then the half-cell records
-    uint32_t sidx[P], w[P], gw[P];  // sub-cell within the cell (label index, x fastest); record index known from LDS (recmask); level-1
+    uint32_t sidx4[(P + 3) / 4], w[P], gw[P];  // sub-cell within the cell (label index, x fastest; byte k % 4 of word k / 4: eight registers
+                                    // less than one each); record index known from LDS (recmask); level-1
                                     // word requested (its own register: a register with a request pending for SOME lanes cannot be
                                     // read by the others without waiting for it)
     uint32_t recmask = 0u;          // bit k: point k's cell carries a one-part record and w[k] is its index (ROUTE only)
-    const double sub_max = (double)(((uint32_t)S << logR) - 1u);
+    // (the scaled reciprocals and the last sub-cell arrive as kernel arguments: computed in the kernel they are vector-unit results —
+    // six vector registers of loop-invariant values)
+    const double sub_max = FUSED ? h.sub_max : (double)(((uint32_t)S << logR) - 1u);
+    const double inv_w_s = FUSED ? h.inv_fw_s : h.inv_fw * S, inv_h_s = FUSED ? h.inv_fh_s : h.inv_fh * S;
+    const uint32_t* __restrict__ const cell_words = HOT_ARG(cell);
+    static_for<(P + 3) / 4>([&](auto J) { sidx4[decltype(J)::value] = 0u; });
+#define SIDX(k) ((sidx4[(k) / 4] >> (8 * ((k) % 4))) & 0xFFu)
     static_for<P>([&](auto K) {
         constexpr int k = decltype(K)::value;
         // dev::cell_of at sub-cell resolution (negative / NaN products clamp to 0, large ones to the last sub-cell)
-        const uint32_t sx = (uint32_t)fmin(fmax((px[k] - h.rx0) * (h.inv_fw * S), 0.0), sub_max);
-        const uint32_t sy = (uint32_t)fmin(fmax((py[k] - h.ry0) * (h.inv_fh * S), 0.0), sub_max);
-        const bool real = px[k] == px[k] && py[k] == py[k];
+        const double pxk = point_x<k>(pr), pyk = point_y<k>(pr);
+        const uint32_t sx = (uint32_t)fmin(fmax((pxk - h.rx0) * inv_w_s, 0.0), sub_max);
+        const uint32_t sy = (uint32_t)fmin(fmax((pyk - h.ry0) * inv_h_s, 0.0), sub_max);
+        const bool real = pxk == pxk && pyk == pyk;
         const uint32_t cx = sx / S, cy = sy / S;
-        sidx[k] = (sy % S) * S + (sx % S);
+        sidx4[k / 4] |= ((sy % S) * S + (sx % S)) << (8 * (k % 4));
         w[k] = gw[k] = 0u;
         bool want = false;
         if (ROUTE) {
@@ -1360,10 +1453,11 @@ __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mas
         } else {
             want = real;
         }
-        if (want) gw[k] = h.cell[(cy << logR) + cx];
+        if (want) gw[k] = cell_words[(cy << logR) + cx];
         GPK_SCHED_FENCE();
     });
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const HalfCell* __restrict__ const half_recs = HOT_ARG(half);
     u32x4 rec[P];  // HalfCell: lw[0], lw[1], part, aux_base  (kept as the 16-byte tuple the request fills: copies out of it would sit
                    // in the requesting branch and wait for the request on the spot — P round trips one after the other)
     static_for<P>([&](auto K) {
@@ -1375,7 +1469,7 @@ __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mas
                 recmask |= 1u << k;
             }
         }
-        if ((recmask >> k) & 1u) rec[k] = *reinterpret_cast<const u32x4*>(h.half + 2u * w[k] + (sidx[k] >> 5));
+        if ((recmask >> k) & 1u) rec[k] = *reinterpret_cast<const u32x4*>(half_recs + 2u * w[k] + (SIDX(k) >> 5));
     });
     GPK_SCHED_FENCE();
     // 3. labels; a `test` point goes into the wave's LDS list with its chain entry; anything a lean index should not hold is deferred
@@ -1392,7 +1486,7 @@ __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mas
         bool test = false;
         uint32_t aux_at = 0u;
         if (has) {
-            const uint32_t sh = 2u * (sidx[k] & 15u), upper = (sidx[k] >> 4) & 1u;
+            const uint32_t si = SIDX(k), sh = 2u * (si & 15u), upper = (si >> 4) & 1u;
             const uint32_t lw = upper ? rec[k].y : rec[k].x;
             const uint32_t lab = (lw >> sh) & 3u;
             if (lab >= 1u) res[k] = rec[k].z & 0x3FFFFFFFu;
@@ -1413,15 +1507,15 @@ __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mas
         }
         const unsigned long long m = __ballot(test);
         if (m) {  // (wave-uniform)
-            const uint32_t at = n_items + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            const uint32_t at = n_items + (FUSED ? lanes_below(m) : (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
             n_items += (uint32_t)__popcll(m);
             if (test) {
                 if (at < (uint32_t)ITEMS) {
                     slots[k / 4] |= at << (8 * (k % 4));
                     tmask |= 1u << k;
                     ChainItem* it = s_items + at;
-                    it->px = px[k];
-                    it->py = py[k];
+                    it->px = point_x<k>(pr);
+                    it->py = point_y<k>(pr);
                     it->aux_at = aux_at;
                 } else {
                     dmask |= 1u << k;  // the list is full
@@ -1430,8 +1524,14 @@ __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mas
         }
         GPK_SCHED_FENCE();
     });
-    uint32_t* __restrict__ tile_counts = h.counts ? h.counts + base : nullptr;
-    uint32_t* __restrict__ tile_code = h.code + base;
+#undef SIDX
+    if constexpr (PREFETCH) {  // the next tile's points: their round trip runs next to the exact step's (px, py are dead from here)
+        if (next_tile >= 0) chain_load_points<P, true, FUSED>(h, next_tile, lane, pr);  // (wave-uniform; the caller names guard-free tiles only)
+        GPK_SCHED_FENCE();
+    }
+    uint32_t* const counts_all = HOT_ARG(counts);
+    uint32_t* __restrict__ tile_counts = counts_all ? counts_all + base : nullptr;
+    uint32_t* __restrict__ tile_code = FUSED ? nullptr : h.code + base;
     // 4. the exact step: one listed point per lane and pass
     n_items = n_items < (uint32_t)ITEMS ? n_items : (uint32_t)ITEMS;
     unsigned long long edges_walked = 0;
@@ -1439,11 +1539,13 @@ __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mas
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const ChainAux* __restrict__ const aux_all = HOT_ARG(sub_aux);
+        const uint32_t* __restrict__ const head_all = HOT_ARG(chain_head);
         for (uint32_t i = (uint32_t)lane; i < n_items; i += 64u) {
-            const uint32_t at = s_items[i].aux_at;
-            const ChainAux* __restrict__ e = h.sub_aux + at;
+            const uint32_t at = GPK_CHAIN_ABLATE == 2 ? (s_items[i].aux_at & 0x3FFFu) : s_items[i].aux_at;  // (2, tuning builds only: chain entries from a 1 MB corner of the table)
+            const ChainAux* __restrict__ e = aux_all + at;
             double2 q = make_double2(s_items[i].px, s_items[i].py);
-            uint32_t hd = h.chain_head[at];
+            uint32_t hd = head_all[at];
             double2 a0 = e->v[0], a1 = e->v[1], a2 = e->v[2], a3 = e->v[3];
             // (all five requests go out before the head is looked at: the compiler would otherwise sink the vertex requests
             // under `count > 0` — a second round trip)
@@ -1457,7 +1559,7 @@ __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mas
                 if (count >= 2) on |= dev::ring_edge_filtered(a1.x, a1.y, a2.x, a2.y, qx, qy, wn, defer);
                 if (count >= 3) on |= dev::ring_edge_filtered(a2.x, a2.y, a3.x, a3.y, qx, qy, wn, defer);
                 if (count > 3) {  // 0.2 % of the chains: the further vertices follow in chain_ext
-                    const double2* __restrict__ ev = h.chain_ext + (hd >> CHAIN_EXT_SHIFT);
+                    const double2* __restrict__ ev = HOT_ARG(chain_ext) + (hd >> CHAIN_EXT_SHIFT);
                     double ax = a3.x, ay = a3.y;
                     for (int j = 3; j < count; ++j) {
                         const double2 b = ev[j - 3];
@@ -1496,13 +1598,83 @@ __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mas
             constexpr int k = decltype(K)::value;
             const bool want = ((dmask >> k) & 1u) != 0u;
             const unsigned long long m = __ballot(want);
-            if (want) s_rare[n_rare + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)(k * 64 + lane);
+            if (want) s_rare[n_rare + (FUSED ? lanes_below(m) : (uint32_t)__popcll(m & ((1ull << lane) - 1ull)))] = (uint32_t)(k * 64 + lane);
             n_rare += (uint32_t)__popcll(m);
         });
     }
-    if (h.stats && n_items) {  // measurement runs only (gpk_join_stats_enable): uniform branch on the pointer
+    if (!FUSED && h.stats && n_items) {  // measurement runs only (gpk_join_stats_enable): uniform branch on the pointer
         if (lane == 0) atomicAdd(&h.stats[0], (unsigned long long)n_items);
         if (edges_walked) atomicAdd(&h.stats[1], edges_walked);
+    }
+    if constexpr (FUSED) {
+        unsigned long long* const stats = HOT_ARG(stats);
+        if (stats && n_items) {
+            if (lane == 0) atomicAdd(&stats[0], (unsigned long long)n_items);
+            if (edges_walked) atomicAdd(&stats[1], edges_walked);
+        }
+        const uint32_t run = *run_io;
+        const uint32_t* const part_geom = HOT_ARG(part_geom);
+        const uint8_t* const polys_validity = HOT_ARG(polys_validity);
+        unsigned long long* s_mh = reinterpret_cast<unsigned long long*>(s_rare + 64 * P);  // the point rows' hit masks, for the rare arm
+        static_assert(sizeof(ChainItem) * chain_items<P>() >= sizeof(uint32_t) * 64 * P + sizeof(unsigned long long) * P, "the list also holds the rows' hit masks");
+        // the ordinary rows: part -> geometry (null geometries dropped), count, the hit at its rank among them
+        uint32_t hits = 0;  // wave-uniform
+        static_for<P>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            const uint32_t li = (uint32_t)(k * 64 + lane);
+            uint32_t r = res[k];
+            if (r != CODE_NONE) {
+                const uint32_t geom = part_geom ? part_geom[r] : r;
+                r = dev::valid_row(polys_validity, geom) ? geom : CODE_NONE;
+            }
+            const bool mine = (FULL || li < rem) && !((dmask >> k) & 1u);  // (a rare row's count and hits are written by its walk)
+            const bool hit = mine && r != CODE_NONE;
+            const unsigned long long m = __ballot(hit);
+            if (mine && tile_counts) dev::store_stream(tile_counts + li, hit ? 1u : 0u);
+            if (hit && out) {
+                const uint32_t at = run + hits + lanes_below(m);
+                if (at < out_cap) out[at] = make_uint2((uint32_t)(base + li), r);
+            }
+            if (n_rare && lane == 0) s_mh[k] = m;
+            hits += (uint32_t)__popcll(m);
+        });
+        // the rare rows, in row order, when nothing of the tile's state is live any more: the generic walk counts the row's hits; a
+        // row that has some opens a gap for them among the hits stored so far (the run's tail moves up) and walks again, storing
+        if (n_rare) {  // (wave-uniform)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            uint32_t cum = 0;  // hits of the rare rows so far
+            for (uint32_t i = 0; i < n_rare; ++i) {
+                const uint32_t li = s_rare[i], rk = li >> 6, rj = li & 63u;
+                uint32_t before = (uint32_t)__popcll(s_mh[rk] & ((1ull << rj) - 1ull));
+                for (uint32_t kk = 0; kk < rk; ++kk) before += (uint32_t)__popcll(s_mh[kk]);
+                const uint32_t at = run + before + cum, end = run + hits + cum;
+                const double2 q = tile_xy[li];
+                uint32_t cnt = 0;
+                for (int phase = 0; phase < 2; ++phase) {
+                    cnt = chain_generic_row_call(HOT_ARG(cold), q.x, q.y, lane, phase ? out + at : nullptr, at < out_cap ? out_cap - at : 0u, (uint32_t)(base + li));
+                    if (phase == 1 || cnt == 0u || !out) break;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the hits stored so far have arrived)
+                    for (uint32_t hi = end; hi > at; hi = hi - at > 64u ? hi - 64u : at) {  // [at, end) up by cnt, from the top
+                        const uint32_t lo = hi - at > 64u ? hi - 64u : at, src = lo + (uint32_t)lane;
+                        uint2 v = make_uint2(0u, 0u);
+                        if (src < hi && src < out_cap) v = out[src];
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (every lane has its entry before any lane stores)
+                        if (src < hi && src + cnt < out_cap && src + cnt >= src) out[src + cnt] = v;
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                if (lane == 0 && tile_counts) tile_counts[li] = cnt;
+                cum += cnt;
+            }
+            hits += cum;
+            if (stats && lane == 0) atomicAdd(&stats[2], (unsigned long long)n_rare);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next tile overwrites the list)
+            __builtin_amdgcn_wave_barrier();
+        }
+        *run_io = run + hits;
+        return;
     }
     // part -> geometry (null geometries dropped), count + code, the tile's total
     unsigned long long hits = 0;  // wave-uniform
@@ -1548,12 +1720,19 @@ __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mas
         if (hits) atomicAdd(&h.super_tot[tile >> PIP_SUPER_SHIFT], hits);  // integer adds: order-independent
     }
 }
+template <int P, bool ROUTE, bool FUSED = false>
+__device__ __forceinline__ void chain_tile_any(const ChainHot& h, const uint2* s_mask, const uint32_t* s_rec0, ChainItem* s_items, int64_t tile, int lane,
+                                               uint2* out, uint32_t out_cap, uint32_t* run_io, PointRegs<P>& pr, int64_t next_tile) {
+    const bool full = FUSED ? tile < (int64_t)h.n_full_tiles : (h.pts_validity == nullptr && (tile + 1) * (int64_t)(64 * P) <= h.n_points);
+    if (full)  // (wave-uniform)
+        chain_tile<P, ROUTE, true, FUSED>(h, s_mask, s_rec0, s_items, tile, lane, out, out_cap, run_io, pr, next_tile);
+    else
+        chain_tile<P, ROUTE, false, FUSED>(h, s_mask, s_rec0, s_items, tile, lane, out, out_cap, run_io, pr, next_tile);
+}
 template <int P, bool ROUTE>
 __device__ __forceinline__ void chain_tile_any(const ChainHot& h, const uint2* s_mask, const uint32_t* s_rec0, ChainItem* s_items, int64_t tile, int lane) {
-    if (h.pts_validity == nullptr && (tile + 1) * (int64_t)(64 * P) <= h.n_points)  // (wave-uniform)
-        chain_tile<P, ROUTE, true>(h, s_mask, s_rec0, s_items, tile, lane);
-    else
-        chain_tile<P, ROUTE, false>(h, s_mask, s_rec0, s_items, tile, lane);
+    PointRegs<P> pr;
+    chain_tile_any<P, ROUTE, false>(h, s_mask, s_rec0, s_items, tile, lane, nullptr, 0u, nullptr, pr, (int64_t)-1);
 }
 
 __global__ __launch_bounds__(PIP_BLOCK) void pip_tile_chain_kernel(ChainHot h) {
@@ -1583,6 +1762,180 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_route_kernel(ChainHot h)
     __syncthreads();
     for (int64_t tile = (int64_t)blockIdx.x * (ROUTE_BLOCK / 64) + (threadIdx.x >> 6); tile < h.n_tiles; tile += stride)
         chain_tile_any<ROUTE_PPT, true>(h, s_mask, s_rec0, s_items[threadIdx.x >> 6], tile, lane);
+}
+
+// The whole join in ONE launch (round 4): persistent work-groups as above, but a wave owns a CONTIGUOUS run of tiles and keeps its
+// hits — already in (l, r) order — in the pair slots of its own rows (ChainHot::stage: scratch, one slot per left row, read back by
+// the wave that wrote it: same CU, same L2).  When its tiles are done a work-group publishes its hit total; the totals of the
+// work-groups before it (one 64-bit word each, tagged with the launch's epoch so that nothing has to be zeroed: agent-scope
+// atomics, the only words that cross XCDs) give its offset in the pair list, and every wave copies its run there.  No result
+// codes, no tile totals, no writer launch: the step's traffic is points in, counts out, hits out + once through the staging slots.
+// A work-group only ever waits for work-groups with SMALLER indices, which the dispatcher places first; concurrent launches from
+// different streams are kept apart by the host (they share the epoch words).  A wave whose hits outgrow its rows' slots (rows in
+// several geometries) decides its tiles a second time, storing straight to the final offsets it then knows.
+struct FusedTail {
+    uint2* pairs;            // may be nullptr: counts and total only
+    int64_t capacity;        // pair slots of `pairs`
+    unsigned long long* slots;   // one word per work-group: epoch << FUSED_TOTAL_BITS | hit total
+    unsigned long long epoch;
+    unsigned long long* grand;
+    unsigned long long* grand_host;
+    uint32_t left_base, pad;
+    unsigned long long* ticket;      // work-groups number themselves in the order they START: ticket - ticket_base
+    unsigned long long ticket_base;  // (the counter only ever grows: the host knows where a launch's numbers begin)
+};
+#ifndef GPK_FUSED_ABLATE
+#define GPK_FUSED_ABLATE 0
+#endif
+#ifndef GPK_FUSED_COPY_UNROLL
+#define GPK_FUSED_COPY_UNROLL 8
+#endif
+constexpr int FUSED_TOTAL_BITS = 40;
+constexpr uint32_t FUSED_SPIN_LIMIT = 1u << 22;
+constexpr unsigned long long FUSED_LOST = ~0ull;  // in the total's place: the launch gave up waiting (gpk_spatial_join reports GPK_ERR_DEVICE)
+__global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_fused_kernel(ChainHot h, FusedTail tail_in_the_argument_segment) {
+    constexpr int WORDS = PIP_ROUTE_RMAX * PIP_ROUTE_RMAX / 32, W = ROUTE_BLOCK / 64, TILE = 64 * FUSED_PPT;
+    __shared__ uint2 s_mask[WORDS];     // RouteWord::bmask, gmask
+    __shared__ uint32_t s_rec0[WORDS];  // RouteWord::rec0
+    __shared__ ChainItem s_items[W][chain_items<FUSED_PPT>()];
+    __shared__ unsigned long long s_wtot[W];
+    __shared__ unsigned long long s_part[W];
+    {
+        const int words = h.R * h.R / 32;
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(h.route);
+        for (int i = threadIdx.x; i < words; i += ROUTE_BLOCK) {
+            const uint4 rw = src[i];
+            s_mask[i] = make_uint2(rw.x, rw.y);
+            s_rec0[i] = rw.z;
+        }
+    }
+    // (the wave's number as a SCALAR: what follows from it — its tile range, where its hits go, how many it has — then lives in scalar
+    // registers; derived from threadIdx.x the compiler takes it all for per-lane values, seven vector registers the tile loop does not have)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // this work-group's number: the order in which the work-groups of the launch started, not blockIdx — a work-group waits (below) for
+    // the totals of those numbered before it, and those are then known to be running or done whatever order the dispatcher chose
+    __shared__ uint32_t s_wg;
+    if (threadIdx.x == 0) {
+        typedef const FusedTail __attribute__((address_space(4))) * TailPtr0;
+        const TailPtr0 tp0 = (TailPtr0)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(ChainHot));
+        s_wg = (uint32_t)(__hip_atomic_fetch_add(tp0->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - tp0->ticket_base);
+    }
+    __syncthreads();
+    const uint32_t wg = __builtin_amdgcn_readfirstlane(s_wg);
+    int tile0, tile1;
+    {
+        const int64_t gwave = (int64_t)wg * W + wave, n_waves = (int64_t)gridDim.x * W;
+        tile0 = (int)(gwave * h.n_tiles / n_waves);
+        tile1 = (int)((gwave + 1) * h.n_tiles / n_waves);
+    }
+    uint2* out = h.stage ? h.stage + (int64_t)tile0 * TILE : nullptr;
+    uint32_t out_cap = (uint32_t)(tile1 - tile0) * (uint32_t)TILE, run = 0u;
+    __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {
+        // guard-free tiles first (a tile's points are requested one tile ahead), then the guarded ones (the column's last tile; every
+        // tile of a column with a validity bitmap): two plain loops — one loop that picks the variant per tile keeps the points that
+        // travel round its back edge in scratch memory
+        PointRegs<FUSED_PPT> pr;
+        const int tile_f = tile1 < h.n_full_tiles ? tile1 : (tile0 > h.n_full_tiles ? tile0 : h.n_full_tiles);
+        if (GPK_FUSED_PREFETCH && tile0 < tile_f) chain_load_points<FUSED_PPT, true, true>(h, (int64_t)tile0, lane, pr);
+        for (int tile = tile0; tile < tile_f; ++tile)
+            chain_tile<FUSED_PPT, true, true, true>(h, s_mask, s_rec0, s_items[wave], (int64_t)tile, lane, out, out_cap, &run, pr,
+                                                   tile + 1 < tile_f ? (int64_t)(tile + 1) : (int64_t)-1);
+        for (int tile = tile_f; tile < tile1; ++tile)
+            chain_tile<FUSED_PPT, true, false, true>(h, s_mask, s_rec0, s_items[wave], (int64_t)tile, lane, out, out_cap, &run, pr, (int64_t)-1);
+        // (the tail of the kernel arguments is read HERE, from the argument segment: named directly the compiler loads it at the top
+        // of the kernel and carries its fourteen scalar registers through the tile loop, which has none to spare)
+        typedef const FusedTail __attribute__((address_space(4))) * TailPtr;
+        static_assert(sizeof(ChainHot) % 8 == 0, "FusedTail follows ChainHot in the argument segment");
+        const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        const TailPtr tp = (TailPtr)(ka + sizeof(ChainHot));
+        FusedTail t;
+        t.pairs = tp->pairs;
+        t.capacity = tp->capacity;
+        t.slots = tp->slots;
+        t.epoch = tp->epoch;
+        t.grand = tp->grand;
+        t.grand_host = tp->grand_host;
+        t.left_base = tp->left_base;
+        t.ticket = nullptr;
+        t.ticket_base = 0;
+#if GPK_FUSED_ABLATE == 2  // tuning builds only: the tile phase alone (no totals, no pair list)
+        break;
+#endif
+        if (pass == 1) {  // the second time round the hits went straight to their final slots: the left rows' base is still to add
+            if (t.left_base) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                for (uint32_t i = (uint32_t)lane; i < run && i < out_cap; i += 64u) out[i].x += t.left_base;
+            }
+            break;
+        }
+        // this work-group's total, published; the totals before it
+        if (lane == 0) s_wtot[wave] = (unsigned long long)run;
+        __syncthreads();
+        unsigned long long wg_tot = 0, mine_off = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const unsigned long long v = s_wtot[w];
+            wg_tot += v;
+            if (w < wave) mine_off += v;
+        }
+        if (threadIdx.x == 0) __hip_atomic_store(&t.slots[wg], (t.epoch << FUSED_TOTAL_BITS) | wg_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long acc = 0;
+        bool gave_up = false;
+        for (unsigned b = threadIdx.x; b < wg; b += ROUTE_BLOCK) {
+            unsigned long long v;
+            uint32_t spins = 0;
+            while (((v = __hip_atomic_load(&t.slots[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> FUSED_TOTAL_BITS) != t.epoch) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > FUSED_SPIN_LIMIT) {  // (seconds: a work-group before this one never ran — report, never hang the device)
+                    gave_up = true;
+                    break;
+                }
+            }
+            acc += v & ((1ull << FUSED_TOTAL_BITS) - 1ull);
+        }
+        const bool lost = __syncthreads_or(gave_up);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) s_part[wave] = acc;
+        __syncthreads();
+        unsigned long long base_off = 0;
+#pragma unroll
+        for (int w = 0; w < W; ++w) base_off += s_part[w];
+        if ((wg == gridDim.x - 1 || lost) && threadIdx.x == 0) {
+            *t.grand = lost ? FUSED_LOST : base_off + wg_tot;
+            if (t.grand_host) *t.grand_host = lost ? FUSED_LOST : base_off + wg_tot;
+        }
+        if (!t.pairs || lost || GPK_FUSED_ABLATE == 1) break;  // (ablation 1, tuning builds only: no copy)
+        const unsigned long long my_off = base_off + mine_off;
+        if (run <= out_cap) {  // the run, moved to its place in the pair list
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint2* __restrict__ src = out;
+            constexpr int CU = GPK_FUSED_COPY_UNROLL;  // entries a lane has in flight: the loop is a chain of round trips otherwise
+            for (uint32_t i0 = 0; i0 < run; i0 += 64u * CU) {
+                uint2 v[CU];
+#pragma unroll
+                for (int u = 0; u < CU; ++u) {
+                    const uint32_t i = i0 + (uint32_t)(u * 64 + lane);
+                    v[u] = i < run ? src[i] : make_uint2(0u, 0u);
+                }
+#pragma unroll
+                for (int u = 0; u < CU; ++u) {
+                    const uint32_t i = i0 + (uint32_t)(u * 64 + lane);
+                    if (i < run && (int64_t)(my_off + i) < t.capacity)
+                        __builtin_nontemporal_store(((unsigned long long)v[u].y << 32) | (unsigned long long)(v[u].x + t.left_base),
+                                                    reinterpret_cast<unsigned long long*>(t.pairs + my_off + i));
+                }
+            }
+            break;
+        }
+        // more hits than slots: decide the tiles again, storing at the final offsets
+        const int64_t room = t.capacity - (int64_t)my_off;
+        out = t.pairs + my_off;
+        out_cap = room <= 0 ? 0u : (room > (int64_t)0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)room);
+        run = 0u;
+    }
 }
 
 // pip_write: turns the per-point codes into the sorted (l, r) pair list.  Reads 4 bytes per point, writes 8
@@ -2111,6 +2464,78 @@ static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, co
     return done(GPK_OK);
 }
 
+// The epoch words of pip_tile_fused_kernel: one buffer per device (zeroed when created; a launch's tag is never 0), a process-wide
+// launch counter, and an event that keeps launches from DIFFERENT streams apart — they share the words, and two such launches
+// running side by side could each hold compute units the other's lower-numbered work-groups still wait for.
+static std::mutex g_fused_mu;
+struct FusedDev {
+    unsigned long long* slots = nullptr;  // n total words, then the ticket counter
+    unsigned long long tickets = 0;       // what the counter holds once every launch queued so far has started its work-groups
+    int n = 0;
+    hipEvent_t done = nullptr;
+    hipStream_t last = nullptr;
+    bool any = false;
+};
+static FusedDev g_fused[16];
+static unsigned long long g_fused_epoch = 0;
+static int32_t fused_launch_begin(hipStream_t s, int wgs, unsigned long long** slots, unsigned long long* epoch, unsigned long long** ticket,
+                                  unsigned long long* ticket_base) {
+    int dev = 0;
+    GPK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) return fail(GPK_ERR_DEVICE, "spatial_join: device %d out of range", dev);
+    g_fused_mu.lock();  // released by fused_launch_end: launch order = event order
+    FusedDev& f = g_fused[dev];
+    auto bail = [&](hipError_t e) {
+        g_fused_mu.unlock();
+        return fail(GPK_ERR_DEVICE, "spatial_join: %s", hipGetErrorString(e));
+    };
+    if (f.n < wgs) {
+        if (f.slots) {
+            (void)hipDeviceSynchronize();
+            (void)hipFree(f.slots);
+            f.slots = nullptr;
+        }
+        const int want = wgs < 1024 ? 1024 : wgs;
+        hipError_t e = hipMalloc((void**)&f.slots, sizeof(unsigned long long) * (size_t)(want + 1));
+        if (e != hipSuccess) return bail(e);
+        e = hipMemset(f.slots, 0, sizeof(unsigned long long) * (size_t)(want + 1));
+        if (e != hipSuccess) return bail(e);
+        f.n = want;
+        f.tickets = 0;
+    }
+    if (!f.done) {
+        const hipError_t e = hipEventCreateWithFlags(&f.done, hipEventDisableTiming);
+        if (e != hipSuccess) return bail(e);
+    }
+    if (f.any && f.last != s) {  // another stream launched last: this launch starts after everything queued there so far
+        hipError_t e = hipEventRecord(f.done, f.last);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, f.done, 0);
+        if (e != hipSuccess) {  // (that stream is gone: whatever it held has run or is drained here)
+            (void)hipGetLastError();
+            e = hipDeviceSynchronize();
+            if (e != hipSuccess) return bail(e);
+        }
+    }
+    ++g_fused_epoch;
+    if ((g_fused_epoch & ((1ull << (64 - FUSED_TOTAL_BITS)) - 1ull)) == 0ull) ++g_fused_epoch;  // (a tag of 0 is what a fresh word holds)
+    *epoch = g_fused_epoch & ((1ull << (64 - FUSED_TOTAL_BITS)) - 1ull);
+    *slots = f.slots;
+    *ticket = f.slots + f.n;
+    *ticket_base = f.tickets;
+    f.tickets += (unsigned long long)wgs;
+    return GPK_OK;
+}
+static void fused_launch_end(hipStream_t s, bool launched) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 16) {
+        g_fused[dev].last = s;
+        g_fused[dev].any = true;
+        if (!launched) g_fused[dev].n = 0;  // the ticket counter and the host's idea of it may differ now: fresh words for the next launch
+    }
+    g_fused_mu.unlock();
+}
+
 // Enqueues the point x polygonal join on `s` (memset of the totals, pip_tile, pip_write) and returns without waiting.
 // Device scratch comes from the calling thread's workspace; *total_out (device or device-mapped, may be NULL) receives
 // the number of hits when the stream gets there.
@@ -2137,8 +2562,14 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
     pvj.slab_xy = right->d.xy;
     const bool chain = right_index->pip.R > 0 && right_index->pip.sub_aux != nullptr;
     const bool route = chain && !no_route && right_index->pip.route != nullptr && right_index->pip.R <= PIP_ROUTE_RMAX;
+    // GPK_TILE_KERNEL=route: A/B runs of the round-3 pair (routed tile kernel + writer) instead of the fused launch
+    static const bool no_fused = [] {
+        const char* e = getenv("GPK_TILE_KERNEL");
+        return e && !strcmp(e, "route");
+    }();
+    const bool fused = route && !no_fused && n < (int64_t)0xFFFFFFFFll;
     const bool one_per_lane = !chain && !lean && right_index->pip.R > 0 && right_index->pip_list_heavy;  // (pip_tile_kernel<., ., 1>)
-    const int tile_points = chain ? 64 * (route ? ROUTE_PPT : CHAIN_PPT) : (lean ? LEAN_TILE : (one_per_lane ? PIP_BLOCK : PIP_TILE));
+    const int tile_points = chain ? 64 * (fused ? FUSED_PPT : (route ? ROUTE_PPT : CHAIN_PPT)) : (lean ? LEAN_TILE : (one_per_lane ? PIP_BLOCK : PIP_TILE));
     const int64_t n_blocks = (n + tile_points - 1) / tile_points;
     const bool want_pairs = pair_capacity > 0;
     const size_t counts_bytes = sizeof(uint32_t) * (size_t)n;
@@ -2147,8 +2578,9 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
     const int64_t n_wblocks = (n + PIP_WTILE - 1) / PIP_WTILE;
     // words in the multi-hit pool (a chain launch has no multi-hit rows in it: a rare row with several hits is CODE_MULTI)
     const uint32_t multi_cap = chain ? 1024u : (uint32_t)(n < (int64_t)0x18000000 ? 2 * n + 1024 : (int64_t)0x30000000);
-    size_t need = align256(counts_bytes + 64) /*code*/ + align256(sizeof(unsigned long long) * (size_t)(n_blocks + n_super + 3)) +
-                  align256(sizeof(uint32_t) * (size_t)multi_cap) + align256(sizeof(ChainCold)) + 1024;
+    const size_t stage_bytes = fused && want_pairs ? sizeof(uint2) * (size_t)n_blocks * (size_t)tile_points : 0;
+    size_t need = align256(fused ? 64 : counts_bytes + 64) /*code*/ + align256(sizeof(unsigned long long) * (size_t)(n_blocks + n_super + 3)) +
+                  align256(sizeof(uint32_t) * (size_t)multi_cap) + align256(sizeof(ChainCold)) + align256(stage_bytes) + 1024;
     if (host_out && out_counts) need += align256(counts_bytes);
     if (host_out && want_pairs) need += align256(pairs_bytes);
     // scratch of the stream-ordered join: one arena per (calling thread, stream), so that joins a thread enqueues on
@@ -2156,13 +2588,14 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
     Workspace& ws = workspace_for_stream(s);
     int32_t rc = ws.begin(need);
     if (rc != GPK_OK) return rc;
-    uint32_t* code = (uint32_t*)ws.take(counts_bytes + 64);
+    uint32_t* code = (uint32_t*)ws.take(fused ? 64 : counts_bytes + 64);
     unsigned long long* btot = (unsigned long long*)ws.take(sizeof(unsigned long long) * (size_t)(n_blocks + n_super + 3));
     unsigned long long* stot = btot + n_blocks;     // n_super super-tile totals
     unsigned long long* grand = stot + n_super;     // total hits
     uint32_t* multi_top = (uint32_t*)(grand + 1);   // words used in the multi-hit pool (zeroed with the totals)
     uint32_t* multi_pool = (uint32_t*)ws.take(sizeof(uint32_t) * (size_t)multi_cap);
     ChainCold* cold = (ChainCold*)ws.take(sizeof(ChainCold));
+    uint2* stage = stage_bytes ? (uint2*)ws.take(stage_bytes) : nullptr;
     uint32_t* counts_dev = out_counts ? (host_out ? (uint32_t*)ws.take(counts_bytes) : out_counts) : nullptr;
     uint32_t* pairs_dev = want_pairs ? (host_out ? (uint32_t*)ws.take(pairs_bytes) : out_pairs) : nullptr;
 
@@ -2178,7 +2611,21 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
     } while (0)
 
     unsigned long long* stats = join_stats_buffer();  // nullptr unless gpk_join_stats_enable(1)
-    if (chain) {  // totals zeroed and the rare arm's arguments written by one small launch
+    if (fused) {  // nothing to zero; the rare arm's arguments are written when they differ from what this arena holds
+        struct {
+            DevGeo polys;
+            IndexView ix;
+            uint64_t serial;
+        } want_cold;
+        memset(&want_cold, 0, sizeof want_cold);
+        want_cold.polys = right->d;
+        want_cold.ix = right_index->v;
+        want_cold.serial = right_index->serial;
+        if (!ws.tag_matches(cold, &want_cold, sizeof want_cold)) {
+            J_LAUNCH("gpk_join_prep", join_prep_kernel, dim3(1), dim3(256), 0, s, stot, 0, cold, right->d, right_index->v);
+            ws.set_tag(cold, &want_cold, sizeof want_cold);
+        }
+    } else if (chain) {  // totals zeroed and the rare arm's arguments written by one small launch
         J_LAUNCH("gpk_join_prep", join_prep_kernel, dim3(1), dim3(256), 0, s, stot, n_super + 2, cold, right->d, right_index->v);
     } else {
         const hipError_t me = hipMemsetAsync(stot, 0, sizeof(unsigned long long) * (size_t)(n_super + 2), s);  // (+ grand, multi_top)
@@ -2213,6 +2660,36 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         hot.super_tot = stot;
         hot.stats = stats;
         hot.cold = cold;
+        hot.stage = stage;
+        hot.n_full_tiles = left->d.validity ? 0 : (int32_t)(n / tile_points);
+        hot.inv_fw_s = pv.inv_fw * (double)PIP_SUB;
+        hot.inv_fh_s = pv.inv_fh * (double)PIP_SUB;
+        hot.sub_max = (double)(((uint32_t)PIP_SUB << hot.logR) - 1u);
+    }
+    if (fused) {  // one launch: persistent work-groups (one per CU), contiguous tiles per wave, pairs written by the same kernel
+        const int tiles_per_wg = ROUTE_BLOCK / 64;
+        int64_t wgs = (int64_t)cu_count();
+        const int64_t want = (n_blocks + tiles_per_wg - 1) / tiles_per_wg;
+        if (wgs > want) wgs = want;
+        FusedTail tail;
+        memset(&tail, 0, sizeof tail);
+        tail.pairs = (uint2*)pairs_dev;
+        tail.capacity = pair_capacity;
+        tail.grand = grand;
+        tail.grand_host = total_out;
+        tail.left_base = left_row_base;
+        int32_t frc = fused_launch_begin(s, (int)wgs, &tail.slots, &tail.epoch, &tail.ticket, &tail.ticket_base);
+        if (frc != GPK_OK) return frc;
+        frc = [&]() -> int32_t {
+            GPK_LAUNCH("gpk_pip_tile", pip_tile_fused_kernel, dim3((unsigned)wgs), dim3(ROUTE_BLOCK), 0, s, hot, tail);
+            return GPK_OK;
+        }();
+        fused_launch_end(s, frc == GPK_OK);
+        if (frc != GPK_OK) return frc;
+        *counts_dev_out = counts_dev;
+        *pairs_dev_out = pairs_dev;
+        *grand_out = grand;
+        return GPK_OK;
     }
     if (chain && route) {  // persistent work-groups, one per CU
         const int tiles_per_wg = ROUTE_BLOCK / 64;
@@ -2432,6 +2909,10 @@ int32_t gpk_index_build_ex(const gpk_geoarray* a, int32_t parts, const double* b
     ix->device = a->device;
     ix->n_geoms = n;
     ix->geom_type = a->d.type;
+    {
+        static std::atomic<uint64_t> next_serial{1};
+        ix->serial = next_serial.fetch_add(1);
+    }
 
     // grid resolution: ~2 cells per geometry along each axis of a square layout
     int gdim = (int)ceil(2.0 * sqrt((double)(n > 0 ? n : 1)));
@@ -2621,6 +3102,7 @@ int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right, co
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return done(fail(GPK_ERR_DEVICE, "spatial_join: %s", hipGetErrorString(e)));
     if (pinned_total) total = *(volatile unsigned long long*)pinned_total;
+    if (total == ~0ull) return done(fail(GPK_ERR_DEVICE, "spatial_join: the fused point join gave up waiting for one of its work-groups"));
     *n_pairs = (int64_t)total;
     if (host_out) {
         if (out_counts) {

@@ -144,9 +144,24 @@ int32_t Workspace::begin(size_t total) {
         }
         cap_ = want;
         device_ = dev;
+        tag_cur_ = false;
     }
     used_ = 0;
+    tag_prev_ = tag_cur_;
+    tag_cur_ = false;
     return GPK_OK;
+}
+bool Workspace::tag_matches(const void* where, const void* bytes, size_t n) {
+    const bool same = tag_prev_ && where == tag_where_ && n == tag_n_ && n <= sizeof tag_ && memcmp(tag_, bytes, n) == 0;
+    if (same) tag_cur_ = true;
+    return same;
+}
+void Workspace::set_tag(const void* where, const void* bytes, size_t n) {
+    if (n > sizeof tag_) return;
+    memcpy(tag_, bytes, n);
+    tag_n_ = n;
+    tag_where_ = where;
+    tag_cur_ = true;
 }
 void* Workspace::take(size_t bytes) {
     bytes = align256(bytes);
@@ -161,6 +176,7 @@ void Workspace::trim(size_t keep_max) {
     (void)hipFree(base_);
     base_ = nullptr;
     cap_ = used_ = 0;
+    tag_cur_ = tag_prev_ = false;
 }
 Workspace::~Workspace() {
     // process teardown: the HIP runtime may already be gone; leak rather than crash.
