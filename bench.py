@@ -179,7 +179,7 @@ class Ctx:
         self.lib.gpk_profile_query(name.encode(), C.byref(ms), C.byref(cnt))
         return (ms.value / max(cnt.value, 1), int(cnt.value))
 
-    def timed(self, step, dominant: str, steps: int, warmup: int, profile: bool = True):
+    def timed(self, step, dominant: str, steps: int, warmup: int, profile: bool = True, one_launch_steps=None):
         """W untimed steps (every kernel bracketed by events after the first: per-kernel durations without taxing the
         timed region), then exactly K steps between barrier + synchronize, only the dominant kernel carrying events.
         -> (seconds max over ranks, dominant-kernel ms per launch, launches, {kernel: ms} from the warm-up)"""
@@ -193,17 +193,31 @@ class Ctx:
         self.torch.cuda.synchronize()
         warm = self._all_kernels(max(warmup - 1, 1))
         lib.gpk_profile_reset()
+        # one_launch_steps(warm) -> True: a step is ONE launch of the dominant kernel (the fused point join).  Its duration then comes
+        # from one pair of HIP events on the launching stream AROUND the K back-to-back launches, divided by K (launch gaps included:
+        # an upper bound of the kernel's own time) — an event pair per launch costs the timed region 5 - 7 us per step, which is
+        # nothing next to three kernels and 6 % of one.
+        span = bool(profile and one_launch_steps is not None and one_launch_steps(warm))
         lib.gpk_profile_filter(dominant.encode())
-        lib.gpk_profile_enable(1 if profile else 0)
+        lib.gpk_profile_enable(1 if (profile and not span) else 0)
+        ev = (self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)) if span else None
         self.barrier()
         t0 = time.perf_counter()
+        if span:
+            ev[0].record(self.torch.cuda.current_stream())
         for i in range(steps):
             step(warmup + i)
+        if span:
+            ev[1].record(self.torch.cuda.current_stream())
         self.barrier()
         t1 = time.perf_counter()
         lib.gpk_profile_enable(0)
         lib.gpk_profile_filter(b"")
-        k_ms, k_n = self.kernel_ms(dominant)
+        if span:
+            k_ms, k_n = ev[0].elapsed_time(ev[1]) / steps, steps
+        else:
+            k_ms, k_n = self.kernel_ms(dominant)
+        self.span_events = span
         lib.gpk_profile_reset()
         self.rank_seconds = self.all_ranks(t1 - t0)  # every rank's own clock around the same K steps (the line carries them)
         return self.max_over_ranks(t1 - t0), k_ms, k_n, warm
@@ -346,7 +360,10 @@ def run_c2(ctx: Ctx) -> None:
         else:
             join_pairs_enqueue(s["pts"], polys, index, "intersects", s["counts"], s["pairs"], s["total"], left_row_base=0, stream=stream)
 
-    elapsed, k_tile, n_tile, warm = ctx.timed(step, "gpk_pip_tile", args.steps, args.warmup, profile=not args.no_profile)
+    # (a step of the fused join is the one launch `gpk_pip_tile`; with GPK_TILE_KERNEL=route — the round-3 pair — the writer shows up)
+    elapsed, k_tile, n_tile, warm = ctx.timed(step, "gpk_pip_tile", args.steps, args.warmup, profile=not args.no_profile,
+                                              one_launch_steps=lambda w: "gpk_pip_write" not in w and not sync_steps)
+    fused = "gpk_pip_write" not in warm
     # what the exact phase did, measured on one extra untimed step (a few atomics per tile: never inside the timed region)
     st = (C.c_int64 * 4)()
     if not args.no_join_stats:
@@ -365,10 +382,11 @@ def run_c2(ctx: Ctx) -> None:
     evals = float(ctx.world) * n * m * args.steps
     ms_per_step = elapsed / args.steps * 1e3
     v_total = polys_host.n_coords
-    # algorithmic bytes of the dominant launch (gpk_pip_tile): points in, polygon coords + offsets in, hit counts out —
-    # each distinct byte once (the 8H pair bytes belong to gpk_pip_write)
-    bytes_tile = 16 * n + 16 * v_total + 2 * 4 * (m + 1) + 4 * n
-    bytes_join = bytes_tile + 8 * h
+    # algorithmic bytes (each distinct byte once): points in, polygon coords + offsets in, hit counts out,
+    # and the 8H pair bytes — all of it belongs to the ONE launch of the fused join; with the round-3 pair of kernels the pair
+    # bytes belong to gpk_pip_write and the dominant launch owns the rest
+    bytes_join = 16 * n + 16 * v_total + 2 * 4 * (m + 1) + 4 * n + 8 * h
+    bytes_tile = bytes_join if fused else bytes_join - 8 * h
     achieved = bytes_tile / (k_tile * 1e-3) / 1e9 if k_tile > 0 else 0.0
     traffic, valu_busy, traffic_note = None, None, None
     if n == 10_000_000 and m == 1000 and args.verts == 64:
@@ -387,7 +405,9 @@ def run_c2(ctx: Ctx) -> None:
         "polygons": m,
         "vertices_per_polygon": args.verts,
         "hits_per_step": h,
-        "algorithm": "two-level exact raster routing (level 1 from an LDS image in persistent work-groups, level 2 = one 16-byte half-cell record) -> `test` sub-cells decided from their local chain (base winding + one or two ring edges, exact orientation filter; uncertifiable rows go through the generic exact walk), sorted (l,r) pairs + counts; N x M logical pairs counted, raster-rejected pairs included",
+        "algorithm": "ONE launch per join (persistent work-groups): two-level exact raster routing (level 1 from an LDS image, level 2 = one 16-byte half-cell record) -> `test` sub-cells decided from the half cell's local chain (base winding + about two ring edges read from the right side's extended coordinates, exact orientation filter; uncertifiable rows go through the generic exact walk) -> a wave's hits parked in its rows' pair slots, work-group totals chained through epoch-tagged words, sorted (l,r) pairs + counts written by the same launch; N x M logical pairs counted, raster-rejected pairs included"
+        if fused
+        else "round-3 pair of kernels (GPK_TILE_KERNEL=route): routed tile kernel + writer",
         "index_tables": index.describe(),
         "index": "rebuilt per step" if args.index_per_step else "prebuilt r_index (spatial_index.rs:20-21)",
         "call": "gpk_spatial_join (blocking)" if sync_steps else "gpk_spatial_join_async (stream-ordered; the timed region ends synchronised)",
@@ -414,6 +434,10 @@ def run_c2(ctx: Ctx) -> None:
         "traffic_note": traffic_note,
         "launch_ms": k_tile,
         "launches": n_tile,
+        "launch_ms_method": "one HIP event pair on the launching stream around the K back-to-back launches / K (a step is one launch; gaps included)"
+        if getattr(ctx, "span_events", False)
+        else "HIP event pair per launch (gpk_profile_*)",
+        "frac_of_achievable": achieved / 6300.0,
         "algorithmic_bytes": bytes_tile,
         "source_hash": source_hash(),
     }

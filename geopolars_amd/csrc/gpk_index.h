@@ -87,6 +87,21 @@ constexpr uint32_t CHAIN_COUNT_MASK = 0xFu;  // bits 0-3: edges in the chain, 1 
 constexpr int CHAIN_BASE_SHIFT = 4;          // bits 4-11: summed winding contribution of every ring edge outside the chain (signed):
                                              // constant over the padded sub-cell
 constexpr int CHAIN_EXT_SHIFT = 12;          // bits 12-31: count > 3: PipView::chain_ext[ext .. ext + count - 3) are vertices 4 .. count
+// GPK_HALF_CHAINS (round 4, the default): ONE chain per half-cell record instead of one per `test` sub-cell.  The chain is the arc of
+// the ring that covers every edge meeting the padded HALF CELL (grown at both ends while the end vertex's y lies in the half's
+// y-interval); the same argument gives winding(p) = base + sum over the chain for every p of the half cell, and an on-boundary
+// point lies on a chain edge.  The chain is named by a word IN the record (HalfCell::aux_base) — count, base, and where its
+// vertices start in PipView::chain_xy, the right side's coordinates with CHAIN_MAX more per ring (a chain may run over the closing
+// vertex: vertex k of the extended ring is coordinate k % edges) — so a `test` point needs no head-word request and reads vertices of
+// a table as hot as the coordinates themselves (C2: 1.2 MB) instead of a cold 64-byte line of a per-sub-cell table (C2: 56 MB +
+// 3.5 MB of head words).  It walks about two edges where the per-sub-cell chain had 1.26.
+#ifndef GPK_HALF_CHAINS
+#define GPK_HALF_CHAINS 1
+#endif
+constexpr uint32_t HCHAIN_COUNT_MASK = 0xFu;  // bits 0-3: edges, 1 .. CHAIN_MAX (0: no chain — several runs, too long, a part with holes,
+                                              // an unclosed ring: the generic walk decides the half's `test` points)
+constexpr int HCHAIN_BASE_SHIFT = 4;          // bits 4-7: the other edges' summed winding contribution, signed
+constexpr int HCHAIN_START_SHIFT = 8;         // bits 8-31: first vertex in PipView::chain_xy
 struct ChainAux {
     double2 v[4];  // the chain's first four vertices, copied (a chain may run over the ring's closing vertex)
 };
@@ -122,6 +137,7 @@ struct PipView {
     const ChainAux* sub_aux;         // lean indexes with chains (see ChainAux); else nullptr
     const uint32_t* chain_head;      // count | base | ext per chain entry
     const double2* chain_ext;        // vertices 4 .. of the chains longer than three edges
+    const double2* chain_xy;         // GPK_HALF_CHAINS: extended ring coordinates the half-cell chains index (then sub_aux / chain_head / chain_ext are null)
     const RouteWord* route;          // LDS image of the level-1 routing (chains + R <= PIP_ROUTE_RMAX); else nullptr
     const SubCell* lrec;             // level-2 records of the BOUNDARY entries of list cells: when set, such an entry is
                                      // `record index << 1 | 1` (the record names the part), else `part << 1 | 1`

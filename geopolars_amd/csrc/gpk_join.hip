@@ -1192,7 +1192,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define GPK_CHAIN_ABLATE 0  // tuning builds only (answers wrong on purpose): 1 = `test` points count as outside
 #endif
 #ifndef GPK_FUSED_PREFETCH
-#define GPK_FUSED_PREFETCH 1
+#define GPK_FUSED_PREFETCH 0  // the next tile's points requested during the exact step (fused kernel): measured 4 % SLOWER (108 vs 104 us)
 #endif
 #ifndef GPK_ROUTE_BLOCK
 #define GPK_ROUTE_BLOCK 1024
@@ -1218,6 +1218,7 @@ struct ChainHot {
     const ChainAux* sub_aux;
     const uint32_t* chain_head;
     const double2* chain_ext;
+    const double2* chain_xy;  // GPK_HALF_CHAINS: the vertices the records' chain words index
     const uint32_t* part_geom;
     const RouteWord* route;
     uint32_t* counts;
@@ -1491,10 +1492,14 @@ __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mas
             const uint32_t lab = (lw >> sh) & 3u;
             if (lab >= 1u) res[k] = rec[k].z & 0x3FFFFFFFu;
             if (lab >= 2u) {
+#if GPK_HALF_CHAINS
+                aux_at = rec[k].w;  // the half's chain word
+#else
                 // rank of this `test` label among the half's: the lower label word (if the label sits in the upper one), then
                 // the fields below it in its own word
                 const uint32_t tl = (lw >> 1) & ~lw & 0x55555555u, tl0 = (rec[k].x >> 1) & ~rec[k].x & 0x55555555u;
                 aux_at = rec[k].w + (upper ? (uint32_t)__popc(tl0) : 0u) + (uint32_t)__popc(tl & ((1u << sh) - 1u));
+#endif
                 if (GPK_CHAIN_ABLATE == 1)
                     res[k] = CODE_NONE;
                 else
@@ -1539,6 +1544,42 @@ __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mas
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#if GPK_HALF_CHAINS
+        const double2* __restrict__ const cxy = HOT_ARG(chain_xy);
+        for (uint32_t i = (uint32_t)lane; i < n_items; i += 64u) {
+            const uint32_t hd = s_items[i].aux_at;  // the half's chain word: count, base, first vertex
+            const double qx = s_items[i].px, qy = s_items[i].py;
+            const int count = (int)(hd & HCHAIN_COUNT_MASK);
+            const double2* __restrict__ v = cxy + (hd >> HCHAIN_START_SHIFT);
+            // the first five vertices (four edges: 99 % of the chains of the C2 right side) are requested together; a short chain
+            // repeats its last vertex's request, which costs nothing new
+            double2 a0 = v[0], a1 = v[count >= 1 ? 1 : 0], a2 = v[count >= 2 ? 2 : (count >= 1 ? 1 : 0)];
+            double2 a3 = a2, a4 = a2;
+            if (count >= 3) {
+                a3 = v[3];
+                a4 = v[count >= 4 ? 4 : 3];
+            }
+            asm volatile("" : "+v"(a0.x), "+v"(a0.y), "+v"(a1.x), "+v"(a1.y), "+v"(a2.x), "+v"(a2.y), "+v"(a3.x), "+v"(a3.y), "+v"(a4.x), "+v"(a4.y));
+            bool inside = false, defer = count == 0;  // no chain for this half cell: the generic walk decides
+            if (count > 0) {
+                int wn = ((int)(hd << (28 - HCHAIN_BASE_SHIFT))) >> 28;  // the signed 4-bit base
+                bool on = dev::ring_edge_filtered(a0.x, a0.y, a1.x, a1.y, qx, qy, wn, defer);
+                if (count >= 2) on |= dev::ring_edge_filtered(a1.x, a1.y, a2.x, a2.y, qx, qy, wn, defer);
+                if (count >= 3) on |= dev::ring_edge_filtered(a2.x, a2.y, a3.x, a3.y, qx, qy, wn, defer);
+                if (count >= 4) on |= dev::ring_edge_filtered(a3.x, a3.y, a4.x, a4.y, qx, qy, wn, defer);
+                if (count > 4) {
+                    double ax = a4.x, ay = a4.y;
+                    for (int j = 4; j < count; ++j) {
+                        const double2 b2 = v[j + 1];
+                        on |= dev::ring_edge_filtered(ax, ay, b2.x, b2.y, qx, qy, wn, defer);
+                        ax = b2.x;
+                        ay = b2.y;
+                    }
+                }
+                inside = !on && wn != 0;
+                edges_walked += (unsigned long long)count;
+            }
+#else
         const ChainAux* __restrict__ const aux_all = HOT_ARG(sub_aux);
         const uint32_t* __restrict__ const head_all = HOT_ARG(chain_head);
         for (uint32_t i = (uint32_t)lane; i < n_items; i += 64u) {
@@ -1571,6 +1612,7 @@ __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mas
                 inside = !on && wn != 0;
                 edges_walked += (unsigned long long)count;
             }
+#endif
             s_items[i].aux_at = (inside && !defer ? 1u : 0u) | (defer ? 2u : 0u);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2560,7 +2602,7 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
     // same column — SpatialIndex(series) next to the series itself — stays valid after that upload is gone)
     PipView pvj = right_index->pip;
     pvj.slab_xy = right->d.xy;
-    const bool chain = right_index->pip.R > 0 && right_index->pip.sub_aux != nullptr;
+    const bool chain = right_index->pip.R > 0 && (GPK_HALF_CHAINS ? right_index->pip.chain_xy != nullptr : right_index->pip.sub_aux != nullptr);
     const bool route = chain && !no_route && right_index->pip.route != nullptr && right_index->pip.R <= PIP_ROUTE_RMAX;
     // GPK_TILE_KERNEL=route: A/B runs of the round-3 pair (routed tile kernel + writer) instead of the fused launch
     static const bool no_fused = [] {
@@ -2652,6 +2694,7 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         hot.sub_aux = pv.sub_aux;
         hot.chain_head = pv.chain_head;
         hot.chain_ext = pv.chain_ext;
+        hot.chain_xy = pv.chain_xy;
         hot.part_geom = pv.part_geom;
         hot.route = pv.route;
         hot.counts = counts_dev;
@@ -2881,7 +2924,7 @@ int32_t gpk_index_describe(const gpk_index* idx, int64_t out[8]) {
     for (int i = 0; i < 8; ++i) out[i] = 0;
     out[0] = idx->pip.R;
     out[1] = idx->pip_lean;
-    out[2] = idx->pip.sub_aux != nullptr;
+    out[2] = GPK_HALF_CHAINS ? idx->pip.chain_xy != nullptr : idx->pip.sub_aux != nullptr;
     out[3] = idx->pip.route != nullptr;
     out[4] = idx->pip_list_heavy;
     return GPK_OK;

@@ -780,6 +780,174 @@ __global__ void chain_ext_kernel(DevGeo a, uint32_t* __restrict__ head, const ui
     head[i] |= (uint32_t)ext_off[i] << CHAIN_EXT_SHIFT;
     for (int j = 4; j <= len; ++j) ext[ext_off[i] + (j - 4)] = a.xy[c0 + (lo + j) % ne];
 }
+// ---- half-cell chains (gpk_index.h: GPK_HALF_CHAINS) -------------------------------------------------------------------------
+// extended ring coordinates: ring r's n coordinates followed by CHAIN_MAX more, entry k = coordinate k % (n - 1)
+__global__ void chain_xy_kernel(DevGeo a, double2* __restrict__ ext) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n_ext = a.n_coords + a.n_rings * CHAIN_MAX;
+    if (k >= n_ext) return;
+    // ring of extended entry k: ext_off[r] = ring_off[r] + r * CHAIN_MAX is increasing in r
+    int lo = 0, hi = (int)a.n_rings - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int64_t)a.ring_off[mid] + (int64_t)mid * CHAIN_MAX <= k)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const int c0 = a.ring_off[lo], n = a.ring_off[lo + 1] - c0;
+    const int j = (int)(k - ((int64_t)c0 + (int64_t)lo * CHAIN_MAX));
+    const int ne = n - 1;
+    ext[k] = n <= 0 ? make_double2(0.0, 0.0) : (ne >= 1 ? a.xy[c0 + j % ne] : a.xy[c0]);
+}
+// One wave per record (as chain_aux_kernel): the wave lists the edges of the part's slab rows in this raster row that meet the
+// padded cell; lanes 0 and 1 then build the chain words of the record's two halves (only a half with `test` labels needs one).
+__global__ __launch_bounds__(256) void half_chain_kernel(DevGeo a, PipView pv, FineGrid g, const int32_t* __restrict__ work_cell,
+                                                         const uint32_t* __restrict__ work_part, int64_t n_work,
+                                                         const int32_t* __restrict__ slab_vidx, const SubCell* __restrict__ sub,
+                                                         uint32_t* __restrict__ hword) {
+    constexpr int S = PIP_SUB, SS = PIP_SUB * PIP_SUB;
+    static_assert(S == 8 && SS == 64, "a record is two halves of four sub-cell rows");
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t item = t / SS;
+    if (item >= n_work) return;  // (whole waves)
+    const int64_t c = work_cell[item];
+    const int part = (int)work_part[item];
+    const SubCell rc = sub[item];
+    const int ci = (int)(c % g.R), cj = (int)(c / g.R);
+    const double fw2 = g.fw / S, fh2 = g.fh / S, px2 = g.pad_x / S, py2 = g.pad_y / S;
+    const double cxl = g.rx0 + (double)(S * ci) * fw2 - px2, cxh = g.rx0 + (double)(S * ci + S) * fw2 + px2;
+    const double cyl = g.ry0 + (double)(S * cj) * fh2 - py2, cyh = g.ry0 + (double)(S * cj + S) * fh2 + py2;
+    __shared__ double4 s_edges[256 / 64][SUB_EDGE_CAP];
+    __shared__ int32_t s_vidx[256 / 64][SUB_EDGE_CAP];
+    const int wave = threadIdx.x >> 6, lane64 = threadIdx.x & 63;
+    int r0, r1;
+    dev::part_rings(a, part, r0, r1);
+    bool list_ok = r1 - r0 == 1;  // a part with holes: no chains (uniform)
+    int n_list = 0;
+    if (list_ok) {
+        int e0, e1;
+        if (pip::slab_span_of_raster_row(pv, r0, cj, e0, e1)) {
+            for (int eb = e0; eb < e1 && list_ok; eb += 64) {
+                const int e = eb + lane64;
+                bool keep = false;
+                double4 ed = make_double4(0, 0, 0, 0);
+                if (e < e1) {
+                    ed = pip::slab_edge(pv, e);
+                    keep = !(fmax(ed.x, ed.z) < cxl || fmin(ed.x, ed.z) > cxh || fmax(ed.y, ed.w) < cyl || fmin(ed.y, ed.w) > cyh);
+                }
+                const unsigned long long m = __ballot(keep);
+                const int add = __popcll(m);
+                if (n_list + add > SUB_EDGE_CAP) {
+                    list_ok = false;
+                    break;
+                }
+                if (keep) {
+                    const int at = n_list + __popcll(m & ((1ull << lane64) - 1ull));
+                    s_edges[wave][at] = ed;
+                    s_vidx[wave][at] = pip::slab_vertex(slab_vidx[e]);
+                }
+                n_list += add;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane64 >= 2) return;
+    const int half = lane64;
+    uint32_t word = 0u;
+    const bool wanted = test_labels_of(rc.labels[2 * half]) + test_labels_of(rc.labels[2 * half + 1]) > 0;
+    const int c0 = list_ok ? a.ring_off[r0] : 0, ne = list_ok ? a.ring_off[r0 + 1] - c0 - 1 : 0;  // the ring's edges: 0 .. ne - 1
+    bool closed = false;
+    if (list_ok && ne >= 1) {
+        const double2 f = a.xy[c0], l = a.xy[c0 + ne];
+        closed = f.x == l.x && f.y == l.y;  // (an unclosed ring has no closing edge for the other walks: no chain, they decide)
+    }
+    if (wanted && closed) {
+        const int sj0 = S * cj + (S / 2) * half;
+        const double xl = cxl, xh = cxh;
+        const double yl = g.ry0 + (double)sj0 * fh2 - py2, yh = g.ry0 + (double)(sj0 + S / 2) * fh2 + py2;
+        // 1. the listed edges that meet this padded half cell (exact: the test that labels sub-cells)
+        unsigned long long touched = 0ull;
+        for (int e = 0; e < n_list; ++e) {
+            const double4 ed = s_edges[wave][e];
+            if (fmax(ed.x, ed.z) < xl || fmin(ed.x, ed.z) > xh || fmax(ed.y, ed.w) < yl || fmin(ed.y, ed.w) > yh) continue;
+            const int o1 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yl), o2 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yl);
+            const int o3 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yh), o4 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yh);
+            if ((o1 > 0 && o2 > 0 && o3 > 0 && o4 > 0) || (o1 < 0 && o2 < 0 && o3 < 0 && o4 < 0)) continue;
+            touched |= 1ull << e;
+        }
+        // the shortest arc [lo, lo + len) of the cycle 0 .. ne - 1 that covers the touched edges (chain_aux_kernel has the argument)
+        int lo = 0, len = 0;
+        if (touched) {
+            int best_gap = -1, best_next = 0;
+            for (unsigned long long ma = touched; ma; ma &= ma - 1ull) {
+                const int ea = s_vidx[wave][__ffsll((long long)ma) - 1] - c0;
+                int nd = ne, nb = ea;
+                for (unsigned long long mb = touched; mb; mb &= mb - 1ull) {
+                    const int eb = s_vidx[wave][__ffsll((long long)mb) - 1] - c0;
+                    int d = eb - ea;
+                    if (d < 0) d += ne;
+                    if (d > 0 && d < nd) {
+                        nd = d;
+                        nb = eb;
+                    }
+                }
+                if (nd > best_gap) {
+                    best_gap = nd;
+                    best_next = nb;
+                }
+            }
+            lo = best_next;
+            len = ne - best_gap + 1;
+        }
+        bool ok = len >= 1 && len <= CHAIN_MAX;
+        // 2. grow while the end vertex's y lies in the half's closed y-interval
+        while (ok && len < ne) {
+            int hv = lo + len;
+            if (hv >= ne) hv -= ne;
+            const double y = a.xy[c0 + hv].y;
+            if (!(y >= yl && y <= yh)) break;
+            ++len;
+            ok = len <= CHAIN_MAX;
+        }
+        while (ok && len < ne) {
+            const double y = a.xy[c0 + lo].y;
+            if (!(y >= yl && y <= yh)) break;
+            lo = lo == 0 ? ne - 1 : lo - 1;
+            ++len;
+            ok = len <= CHAIN_MAX;
+        }
+        if (ok) {
+            // 3. base: the other edges' winding at the half's centre — they all sit in the centre's slab row
+            const double cx = g.rx0 + ((double)(S * ci) + 0.5 * S) * fw2, cy = g.ry0 + ((double)sj0 + 0.25 * S) * fh2;
+            int e0, e1, wn = 0;
+            bool on = false;
+            if (pip::slab_range(pv, r0, pip::row_of(pv, cy), e0, e1)) {
+                for (int e = e0; e < e1; ++e) {
+                    int d = pip::slab_vertex(slab_vidx[e]) - c0 - lo;
+                    if (d < 0) d += ne;
+                    if (d < len) continue;  // an edge of the arc
+                    const double4 ed = pip::slab_edge(pv, e);
+                    on |= dev::ring_edge(ed.x, ed.y, ed.z, ed.w, cx, cy, wn);
+                }
+            }
+            const int64_t start = (int64_t)c0 + (int64_t)r0 * CHAIN_MAX + lo;
+            if (!on && wn >= -8 && wn <= 7 && start < ((int64_t)1 << (32 - HCHAIN_START_SHIFT)))
+                word = (uint32_t)len | ((uint32_t)(wn & 15) << HCHAIN_BASE_SHIFT) | ((uint32_t)start << HCHAIN_START_SHIFT);
+        }
+    }
+    hword[2 * item + half] = word;
+}
+__global__ void half_chain_commit_kernel(SubCell* __restrict__ sub, int64_t n_sub, const uint32_t* __restrict__ hword) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_sub) return;
+    const SubCell rc = sub[i];
+    HalfCell* h = reinterpret_cast<HalfCell*>(sub + i);
+    h[0] = HalfCell{{rc.labels[0], rc.labels[1]}, rc.part_flags & ~SUB_INDIRECT, hword[2 * i]};
+    h[1] = HalfCell{{rc.labels[2], rc.labels[3]}, rc.part_flags & ~SUB_INDIRECT, hword[2 * i + 1]};
+}
 // an index with chains: every one-part record is rewritten as two half-cell records (gpk_index.h: HalfCell) — after chain_aux_kernel,
 // which reads the SubCell form
 __global__ void chain_commit_kernel(SubCell* __restrict__ sub, int64_t n_sub, const int32_t* __restrict__ aux_base) {
@@ -1242,7 +1410,36 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
     ix->pip_lean = (int64_t)list_len * 8 <= (int64_t)n_sub && n_refined == 0 && boundary_cells_have_records ? 1 : 0;
     if (getenv("GPK_DEBUG_INDEX")) fprintf(stderr, "[gpk] lean join kernel eligible: %d (list %d, refined rings %d, one-part records %d)\n", ix->pip_lean, list_len, n_refined, n_sub);
     // local chains for the `test` sub-cells of a lean index (gpk_index.h: ChainAux): the join then decides them in the owning lane
-    if (ix->pip_lean && slab_vidx && n_sub > 0 && swork_cell && !getenv("GPK_NO_CHAINS")) {
+    if (GPK_HALF_CHAINS && ix->pip_lean && slab_vidx && n_sub > 0 && swork_cell && !getenv("GPK_NO_CHAINS") &&
+        d.n_coords + d.n_rings * CHAIN_MAX < ((int64_t)1 << (32 - HCHAIN_START_SHIFT))) {
+        // half-cell chains (gpk_index.h: GPK_HALF_CHAINS): the extended coordinates, one chain word per half record, the records
+        // rewritten as half-cell records carrying their word — three launches, no table sized by a read-back
+        const int64_t n_ext = d.n_coords + d.n_rings * CHAIN_MAX;
+        double2* cxy = nullptr;
+        GPK_HIP(cached_malloc((void**)&cxy, sizeof(double2) * (size_t)n_ext));
+        keep(cxy);
+        uint32_t* hword;
+        GPK_TRY(t.alloc(&hword, (size_t)n_sub * 2 + 2));
+        pv.sub = sub;
+        GPK_LAUNCH("gpk_pipidx_chain_xy", chain_xy_kernel, blocks_for(n_ext), dim3(256), 0, s, d, cxy);
+        GPK_LAUNCH("gpk_pipidx_half_chain", half_chain_kernel, blocks_for((int64_t)n_sub * PIP_SUB * PIP_SUB), dim3(256), 0, s, d, pv, g,
+                   (const int32_t*)swork_cell, (const uint32_t*)swork_part, (int64_t)n_sub, (const int32_t*)slab_vidx, (const SubCell*)sub, hword);
+        GPK_LAUNCH("gpk_pipidx_chain_commit", half_chain_commit_kernel, blocks_for(n_sub), dim3(256), 0, s, sub, (int64_t)n_sub, (const uint32_t*)hword);
+        pv.chain_xy = cxy;
+        ix->nbytes += (int64_t)(sizeof(double2) * (size_t)n_ext);
+        if (R <= PIP_ROUTE_RMAX && !getenv("GPK_NO_ROUTE_IMAGE")) {
+            RouteWord* route = nullptr;
+            const int64_t n_words = n_cells / 32;
+            GPK_HIP(cached_malloc((void**)&route, sizeof(RouteWord) * (size_t)n_words));
+            keep(route);
+            GPK_LAUNCH("gpk_pipidx_route", route_build_kernel, blocks_for(n_words), dim3(256), 0, s, (const uint32_t*)cell, n_words, route);
+            pv.route = route;
+            ix->nbytes += (int64_t)(sizeof(RouteWord) * (size_t)n_words);
+        }
+        GPK_HIP(hipStreamSynchronize(s));  // (the temporaries go back to the arena when this function returns)
+        if (getenv("GPK_DEBUG_INDEX")) fprintf(stderr, "[gpk] half-cell chains: %d records, %lld extended coordinates%s\n", n_sub, (long long)n_ext, pv.route ? ", routing image" : "");
+        stamp("local chains");
+    } else if (!GPK_HALF_CHAINS && ix->pip_lean && slab_vidx && n_sub > 0 && swork_cell && !getenv("GPK_NO_CHAINS")) {
         int32_t *ccnt, *cbase_tmp;
         GPK_TRY(t.alloc(&ccnt, (size_t)n_sub + 1));
         GPK_TRY(t.alloc(&cbase_tmp, (size_t)n_sub + 1));
