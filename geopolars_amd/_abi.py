@@ -131,6 +131,7 @@ _PROTOS = {
     "gpk_comm_free": (C.c_int32, [_VP]),
     "gpk_comm_info": (C.c_int32, [_VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gpk_allgatherv_geoarray": (C.c_int32, [_VP, _VP, _VP, C.POINTER(_VP), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "gpk_geoarray_concat": (C.c_int32, [C.POINTER(_VP), C.c_int32, _VP, C.POINTER(_VP), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "gpk_allgatherv_rows_f64": (C.c_int32, [_VP, _VP, C.c_int64, C.c_int32, _VP, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _VP]),
     "gpk_device_cache_release": (C.c_int32, []),
     "gpk_join_stats_enable": (C.c_int32, [C.c_int32]),

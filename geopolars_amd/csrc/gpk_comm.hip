@@ -15,9 +15,19 @@
 #include <mutex>
 #include <vector>
 
-#include <rccl/rccl.h>
-
 #include "gpk_common.h"
+
+// The handful of RCCL declarations this file needs, written out: the library is opened with dlopen, and a ROCm install without
+// the RCCL development headers must still be able to BUILD this translation unit (the entry points then report GPK_ERR_DEVICE
+// at run time when no librccl.so can be opened).  Values as in rccl.h (they are NCCL's ABI).
+extern "C" {
+typedef struct gpkNcclComm* ncclComm_t;
+typedef struct {
+    char internal[128];
+} ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6, ncclFloat32 = 7, ncclFloat64 = 8 } ncclDataType_t;
+}
 
 namespace gpk {
 
@@ -111,27 +121,267 @@ __global__ void bytes_to_bitmap_kernel(const uint8_t* __restrict__ bytes, int64_
 
 }  // namespace gpk
 
-using namespace gpk;
-
 struct gpk_comm {
     ncclComm_t comm;
     int32_t rank, world, device;
 };
 
-// every rank's piece of one buffer lands at its final place: a grouped round of `world` broadcasts (elements of `elem` bytes)
-static int32_t gather_pieces(const Rccl* r, gpk_comm* c, const void* mine, const int64_t* counts, const int64_t* dst_begin, size_t elem, char* out, hipStream_t s) {
-    GPK_NCCL(r, r->GroupStart());
-    for (int k = 0; k < c->world; ++k) {
-        if (counts[k] == 0) continue;  // (every rank skips the same pieces: the counts come from the header)
-        const ncclResult_t n = r->Broadcast(k == c->rank ? mine : nullptr, out + (size_t)dst_begin[k] * elem, (size_t)counts[k] * elem, ncclUint8, k, c->comm, s);
-        if (n != ncclSuccess) {
-            (void)r->GroupEnd();
-            return fail(GPK_ERR_DEVICE, "ncclBroadcast failed: %s", r->GetErrorString(n));
-        }
+namespace gpk {
+
+// ---- who holds the shards of a column, and how a piece gets to its place --------------------------------------------------
+// The exchange has two halves.  MOVE: the lengths of every shard become known everywhere and shard k's bytes of each buffer land
+// at an offset of the gathered buffer — between ranks with one small all-gather + one grouped round of broadcasts per buffer
+// (RCCL), or, when one process holds all the shards (a chunked column, a test), with device-to-device copies.  ASSEMBLE: where
+// the pieces land (shard k > 0 drops the leading entry of its offsets), what is added to shard k's offsets (the children of the
+// shards before it, minus the shard's own first offset: a device view need not start at 0), how validity bits are repacked
+// (a shard's rows do not start on a byte of the gathered bitmap).  assemble_column is written once against `Shards`; only
+// move_pieces / gather_header know which kind it is — so gpk_geoarray_concat runs, on one GPU with K shards, every line of
+// placement arithmetic that gpk_allgatherv_geoarray runs with K ranks.
+struct Shards {
+    int W = 0;                                   // ranks, or shards held here
+    int me = -1;                                 // this rank (RCCL), -1: every shard is local
+    const Rccl* r = nullptr;
+    gpk_comm* c = nullptr;
+    const gpk_geoarray* const* local = nullptr;  // me < 0: the K shards; me >= 0: local[0] = this rank's shard
+    const DevGeo& mine_or(int k) const { return me < 0 ? local[k]->d : local[0]->d; }
+    bool holds(int k) const { return me < 0 || k == me; }
+};
+constexpr int HDR = 9;  // n_geoms, n_parts, n_rings, n_coords, has_validity, type, first geom / part / ring offset
+__global__ void first_offsets_kernel(const int32_t* __restrict__ geom_off, const int32_t* __restrict__ part_off, const int32_t* __restrict__ ring_off,
+                                     int64_t* __restrict__ hdr) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    hdr[6] = geom_off ? geom_off[0] : 0;
+    hdr[7] = part_off ? part_off[0] : 0;
+    hdr[8] = ring_off ? ring_off[0] : 0;
+}
+static void header_of(const DevGeo& d, int64_t* h) {
+    const bool has_part = d.type == GPK_GEOM_MULTIPOLYGON,
+               has_ring = d.type == GPK_GEOM_POLYGON || d.type == GPK_GEOM_MULTILINESTRING || d.type == GPK_GEOM_MULTIPOLYGON;
+    h[0] = d.n_geoms;
+    h[1] = has_part ? d.n_parts : 0;
+    h[2] = has_ring ? d.n_rings : 0;
+    h[3] = d.n_coords;
+    h[4] = d.validity ? 1 : 0;
+    h[5] = d.type;
+    h[6] = h[7] = h[8] = 0;
+}
+// hdr[HDR * W] on the host: every shard's sizes and first offsets (the only host read of the exchange)
+static int32_t gather_header(const Shards& S, std::vector<int64_t>& hdr, hipStream_t s) {
+    const int W = S.W;
+    hdr.assign((size_t)HDR * W, 0);
+    GPK_TRY(workspace_aux(0).begin(sizeof(int64_t) * (size_t)(HDR * (W + 1)) + 512));
+    int64_t* hdr_dev = (int64_t*)workspace_aux(0).take(sizeof(int64_t) * (size_t)(HDR * (W + 1)));
+    auto stage = [&](const DevGeo& d, int64_t* at) -> int32_t {  // one shard's header row, its first offsets read on the device
+        int64_t h[HDR];
+        header_of(d, h);
+        GPK_HIP(hipMemcpyAsync(at, h, sizeof h, hipMemcpyHostToDevice, s));
+        if (d.n_geoms > 0) hipLaunchKernelGGL(first_offsets_kernel, dim3(1), dim3(64), 0, s, d.geom_off, d.part_off, d.ring_off, at);
+        GPK_HIP(hipStreamSynchronize(s));  // (h is a local)
+        return GPK_OK;
+    };
+    if (S.me < 0) {
+        for (int k = 0; k < W; ++k) GPK_TRY(stage(S.local[k]->d, hdr_dev + (size_t)HDR * k));
+    } else {
+        GPK_TRY(stage(S.local[0]->d, hdr_dev + (size_t)HDR * W));
+        GPK_NCCL(S.r, S.r->AllGather(hdr_dev + (size_t)HDR * W, hdr_dev, HDR, ncclInt64, S.c->comm, s));
     }
-    GPK_NCCL(r, r->GroupEnd());
+    GPK_HIP(hipMemcpyAsync(hdr.data(), hdr_dev, sizeof(int64_t) * (size_t)(HDR * W), hipMemcpyDeviceToHost, s));
+    GPK_HIP(hipStreamSynchronize(s));
     return GPK_OK;
 }
+// piece k of one buffer (counts[k] elements of `elem` bytes, read at src(k)) -> out + begin[k] * elem.  Every rank issues the same
+// sequence of collectives whatever its own shard holds (the counts come from the header).
+template <typename SrcOf>
+static int32_t move_pieces(const Shards& S, SrcOf src, const int64_t* counts, const int64_t* begin, size_t elem, char* out, hipStream_t s) {
+    if (S.me < 0) {
+        for (int k = 0; k < S.W; ++k)
+            if (counts[k] > 0) GPK_HIP(hipMemcpyAsync(out + (size_t)begin[k] * elem, src(k), (size_t)counts[k] * elem, hipMemcpyDeviceToDevice, s));
+        return GPK_OK;
+    }
+    GPK_NCCL(S.r, S.r->GroupStart());
+    for (int k = 0; k < S.W; ++k) {
+        if (counts[k] == 0) continue;
+        const ncclResult_t n = S.r->Broadcast(k == S.me ? src(k) : nullptr, out + (size_t)begin[k] * elem, (size_t)counts[k] * elem, ncclUint8, k, S.c->comm, s);
+        if (n != ncclSuccess) {
+            (void)S.r->GroupEnd();
+            return fail(GPK_ERR_DEVICE, "ncclBroadcast failed: %s", S.r->GetErrorString(n));
+        }
+    }
+    GPK_NCCL(S.r, S.r->GroupEnd());
+    return GPK_OK;
+}
+// every rank learns whether every rank got this far (its allocations succeeded): a rank that failed locally must not leave
+// the others waiting inside the broadcasts that follow
+static int32_t agree(const Shards& S, int32_t my_rc, hipStream_t s) {
+    if (S.me < 0) return my_rc;
+    int64_t* w = (int64_t*)workspace_aux(0).take(sizeof(int64_t) * (size_t)(S.W + 1));
+    if (!w) return my_rc != GPK_OK ? my_rc : fail(GPK_ERR_OOM, "allgatherv: scratch");
+    const int64_t mine = my_rc;
+    std::vector<int64_t> all((size_t)S.W);
+    GPK_HIP(hipMemcpyAsync(w + S.W, &mine, sizeof mine, hipMemcpyHostToDevice, s));
+    GPK_NCCL(S.r, S.r->AllGather(w + S.W, w, 1, ncclInt64, S.c->comm, s));
+    GPK_HIP(hipMemcpyAsync(all.data(), w, sizeof(int64_t) * (size_t)S.W, hipMemcpyDeviceToHost, s));
+    GPK_HIP(hipStreamSynchronize(s));
+    if (my_rc != GPK_OK) return my_rc;
+    for (int k = 0; k < S.W; ++k)
+        if (all[(size_t)k] != GPK_OK) return fail((int32_t)all[(size_t)k], "allgatherv: rank %d could not allocate its copy of the column", k);
+    return GPK_OK;
+}
+
+static int32_t assemble_column(const Shards& S, hipStream_t s, gpk_geoarray** out, int64_t* row_bases /* W + 1, may be NULL */, int64_t* out_bytes) {
+    const int W = S.W;
+    *out = nullptr;
+    const DevGeo& d0 = S.mine_or(0);
+    const int32_t type = d0.type;
+    const bool has_geom = type != GPK_GEOM_POINT, has_part = type == GPK_GEOM_MULTIPOLYGON,
+               has_ring = type == GPK_GEOM_POLYGON || type == GPK_GEOM_MULTILINESTRING || type == GPK_GEOM_MULTIPOLYGON;
+    std::vector<int64_t> hdr;
+    GPK_TRY(gather_header(S, hdr, s));
+    bool any_valid = false;
+    int64_t tot[4] = {0, 0, 0, 0};
+    for (int k = 0; k < W; ++k) {
+        if (hdr[(size_t)HDR * k + 5] != type)
+            return fail(GPK_ERR_MISMATCHED_GEOMETRY, "allgatherv: shard %d holds geometry type %lld, this one %d", k, (long long)hdr[(size_t)HDR * k + 5], type);
+        any_valid = any_valid || hdr[(size_t)HDR * k + 4] != 0;
+        for (int q = 0; q < 4; ++q) tot[q] += hdr[(size_t)HDR * k + q];
+    }
+    if (tot[0] > INT32_MAX || tot[1] > INT32_MAX || tot[2] > INT32_MAX || tot[3] > INT32_MAX)
+        return fail(GPK_ERR_INVALID_ARGUMENT, "allgatherv: the gathered column exceeds 2^31 - 1 rows / rings / coordinates (Arrow i32 offsets)");
+    if (row_bases) {
+        row_bases[0] = 0;
+        for (int k = 0; k < W; ++k) row_bases[k + 1] = row_bases[k] + hdr[(size_t)HDR * k + 0];
+    }
+
+    gpk_geoarray* a = new gpk_geoarray;
+    memset(a, 0, sizeof *a);
+    a->device = S.local[0]->device;
+    a->d.type = type;
+    a->d.n_geoms = tot[0];
+    a->d.n_parts = has_part ? tot[1] : (is_polygonal(type) ? tot[0] : 0);
+    a->d.n_rings = has_ring ? tot[2] : 0;
+    a->d.n_coords = tot[3];
+    auto done = [&](int32_t rc) {
+        if (rc != GPK_OK) {
+            (void)hipStreamSynchronize(s);
+            gpk_geoarray_free(a);
+        } else {
+            *out = a;
+        }
+        return rc;
+    };
+    // ---- every output buffer and all scratch first, then agree that every rank has them: nothing below can fail locally
+    struct Level {
+        bool present;
+        int slot, rows_q, child_q, first_q;  // header columns: rows of this level, rows of its child level (3 = coordinates), first offset
+        const int32_t* DevGeo::*src;
+        const int32_t** view;
+    } levels[3] = {
+        {has_geom, 1, 0, has_part ? 1 : (has_ring ? 2 : 3), 6, &DevGeo::geom_off, &a->d.geom_off},
+        {has_part, 2, 1, 2, 7, &DevGeo::part_off, &a->d.part_off},
+        {has_ring, 3, 2, 3, 8, &DevGeo::ring_off, &a->d.ring_off},
+    };
+    auto alloc = [&](int slot, size_t bytes, const void** view) -> int32_t {
+        void* p = nullptr;
+        const hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
+        if (e != hipSuccess) return fail(GPK_ERR_OOM, "allgatherv: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        a->owned[slot] = p;
+        *view = p;
+        a->nbytes += (int64_t)bytes;
+        return GPK_OK;
+    };
+    int32_t rc = alloc(0, sizeof(double2) * (size_t)tot[3], (const void**)&a->d.xy);
+    for (const Level& L : levels)
+        if (rc == GPK_OK && L.present) rc = alloc(L.slot, sizeof(int32_t) * (size_t)(tot[L.rows_q] + 1), (const void**)L.view);
+    const bool validity = any_valid && tot[0] > 0;
+    uint8_t *all_bytes = nullptr, *my_bytes = nullptr;
+    int32_t* zero_word = nullptr;
+    if (rc == GPK_OK && validity) rc = alloc(4, (size_t)((tot[0] + 7) / 8), (const void**)&a->d.validity);
+    if (rc == GPK_OK) {
+        int64_t local_rows = 0;
+        for (int k = 0; k < W; ++k)
+            if (S.holds(k)) local_rows += hdr[(size_t)HDR * k + 0];
+        rc = workspace_aux(1).begin((validity ? (size_t)tot[0] + (size_t)local_rows : 0) + 2048);
+        if (rc == GPK_OK) {
+            zero_word = (int32_t*)workspace_aux(1).take(256);
+            if (validity) {
+                all_bytes = (uint8_t*)workspace_aux(1).take((size_t)tot[0]);
+                my_bytes = (uint8_t*)workspace_aux(1).take((size_t)(local_rows ? local_rows : 1));
+            }
+            if (!zero_word || (validity && (!all_bytes || !my_bytes))) rc = fail(GPK_ERR_OOM, "allgatherv: scratch");
+        }
+    }
+    rc = agree(S, rc, s);
+    if (rc != GPK_OK) return done(rc);
+    {
+        const hipError_t e = hipMemsetAsync(zero_word, 0, 256, s);
+        if (e != hipSuccess) return done(fail(GPK_ERR_DEVICE, "allgatherv: %s", hipGetErrorString(e)));
+    }
+
+    std::vector<int64_t> cnt((size_t)W), begin((size_t)W + 1);
+    // ---- coordinates
+    begin[0] = 0;
+    for (int k = 0; k < W; ++k) {
+        cnt[(size_t)k] = hdr[(size_t)HDR * k + 3];
+        begin[(size_t)k + 1] = begin[(size_t)k] + cnt[(size_t)k];
+    }
+    if ((rc = move_pieces(S, [&](int k) { return (const void*)S.mine_or(k).xy; }, cnt.data(), begin.data(), sizeof(double2), (char*)a->owned[0], s)) != GPK_OK) return done(rc);
+    // ---- offsets, outermost first: level `lvl` has rows + 1 entries per shard; its values count the children of the next level
+    for (const Level& L : levels) {
+        if (!L.present) continue;
+        RebaseArgs ra;
+        ra.world = W;
+        int64_t at = 0, child = 0;
+        for (int k = 0; k < W; ++k) {
+            const int64_t rows = hdr[(size_t)HDR * k + L.rows_q];
+            // shard 0 sends rows + 1 entries (its leading entry included), the others rows entries (from their entry 1 on)
+            cnt[(size_t)k] = k == 0 ? rows + 1 : rows;
+            begin[(size_t)k] = at;
+            ra.dst_begin[k] = at;
+            ra.shift[k] = child - hdr[(size_t)HDR * k + L.first_q];  // (a shard's offsets need not start at 0)
+            at += cnt[(size_t)k];
+            child += hdr[(size_t)HDR * k + L.child_q];
+        }
+        begin[(size_t)W] = at;
+        ra.dst_begin[W] = at;
+        auto src = [&](int k) -> const void* {
+            const int32_t* p = S.mine_or(k).*(L.src);
+            if (!p) return (const void*)zero_word;  // an empty shard without an offsets buffer: its one entry (shard 0 only) is 0
+            return (const void*)(k == 0 ? p : p + 1);
+        };
+        if ((rc = move_pieces(S, src, cnt.data(), begin.data(), sizeof(int32_t), (char*)a->owned[L.slot], s)) != GPK_OK) return done(rc);
+        if (at > 0) hipLaunchKernelGGL(rebase_offsets_kernel, dim3((unsigned)((at + 255) / 256)), dim3(256), 0, s, (int32_t*)a->owned[L.slot], ra);
+    }
+    // ---- validity: one byte per row travels (bit offsets of a shard's rows are not byte-aligned in the gathered bitmap)
+    if (validity) {
+        std::vector<const uint8_t*> my_at((size_t)W, nullptr);
+        int64_t used = 0;
+        for (int k = 0; k < W; ++k) {
+            if (!S.holds(k)) continue;
+            const DevGeo& dk = S.mine_or(k);
+            my_at[(size_t)k] = my_bytes + used;
+            if (dk.n_geoms > 0)
+                hipLaunchKernelGGL(bitmap_to_bytes_kernel, dim3((unsigned)((dk.n_geoms + 255) / 256)), dim3(256), 0, s, dk.validity, dk.n_geoms, my_bytes + used);
+            used += dk.n_geoms;
+        }
+        begin[0] = 0;
+        for (int k = 0; k < W; ++k) {
+            cnt[(size_t)k] = hdr[(size_t)HDR * k + 0];
+            begin[(size_t)k + 1] = begin[(size_t)k] + cnt[(size_t)k];
+        }
+        if ((rc = move_pieces(S, [&](int k) { return (const void*)my_at[(size_t)k]; }, cnt.data(), begin.data(), 1, (char*)all_bytes, s)) != GPK_OK) return done(rc);
+        hipLaunchKernelGGL(bytes_to_bitmap_kernel, dim3((unsigned)(((tot[0] + 7) / 8 + 255) / 256)), dim3(256), 0, s, (const uint8_t*)all_bytes, tot[0], (uint8_t*)a->owned[4]);
+    }
+    if (out_bytes) *out_bytes = a->nbytes;
+    {
+        const hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return done(fail(GPK_ERR_DEVICE, "allgatherv: %s", hipGetErrorString(e)));
+    }
+    return done(GPK_OK);
+}
+
+}  // namespace gpk
+
+using namespace gpk;
 
 extern "C" {
 
@@ -205,7 +455,12 @@ int32_t gpk_allgatherv_rows_f64(gpk_comm* c, const double* local_dev, int64_t n_
     if (!out_dev) return GPK_OK;
     if (out_capacity_rows < *out_total_rows)
         return fail(GPK_ERR_CAPACITY, "allgatherv: %lld rows but capacity %lld", (long long)*out_total_rows, (long long)out_capacity_rows);
-    GPK_TRY(gather_pieces(r, c, local_dev, cnt.data(), begin.data(), sizeof(double) * (size_t)width, (char*)out_dev, s));
+    Shards S;
+    S.W = c->world;
+    S.me = c->rank;
+    S.r = r;
+    S.c = c;
+    GPK_TRY(move_pieces(S, [&](int) { return (const void*)local_dev; }, cnt.data(), begin.data(), sizeof(double) * (size_t)width, (char*)out_dev, s));
     GPK_HIP(hipStreamSynchronize(s));
     return GPK_OK;
 }
@@ -218,128 +473,34 @@ int32_t gpk_allgatherv_geoarray(gpk_comm* c, const gpk_geoarray* shard, void* st
     *out = nullptr;
     const Rccl* r;
     GPK_TRY(rccl(&r));
-    hipStream_t s = (hipStream_t)stream;
-    const DevGeo& d = shard->d;
-    const int W = c->world;
-    const bool has_geom = d.type != GPK_GEOM_POINT, has_part = d.type == GPK_GEOM_MULTIPOLYGON,
-               has_ring = d.type == GPK_GEOM_POLYGON || d.type == GPK_GEOM_MULTILINESTRING || d.type == GPK_GEOM_MULTIPOLYGON;
-    // header: n_geoms, n_parts, n_rings, n_coords, has_validity, type
-    constexpr int H = 6;
-    int64_t mine[H] = {d.n_geoms, has_part ? d.n_parts : 0, has_ring ? d.n_rings : 0, d.n_coords, d.validity ? 1 : 0, d.type};
-    GPK_TRY(workspace_aux(0).begin(sizeof(int64_t) * (size_t)(H * (W + 1)) + 512));
-    int64_t* hdr_dev = (int64_t*)workspace_aux(0).take(sizeof(int64_t) * (size_t)(H * (W + 1)));
-    GPK_HIP(hipMemcpyAsync(hdr_dev + (size_t)H * W, mine, sizeof mine, hipMemcpyHostToDevice, s));
-    GPK_NCCL(r, r->AllGather(hdr_dev + (size_t)H * W, hdr_dev, H, ncclInt64, c->comm, s));
-    std::vector<int64_t> hdr((size_t)H * W);
-    GPK_HIP(hipMemcpyAsync(hdr.data(), hdr_dev, sizeof(int64_t) * (size_t)(H * W), hipMemcpyDeviceToHost, s));
-    GPK_HIP(hipStreamSynchronize(s));  // the only host read of the exchange: six integers per rank
-    bool any_valid = false;
-    int64_t tot[4] = {0, 0, 0, 0};
-    for (int k = 0; k < W; ++k) {
-        if (hdr[(size_t)H * k + 5] != d.type) return fail(GPK_ERR_MISMATCHED_GEOMETRY, "allgatherv: rank %d holds geometry type %lld, this rank %d", k, (long long)hdr[(size_t)H * k + 5], d.type);
-        any_valid = any_valid || hdr[(size_t)H * k + 4] != 0;
-        for (int q = 0; q < 4; ++q) tot[q] += hdr[(size_t)H * k + q];
-    }
-    if (tot[0] > INT32_MAX || tot[1] > INT32_MAX || tot[2] > INT32_MAX || tot[3] > INT32_MAX)
-        return fail(GPK_ERR_INVALID_ARGUMENT, "allgatherv: the gathered column exceeds 2^31 - 1 rows / rings / coordinates (Arrow i32 offsets)");
+    Shards S;
+    S.W = c->world;
+    S.me = c->rank;
+    S.r = r;
+    S.c = c;
+    const gpk_geoarray* one[1] = {shard};
+    S.local = one;
+    std::vector<int64_t> bases((size_t)c->world + 1);
+    GPK_TRY(assemble_column(S, (hipStream_t)stream, out, bases.data(), out_bytes));
+    if (out_row_base) *out_row_base = bases[(size_t)c->rank];
+    return GPK_OK;
+}
 
-    gpk_geoarray* a = new gpk_geoarray;
-    memset(a, 0, sizeof *a);
-    a->device = shard->device;
-    a->d.type = d.type;
-    a->d.n_geoms = tot[0];
-    a->d.n_parts = has_part ? tot[1] : (is_polygonal(d.type) ? tot[0] : 0);
-    a->d.n_rings = has_ring ? tot[2] : 0;
-    a->d.n_coords = tot[3];
-    auto done = [&](int32_t rc) {
-        if (rc != GPK_OK) {
-            (void)hipStreamSynchronize(s);
-            gpk_geoarray_free(a);
-        } else {
-            *out = a;
-        }
-        return rc;
-    };
-    auto alloc = [&](int slot, size_t bytes, const void** view) -> int32_t {
-        void* p = nullptr;
-        GPK_HIP(hipMalloc(&p, bytes ? bytes : 8));
-        a->owned[slot] = p;
-        *view = p;
-        a->nbytes += (int64_t)bytes;
-        return GPK_OK;
-    };
-    std::vector<int64_t> cnt((size_t)W), begin((size_t)W + 1);
-    int32_t rc;
-    // coordinates
-    if ((rc = alloc(0, sizeof(double2) * (size_t)tot[3], (const void**)&a->d.xy)) != GPK_OK) return done(rc);
-    begin[0] = 0;
-    for (int k = 0; k < W; ++k) {
-        cnt[(size_t)k] = hdr[(size_t)H * k + 3];
-        begin[(size_t)k + 1] = begin[(size_t)k] + cnt[(size_t)k];
-    }
-    if ((rc = gather_pieces(r, c, d.xy, cnt.data(), begin.data(), sizeof(double2), (char*)a->owned[0], s)) != GPK_OK) return done(rc);
-    // offsets, outermost first: level `lvl` has rows[lvl] entries + 1 per shard; its values count the children of the next level
-    struct Level {
-        bool present;
-        int slot, rows_q, child_q;  // header columns: rows of this level, rows of its child level (3 = coordinates)
-        const int32_t* src;
-        const int32_t** view;
-    } levels[3] = {
-        {has_geom, 1, 0, has_part ? 1 : (has_ring ? 2 : 3), d.geom_off, &a->d.geom_off},
-        {has_part, 2, 1, 2, d.part_off, &a->d.part_off},
-        {has_ring, 3, 2, 3, d.ring_off, &a->d.ring_off},
-    };
-    for (const Level& L : levels) {
-        if (!L.present) continue;
-        const int64_t total_rows = tot[L.rows_q];
-        if ((rc = alloc(L.slot, sizeof(int32_t) * (size_t)(total_rows + 1), (const void**)L.view)) != GPK_OK) return done(rc);
-        RebaseArgs ra;
-        ra.world = W;
-        int64_t at = 0, child = 0;
-        const int32_t* my_src = L.src;
-        for (int k = 0; k < W; ++k) {
-            const int64_t rows = hdr[(size_t)H * k + L.rows_q];
-            // shard 0 sends rows + 1 entries (its leading 0 included), the others rows entries (from their entry 1 on)
-            cnt[(size_t)k] = k == 0 ? rows + 1 : rows;
-            begin[(size_t)k] = at;
-            ra.dst_begin[k] = at;
-            ra.shift[k] = child;
-            at += cnt[(size_t)k];
-            child += hdr[(size_t)H * k + L.child_q];
-        }
-        begin[(size_t)W] = at;
-        ra.dst_begin[W] = at;
-        if (c->rank != 0 && my_src) my_src += 1;
-        if ((rc = gather_pieces(r, c, my_src, cnt.data(), begin.data(), sizeof(int32_t), (char*)a->owned[L.slot], s)) != GPK_OK) return done(rc);
-        if (at > 0) hipLaunchKernelGGL(rebase_offsets_kernel, dim3((unsigned)((at + 255) / 256)), dim3(256), 0, s, (int32_t*)a->owned[L.slot], ra);
-    }
-    // validity: one byte per row travels (bit offsets of a shard's rows are not byte-aligned in the gathered bitmap)
-    if (any_valid && tot[0] > 0) {
-        if ((rc = alloc(4, (size_t)((tot[0] + 7) / 8), (const void**)&a->d.validity)) != GPK_OK) return done(rc);
-        if ((rc = workspace_aux(1).begin((size_t)tot[0] + (size_t)d.n_geoms + 1024)) != GPK_OK) return done(rc);
-        uint8_t* all_bytes = (uint8_t*)workspace_aux(1).take((size_t)tot[0]);
-        uint8_t* my_bytes = (uint8_t*)workspace_aux(1).take((size_t)(d.n_geoms ? d.n_geoms : 1));
-        if (d.n_geoms > 0)
-            hipLaunchKernelGGL(bitmap_to_bytes_kernel, dim3((unsigned)((d.n_geoms + 255) / 256)), dim3(256), 0, s, d.validity, d.n_geoms, my_bytes);
-        begin[0] = 0;
-        for (int k = 0; k < W; ++k) {
-            cnt[(size_t)k] = hdr[(size_t)H * k + 0];
-            begin[(size_t)k + 1] = begin[(size_t)k] + cnt[(size_t)k];
-        }
-        if ((rc = gather_pieces(r, c, my_bytes, cnt.data(), begin.data(), 1, (char*)all_bytes, s)) != GPK_OK) return done(rc);
-        hipLaunchKernelGGL(bytes_to_bitmap_kernel, dim3((unsigned)(((tot[0] + 7) / 8 + 255) / 256)), dim3(256), 0, s, (const uint8_t*)all_bytes, tot[0], (uint8_t*)a->owned[4]);
-    }
-    if (out_row_base) {
-        int64_t b = 0;
-        for (int k = 0; k < c->rank; ++k) b += hdr[(size_t)H * k + 0];
-        *out_row_base = b;
-    }
-    if (out_bytes) *out_bytes = a->nbytes;
-    {
-        const hipError_t e = hipStreamSynchronize(s);
-        if (e != hipSuccess) return done(fail(GPK_ERR_DEVICE, "allgatherv: %s", hipGetErrorString(e)));
-    }
-    return done(GPK_OK);
+// K chunks of one column held by THIS process -> one array (Arrow's rechunk, py-geopolars/src/ffi.rs:56,73,93: the reference
+// turns every Series into a single chunk before it looks at it).  The assembly is the all-gatherv's own (assemble_column): the
+// pieces are placed with device copies instead of broadcasts.  out_row_bases[n_shards + 1] (host, may be NULL): first row of
+// every chunk in the result.
+int32_t gpk_geoarray_concat(const gpk_geoarray* const* shards, int32_t n_shards, void* stream, gpk_geoarray** out, int64_t* out_row_bases, int64_t* out_bytes) {
+    if (!shards || !out || n_shards < 1 || n_shards > COMM_MAX_WORLD) return fail(GPK_ERR_INVALID_ARGUMENT, "concat: 1 .. %d chunks", COMM_MAX_WORLD);
+    *out = nullptr;
+    for (int k = 0; k < n_shards; ++k)
+        if (!shards[k]) return fail(GPK_ERR_INVALID_ARGUMENT, "concat: chunk %d is NULL", k);
+    GPK_TRY(require_device());
+    Shards S;
+    S.W = n_shards;
+    S.me = -1;
+    S.local = shards;
+    return assemble_column(S, (hipStream_t)stream, out, out_row_bases, out_bytes);
 }
 
 }  // extern "C"

@@ -382,6 +382,19 @@ class DeviceGeoArray:
             validity = bm if has.value else None
         return GeoArrowArray(gt, xy, geom_offsets=go, part_offsets=po, ring_offsets=ro, validity=validity, n_geoms=n_geoms)
 
+    @staticmethod
+    def concat(chunks: Sequence["DeviceGeoArray"], stream: int = 0) -> tuple["DeviceGeoArray", np.ndarray]:
+        """K device-resident chunks of one column -> (one array, first row of every chunk): Arrow's rechunk
+        (py-geopolars/src/ffi.rs:56) on the device (gpk_geoarray_concat — the all-gatherv's own assembly, fed by device copies)."""
+        k = len(chunks)
+        arr = (C.c_void_p * k)(*[c.handle for c in chunks])
+        out = C.c_void_p()
+        bases = (C.c_int64 * (k + 1))()
+        nb = C.c_int64(0)
+        _abi.check(_abi.lib().gpk_geoarray_concat(arr, k, stream, C.byref(out), bases, C.byref(nb)))
+        total = int(bases[k])
+        return DeviceGeoArray(out.value, chunks[0].geom_type, total, -1), np.array(list(bases), dtype=np.int64)
+
     def nbytes(self) -> int:
         n = C.c_int64(0)
         _abi.check(_abi.lib().gpk_geoarray_nbytes(self.handle, C.byref(n)))

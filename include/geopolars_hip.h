@@ -365,6 +365,16 @@ int32_t gpk_take_binary(const uint8_t* values, const int32_t* offsets, const uin
                         const int64_t* idx, int64_t n_idx, int32_t* out_offsets, uint8_t* out_values,
                         int64_t capacity, int64_t* n_bytes, uint8_t* out_validity, int32_t space, void* stream);
 
+/* ---- chunked columns ------------------------------------------------------------------------------------ */
+/* K chunks of one column held by this process -> ONE array (a new handle, gpk_geoarray_free): Arrow's rechunk — the reference turns
+ * every Series into a single chunk before it looks at it (py-geopolars/src/ffi.rs:56,73,93).  Device-resident: the chunks' buffers
+ * are placed with device copies, offsets rebased (a chunk's offsets need not start at 0: a sliced Arrow array), validity bits
+ * repacked across chunk boundaries that do not fall on a byte.  The placement / rebase / repack code is the all-gatherv's own
+ * (below): what runs here with K chunks is what runs there with K ranks.  All chunks must have the same geometry type
+ * (GPK_ERR_MISMATCHED_GEOMETRY); 1 <= n_chunks <= 64.  out_row_bases[n_chunks + 1] (host, may be NULL): first row of every chunk. */
+int32_t gpk_geoarray_concat(const gpk_geoarray* const* chunks, int32_t n_chunks, void* stream, gpk_geoarray** out,
+                            int64_t* out_row_bases, int64_t* out_bytes);
+
 /* ---- multi-GPU: the one collective of the path ------------------------------------ */
 /* One process per GPU; the LEFT series is sharded by rows and needs no collective (disjoint output rows, pairs carry
  * `left_row_base`).  A RIGHT side that is itself produced sharded is exchanged once — where `spatial_join` receives its right
