@@ -22,6 +22,12 @@ RANDOM sample of rows (>= 200k, `--parity-rows`); a run that fails parity prints
 """
 from __future__ import annotations
 
+import os as _os
+
+# the cpu_baseline leg runs the oracle with OpenMP on every host core: pin the threads before any OpenMP runtime is loaded (torch
+# brings one) — unpinned, the same code on "128 cores" measured 2.4e11 and 7.0e11 evals/s on two driver boxes
+_os.environ.setdefault("OMP_PROC_BIND", "close")
+_os.environ.setdefault("OMP_PLACES", "cores")
 import argparse
 import ctypes as C
 import glob
@@ -478,12 +484,13 @@ def cpu_baseline_join(left_host, right_host, predicate: str, gpu_counts, target_
     dt = max(time.perf_counter() - t0, 1e-3)
     sample = int(min(n, max(probe, probe * target_s / (2.0 * dt))))  # two timed runs of ~target_s/2 each
     sub = left_host.take(np.arange(sample))
-    best, runs, spent, threads, counts = None, 0, 0.0, 0, None
+    best, runs, spent, threads, counts, times = None, 0, 0.0, 0, None, []
     while runs < 2 or (runs < 9 and spent < target_s / 4):  # the whole job is a fraction of a second on a big host: repeat
         t0 = time.perf_counter()
         _, counts, threads = pyoracle.spatial_join(sub, right_host, predicate, mode=1, n_threads=0, capacity=4 * sample)
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
+        times.append(dt)
         runs += 1
         spent += dt
     got = gpu_counts[:sample].cpu().numpy().astype(np.uint32)
@@ -500,9 +507,25 @@ def cpu_baseline_join(left_host, right_host, predicate: str, gpu_counts, target_
         "kind": "port",
         "sample": f"first {sample} of the {n} left rows x {m} right rows, min of {runs} runs, grid directory + exact refine, OpenMP dynamic",
         "seconds": best,
+        "value_median": sample * m / float(np.median(times)),
+        "seconds_median": float(np.median(times)),
+        "host": host_description(),
         "parity_checked_rows": sample,
         "single_thread": {"value": s1 * m / t_single, "unit": "evals/s", "sample_rows": s1, "seconds": t_single},
     }
+
+
+def host_description() -> dict:
+    """what the CPU baseline ran on: logical CPUs, the model string, the thread placement asked for"""
+    model = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"nproc": os.cpu_count(), "cpu_model": model, "OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES")}
 
 
 # ======================================================================================================

@@ -282,8 +282,8 @@ static int32_t assemble_column(const Shards& S, hipStream_t s, gpk_geoarray** ou
     };
     auto alloc = [&](int slot, size_t bytes, const void** view) -> int32_t {
         void* p = nullptr;
-        const hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
-        if (e != hipSuccess) return fail(GPK_ERR_OOM, "allgatherv: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        const hipError_t e = device_malloc(&p, bytes ? bytes : 8);
+        if (e != hipSuccess) return fail(GPK_ERR_OOM, "allgatherv: device_malloc(%zu) failed: %s", bytes, hipGetErrorString(e));
         a->owned[slot] = p;
         *view = p;
         a->nbytes += (int64_t)bytes;

@@ -115,6 +115,13 @@ inline size_t align256(size_t n) { return (n + 255) & ~size_t(255); }
 // cached_free does NOT wait for the device the way hipFree does: the caller guarantees that nothing still reads the block
 // (gpk_index_free synchronises the device once for all of an index's tables).
 hipError_t cached_malloc(void** p, size_t bytes);
+// hipMalloc for everything that is NOT recycled (uploads, workspaces, result arrays): on failure the cache's idle blocks are handed
+// back to the driver and the request is tried once more — up to GPK_DEVICE_CACHE_MB of device memory may sit idle in the cache
+hipError_t device_malloc(void** p, size_t bytes);
+template <typename T>
+inline hipError_t device_malloc(T** p, size_t bytes) {
+    return device_malloc(reinterpret_cast<void**>(p), bytes);
+}
 void cached_free(void* p);
 void cached_release_all();  // gpk_device_cache_release
 

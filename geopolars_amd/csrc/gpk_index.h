@@ -174,7 +174,7 @@ struct gpk_index {
     gpk::PipView pip;
     gpk::GridParams host_grid;
     int device;
-    int64_t n_geoms;
+    int64_t n_geoms, n_coords, n_rings;  // of the indexed array: a join checks the array it is handed against all three
     int32_t geom_type;
     void* owned[24];  // bbox, grid, cell_off, items, then the PipView tables
     int64_t nbytes;

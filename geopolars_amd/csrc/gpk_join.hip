@@ -2538,7 +2538,7 @@ static int32_t fused_launch_begin(hipStream_t s, int wgs, unsigned long long** s
             f.slots = nullptr;
         }
         const int want = wgs < 1024 ? 1024 : wgs;
-        hipError_t e = hipMalloc((void**)&f.slots, sizeof(unsigned long long) * (size_t)(want + 1));
+        hipError_t e = device_malloc((void**)&f.slots, sizeof(unsigned long long) * (size_t)(want + 1));
         if (e != hipSuccess) return bail(e);
         e = hipMemset(f.slots, 0, sizeof(unsigned long long) * (size_t)(want + 1));
         if (e != hipSuccess) return bail(e);
@@ -2881,7 +2881,7 @@ extern "C" {
 int32_t gpk_join_stats_enable(int32_t on) {
     if (on && !g_join_stats) {
         GPK_TRY(require_device());
-        GPK_HIP(hipMalloc((void**)&g_join_stats, JOIN_STATS_WORDS * sizeof(unsigned long long)));
+        GPK_HIP(device_malloc((void**)&g_join_stats, JOIN_STATS_WORDS * sizeof(unsigned long long)));
         GPK_HIP(hipMemset(g_join_stats, 0, JOIN_STATS_WORDS * sizeof(unsigned long long)));
     }
     g_join_stats_on = on != 0;
@@ -2912,9 +2912,15 @@ int32_t gpk_join_trace(unsigned long long* out, int64_t n_words) {  // diagnosis
 
 int32_t gpk_index_free(gpk_index* idx) {
     if (!idx) return GPK_OK;
-    (void)hipDeviceSynchronize();  // (hipFree's implicit wait, once: a join enqueued against this index may still be running)
+    // (hipFree's implicit wait, once: a join enqueued against this index may still be running — on the device that OWNS the tables,
+    // which need not be the calling thread's current one: the blocks go back to a process-wide cache tagged by device)
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != idx->device) (void)hipSetDevice(idx->device);
+    (void)hipDeviceSynchronize();
     for (int i = 0; i < 24; ++i)
         if (idx->owned[i]) cached_free(idx->owned[i]);
+    if (cur >= 0 && cur != idx->device) (void)hipSetDevice(cur);
     delete idx;
     return GPK_OK;
 }
@@ -2952,6 +2958,8 @@ int32_t gpk_index_build_ex(const gpk_geoarray* a, int32_t parts, const double* b
     ix->device = a->device;
     ix->n_geoms = n;
     ix->geom_type = a->d.type;
+    ix->n_coords = a->d.n_coords;
+    ix->n_rings = a->d.n_rings;
     {
         static std::atomic<uint64_t> next_serial{1};
         ix->serial = next_serial.fetch_add(1);
@@ -3113,7 +3121,8 @@ int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right, co
         // (an index that serves ONE join skips the per-entry records of list cells: they cost more to build than one join saves)
         GPK_TRY(gpk_index_build_ex(right, GPK_INDEX_BBOX_GRID | (pip ? GPK_INDEX_PIP | GPK_INDEX_PIP_LIGHT : 0), nullptr, stream, &tmp_index));
         right_index = tmp_index;
-    } else if (right_index->n_geoms != right->d.n_geoms) {
+    } else if (right_index->n_geoms != right->d.n_geoms || right_index->n_coords != right->d.n_coords || right_index->n_rings != right->d.n_rings) {
+        // (an index whose slabs name coordinates by index reads THIS array's coordinates: rows alone do not identify the column)
         return fail(GPK_ERR_INVALID_ARGUMENT, "right_index was built over a different array");
     }
     auto done = [&](int32_t rc) {
@@ -3177,7 +3186,8 @@ int32_t gpk_spatial_join_async(const gpk_geoarray* left, const gpk_geoarray* rig
         return fail(GPK_ERR_MISMATCHED_GEOMETRY,
                     "spatial_join_async: only point x polygon/multipolygon is stream-ordered (left type %d x right type %d)",
                     left->d.type, right->d.type);
-    if (right_index->n_geoms != right->d.n_geoms) return fail(GPK_ERR_INVALID_ARGUMENT, "right_index was built over a different array");
+    if (right_index->n_geoms != right->d.n_geoms || right_index->n_coords != right->d.n_coords || right_index->n_rings != right->d.n_rings)
+        return fail(GPK_ERR_INVALID_ARGUMENT, "right_index was built over a different array");
     hipStream_t s = (hipStream_t)stream;
     if (left->d.n_geoms == 0) {
         if (n_pairs_dev) GPK_HIP(hipMemsetAsync(n_pairs_dev, 0, sizeof(int64_t), s));

@@ -1029,7 +1029,7 @@ struct Temps {  // scratch of the build: carved from the thread's auxiliary aren
             hipError_t e = cached_malloc(&q, bytes);
             malloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             malloc_bytes += bytes;
-            if (e != hipSuccess) return fail(GPK_ERR_OOM, "index build: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+            if (e != hipSuccess) return fail(GPK_ERR_OOM, "index build: device_malloc(%zu) failed: %s", bytes, hipGetErrorString(e));
             if (n < 48) p[n++] = q;
         }
         *out = (T*)q;
@@ -1037,7 +1037,8 @@ struct Temps {  // scratch of the build: carved from the thread's auxiliary aren
     }
     ~Temps() {
         const auto t0 = std::chrono::steady_clock::now();
-        if (n) (void)hipDeviceSynchronize();  // (what hipFree did implicitly: no kernel of the build still reads a temporary)
+        if (n) (void)hipDeviceSynchronize();  // (what hipFree did implicitly: no kernel of the build still reads a temporary; the build
+                                              // runs on the calling thread's current device, which is the one that allocated them)
         for (int i = 0; i < n; ++i) cached_free(p[i]);
         if (getenv("GPK_DEBUG_INDEX"))
             fprintf(stderr, "[gpk] index build: %d temporaries beyond the arena (%.2f GB): hipMalloc %.3f ms, hipFree %.3f ms\n", n, (double)malloc_bytes / 1e9,

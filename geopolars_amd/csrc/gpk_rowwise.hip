@@ -728,7 +728,7 @@ static int32_t rowmap_build_dev(const gpk_geoarray* ls, const uint32_t* rows_dev
     };
     const size_t nb = align256(sizeof(uint32_t) * (size_t)(n > 0 ? n : 1));
     {
-        const hipError_t e1 = hipMalloc((void**)&m->perm, nb), e2 = hipMalloc((void**)&m->tsorted, nb);
+        const hipError_t e1 = device_malloc((void**)&m->perm, nb), e2 = device_malloc((void**)&m->tsorted, nb);
         if (e1 != hipSuccess || e2 != hipSuccess) return fin(fail(GPK_ERR_OOM, "row map: hipMalloc failed"));
     }
     m->nbytes = (int64_t)(2 * nb);
@@ -741,7 +741,7 @@ static int32_t rowmap_build_dev(const gpk_geoarray* ls, const uint32_t* rows_dev
         if (e != hipSuccess) return fin(fail(GPK_ERR_DEVICE, "row map: %s", hipGetErrorString(e)));
     }
     const size_t total = 5 * ib + 2 * kb + align256(sort_bytes + 256) + align256(sizeof(unsigned long long) * (size_t)((L + 256) / 256 + 4));
-    if (hipMalloc(&tmp, total) != hipSuccess) return fin(fail(GPK_ERR_OOM, "row map: hipMalloc(%zu) failed", total));
+    if (device_malloc(&tmp, total) != hipSuccess) return fin(fail(GPK_ERR_OOM, "row map: device_malloc(%zu) failed", total));
     char* base = (char*)tmp;
     int32_t* cnt = (int32_t*)base;
     int32_t* cnt_sorted = (int32_t*)(base + ib);
@@ -781,7 +781,7 @@ static int32_t rowmap_build_dev(const gpk_geoarray* ls, const uint32_t* rows_dev
             while (bits < 32 && (1ll << bits) < L + 1) ++bits;  // keys 0..L (L = "no such target")
             size_t tb = 0;
             GPK_HIP(rocprim::radix_sort_pairs(nullptr, tb, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, m->perm, (size_t)n, 0, bits, s));
-            GPK_HIP(hipMalloc(&sort_tmp, 3 * nb + tb + 256));
+            GPK_HIP(device_malloc(&sort_tmp, 3 * nb + tb + 256));
             uint32_t* iota = (uint32_t*)sort_tmp;
             uint32_t* keys_in = (uint32_t*)((char*)sort_tmp + nb);
             uint32_t* keys_sorted = (uint32_t*)((char*)sort_tmp + 2 * nb);
@@ -833,7 +833,7 @@ int32_t gpk_rowmap_build(const gpk_geoarray* b, const uint32_t* b_rows, int64_t 
     const uint32_t* rows_dev = b_rows;
     void* staged = nullptr;
     if (rows_space != GPK_MEM_DEVICE && n_rows > 0) {
-        GPK_HIP(hipMalloc(&staged, sizeof(uint32_t) * (size_t)n_rows));
+        GPK_HIP(device_malloc(&staged, sizeof(uint32_t) * (size_t)n_rows));
         const hipError_t e = hipMemcpyAsync(staged, b_rows, sizeof(uint32_t) * (size_t)n_rows, hipMemcpyHostToDevice, s);
         if (e != hipSuccess) {
             (void)hipFree(staged);

@@ -56,6 +56,15 @@ BlockCache& block_cache() {
 }
 }  // namespace
 
+hipError_t device_malloc(void** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        cached_release_all();
+        e = hipMalloc(p, bytes);
+    }
+    return e;
+}
 hipError_t cached_malloc(void** p, size_t bytes) {
     BlockCache& c = block_cache();
     if (bytes == 0) bytes = 1;
@@ -133,14 +142,14 @@ int32_t Workspace::begin(size_t total) {
             cap_ = 0;
         }
         size_t want = total + total / 4;
-        hipError_t e = hipMalloc((void**)&base_, want);
+        hipError_t e = device_malloc((void**)&base_, want);
         if (e != hipSuccess) {
             want = total;
-            e = hipMalloc((void**)&base_, want);
+            e = device_malloc((void**)&base_, want);
         }
         if (e != hipSuccess) {
             base_ = nullptr;
-            return fail(GPK_ERR_OOM, "workspace hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+            return fail(GPK_ERR_OOM, "workspace device_malloc(%zu) failed: %s", want, hipGetErrorString(e));
         }
         cap_ = want;
         device_ = dev;
@@ -444,7 +453,7 @@ int32_t gpk_geoarray_upload(const gpk_geoarrow_desc* d, void* stream, gpk_geoarr
             continue;
         }
         void* p = nullptr;
-        hipError_t e = hipMalloc(&p, bufs[i].bytes);
+        hipError_t e = device_malloc(&p, bufs[i].bytes);
         if (e == hipSuccess) e = hipMemcpyAsync(p, bufs[i].src, bufs[i].bytes, hipMemcpyHostToDevice, s);
         if (e != hipSuccess) {
             if (p) (void)hipFree(p);

@@ -336,7 +336,7 @@ int32_t gpk_explode(const gpk_geoarray* a, int32_t* out_parent, int32_t parent_s
     if (need_valid) {  // the members' bitmap is owned by the result
         const size_t vb = (((size_t)members + 31) / 32) * 4;
         void* v = nullptr;
-        if (hipMalloc(&v, vb) != hipSuccess) return cleanup(fail(GPK_ERR_OOM, "explode: hipMalloc(%zu) failed", vb));
+        if (device_malloc(&v, vb) != hipSuccess) return cleanup(fail(GPK_ERR_OOM, "explode: device_malloc(%zu) failed", vb));
         e->owned[4] = v;
         e->d.validity = (const uint8_t*)v;
         if (hipMemsetAsync(v, 0, vb, s) != hipSuccess) return cleanup(fail(GPK_ERR_DEVICE, "explode: memset failed"));

@@ -1033,7 +1033,7 @@ static int32_t seq_classes_of(const gpk_geoarray* a, hipStream_t s, const gpk_se
     };
     if (n_seq > 0) {
         int32_t* cursor = nullptr;
-        hipError_t e = hipMalloc((void**)&cursor, 4 * sizeof(int32_t));
+        hipError_t e = device_malloc((void**)&cursor, 4 * sizeof(int32_t));
         if (e != hipSuccess) return bail(fail(GPK_ERR_OOM, "size classes: %s", hipGetErrorString(e)));
         int32_t h[4] = {0, 0, 0, 0};
         auto run = [&]() -> int32_t {
@@ -1052,7 +1052,7 @@ static int32_t seq_classes_of(const gpk_geoarray* a, hipStream_t s, const gpk_se
                 single |= (int64_t)h[k] == n_seq;
             }
             if (single) return GPK_OK;  // one class holds everything: kernels walk the sequences in order, no list
-            GPK_HIP(hipMalloc((void**)&c->lists, sizeof(int32_t) * (size_t)n_seq));
+            GPK_HIP(device_malloc((void**)&c->lists, sizeof(int32_t) * (size_t)n_seq));
             int32_t b32[4] = {(int32_t)c->begin[0], (int32_t)c->begin[1], (int32_t)c->begin[2], (int32_t)c->begin[3]};
             GPK_HIP(hipMemcpyAsync(cursor, b32, sizeof b32, hipMemcpyHostToDevice, s));
             GPK_LAUNCH("gpk_seq_classify", seq_classify_kernel<true>, dim3(cls_blocks), dim3(256), 0, s, seq_off, n_seq, cursor,
@@ -1084,9 +1084,9 @@ static int32_t seq_classes_of(const gpk_geoarray* a, hipStream_t s, const gpk_se
             int32_t* chunks = nullptr;
             unsigned long long* btot = nullptr;
             auto run2 = [&]() -> int32_t {
-                GPK_HIP(hipMalloc((void**)&chunks, sizeof(int32_t) * (size_t)(nl + 1)));
-                GPK_HIP(hipMalloc((void**)&btot, sizeof(unsigned long long) * (size_t)(nb + 2)));
-                GPK_HIP(hipMalloc((void**)&c->chunk_begin, sizeof(int32_t) * (size_t)(nl + 1)));
+                GPK_HIP(device_malloc((void**)&chunks, sizeof(int32_t) * (size_t)(nl + 1)));
+                GPK_HIP(device_malloc((void**)&btot, sizeof(unsigned long long) * (size_t)(nb + 2)));
+                GPK_HIP(device_malloc((void**)&c->chunk_begin, sizeof(int32_t) * (size_t)(nl + 1)));
                 const int32_t* list = c->lists ? c->lists + c->begin[3] : nullptr;
                 GPK_LAUNCH("gpk_seq_long_chunks", long_chunk_count_kernel, dim3((unsigned)nb), dim3(256), 0, s, seq_off, list, nl, chunks);
                 GPK_TRY(exclusive_scan_i32(chunks, nl, c->chunk_begin, nullptr, btot, s));

@@ -307,8 +307,8 @@ extern "C" int32_t gpk_geoarray_from_wkb(const uint8_t* wkb_values, const int32_
             *p = workspace_aux(1).take(bytes ? bytes : 8);
             if (*p) return GPK_OK;
         }
-        hipError_t e = hipMalloc(p, bytes ? bytes : 8);
-        if (e != hipSuccess) return fail(GPK_ERR_OOM, "gpk_geoarray_from_wkb: hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+        hipError_t e = device_malloc(p, bytes ? bytes : 8);
+        if (e != hipSuccess) return fail(GPK_ERR_OOM, "gpk_geoarray_from_wkb: device_malloc(%zu): %s", bytes, hipGetErrorString(e));
         if (temporary) tmp[n_tmp++] = *p;
         return GPK_OK;
     };

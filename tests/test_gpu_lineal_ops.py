@@ -42,6 +42,42 @@ def test_geodesic_length_parity(gpk, oracle, method):
     assert np.array_equal(GeoSeries(synth.uniform_points(10)).geodesic_length(method), np.zeros(10))
 
 
+def _pairs_as_lines(l1, p1, l2, p2):
+    n = len(l1)
+    xy = np.empty((2 * n, 2))
+    xy[0::2, 0], xy[0::2, 1], xy[1::2, 0], xy[1::2, 1] = l1, p1, l2, p2
+    return GeoArrowArray(_abi.GEOM_LINESTRING, xy, geom_offsets=np.arange(0, 2 * n + 1, 2, dtype=np.int32))
+
+
+def test_karney_kernel_against_an_independent_solver(gpk):
+    """the HIP kernel (csrc/gpk_karney.h) against oracle/geodesic_quadrature.py — Bessel's reduction evaluated by Gauss-Legendre
+    quadrature, the azimuth found by bisection: no series, no Newton step, nothing shared with the kernel or with the C oracle
+    (which is the kernel's algorithm written a second time).  Random pairs over the whole ellipsoid, nearly antipodal pairs at
+    three scales, short lines, meridians, the equator, the poles."""
+    from oracle import geodesic_quadrature as gq
+
+    rng = np.random.default_rng(41)
+    sets = []
+    n = 12_000
+    sets.append((rng.uniform(-180, 180, n), rng.uniform(-90, 90, n), rng.uniform(-180, 180, n), rng.uniform(-90, 90, n)))
+    for spread in (0.5, 0.01, 1e-4):  # nearly antipodal: the regime Karney's paper is about (Vincenty's iteration fails here)
+        m = 3_000
+        p1, l1 = rng.uniform(-75, 75, m), rng.uniform(-180, 180, m)
+        sets.append((l1, p1, l1 + 180.0 + rng.normal(0, spread, m), -p1 + rng.normal(0, spread, m)))
+    m = 2_000
+    p1, l1 = rng.uniform(-89, 89, m), rng.uniform(-180, 180, m)
+    sets.append((l1, p1, l1 + rng.normal(0, 1e-3, m), p1 + rng.normal(0, 1e-3, m)))  # short lines
+    sets.append((l1, p1, l1, rng.uniform(-90, 90, m)))  # meridians
+    sets.append((l1, p1, l1 + 180.0, rng.uniform(-90, 90, m)))  # over a pole
+    sets.append((l1, np.zeros(m), rng.uniform(-180, 180, m), np.zeros(m)))  # along (or, past (1 - f) * 180 degrees, off) the equator
+    sets.append((l1, np.full(m, 90.0), rng.uniform(-180, 180, m), rng.uniform(-90, 90, m)))  # from the pole
+    for l1, p1, l2, p2 in sets:
+        p2 = np.clip(p2, -90.0, 90.0)
+        got = GeoSeries(_pairs_as_lines(l1, p1, l2, p2)).geodesic_length("geodesic")
+        exp = gq.inverse_distance(l1, p1, l2, p2)
+        assert np.all(np.abs(got - exp) <= 1e-9 * exp + 2e-8)  # (1e-9 relative: the north star's tolerance; 20 nm absolute for millimetre lines)
+
+
 def test_geodesic_published_values_and_methods(gpk):
     nyc_london = GeoSeries(GeoArrowArray.from_linestrings([[(-74.006, 40.7128), (-0.1278, 51.5074)]]))
     assert round(float(nyc_london.geodesic_length("haversine")[0])) == 5_570_230  # geo's HaversineLength doc example

@@ -151,3 +151,48 @@ def test_simplify_rules_particular_to_geo(oracle):
     two = GeoArrowArray.from_linestrings([[(0, 0), (1, 1)], [(5, 5)], []])
     xy, off = oracle.simplify(two, 10.0)
     assert off.tolist() == [0, 2, 3, 3]
+
+
+def test_karney_restatement_against_an_independent_solver(oracle):
+    """oracle/gpk_oracle.c's Karney restatement (series + Newton, the algorithm of the HIP kernel written a second time) against
+    oracle/geodesic_quadrature.py: the same geodesic problem solved by Gauss-Legendre quadrature of Bessel's integrals and a
+    bisection on the azimuth — a different derivation, so the two cannot share a bug.  The independent solver itself is first
+    held against the values GeographicLib publishes."""
+    from oracle import geodesic_quadrature as gq
+
+    published = [  # (lon1, lat1, lon2, lat2, metres): GeographicLib's documentation / GeodTest line 1 / Karney 2013 / closed forms
+        (174.81, -41.32, -5.50, 40.96, 19959679.26735382),
+        (-73.8, 40.6, -0.5, 51.6, 5551759.4003186841),
+        (-139.44815, 35.60777, -69.95921, -11.17491, 8935244.5604818305),
+        (0.0, 0.0, 179.5, 0.5, 19936288.578965),
+        (0.0, 0.0, 90.0, 0.0, 6378137.0 * np.pi / 2),
+        (0.0, 0.0, 0.0, 90.0, 10001965.729313),
+        (0.0, 0.0, 180.0, 0.0, 2 * 10001965.729313),
+    ]
+    for l1, p1, l2, p2, metres in published:
+        assert abs(float(gq.inverse_distance([l1], [p1], [l2], [p2])[0]) - metres) < 2e-6
+
+    def c_oracle(l1, p1, l2, p2):
+        n = len(l1)
+        xy = np.empty((2 * n, 2))
+        xy[0::2, 0], xy[0::2, 1], xy[1::2, 0], xy[1::2, 1] = l1, p1, l2, p2
+        return oracle.geodesic_length(GeoArrowArray(_abi.GEOM_LINESTRING, xy, geom_offsets=np.arange(0, 2 * n + 1, 2, dtype=np.int32)), "geodesic")
+
+    rng = np.random.default_rng(40)
+    n = 12_000
+    sets = [(rng.uniform(-180, 180, n), rng.uniform(-90, 90, n), rng.uniform(-180, 180, n), rng.uniform(-90, 90, n))]
+    for spread in (0.5, 0.01, 1e-4):
+        m = 3_000
+        p1, l1 = rng.uniform(-75, 75, m), rng.uniform(-180, 180, m)
+        sets.append((l1, p1, l1 + 180.0 + rng.normal(0, spread, m), -p1 + rng.normal(0, spread, m)))
+    m = 2_000
+    p1, l1 = rng.uniform(-89, 89, m), rng.uniform(-180, 180, m)
+    sets.append((l1, p1, l1 + rng.normal(0, 1e-3, m), p1 + rng.normal(0, 1e-3, m)))
+    sets.append((l1, p1, l1, rng.uniform(-90, 90, m)))
+    sets.append((l1, p1, l1 + 180.0, rng.uniform(-90, 90, m)))
+    sets.append((l1, np.zeros(m), rng.uniform(-180, 180, m), np.zeros(m)))
+    sets.append((l1, np.full(m, 90.0), rng.uniform(-180, 180, m), rng.uniform(-90, 90, m)))
+    for l1, p1, l2, p2 in sets:
+        p2 = np.clip(p2, -90.0, 90.0)
+        got, exp = c_oracle(l1, p1, l2, p2), gq.inverse_distance(l1, p1, l2, p2)
+        assert np.all(np.abs(got - exp) <= 1e-9 * exp + 2e-8)
