@@ -939,6 +939,57 @@ def run_c5(ctx: Ctx) -> None:
         index_full = {"parts": "GPK_INDEX_BBOX_GRID | GPK_INDEX_PIP | GPK_INDEX_PIP_FULL", "build_ms": full_build_ms, "bytes": full.nbytes(),
                       "join_ms": (time.perf_counter() - t0) * 1e3 / 5, "pairs_equal_the_default_index": int(total.item()) == h}
         full.free()
+    # ---- the ONE-SHOT cost with the RIGHT side partitioned (dist.join_partition_right): every rank indexes its own shard of the
+    # multipolygons (1 / N of the build) and joins ALL points against it.  At N = 1 the work of rank 0 of `--simulate-ranks` ranks
+    # is measured on this GPU (its shard of the right side = the first 1 / K of the rows, all K x n points) — the collective that
+    # replicates the points (16 bytes a row) is the one thing that cannot be timed on one GPU.
+    one_shot = None
+    if not args.no_one_shot:
+        try:
+            from geopolars_amd.dist import join_partition_right
+
+            K = W if W > 1 else max(1, args.simulate_ranks)
+            if W > 1:
+                my_shard, my_base, xy_mine = shard, ctx.rank * (M // W), torch.from_numpy(pts_host.xy).to(dev)
+            else:
+                sh_host = c5_chunk(0, rows_per_chunk) if K == C5_CHUNKS else GeoArrowArray.concat([c5_chunk(k, rows_per_chunk) for k in range(C5_CHUNKS // K)])
+                my_shard, my_base = GeoBuffers.from_host(sh_host, dev), 0
+                xy_mine = torch.cat([torch.from_numpy(synth.uniform_points(n, seed=52 + r).xy).to(dev) for r in range(K)])
+            my_dev = my_shard.to_device_geoarray(stream)
+            join_partition_right(xy_mine[: min(len(xy_mine), 100_000)], my_dev, my_base, "within", stream=stream)  # (arenas, size classes: one-off per process / column)
+            ctx.barrier()
+            t0 = time.perf_counter()
+            res = join_partition_right(xy_mine, my_dev, my_base, "within", stream=stream, pair_capacity=int(xy_mine.shape[0]) if W == 1 else None)
+            ctx.barrier()
+            wall = ctx.max_over_ranks(time.perf_counter() - t0) * 1e3
+            one_shot = {
+                "what": f"dist.join_partition_right: points replicated, rank r indexes 1/{K} of the multipolygons and joins all {int(res['counts'].shape[0])} points against them" + ("" if W > 1 else f" — rank 0 of {K}, measured on this one GPU (no collective)"),
+                "ranks": K,
+                "index_build_ms": res["ms"]["index"],
+                "join_ms": res["ms"]["join"],
+                "gather_points_ms": res["ms"]["gather"] if W > 1 else None,
+                "wall_ms_max_over_ranks": wall,
+                "pairs_on_this_rank": int(res["pairs"].shape[0]),
+                "compare": {"replicated_right_one_shot_ms": build_ms + elapsed / args.steps * 1e3, "note": "index over ALL multipolygons on every rank + one step"},
+            }
+            if W == 1:  # parity of the partitioned join on a random sample of its rows against the oracle on the same shard
+                from oracle import pyoracle
+
+                pyoracle.build()
+                nn = int(res["counts"].shape[0])
+                idx = sample_rows(nn, min(args.parity_rows, 100_000), seed=99)
+                sub = GeoArrowArray.from_points(xy_mine[torch.from_numpy(idx).to(dev)].cpu().numpy())
+                ep, ec, _ = pyoracle.spatial_join(sub, my_shard.to_host(), "within", mode=1, n_threads=0)
+                gc = res["counts"].cpu().numpy().astype(np.uint32)
+                got = pairs_of_rows(res["pairs"].cpu().numpy().astype(np.uint32), idx.astype(np.uint32))
+                if not np.array_equal(gc[idx], ec) or not np.array_equal(got, ep):
+                    raise SystemExit("bench.py: the right-partitioned join differs from the CPU oracle on its parity sample")
+                one_shot["parity"] = {"rows": int(len(idx)), "pairs": int(len(ep)), "bit_exact": True}
+            del res, xy_mine
+        except SystemExit:
+            raise
+        except Exception as e:  # (a measurement next to the line, never the line itself)
+            one_shot = {"error": repr(e)}
     if ctx.rank != 0:
         ctx.finish()
         return
@@ -967,6 +1018,7 @@ def run_c5(ctx: Ctx) -> None:
         "area_GBps": area_bytes / (area_ms * 1e-3) / 1e9 if area_ms > 0 else None,
         "area_all_multipolygons_ms": area_all_ms,
         "build_plus_step_ms": build_ms + ms_per_step,
+        "one_shot_right_partitioned": one_shot,
         "right_side_exchange": {"ms": exchange["ms"], "bytes": exchange["bytes"], "what": "all-gatherv of the right GeoArrow buffers, device-resident, outside the timed region; every rank then builds the index over the gathered column"},
         "host_generation_s": gen_s,
         "kernel_ms_per_step": warm,
@@ -1044,6 +1096,8 @@ def main() -> None:
     ap.add_argument("--diag-sorted-points", action="store_true", help="c5, diagnosis: feed the points in raster order (how much of the tile kernel is locality)")
     ap.add_argument("--no-index-variants", action="store_true", help="c5: skip the extra build + joins of the GPK_INDEX_PIP_FULL index")
     ap.add_argument("--parity-rows", type=int, default=300_000, help="random sample of left rows compared with the oracle")
+    ap.add_argument("--no-one-shot", action="store_true", help="c5: skip the right-partitioned one-shot measurement")
+    ap.add_argument("--simulate-ranks", type=int, default=8, help="c5 at N = 1: whose work the right-partitioned one-shot join measures (rank 0 of this many)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--index-per-step", action="store_true", help="c2: rebuild the right-side index inside every step")

@@ -26,17 +26,19 @@ from .geoseries import GeoSeries
 class SpatialIndex:
     """Device-resident bbox grid directory over one series (the R-tree's replacement)."""
 
-    def __init__(self, series: GeoSeries, stream: int = 0, for_points: bool = True, full: bool = False):
+    def __init__(self, series: GeoSeries, stream: int = 0, for_points: bool = True, full: bool = False, light: bool = False):
         """for_points=False skips the point-in-polygon raster + edge slabs (only point x polygonal joins read them);
         full=True builds per-entry records for every list cell (GPK_INDEX_PIP_FULL: an index that serves hundreds of joins)."""
         self.series = series
         h = C.c_void_p()
         parts = _abi.INDEX_BBOX_GRID | (_abi.INDEX_PIP if for_points else 0) | (_abi.INDEX_PIP_FULL if for_points and full else 0)
+        if for_points and light and not full:  # an index that serves ONE join (what gpk_spatial_join builds for itself without r_index)
+            parts |= _abi.INDEX_PIP_LIGHT
         _abi.check(_abi.lib().gpk_index_build_ex(series.device().handle, parts, None, stream, C.byref(h)))
         self._h = h
 
     @staticmethod
-    def from_device(dev: DeviceGeoArray, stream: int = 0, for_points: bool = True, bboxes=None, full: bool = False) -> "SpatialIndex":
+    def from_device(dev: DeviceGeoArray, stream: int = 0, for_points: bool = True, bboxes=None, full: bool = False, light: bool = False) -> "SpatialIndex":
         """Index over a device-resident array.  `bboxes`: optional (n, 4) float64 CUDA tensor of precomputed leaves
         (minx, miny, maxx, maxy per geometry, e.g. all-gathered from the ranks that own the shards)."""
         self = SpatialIndex.__new__(SpatialIndex)
@@ -44,6 +46,8 @@ class SpatialIndex:
         self._dev = dev
         h = C.c_void_p()
         parts = _abi.INDEX_BBOX_GRID | (_abi.INDEX_PIP if for_points else 0) | (_abi.INDEX_PIP_FULL if for_points and full else 0)
+        if for_points and light and not full:  # an index that serves ONE join (what gpk_spatial_join builds for itself without r_index)
+            parts |= _abi.INDEX_PIP_LIGHT
         _abi.check(_abi.lib().gpk_index_build_ex(dev.handle, parts, bboxes.data_ptr() if bboxes is not None else None, stream, C.byref(h)))
         self._h = h
         return self

@@ -64,6 +64,13 @@ def _worker(rank: int, world: int, port: int, kind: str, q):
         box = np.arange(4 * (hi - lo), dtype=np.float64).reshape(-1, 4) + 1000.0 * rank
         leaves = all_gather_leaves(torch.from_numpy(box)).numpy()
         ok = ok and leaves.shape == (len(full), 4) and np.array_equal(leaves[lo:hi], box)
+        # the points of a right-partitioned one-shot join (dist.join_partition_right): shards of unequal length, in rank order
+        from geopolars_amd.dist import all_gather_points
+
+        mine = np.arange(2 * (5 + 3 * rank), dtype=np.float64).reshape(-1, 2) + 100.0 * rank
+        allp, lens = all_gather_points(torch.from_numpy(mine))
+        exp = np.concatenate([np.arange(2 * (5 + 3 * r), dtype=np.float64).reshape(-1, 2) + 100.0 * r for r in range(world)])
+        ok = ok and lens == [5 + 3 * r for r in range(world)] and np.array_equal(allp.numpy(), exp)
         q.put((rank, ok, lo, hi))
     finally:
         dist.destroy_process_group()

@@ -207,3 +207,34 @@ def test_c_abi_communicator_at_world_1(gpk, oracle):
     assert np.array_equal(counts.cpu().numpy().astype(np.uint32), exp_counts)
     assert np.array_equal(pairs[:h].cpu().numpy().astype(np.uint32), exp_pairs)
     comm.free()
+
+
+@pytest.mark.parametrize("k", [2, 4, 8])
+def test_right_partitioned_one_shot_join_equals_the_whole_join(gpk, oracle, k):
+    """dist.join_partition_right with K shards of the RIGHT side on one GPU (what ranks 0 .. K - 1 would each do): the shards'
+    pair sets are disjoint, their union is the join, their partial hit counts add up (spatial_index.rs:47-71: the index of
+    one shard is 1 / K of the build)"""
+    import torch
+
+    from geopolars_amd.dist import join_partition_right
+    from geopolars_amd.geoarrow import DeviceGeoArray
+
+    right = synth.powerlaw_multipolygons(6_000, seed=21)
+    left = synth.uniform_points(80_001, seed=22)
+    ep, ec, _ = oracle.spatial_join(left, right, "within", mode=0)
+    xy = torch.from_numpy(left.xy).cuda()
+    w = np.diff(right.geom_offsets)
+    got_pairs, got_counts = [], np.zeros(len(left), dtype=np.int64)
+    for r in range(k):
+        lo, hi = shard_rows(len(right), k, r, weights=w)
+        shard = DeviceGeoArray.upload(slice_rows(right, lo, hi))
+        res = join_partition_right(xy, shard, lo, "within", pair_capacity=1024)  # (a buffer too small on purpose: the call sizes it from the reported total)
+        p = res["pairs"].cpu().numpy().astype(np.uint32)
+        assert len(p) == 0 or (p[:, 1].min() >= lo and p[:, 1].max() < hi)
+        got_pairs.append(p)
+        got_counts += res["counts"].cpu().numpy().astype(np.int64)
+        assert set(res["ms"]) == {"gather", "index", "join"}
+    allp = np.concatenate(got_pairs)
+    allp = allp[np.lexsort((allp[:, 1], allp[:, 0]))]
+    assert np.array_equal(allp, ep)
+    assert np.array_equal(got_counts.astype(np.uint32), ec)
