@@ -800,98 +800,85 @@ __global__ void chain_xy_kernel(DevGeo a, double2* __restrict__ ext) {
     const int ne = n - 1;
     ext[k] = n <= 0 ? make_double2(0.0, 0.0) : (ne >= 1 ? a.xy[c0 + j % ne] : a.xy[c0]);
 }
-// One wave per record (as chain_aux_kernel): the wave lists the edges of the part's slab rows in this raster row that meet the
-// padded cell; lanes 0 and 1 then build the chain words of the record's two halves (only a half with `test` labels needs one).
+// One LANE per half record (two per record): the half's chain word.  The lane walks the edges of the part's slab row of ITS half
+// (PIP_SLAB_MUL = 2 base slab rows per raster row: a half cell is exactly one slab row, so the row's slab holds every edge whose
+// y-range meets the half) straight from the slab table — about seven edges — instead of a wave staging the cell's edges for two
+// working lanes (86 k waves of 2 busy lanes for the C2 right side: 0.23 ms; this form: a twentieth of the waves).
 __global__ __launch_bounds__(256) void half_chain_kernel(DevGeo a, PipView pv, FineGrid g, const int32_t* __restrict__ work_cell,
                                                          const uint32_t* __restrict__ work_part, int64_t n_work,
                                                          const int32_t* __restrict__ slab_vidx, const SubCell* __restrict__ sub,
                                                          uint32_t* __restrict__ hword) {
-    constexpr int S = PIP_SUB, SS = PIP_SUB * PIP_SUB;
-    static_assert(S == 8 && SS == 64, "a record is two halves of four sub-cell rows");
+    constexpr int S = PIP_SUB;
+    static_assert(S == 8 && PIP_SLAB_MUL == 2, "a record is two halves of four sub-cell rows, one base slab row each");
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t item = t / SS;
-    if (item >= n_work) return;  // (whole waves)
+    const int64_t item = t >> 1;
+    const int half = (int)(t & 1);
+    if (item >= n_work) return;
     const int64_t c = work_cell[item];
     const int part = (int)work_part[item];
-    const SubCell rc = sub[item];
-    const int ci = (int)(c % g.R), cj = (int)(c / g.R);
-    const double fw2 = g.fw / S, fh2 = g.fh / S, px2 = g.pad_x / S, py2 = g.pad_y / S;
-    const double cxl = g.rx0 + (double)(S * ci) * fw2 - px2, cxh = g.rx0 + (double)(S * ci + S) * fw2 + px2;
-    const double cyl = g.ry0 + (double)(S * cj) * fh2 - py2, cyh = g.ry0 + (double)(S * cj + S) * fh2 + py2;
-    __shared__ double4 s_edges[256 / 64][SUB_EDGE_CAP];
-    __shared__ int32_t s_vidx[256 / 64][SUB_EDGE_CAP];
-    const int wave = threadIdx.x >> 6, lane64 = threadIdx.x & 63;
+    const uint32_t lw0 = sub[item].labels[2 * half], lw1 = sub[item].labels[2 * half + 1];
+    uint32_t word = 0u;
     int r0, r1;
     dev::part_rings(a, part, r0, r1);
-    bool list_ok = r1 - r0 == 1;  // a part with holes: no chains (uniform)
-    int n_list = 0;
-    if (list_ok) {
-        int e0, e1;
-        if (pip::slab_span_of_raster_row(pv, r0, cj, e0, e1)) {
-            for (int eb = e0; eb < e1 && list_ok; eb += 64) {
-                const int e = eb + lane64;
-                bool keep = false;
-                double4 ed = make_double4(0, 0, 0, 0);
-                if (e < e1) {
-                    ed = pip::slab_edge(pv, e);
-                    keep = !(fmax(ed.x, ed.z) < cxl || fmin(ed.x, ed.z) > cxh || fmax(ed.y, ed.w) < cyl || fmin(ed.y, ed.w) > cyh);
-                }
-                const unsigned long long m = __ballot(keep);
-                const int add = __popcll(m);
-                if (n_list + add > SUB_EDGE_CAP) {
-                    list_ok = false;
+    if (test_labels_of(lw0) + test_labels_of(lw1) > 0 && r1 - r0 == 1) {  // (a part with holes: no chains)
+        const int ci = (int)(c % g.R), cj = (int)(c / g.R);
+        const double fw2 = g.fw / S, fh2 = g.fh / S, px2 = g.pad_x / S, py2 = g.pad_y / S;
+        const int sj0 = S * cj + (S / 2) * half;
+        const double xl = g.rx0 + (double)(S * ci) * fw2 - px2, xh = g.rx0 + (double)(S * ci + S) * fw2 + px2;
+        const double yl = g.ry0 + (double)sj0 * fh2 - py2, yh = g.ry0 + (double)(sj0 + S / 2) * fh2 + py2;
+        const int c0 = a.ring_off[r0], ne = a.ring_off[r0 + 1] - c0 - 1;  // the ring's edges: 0 .. ne - 1
+        bool closed = false;
+        if (ne >= 1) {
+            const double2 f = a.xy[c0], l = a.xy[c0 + ne];
+            closed = f.x == l.x && f.y == l.y;  // (an unclosed ring has no closing edge for the other walks: no chain, they decide)
+        }
+        // the half's slab row (shift 0: lean indexes have no refined rings) — and, because the padding reaches into the neighbouring
+        // rows by less than a row, the rows below and above it: an edge that only touches the PADDED half lives there
+        const double cy = g.ry0 + ((double)sj0 + 0.25 * S) * fh2;
+        const int row_c = pip::row_of(pv, cy);                     // finest row of the half's centre
+        const int step = 1 << PIP_FINE_LOG2;                       // finest rows per base slab row
+        int e0 = 0, e1 = 0;
+        bool have = false;
+        // 1. the edges that meet this padded half cell (exact: the test that labels sub-cells), as (first, last) ring positions of
+        //    the shortest covering arc — found in one pass: the arc is grown edge by edge (edges arrive in no order)
+        int lo = 0, len = 0;
+        bool ok = closed;
+        int n_touched = 0;
+        int touched[CHAIN_MAX + 1];
+        for (int dr = -1; dr <= 1 && ok; ++dr) {
+            if (!pip::slab_range(pv, r0, row_c + dr * step, e0, e1)) continue;
+            have = true;
+            for (int e = e0; e < e1 && ok; ++e) {
+                const double4 ed = pip::slab_edge(pv, e);
+                if (fmax(ed.x, ed.z) < xl || fmin(ed.x, ed.z) > xh || fmax(ed.y, ed.w) < yl || fmin(ed.y, ed.w) > yh) continue;
+                const int o1 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yl), o2 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yl);
+                const int o3 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yh), o4 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yh);
+                if ((o1 > 0 && o2 > 0 && o3 > 0 && o4 > 0) || (o1 < 0 && o2 < 0 && o3 < 0 && o4 < 0)) continue;
+                const int ei = pip::slab_vertex(slab_vidx[e]) - c0;
+                bool seen = false;
+                for (int q = 0; q < n_touched; ++q) seen = seen || touched[q] == ei;  // (an edge spanning rows is listed in each)
+                if (seen) continue;
+                if (n_touched >= CHAIN_MAX) {
+                    ok = false;
                     break;
                 }
-                if (keep) {
-                    const int at = n_list + __popcll(m & ((1ull << lane64) - 1ull));
-                    s_edges[wave][at] = ed;
-                    s_vidx[wave][at] = pip::slab_vertex(slab_vidx[e]);
-                }
-                n_list += add;
+                touched[n_touched++] = ei;
             }
         }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane64 >= 2) return;
-    const int half = lane64;
-    uint32_t word = 0u;
-    const bool wanted = test_labels_of(rc.labels[2 * half]) + test_labels_of(rc.labels[2 * half + 1]) > 0;
-    const int c0 = list_ok ? a.ring_off[r0] : 0, ne = list_ok ? a.ring_off[r0 + 1] - c0 - 1 : 0;  // the ring's edges: 0 .. ne - 1
-    bool closed = false;
-    if (list_ok && ne >= 1) {
-        const double2 f = a.xy[c0], l = a.xy[c0 + ne];
-        closed = f.x == l.x && f.y == l.y;  // (an unclosed ring has no closing edge for the other walks: no chain, they decide)
-    }
-    if (wanted && closed) {
-        const int sj0 = S * cj + (S / 2) * half;
-        const double xl = cxl, xh = cxh;
-        const double yl = g.ry0 + (double)sj0 * fh2 - py2, yh = g.ry0 + (double)(sj0 + S / 2) * fh2 + py2;
-        // 1. the listed edges that meet this padded half cell (exact: the test that labels sub-cells)
-        unsigned long long touched = 0ull;
-        for (int e = 0; e < n_list; ++e) {
-            const double4 ed = s_edges[wave][e];
-            if (fmax(ed.x, ed.z) < xl || fmin(ed.x, ed.z) > xh || fmax(ed.y, ed.w) < yl || fmin(ed.y, ed.w) > yh) continue;
-            const int o1 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yl), o2 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yl);
-            const int o3 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yh), o4 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yh);
-            if ((o1 > 0 && o2 > 0 && o3 > 0 && o4 > 0) || (o1 < 0 && o2 < 0 && o3 < 0 && o4 < 0)) continue;
-            touched |= 1ull << e;
-        }
-        // the shortest arc [lo, lo + len) of the cycle 0 .. ne - 1 that covers the touched edges (chain_aux_kernel has the argument)
-        int lo = 0, len = 0;
-        if (touched) {
+        ok = ok && have && n_touched > 0;
+        if (ok) {
+            // the shortest arc [lo, lo + len) of the cycle 0 .. ne - 1 that covers the touched edges: the complement of the widest
+            // gap between one touched edge and the next one after it
             int best_gap = -1, best_next = 0;
-            for (unsigned long long ma = touched; ma; ma &= ma - 1ull) {
-                const int ea = s_vidx[wave][__ffsll((long long)ma) - 1] - c0;
+            for (int p = 0; p < n_touched; ++p) {
+                const int ea = touched[p];
                 int nd = ne, nb = ea;
-                for (unsigned long long mb = touched; mb; mb &= mb - 1ull) {
-                    const int eb = s_vidx[wave][__ffsll((long long)mb) - 1] - c0;
-                    int d = eb - ea;
-                    if (d < 0) d += ne;
-                    if (d > 0 && d < nd) {
-                        nd = d;
-                        nb = eb;
+                for (int q = 0; q < n_touched; ++q) {
+                    int dd = touched[q] - ea;
+                    if (dd < 0) dd += ne;
+                    if (dd > 0 && dd < nd) {
+                        nd = dd;
+                        nb = touched[q];
                     }
                 }
                 if (nd > best_gap) {
@@ -901,8 +888,8 @@ __global__ __launch_bounds__(256) void half_chain_kernel(DevGeo a, PipView pv, F
             }
             lo = best_next;
             len = ne - best_gap + 1;
+            ok = len >= 1 && len <= CHAIN_MAX;
         }
-        bool ok = len >= 1 && len <= CHAIN_MAX;
         // 2. grow while the end vertex's y lies in the half's closed y-interval
         while (ok && len < ne) {
             int hv = lo + len;
@@ -921,14 +908,14 @@ __global__ __launch_bounds__(256) void half_chain_kernel(DevGeo a, PipView pv, F
         }
         if (ok) {
             // 3. base: the other edges' winding at the half's centre — they all sit in the centre's slab row
-            const double cx = g.rx0 + ((double)(S * ci) + 0.5 * S) * fw2, cy = g.ry0 + ((double)sj0 + 0.25 * S) * fh2;
-            int e0, e1, wn = 0;
+            const double cx = g.rx0 + ((double)(S * ci) + 0.5 * S) * fw2;
+            int wn = 0;
             bool on = false;
-            if (pip::slab_range(pv, r0, pip::row_of(pv, cy), e0, e1)) {
+            if (pip::slab_range(pv, r0, row_c, e0, e1)) {
                 for (int e = e0; e < e1; ++e) {
-                    int d = pip::slab_vertex(slab_vidx[e]) - c0 - lo;
-                    if (d < 0) d += ne;
-                    if (d < len) continue;  // an edge of the arc
+                    int dd = pip::slab_vertex(slab_vidx[e]) - c0 - lo;
+                    if (dd < 0) dd += ne;
+                    if (dd < len) continue;  // an edge of the arc
                     const double4 ed = pip::slab_edge(pv, e);
                     on |= dev::ring_edge(ed.x, ed.y, ed.z, ed.w, cx, cy, wn);
                 }
@@ -1423,7 +1410,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
         GPK_TRY(t.alloc(&hword, (size_t)n_sub * 2 + 2));
         pv.sub = sub;
         GPK_LAUNCH("gpk_pipidx_chain_xy", chain_xy_kernel, blocks_for(n_ext), dim3(256), 0, s, d, cxy);
-        GPK_LAUNCH("gpk_pipidx_half_chain", half_chain_kernel, blocks_for((int64_t)n_sub * PIP_SUB * PIP_SUB), dim3(256), 0, s, d, pv, g,
+        GPK_LAUNCH("gpk_pipidx_half_chain", half_chain_kernel, blocks_for((int64_t)n_sub * 2), dim3(256), 0, s, d, pv, g,
                    (const int32_t*)swork_cell, (const uint32_t*)swork_part, (int64_t)n_sub, (const int32_t*)slab_vidx, (const SubCell*)sub, hword);
         GPK_LAUNCH("gpk_pipidx_chain_commit", half_chain_commit_kernel, blocks_for(n_sub), dim3(256), 0, s, sub, (int64_t)n_sub, (const uint32_t*)hword);
         pv.chain_xy = cxy;
