@@ -471,8 +471,19 @@ int32_t gpk_geoarray_upload(const gpk_geoarrow_desc* d, void* stream, gpk_geoarr
 
 int32_t gpk_geoarray_free(gpk_geoarray* a) {
     if (!a) return GPK_OK;
+    // (owned buffers may come from the block cache — decoded WKB columns — which does not wait the way hipFree does: wait once, on
+    // the owning device, for whatever still reads them)
+    bool any = false;
+    for (int i = 0; i < 5; ++i) any = any || a->owned[i] != nullptr;
+    if (any) {
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (cur != a->device) (void)hipSetDevice(a->device);
+        (void)hipDeviceSynchronize();
+        if (cur >= 0 && cur != a->device) (void)hipSetDevice(cur);
+    }
     for (int i = 0; i < 5; ++i)
-        if (a->owned[i]) (void)hipFree(a->owned[i]);
+        if (a->owned[i]) cached_free(a->owned[i]);
     if (a->classes) {
         if (a->classes->lists) (void)hipFree(a->classes->lists);
         if (a->classes->chunk_begin) (void)hipFree(a->classes->chunk_begin);

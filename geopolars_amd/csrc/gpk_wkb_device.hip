@@ -163,8 +163,17 @@ __device__ inline bool parse_row(WkbCursor& r, RowCount& rc, double2* __restrict
     return r.ok;
 }
 
-__global__ void wkb_scan_kernel(const uint8_t* __restrict__ values, const int32_t* __restrict__ offsets, int64_t n_rows,
-                                const uint8_t* __restrict__ validity, RowCount* __restrict__ rows, uint32_t* __restrict__ flags) {
+// the three quantities a row contributes to the output's offset levels.  `parts` is what a MULTIPOLYGON column counts (a polygon row is
+// one part, a multipolygon row its k members); the other column types never read it.
+__device__ __forceinline__ int row_parts(const RowCount& rc) { return rc.type == 0 ? 0 : (rc.type == 3 ? 1 : rc.k); }
+constexpr int WKB_BLOCK = 256;
+// One lane per row parses the headers and counts; the work-group also leaves its TOTALS of coordinates / rings / parts
+// (block_tot[ch * (n_blocks + 1) + block]): after one small scan of those, wkb_fill_kernel finds every row's output positions with a
+// block scan of the same counts — no per-row position arrays, no extent pass, no three grid-wide scans (round 3: nine more launches
+// and a second read-back between them).
+__global__ __launch_bounds__(WKB_BLOCK) void wkb_scan_kernel(const uint8_t* __restrict__ values, const int32_t* __restrict__ offsets, int64_t n_rows,
+                                                             const uint8_t* __restrict__ validity, RowCount* __restrict__ rows, uint32_t* __restrict__ flags,
+                                                             unsigned long long* __restrict__ block_tot, int64_t n_blocks) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     RowCount rc{0, 0, 0, 0};
     uint32_t bits = 0;
@@ -183,70 +192,170 @@ __global__ void wkb_scan_kernel(const uint8_t* __restrict__ values, const int32_
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) bits |= (uint32_t)__shfl_xor((int)bits, o, 64);
     if ((threadIdx.x & 63) == 0 && bits && (bits & ~__atomic_load_n(flags, __ATOMIC_RELAXED)) != 0u) atomicOr(flags, bits);
-}
-
-// per-row output extents for the chosen column type
-__global__ void wkb_extent_kernel(const RowCount* __restrict__ rows, int64_t n_rows, int out_type, int32_t* __restrict__ n_coords,
-                                  int32_t* __restrict__ n_rings, int32_t* __restrict__ n_parts) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rows) return;
-    const RowCount rc = rows[i];
-    int c = rc.coords, rg = 0, pt = 0;
-    if (out_type == GPK_GEOM_POINT) {
-        c = 1;  // a null or empty point row still owns one (NaN) coordinate slot
-    } else if (out_type == GPK_GEOM_MULTILINESTRING || out_type == GPK_GEOM_POLYGON || out_type == GPK_GEOM_MULTIPOLYGON) {
-        rg = rc.rings;
-        if (out_type == GPK_GEOM_MULTIPOLYGON) pt = rc.type == 0 ? 0 : (rc.type == 3 ? 1 : rc.k);
+    {  // the longest row (flags[1]): what picks the form of the coordinate copy — again only a wave that raises it touches the word
+        uint32_t mx = (uint32_t)rc.coords;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+        if ((threadIdx.x & 63) == 0 && mx > __atomic_load_n(flags + 1, __ATOMIC_RELAXED)) atomicMax(flags + 1, mx);
     }
-    n_coords[i] = c;
-    n_rings[i] = rg;
-    n_parts[i] = pt;
+    // totals of the work-group's rows
+    __shared__ unsigned long long s_tot[WKB_BLOCK / 64][3];
+    unsigned long long c = (unsigned long long)rc.coords, g = (unsigned long long)rc.rings, q = (unsigned long long)row_parts(rc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        c += __shfl_xor(c, o, 64);
+        g += __shfl_xor(g, o, 64);
+        q += __shfl_xor(q, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_tot[threadIdx.x >> 6][0] = c;
+        s_tot[threadIdx.x >> 6][1] = g;
+        s_tot[threadIdx.x >> 6][2] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        unsigned long long t = 0;
+#pragma unroll
+        for (int w = 0; w < WKB_BLOCK / 64; ++w) t += s_tot[w][threadIdx.x];
+        block_tot[(int64_t)threadIdx.x * (n_blocks + 1) + blockIdx.x] = t;
+    }
+}
+// the three channels' block totals -> exclusive offsets in place; channel ch's grand total lands in its slot n_blocks and in
+// totals_host[ch] (device-mapped host memory: read after the stream sync, no copy)
+__global__ __launch_bounds__(1024) void wkb_totals_kernel(unsigned long long* __restrict__ block_tot, int64_t n_blocks, unsigned long long* __restrict__ totals_host,
+                                                          const uint32_t* __restrict__ flags) {
+    __shared__ unsigned long long lds[17];
+    unsigned long long* v = block_tot + (int64_t)blockIdx.x * (n_blocks + 1);
+    unsigned long long carry = 0;
+    for (int64_t base = 0; base < n_blocks; base += 1024) {
+        const int64_t j = base + threadIdx.x;
+        const unsigned long long x = j < n_blocks ? v[j] : 0ull;
+        unsigned long long tot;
+        const unsigned long long ex = dev::block_exclusive_scan<unsigned long long, 1024>(x, lds, &tot);
+        if (j < n_blocks) v[j] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) {
+        v[n_blocks] = carry;
+        totals_host[blockIdx.x] = carry;
+        if (blockIdx.x == 0) totals_host[3] = (unsigned long long)flags[0] | ((unsigned long long)flags[1] << 32);
+    }
 }
 
-__global__ void wkb_fill_kernel(const uint8_t* __restrict__ values, const int32_t* __restrict__ offsets, int64_t n_rows,
-                                const uint8_t* __restrict__ validity, int out_type, const int32_t* __restrict__ cpos,
-                                const int32_t* __restrict__ rpos, const int32_t* __restrict__ ppos, double2* __restrict__ xy,
-                                int32_t* __restrict__ geom_off, int32_t* __restrict__ part_off, int32_t* __restrict__ ring_off,
-                                int32_t* __restrict__ seq_src) {
+// One lane per row parses again and writes offsets (and, for point columns, coordinates).  A row's output positions = the
+// work-group's offsets (wkb_totals_kernel) + a block scan of the rows' counts (wkb_scan_kernel left them in `rows`).
+__global__ __launch_bounds__(WKB_BLOCK) void wkb_fill_kernel(const uint8_t* __restrict__ values, const int32_t* __restrict__ offsets, int64_t n_rows,
+                                                             const uint8_t* __restrict__ validity, int out_type, const RowCount* __restrict__ rows,
+                                                             const unsigned long long* __restrict__ block_off, int64_t n_blocks, double2* __restrict__ xy,
+                                                             int32_t* __restrict__ geom_off, int32_t* __restrict__ part_off, int32_t* __restrict__ ring_off,
+                                                             int32_t* __restrict__ seq_src) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rows) return;
     const bool out_point = out_type == GPK_GEOM_POINT;
     const bool has_ring = out_type == GPK_GEOM_MULTILINESTRING || out_type == GPK_GEOM_POLYGON || out_type == GPK_GEOM_MULTIPOLYGON;
     const bool has_part = out_type == GPK_GEOM_MULTIPOLYGON;
+    const RowCount mine = i < n_rows ? rows[i] : RowCount{0, 0, 0, 0};
+    __shared__ unsigned long long lds[WKB_BLOCK / 64 + 1];
+    unsigned long long tot;
+    const int nc = mine.coords, nr = has_ring ? mine.rings : 0, np = has_part ? row_parts(mine) : 0;
+    const int64_t cpos = out_point ? i : (int64_t)(block_off[blockIdx.x] + dev::block_exclusive_scan<unsigned long long, WKB_BLOCK>((unsigned long long)nc, lds, &tot));
+    const int64_t rpos = has_ring ? (int64_t)(block_off[(n_blocks + 1) + blockIdx.x] + dev::block_exclusive_scan<unsigned long long, WKB_BLOCK>((unsigned long long)nr, lds, &tot)) : 0;
+    const int64_t ppos = has_part ? (int64_t)(block_off[2 * (n_blocks + 1) + blockIdx.x] + dev::block_exclusive_scan<unsigned long long, WKB_BLOCK>((unsigned long long)np, lds, &tot)) : 0;
+    if (i >= n_rows) return;
     if (dev::valid_row(validity, i)) {
         WkbCursor r{values + offsets[i], values + offsets[i + 1], true};
         RowCount rc;
         // sequences are numbered like the rings (ring types) or like the rows (a LINESTRING column: one per row)
-        (void)parse_row<true>(r, rc, xy, cpos[i], has_ring ? ring_off : nullptr, has_ring ? rpos[i] : 0, has_part ? part_off : nullptr,
-                              has_part ? ppos[i] : 0, out_point, values, seq_src, has_ring ? (int64_t)rpos[i] : i);
+        (void)parse_row<true>(r, rc, xy, cpos, has_ring ? ring_off : nullptr, rpos, has_part ? part_off : nullptr, ppos, out_point, values, seq_src,
+                              has_ring ? rpos : i);
     } else if (seq_src && !has_ring) {
         seq_src[i] = 0;  // null row of a LINESTRING column: an empty sequence
     } else if (out_point) {
-        xy[cpos[i]] = make_double2(NAN, NAN);
+        xy[cpos] = make_double2(NAN, NAN);
     }
     if (i == 0) {
         if (geom_off) geom_off[0] = 0;
         if (has_ring) ring_off[0] = 0;
         if (has_part) part_off[0] = 0;
     }
-    if (geom_off) {
-        // level-1 offsets: end position of row i at the column's first nesting level
-        const int32_t* lvl = has_part ? ppos : (has_ring ? rpos : cpos);
-        geom_off[i + 1] = lvl[i + 1];
-    }
+    if (geom_off)  // level-1 offsets: end position of row i at the column's first nesting level
+        geom_off[i + 1] = (int32_t)(has_part ? ppos + np : (has_ring ? rpos + nr : cpos + nc));
 }
 
 // ---- coordinate runs: WKB bytes -> xy ---------------------------------------------------------------------------
 // sequence q (a ring / member line, or the row of a LINESTRING column) starts at values + seq_src[q] and fills
-// xy[seq_off[q] .. seq_off[q + 1]).  8 lanes per sequence; sequences longer than WKB_LONG are listed for
-// wkb_copy_long_kernel, which spreads each of them over the whole grid.
-constexpr int WKB_COPY_GS = 8, WKB_LONG = 4096;
+// xy[seq_off[q] .. seq_off[q + 1]).  The work is cut by OUTPUT coordinate, not by sequence: a work-group owns WKB_CP_TILE
+// consecutive coordinates of xy whatever sequences they belong to (a 100k-vertex ring and a thousand triangles cost the same per
+// coordinate — eight lanes per sequence left half the lanes idle on 4-coordinate rings and one group alone on a long one: 1.8 TB/s
+// on a power-law column against 3.7 on 64-vertex rings).  The sequences that meet the tile are found with two binary searches,
+// their offsets staged in LDS, and every lane finds the sequence of each of its coordinates there.
 __device__ __forceinline__ double2 load_xy_unaligned(const uint8_t* p) {
     double2 v;
     __builtin_memcpy(&v, p, 16);
     return v;
 }
-__global__ __launch_bounds__(256) void wkb_copy_kernel(const uint8_t* __restrict__ values, const int32_t* __restrict__ seq_src,
+constexpr int WKB_CP_BLOCK = 256, WKB_CP_PER = 8, WKB_CP_TILE = WKB_CP_BLOCK * WKB_CP_PER, WKB_CP_SEQS = 2560;
+__global__ __launch_bounds__(WKB_CP_BLOCK) void wkb_copy_kernel(const uint8_t* __restrict__ values, const int32_t* __restrict__ seq_src,
+                                                                const int32_t* __restrict__ seq_off, int64_t n_seq, int64_t n_coords, double2* __restrict__ xy) {
+    __shared__ int32_t s_off[WKB_CP_SEQS + 1], s_src[WKB_CP_SEQS];
+    __shared__ int32_t s_q[2];
+    const int64_t c_lo = (int64_t)blockIdx.x * WKB_CP_TILE, c_hi = c_lo + WKB_CP_TILE < n_coords ? c_lo + WKB_CP_TILE : n_coords;
+    // last sequence that starts at or before coordinate c: upper_bound(seq_off[0 .. n_seq], c) - 1 (empty sequences share an offset
+    // with their successor: the LAST of them is the one that holds the coordinate)
+    auto seq_of = [&](int64_t c) {
+        int64_t lo = 0, hi = n_seq;  // invariant: seq_off[lo] <= c < seq_off[hi]
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)seq_off[mid] <= c)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        return lo;
+    };
+    if (threadIdx.x < 2) s_q[threadIdx.x] = (int32_t)seq_of(threadIdx.x == 0 ? c_lo : c_hi - 1);
+    __syncthreads();
+    const int q0 = s_q[0], q1 = s_q[1], nq = q1 - q0 + 1;
+    const bool staged = nq <= WKB_CP_SEQS;  // (more: a run of empty sequences inside the tile — the lanes search the global offsets)
+    if (staged) {
+        for (int t = threadIdx.x; t <= nq; t += WKB_CP_BLOCK) s_off[t] = seq_off[q0 + t];
+        for (int t = threadIdx.x; t < nq; t += WKB_CP_BLOCK) s_src[t] = seq_src[q0 + t];
+    }
+    __syncthreads();
+    double2 v[WKB_CP_PER];
+    int64_t cs[WKB_CP_PER];
+#pragma unroll
+    for (int j = 0; j < WKB_CP_PER; ++j) {  // all loads of a lane in flight before the first store
+        const int64_t c = c_lo + j * WKB_CP_BLOCK + threadIdx.x;
+        cs[j] = c;
+        if (c >= c_hi) continue;
+        int64_t src;
+        if (staged) {
+            // (marking every sequence's first coordinate and carrying the marks forward with a running maximum — no search — was
+            // measured: the four barriers of that scan cost more than eleven LDS reads per coordinate, 1.11 against 0.94 ms on 2M x 64)
+            int lo = 0, hi = nq;  // s_off[lo] <= c < s_off[hi]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if ((int64_t)s_off[mid] <= c)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            src = (int64_t)s_src[lo] + 16 * (c - (int64_t)s_off[lo]);
+        } else {
+            const int64_t q = seq_of(c);
+            src = (int64_t)seq_src[q] + 16 * (c - (int64_t)seq_off[q]);
+        }
+        v[j] = load_xy_unaligned(values + src);
+    }
+#pragma unroll
+    for (int j = 0; j < WKB_CP_PER; ++j)
+        if (cs[j] < c_hi) xy[cs[j]] = v[j];
+}
+
+// Columns of SHORT sequences (building footprints: a dozen coordinates per ring) keep the lane-group form — 8 lanes per sequence, no
+// search: 0.49 ms against 0.60 on 8M x 8-vertex polygons; sequences beyond WKB_LONG are listed for wkb_copy_long_kernel.
+constexpr int WKB_COPY_GS = 8, WKB_LONG = 4096;
+__global__ __launch_bounds__(256) void wkb_copy_groups_kernel(const uint8_t* __restrict__ values, const int32_t* __restrict__ seq_src,
                                                         const int32_t* __restrict__ seq_off, int64_t n_seq, double2* __restrict__ xy,
                                                         int32_t* __restrict__ long_list) {
     const int lane = threadIdx.x & (WKB_COPY_GS - 1);
@@ -291,7 +400,8 @@ extern "C" int32_t gpk_geoarray_from_wkb(const uint8_t* wkb_values, const int32_
     int n_tmp = 0;
     gpk_geoarray* a = nullptr;
     auto done = [&](int32_t rc) {
-        for (int i = 0; i < n_tmp; ++i) (void)hipFree(tmp[i]);
+        if (n_tmp) (void)hipStreamSynchronize(s);
+        for (int i = 0; i < n_tmp; ++i) cached_free(tmp[i]);
         if (rc != GPK_OK && a) gpk_geoarray_free(a);
         return rc;
     };
@@ -307,8 +417,10 @@ extern "C" int32_t gpk_geoarray_from_wkb(const uint8_t* wkb_values, const int32_
             *p = workspace_aux(1).take(bytes ? bytes : 8);
             if (*p) return GPK_OK;
         }
-        hipError_t e = device_malloc(p, bytes ? bytes : 8);
-        if (e != hipSuccess) return fail(GPK_ERR_OOM, "gpk_geoarray_from_wkb: device_malloc(%zu): %s", bytes, hipGetErrorString(e));
+        // (the decoded buffers come from the library's block cache like index tables do: a dataframe pipeline decodes and drops
+        // columns all the time, and five hipMalloc + five hipFree were half of this call's wall time)
+        hipError_t e = cached_malloc(p, bytes ? bytes : 8);
+        if (e != hipSuccess) return fail(GPK_ERR_OOM, "gpk_geoarray_from_wkb: hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
         if (temporary) tmp[n_tmp++] = *p;
         return GPK_OK;
     };
@@ -343,29 +455,29 @@ extern "C" int32_t gpk_geoarray_from_wkb(const uint8_t* wkb_values, const int32_
     }
     RowCount* rows = nullptr;
     uint32_t* flags = nullptr;
-    int32_t *nc = nullptr, *nr = nullptr, *np = nullptr, *cpos = nullptr, *rpos = nullptr, *ppos = nullptr;
     unsigned long long* btot = nullptr;
-    W_TRY(dalloc((void**)&rows, sizeof(RowCount) * (size_t)n_rows, true));
+    const int64_t n_blocks = (n_rows + WKB_BLOCK - 1) / WKB_BLOCK > 0 ? (n_rows + WKB_BLOCK - 1) / WKB_BLOCK : 1;
+    W_TRY(dalloc((void**)&rows, sizeof(RowCount) * (size_t)(n_rows ? n_rows : 1), true));
     W_TRY(dalloc((void**)&flags, 64, true));
-    const size_t ib = sizeof(int32_t) * (size_t)(n_rows + 1);
-    W_TRY(dalloc((void**)&nc, ib, true));
-    W_TRY(dalloc((void**)&nr, ib, true));
-    W_TRY(dalloc((void**)&np, ib, true));
-    W_TRY(dalloc((void**)&cpos, ib, true));
-    W_TRY(dalloc((void**)&rpos, ib, true));
-    W_TRY(dalloc((void**)&ppos, ib, true));
-    W_TRY(dalloc((void**)&btot, sizeof(unsigned long long) * (size_t)((n_rows + 255) / 256 + 4), true));
+    W_TRY(dalloc((void**)&btot, sizeof(unsigned long long) * (size_t)(3 * (n_blocks + 1)), true));
     W_HIP(hipMemsetAsync(flags, 0, 64, s));
-    const dim3 grid((unsigned)((n_rows + 255) / 256 > 0 ? (n_rows + 255) / 256 : 1)), block(256);
+    // the one read-back of the call: the column's type flags and the three totals, through device-mapped host memory
+    static thread_local unsigned long long* totals_host = nullptr;
+    if (!totals_host && hipHostMalloc((void**)&totals_host, 64, hipHostMallocMapped) != hipSuccess) totals_host = nullptr;
+    if (!totals_host) return done(fail(GPK_ERR_OOM, "gpk_geoarray_from_wkb: hipHostMalloc failed"));
+    const dim3 grid((unsigned)n_blocks), block(WKB_BLOCK);
+    totals_host[0] = totals_host[1] = totals_host[2] = totals_host[3] = 0;
     auto launch1 = [&]() -> int32_t {
-        if (n_rows > 0)
-            GPK_LAUNCH("gpk_wkb_scan", wkb_scan_kernel, grid, block, 0, s, values_dev, offsets_dev, n_rows, validity_dev, rows, flags);
+        if (n_rows > 0) {
+            GPK_LAUNCH("gpk_wkb_scan", wkb_scan_kernel, grid, block, 0, s, values_dev, offsets_dev, n_rows, validity_dev, rows, flags, btot, n_blocks);
+            GPK_LAUNCH("gpk_wkb_totals", wkb_totals_kernel, dim3(3), dim3(1024), 0, s, btot, n_blocks, totals_host, (const uint32_t*)flags);
+        }
         return GPK_OK;
     };
     W_TRY(launch1());
-    uint32_t hflags = 0;
-    W_HIP(hipMemcpyAsync(&hflags, flags, sizeof hflags, hipMemcpyDeviceToHost, s));
     W_HIP(hipStreamSynchronize(s));
+    const uint32_t hflags = (uint32_t)((volatile unsigned long long*)totals_host)[3];
+    const uint32_t longest_row = (uint32_t)(((volatile unsigned long long*)totals_host)[3] >> 32);
     if (hflags & 0x80000000u)
         return done(fail(GPK_ERR_MISMATCHED_GEOMETRY, "gpk_geoarray_from_wkb: malformed, big-endian or Z/M WKB in the column (use gpk_wkb_decode on the host)"));
     const bool fp = hflags & ((1u << 1) | (1u << 4)), fl = hflags & ((1u << 2) | (1u << 5)), fg = hflags & ((1u << 3) | (1u << 6));
@@ -376,22 +488,12 @@ extern "C" int32_t gpk_geoarray_from_wkb(const uint8_t* wkb_values, const int32_
     if (fl) out_type = multi ? GPK_GEOM_MULTILINESTRING : GPK_GEOM_LINESTRING;
     if (fg) out_type = multi ? GPK_GEOM_MULTIPOLYGON : GPK_GEOM_POLYGON;
     if (fp) out_type = multi ? GPK_GEOM_MULTIPOINT : GPK_GEOM_POINT;
-
-    int32_t tot_c = 0, tot_r = 0, tot_p = 0;
-    auto launch2 = [&]() -> int32_t {
-        if (n_rows > 0) {
-            GPK_LAUNCH("gpk_wkb_extent", wkb_extent_kernel, grid, block, 0, s, (const RowCount*)rows, n_rows, out_type, nc, nr, np);
-            GPK_TRY(exclusive_scan_i32(nc, n_rows, cpos, nullptr, btot, s));
-            GPK_TRY(exclusive_scan_i32(nr, n_rows, rpos, nullptr, btot, s));
-            GPK_TRY(exclusive_scan_i32(np, n_rows, ppos, nullptr, btot, s));
-            GPK_HIP(hipMemcpyAsync(&tot_c, cpos + n_rows, 4, hipMemcpyDeviceToHost, s));
-            GPK_HIP(hipMemcpyAsync(&tot_r, rpos + n_rows, 4, hipMemcpyDeviceToHost, s));
-            GPK_HIP(hipMemcpyAsync(&tot_p, ppos + n_rows, 4, hipMemcpyDeviceToHost, s));
-            GPK_HIP(hipStreamSynchronize(s));
-        }
-        return GPK_OK;
-    };
-    W_TRY(launch2());
+    const unsigned long long t_c = ((volatile unsigned long long*)totals_host)[0], t_r = ((volatile unsigned long long*)totals_host)[1],
+                             t_p = ((volatile unsigned long long*)totals_host)[2];
+    if (t_c > (unsigned long long)INT32_MAX || t_r > (unsigned long long)INT32_MAX || t_p > (unsigned long long)INT32_MAX)
+        return done(fail(GPK_ERR_INVALID_OFFSETS, "gpk_geoarray_from_wkb: the decoded column exceeds i32 offsets"));
+    // (a POINT column owns one coordinate slot per row, null and empty rows included)
+    const int32_t tot_c = out_type == GPK_GEOM_POINT ? (int32_t)n_rows : (int32_t)t_c, tot_r = (int32_t)t_r, tot_p = (int32_t)t_p;
 
     a = new gpk_geoarray;
     memset(a, 0, sizeof *a);
@@ -429,21 +531,32 @@ extern "C" int32_t gpk_geoarray_from_wkb(const uint8_t* wkb_values, const int32_
     const bool has_seq = out_type == GPK_GEOM_LINESTRING || has_ring;
     const int64_t n_seq = has_ring ? (int64_t)tot_r : n_rows;
     int32_t *seq_src = nullptr, *long_list = nullptr;
+    // the copy's form: by output coordinate (balanced whatever the lengths), or — columns whose sequences average at most 16
+    // coordinates and hold no long row — 8 lanes per sequence
+    // (and no row longer than 64: a power-law column averages 9 coordinates a ring and still wants the balanced form — 0.22 against 0.54 ms)
+    const bool short_seqs = has_seq && n_seq > 0 && (int64_t)tot_c <= 16 * n_seq && longest_row <= 64u;
     if (has_seq && n_rows > 0) {
         W_TRY(dalloc((void**)&seq_src, sizeof(int32_t) * (size_t)(n_seq + 1), true));
-        W_TRY(dalloc((void**)&long_list, sizeof(int32_t) * (size_t)(n_seq + 2), true));
-        W_HIP(hipMemsetAsync(long_list, 0, sizeof(int32_t), s));
+        if (short_seqs) {
+            W_TRY(dalloc((void**)&long_list, sizeof(int32_t) * (size_t)(n_seq + 2), true));
+            W_HIP(hipMemsetAsync(long_list, 0, sizeof(int32_t), s));
+        }
     }
     auto launch3 = [&]() -> int32_t {
         if (n_rows > 0) {
-            GPK_LAUNCH("gpk_wkb_fill", wkb_fill_kernel, grid, block, 0, s, values_dev, offsets_dev, n_rows, validity_dev, out_type,
-                       (const int32_t*)cpos, (const int32_t*)rpos, (const int32_t*)ppos, xy, go, po, ro, seq_src);
+            GPK_LAUNCH("gpk_wkb_fill", wkb_fill_kernel, grid, block, 0, s, values_dev, offsets_dev, n_rows, validity_dev, out_type, (const RowCount*)rows,
+                       (const unsigned long long*)btot, n_blocks, xy, go, po, ro, seq_src);
             if (has_seq && n_seq > 0 && tot_c > 0) {
                 const int32_t* seq_off = has_ring ? (const int32_t*)ro : (const int32_t*)go;
-                GPK_LAUNCH("gpk_wkb_copy", wkb_copy_kernel, dim3((unsigned)((n_seq * WKB_COPY_GS + 255) / 256)), dim3(256), 0, s, values_dev,
-                           (const int32_t*)seq_src, seq_off, n_seq, xy, long_list);
-                GPK_LAUNCH("gpk_wkb_copy_long", wkb_copy_long_kernel, dim3((unsigned)(cu_count() * 8)), dim3(256), 0, s, values_dev,
-                           (const int32_t*)seq_src, seq_off, (const int32_t*)long_list, xy);
+                if (short_seqs) {
+                    GPK_LAUNCH("gpk_wkb_copy", wkb_copy_groups_kernel, dim3((unsigned)((n_seq * WKB_COPY_GS + 255) / 256)), dim3(256), 0, s, values_dev,
+                               (const int32_t*)seq_src, seq_off, n_seq, xy, long_list);
+                    GPK_LAUNCH("gpk_wkb_copy_long", wkb_copy_long_kernel, dim3((unsigned)(cu_count() * 8)), dim3(256), 0, s, values_dev,
+                               (const int32_t*)seq_src, seq_off, (const int32_t*)long_list, xy);
+                } else {
+                    GPK_LAUNCH("gpk_wkb_copy", wkb_copy_kernel, dim3((unsigned)(((int64_t)tot_c + WKB_CP_TILE - 1) / WKB_CP_TILE)), dim3(WKB_CP_BLOCK), 0, s, values_dev,
+                               (const int32_t*)seq_src, seq_off, n_seq, (int64_t)tot_c, xy);
+                }
             }
         } else if (go) {
             GPK_HIP(hipMemsetAsync(go, 0, sizeof(int32_t), s));
