@@ -22,12 +22,10 @@ RANDOM sample of rows (>= 200k, `--parity-rows`); a run that fails parity prints
 """
 from __future__ import annotations
 
-import os as _os
-
-# the cpu_baseline leg runs the oracle with OpenMP on every host core: pin the threads before any OpenMP runtime is loaded (torch
-# brings one) — unpinned, the same code on "128 cores" measured 2.4e11 and 7.0e11 evals/s on two driver boxes
-_os.environ.setdefault("OMP_PROC_BIND", "close")
-_os.environ.setdefault("OMP_PLACES", "cores")
+# (Thread placement of the cpu_baseline leg: OMP_PROC_BIND=close / OMP_PLACES=cores was tried to make it repeatable across driver boxes
+# and made it five times SLOWER on the GPU box (1.0e11 against 5.8e11 evals/s: the container's CPU set and the places do not line up),
+# so the OpenMP runtime is left to place its threads; the line reports the minimum and the median of the runs, the CPU model, the
+# logical CPUs and how many of them this process may run on.)
 import argparse
 import ctypes as C
 import glob
@@ -526,7 +524,11 @@ def host_description() -> dict:
                 break
     except OSError:
         pass
-    return {"nproc": os.cpu_count(), "cpu_model": model, "OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES")}
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = None
+    return {"nproc": os.cpu_count(), "cpus_this_process_may_use": usable, "cpu_model": model, "OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES")}
 
 
 # ======================================================================================================
