@@ -2513,6 +2513,7 @@ static std::mutex g_fused_mu;
 struct FusedDev {
     unsigned long long* slots = nullptr;  // n total words, then the ticket counter
     unsigned long long tickets = 0;       // what the counter holds once every launch queued so far has started its work-groups
+    unsigned long long era = 0;           // launch counter >> 24 when the words were last cleared
     int n = 0;
     hipEvent_t done = nullptr;
     hipStream_t last = nullptr;
@@ -2544,6 +2545,7 @@ static int32_t fused_launch_begin(hipStream_t s, int wgs, unsigned long long** s
         if (e != hipSuccess) return bail(e);
         f.n = want;
         f.tickets = 0;
+        f.era = g_fused_epoch >> (64 - FUSED_TOTAL_BITS);
     }
     if (!f.done) {
         const hipError_t e = hipEventCreateWithFlags(&f.done, hipEventDisableTiming);
@@ -2560,6 +2562,13 @@ static int32_t fused_launch_begin(hipStream_t s, int wgs, unsigned long long** s
     }
     ++g_fused_epoch;
     if ((g_fused_epoch & ((1ull << (64 - FUSED_TOTAL_BITS)) - 1ull)) == 0ull) ++g_fused_epoch;  // (a tag of 0 is what a fresh word holds)
+    // the tag is 24 bits of the launch counter: when it has wrapped since this device's words were last cleared, a word written 16.7 M
+    // launches ago by a larger grid could carry the new launch's tag — clear them (stream-ordered, behind every earlier launch)
+    if ((g_fused_epoch >> (64 - FUSED_TOTAL_BITS)) != f.era) {
+        const hipError_t e = hipMemsetAsync(f.slots, 0, sizeof(unsigned long long) * (size_t)f.n, s);
+        if (e != hipSuccess) return bail(e);
+        f.era = g_fused_epoch >> (64 - FUSED_TOTAL_BITS);
+    }
     *epoch = g_fused_epoch & ((1ull << (64 - FUSED_TOTAL_BITS)) - 1ull);
     *slots = f.slots;
     *ticket = f.slots + f.n;
