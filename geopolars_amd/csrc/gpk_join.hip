@@ -1334,6 +1334,12 @@ __device__ __noinline__ uint32_t chain_generic_row_call(const ChainCold* cold, d
     uint32_t first;
     return chain_generic_row<false>(cold, px, py, lane, &first, emit, emit_room, l);
 }
+// (count in the low half, the first hit's geometry in the high half)
+__device__ __noinline__ unsigned long long chain_generic_row_first_call(const ChainCold* cold, double px, double py, int lane) {
+    uint32_t first;
+    const uint32_t cnt = chain_generic_row<false>(cold, px, py, lane, &first);
+    return ((unsigned long long)first << 32) | cnt;
+}
 // one `test` point of a tile, in the wave's LDS list (24 bytes; reading the point again from memory instead was measured: the
 // tile's lines are streamed with the non-temporal hint and are gone from the L2 — 20 us more per launch)
 struct ChainItem {
@@ -1343,8 +1349,8 @@ struct ChainItem {
 };
 // list slots per wave = one pass of the exact step: a quarter of the tile's points.  A tile with more `test` points than that (the
 // raster is far too coarse for such a right side) hands the surplus to the generic walk like any other deferred row.
-template <int P>
-constexpr int chain_items() { return 16 * P; }
+template <int P, bool LH = false>
+constexpr int chain_items() { return LH ? 12 * P : 16 * P; }  // (LH: the kernel that also keeps its hits in LDS)
 
 // The P points a lane holds, as 2 * P separately named doubles: a `double[P]` that lives across loop iterations (the fused kernel
 // requests a tile's points one tile ahead) is promoted to ONE 2 * P-register vector value — every use then drags the whole tuple
@@ -1400,10 +1406,20 @@ __device__ __forceinline__ void chain_load_points_any(const ChainHot& h, int64_t
 // FUSED (pip_tile_fused_kernel): no result codes and tile totals — the tile's hits go, in row order, to out[run ...] (slots below
 // out_cap only) as (l_add + row, geometry) and `run` moves on by their number; the rare rows are settled BEFORE the others are
 // ranked (their hit counts shift the ranks) and store their hits themselves
-template <int P, bool ROUTE, bool FULL, bool FUSED = false>
+// LH (pip_tile_fused_kernel<true>): the hits stay in LDS — lh.ids[run ...] 16-bit geometry ids in row order, lh.masks[k] the hit mask
+// of the tile's point row k — until the work-group knows where its pairs go; the routing image carries 16-bit record ranks
+// relative to a per-row base (s_rec0 = the uint16 ranks, lh.rowbase the bases).
+struct LdsHits {
+    uint16_t* ids;              // the wave's hit list (capacity `cap`)
+    unsigned long long* masks;  // this TILE's P masks
+    const uint32_t* rowbase;    // record rank of the first record of every raster row
+    uint32_t* over;             // set when the wave cannot keep its hits here (capacity, a row in several geometries): it decides its tiles again
+    uint32_t cap;
+};
+template <int P, bool ROUTE, bool FULL, bool FUSED = false, bool LH = false, bool IMG16 = LH>
 __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mask, const uint32_t* s_rec0, ChainItem* s_items, int64_t tile, int lane,
-                                           uint2* out, uint32_t out_cap, uint32_t* run_io, PointRegs<P>& pr, int64_t next_tile) {
-    constexpr int S = PIP_SUB, CHAIN_TILE = 64 * P, ITEMS = chain_items<P>();
+                                           uint2* out, uint32_t out_cap, uint32_t* run_io, PointRegs<P>& pr, int64_t next_tile, const LdsHits lh = LdsHits{}) {
+    constexpr int S = PIP_SUB, CHAIN_TILE = 64 * P, ITEMS = chain_items<P, IMG16>();  // (IMG16: the kernel that keeps its hits in LDS, either pass)
     const int64_t base = tile * CHAIN_TILE;
     const int64_t n_points = FULL ? 0 : (HOT_ARG(n_points));
     const uint32_t rem = FULL ? (uint32_t)CHAIN_TILE : (uint32_t)(n_points - base < (int64_t)CHAIN_TILE ? n_points - base : (int64_t)CHAIN_TILE);
@@ -1446,7 +1462,10 @@ __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mas
             const uint32_t at = (cy << (logR - 5)) + (cx >> 5), bit = cx & 31u;
             const uint2 m = s_mask[at];  // RouteWord: bmask, gmask
             if (real && ((m.x >> bit) & 1u)) {
-                w[k] = s_rec0[at] + (uint32_t)__popc(m.x & ((1u << bit) - 1u));
+                if constexpr (IMG16)
+                    w[k] = lh.rowbase[cy] + (uint32_t)reinterpret_cast<const uint16_t*>(s_rec0)[at] + (uint32_t)__popc(m.x & ((1u << bit) - 1u));
+                else
+                    w[k] = s_rec0[at] + (uint32_t)__popc(m.x & ((1u << bit) - 1u));
                 recmask |= 1u << k;
             } else {
                 want = real && ((m.y >> bit) & 1u);
@@ -1634,7 +1653,7 @@ __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mas
     // the tile, when nothing of the tile's state is live any more
     uint32_t n_rare = 0;  // wave-uniform
     uint32_t* s_rare = reinterpret_cast<uint32_t*>(s_items);
-    static_assert(sizeof(ChainItem) * chain_items<P>() >= sizeof(uint32_t) * 64 * P, "the list holds a tile of rare rows");
+    static_assert(sizeof(ChainItem) * ITEMS >= sizeof(uint32_t) * 64 * P, "the list holds a tile of rare rows");
     if (__any(dmask != 0u)) {
         static_for<P>([&](auto K) {
             constexpr int k = decltype(K)::value;
@@ -1657,8 +1676,78 @@ __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mas
         const uint32_t run = *run_io;
         const uint32_t* const part_geom = HOT_ARG(part_geom);
         const uint8_t* const polys_validity = HOT_ARG(polys_validity);
+        if constexpr (LH) {
+            // the ordinary rows: part -> geometry, count, the hit's 16-bit geometry id at its rank in the wave's LDS list, the row's mask
+            uint32_t hits = 0;  // wave-uniform
+            static_for<P>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                const uint32_t li = (uint32_t)(k * 64 + lane);
+                uint32_t r = res[k];
+                if (r != CODE_NONE) {
+                    const uint32_t geom = part_geom ? part_geom[r] : r;
+                    r = dev::valid_row(polys_validity, geom) ? geom : CODE_NONE;
+                }
+                const bool mine = (FULL || li < rem) && !((dmask >> k) & 1u);
+                const bool hit = mine && r != CODE_NONE;
+                const unsigned long long m = __ballot(hit);
+                if (mine && tile_counts) dev::store_stream(tile_counts + li, hit ? 1u : 0u);
+                if (hit) {
+                    const uint32_t at = run + hits + lanes_below(m);
+                    if (at < lh.cap) lh.ids[at] = (uint16_t)r;
+                }
+                if (lane == 0) lh.masks[k] = m;
+                hits += (uint32_t)__popcll(m);
+            });
+            // the rare rows, in row order: a row with ONE hit takes its place in the list (the tail moves up by one, its bit joins the row's
+            // mask); a row in several geometries cannot be told by a bit — the wave gives up the list and decides its tiles again
+            if (n_rare) {  // (wave-uniform)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (uint32_t i = 0; i < n_rare; ++i) {
+                    const uint32_t li = s_rare[i], rk = li >> 6, rj = li & 63u;
+                    uint32_t before = (uint32_t)__popcll(lh.masks[rk] & ((1ull << rj) - 1ull));  // (earlier rare rows' bits are in the masks by now)
+                    for (uint32_t kk = 0; kk < rk; ++kk) before += (uint32_t)__popcll(lh.masks[kk]);
+                    const uint32_t at = run + before, end = run + hits;
+                    const double2 q = tile_xy[li];
+                    const unsigned long long cf = chain_generic_row_first_call(HOT_ARG(cold), q.x, q.y, lane);
+                    const uint32_t cnt = (uint32_t)cf, first = (uint32_t)(cf >> 32);
+                    if (cnt == 1u) {
+                        for (uint32_t hi = end; hi > at; hi = hi - at > 64u ? hi - 64u : at) {  // [at, end) up by one, from the top
+                            const uint32_t lo = hi - at > 64u ? hi - 64u : at, src = lo + (uint32_t)lane;
+                            uint16_t v = 0;
+                            if (src < hi && src < lh.cap) v = lh.ids[src];
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            if (src < hi && src + 1u < lh.cap) lh.ids[src + 1u] = v;
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        }
+                        if (lane == 0) {
+                            if (at < lh.cap) lh.ids[at] = (uint16_t)first;
+                            lh.masks[rk] |= 1ull << rj;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    } else if (cnt > 1u && lane == 0) {
+                        *lh.over = 1u;
+                    }
+                    if (lane == 0 && tile_counts) tile_counts[li] = cnt;
+                    hits += cnt;
+                }
+                if (stats && lane == 0) atomicAdd(&stats[2], (unsigned long long)n_rare);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next tile overwrites the rare list)
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (run + hits > lh.cap && lane == 0) *lh.over = 1u;
+            *run_io = run + hits;
+            return;
+        }
         unsigned long long* s_mh = reinterpret_cast<unsigned long long*>(s_rare + 64 * P);  // the point rows' hit masks, for the rare arm
-        static_assert(sizeof(ChainItem) * chain_items<P>() >= sizeof(uint32_t) * 64 * P + sizeof(unsigned long long) * P, "the list also holds the rows' hit masks");
+        static_assert(sizeof(ChainItem) * ITEMS >= sizeof(uint32_t) * 64 * P + sizeof(unsigned long long) * P, "the list also holds the rows' hit masks");
         // the ordinary rows: part -> geometry (null geometries dropped), count, the hit at its rank among them
         uint32_t hits = 0;  // wave-uniform
         static_for<P>([&](auto K) {
@@ -1835,20 +1924,60 @@ struct FusedTail {
 constexpr int FUSED_TOTAL_BITS = 40;
 constexpr uint32_t FUSED_SPIN_LIMIT = 1u << 22;
 constexpr unsigned long long FUSED_LOST = ~0ull;  // in the total's place: the launch gave up waiting (gpk_spatial_join reports GPK_ERR_DEVICE)
+// LH = true (round 4, second form): the wave's hits never leave the CU before they are final — 16-bit geometry ids in an LDS list, one
+// 64-bit hit mask per point row — so there are no staging stores, no staging reads, and the copy phase is a stream of stores out of
+// LDS.  Eligible when geometry ids fit 16 bits and a wave owns at most FUSED_LH_TILES tiles (the host checks); the routing image
+// shrinks to make room (16-bit record ranks relative to a per-row base, 96 list slots per wave).  A wave whose hits do not fit its
+// list, or that meets a row in several geometries, decides its tiles again, storing at the final offsets (as the staging form does).
+#ifndef GPK_LH_EMIT_RANK
+#define GPK_LH_EMIT_RANK 0
+#endif
+#ifndef GPK_LH_NT
+#define GPK_LH_NT 1
+#endif
+constexpr int FUSED_LH_TILES = 5;
+constexpr int FUSED_LH_IDS = 1120;  // 16-bit hit slots per wave: 2240 + 320 bytes of masks = 2560 bytes per wave, 40 KB per work-group
+template <bool LH>
 __global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_fused_kernel(ChainHot h, FusedTail tail_in_the_argument_segment) {
-    constexpr int WORDS = PIP_ROUTE_RMAX * PIP_ROUTE_RMAX / 32, W = ROUTE_BLOCK / 64, TILE = 64 * FUSED_PPT;
-    __shared__ uint2 s_mask[WORDS];     // RouteWord::bmask, gmask
-    __shared__ uint32_t s_rec0[WORDS];  // RouteWord::rec0
-    __shared__ ChainItem s_items[W][chain_items<FUSED_PPT>()];
+    constexpr int WORDS = PIP_ROUTE_RMAX * PIP_ROUTE_RMAX / 32, W = ROUTE_BLOCK / 64, TILE = 64 * FUSED_PPT, P = FUSED_PPT;
+    __shared__ uint2 s_mask[WORDS];                                 // RouteWord::bmask, gmask
+    __shared__ uint32_t s_rec0[LH ? WORDS / 2 : WORDS];             // RouteWord::rec0 (LH: as uint16 ranks within the raster row)
+    __shared__ uint32_t s_rowbase[LH ? PIP_ROUTE_RMAX : 1];         // LH: record rank of the row's first record
+    __shared__ ChainItem s_items[W][chain_items<P, LH>()];
+    __shared__ uint16_t s_ids[LH ? W : 1][LH ? FUSED_LH_IDS : 1];
+    __shared__ unsigned long long s_hmask[LH ? W : 1][LH ? FUSED_LH_TILES * P : 1];
+    __shared__ uint32_t s_over[W];
     __shared__ unsigned long long s_wtot[W];
     __shared__ unsigned long long s_part[W];
     {
         const int words = h.R * h.R / 32;
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(h.route);
-        for (int i = threadIdx.x; i < words; i += ROUTE_BLOCK) {
-            const uint4 rw = src[i];
-            s_mask[i] = make_uint2(rw.x, rw.y);
-            s_rec0[i] = rw.z;
+        if constexpr (LH) {
+            const int per_row = h.R / 32;  // (R >= 32: the host checks)
+            for (int row = threadIdx.x; row < h.R; row += ROUTE_BLOCK) {
+                uint32_t first = 0u;
+                for (int j = 0; j < per_row; ++j) {
+                    const uint4 rw = src[row * per_row + j];
+                    if (rw.x) {
+                        first = rw.z;
+                        break;
+                    }
+                }
+                s_rowbase[row] = first;
+            }
+            __syncthreads();
+            uint16_t* rec16 = reinterpret_cast<uint16_t*>(s_rec0);
+            for (int i = threadIdx.x; i < words; i += ROUTE_BLOCK) {
+                const uint4 rw = src[i];
+                s_mask[i] = make_uint2(rw.x, rw.y);
+                rec16[i] = rw.x ? (uint16_t)(rw.z - s_rowbase[i / per_row]) : (uint16_t)0;
+            }
+        } else {
+            for (int i = threadIdx.x; i < words; i += ROUTE_BLOCK) {
+                const uint4 rw = src[i];
+                s_mask[i] = make_uint2(rw.x, rw.y);
+                s_rec0[i] = rw.z;
+            }
         }
     }
     // (the wave's number as a SCALAR: what follows from it — its tile range, where its hits go, how many it has — then lives in scalar
@@ -1862,6 +1991,7 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_fused_kernel(ChainHot h,
         const TailPtr0 tp0 = (TailPtr0)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(ChainHot));
         s_wg = (uint32_t)(__hip_atomic_fetch_add(tp0->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - tp0->ticket_base);
     }
+    if (lane == 0) s_over[wave] = 0u;
     __syncthreads();
     const uint32_t wg = __builtin_amdgcn_readfirstlane(s_wg);
     int tile0, tile1;
@@ -1870,88 +2000,149 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_fused_kernel(ChainHot h,
         tile0 = (int)(gwave * h.n_tiles / n_waves);
         tile1 = (int)((gwave + 1) * h.n_tiles / n_waves);
     }
-    uint2* out = h.stage ? h.stage + (int64_t)tile0 * TILE : nullptr;
+    uint2* out = (!LH && h.stage) ? h.stage + (int64_t)tile0 * TILE : nullptr;
     uint32_t out_cap = (uint32_t)(tile1 - tile0) * (uint32_t)TILE, run = 0u;
-    __syncthreads();
-    for (int pass = 0; pass < 2; ++pass) {
-        // guard-free tiles first (a tile's points are requested one tile ahead), then the guarded ones (the column's last tile; every
-        // tile of a column with a validity bitmap): two plain loops — one loop that picks the variant per tile keeps the points that
-        // travel round its back edge in scratch memory
-        PointRegs<FUSED_PPT> pr;
-        const int tile_f = tile1 < h.n_full_tiles ? tile1 : (tile0 > h.n_full_tiles ? tile0 : h.n_full_tiles);
-        if (GPK_FUSED_PREFETCH && tile0 < tile_f) chain_load_points<FUSED_PPT, true, true>(h, (int64_t)tile0, lane, pr);
-        for (int tile = tile0; tile < tile_f; ++tile)
-            chain_tile<FUSED_PPT, true, true, true>(h, s_mask, s_rec0, s_items[wave], (int64_t)tile, lane, out, out_cap, &run, pr,
-                                                   tile + 1 < tile_f ? (int64_t)(tile + 1) : (int64_t)-1);
-        for (int tile = tile_f; tile < tile1; ++tile)
-            chain_tile<FUSED_PPT, true, false, true>(h, s_mask, s_rec0, s_items[wave], (int64_t)tile, lane, out, out_cap, &run, pr, (int64_t)-1);
-        // (the tail of the kernel arguments is read HERE, from the argument segment: named directly the compiler loads it at the top
-        // of the kernel and carries its fourteen scalar registers through the tile loop, which has none to spare)
-        typedef const FusedTail __attribute__((address_space(4))) * TailPtr;
-        static_assert(sizeof(ChainHot) % 8 == 0, "FusedTail follows ChainHot in the argument segment");
-        const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(ka));
-        const TailPtr tp = (TailPtr)(ka + sizeof(ChainHot));
-        FusedTail t;
-        t.pairs = tp->pairs;
-        t.capacity = tp->capacity;
-        t.slots = tp->slots;
-        t.epoch = tp->epoch;
-        t.grand = tp->grand;
-        t.grand_host = tp->grand_host;
-        t.left_base = tp->left_base;
-        t.ticket = nullptr;
-        t.ticket_base = 0;
-#if GPK_FUSED_ABLATE == 2  // tuning builds only: the tile phase alone (no totals, no pair list)
-        break;
-#endif
-        if (pass == 1) {  // the second time round the hits went straight to their final slots: the left rows' base is still to add
-            if (t.left_base) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                for (uint32_t i = (uint32_t)lane; i < run && i < out_cap; i += 64u) out[i].x += t.left_base;
+    // guard-free tiles first, then the guarded ones (the column's last tile; every tile of a column with a validity bitmap): two plain
+    // loops — one loop that picks the variant per tile keeps the values that travel round its back edge in scratch memory
+    const int tile_f = tile1 < h.n_full_tiles ? tile1 : (tile0 > h.n_full_tiles ? tile0 : h.n_full_tiles);
+    {
+        PointRegs<P> pr;
+        if constexpr (LH) {
+            LdsHits lh{s_ids[wave], s_hmask[wave], s_rowbase, &s_over[wave], (uint32_t)FUSED_LH_IDS};
+            for (int tile = tile0; tile < tile_f; ++tile) {
+                lh.masks = s_hmask[wave] + (tile - tile0) * P;
+                chain_tile<P, true, true, true, true>(h, s_mask, s_rec0, s_items[wave], (int64_t)tile, lane, nullptr, 0u, &run, pr, (int64_t)-1, lh);
             }
-            break;
+            for (int tile = tile_f; tile < tile1; ++tile) {
+                lh.masks = s_hmask[wave] + (tile - tile0) * P;
+                chain_tile<P, true, false, true, true>(h, s_mask, s_rec0, s_items[wave], (int64_t)tile, lane, nullptr, 0u, &run, pr, (int64_t)-1, lh);
+            }
+        } else {
+            if (GPK_FUSED_PREFETCH && tile0 < tile_f) chain_load_points<P, true, true>(h, (int64_t)tile0, lane, pr);
+            for (int tile = tile0; tile < tile_f; ++tile)
+                chain_tile<P, true, true, true>(h, s_mask, s_rec0, s_items[wave], (int64_t)tile, lane, out, out_cap, &run, pr,
+                                                tile + 1 < tile_f ? (int64_t)(tile + 1) : (int64_t)-1);
+            for (int tile = tile_f; tile < tile1; ++tile)
+                chain_tile<P, true, false, true>(h, s_mask, s_rec0, s_items[wave], (int64_t)tile, lane, out, out_cap, &run, pr, (int64_t)-1);
         }
-        // this work-group's total, published; the totals before it
-        if (lane == 0) s_wtot[wave] = (unsigned long long)run;
-        __syncthreads();
-        unsigned long long wg_tot = 0, mine_off = 0;
+    }
+#if GPK_FUSED_ABLATE == 2  // tuning builds only: the tile phase alone (no totals, no pair list)
+    return;
+#endif
+    // (the tail of the kernel arguments is read HERE, from the argument segment: named directly the compiler loads it at the top
+    // of the kernel and carries its fourteen scalar registers through the tile loop, which has none to spare)
+    typedef const FusedTail __attribute__((address_space(4))) * TailPtr;
+    static_assert(sizeof(ChainHot) % 8 == 0, "FusedTail follows ChainHot in the argument segment");
+    const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    const TailPtr tp = (TailPtr)(ka + sizeof(ChainHot));
+    FusedTail t;
+    t.pairs = tp->pairs;
+    t.capacity = tp->capacity;
+    t.slots = tp->slots;
+    t.epoch = tp->epoch;
+    t.grand = tp->grand;
+    t.grand_host = tp->grand_host;
+    t.left_base = tp->left_base;
+    t.ticket = nullptr;
+    t.ticket_base = 0;
+    // this work-group's total, published; the totals before it
+    if (lane == 0) s_wtot[wave] = (unsigned long long)run;
+    __syncthreads();
+    unsigned long long wg_tot = 0, mine_off = 0;
 #pragma unroll
-        for (int w = 0; w < W; ++w) {
-            const unsigned long long v = s_wtot[w];
-            wg_tot += v;
-            if (w < wave) mine_off += v;
+    for (int w = 0; w < W; ++w) {
+        const unsigned long long v = s_wtot[w];
+        wg_tot += v;
+        if (w < wave) mine_off += v;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(&t.slots[wg], (t.epoch << FUSED_TOTAL_BITS) | wg_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long acc = 0;
+    bool gave_up = false;
+    for (unsigned b = threadIdx.x; b < wg; b += ROUTE_BLOCK) {
+        unsigned long long v;
+        uint32_t spins = 0;
+        while (((v = __hip_atomic_load(&t.slots[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> FUSED_TOTAL_BITS) != t.epoch) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > FUSED_SPIN_LIMIT) {  // (seconds: a work-group before this one never ran — report, never hang the device)
+                gave_up = true;
+                break;
+            }
         }
-        if (threadIdx.x == 0) __hip_atomic_store(&t.slots[wg], (t.epoch << FUSED_TOTAL_BITS) | wg_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned long long acc = 0;
-        bool gave_up = false;
-        for (unsigned b = threadIdx.x; b < wg; b += ROUTE_BLOCK) {
-            unsigned long long v;
-            uint32_t spins = 0;
-            while (((v = __hip_atomic_load(&t.slots[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> FUSED_TOTAL_BITS) != t.epoch) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > FUSED_SPIN_LIMIT) {  // (seconds: a work-group before this one never ran — report, never hang the device)
-                    gave_up = true;
-                    break;
+        acc += v & ((1ull << FUSED_TOTAL_BITS) - 1ull);
+    }
+    const bool lost = __syncthreads_or(gave_up);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) s_part[wave] = acc;
+    __syncthreads();
+    unsigned long long base_off = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) base_off += s_part[w];
+    if ((wg == gridDim.x - 1 || lost) && threadIdx.x == 0) {
+        *t.grand = lost ? FUSED_LOST : base_off + wg_tot;
+        if (t.grand_host) *t.grand_host = lost ? FUSED_LOST : base_off + wg_tot;
+    }
+    if (!t.pairs || lost || GPK_FUSED_ABLATE == 1) return;  // (ablation 1, tuning builds only: no copy)
+    const unsigned long long my_off = base_off + mine_off;
+    bool redo;
+    if constexpr (LH) {
+        redo = s_over[wave] != 0u;  // (set by this wave's own lane 0: wave-uniform)
+        if (!redo && !GPK_LH_EMIT_RANK) {  // the hits, out of LDS, to their place in the pair list: a row's rank = the hits before it
+            uint32_t pos = 0;
+            for (int tile = tile0; tile < tile1; ++tile) {
+#pragma unroll
+                for (int k = 0; k < P; ++k) {
+                    const unsigned long long m = s_hmask[wave][(tile - tile0) * P + k];
+                    const uint32_t rank = pos + lanes_below(m);
+                    if ((m >> lane) & 1ull) {
+                        const unsigned long long at = my_off + rank;
+                        const uint32_t row = (uint32_t)((int64_t)tile * TILE + k * 64 + lane) + t.left_base;
+                        if ((int64_t)at < t.capacity) {
+                            const unsigned long long v = ((unsigned long long)s_ids[wave][rank] << 32) | (unsigned long long)row;
+                            if (GPK_LH_NT)
+                                __builtin_nontemporal_store(v, reinterpret_cast<unsigned long long*>(t.pairs + at));
+                            else
+                                *reinterpret_cast<unsigned long long*>(t.pairs + at) = v;
+                        }
+                    }
+                    pos += (uint32_t)__popcll(m);
                 }
             }
-            acc += v & ((1ull << FUSED_TOTAL_BITS) - 1ull);
-        }
-        const bool lost = __syncthreads_or(gave_up);
+        } else if (!redo) {
+            // the hits, out of LDS, to their place in the pair list.  First every hit row writes its number (within the wave's rows) at
+            // its rank — into the list slots, which are free now —, then the lanes walk the RANKS: a wave stores 512 contiguous bytes per
+            // instruction (stored row by row, an instruction covered ~180 bytes of two lines: 10.7 us for the 28 MB)
+            uint16_t* rows16 = reinterpret_cast<uint16_t*>(s_items[wave]);
+            static_assert(sizeof(ChainItem) * chain_items<P, true>() >= sizeof(uint16_t) * FUSED_LH_IDS, "the list slots hold a row number per hit");
+            static_assert(FUSED_LH_TILES * TILE <= 65536, "a row's number within the wave's rows fits 16 bits");
+            uint32_t pos = 0;
+            for (int tile = tile0; tile < tile1; ++tile) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (lane == 0) s_part[wave] = acc;
-        __syncthreads();
-        unsigned long long base_off = 0;
-#pragma unroll
-        for (int w = 0; w < W; ++w) base_off += s_part[w];
-        if ((wg == gridDim.x - 1 || lost) && threadIdx.x == 0) {
-            *t.grand = lost ? FUSED_LOST : base_off + wg_tot;
-            if (t.grand_host) *t.grand_host = lost ? FUSED_LOST : base_off + wg_tot;
+                for (int k = 0; k < P; ++k) {
+                    const unsigned long long m = s_hmask[wave][(tile - tile0) * P + k];
+                    if ((m >> lane) & 1ull) rows16[pos + lanes_below(m)] = (uint16_t)((tile - tile0) * TILE + k * 64 + lane);
+                    pos += (uint32_t)__popcll(m);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t row_base = (uint32_t)((int64_t)tile0 * TILE) + t.left_base;
+            for (uint32_t r = (uint32_t)lane; r < run; r += 64u) {
+                const unsigned long long at = my_off + r;
+                if ((int64_t)at < t.capacity) {
+                    const unsigned long long v = ((unsigned long long)s_ids[wave][r] << 32) | (unsigned long long)(row_base + rows16[r]);
+                    if (GPK_LH_NT)
+                        __builtin_nontemporal_store(v, reinterpret_cast<unsigned long long*>(t.pairs + at));
+                    else
+                        *reinterpret_cast<unsigned long long*>(t.pairs + at) = v;
+                }
+            }
         }
-        if (!t.pairs || lost || GPK_FUSED_ABLATE == 1) break;  // (ablation 1, tuning builds only: no copy)
-        const unsigned long long my_off = base_off + mine_off;
-        if (run <= out_cap) {  // the run, moved to its place in the pair list
+    } else {
+        redo = run > out_cap;
+        if (!redo) {  // the run, moved to its place in the pair list
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const uint2* __restrict__ src = out;
             constexpr int CU = GPK_FUSED_COPY_UNROLL;  // entries a lane has in flight: the loop is a chain of round trips otherwise
@@ -1970,13 +2161,28 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_fused_kernel(ChainHot h,
                                                     reinterpret_cast<unsigned long long*>(t.pairs + my_off + i));
                 }
             }
-            break;
         }
-        // more hits than slots: decide the tiles again, storing at the final offsets
+    }
+    if (!redo) return;
+    // the wave could not park its hits (rows in several geometries; more hits than slots): it decides its tiles again, storing at the
+    // final offsets, and adds the left rows' base afterwards
+    {
         const int64_t room = t.capacity - (int64_t)my_off;
         out = t.pairs + my_off;
         out_cap = room <= 0 ? 0u : (room > (int64_t)0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)room);
+        const uint32_t left_base = t.left_base;
         run = 0u;
+        PointRegs<P> pr;
+        LdsHits lh{};
+        lh.rowbase = s_rowbase;
+        for (int tile = tile0; tile < tile_f; ++tile)
+            chain_tile<P, true, true, true, false, LH>(h, s_mask, s_rec0, s_items[wave], (int64_t)tile, lane, out, out_cap, &run, pr, (int64_t)-1, lh);
+        for (int tile = tile_f; tile < tile1; ++tile)
+            chain_tile<P, true, false, true, false, LH>(h, s_mask, s_rec0, s_items[wave], (int64_t)tile, lane, out, out_cap, &run, pr, (int64_t)-1, lh);
+        if (left_base) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (uint32_t i = (uint32_t)lane; i < run && i < out_cap; i += 64u) out[i].x += left_base;
+        }
     }
 }
 
@@ -2629,7 +2835,21 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
     const int64_t n_wblocks = (n + PIP_WTILE - 1) / PIP_WTILE;
     // words in the multi-hit pool (a chain launch has no multi-hit rows in it: a rare row with several hits is CODE_MULTI)
     const uint32_t multi_cap = chain ? 1024u : (uint32_t)(n < (int64_t)0x18000000 ? 2 * n + 1024 : (int64_t)0x30000000);
-    const size_t stage_bytes = fused && want_pairs ? sizeof(uint2) * (size_t)n_blocks * (size_t)tile_points : 0;
+    // the fused kernel's second form keeps the hits in LDS (no staging slots): geometry ids must fit 16 bits and a wave own at most
+    // FUSED_LH_TILES tiles.  GPK_FUSED_LDS=0: the staging form (A/B runs)
+    static const bool no_lds_hits = [] {
+        const char* e = getenv("GPK_FUSED_LDS");
+        return e && *e == '0';
+    }();
+    int64_t fused_wgs = (int64_t)cu_count();
+    {
+        const int64_t want = (n_blocks + ROUTE_BLOCK / 64 - 1) / (ROUTE_BLOCK / 64);
+        if (fused_wgs > want) fused_wgs = want;
+        if (fused_wgs < 1) fused_wgs = 1;
+    }
+    const bool lds_hits = fused && !no_lds_hits && right->d.n_geoms <= 65535 && right_index->pip.R >= 32 &&
+                          (n_blocks + fused_wgs * (ROUTE_BLOCK / 64) - 1) / (fused_wgs * (ROUTE_BLOCK / 64)) <= FUSED_LH_TILES;
+    const size_t stage_bytes = fused && want_pairs && !lds_hits ? sizeof(uint2) * (size_t)n_blocks * (size_t)tile_points : 0;
     size_t need = align256(fused ? 64 : counts_bytes + 64) /*code*/ + align256(sizeof(unsigned long long) * (size_t)(n_blocks + n_super + 3)) +
                   align256(sizeof(uint32_t) * (size_t)multi_cap) + align256(sizeof(ChainCold)) + align256(stage_bytes) + 1024;
     if (host_out && out_counts) need += align256(counts_bytes);
@@ -2719,10 +2939,7 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         hot.sub_max = (double)(((uint32_t)PIP_SUB << hot.logR) - 1u);
     }
     if (fused) {  // one launch: persistent work-groups (one per CU), contiguous tiles per wave, pairs written by the same kernel
-        const int tiles_per_wg = ROUTE_BLOCK / 64;
-        int64_t wgs = (int64_t)cu_count();
-        const int64_t want = (n_blocks + tiles_per_wg - 1) / tiles_per_wg;
-        if (wgs > want) wgs = want;
+        const int64_t wgs = fused_wgs;
         FusedTail tail;
         memset(&tail, 0, sizeof tail);
         tail.pairs = (uint2*)pairs_dev;
@@ -2733,7 +2950,10 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         int32_t frc = fused_launch_begin(s, (int)wgs, &tail.slots, &tail.epoch, &tail.ticket, &tail.ticket_base);
         if (frc != GPK_OK) return frc;
         frc = [&]() -> int32_t {
-            GPK_LAUNCH("gpk_pip_tile", pip_tile_fused_kernel, dim3((unsigned)wgs), dim3(ROUTE_BLOCK), 0, s, hot, tail);
+            if (lds_hits)
+                GPK_LAUNCH("gpk_pip_tile", pip_tile_fused_kernel<true>, dim3((unsigned)wgs), dim3(ROUTE_BLOCK), 0, s, hot, tail);
+            else
+                GPK_LAUNCH("gpk_pip_tile", pip_tile_fused_kernel<false>, dim3((unsigned)wgs), dim3(ROUTE_BLOCK), 0, s, hot, tail);
             return GPK_OK;
         }();
         fused_launch_end(s, frc == GPK_OK);

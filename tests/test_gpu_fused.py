@@ -1,5 +1,6 @@
 """GPU parity of the one-launch point join (gpk_join.hip: pip_tile_fused_kernel — tiles decided, hits ranked and the sorted (l, r)
-pair list written by the same persistent work-groups) through the C ABI vs the CPU oracle, bit-exact on counts, pairs and totals
+pair list written by the same persistent work-groups; two forms: hits kept in LDS until their place is known — geometry ids of 16 bits,
+at most five tiles per wave — or parked in staging slots, GPK_FUSED_LDS=0 / longer columns) through the C ABI vs the CPU oracle, bit-exact on counts, pairs and totals
 (`Contains<Point>`, spatial_index.rs:91-96; sorted pairs = the two index vectors of spatial_index.rs:145-159).
 
 What only this kernel has, and what is aimed at here: a wave's hits parked in the pair slots of its own rows and moved to their
@@ -162,4 +163,45 @@ def test_the_round_three_pair_of_kernels_still_answers_the_same(gpk, oracle):
         "print('ok', int(ec.sum()))\n"
     )
     r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, GPK_TILE_KERNEL="route"))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr[-3000:]
+
+
+def test_a_column_too_long_for_the_lds_form_takes_the_staging_form(gpk, oracle):
+    """more than 5 tiles per wave (> 10.7 M points on 256 CUs): the hits are parked in staging slots instead of LDS"""
+    polys = synth.star_polygons(1000, 64)
+    pts = synth.uniform_points(11_000_003, seed=77)
+    ep, ec, _ = oracle.spatial_join(pts, polys, "intersects", mode=1)
+    gp, gc = join_pairs(GeoSeries(pts), GeoSeries(polys), "intersects", r_index=SpatialIndex(GeoSeries(polys)))
+    assert np.array_equal(gc, ec) and np.array_equal(gp, ep)
+
+
+def test_the_staging_form_on_the_same_inputs(gpk, oracle):
+    """GPK_FUSED_LDS=0 (read once per process): rows in several geometries, left_row_base, ragged tails — in its own interpreter"""
+    import os, subprocess, sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, 'tests')\n"
+        "from geopolars_amd import synth\n"
+        "from geopolars_amd.geoarrow import GeoArrowArray\n"
+        "from geopolars_amd.geoseries import GeoSeries\n"
+        "from geopolars_amd.spatial_index import SpatialIndex, join_pairs\n"
+        "from oracle import pyoracle\n"
+        "import test_gpu_fused as T\n"
+        "pyoracle.build()\n"
+        "polys = T._stacked(900, 37)\n"
+        "rng = np.random.default_rng(3)\n"
+        "pts = np.concatenate([synth.uniform_points(60_001, seed=4).xy, np.column_stack([rng.uniform(499.0, 505.0, 3000), rng.uniform(959.0, 965.0, 3000)])])\n"
+        "rng.shuffle(pts)\n"
+        "pts = GeoArrowArray.from_points(pts)\n"
+        "right = GeoSeries(polys); index = SpatialIndex(right)\n"
+        "ep, ec, _ = pyoracle.spatial_join(pts, polys, 'intersects', mode=0)\n"
+        "for base in (0, 123456):\n"
+        "    gp, gc = join_pairs(GeoSeries(pts), right, 'intersects', r_index=index, left_row_base=base)\n"
+        "    e = ep.copy(); e[:, 0] += base\n"
+        "    assert np.array_equal(gc, ec) and np.array_equal(gp, e)\n"
+        "print('ok', int(ec.sum()), int(ec.max()))\n"
+    )
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, GPK_FUSED_LDS="0"))
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr[-3000:]
