@@ -130,8 +130,11 @@ __device__ __forceinline__ int ring_of_coord(const int32_t* __restrict__ ring_of
 }
 // edge starting at coordinate i (a single-coordinate ring contributes one degenerate edge so that the
 // "ring of one coordinate" arm of coord_pos_relative_to_ring is reproduced by the edge walk)
-__device__ __forceinline__ bool edge_at(const DevGeo& a, int i, int& r, double2& s, double2& e) {
-    r = ring_of_coord(a.ring_off, (int)a.n_rings, i);
+// coord_ring: the ring of every coordinate, one load (ring_start_kernel + a scan, built once per index build) — the per-edge
+// kernels below ran 23 DEPENDENT loads of a binary search over the ring offsets per coordinate and were bound by that chain
+// (C5: 143.9M coordinates, 5.0M rings; six launches, 46 of the build's 92 ms).
+__device__ __forceinline__ bool edge_at(const DevGeo& a, const int32_t* __restrict__ coord_ring, int i, int& r, double2& s, double2& e) {
+    r = coord_ring[i];
     const int c0 = a.ring_off[r], c1 = a.ring_off[r + 1];
     if (i >= c1) return false;  // coordinate belongs to an empty-ring gap (cannot happen with valid offsets)
     s = a.xy[i];
@@ -146,35 +149,77 @@ __device__ __forceinline__ bool edge_at(const DevGeo& a, int i, int& r, double2&
     return false;
 }
 
+// flag[ring_off[r]] += 1 for every ring r >= 1 that starts below n_coords: the inclusive prefix sum at coordinate i is then the
+// largest r with ring_off[r] <= i (ring_of_coord's answer, empty rings included) — the build scans it in place
+__global__ void ring_start_kernel(const int32_t* __restrict__ ring_off, int64_t n_rings, int64_t n_coords, int32_t* __restrict__ flag) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < 1 || r >= n_rings) return;
+    const int32_t o = ring_off[r];
+    if (o >= 0 && (int64_t)o < n_coords) atomicAdd(&flag[o], 1);
+}
+
 template <bool FILL>
-__global__ void slab_register_kernel(DevGeo a, FineGrid f, const int32_t* __restrict__ row0,
+__global__ void slab_register_kernel(DevGeo a, const int32_t* __restrict__ coord_ring, FineGrid f, const int32_t* __restrict__ row0,
                                      const int32_t* __restrict__ slab_base, int32_t* __restrict__ cnt_or_cursor,
                                      double4* __restrict__ edges, int32_t* __restrict__ vidx = nullptr) {
     // vidx (optional, FILL only): the coordinate index every slab entry's edge starts at (chain_aux_kernel; PipView::slab_vidx when the
     // index keeps no edge copies: `edges` is nullptr then)
+    //
+    // One atomic per RUN of lanes that register in the same slab, not one per edge: consecutive edges of a ring mostly lie in one
+    // slab row (SLAB_TARGET of them share it), and 144M same-address atomics in a row were what bound this kernel (C5: 6.8 + 10.2 ms
+    // for the two passes after the ring search had gone).  The head lane of a run adds the run's length and hands every lane its
+    // slot; an edge that spans several rows registers the first one this way and the others one atomic each, as before.
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n_coords) return;
-    int r;
-    double2 s, e;
-    if (!edge_at(a, (int)i, r, s, e)) return;
-    if (slab_base[r + 1] == slab_base[r]) return;
+    const int lane = (int)(threadIdx.x & 63);
+    int r = 0;
+    double2 s = make_double2(0, 0), e = s;
+    bool live = i < a.n_coords && edge_at(a, coord_ring, (int)i, r, s, e);
+    if (live) live = slab_base[r + 1] != slab_base[r];
     const double ylo = s.y < e.y ? s.y : e.y, yhi = s.y > e.y ? s.y : e.y;
-    if (!(ylo == ylo) || !(yhi == yhi)) return;
-    const int rr = row0[r];
-    const int down = PIP_FINE_LOG2 - slab_shift_of(rr);  // f is the finest row grid
-    const int j0 = frow(f, ylo) >> down, j1 = frow(f, yhi) >> down;
+    if (!(ylo == ylo) || !(yhi == yhi)) live = false;
+    int j0 = 0, j1 = -1, sl0 = -1 - lane;  // dead lanes: keys no neighbour shares
+    int rr = 0;
+    if (live) {
+        rr = row0[r];
+        const int down = PIP_FINE_LOG2 - slab_shift_of(rr);  // f is the finest row grid
+        j0 = frow(f, ylo) >> down;
+        j1 = frow(f, yhi) >> down;
+        sl0 = slab_base[r] + (j0 - slab_row0_of(rr));
+    }
+    const int prev = __shfl_up(sl0, 1, 64);
+    const unsigned long long heads = __ballot(lane == 0 || sl0 != prev);
+    const int head = 63 - __clzll((long long)(heads & (~0ull >> (63 - lane))));  // the run's first lane (heads has bit 0 set)
+    const unsigned long long above = lane == 63 ? 0ull : heads >> (lane + 1);
+    const int run = above ? __ffsll((long long)above) : 64 - lane;  // (meaningful on head lanes)
+    int base = 0;
+    if (live && head == lane) base = atomicAdd(&cnt_or_cursor[sl0], run);
+    base = __shfl(base, head, 64);
+    if (!live) return;
     const bool degenerate = FILL && a.ring_off[r + 1] - a.ring_off[r] == 1;  // edge_at: (s, s) of a one-coordinate ring
-    for (int j = j0; j <= j1; ++j) {
+    auto put = [&](int slot) {
+        if (edges) edges[slot] = make_double4(s.x, s.y, e.x, e.y);
+        if (vidx) vidx[slot] = degenerate ? ~(int32_t)i : (int32_t)i;
+    };
+    if (FILL) put(base + (lane - head));
+    for (int j = j0 + 1; j <= j1; ++j) {
         const int sl = slab_base[r] + (j - slab_row0_of(rr));
         const int slot = atomicAdd(&cnt_or_cursor[sl], 1);
-        if (FILL) {
-            if (edges) edges[slot] = make_double4(s.x, s.y, e.x, e.y);
-            if (vidx) vidx[slot] = degenerate ? ~(int32_t)i : (int32_t)i;
-        }
+        if (FILL) put(slot);
     }
 }
 
 // cells an edge may touch (see the header comment); f(i, j) is called for each
+// Does the segment s -> e's supporting LINE separate the closed rectangle [xl, xh] x [yl, yh] strictly from itself — are all four
+// corners strictly on one side?  orient2d(s, e, c) is the sign of a function that is LINEAR in the corner c:
+//     sx ey - sy ex + cx (sy - ey) + cy (ex - sx),
+// so its minimum and maximum over the rectangle sit at the two corners picked by the signs of (sy - ey) and (ex - sx): two exact
+// orientations answer what four were computed for (round 4: the labelling kernels of the index build are bound by this arithmetic).
+// Exact: dev::orient2d returns the sign of the true value, and the extreme corners of the true function are the ones picked.
+__device__ __forceinline__ bool line_clear_of_rect(double sx, double sy, double ex, double ey, double xl, double yl, double xh, double yh) {
+    const bool x_up = sy > ey, y_up = ex > sx;  // the function grows with cx / with cy (a zero coefficient: either corner)
+    const double max_x = x_up ? xh : xl, min_x = x_up ? xl : xh, max_y = y_up ? yh : yl, min_y = y_up ? yl : yh;
+    return dev::orient2d(sx, sy, ex, ey, min_x, min_y) > 0 || dev::orient2d(sx, sy, ex, ey, max_x, max_y) < 0;
+}
 template <typename F>
 __device__ __forceinline__ void for_each_touched_cell(const FineGrid& g, double2 s, double2 e, F&& f) {
     const double xlo = s.x < e.x ? s.x : e.x, xhi = s.x > e.x ? s.x : e.x;
@@ -195,18 +240,12 @@ __device__ __forceinline__ void for_each_touched_cell(const FineGrid& g, double2
             }
             const double xl = g.rx0 + (double)i * g.fw - g.pad_x, xh = g.rx0 + (double)(i + 1) * g.fw + g.pad_x;
             const double yl = g.ry0 + (double)j * g.fh - g.pad_y, yh = g.ry0 + (double)(j + 1) * g.fh + g.pad_y;
-            const int o1 = dev::orient2d(s.x, s.y, e.x, e.y, xl, yl);
-            const int o2 = dev::orient2d(s.x, s.y, e.x, e.y, xh, yl);
-            const int o3 = dev::orient2d(s.x, s.y, e.x, e.y, xh, yh);
-            const int o4 = dev::orient2d(s.x, s.y, e.x, e.y, xl, yh);
-            const bool all_pos = o1 > 0 && o2 > 0 && o3 > 0 && o4 > 0;
-            const bool all_neg = o1 < 0 && o2 < 0 && o3 < 0 && o4 < 0;
-            if (!(all_pos || all_neg)) f(i, j);
+            if (!line_clear_of_rect(s.x, s.y, e.x, e.y, xl, yl, xh, yh)) f(i, j);
         }
 }
 
 template <bool FILL>
-__global__ void mark_kernel(DevGeo a, FineGrid g, const int32_t* __restrict__ ring_part,
+__global__ void mark_kernel(DevGeo a, const int32_t* __restrict__ coord_ring, FineGrid g, const int32_t* __restrict__ ring_part,
                             int32_t* __restrict__ cnt_or_off, unsigned long long* __restrict__ keys) {
     // count pass: cnt[i] = cells touched by the edge that starts at coordinate i; fill pass: the edge writes its keys
     // at off[i].. (exclusive scan of the counts) — no atomics, deterministic layout
@@ -214,7 +253,7 @@ __global__ void mark_kernel(DevGeo a, FineGrid g, const int32_t* __restrict__ ri
     if (i >= a.n_coords) return;
     int r;
     double2 s, e;
-    if (!edge_at(a, (int)i, r, s, e)) {
+    if (!edge_at(a, coord_ring, (int)i, r, s, e)) {
         if (!FILL) cnt_or_off[i] = 0;
         return;
     }
@@ -232,41 +271,47 @@ __global__ void unique_flags_kernel(const unsigned long long* __restrict__ sorte
     if (i >= n) return;
     flag[i] = (i == 0 || sorted[i] != sorted[i - 1]) ? 1 : 0;
 }
+// (+ cell_marks[c] += 1 for every unique mark of cell c: scanned, the cell kernels read their marks' range instead of running two
+// 24-step binary searches over the marks per cell)
 __global__ void unique_compact_kernel(const unsigned long long* __restrict__ sorted, int64_t n, const int32_t* __restrict__ pos,
-                                      unsigned long long* __restrict__ out) {
+                                      unsigned long long* __restrict__ out, int32_t* __restrict__ cell_marks) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (i == 0 || sorted[i] != sorted[i - 1]) out[pos[i]] = sorted[i];
-}
-
-__device__ __forceinline__ int64_t lower_bound_u64(const unsigned long long* __restrict__ v, int64_t n, unsigned long long key) {
-    int64_t lo = 0, hi = n;
-    while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (v[mid] < key)
-            lo = mid + 1;
-        else
-            hi = mid;
+    const unsigned long long key = sorted[i];
+    if (i == 0 || key != sorted[i - 1]) {
+        out[pos[i]] = key;
+        atomicAdd(&cell_marks[key >> 32], 1);
     }
-    return lo;
 }
 
+constexpr int CELL_SCRATCH = 8;  // entries per cell the count pass keeps for the fill pass (cell_build_kernel)
 // One thread per raster cell: merge (a) the parts whose edges may touch the cell and (b) the parts that
 // strictly contain the cell's centre, in ascending part order.
 template <bool FILL>
 __global__ void cell_build_kernel(DevGeo a, IndexView ix, PipView pv, FineGrid g,
-                                  const unsigned long long* __restrict__ marks, int64_t n_marks,
+                                  const unsigned long long* __restrict__ marks, const int32_t* __restrict__ mark_start,
                                   int32_t* __restrict__ need, const int32_t* __restrict__ list_off,
-                                  uint32_t* __restrict__ cell, uint32_t* __restrict__ list) {
+                                  uint32_t* __restrict__ cell, uint32_t* __restrict__ list, uint32_t* __restrict__ scratch) {
+    // scratch (n_cells x CELL_SCRATCH words, entry k of cell c at [k * n_cells + c]; may be null): the count pass leaves the first
+    // entries of every cell there and the fill pass copies the lists that fit instead of walking the candidates' slabs a second time
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= (int64_t)g.R * g.R) return;
+    const int64_t n_cells = (int64_t)g.R * g.R;
+    if (c >= n_cells) return;
     if (FILL && need[c] == 0) return;  // empty and one-entry cells got their word from the count pass: only list cells walk again
+    if (FILL && scratch && need[c] - 1 <= CELL_SCRATCH) {
+        const int m = need[c] - 1;
+        uint32_t* out = list + list_off[c];
+        out[0] = (uint32_t)m;
+        for (int k = 0; k < m; ++k) out[1 + k] = scratch[(int64_t)k * n_cells + c];
+        cell[c] = (CELL_TAG_LIST << 30) | (uint32_t)list_off[c];
+        return;
+    }
     const int ci = (int)(c % g.R), cj = (int)(c / g.R);
     const double cx = g.rx0 + ((double)ci + 0.5) * g.fw, cy = g.ry0 + ((double)cj + 0.5) * g.fh;
     const bool border = ci == 0 || cj == 0 || ci == g.R - 1 || cj == g.R - 1;
     const bool centre_ok = !border && fcol(g, cx) == ci && frow(g, cy) == cj;
-    int64_t m = lower_bound_u64(marks, n_marks, (unsigned long long)c << 32);
-    const int64_t m_end = lower_bound_u64(marks, n_marks, (unsigned long long)(c + 1) << 32);
+    int64_t m = mark_start[c];  // the cell's marks: exclusive scan of the per-cell counts (unique_compact_kernel)
+    const int64_t m_end = mark_start[c + 1];
 
     int n = 0;
     uint32_t first_entry = 0;
@@ -280,6 +325,7 @@ __global__ void cell_build_kernel(DevGeo a, IndexView ix, PipView pv, FineGrid g
         const uint32_t e = (part << 1) | boundary;
         if (n == 0) first_entry = e;
         if (out) out[n] = e;
+        if (!FILL && scratch && n < CELL_SCRATCH) scratch[(int64_t)n * n_cells + c] = e;
         ++n;
     };
     auto flush_marks_below = [&](unsigned long long part_limit) {  // emit marks with part < part_limit
@@ -382,6 +428,9 @@ __global__ void sub_head_kernel(PipView pv, FineGrid g, const int32_t* __restric
 // exactly" when any edge of ANY ring of a part that crosses the cell (taken from the rings' slabs of this raster row)
 // is not strictly on one side of the sub-cell's padded rectangle; otherwise it inherits the exact position of its
 // centre.  NP = 1: SubCell records (one crossing part); NP = 2: SubCell2 records (two parts, see gpk_index.h).
+#ifndef GPK_SUBBUILD_ABLATE
+#define GPK_SUBBUILD_ABLATE 0  // tuning builds only: 1 = box test only, 2 = no centre walk, 4 = no touch loop
+#endif
 constexpr int SUB_EDGE_CAP = 48;  // edges of a cell's slab rows kept in LDS per wave (sub_build_kernel)
 // WORK (NP = 1 only): the records are those of (cell, part) work items — the boundary entries of list cells,
 // work_cell[w] / work_part[w] -> sub[w] — instead of one per flagged cell.
@@ -429,13 +478,7 @@ __global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, Fi
     auto edge_touches = [&](const double4 ed) {
         // cheap reject: edge bbox vs padded rectangle (closed)
         if (fmax(ed.x, ed.z) < xl || fmin(ed.x, ed.z) > xh || fmax(ed.y, ed.w) < yl || fmin(ed.y, ed.w) > yh) return false;
-        const int o1 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yl);
-        const int o2 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yl);
-        const int o3 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yh);
-        const int o4 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yh);
-        const bool all_pos = o1 > 0 && o2 > 0 && o3 > 0 && o4 > 0;
-        const bool all_neg = o1 < 0 && o2 < 0 && o3 < 0 && o4 < 0;
-        return !(all_pos || all_neg);
+        return !line_clear_of_rect(ed.x, ed.y, ed.z, ed.w, xl, yl, xh, yh);
     };
     // the record's labels from the two ballots (low / high label bit): lanes 0..3 interleave their 16 sub-cells' bits into one word
     // each and store it — 64 global atomics on four addresses per record were most of this kernel's time
@@ -465,8 +508,21 @@ __global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, Fi
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             bool touched = false;
+#if GPK_SUBBUILD_ABLATE & 4
+            touched = n_all == 77u;
+#elif GPK_SUBBUILD_ABLATE & 1
+            for (uint32_t e = 0; e < n_all && !touched; ++e) {
+                const double4 ed = s_edges_all[wave][e];
+                touched = !(fmax(ed.x, ed.z) < xl || fmin(ed.x, ed.z) > xh || fmax(ed.y, ed.w) < yl || fmin(ed.y, ed.w) > yh);
+            }
+#else
             for (uint32_t e = 0; e < n_all && !touched; ++e) touched = edge_touches(s_edges_all[wave][e]);
+#endif
             uint32_t label = 2u;
+#if GPK_SUBBUILD_ABLATE & 2
+            if (!touched) label = (uint32_t)(xl > yl);
+            else
+#endif
             if (!touched) {
                 const double cx = g.rx0 + ((double)si + 0.5) * fw2, cy = g.ry0 + ((double)sj + 0.5) * fh2;
                 const bool ok = dev::cell_of(cx, g.rx0, g.inv_fw * S, g.R * S) == si && dev::cell_of(cy, g.ry0, g.inv_fh * S, g.R * S) == sj;
@@ -486,53 +542,90 @@ __global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, Fi
             return;
         }
     }
-    int n_list = 0;         // wave-uniform
-    bool list_ok = true;    // false: more than SUB_EDGE_CAP edges meet the cell -> every lane walks the slabs itself
-
-    for (int q = 0; q < NP && list_ok; ++q) {
+    // General path: every edge of every ring of the part(s) registered in this raster row goes past the wave once, 64 to a load —
+    // lane j first resolves the slab span of ring j (all rings' spans behind ONE chain of dependent gathers, not one chain per ring),
+    // the spans are laid end to end, and lane q of each round takes edge q of that sequence.  Survivors of the cell's box are
+    // compacted by ballot into the LDS list; a full list is drained (every lane tests its sub-cell against it) and refilled, so
+    // no cell falls back to 64 private walks.  (Round 4: one serial ring after the other with its own span lookup and edge rounds
+    // was 20 of this kernel's 26 ms on the power-law multipolygon column, whose large parts carry holes.)
+    __shared__ int s_span_e0[256 / 64][64], s_span_at[256 / 64][64];
+    int n_list = 0;  // wave-uniform
+    bool touched = false;
+    auto drain = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int e = 0; e < n_list && !touched; ++e) touched = edge_touches(s_edges[wave][e]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        n_list = 0;
+    };
+#if GPK_SUBBUILD_ABLATE & 16
+    if (false)
+#endif
+    for (int q = 0; q < NP; ++q) {
         if (!crosses[q]) continue;
         int r0, r1;
         dev::part_rings(a, part[q], r0, r1);
-        for (int r = r0; r < r1 && list_ok; ++r) {
-            int e0, e1;
-            if (!pip::slab_span_of_raster_row(pv, r, cj, e0, e1)) continue;
-            for (int eb = e0; eb < e1 && list_ok; eb += 64) {
-                const int e = eb + lane64;
+        for (int rb = r0; rb < r1; rb += 64) {
+            const int n_r = r1 - rb < 64 ? r1 - rb : 64;
+            int e0 = 0, cnt = 0;
+            if (lane64 < n_r) {
+                int a0, a1;
+                if (pip::slab_span_of_raster_row(pv, rb + lane64, cj, a0, a1)) {
+                    e0 = a0;
+                    cnt = a1 - a0;
+                }
+            }
+            const int incl = dev::wave_inclusive_scan(cnt);
+            const int total = __shfl(incl, 63, 64);
+            s_span_e0[wave][lane64] = e0;
+            s_span_at[wave][lane64] = incl - cnt;  // where ring j's edges start in the sequence (lanes past n_r: `total`)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int base = 0; base < total; base += 64) {
+                const int t = base + lane64;
                 bool keep = false;
                 double4 ed = make_double4(0, 0, 0, 0);
-                if (e < e1) {
-                    ed = pip::slab_edge(pv, e);
+                if (t < total) {
+                    int lo = 0, hi = n_r;  // the last ring whose start is <= t (rings without edges here share their successor's start)
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_span_at[wave][mid] <= t)
+                            lo = mid;
+                        else
+                            hi = mid;
+                    }
+                    ed = pip::slab_edge(pv, s_span_e0[wave][lo] + (t - s_span_at[wave][lo]));
                     keep = !(fmax(ed.x, ed.z) < cxl || fmin(ed.x, ed.z) > cxh || fmax(ed.y, ed.w) < cyl || fmin(ed.y, ed.w) > cyh);
                 }
                 const unsigned long long m = __ballot(keep);
+                if (!m) continue;
                 const int add = __popcll(m);
-                if (n_list + add > SUB_EDGE_CAP) {
-                    list_ok = false;
-                    break;
+                if (n_list + add <= SUB_EDGE_CAP) {
+                    if (keep) s_edges[wave][n_list + __popcll(m & ((1ull << lane64) - 1ull))] = ed;
+                    n_list += add;
+                } else {  // more survivors than the list holds: drain it, then this round's go through in two halves
+                    drain();
+                    const unsigned long long mlo = m & 0xFFFFFFFFull, mhi = m >> 32;
+                    static_assert(SUB_EDGE_CAP >= 32, "half a round must fit the list");
+                    if (keep && lane64 < 32) s_edges[wave][__popcll(mlo & ((1ull << lane64) - 1ull))] = ed;
+                    n_list = __popcll(mlo);
+                    if (n_list + __popcll(mhi) > SUB_EDGE_CAP) drain();
+                    if (keep && lane64 >= 32) s_edges[wave][n_list + __popcll(mhi & ((1ull << (lane64 - 32)) - 1ull))] = ed;
+                    n_list += __popcll(mhi);
                 }
-                if (keep) s_edges[wave][n_list + __popcll(m & ((1ull << lane64) - 1ull))] = ed;
-                n_list += add;
             }
+            // (the span tables are rewritten by the next round of rings: every lane is past its reads — the wave runs in lockstep
+            // through the uniform loops above, and the barrier at the top of the next round's reads orders the rest)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    bool touched = false;
-    if (list_ok) {
-        for (int e = 0; e < n_list && !touched; ++e) touched = edge_touches(s_edges[wave][e]);
-    } else {
-        for (int q = 0; q < NP && !touched; ++q) {
-            if (!crosses[q]) continue;
-            int r0, r1;
-            dev::part_rings(a, part[q], r0, r1);
-            for (int r = r0; r < r1 && !touched; ++r) {
-                int e0, e1;
-                if (!pip::slab_span_of_raster_row(pv, r, cj, e0, e1)) continue;
-                for (int e = e0; e < e1 && !touched; ++e) touched = edge_touches(pip::slab_edge(pv, e));
-            }
-        }
-    }
+    drain();
     const uint32_t test_label = NP == 2 ? 3u : 2u;
     uint32_t label = test_label;
     if (!touched) {
@@ -541,7 +634,11 @@ __global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, Fi
         const bool ok = dev::cell_of(cx, g.rx0, g.inv_fw * S, g.R * S) == si && dev::cell_of(cy, g.ry0, g.inv_fh * S, g.R * S) == sj;
         if (ok) {
             if (NP == 1) {
+#if GPK_SUBBUILD_ABLATE & 8
+                const int p = cx > cy ? dev::POS_INSIDE : dev::POS_OUTSIDE;
+#else
                 const int p = pip::part_pos_single(pv, a, part[0], cx, cy);
+#endif
                 label = p == dev::POS_INSIDE ? 1u : (p == dev::POS_OUTSIDE ? 0u : 2u);
             } else {
                 const int pa = pip::part_pos_single(pv, a, part[0], cx, cy), pb = pip::part_pos_single(pv, a, part[1], cx, cy);
@@ -685,9 +782,7 @@ __global__ __launch_bounds__(256) void chain_aux_kernel(DevGeo a, PipView pv, Fi
         for (int e = 0; e < n_list; ++e) {
             const double4 ed = s_edges[wave][e];
             if (fmax(ed.x, ed.z) < xl || fmin(ed.x, ed.z) > xh || fmax(ed.y, ed.w) < yl || fmin(ed.y, ed.w) > yh) continue;
-            const int o1 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yl), o2 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yl);
-            const int o3 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yh), o4 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yh);
-            if ((o1 > 0 && o2 > 0 && o3 > 0 && o4 > 0) || (o1 < 0 && o2 < 0 && o3 < 0 && o4 < 0)) continue;
+            if (line_clear_of_rect(ed.x, ed.y, ed.z, ed.w, xl, yl, xh, yh)) continue;
             touched |= 1ull << e;
         }
         // the shortest arc [lo, lo + len) of the cycle 0 .. ne - 1 that covers the touched edges: the complement of the widest
@@ -851,9 +946,7 @@ __global__ __launch_bounds__(256) void half_chain_kernel(DevGeo a, PipView pv, F
             for (int e = e0; e < e1 && ok; ++e) {
                 const double4 ed = pip::slab_edge(pv, e);
                 if (fmax(ed.x, ed.z) < xl || fmin(ed.x, ed.z) > xh || fmax(ed.y, ed.w) < yl || fmin(ed.y, ed.w) > yh) continue;
-                const int o1 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yl), o2 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yl);
-                const int o3 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xh, yh), o4 = dev::orient2d(ed.x, ed.y, ed.z, ed.w, xl, yh);
-                if ((o1 > 0 && o2 > 0 && o3 > 0 && o4 > 0) || (o1 < 0 && o2 < 0 && o3 < 0 && o4 < 0)) continue;
+                if (line_clear_of_rect(ed.x, ed.y, ed.z, ed.w, xl, yl, xh, yh)) continue;
                 const int ei = pip::slab_vertex(slab_vidx[e]) - c0;
                 bool seen = false;
                 for (int q = 0; q < n_touched; ++q) seen = seen || touched[q] == ei;  // (an edge spanning rows is listed in each)
@@ -1084,7 +1177,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
     {
         // (nine per-cell arrays, the mark keys x 3, the sort's scratch, the chain pass: a temporary that misses the arena costs a
         // hipMalloc + a hipFree — 0.2 ms each on this runtime, a third of the whole build of a 1000-polygon right side)
-        size_t est = (size_t)n_rings * 64 + (size_t)n_cells * 48 + (size_t)d.n_coords * 160 + (8u << 20);
+        size_t est = (size_t)n_rings * 64 + (size_t)n_cells * 96 + (size_t)d.n_coords * 168 + (8u << 20);
         if (est > (size_t(256) << 20)) est = size_t(256) << 20;
         (void)workspace_aux(1).begin(est);
     }
@@ -1130,6 +1223,13 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
     int64_t max_scan = n_cells > d.n_coords ? n_cells : d.n_coords;  // longest array scanned with btot (grown below for the slabs)
     if (n_rings > max_scan) max_scan = n_rings;
     GPK_TRY(t.alloc(&btot, (size_t)((max_scan + 255) / 256 + 4)));
+    // the ring of every coordinate (edge_at): ring starts scattered, scanned in place; coord_ring[i] = the INCLUSIVE sum at i
+    int32_t* ring_starts;
+    GPK_TRY(t.alloc(&ring_starts, (size_t)d.n_coords + 2));
+    GPK_HIP(hipMemsetAsync(ring_starts, 0, sizeof(int32_t) * (size_t)(d.n_coords + 2), s));
+    GPK_LAUNCH("gpk_pipidx_ring_start", ring_start_kernel, blocks_for(n_rings), dim3(256), 0, s, d.ring_off, n_rings, d.n_coords, ring_starts);
+    GPK_TRY(exclusive_scan_i32(ring_starts, d.n_coords + 1, ring_starts, nullptr, btot, s));
+    const int32_t* coord_ring = ring_starts + 1;
     FineGrid gs = g;  // the FINEST slab-row grid (an exact power-of-two refinement of the raster row function); a ring's
                       // own rows are a right shift of it (ring_rows_kernel)
     gs.R = g.R * (PIP_SLAB_MUL << PIP_FINE_LOG2);
@@ -1164,7 +1264,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
         ix->owned[slab_off_slot] = slab_off;
         GPK_HIP(hipMemsetAsync(slab_cnt, 0, sizeof(int32_t) * (size_t)(n_slabs + 1), s));
         GPK_HIP(hipMemsetAsync(slab_off, 0, sizeof(int32_t) * (size_t)(n_slabs + 1), s));
-        GPK_LAUNCH("gpk_pipidx_slab_count", slab_register_kernel<false>, blocks_for(d.n_coords), dim3(256), 0, s, d, gs, row0, slab_base,
+        GPK_LAUNCH("gpk_pipidx_slab_count", slab_register_kernel<false>, blocks_for(d.n_coords), dim3(256), 0, s, d, coord_ring, gs, row0, slab_base,
                    slab_cnt, (double4*)nullptr);
         n_edges = 0;
         if (n_slabs > 0) {
@@ -1190,7 +1290,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
         GPK_HIP(cached_malloc((void**)&slab_vidx, sizeof(int32_t) * (size_t)n_edges));
         keep(slab_vidx);
     }
-    GPK_LAUNCH("gpk_pipidx_slab_fill", slab_register_kernel<true>, blocks_for(d.n_coords), dim3(256), 0, s, d, gs, row0, slab_base,
+    GPK_LAUNCH("gpk_pipidx_slab_fill", slab_register_kernel<true>, blocks_for(d.n_coords), dim3(256), 0, s, d, coord_ring, gs, row0, slab_base,
                cursor, edges, slab_vidx);
 
     stamp("slab fill (+ edges malloc)");
@@ -1222,7 +1322,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
     int32_t *mark_cnt, *mark_off;
     GPK_TRY(t.alloc(&mark_cnt, (size_t)d.n_coords + 1));
     GPK_TRY(t.alloc(&mark_off, (size_t)d.n_coords + 1));
-    GPK_LAUNCH("gpk_pipidx_mark_count", mark_kernel<false>, blocks_for(d.n_coords), dim3(256), 0, s, d, g, ring_part, mark_cnt,
+    GPK_LAUNCH("gpk_pipidx_mark_count", mark_kernel<false>, blocks_for(d.n_coords), dim3(256), 0, s, d, coord_ring, g, ring_part, mark_cnt,
                (unsigned long long*)nullptr);
     GPK_TRY(exclusive_scan_i32(mark_cnt, d.n_coords, mark_off, nullptr, btot, s));
     unsigned long long n_marks_raw = 0;  // the scan keeps its grand total in 64 bits
@@ -1236,8 +1336,11 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
     GPK_TRY(t.alloc(&sorted, (size_t)n_marks_raw));
     marks = keys;  // the unsorted keys are dead once the sort has run: the unique marks are compacted into their buffer
     int64_t n_marks = 0;
+    int32_t* mark_start;  // marks of cell c: [mark_start[c], mark_start[c + 1])
+    GPK_TRY(t.alloc(&mark_start, (size_t)n_cells + 2));
+    GPK_HIP(hipMemsetAsync(mark_start, 0, sizeof(int32_t) * (size_t)(n_cells + 2), s));
     if (n_marks_raw > 0) {
-        GPK_LAUNCH("gpk_pipidx_mark_fill", mark_kernel<true>, blocks_for(d.n_coords), dim3(256), 0, s, d, g, ring_part, mark_off, keys);
+        GPK_LAUNCH("gpk_pipidx_mark_fill", mark_kernel<true>, blocks_for(d.n_coords), dim3(256), 0, s, d, coord_ring, g, ring_part, mark_off, keys);
         size_t tmp_bytes = 0;
         GPK_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, keys, sorted, (size_t)n_marks_raw, 0, 64, s));
         char* tmp;
@@ -1252,7 +1355,8 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
                    (int64_t)n_marks_raw, flag);
         GPK_TRY(exclusive_scan_i32(flag, (int64_t)n_marks_raw, pos, nullptr, btot2, s));
         GPK_LAUNCH("gpk_pipidx_unique_compact", unique_compact_kernel, blocks_for((int64_t)n_marks_raw), dim3(256), 0, s, sorted,
-                   (int64_t)n_marks_raw, pos, marks);
+                   (int64_t)n_marks_raw, pos, marks, mark_start);
+        GPK_TRY(exclusive_scan_i32(mark_start, n_cells, mark_start, nullptr, btot, s));
         int32_t nu = 0;
         GPK_HIP(hipMemcpyAsync(&nu, pos + n_marks_raw, sizeof nu, hipMemcpyDeviceToHost, s));
         GPK_HIP(hipStreamSynchronize(s));
@@ -1267,8 +1371,10 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
     int32_t *need, *list_off;
     GPK_TRY(t.alloc(&need, (size_t)n_cells + 1));
     GPK_TRY(t.alloc(&list_off, (size_t)n_cells + 1));
-    GPK_LAUNCH("gpk_pipidx_cell_count", cell_build_kernel<false>, blocks_for(n_cells), dim3(256), 0, s, d, ix->v, pv, g, marks, n_marks,
-               need, (const int32_t*)nullptr, cell, (uint32_t*)nullptr);
+    uint32_t* cell_scratch = nullptr;  // 32 bytes a cell (C5: 0.5 GB of temporaries against a second pass over every candidate's slabs)
+    GPK_TRY(t.alloc(&cell_scratch, (size_t)n_cells * CELL_SCRATCH));
+    GPK_LAUNCH("gpk_pipidx_cell_count", cell_build_kernel<false>, blocks_for(n_cells), dim3(256), 0, s, d, ix->v, pv, g, marks, mark_start,
+               need, (const int32_t*)nullptr, cell, (uint32_t*)nullptr, cell_scratch);
     GPK_TRY(exclusive_scan_i32(need, n_cells, list_off, nullptr, btot, s));
     int32_t list_len = 0;
     GPK_HIP(hipMemcpyAsync(&list_len, list_off + n_cells, sizeof list_len, hipMemcpyDeviceToHost, s));
@@ -1277,8 +1383,8 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
     uint32_t* list = nullptr;
     GPK_HIP(cached_malloc((void**)&list, sizeof(uint32_t) * (size_t)(list_len ? list_len : 1)));
     keep(list);
-    GPK_LAUNCH("gpk_pipidx_cell_fill", cell_build_kernel<true>, blocks_for(n_cells), dim3(256), 0, s, d, ix->v, pv, g, marks, n_marks,
-               need, list_off, cell, list);
+    GPK_LAUNCH("gpk_pipidx_cell_fill", cell_build_kernel<true>, blocks_for(n_cells), dim3(256), 0, s, d, ix->v, pv, g, marks, mark_start,
+               need, list_off, cell, list, cell_scratch);
     GPK_HIP(hipStreamSynchronize(s));
     pv.cell = cell;
     pv.list = list;
