@@ -428,14 +428,11 @@ __global__ void sub_head_kernel(PipView pv, FineGrid g, const int32_t* __restric
 // exactly" when any edge of ANY ring of a part that crosses the cell (taken from the rings' slabs of this raster row)
 // is not strictly on one side of the sub-cell's padded rectangle; otherwise it inherits the exact position of its
 // centre.  NP = 1: SubCell records (one crossing part); NP = 2: SubCell2 records (two parts, see gpk_index.h).
-#ifndef GPK_SUBBUILD_ABLATE
-#define GPK_SUBBUILD_ABLATE 0  // tuning builds only: 1 = box test only, 2 = no centre walk, 4 = no touch loop
-#endif
 constexpr int SUB_EDGE_CAP = 48;  // edges of a cell's slab rows kept in LDS per wave (sub_build_kernel)
 // WORK (NP = 1 only): the records are those of (cell, part) work items — the boundary entries of list cells,
 // work_cell[w] / work_part[w] -> sub[w] — instead of one per flagged cell.
 template <int NP, bool WORK = false>
-__global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, FineGrid g, const int32_t* __restrict__ flag,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void sub_build_kernel(DevGeo a, PipView pv, FineGrid g, const int32_t* __restrict__ flag,
                                                         const int32_t* __restrict__ pos, int64_t n_cells, const uint32_t* __restrict__ cell,
                                                         const uint32_t* __restrict__ list, SubCell* __restrict__ sub,
                                                         SubCell2* __restrict__ sub2, const int32_t* __restrict__ work_cell = nullptr,
@@ -508,21 +505,8 @@ __global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, Fi
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             bool touched = false;
-#if GPK_SUBBUILD_ABLATE & 4
-            touched = n_all == 77u;
-#elif GPK_SUBBUILD_ABLATE & 1
-            for (uint32_t e = 0; e < n_all && !touched; ++e) {
-                const double4 ed = s_edges_all[wave][e];
-                touched = !(fmax(ed.x, ed.z) < xl || fmin(ed.x, ed.z) > xh || fmax(ed.y, ed.w) < yl || fmin(ed.y, ed.w) > yh);
-            }
-#else
             for (uint32_t e = 0; e < n_all && !touched; ++e) touched = edge_touches(s_edges_all[wave][e]);
-#endif
             uint32_t label = 2u;
-#if GPK_SUBBUILD_ABLATE & 2
-            if (!touched) label = (uint32_t)(xl > yl);
-            else
-#endif
             if (!touched) {
                 const double cx = g.rx0 + ((double)si + 0.5) * fw2, cy = g.ry0 + ((double)sj + 0.5) * fh2;
                 const bool ok = dev::cell_of(cx, g.rx0, g.inv_fw * S, g.R * S) == si && dev::cell_of(cy, g.ry0, g.inv_fh * S, g.R * S) == sj;
@@ -551,19 +535,39 @@ __global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, Fi
     __shared__ int s_span_e0[256 / 64][64], s_span_at[256 / 64][64];
     int n_list = 0;  // wave-uniform
     bool touched = false;
-    auto drain = [&]() {
+    auto wave_min = [&](double v) {
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) v = fmin(v, __shfl_xor(v, o, 64));
+        return v;
+    };
+    // boxed (the drains of a list that overflowed): a part with thousands of vertices inside this raster row sends hundreds of
+    // full lists past the wave, each a run of consecutive short edges — the list's own box (one wave reduction) lets every
+    // sub-cell away from that run skip it, where it would have box-tested each of its edges (64 x edges tests per cell otherwise)
+    auto drain = [&](bool boxed = false) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int e = 0; e < n_list && !touched; ++e) touched = edge_touches(s_edges[wave][e]);
+        bool skip = false;
+        if (boxed) {
+            const double inf = __builtin_inf();
+            double4 b = make_double4(inf, inf, inf, inf);  // (min x, min y, -max x, -max y) of lane e's edge
+            bool odd = false;                               // a NaN coordinate: no box, every lane walks the list
+            if (lane64 < n_list) {
+                const double4 ed = s_edges[wave][lane64];
+                b = make_double4(fmin(ed.x, ed.z), fmin(ed.y, ed.w), -fmax(ed.x, ed.z), -fmax(ed.y, ed.w));
+                odd = !(ed.x == ed.x) || !(ed.y == ed.y) || !(ed.z == ed.z) || !(ed.w == ed.w);
+            }
+            if (!__ballot(odd)) {
+                const double bx0 = wave_min(b.x), by0 = wave_min(b.y), bx1 = -wave_min(b.z), by1 = -wave_min(b.w);
+                skip = bx1 < xl || bx0 > xh || by1 < yl || by0 > yh;  // every edge of the list fails the same comparisons
+            }
+        }
+        for (int e = 0; e < n_list && !touched && !skip; ++e) touched = edge_touches(s_edges[wave][e]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         n_list = 0;
     };
-#if GPK_SUBBUILD_ABLATE & 16
-    if (false)
-#endif
     for (int q = 0; q < NP; ++q) {
         if (!crosses[q]) continue;
         int r0, r1;
@@ -601,21 +605,18 @@ __global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, Fi
                     ed = pip::slab_edge(pv, s_span_e0[wave][lo] + (t - s_span_at[wave][lo]));
                     keep = !(fmax(ed.x, ed.z) < cxl || fmin(ed.x, ed.z) > cxh || fmax(ed.y, ed.w) < cyl || fmin(ed.y, ed.w) > cyh);
                 }
-                const unsigned long long m = __ballot(keep);
-                if (!m) continue;
-                const int add = __popcll(m);
-                if (n_list + add <= SUB_EDGE_CAP) {
-                    if (keep) s_edges[wave][n_list + __popcll(m & ((1ull << lane64) - 1ull))] = ed;
-                    n_list += add;
-                } else {  // more survivors than the list holds: drain it, then this round's go through in two halves
-                    drain();
-                    const unsigned long long mlo = m & 0xFFFFFFFFull, mhi = m >> 32;
-                    static_assert(SUB_EDGE_CAP >= 32, "half a round must fit the list");
-                    if (keep && lane64 < 32) s_edges[wave][__popcll(mlo & ((1ull << lane64) - 1ull))] = ed;
-                    n_list = __popcll(mlo);
-                    if (n_list + __popcll(mhi) > SUB_EDGE_CAP) drain();
-                    if (keep && lane64 >= 32) s_edges[wave][n_list + __popcll(mhi & ((1ull << (lane64 - 32)) - 1ull))] = ed;
-                    n_list += __popcll(mhi);
+                unsigned long long pending = __ballot(keep);
+                while (pending) {  // (wave-uniform) survivors go to the list as far as it has room; a full list is drained and refilled
+                    const int rank = __popcll(pending & ((1ull << lane64) - 1ull));
+                    const bool put = keep && rank < SUB_EDGE_CAP - n_list;
+                    if (put) {
+                        s_edges[wave][n_list + rank] = ed;
+                        keep = false;
+                    }
+                    const unsigned long long taken = __ballot(put);
+                    n_list += __popcll(taken);
+                    pending &= ~taken;
+                    if (pending) drain(true);
                 }
             }
             // (the span tables are rewritten by the next round of rings: every lane is past its reads — the wave runs in lockstep
@@ -634,11 +635,7 @@ __global__ __launch_bounds__(256) void sub_build_kernel(DevGeo a, PipView pv, Fi
         const bool ok = dev::cell_of(cx, g.rx0, g.inv_fw * S, g.R * S) == si && dev::cell_of(cy, g.ry0, g.inv_fh * S, g.R * S) == sj;
         if (ok) {
             if (NP == 1) {
-#if GPK_SUBBUILD_ABLATE & 8
-                const int p = cx > cy ? dev::POS_INSIDE : dev::POS_OUTSIDE;
-#else
                 const int p = pip::part_pos_single(pv, a, part[0], cx, cy);
-#endif
                 label = p == dev::POS_INSIDE ? 1u : (p == dev::POS_OUTSIDE ? 0u : 2u);
             } else {
                 const int pa = pip::part_pos_single(pv, a, part[0], cx, cy), pb = pip::part_pos_single(pv, a, part[1], cx, cy);
