@@ -22,7 +22,7 @@ namespace gpk {
 
 enum : int {
     ST_AREA2 = 0,  // twice the signed ring area (shifted by the first coordinate)
-    ST_ACX = 1,    // sum (ex+sx)*cross  (shifted)
+    ST_ACX = 1,    // the ring's centroid x (sum (ex+sx)*cross of the shifted ring / (6 area) + the shift; a zero-area ring: unused)
     ST_ACY = 2,
     ST_LEN = 3,  // sum of segment lengths
     ST_LMX = 4,  // sum of midpoint * length
@@ -169,6 +169,19 @@ __device__ __forceinline__ void seq_store_any(const SeqPartial& a, double* __res
                                               const double2* __restrict__ xy, const FinalOut& f) {
     if ((MASK & M_CENT) && !(MASK & M_DEGEN) && f.degen_flag && c1 > c0 && a.a2 / 2.0 == 0.0) *f.degen_flag = 1;  // (benign race: every writer stores 1)
     if (FIN == FIN_NONE) {
+        if ((MASK & M_CENT) && !(MASK & M_DEGEN)) {
+            // the ring's centroid, not its raw moments: the per-geometry pass then needs no first coordinate of the ring (a scattered
+            // 64-byte line per ring, half of centroid_combine_kernel's time on a column of multipolygons); wc_add_ring's arithmetic
+            SeqPartial b = a;
+            const double area = a.a2 / 2.0;
+            if (c1 > c0 && area != 0.0) {
+                const double2 sh = xy[c0];
+                b.acx = a.acx / (6.0 * area) + sh.x;
+                b.acy = a.acy / (6.0 * area) + sh.y;
+            }
+            seq_store<MASK>(b, stats, n_seq, s);
+            return;
+        }
         seq_store<MASK>(a, stats, n_seq, s);
         return;
     }
@@ -727,17 +740,14 @@ __device__ inline void wc_add_linestring_direct(WC& c, const double2* xy, int c0
         wc_add_raw(c, 0, p.x * k, p.y * k, k);
     }
 }
-__device__ __forceinline__ void wc_add_ring(WC& c, const double* stats, int64_t n_seq, int r,
-                                            const double2* xy, int c0, int n) {
+__device__ __forceinline__ void wc_add_ring(WC& c, const double* stats, int64_t n_seq, int r, const DevGeo& a) {
     const double area = stats[ST_AREA2 * n_seq + r] / 2.0;
-    if (area == 0.0) {
-        wc_add_linestring(c, stats, n_seq, r, xy, c0, n);
+    if (area == 0.0) {  // (rare: only here are the ring's offsets and first coordinate read)
+        const int c0 = a.ring_off[r];
+        wc_add_linestring(c, stats, n_seq, r, a.xy, c0, a.ring_off[r + 1] - c0);
         return;
     }
-    const double2 sh = xy[c0];
-    const double cx = stats[ST_ACX * n_seq + r] / (6.0 * area) + sh.x;
-    const double cy = stats[ST_ACY * n_seq + r] / (6.0 * area) + sh.y;
-    wc_add(c, 2, cx, cy, fabs(area));
+    wc_add(c, 2, stats[ST_ACX * n_seq + r], stats[ST_ACY * n_seq + r], fabs(area));  // (the ring pass stored the ring's centroid: seq_store_any)
 }
 
 __global__ void centroid_combine_kernel(DevGeo a, const double* __restrict__ stats, int64_t n_seq,
@@ -754,17 +764,16 @@ __global__ void centroid_combine_kernel(DevGeo a, const double* __restrict__ sta
                 dev::part_rings(a, p, r0, r1);
                 if (r1 <= r0) continue;
                 WC ext{-1, 0, 0, 0}, in{-1, 0, 0, 0};
-                const int e0 = a.ring_off[r0], en = a.ring_off[r0 + 1] - e0;
-                wc_add_ring(ext, stats, n_seq, r0, a.xy, e0, en);
-                for (int r = r0 + 1; r < r1; ++r)
-                    wc_add_ring(in, stats, n_seq, r, a.xy, a.ring_off[r], a.ring_off[r + 1] - a.ring_off[r]);
+                wc_add_ring(ext, stats, n_seq, r0, a);
+                for (int r = r0 + 1; r < r1; ++r) wc_add_ring(in, stats, n_seq, r, a);
                 if (ext.dim < 0) continue;
                 if (in.dim >= 0 && in.dim == ext.dim) {
                     ext.w -= in.w;
                     ext.ax -= in.ax;
                     ext.ay -= in.ay;
                     if (ext.w == 0.0) {
-                        wc_add_linestring_direct(c, a.xy, e0, en);
+                        const int e0 = a.ring_off[r0];
+                        wc_add_linestring_direct(c, a.xy, e0, a.ring_off[r0 + 1] - e0);
                         continue;
                     }
                 }
