@@ -35,6 +35,17 @@ enum : int {
     ST_SUMY = 11,
     ST_COUNT = 12
 };
+// The four bound statistics of a sequence are ONE 32-byte record (array of structures inside the structure of arrays: rows
+// ST_MINX .. ST_MAXY of the table, shifted by two doubles when n_seq is odd so that the records are 32-byte aligned — the table's
+// base is 256-byte aligned, 6 * n_seq doubles precede them): one store per ring in the ring pass and one load in the per-geometry
+// pass instead of four 8-byte ones n_seq apart (on a ragged column those were four partial-sector writes per ring).  The shift
+// reaches two doubles into the ST_SUMX rows: no pass asks for M_BBOX and M_SUM together (seq_store).
+__device__ __forceinline__ double4* bbox_records(double* stats, int64_t n_seq) {
+    return reinterpret_cast<double4*>(stats + ST_MINX * n_seq + ((n_seq & 1) ? 2 : 0));
+}
+__device__ __forceinline__ const double4* bbox_records(const double* stats, int64_t n_seq) {
+    return reinterpret_cast<const double4*>(stats + ST_MINX * n_seq + ((n_seq & 1) ? 2 : 0));
+}
 constexpr unsigned M_AREA = 1u << 0, M_CENT = 1u << 1, M_LEN = 1u << 2, M_BBOX = 1u << 3, M_SUM = 1u << 4;
 // M_CENT = area-weighted accumulators only; M_LENC = length-weighted ones (a hypot per edge); M_DEGEN restricts a
 // pass to sequences whose ring area came out zero (the only rings whose centroid needs the length partials)
@@ -135,12 +146,8 @@ __device__ __forceinline__ void seq_store(const SeqPartial& a, double* __restric
         stats[ST_LMY * n_seq + s] = a.lmy;
     }
     if (MASK & (M_LEN | M_LENC)) stats[ST_LEN * n_seq + s] = a.len;
-    if (MASK & M_BBOX) {
-        stats[ST_MINX * n_seq + s] = a.mnx;
-        stats[ST_MINY * n_seq + s] = a.mny;
-        stats[ST_MAXX * n_seq + s] = a.mxx;
-        stats[ST_MAXY * n_seq + s] = a.mxy;
-    }
+    static_assert(!((MASK & M_BBOX) && (MASK & M_SUM)), "bbox_records reaches into the ST_SUMX rows");
+    if (MASK & M_BBOX) bbox_records(stats, n_seq)[s] = make_double4(a.mnx, a.mny, a.mxx, a.mxy);
     if (MASK & M_SUM) {
         stats[ST_SUMX * n_seq + s] = a.sx;
         stats[ST_SUMY * n_seq + s] = a.sy;
@@ -650,10 +657,11 @@ __global__ void bounds_combine_kernel(DevGeo a, const double* __restrict__ stats
                 dev::part_rings(a, p, r0, r1);
                 if (r1 <= r0 || a.ring_off[r0 + 1] == a.ring_off[r0]) continue;
                 have = true;
-                mnx = fmin(mnx, stats[ST_MINX * n_seq + r0]);
-                mny = fmin(mny, stats[ST_MINY * n_seq + r0]);
-                mxx = fmax(mxx, stats[ST_MAXX * n_seq + r0]);
-                mxy = fmax(mxy, stats[ST_MAXY * n_seq + r0]);
+                const double4 b = bbox_records(stats, n_seq)[r0];
+                mnx = fmin(mnx, b.x);
+                mny = fmin(mny, b.y);
+                mxx = fmax(mxx, b.z);
+                mxy = fmax(mxy, b.w);
             }
         } else {
             int s0, s1;
@@ -662,10 +670,11 @@ __global__ void bounds_combine_kernel(DevGeo a, const double* __restrict__ stats
             for (int s = s0; s < s1; ++s) {
                 if (so[s + 1] == so[s]) continue;
                 have = true;
-                mnx = fmin(mnx, stats[ST_MINX * n_seq + s]);
-                mny = fmin(mny, stats[ST_MINY * n_seq + s]);
-                mxx = fmax(mxx, stats[ST_MAXX * n_seq + s]);
-                mxy = fmax(mxy, stats[ST_MAXY * n_seq + s]);
+                const double4 b = bbox_records(stats, n_seq)[s];
+                mnx = fmin(mnx, b.x);
+                mny = fmin(mny, b.y);
+                mxx = fmax(mxx, b.z);
+                mxy = fmax(mxy, b.w);
             }
         }
     }
@@ -1201,8 +1210,7 @@ __global__ void stats_to_bbox_kernel(const double* __restrict__ stats, const int
     if (seq_off[s + 1] == seq_off[s])
         out[s] = make_double4(NAN, NAN, NAN, NAN);
     else
-        out[s] = make_double4(stats[ST_MINX * n_seq + s], stats[ST_MINY * n_seq + s], stats[ST_MAXX * n_seq + s],
-                              stats[ST_MAXY * n_seq + s]);
+        out[s] = bbox_records(stats, n_seq)[s];
 }
 
 int32_t ring_bboxes(const gpk_geoarray* a, double4* out_dev, hipStream_t s) {
