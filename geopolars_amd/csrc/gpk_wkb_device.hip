@@ -294,10 +294,31 @@ __device__ __forceinline__ double2 load_xy_unaligned(const uint8_t* p) {
     return v;
 }
 constexpr int WKB_CP_BLOCK = 256, WKB_CP_PER = 8, WKB_CP_TILE = WKB_CP_BLOCK * WKB_CP_PER, WKB_CP_SEQS = 2560;
+// tile_seq[t] = the sequence that holds the first coordinate of tile t (tile_seq[n_tiles] = the last sequence), one LANE per tile:
+// the copy's work-groups used to open with two binary searches over all the offsets — some twenty DEPENDENT loads before a work-group
+// of a few microseconds' work could start (the chain, not the bytes, set the kernel's time on columns of many short sequences)
+__global__ void wkb_tile_seq_kernel(const int32_t* __restrict__ seq_off, int64_t n_seq, int64_t n_tiles, int32_t* __restrict__ tile_seq) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > n_tiles) return;
+    if (t == n_tiles) {
+        tile_seq[t] = (int32_t)(n_seq - 1);
+        return;
+    }
+    const int64_t c = t * WKB_CP_TILE;
+    int64_t lo = 0, hi = n_seq;  // invariant: seq_off[lo] <= c < seq_off[hi]
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)seq_off[mid] <= c)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    tile_seq[t] = (int32_t)lo;
+}
 __global__ __launch_bounds__(WKB_CP_BLOCK) void wkb_copy_kernel(const uint8_t* __restrict__ values, const int32_t* __restrict__ seq_src,
-                                                                const int32_t* __restrict__ seq_off, int64_t n_seq, int64_t n_coords, double2* __restrict__ xy) {
+                                                                const int32_t* __restrict__ seq_off, int64_t n_seq, int64_t n_coords, double2* __restrict__ xy,
+                                                                const int32_t* __restrict__ tile_seq) {
     __shared__ int32_t s_off[WKB_CP_SEQS + 1], s_src[WKB_CP_SEQS];
-    __shared__ int32_t s_q[2];
     const int64_t c_lo = (int64_t)blockIdx.x * WKB_CP_TILE, c_hi = c_lo + WKB_CP_TILE < n_coords ? c_lo + WKB_CP_TILE : n_coords;
     // last sequence that starts at or before coordinate c: upper_bound(seq_off[0 .. n_seq], c) - 1 (empty sequences share an offset
     // with their successor: the LAST of them is the one that holds the coordinate)
@@ -312,9 +333,9 @@ __global__ __launch_bounds__(WKB_CP_BLOCK) void wkb_copy_kernel(const uint8_t* _
         }
         return lo;
     };
-    if (threadIdx.x < 2) s_q[threadIdx.x] = (int32_t)seq_of(threadIdx.x == 0 ? c_lo : c_hi - 1);
-    __syncthreads();
-    const int q0 = s_q[0], q1 = s_q[1], nq = q1 - q0 + 1;
+    // the sequences that meet the tile: from its first coordinate's to the next tile's first coordinate's (the last sequence for the
+    // last tile) — at most one more than meet it, and s_off[nq] = the start of the sequence after them stays beyond every coordinate
+    const int q0 = tile_seq[blockIdx.x], q1 = tile_seq[blockIdx.x + 1], nq = q1 - q0 + 1;
     const bool staged = nq <= WKB_CP_SEQS;  // (more: a run of empty sequences inside the tile — the lanes search the global offsets)
     if (staged) {
         for (int t = threadIdx.x; t <= nq; t += WKB_CP_BLOCK) s_off[t] = seq_off[q0 + t];
@@ -530,7 +551,7 @@ extern "C" int32_t gpk_geoarray_from_wkb(const uint8_t* wkb_values, const int32_
     // coordinate runs of line / polygon columns are moved by wkb_copy_kernel from the positions the fill records
     const bool has_seq = out_type == GPK_GEOM_LINESTRING || has_ring;
     const int64_t n_seq = has_ring ? (int64_t)tot_r : n_rows;
-    int32_t *seq_src = nullptr, *long_list = nullptr;
+    int32_t *seq_src = nullptr, *long_list = nullptr, *tile_seq = nullptr;
     // the copy's form: by output coordinate (balanced whatever the lengths), or — columns whose sequences average at most 16
     // coordinates and hold no long row — 8 lanes per sequence
     // (and no row longer than 64: a power-law column averages 9 coordinates a ring and still wants the balanced form — 0.22 against 0.54 ms)
@@ -540,6 +561,8 @@ extern "C" int32_t gpk_geoarray_from_wkb(const uint8_t* wkb_values, const int32_
         if (short_seqs) {
             W_TRY(dalloc((void**)&long_list, sizeof(int32_t) * (size_t)(n_seq + 2), true));
             W_HIP(hipMemsetAsync(long_list, 0, sizeof(int32_t), s));
+        } else {
+            W_TRY(dalloc((void**)&tile_seq, sizeof(int32_t) * (size_t)(((int64_t)tot_c + WKB_CP_TILE - 1) / WKB_CP_TILE + 2), true));
         }
     }
     auto launch3 = [&]() -> int32_t {
@@ -554,8 +577,10 @@ extern "C" int32_t gpk_geoarray_from_wkb(const uint8_t* wkb_values, const int32_
                     GPK_LAUNCH("gpk_wkb_copy_long", wkb_copy_long_kernel, dim3((unsigned)(cu_count() * 8)), dim3(256), 0, s, values_dev,
                                (const int32_t*)seq_src, seq_off, (const int32_t*)long_list, xy);
                 } else {
-                    GPK_LAUNCH("gpk_wkb_copy", wkb_copy_kernel, dim3((unsigned)(((int64_t)tot_c + WKB_CP_TILE - 1) / WKB_CP_TILE)), dim3(WKB_CP_BLOCK), 0, s, values_dev,
-                               (const int32_t*)seq_src, seq_off, n_seq, (int64_t)tot_c, xy);
+                    const int64_t n_tiles = ((int64_t)tot_c + WKB_CP_TILE - 1) / WKB_CP_TILE;
+                    GPK_LAUNCH("gpk_wkb_tile_seq", wkb_tile_seq_kernel, dim3((unsigned)((n_tiles + 256) / 256)), dim3(256), 0, s, seq_off, n_seq, n_tiles, tile_seq);
+                    GPK_LAUNCH("gpk_wkb_copy", wkb_copy_kernel, dim3((unsigned)n_tiles), dim3(WKB_CP_BLOCK), 0, s, values_dev, (const int32_t*)seq_src, seq_off, n_seq,
+                               (int64_t)tot_c, xy, (const int32_t*)tile_seq);
                 }
             }
         } else if (go) {
