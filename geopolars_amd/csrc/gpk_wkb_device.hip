@@ -177,7 +177,29 @@ __global__ __launch_bounds__(WKB_BLOCK) void wkb_scan_kernel(const uint8_t* __re
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     RowCount rc{0, 0, 0, 0};
     uint32_t bits = 0;
+    bool parsed = false;
     if (i < n_rows && dev::valid_row(validity, i)) {
+        // A plain little-endian one-ring POLYGON or LINESTRING row (no SRID word, no Z / M flags) is settled from ONE 16-byte request:
+        // byte order, type, ring count / length and the ring's length sit in its first 13 bytes.  parse_row reads them with four
+        // dependent loads — four L1 requests a row, and the rate of those, not the bytes, set this kernel's time on columns of small
+        // polygons.  Anything else (and a row whose coordinates would not fit its bytes) goes through parse_row as before.
+        const int32_t o0 = offsets[i], o1 = offsets[i + 1];
+        const int64_t len = (int64_t)o1 - o0;
+        if (len >= 16) {
+            uint32_t w[4];
+            __builtin_memcpy(w, values + o0, 16);
+            const uint32_t type = (w[0] >> 8) | (w[1] << 24), a = (w[1] >> 8) | (w[2] << 24), b = (w[2] >> 8) | (w[3] << 24);
+            if ((w[0] & 0xFFu) == 1u && type == 3u && a == 1u && 13 + 16 * (int64_t)b <= len && b <= 0x7FFFFFFFu / 16u) {
+                rc = RowCount{3, 1, 1, (int32_t)b};
+                parsed = true;
+            } else if ((w[0] & 0xFFu) == 1u && type == 2u && 9 + 16 * (int64_t)a <= len && a <= 0x7FFFFFFFu / 16u) {
+                rc = RowCount{2, 1, 1, (int32_t)a};
+                parsed = true;
+            }
+        }
+        if (parsed) bits = 1u << rc.type;
+    }
+    if (i < n_rows && dev::valid_row(validity, i) && !parsed) {
         WkbCursor r{values + offsets[i], values + offsets[i + 1], true};
         if (!parse_row<false>(r, rc, nullptr, 0, nullptr, 0, nullptr, 0, false)) {
             bits = 0x80000000u;  // malformed / unsupported
@@ -261,8 +283,20 @@ __global__ __launch_bounds__(WKB_BLOCK) void wkb_fill_kernel(const uint8_t* __re
     const int64_t rpos = has_ring ? (int64_t)(block_off[(n_blocks + 1) + blockIdx.x] + dev::block_exclusive_scan<unsigned long long, WKB_BLOCK>((unsigned long long)nr, lds, &tot)) : 0;
     const int64_t ppos = has_part ? (int64_t)(block_off[2 * (n_blocks + 1) + blockIdx.x] + dev::block_exclusive_scan<unsigned long long, WKB_BLOCK>((unsigned long long)np, lds, &tot)) : 0;
     if (i >= n_rows) return;
-    if (dev::valid_row(validity, i)) {
-        WkbCursor r{values + offsets[i], values + offsets[i + 1], true};
+    const int32_t o0 = offsets[i], o1 = offsets[i + 1];
+    const int64_t len = (int64_t)o1 - o0;
+    // One-ring polygons and linestrings whose row is exactly header + coordinates need no second look at their bytes: the scan pass
+    // parsed the row inside [o0, o1), so a length of 13 (9) + 16 n leaves no room for an SRID word or anything else — the ring's
+    // coordinates start at o0 + 13 (o0 + 9).  (Columns of building footprints: the fill pass read a cache line per row for this.)
+    if (dev::valid_row(validity, i) && mine.type == 3 && mine.rings == 1 && has_ring && len == 13 + 16 * (int64_t)nc) {
+        ring_off[rpos + 1] = (int32_t)(cpos + nc);
+        if (has_part) part_off[ppos + 1] = (int32_t)(rpos + 1);
+        if (seq_src) seq_src[rpos] = o0 + 13;
+    } else if (dev::valid_row(validity, i) && mine.type == 2 && !out_point && len == 9 + 16 * (int64_t)nc) {
+        if (has_ring) ring_off[rpos + 1] = (int32_t)(cpos + nc);
+        if (seq_src) seq_src[has_ring ? rpos : i] = o0 + 9;
+    } else if (dev::valid_row(validity, i)) {
+        WkbCursor r{values + o0, values + o1, true};
         RowCount rc;
         // sequences are numbered like the rings (ring types) or like the rows (a LINESTRING column: one per row)
         (void)parse_row<true>(r, rc, xy, cpos, has_ring ? ring_off : nullptr, rpos, has_part ? part_off : nullptr, ppos, out_point, values, seq_src,
