@@ -340,3 +340,41 @@ def test_index_tables_are_recycled_and_released(gpk, oracle):
     pa, ca = join_pairs(ps, qs, "intersects", r_index=a)
     pb, cb = join_pairs(ps, qs, "intersects", r_index=b)
     assert np.array_equal(pa, ep) and np.array_equal(pb, ep) and np.array_equal(ca, ec) and np.array_equal(cb, ec)
+
+
+@pytest.mark.parametrize("with_hole", [False, True])
+def test_parts_with_thousands_of_vertices_inside_one_raster_cell(gpk, oracle, with_hole):
+    """The index build's level-2 records for a part whose whole ring — thousands of edges — lies inside one or two raster cells (the
+    tail of a power-law column): its cells' edge lists overflow many times over (drained against their own box and refilled,
+    csrc/gpk_pipindex.hip: sub_build_kernel), its slab rows are refined, and with a hole its rings' spans are laid end to end.  Points
+    are thrown densely at those parts and over the whole column; every pair against the oracle."""
+    rng = np.random.default_rng(77)
+    n_small = 3000
+    small = synth.star_polygons(n_small, 12, seed=5)
+    rings, parts = [], []
+    centres = rng.uniform(20.0, 80.0, (6, 2))
+    for k, (cx, cy) in enumerate(centres):
+        nv = (900, 2500, 6000, 15000, 333, 40000)[k]
+        ang = np.linspace(0.0, 2.0 * np.pi, nv, endpoint=False)
+        rad = 0.11 * (0.8 + 0.2 * np.sin(7.0 * ang + k))  # about a raster cell across for a column of this size
+        ext = np.stack([cx + rad * np.cos(ang), cy + rad * np.sin(ang)], axis=1)
+        ext = np.concatenate([ext, ext[:1]])
+        part = [ext]
+        if with_hole:
+            hole = np.stack([cx + 0.4 * rad * np.cos(-ang), cy + 0.4 * rad * np.sin(-ang)], axis=1)
+            part.append(np.concatenate([hole, hole[:1]]))
+        parts.append(part)
+    xy = np.concatenate([small.xy] + [r for p in parts for r in p])
+    ring_lens = list(np.diff(small.ring_offsets)) + [len(r) for p in parts for r in p]
+    ring_off = np.concatenate([[0], np.cumsum(ring_lens)]).astype(np.int32)
+    geom_rings = list(np.diff(small.geom_offsets)) + [len(p) for p in parts]
+    geom_off = np.concatenate([[0], np.cumsum(geom_rings)]).astype(np.int32)
+    right = GeoArrowArray(_abi.GEOM_POLYGON, xy, geom_offsets=geom_off, ring_offsets=ring_off)
+    near = np.concatenate([c + rng.uniform(-0.2, 0.2, (20_000, 2)) for c in centres])
+    on_vertices = np.concatenate([p[0][:: max(1, len(p[0]) // 500)] for p in parts])  # boundary points: not contained
+    left = GeoArrowArray.from_points(np.concatenate([synth.uniform_points(200_000, seed=3).xy, near, on_vertices]))
+    ep, ec, _ = oracle.spatial_join(left, right, "intersects", mode=0)
+    rs = GeoSeries(right)
+    gp, gc = join_pairs(GeoSeries(left), rs, "intersects", r_index=SpatialIndex(rs))
+    assert np.array_equal(gc, ec) and np.array_equal(gp, ep)
+    assert ec[200_000 : 200_000 + len(near)].sum() > 10_000  # the dense points do land inside the many-vertex parts

@@ -152,3 +152,94 @@ def test_geometry_valued_results_leave_as_wkb(gpk, oracle, name):
     assert back.geom_type == _abi.GEOM_POINT and len(back) == len(s)
     ok = ~np.isnan(exp_xy[:, 0])
     assert np.allclose(back.xy[ok], exp_xy[ok], rtol=1e-9, atol=0)
+
+
+# ---- the scan pass's one-request path and the fill pass's length-only path (round 4) and the rows that must NOT take them ----------
+def _poly_row(rings, srid=None, trailing=b""):
+    t = 3 | (0x20000000 if srid is not None else 0)
+    b = struct.pack("<BI", 1, t) + (struct.pack("<I", srid) if srid is not None else b"") + struct.pack("<I", len(rings))
+    for r in rings:
+        b += struct.pack("<I", len(r)) + b"".join(struct.pack("<dd", x, y) for x, y in r)
+    return b + trailing
+
+
+def _line_row(coords, srid=None, trailing=b""):
+    t = 2 | (0x20000000 if srid is not None else 0)
+    b = struct.pack("<BI", 1, t) + (struct.pack("<I", srid) if srid is not None else b"") + struct.pack("<I", len(coords))
+    return b + b"".join(struct.pack("<dd", x, y) for x, y in coords) + trailing
+
+
+def _column(rows):
+    offsets = np.zeros(len(rows) + 1, np.int32)
+    offsets[1:] = np.cumsum([len(r) for r in rows])
+    return np.frombuffer(b"".join(rows), np.uint8), offsets
+
+
+def test_plain_rows_next_to_rows_with_an_srid_word_trailing_bytes_and_empty_rings(gpk):
+    """Every row shape around the plain little-endian one-ring row: the decoded column is written out by hand here (neither decoder
+    is the reference), and the host decoder must agree too."""
+    rng = np.random.default_rng(5)
+    ring = lambda n: [tuple(v) for v in rng.uniform(-50, 50, (n, 2))]
+    shapes, rows = [], []
+    for k in range(400):
+        kind = k % 8
+        if kind == 0:
+            r = [ring(4 + k % 9)]
+            rows.append(_poly_row(r))  # plain: one request in the scan pass, length only in the fill pass
+        elif kind == 1:
+            r = [ring(5)]
+            rows.append(_poly_row(r, srid=4326))  # 17 header bytes
+        elif kind == 2:
+            r = [ring(3)]
+            rows.append(_poly_row(r, trailing=b"\x07" * (1 + k % 5)))  # bytes after the geometry: parsed inside its row, not by length
+        elif kind == 3:
+            r = [[]]
+            rows.append(_poly_row(r))  # one empty ring: 13 bytes, below the 16-byte request
+        elif kind == 4:
+            r = [ring(6), ring(4)]
+            rows.append(_poly_row(r))  # a hole
+        elif kind == 5:
+            r = []
+            rows.append(_poly_row(r))  # POLYGON EMPTY
+        elif kind == 6:
+            r = [ring(1)]
+            rows.append(_poly_row(r))  # a one-coordinate ring: 29 bytes
+        else:
+            r = [ring(64)]
+            rows.append(_poly_row(r))
+        shapes.append(r)
+    values, offsets = _column(rows)
+    xy = np.array([c for r in shapes for ringc in r for c in ringc], np.float64).reshape(-1, 2)
+    ring_off = np.concatenate([[0], np.cumsum([len(ringc) for r in shapes for ringc in r])]).astype(np.int32)
+    geom_off = np.concatenate([[0], np.cumsum([len(r) for r in shapes])]).astype(np.int32)
+    want = GeoArrowArray(_abi.GEOM_POLYGON, xy, geom_offsets=geom_off, ring_offsets=ring_off)
+    same(DeviceGeoArray.from_wkb(values, offsets).download(), want)
+    same(GeoArrowArray.from_wkb(values, offsets), want)
+    # the encoder's output of the decoded column decodes to it again (plain rows only now)
+    v2, o2 = DeviceGeoArray.from_wkb(values, offsets).to_wkb()
+    same(DeviceGeoArray.from_wkb(v2, o2).download(), want)
+
+    lines, lrows = [], []
+    for k in range(300):
+        c = ring(k % 7)  # 0 .. 6 coordinates (0: nine bytes)
+        lines.append(c)
+        lrows.append(_line_row(c, srid=3857 if k % 3 == 1 else None, trailing=b"\x01\x02" if k % 3 == 2 else b""))
+    values, offsets = _column(lrows)
+    want = GeoArrowArray(_abi.GEOM_LINESTRING, np.array([p for c in lines for p in c], np.float64).reshape(-1, 2),
+                         geom_offsets=np.concatenate([[0], np.cumsum([len(c) for c in lines])]).astype(np.int32))
+    same(DeviceGeoArray.from_wkb(values, offsets).download(), want)
+    same(GeoArrowArray.from_wkb(values, offsets), want)
+
+
+def test_a_ring_longer_than_its_row_is_reported(gpk):
+    good = _poly_row([[(0.0, 0.0), (1.0, 0.0), (1.0, 1.0), (0.0, 0.0)]])
+    bad = bytearray(good)
+    bad[9:13] = struct.pack("<I", 5)  # claims five coordinates, the row holds four
+    values, offsets = _column([good, bytes(bad), good])
+    with pytest.raises(_abi.MismatchedGeometry):
+        DeviceGeoArray.from_wkb(values, offsets)
+    huge = bytearray(good)
+    huge[9:13] = struct.pack("<I", 0xFFFFFFF0)  # 16 n overflows 32 bits
+    values, offsets = _column([bytes(huge)])
+    with pytest.raises(_abi.MismatchedGeometry):
+        DeviceGeoArray.from_wkb(values, offsets)
