@@ -107,11 +107,10 @@ __global__ void ring_rows_kernel(const double4* __restrict__ ring_bbox, int64_t 
     int sh = 0;
     while (sh < max_shift && n_edges > (int64_t)SLAB_TARGET * (base_rows << sh)) ++sh;
     const int j0 = f0 >> (PIP_FINE_LOG2 - sh), j1 = f1 >> (PIP_FINE_LOG2 - sh);
-    {  // refined rings, counted per wave (a column of big rings — C5: a million of them — put one atomic per ring on this one word);
-       // the join picks its lean kernel when there are none
-        const unsigned long long m = __ballot(sh > 0);
-        if (m && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(n_refined, (int)__popcll(m));
-    }
+    // "some ring has refined rows" (the join picks its lean kernel when there is none): a plain store of 1 by one lane of every wave
+    // that holds such a ring — a count by atomics, even one per wave, was 90k atomics on ONE word for the power-law column, 1.9 ms of
+    // a kernel that otherwise takes 0.1
+    if (sh > 0 && (int)(threadIdx.x & 63) == __ffsll((long long)__ballot(sh > 0)) - 1) *n_refined = 1;
     row0[r] = j0 | (sh << 24);
     nrows[r] = j1 - j0 + 1;
 }
@@ -247,23 +246,42 @@ __device__ __forceinline__ void for_each_touched_cell(const FineGrid& g, double2
 template <bool FILL>
 __global__ void mark_kernel(DevGeo a, const int32_t* __restrict__ coord_ring, FineGrid g, const int32_t* __restrict__ ring_part,
                             int32_t* __restrict__ cnt_or_off, unsigned long long* __restrict__ keys) {
-    // count pass: cnt[i] = cells touched by the edge that starts at coordinate i; fill pass: the edge writes its keys
-    // at off[i].. (exclusive scan of the counts) — no atomics, deterministic layout
+    // count pass: cnt[i] = keys of the edge that starts at coordinate i; fill pass: the edge writes its keys at off[i].. (exclusive
+    // scan of the counts) — no atomics, deterministic layout.  An edge that touches ONE cell and whose predecessor in the wave (the
+    // previous edge of the same ring, nearly always) touched that one cell of the same part writes nothing: runs of short edges
+    // inside a cell were most of the raw marks (C5: a part of thousands of vertices marks its two or three cells thousands of
+    // times), and every one of them went through the sort and the unique pass.  Both passes see the same lanes, so they agree.
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n_coords) return;
-    int r;
-    double2 s, e;
-    if (!edge_at(a, coord_ring, (int)i, r, s, e)) {
-        if (!FILL) cnt_or_off[i] = 0;
-        return;
+    const int lane = (int)(threadIdx.x & 63);
+    int r = 0;
+    double2 s = make_double2(0, 0), e = s;
+    const bool live = i < a.n_coords && edge_at(a, coord_ring, (int)i, r, s, e);
+    const unsigned long long none = ~0ull;
+    unsigned long long first = none;
+    const int64_t o0 = FILL && i < a.n_coords ? (int64_t)cnt_or_off[i] : 0;
+    int64_t n = 0;
+    if (live) {
+        const unsigned long long part = (unsigned long long)ring_part[r];
+        for_each_touched_cell(g, s, e, [&](int ci, int cj) {
+            const unsigned long long key = ((unsigned long long)(cj * g.R + ci) << 32) | part;
+            if (n == 0) {
+                first = key;  // held back: written below unless it repeats the previous lane's
+            } else if (FILL) {
+                if (n == 1) keys[o0] = first;
+                keys[o0 + n] = key;
+            }
+            ++n;
+        });
     }
-    const unsigned long long part = (unsigned long long)ring_part[r];
-    int64_t n = FILL ? (int64_t)cnt_or_off[i] : 0;
-    for_each_touched_cell(g, s, e, [&](int ci, int cj) {
-        if (FILL) keys[n] = ((unsigned long long)(cj * g.R + ci) << 32) | part;
-        ++n;
-    });
-    if (!FILL) cnt_or_off[i] = (int32_t)(n < 0x7FFFFFFF ? n : 0x7FFFFFFF);
+    const unsigned long long single = n == 1 ? first : none;
+    const unsigned long long prev = __shfl_up(single, 1, 64);
+    const bool repeat = lane > 0 && single != none && single == prev;
+    if (i >= a.n_coords) return;
+    if (!FILL) {
+        cnt_or_off[i] = repeat ? 0 : (int32_t)(n < 0x7FFFFFFF ? n : 0x7FFFFFFF);
+    } else if (n == 1 && !repeat) {
+        keys[o0] = first;
+    }
 }
 
 __global__ void unique_flags_kernel(const unsigned long long* __restrict__ sorted, int64_t n, int32_t* __restrict__ flag) {
@@ -291,7 +309,8 @@ template <bool FILL>
 __global__ void cell_build_kernel(DevGeo a, IndexView ix, PipView pv, FineGrid g,
                                   const unsigned long long* __restrict__ marks, const int32_t* __restrict__ mark_start,
                                   int32_t* __restrict__ need, const int32_t* __restrict__ list_off,
-                                  uint32_t* __restrict__ cell, uint32_t* __restrict__ list, uint32_t* __restrict__ scratch) {
+                                  uint32_t* __restrict__ cell, uint32_t* __restrict__ list, uint32_t* __restrict__ scratch,
+                                  const double4* __restrict__ ring_bbox) {
     // scratch (n_cells x CELL_SCRATCH words, entry k of cell c at [k * n_cells + c]; may be null): the count pass leaves the first
     // entries of every cell there and the fill pass copies the lists that fit instead of walking the candidates' slabs a second time
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -352,6 +371,15 @@ __global__ void cell_build_kernel(DevGeo a, IndexView ix, PipView pv, FineGrid g
                 emit((uint32_t)p, 1u);
                 ++m;
                 continue;
+            }
+            if (p1 - p0 > 1) {
+                // a member of a multipolygon: the centre passed the GEOMETRY's box, which spans all members — outside this member's
+                // exterior box it is outside the member, and the walk of its slab (PartInfo, row offsets, a dozen edges) is skipped
+                int r0, r1;
+                dev::part_rings(a, p, r0, r1);
+                if (r1 <= r0) continue;
+                const double4 rb = ring_bbox[r0];
+                if (!(cx >= rb.x && cx <= rb.z && cy >= rb.y && cy <= rb.w)) continue;
             }
             const int pos = pip::part_pos_single(pv, a, p, cx, cy);
             if (pos == dev::POS_OUTSIDE) continue;
@@ -1339,10 +1367,14 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
     if (n_marks_raw > 0) {
         GPK_LAUNCH("gpk_pipidx_mark_fill", mark_kernel<true>, blocks_for(d.n_coords), dim3(256), 0, s, d, coord_ring, g, ring_part, mark_off, keys);
         size_t tmp_bytes = 0;
-        GPK_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, keys, sorted, (size_t)n_marks_raw, 0, 64, s));
+        // (cell << 32 | part: the cell number has cell_bits significant bits — one radix pass fewer than over all 64)
+        unsigned cell_bits = 1;
+        while (cell_bits < 32 && (1ll << cell_bits) < n_cells) ++cell_bits;
+        const unsigned sort_end = 32 + cell_bits;
+        GPK_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, keys, sorted, (size_t)n_marks_raw, 0, sort_end, s));
         char* tmp;
         GPK_TRY(t.alloc(&tmp, tmp_bytes));
-        GPK_HIP(rocprim::radix_sort_keys(tmp, tmp_bytes, keys, sorted, (size_t)n_marks_raw, 0, 64, s));
+        GPK_HIP(rocprim::radix_sort_keys(tmp, tmp_bytes, keys, sorted, (size_t)n_marks_raw, 0, sort_end, s));
         int32_t *flag, *pos;
         GPK_TRY(t.alloc(&flag, (size_t)n_marks_raw + 1));
         GPK_TRY(t.alloc(&pos, (size_t)n_marks_raw + 1));
@@ -1371,7 +1403,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
     uint32_t* cell_scratch = nullptr;  // 32 bytes a cell (C5: 0.5 GB of temporaries against a second pass over every candidate's slabs)
     GPK_TRY(t.alloc(&cell_scratch, (size_t)n_cells * CELL_SCRATCH));
     GPK_LAUNCH("gpk_pipidx_cell_count", cell_build_kernel<false>, blocks_for(n_cells), dim3(256), 0, s, d, ix->v, pv, g, marks, mark_start,
-               need, (const int32_t*)nullptr, cell, (uint32_t*)nullptr, cell_scratch);
+               need, (const int32_t*)nullptr, cell, (uint32_t*)nullptr, cell_scratch, (const double4*)ring_bbox);
     GPK_TRY(exclusive_scan_i32(need, n_cells, list_off, nullptr, btot, s));
     int32_t list_len = 0;
     GPK_HIP(hipMemcpyAsync(&list_len, list_off + n_cells, sizeof list_len, hipMemcpyDeviceToHost, s));
@@ -1381,7 +1413,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
     GPK_HIP(cached_malloc((void**)&list, sizeof(uint32_t) * (size_t)(list_len ? list_len : 1)));
     keep(list);
     GPK_LAUNCH("gpk_pipidx_cell_fill", cell_build_kernel<true>, blocks_for(n_cells), dim3(256), 0, s, d, ix->v, pv, g, marks, mark_start,
-               need, list_off, cell, list, cell_scratch);
+               need, list_off, cell, list, cell_scratch, (const double4*)ring_bbox);
     GPK_HIP(hipStreamSynchronize(s));
     pv.cell = cell;
     pv.list = list;
@@ -1499,7 +1531,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
     // (a few list cells are tolerated — polygons whose boxes touch share a cell here and there; the lean kernel sends
     // their points through the generic walk: at most 1 list word per 8 one-part records)
     ix->pip_lean = (int64_t)list_len * 8 <= (int64_t)n_sub && n_refined == 0 && boundary_cells_have_records ? 1 : 0;
-    if (getenv("GPK_DEBUG_INDEX")) fprintf(stderr, "[gpk] lean join kernel eligible: %d (list %d, refined rings %d, one-part records %d)\n", ix->pip_lean, list_len, n_refined, n_sub);
+    if (getenv("GPK_DEBUG_INDEX")) fprintf(stderr, "[gpk] lean join kernel eligible: %d (list %d, refined rings: %s, one-part records %d)\n", ix->pip_lean, list_len, n_refined ? "some" : "none", n_sub);
     // local chains for the `test` sub-cells of a lean index (gpk_index.h: ChainAux): the join then decides them in the owning lane
     if (GPK_HALF_CHAINS && ix->pip_lean && slab_vidx && n_sub > 0 && swork_cell && !getenv("GPK_NO_CHAINS") &&
         d.n_coords + d.n_rings * CHAIN_MAX < ((int64_t)1 << (32 - HCHAIN_START_SHIFT))) {
