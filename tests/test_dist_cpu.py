@@ -138,3 +138,27 @@ def test_row_sharded_polygon_join_equals_unsharded(oracle, pred):
         counts.append(c)
     assert np.array_equal(np.concatenate(parts), full_pairs)
     assert np.array_equal(np.concatenate(counts), full_counts)
+
+
+@pytest.mark.parametrize("k", [2, 4, 8])
+def test_right_partitioned_join_equals_unsharded(oracle, k):
+    """dist.join_partition_right's decomposition (the one-shot layout: every rank indexes ITS shard of the right side and joins ALL
+    left rows): the ranks' pair lists, right ids offset by the shard's first row, are disjoint and their union — re-ordered by
+    (left, right) — is the unsharded join; per-row counts add up.  (The oracle is the join engine here; the GPU form of the same
+    statement is tests/test_gpu_dist.py.)"""
+    right = synth.powerlaw_multipolygons(600, seed=8)
+    pts = synth.uniform_points(30_000, seed=9)
+    full_pairs, full_counts, _ = oracle.spatial_join(pts, right, "within", mode=1)
+    assert len(full_pairs) > 100
+    parts, counts = [], np.zeros(len(pts), np.int64)
+    for r in range(k):
+        lo, hi = shard_rows(len(right), k, r)
+        p, c, _ = oracle.spatial_join(pts, slice_rows(right, lo, hi), "within", mode=1)
+        p = p.copy()
+        p[:, 1] += lo
+        parts.append(p)
+        counts += c
+    merged = np.concatenate(parts)
+    merged = merged[np.lexsort((merged[:, 1], merged[:, 0]))]
+    assert np.array_equal(merged, full_pairs)
+    assert np.array_equal(counts, full_counts.astype(np.int64))
