@@ -197,30 +197,37 @@ def all_gatherv_geoarray(local: GeoArrowArray, device: Optional[torch.device] = 
     return all_gatherv_buffers(GeoBuffers.from_host(local, device), group).to_host()
 
 
-def broadcast_geoarray(a: Optional[GeoArrowArray], src: int = 0, device: Optional[torch.device] = None, group=None) -> GeoArrowArray:
-    """Replicate a small right side (C2's 1k polygons) from `src` to every rank: header, then each
-    buffer (validity included) with one broadcast."""
-    device = device or torch.device("cpu")
+def broadcast_buffers(local: Optional[GeoBuffers], src: int = 0, device: Optional[torch.device] = None, group=None) -> GeoBuffers:
+    """Replicate a small right side (C2's 1k polygons) from `src` to every rank, device to device: a header, then each buffer with
+    one broadcast.  `local` is read on `src` only (its tensors already live on `device`); the result stays on `device` — what
+    `to_device_geoarray()` borrows (no host round trip: round 3's replicate went through numpy on every rank)."""
+    device = device or (local.xy.device if local is not None else torch.device("cpu"))
     rank = dist.get_rank(group)
     hdr = torch.zeros(8, dtype=torch.int64, device=device)
     if rank == src:
+        lv = [getattr(local, k) for k in _LEVELS]
         hdr[:7] = torch.tensor(
-            [a.geom_type, a.n_geoms, a.n_coords, a.n_parts if a.part_offsets is not None else -1, a.n_rings if a.ring_offsets is not None else -1, 0 if a.geom_offsets is None else 1, 0 if a.validity is None else 1]
+            [local.geom_type, local.n_geoms, int(local.xy.shape[0])] + [-1 if t is None else int(t.shape[0]) for t in lv] + [0 if local.valid is None else 1]
         )
     dist.broadcast(hdr, src, group=group)
-    gt, n_geoms, n_coords, n_parts, n_rings, has_go, has_valid = (int(v) for v in hdr[:7].tolist())
+    gt, n_geoms, n_coords, n_go, n_po, n_ro, has_valid = (int(v) for v in hdr[:7].tolist())
 
-    def bc(arr, n, dtype):
-        t = torch.from_numpy(np.ascontiguousarray(arr)).to(device) if rank == src else torch.empty(n, dtype=dtype, device=device)
+    def bc(t, shape, dtype):
+        t = t.contiguous() if rank == src else torch.empty(shape, dtype=dtype, device=device)
         dist.broadcast(t, src, group=group)
-        return t.cpu().numpy()
+        return t
 
-    xy = bc(a.xy.reshape(-1) if rank == src else None, 2 * n_coords, torch.float64).reshape(-1, 2)
-    go = bc(a.geom_offsets if rank == src else None, n_geoms + 1, torch.int32) if has_go else None
-    po = bc(a.part_offsets if rank == src else None, n_parts + 1, torch.int32) if n_parts >= 0 else None
-    ro = bc(a.ring_offsets if rank == src else None, n_rings + 1, torch.int32) if n_rings >= 0 else None
-    validity = bc(a.validity if rank == src else None, (n_geoms + 7) // 8, torch.uint8) if has_valid else None
-    return GeoArrowArray(gt, xy, geom_offsets=go, part_offsets=po, ring_offsets=ro, validity=validity, n_geoms=n_geoms)
+    xy = bc(local.xy if rank == src else None, (n_coords, 2), torch.float64)
+    levels = [bc(getattr(local, k) if rank == src else None, (n,), torch.int32) if n >= 0 else None for k, n in zip(_LEVELS, (n_go, n_po, n_ro))]
+    valid = bc(local.valid if rank == src else None, (n_geoms,), torch.uint8) if has_valid else None
+    return GeoBuffers(gt, xy, levels[0], levels[1], levels[2], valid)
+
+
+def broadcast_geoarray(a: Optional[GeoArrowArray], src: int = 0, device: Optional[torch.device] = None, group=None) -> GeoArrowArray:
+    """The host-array form of broadcast_buffers (a host column in, a host column out on every rank)."""
+    device = device or torch.device("cpu")
+    local = GeoBuffers.from_host(a, device) if dist.get_rank(group) == src else None
+    return broadcast_buffers(local, src, device, group).to_host()
 
 
 # ---- the same exchange behind the C ABI (gpk_comm_*, gpk_allgatherv_*: RCCL opened by the library itself) ---------------------
