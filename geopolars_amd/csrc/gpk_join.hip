@@ -1415,8 +1415,14 @@ struct LdsHits {
     const uint32_t* rowbase;    // record rank of the first record of every raster row
     uint32_t* over;             // set when the wave cannot keep its hits here (capacity, a row in several geometries): it decides its tiles again
     uint32_t cap;
+    // POOL (pip_tile_pool_kernel): the work-group's hit pool — a tile's hits take `ids[start ...]` (start drawn from *pool_top once the tile
+    // knows how many it has; capacity `cap`), the tile's record = its P masks (`masks`), *tile_start (~0: the tile is decided again at
+    // emission — pool full, or a row in several geometries) and *tile_tot (pairs the tile contributes)
+    uint32_t* pool_top;
+    uint32_t* tile_start;
+    uint32_t* tile_tot;
 };
-template <int P, bool ROUTE, bool FULL, bool FUSED = false, bool LH = false, bool IMG16 = LH>
+template <int P, bool ROUTE, bool FULL, bool FUSED = false, bool LH = false, bool IMG16 = LH, bool POOL = false>
 __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mask, const uint32_t* s_rec0, ChainItem* s_items, int64_t tile, int lane,
                                            uint2* out, uint32_t out_cap, uint32_t* run_io, PointRegs<P>& pr, int64_t next_tile, const LdsHits lh = LdsHits{}) {
     constexpr int S = PIP_SUB, CHAIN_TILE = 64 * P, ITEMS = chain_items<P, IMG16>();  // (IMG16: the kernel that keeps its hits in LDS, either pass)
@@ -1668,7 +1674,11 @@ __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mas
         if (edges_walked) atomicAdd(&h.stats[1], edges_walked);
     }
     if constexpr (FUSED) {
+#ifdef GPK_TILE_TRACE
+        unsigned long long* const stats = nullptr;  // (the trace build stamps the wall clock into that buffer: no counting)
+#else
         unsigned long long* const stats = HOT_ARG(stats);
+#endif
         if (stats && n_items) {
             if (lane == 0) atomicAdd(&stats[0], (unsigned long long)n_items);
             if (edges_walked) atomicAdd(&stats[1], edges_walked);
@@ -1676,6 +1686,78 @@ __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mas
         const uint32_t run = *run_io;
         const uint32_t* const part_geom = HOT_ARG(part_geom);
         const uint8_t* const polys_validity = HOT_ARG(polys_validity);
+        if constexpr (POOL) {
+            // the rare rows FIRST: the generic walk's verdict turns a row with at most one hit into an ordinary row (its lane takes the
+            // geometry), so the ranking below sees every hit of the tile; a row in several geometries cannot be told by a bit per row —
+            // the tile is decided again at emission, storing at its final offsets
+            uint32_t geom_known = 0u, multi_hits = 0u;  // bit k: res[k] is a geometry id already; hits of the multi-geometry rows
+            if (n_rare) {  // (wave-uniform)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (uint32_t i = 0; i < n_rare; ++i) {
+                    const uint32_t li = s_rare[i], rk = li >> 6, rj = li & 63u;
+                    const double2 q = tile_xy[li];
+                    const unsigned long long cf = chain_generic_row_first_call(HOT_ARG(cold), q.x, q.y, lane);
+                    const uint32_t cnt = (uint32_t)cf, first = (uint32_t)(cf >> 32);
+                    if (cnt <= 1u) {
+                        static_for<P>([&](auto K) {
+                            constexpr int k = decltype(K)::value;
+                            if ((uint32_t)k == rk && (uint32_t)lane == rj) {
+                                res[k] = cnt ? first : CODE_NONE;
+                                dmask &= ~(1u << k);
+                                geom_known |= 1u << k;
+                            }
+                        });
+                    } else {
+                        multi_hits += cnt;
+                        if (lane == 0 && tile_counts) tile_counts[li] = cnt;
+                    }
+                }
+                if (stats && lane == 0) atomicAdd(&stats[2], (unsigned long long)n_rare);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next tile overwrites the rare list)
+                __builtin_amdgcn_wave_barrier();
+            }
+            // part -> geometry, count, the row's mask into the tile's record
+            uint32_t hitbits = 0u, hits = 0u;  // (hits: wave-uniform)
+            static_for<P>([&](auto K) {
+                constexpr int k = decltype(K)::value;
+                const uint32_t li = (uint32_t)(k * 64 + lane);
+                uint32_t r = res[k];
+                if (r != CODE_NONE && !((geom_known >> k) & 1u)) {
+                    const uint32_t geom = part_geom ? part_geom[r] : r;
+                    r = dev::valid_row(polys_validity, geom) ? geom : CODE_NONE;
+                }
+                res[k] = r;
+                const bool mine = (FULL || li < rem) && !((dmask >> k) & 1u);
+                const bool hit = mine && r != CODE_NONE;
+                const unsigned long long m = __ballot(hit);
+                if (mine && tile_counts) dev::store_stream(tile_counts + li, hit ? 1u : 0u);
+                if (hit) hitbits |= 1u << k;
+                if (lane == 0) lh.masks[k] = m;
+                hits += (uint32_t)__popcll(m);
+            });
+            // the tile's place in the pool, then the ids at their ranks
+            // (all 64 lanes add `hits`: *pool_top runs in units of 64 — see the tile draw in pip_tile_pool_kernel)
+            uint32_t start = __hip_atomic_fetch_add(lh.pool_top, hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            start = __builtin_amdgcn_readfirstlane(start) >> 6;
+            const bool again = multi_hits != 0u || start + hits > lh.cap;
+            if (!again) {
+                uint32_t pos = start;
+                static_for<P>([&](auto K) {
+                    constexpr int k = decltype(K)::value;
+                    const bool hit = ((hitbits >> k) & 1u) != 0u;
+                    const unsigned long long m = __ballot(hit);
+                    if (hit) lh.ids[pos + lanes_below(m)] = (uint16_t)res[k];
+                    pos += (uint32_t)__popcll(m);
+                });
+            }
+            if (lane == 0) {
+                *lh.tile_start = again ? 0xFFFFFFFFu : start;
+                *lh.tile_tot = hits + multi_hits;
+            }
+            return;
+        }
         if constexpr (LH) {
             // the ordinary rows: part -> geometry, count, the hit's 16-bit geometry id at its rank in the wave's LDS list, the row's mask
             uint32_t hits = 0;  // wave-uniform
@@ -1904,6 +1986,58 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_route_kernel(ChainHot h)
 // A work-group only ever waits for work-groups with SMALLER indices, which the dispatcher places first; concurrent launches from
 // different streams are kept apart by the host (they share the epoch words).  A wave whose hits outgrow its rows' slots (rows in
 // several geometries) decides its tiles a second time, storing straight to the final offsets it then knows.
+#ifndef GPK_FUSED_ABLATE
+#define GPK_FUSED_ABLATE 0
+#endif
+#ifndef GPK_LH_EMIT_OLD
+#define GPK_LH_EMIT_OLD 0  // 1: the round-4 emission loop (A/B runs)
+#endif
+// The hits of `n_rows` point rows (64 points each, n_rows a multiple of 8, at most 64), out of LDS — masks[j] = the hit mask of row j,
+// ids[] = the hits' 16-bit geometry ids in row order — to pairs[my_off ...] as (first_row + 64 j + lane, id).  Lane j reads mask j:
+// ONE LDS round trip for all masks and one wave scan give every row's rank base; the loop then reads masks and bases out of registers
+// (v_readlane) and has eight id gathers in flight before the first store.  (Row by row with the mask read from LDS in every
+// iteration the loop was a chain of 2 n_rows dependent LDS round trips: 6 of the 10.7 us the emission cost in round 4.)
+__device__ __forceinline__ void emit_hit_rows(const unsigned long long* masks, const uint16_t* ids, int n_rows, uint32_t first_row, unsigned long long my_off,
+                                              uint2* pairs, int64_t capacity, int lane, bool nontemporal) {
+    const unsigned long long mv = lane < n_rows ? masks[lane] : 0ull;
+    const uint32_t cnt = (uint32_t)__popcll(mv);
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    const uint32_t excl = incl - cnt, mlo = (uint32_t)mv, mhi = (uint32_t)(mv >> 32);
+    for (int j0 = 0; j0 < n_rows; j0 += 8) {
+        uint32_t idv[8], rank[8], act = 0u;
+        static_for<8>([&](auto U) {
+            constexpr int u = decltype(U)::value;
+            const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mhi, j0 + u) << 32) | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mlo, j0 + u);
+            rank[u] = (uint32_t)__builtin_amdgcn_readlane((int)excl, j0 + u) + lanes_below(m);
+            idv[u] = 0u;
+            if ((m >> lane) & 1ull) {
+                act |= 1u << u;
+                idv[u] = (uint32_t)ids[rank[u]];
+            }
+        });
+        asm volatile("" : "+v"(idv[0]), "+v"(idv[1]), "+v"(idv[2]), "+v"(idv[3]), "+v"(idv[4]), "+v"(idv[5]), "+v"(idv[6]), "+v"(idv[7]));
+        static_for<8>([&](auto U) {
+            constexpr int u = decltype(U)::value;
+            if ((act >> u) & 1u) {
+                const unsigned long long at = my_off + rank[u];
+                if ((int64_t)at < capacity) {
+                    const unsigned long long v = ((unsigned long long)idv[u] << 32) | (unsigned long long)(first_row + (uint32_t)((j0 + u) * 64 + lane));
+                    if (GPK_FUSED_ABLATE == 3)  // (tuning builds only: everything but the store)
+                        asm volatile("" ::"v"(v), "v"(at));
+                    else if (nontemporal)
+                        __builtin_nontemporal_store(v, reinterpret_cast<unsigned long long*>(pairs + at));
+                    else
+                        *reinterpret_cast<unsigned long long*>(pairs + at) = v;
+                }
+            }
+        });
+    }
+}
 struct FusedTail {
     uint2* pairs;            // may be nullptr: counts and total only
     int64_t capacity;        // pair slots of `pairs`
@@ -1914,9 +2048,11 @@ struct FusedTail {
     uint32_t left_base, pad;
     unsigned long long* ticket;      // work-groups number themselves in the order they START: ticket - ticket_base
     unsigned long long ticket_base;  // (the counter only ever grows: the host knows where a launch's numbers begin)
+    unsigned long long* lost;        // a work-group that gave up waiting stores the launch's epoch here; the work-group that writes the total
+                                     // reads it AFTER its own waits (which cover every word anybody waited for): FUSED_LOST is sticky
 };
-#ifndef GPK_FUSED_ABLATE
-#define GPK_FUSED_ABLATE 0
+#ifndef GPK_FUSED_STAGGER
+#define GPK_FUSED_STAGGER 0
 #endif
 #ifndef GPK_FUSED_COPY_UNROLL
 #define GPK_FUSED_COPY_UNROLL 8
@@ -1937,9 +2073,26 @@ constexpr unsigned long long FUSED_LOST = ~0ull;  // in the total's place: the l
 #endif
 constexpr int FUSED_LH_TILES = 5;
 constexpr int FUSED_LH_IDS = 1120;  // 16-bit hit slots per wave: 2240 + 320 bytes of masks = 2560 bytes per wave, 40 KB per work-group
+// GPK_TILE_TRACE (diagnosis builds only; tools/fused_trace.py): lane 0 of waves 0, 5, 10, 15 of every work-group stamps the wall clock
+// (100 MHz) at the kernel's stage boundaries: 16 words per traced wave at stats[8 + ((blockIdx.x * 4 + wave / 5) * 16 + i)]
+#ifdef GPK_TILE_TRACE
+#define FUSED_STAMP(i)                                                                                                         \
+    do {                                                                                                                       \
+        unsigned long long* _st = kernel_arg_at<unsigned long long*>((uint32_t)offsetof(ChainHot, stats));                   \
+        if (_st && lane == 0 && wave % 5 == 0 && blockIdx.x < 900u) _st[8 + (blockIdx.x * 4 + wave / 5) * 16 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define FUSED_STAMP(i) do {} while (0)
+#endif
 template <bool LH>
 __global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_fused_kernel(ChainHot h, FusedTail tail_in_the_argument_segment) {
     constexpr int WORDS = PIP_ROUTE_RMAX * PIP_ROUTE_RMAX / 32, W = ROUTE_BLOCK / 64, TILE = 64 * FUSED_PPT, P = FUSED_PPT;
+#ifdef GPK_TILE_TRACE
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        FUSED_STAMP(0);
+    }
+#endif
     __shared__ uint2 s_mask[WORDS];                                 // RouteWord::bmask, gmask
     __shared__ uint32_t s_rec0[LH ? WORDS / 2 : WORDS];             // RouteWord::rec0 (LH: as uint16 ranks within the raster row)
     __shared__ uint32_t s_rowbase[LH ? PIP_ROUTE_RMAX : 1];         // LH: record rank of the row's first record
@@ -1949,28 +2102,25 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_fused_kernel(ChainHot h,
     __shared__ uint32_t s_over[W];
     __shared__ unsigned long long s_wtot[W];
     __shared__ unsigned long long s_part[W];
+    __shared__ uint32_t s_wg;
+    // (the work-group's ticket is asked for before the image is read and used after: its round trip is the image's)
+    typedef const FusedTail __attribute__((address_space(4))) * TailPtr0;
+    const TailPtr0 tail_at_entry = (TailPtr0)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(ChainHot));
+    unsigned long long my_ticket = 0ull;
+    if (threadIdx.x == 0) my_ticket = __hip_atomic_fetch_add(tail_at_entry->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     {
         const int words = h.R * h.R / 32;
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(h.route);
         if constexpr (LH) {
+            // (RouteWord::pad = rec0's rank within its raster row: one pass of independent reads; a row's base = rec0 - pad of any of
+            // its words that has records — the lanes that find one all store the same value)
             const int per_row = h.R / 32;  // (R >= 32: the host checks)
-            for (int row = threadIdx.x; row < h.R; row += ROUTE_BLOCK) {
-                uint32_t first = 0u;
-                for (int j = 0; j < per_row; ++j) {
-                    const uint4 rw = src[row * per_row + j];
-                    if (rw.x) {
-                        first = rw.z;
-                        break;
-                    }
-                }
-                s_rowbase[row] = first;
-            }
-            __syncthreads();
             uint16_t* rec16 = reinterpret_cast<uint16_t*>(s_rec0);
             for (int i = threadIdx.x; i < words; i += ROUTE_BLOCK) {
                 const uint4 rw = src[i];
                 s_mask[i] = make_uint2(rw.x, rw.y);
-                rec16[i] = rw.x ? (uint16_t)(rw.z - s_rowbase[i / per_row]) : (uint16_t)0;
+                rec16[i] = (uint16_t)rw.w;
+                if (rw.x) s_rowbase[i / per_row] = rw.z - rw.w;
             }
         } else {
             for (int i = threadIdx.x; i < words; i += ROUTE_BLOCK) {
@@ -1983,14 +2133,10 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_fused_kernel(ChainHot h,
     // (the wave's number as a SCALAR: what follows from it — its tile range, where its hits go, how many it has — then lives in scalar
     // registers; derived from threadIdx.x the compiler takes it all for per-lane values, seven vector registers the tile loop does not have)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    FUSED_STAMP(1);
     // this work-group's number: the order in which the work-groups of the launch started, not blockIdx — a work-group waits (below) for
     // the totals of those numbered before it, and those are then known to be running or done whatever order the dispatcher chose
-    __shared__ uint32_t s_wg;
-    if (threadIdx.x == 0) {
-        typedef const FusedTail __attribute__((address_space(4))) * TailPtr0;
-        const TailPtr0 tp0 = (TailPtr0)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(ChainHot));
-        s_wg = (uint32_t)(__hip_atomic_fetch_add(tp0->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - tp0->ticket_base);
-    }
+    if (threadIdx.x == 0) s_wg = (uint32_t)(my_ticket - tail_at_entry->ticket_base);
     if (lane == 0) s_over[wave] = 0u;
     __syncthreads();
     const uint32_t wg = __builtin_amdgcn_readfirstlane(s_wg);
@@ -2002,6 +2148,9 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_fused_kernel(ChainHot h,
     }
     uint2* out = (!LH && h.stage) ? h.stage + (int64_t)tile0 * TILE : nullptr;
     uint32_t out_cap = (uint32_t)(tile1 - tile0) * (uint32_t)TILE, run = 0u;
+#if GPK_FUSED_STAGGER  // tuning builds: the waves of a work-group start their first tile GPK_FUSED_STAGGER * 64 clocks apart
+    for (int i = 0; i < wave; ++i) __builtin_amdgcn_s_sleep(GPK_FUSED_STAGGER);
+#endif
     // guard-free tiles first, then the guarded ones (the column's last tile; every tile of a column with a validity bitmap): two plain
     // loops — one loop that picks the variant per tile keeps the values that travel round its back edge in scratch memory
     const int tile_f = tile1 < h.n_full_tiles ? tile1 : (tile0 > h.n_full_tiles ? tile0 : h.n_full_tiles);
@@ -2009,9 +2158,11 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_fused_kernel(ChainHot h,
         PointRegs<P> pr;
         if constexpr (LH) {
             LdsHits lh{s_ids[wave], s_hmask[wave], s_rowbase, &s_over[wave], (uint32_t)FUSED_LH_IDS};
+            FUSED_STAMP(2);
             for (int tile = tile0; tile < tile_f; ++tile) {
                 lh.masks = s_hmask[wave] + (tile - tile0) * P;
                 chain_tile<P, true, true, true, true>(h, s_mask, s_rec0, s_items[wave], (int64_t)tile, lane, nullptr, 0u, &run, pr, (int64_t)-1, lh);
+                FUSED_STAMP(3 + (tile - tile0));
             }
             for (int tile = tile_f; tile < tile1; ++tile) {
                 lh.masks = s_hmask[wave] + (tile - tile0) * P;
@@ -2047,8 +2198,10 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_fused_kernel(ChainHot h,
     t.ticket = nullptr;
     t.ticket_base = 0;
     // this work-group's total, published; the totals before it
+    FUSED_STAMP(9);
     if (lane == 0) s_wtot[wave] = (unsigned long long)run;
     __syncthreads();
+    FUSED_STAMP(10);
     unsigned long long wg_tot = 0, mine_off = 0;
 #pragma unroll
     for (int w = 0; w < W; ++w) {
@@ -2080,15 +2233,26 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_fused_kernel(ChainHot h,
 #pragma unroll
     for (int w = 0; w < W; ++w) base_off += s_part[w];
     if ((wg == gridDim.x - 1 || lost) && threadIdx.x == 0) {
-        *t.grand = lost ? FUSED_LOST : base_off + wg_tot;
-        if (t.grand_host) *t.grand_host = lost ? FUSED_LOST : base_off + wg_tot;
+        // (a work-group that gave up says so in the launch's `lost` word before anything else; the last work-group waited for every
+        // word any other waited for, so it reads `lost` after the store of whoever gave up: the total cannot hide a lost work-group)
+        unsigned long long* const lostp = tp->lost;
+        if (lost) __hip_atomic_store(lostp, t.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool any_lost = lost || __hip_atomic_load(lostp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == t.epoch;
+        if (wg == gridDim.x - 1 || lost) {
+            *t.grand = any_lost ? FUSED_LOST : base_off + wg_tot;
+            if (t.grand_host) *t.grand_host = any_lost ? FUSED_LOST : base_off + wg_tot;
+        }
     }
+    FUSED_STAMP(11);
     if (!t.pairs || lost || GPK_FUSED_ABLATE == 1) return;  // (ablation 1, tuning builds only: no copy)
     const unsigned long long my_off = base_off + mine_off;
     bool redo;
     if constexpr (LH) {
         redo = s_over[wave] != 0u;  // (set by this wave's own lane 0: wave-uniform)
-        if (!redo && !GPK_LH_EMIT_RANK) {  // the hits, out of LDS, to their place in the pair list: a row's rank = the hits before it
+        if (!redo && !GPK_LH_EMIT_RANK && !GPK_LH_EMIT_OLD) {
+            static_assert(FUSED_LH_TILES * P <= 64, "one mask per lane");
+            emit_hit_rows(s_hmask[wave], s_ids[wave], (tile1 - tile0) * P, (uint32_t)((int64_t)tile0 * TILE) + t.left_base, my_off, t.pairs, t.capacity, lane, GPK_LH_NT != 0);
+        } else if (!redo && !GPK_LH_EMIT_RANK) {  // the hits, out of LDS, to their place in the pair list: a row's rank = the hits before it
             uint32_t pos = 0;
             for (int tile = tile0; tile < tile1; ++tile) {
 #pragma unroll
@@ -2100,7 +2264,9 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_fused_kernel(ChainHot h,
                         const uint32_t row = (uint32_t)((int64_t)tile * TILE + k * 64 + lane) + t.left_base;
                         if ((int64_t)at < t.capacity) {
                             const unsigned long long v = ((unsigned long long)s_ids[wave][rank] << 32) | (unsigned long long)row;
-                            if (GPK_LH_NT)
+                            if (GPK_FUSED_ABLATE == 3)  // (tuning builds only: everything but the store)
+                                asm volatile("" ::"v"(v), "v"(at));
+                            else if (GPK_LH_NT)
                                 __builtin_nontemporal_store(v, reinterpret_cast<unsigned long long*>(t.pairs + at));
                             else
                                 *reinterpret_cast<unsigned long long*>(t.pairs + at) = v;
@@ -2163,6 +2329,11 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_fused_kernel(ChainHot h,
             }
         }
     }
+    FUSED_STAMP(12);
+#ifdef GPK_TILE_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FUSED_STAMP(13);
+#endif
     if (!redo) return;
     // the wave could not park its hits (rows in several geometries; more hits than slots): it decides its tiles again, storing at the
     // final offsets, and adds the left rows' base afterwards
@@ -2184,6 +2355,529 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_fused_kernel(ChainHot h,
             for (uint32_t i = (uint32_t)lane; i < run && i < out_cap; i += 64u) out[i].x += left_base;
         }
     }
+}
+
+// ---- round 5: the same join with its pair list written WHILE tiles are still being decided --------------------------------------
+// pip_tile_fused_kernel emits every pair after the slowest work-group's last tile: 28 MB of stores drained with nothing else in
+// flight (10.7 us of a 97 us launch on C2), and its hits wait in LDS for the whole of a wave's run, which ties the kernel to columns of
+// at most FUSED_LH_TILES tiles per wave.  Here the unit of ordering is a CHUNK — W consecutive tiles, one per wave of a work-group:
+//   * work-groups take chunks from one agent-scope counter in the order they ask (a chunk's pairs follow those of every chunk numbered
+//     before it, and every such chunk has been TAKEN by a running work-group: whatever the dispatcher does, nobody waits for a
+//     work-group that has not started);
+//   * when the last of its waves has decided its tile, a work-group publishes the chunk's hit total (epoch-tagged word, as before);
+//   * a wave emits the hits of its tile of chunk k after it has decided its tile of chunk k + 1: by then the totals of the chunks
+//     before chunk k are (nearly always) there, so the stores of one chunk travel next to the loads of the next, and only the last
+//     chunk of every work-group is emitted with nothing behind it;
+//   * the place of chunk c = the pairs of all GENERATIONS (256 chunks) before its own — carried in LDS from chunk to chunk, one
+//     256-word read per generation — + the totals of its own generation's chunks before it: at most 511 words per chunk and
+//     work-group, read by whichever wave needs the place first.
+// LDS holds two tiles' hits per wave whatever the column's length.  Eligible: geometry ids of 16 bits, a routing image (R >= 32).
+struct ChunkTail {
+    uint2* pairs;            // may be nullptr: counts and total only
+    int64_t capacity;        // pair slots of `pairs`
+    unsigned long long* slots;   // one word per chunk: epoch << FUSED_TOTAL_BITS | hits of the chunk
+    unsigned long long epoch;
+    unsigned long long* grand;
+    unsigned long long* grand_host;
+    uint32_t left_base, n_chunks;
+    unsigned long long* counter;      // chunk tickets of THIS launch (zero when it starts)
+    unsigned long long* counter_zero; // the counter of a later launch: zeroed by the work-group that takes chunk 0
+    unsigned long long* lost;         // a work-group that gave up waiting stores the launch's epoch here: the total becomes FUSED_LOST
+};
+constexpr int CHUNK_GEN_SHIFT = 8, CHUNK_GEN = 1 << CHUNK_GEN_SHIFT;
+constexpr unsigned long long CHUNK_WAIT_TICKS = 200000000ull;  // two seconds of the 100 MHz wall clock: a chunk's owner never ran
+#ifndef GPK_CHUNK_ABLATE
+#define GPK_CHUNK_ABLATE 0  // tuning builds only: 1 = no emission (totals and places only)
+#endif
+// the total of chunk `at` (spinning on the epoch tag; wall-clock bounded: *lost)
+__device__ __forceinline__ unsigned long long chunk_total_wait(const unsigned long long* slots, uint32_t at, unsigned long long epoch, bool* lost) {
+    unsigned long long v = __hip_atomic_load(&slots[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((v >> FUSED_TOTAL_BITS) != epoch) {
+        const unsigned long long t0 = wall_clock64();
+        uint32_t spins = 0;
+        while (((v = __hip_atomic_load(&slots[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> FUSED_TOTAL_BITS) != epoch) {
+            __builtin_amdgcn_s_sleep(8);
+            if ((++spins & 1023u) == 0u && wall_clock64() - t0 > CHUNK_WAIT_TICKS) {
+                *lost = true;
+                return 0ull;
+            }
+        }
+    }
+    return v & ((1ull << FUSED_TOTAL_BITS) - 1ull);
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t lds_tag(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#define LDS_ORDER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")  // (this wave's LDS writes so far are done before what follows)
+__global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_chunked_kernel(ChainHot h, ChunkTail tail_in_the_argument_segment) {
+    constexpr int WORDS = PIP_ROUTE_RMAX * PIP_ROUTE_RMAX / 32, W = ROUTE_BLOCK / 64, TILE = 64 * FUSED_PPT, P = FUSED_PPT;
+    __shared__ uint2 s_mask[WORDS];                  // RouteWord::bmask, gmask
+    __shared__ uint32_t s_rec0[WORDS / 2];           // RouteWord::rec0 as uint16 ranks within the raster row
+    __shared__ uint32_t s_rowbase[PIP_ROUTE_RMAX];   // record rank of the row's first record
+    __shared__ ChainItem s_items[W][chain_items<P, true>()];
+    __shared__ uint16_t s_ids[W][2][TILE];           // a wave's hits of its tiles of chunks k and k + 1 (one slot per row: no overflow)
+    __shared__ unsigned long long s_hmask[W][2][P];
+    __shared__ uint32_t s_over[W][2];
+    // rings over the work-group's local chunk number k (k & 3: its waves are never more than two chunks apart — a wave starts chunk
+    // k + 2 after emitting chunk k, whose place needs every wave's total of chunk k)
+    __shared__ uint32_t s_wtot[4][W], s_arrive[4], s_arrived_tag[4];  // (s_arrived_tag: k + 1 once every wave's total of round k is in s_wtot)
+    __shared__ uint32_t s_chunk[4], s_chunk_tag[4], s_chunk_claim[4];  // tags: k + 1
+    __shared__ unsigned long long s_place[4];
+    __shared__ uint32_t s_place_tag[4], s_place_claim[4];
+    __shared__ uint32_t s_kgen, s_lost;              // s_kcum = the pairs of the generations before s_kgen
+    __shared__ unsigned long long s_kcum;
+    {
+        const int words = h.R * h.R / 32;
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(h.route);
+        const int per_row = h.R / 32;  // (R >= 32: the host checks)
+        // (thread 0: this work-group's first chunk, asked for now, posted when the row bases are in)
+        typedef const ChunkTail __attribute__((address_space(4))) * TailPtr0;
+        const TailPtr0 tp0 = (TailPtr0)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(ChainHot));
+        uint32_t first_c = 0u;
+        if (threadIdx.x == 0) first_c = __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(tp0->counter), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x < 4) {
+            s_arrive[threadIdx.x] = 0u;
+            s_chunk_tag[threadIdx.x] = s_chunk_claim[threadIdx.x] = s_arrived_tag[threadIdx.x] = 0u;
+            s_place_tag[threadIdx.x] = s_place_claim[threadIdx.x] = 0u;
+        }
+        if (threadIdx.x == 0) {
+            s_kgen = 0u;
+            s_lost = 0u;
+            s_kcum = 0ull;
+            if (first_c == 0u) __hip_atomic_store(tp0->counter_zero, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_chunk[0] = first_c < tp0->n_chunks ? first_c : 0xFFFFFFFFu;
+            s_chunk_claim[0] = 1u;
+            s_chunk_tag[0] = 1u;
+        }
+        uint16_t* rec16 = reinterpret_cast<uint16_t*>(s_rec0);
+        for (int i = threadIdx.x; i < words; i += ROUTE_BLOCK) {  // (one pass: see pip_tile_fused_kernel)
+            const uint4 rw = src[i];
+            s_mask[i] = make_uint2(rw.x, rw.y);
+            rec16[i] = (uint16_t)rw.w;
+            if (rw.x) s_rowbase[i / per_row] = rw.z - rw.w;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __syncthreads();
+#if GPK_CHUNK_ABLATE == 2  // tuning builds only: launch + routing image
+    return;
+#endif
+    typedef const ChunkTail __attribute__((address_space(4))) * TailPtr;
+    static_assert(sizeof(ChainHot) % 8 == 0, "ChunkTail follows ChainHot in the argument segment");
+    // (the tail is read from the argument segment where it is used: see pip_tile_fused_kernel)
+    auto tail = [&]() -> TailPtr {
+        const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        return (TailPtr)(ka + sizeof(ChainHot));
+    };
+    for (uint32_t k = 0;; ++k) {
+        const uint32_t slot = k & 3u, buf = k & 1u;
+        // ---- the chunk of round k: asked for a round ahead (chunk 0 at the top of the kernel, chunk k + 1 by the first wave that starts
+        // round k: the counter's round trip runs next to a tile), so this wait is over before it starts unless that wave is the slowest
+        while (lds_tag(&s_chunk_tag[slot]) != k + 1u) __builtin_amdgcn_s_sleep(2);
+        asm volatile("" ::: "memory");
+        const uint32_t c = __builtin_amdgcn_readfirstlane(s_chunk[slot]);
+        const bool valid = c != 0xFFFFFFFFu;
+        if (valid) {
+            const int64_t tile = (int64_t)c * W + wave;
+            uint32_t run = 0u;
+            if (lane == 0) s_over[wave][buf] = 0u;
+            // the first wave to start round k asks for the chunk of round k + 1 (not waited for here)
+            const uint32_t nslot = (k + 1u) & 3u;
+            uint32_t first = 0u, next_c = 0xFFFFFFFFu;
+            if (lane == 0) first = __hip_atomic_fetch_max(&s_chunk_claim[nslot], k + 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < k + 2u ? 1u : 0u;
+            first = __builtin_amdgcn_readfirstlane(first);
+            if (first && lane == 0 && !lds_tag(&s_lost))
+                next_c = __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(tail()->counter), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tile < h.n_tiles) {
+                PointRegs<P> pr;
+                LdsHits lh{s_ids[wave][buf], s_hmask[wave][buf], s_rowbase, &s_over[wave][buf], (uint32_t)TILE};
+                if (tile < (int64_t)h.n_full_tiles)
+                    chain_tile<P, true, true, true, true>(h, s_mask, s_rec0, s_items[wave], tile, lane, nullptr, 0u, &run, pr, (int64_t)-1, lh);
+                else
+                    chain_tile<P, true, false, true, true>(h, s_mask, s_rec0, s_items[wave], tile, lane, nullptr, 0u, &run, pr, (int64_t)-1, lh);
+            }
+            if (first && lane == 0) {
+                s_chunk[nslot] = next_c < tail()->n_chunks ? next_c : 0xFFFFFFFFu;
+                LDS_ORDER();
+                __hip_atomic_store(&s_chunk_tag[nslot], k + 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            // the wave's total; the last wave to arrive publishes the chunk's
+            if (lane == 0) {
+                s_wtot[slot][wave] = run;
+                LDS_ORDER();
+                const uint32_t before = __hip_atomic_fetch_add(&s_arrive[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (before == (uint32_t)(W - 1)) {
+                    unsigned long long tot = 0;
+#pragma unroll
+                    for (int w = 0; w < W; ++w) tot += (unsigned long long)s_wtot[slot][w];
+                    __hip_atomic_store(&s_arrive[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(&s_arrived_tag[slot], k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const TailPtr tp = tail();
+                    __hip_atomic_store(&tp->slots[c], (tp->epoch << FUSED_TOTAL_BITS) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        // ---- the hits of round k - 1, to their place in the pair list
+        if (k > 0u) {
+            const uint32_t q = k - 1u, qslot = q & 3u, qbuf = q & 1u;
+            const uint32_t cq = __builtin_amdgcn_readfirstlane(s_chunk[qslot]);  // (valid: the loop left otherwise)
+            const TailPtr tp = tail();
+            uint2* const pairs = tp->pairs;
+            const uint32_t n_chunks = tp->n_chunks;
+            const bool is_last = cq + 1u == n_chunks;
+            if (pairs != nullptr || is_last) {  // (count-only calls: only the last chunk's place — the total — is asked for)
+                if (lds_tag(&s_place_tag[qslot]) != q + 1u) {
+                    uint32_t old = 0u;
+                    if (lane == 0) old = __hip_atomic_fetch_max(&s_place_claim[qslot], q + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    old = __builtin_amdgcn_readfirstlane(old);
+                    if (old < q + 1u) {
+                        // the generations before the chunk's (carried from the work-group's previous chunk), then its own generation's
+                        // chunks before it
+                        const unsigned long long* slots = tp->slots;
+                        const unsigned long long epoch = tp->epoch;
+                        const uint32_t gen = cq >> CHUNK_GEN_SHIFT;
+                        uint32_t kgen = s_kgen;
+                        unsigned long long kcum = s_kcum;
+                        bool lost = false;
+                        while (kgen < gen && !lost) {
+                            unsigned long long part = 0;
+#pragma unroll
+                            for (int j = 0; j < CHUNK_GEN / 64; ++j) part += chunk_total_wait(slots, (kgen << CHUNK_GEN_SHIFT) + (uint32_t)(j * 64 + lane), epoch, &lost);
+                            lost = __any(lost);
+                            kcum += wave_sum_u64(part);
+                            ++kgen;
+                        }
+                        unsigned long long part = 0;
+                        if (!lost)
+                            for (uint32_t i = (uint32_t)lane; i < (cq & (uint32_t)(CHUNK_GEN - 1)); i += 64u)
+                                part += chunk_total_wait(slots, (gen << CHUNK_GEN_SHIFT) + i, epoch, &lost);
+                        lost = __any(lost);
+                        const unsigned long long place = kcum + wave_sum_u64(part);
+                        if (lane == 0) {
+                            if (lost) {
+                                __hip_atomic_store(tp->lost, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store(&s_lost, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            }
+                            s_kgen = kgen;
+                            s_kcum = kcum;
+                            s_place[qslot] = lost ? FUSED_LOST : place;
+                            LDS_ORDER();
+                            __hip_atomic_store(&s_place_tag[qslot], q + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                    while (lds_tag(&s_place_tag[qslot]) != q + 1u) __builtin_amdgcn_s_sleep(2);
+                }
+                // (the other waves' totals of round q: a wave a whole round behind the others is waited for here)
+                while (lds_tag(&s_arrived_tag[qslot]) != q + 1u) __builtin_amdgcn_s_sleep(2);
+                asm volatile("" ::: "memory");
+                const unsigned long long place = s_place[qslot];
+                uint32_t mine_off = 0u, wg_tot = 0u;
+#pragma unroll
+                for (int w = 0; w < W; ++w) {
+                    const uint32_t v = s_wtot[qslot][w];
+                    wg_tot += v;
+                    if (w < wave) mine_off += v;
+                }
+                if (is_last && wave == 0 && lane == 0) {  // the launch's total: the last chunk's place + its hits — unless some work-group gave up
+                    const bool any_lost = place == FUSED_LOST || __hip_atomic_load(tp->lost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tp->epoch;
+                    const unsigned long long total = any_lost ? FUSED_LOST : place + (unsigned long long)wg_tot;
+                    *tp->grand = total;
+                    if (tp->grand_host) *tp->grand_host = total;
+                }
+                const int64_t tile = (int64_t)cq * W + wave;
+                if (pairs != nullptr && place != FUSED_LOST && tile < h.n_tiles && GPK_CHUNK_ABLATE != 1) {
+                    const unsigned long long my_off = place + (unsigned long long)mine_off;
+                    const int64_t capacity = tp->capacity;
+                    const uint32_t left_base = tp->left_base;
+                    if (s_over[wave][qbuf] == 0u) {  // (set by this wave's own lane 0: wave-uniform)
+                        emit_hit_rows(s_hmask[wave][qbuf], s_ids[wave][qbuf], P, (uint32_t)(tile * TILE) + left_base, my_off, pairs, capacity, lane, GPK_LH_NT != 0);
+                    } else {
+                        // a row of the tile lies in several geometries (a bit per row cannot say that): the wave decides the tile again,
+                        // storing at the final offsets, and adds the left rows' base afterwards
+                        const int64_t room = capacity - (int64_t)my_off;
+                        uint2* const out = pairs + my_off;
+                        const uint32_t out_cap = room <= 0 ? 0u : (room > (int64_t)0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)room);
+                        uint32_t run = 0u;
+                        PointRegs<P> pr;
+                        LdsHits lh{};
+                        lh.rowbase = s_rowbase;
+                        if (tile < (int64_t)h.n_full_tiles)
+                            chain_tile<P, true, true, true, false, true>(h, s_mask, s_rec0, s_items[wave], tile, lane, out, out_cap, &run, pr, (int64_t)-1, lh);
+                        else
+                            chain_tile<P, true, false, true, false, true>(h, s_mask, s_rec0, s_items[wave], tile, lane, out, out_cap, &run, pr, (int64_t)-1, lh);
+                        if (left_base) {
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            for (uint32_t i = (uint32_t)lane; i < run && i < out_cap; i += 64u) out[i].x += left_base;
+                        }
+                    }
+                }
+            }
+        }
+        if (!valid) break;
+    }
+}
+
+// ---- round 5: tiles handed out INSIDE the work-group ---------------------------------------------------------------------------------
+// pip_tile_fused_kernel<true> gives every wave a contiguous run of tiles; its timeline (tools/fused_trace.py, C2) shows what that costs:
+// a wave owns four or five tiles (4.77 on average) and waves run at different speeds, so the median wave is done at 72 us, the
+// median work-group's LAST wave at 80, and every work-group waits for its last wave.  Here a work-group still owns a contiguous range
+// of tiles (its pairs are contiguous in the pair list), but its waves draw tiles from an LDS counter one at a time; hits go to ONE pool
+// of 16-bit geometry ids per work-group (a tile takes its place in it with a single LDS atomic once it knows its hit count), a tile's
+// record = its masks + where its ids start, and after the work-group's barrier tile t's pairs go to place + the totals of the range's
+// tiles before t.  Rare rows are settled BEFORE the tile's hits are ranked (chain_tile, POOL), so their hits are ordinary hits; a tile
+// with a row in several geometries, or one that finds the pool full, is decided again at emission.  Same eligibility as the LDS-hits
+// form (16-bit geometry ids, at most POOL_TILES tiles per work-group); longer columns take pip_tile_chunked_kernel.
+#ifndef GPK_POOL_STRIDED
+#define GPK_POOL_STRIDED 1
+#endif
+constexpr int POOL_TILES = FUSED_LH_TILES * (ROUTE_BLOCK / 64);   // tile records per work-group
+constexpr int POOL_IDS = 17408;                                   // 16-bit hit slots per work-group (34 KB)
+__global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_pool_kernel(ChainHot h, FusedTail tail_in_the_argument_segment) {
+    constexpr int WORDS = PIP_ROUTE_RMAX * PIP_ROUTE_RMAX / 32, W = ROUTE_BLOCK / 64, TILE = 64 * FUSED_PPT, P = FUSED_PPT;
+    __shared__ uint2 s_mask[WORDS];                  // RouteWord::bmask, gmask
+    __shared__ uint32_t s_rec0[WORDS / 2];           // RouteWord::pad: uint16 record ranks within the raster row
+    __shared__ uint32_t s_rowbase[PIP_ROUTE_RMAX];   // record rank of the row's first record
+    __shared__ ChainItem s_items[W][chain_items<P, true>()];
+    __shared__ uint16_t s_pool[POOL_IDS];
+    __shared__ unsigned long long s_tmask[POOL_TILES][P];
+    __shared__ uint32_t s_tstart[POOL_TILES], s_ttot[POOL_TILES], s_texcl[POOL_TILES];
+    __shared__ uint32_t s_next, s_next2, s_pool_top, s_wg, s_wgtot, s_gave_up;
+    __shared__ unsigned long long s_part[W];
+    typedef const FusedTail __attribute__((address_space(4))) * TailPtr;
+    static_assert(sizeof(ChainHot) % 8 == 0, "FusedTail follows ChainHot in the argument segment");
+    auto tail = [&]() -> TailPtr {  // (read where it is used: see pip_tile_fused_kernel)
+        const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        return (TailPtr)(ka + sizeof(ChainHot));
+    };
+#ifdef GPK_TILE_TRACE
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        FUSED_STAMP(0);
+    }
+#endif
+    // (the work-group's ticket is asked for before the image is read and used after: its round trip is the image's)
+    unsigned long long my_ticket = 0ull;
+    if (threadIdx.x == 0) my_ticket = __hip_atomic_fetch_add(tail()->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {
+        const int words = h.R * h.R / 32, per_row = h.R / 32;  // (R >= 32: the host checks)
+        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(h.route);
+        uint16_t* rec16 = reinterpret_cast<uint16_t*>(s_rec0);
+        for (int i = threadIdx.x; i < words; i += ROUTE_BLOCK) {  // (one pass: see pip_tile_fused_kernel)
+            const uint4 rw = src[i];
+            s_mask[i] = make_uint2(rw.x, rw.y);
+            rec16[i] = (uint16_t)rw.w;
+            if (rw.x) s_rowbase[i / per_row] = rw.z - rw.w;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    FUSED_STAMP(1);
+    if (threadIdx.x == 0) {
+        s_wg = (uint32_t)(my_ticket - tail()->ticket_base);
+        s_next = 0u;
+        s_next2 = 0u;
+        s_pool_top = 0u;
+        s_gave_up = 0u;
+    }
+    __syncthreads();
+    const uint32_t wg = __builtin_amdgcn_readfirstlane(s_wg);
+    const int T0 = (int)((int64_t)wg * h.n_tiles / (int64_t)gridDim.x), T1 = (int)((int64_t)(wg + 1u) * h.n_tiles / (int64_t)gridDim.x);
+    const uint32_t nt = (uint32_t)(T1 - T0);  // (<= POOL_TILES: the host checks)
+    // ---- the tiles, one at a time from the work-group's counters: the guard-free tiles of the range first (a prefix of it: whole tiles
+    // of a column without a validity bitmap), then the guarded ones — two plain loops, each around ONE instance of the tile code (a loop
+    // that picks the variant per tile keeps what travels round its back edge in scratch memory: + 13 us on C2)
+    FUSED_STAMP(2);
+#ifdef GPK_TILE_TRACE
+    int n_mine = 0;
+#endif
+    const uint32_t nf = (int64_t)T1 <= (int64_t)h.n_full_tiles ? nt : ((int64_t)T0 >= (int64_t)h.n_full_tiles ? 0u : (uint32_t)(h.n_full_tiles - T0));
+#if GPK_POOL_STRIDED
+    const uint32_t nf_stride = (nf + (uint32_t)W - 1u) / (uint32_t)W, nf_draws = nf_stride * (uint32_t)W;
+#else
+    const uint32_t nf_draws = nf;
+#endif
+    for (;;) {
+        // (EVERY lane adds 1 — the counter runs in units of 64 — and the wave barrier keeps the iterations apart.  Under `if (lane == 0)`
+        // the compiler threaded lane 0 from the tile record's store at the end of one iteration straight into the draw of the next, and
+        // the loop it built around the readfirstlane never ended; with per-lane values (lane 0 adds 1, the others 0) its atomic optimizer
+        // walks the 64 lanes one by one: + 1000 scalar and + 400 vector instructions per tile for the two atomics of a tile.  A uniform
+        // value costs one v_mbcnt and ONE LDS atomic.)
+        __builtin_amdgcn_wave_barrier();
+        uint32_t t = __hip_atomic_fetch_add(&s_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        t = __builtin_amdgcn_readfirstlane(t) >> 6;
+        if (t >= nf_draws) break;
+#if GPK_POOL_STRIDED
+        // draw d -> tile (d % W) * stride + d / W: the W tiles in flight in a work-group lie `stride` tiles apart, as the runs of
+        // pip_tile_fused_kernel's waves do (W neighbouring tiles at a time measured 3 - 4 us slower per tile: they share memory channels)
+        t = (t % (uint32_t)W) * nf_stride + t / (uint32_t)W;
+        if (t >= nf) continue;
+#endif
+        PointRegs<P> pr;
+        LdsHits lh{s_pool, s_tmask[t], s_rowbase, nullptr, (uint32_t)POOL_IDS, &s_pool_top, &s_tstart[t], &s_ttot[t]};
+        uint32_t unused_run = 0u;
+        chain_tile<P, true, true, true, false, true, true>(h, s_mask, s_rec0, s_items[wave], (int64_t)T0 + t, lane, nullptr, 0u, &unused_run, pr, (int64_t)-1, lh);
+#ifdef GPK_TILE_TRACE
+        if (n_mine < 6) FUSED_STAMP(3 + n_mine);
+        ++n_mine;
+#endif
+    }
+    for (;;) {
+        __builtin_amdgcn_wave_barrier();
+        uint32_t t = __hip_atomic_fetch_add(&s_next2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        t = (__builtin_amdgcn_readfirstlane(t) >> 6) + nf;
+        if (t >= nt) break;
+        PointRegs<P> pr;
+        LdsHits lh{s_pool, s_tmask[t], s_rowbase, nullptr, (uint32_t)POOL_IDS, &s_pool_top, &s_tstart[t], &s_ttot[t]};
+        uint32_t unused_run = 0u;
+        chain_tile<P, true, false, true, false, true, true>(h, s_mask, s_rec0, s_items[wave], (int64_t)T0 + t, lane, nullptr, 0u, &unused_run, pr, (int64_t)-1, lh);
+    }
+    FUSED_STAMP(9);
+#if GPK_FUSED_ABLATE == 2  // tuning builds only: the tile phase alone
+    return;
+#endif
+    __syncthreads();
+    FUSED_STAMP(10);
+    // ---- the tiles' places within the work-group's pairs (wave 0: one scan over at most 128 totals), the work-group's total
+    static_assert(POOL_TILES <= 128, "two totals per lane");
+    if (wave == 0) {
+        const uint32_t v0 = (uint32_t)lane < nt ? s_ttot[lane] : 0u, v1 = (uint32_t)(lane + 64) < nt ? s_ttot[lane + 64] : 0u;
+        uint32_t i0 = v0, i1 = v1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t a = __shfl_up(i0, o, 64), b = __shfl_up(i1, o, 64);
+            if (lane >= o) {
+                i0 += a;
+                i1 += b;
+            }
+        }
+        const uint32_t sum0 = __shfl(i0, 63, 64), sum1 = __shfl(i1, 63, 64);
+        if ((uint32_t)lane < nt) s_texcl[lane] = i0 - v0;
+        if ((uint32_t)(lane + 64) < nt) s_texcl[lane + 64] = sum0 + i1 - v1;
+        if (lane == 0) s_wgtot = sum0 + sum1;
+    }
+    __syncthreads();
+    const unsigned long long wg_tot = (unsigned long long)s_wgtot;
+    const TailPtr tp = tail();
+    FusedTail t;
+    t.pairs = tp->pairs;
+    t.capacity = tp->capacity;
+    t.slots = tp->slots;
+    t.epoch = tp->epoch;
+    t.left_base = tp->left_base;
+    if (threadIdx.x == 0) __hip_atomic_store(&t.slots[wg], (t.epoch << FUSED_TOTAL_BITS) | wg_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long acc = 0;
+    bool gave_up = false;
+    for (unsigned b = threadIdx.x; b < wg; b += ROUTE_BLOCK) {
+        unsigned long long v;
+        uint32_t spins = 0;
+        while (((v = __hip_atomic_load(&t.slots[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> FUSED_TOTAL_BITS) != t.epoch) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > FUSED_SPIN_LIMIT) {  // (seconds: a work-group before this one never ran — report, never hang the device)
+                gave_up = true;
+                break;
+            }
+        }
+        acc += v & ((1ull << FUSED_TOTAL_BITS) - 1ull);
+    }
+    if (gave_up) __hip_atomic_store(&s_gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
+    const bool lost = s_gave_up != 0u;
+
+    acc = wave_sum_u64(acc);
+    if (lane == 0) s_part[wave] = acc;
+    __syncthreads();
+    unsigned long long base_off = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) base_off += s_part[w];
+    if ((wg == gridDim.x - 1 || lost) && threadIdx.x == 0) {  // (see pip_tile_fused_kernel: FUSED_LOST is sticky)
+        unsigned long long* const lostp = tp->lost;
+        if (lost) __hip_atomic_store(lostp, t.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool any_lost = lost || __hip_atomic_load(lostp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == t.epoch;
+        unsigned long long* const grand = tp->grand;
+        unsigned long long* const grand_host = tp->grand_host;
+        *grand = any_lost ? FUSED_LOST : base_off + wg_tot;
+        if (grand_host) *grand_host = any_lost ? FUSED_LOST : base_off + wg_tot;
+    }
+    FUSED_STAMP(11);
+    if (!t.pairs || lost || GPK_FUSED_ABLATE == 1) return;  // (ablation 1, tuning builds only: no emission)
+    // ---- emission: the tiles of the range dealt round the waves (wave w: tiles w, w + W, ...: at most POOL_TILES / W of them).  One
+    // pass for all of a wave's tiles: lane j holds point row j % P of the wave's tile j / P — its mask, where its ids start in the pool,
+    // where its pairs go (one LDS round trip + one wave scan for everything) — and the loop reads rows out of registers, eight id
+    // gathers in flight before the first store (tile by tile this was 7 us of a 94 us launch)
+    static_assert(POOL_TILES / W * P <= 64, "one (tile, row) per lane");
+    {
+        const uint32_t n_mine = nt > (uint32_t)wave ? (nt - (uint32_t)wave + (uint32_t)W - 1u) / (uint32_t)W : 0u;
+        const uint32_t tj = (uint32_t)lane / (uint32_t)P, kj = (uint32_t)lane % (uint32_t)P, et_j = (uint32_t)wave + tj * (uint32_t)W;
+        const bool have = tj < n_mine;
+        const uint32_t start_j = have ? s_tstart[et_j] : 0xFFFFFFFFu;
+        const unsigned long long mv = have && start_j != 0xFFFFFFFFu ? s_tmask[et_j][kj] : 0ull;
+        const uint32_t cnt = (uint32_t)__popcll(mv);
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int o = 1; o < P; o <<= 1) {  // (inclusive scan within the P lanes of a tile)
+            const uint32_t v = __shfl_up(incl, o, P);
+            if ((int)kj >= o) incl += v;
+        }
+        const uint32_t gex = incl - cnt;
+        const uint32_t outb = have ? s_texcl[et_j] + gex : 0u, idsb = start_j + gex;
+        const uint32_t rowb = (uint32_t)(((int64_t)T0 + et_j) * TILE) + kj * 64u + t.left_base;
+        const uint32_t mlo = (uint32_t)mv, mhi = (uint32_t)(mv >> 32);
+        for (uint32_t j0 = 0; j0 < n_mine * (uint32_t)P; j0 += 8u) {
+            uint32_t idv[8], rank[8], act = 0u;
+            static_for<8>([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                const int j = (int)j0 + u;
+                const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mhi, j) << 32) | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mlo, j);
+                rank[u] = lanes_below(m);
+                idv[u] = 0u;
+                if ((m >> lane) & 1ull) {
+                    act |= 1u << u;
+                    idv[u] = (uint32_t)s_pool[(uint32_t)__builtin_amdgcn_readlane((int)idsb, j) + rank[u]];
+                }
+            });
+            asm volatile("" : "+v"(idv[0]), "+v"(idv[1]), "+v"(idv[2]), "+v"(idv[3]), "+v"(idv[4]), "+v"(idv[5]), "+v"(idv[6]), "+v"(idv[7]));
+            static_for<8>([&](auto U) {
+                constexpr int u = decltype(U)::value;
+                const int j = (int)j0 + u;
+                if ((act >> u) & 1u) {
+                    const unsigned long long at = base_off + (unsigned long long)((uint32_t)__builtin_amdgcn_readlane((int)outb, j) + rank[u]);
+                    if ((int64_t)at < t.capacity) {
+                        const unsigned long long v = ((unsigned long long)idv[u] << 32) | (unsigned long long)((uint32_t)__builtin_amdgcn_readlane((int)rowb, j) + (uint32_t)lane);
+                        if (GPK_LH_NT)
+                            __builtin_nontemporal_store(v, reinterpret_cast<unsigned long long*>(t.pairs + at));
+                        else
+                            *reinterpret_cast<unsigned long long*>(t.pairs + at) = v;
+                    }
+                }
+            });
+        }
+    }
+    // the tiles that are decided again, storing at their final offsets (a row in several geometries; the pool was full)
+    for (uint32_t et = (uint32_t)wave; et < nt; et += (uint32_t)W) {
+        if (s_tstart[et] != 0xFFFFFFFFu) continue;
+        const unsigned long long my_off = base_off + (unsigned long long)s_texcl[et];
+        const int64_t tile = (int64_t)T0 + et;
+        const int64_t room = t.capacity - (int64_t)my_off;
+        uint2* const out = t.pairs + my_off;
+        const uint32_t out_cap = room <= 0 ? 0u : (room > (int64_t)0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)room);
+        uint32_t run = 0u;
+        PointRegs<P> pr;
+        LdsHits lh{};
+        lh.rowbase = s_rowbase;
+        if (tile < (int64_t)h.n_full_tiles)
+            chain_tile<P, true, true, true, false, true>(h, s_mask, s_rec0, s_items[wave], tile, lane, out, out_cap, &run, pr, (int64_t)-1, lh);
+        else
+            chain_tile<P, true, false, true, false, true>(h, s_mask, s_rec0, s_items[wave], tile, lane, out, out_cap, &run, pr, (int64_t)-1, lh);
+        if (t.left_base) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (uint32_t i = (uint32_t)lane; i < run && i < out_cap; i += 64u) out[i].x += t.left_base;
+        }
+    }
+    FUSED_STAMP(12);
 }
 
 // pip_write: turns the per-point codes into the sorted (l, r) pair list.  Reads 4 bytes per point, writes 8
@@ -2712,14 +3406,19 @@ static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, co
     return done(GPK_OK);
 }
 
-// The epoch words of pip_tile_fused_kernel: one buffer per device (zeroed when created; a launch's tag is never 0), a process-wide
+// The epoch words of the fused point joins: one buffer per device (zeroed when created; a launch's tag is never 0), a process-wide
 // launch counter, and an event that keeps launches from DIFFERENT streams apart — they share the words, and two such launches
 // running side by side could each hold compute units the other's lower-numbered work-groups still wait for.
+// Layout: n total words | the `lost` word of pip_tile_chunked_kernel | the ticket counter of pip_tile_fused_kernel | FUSED_COUNTERS
+// chunk counters — launch number i counts in word i % FUSED_COUNTERS and zeroes word (i + FUSED_COUNTERS / 2) % FUSED_COUNTERS for
+// the launch that will use it (launches on one device run one after the other): no counter is ever zeroed from the host.
 static std::mutex g_fused_mu;
+constexpr int FUSED_COUNTERS = 64;
 struct FusedDev {
-    unsigned long long* slots = nullptr;  // n total words, then the ticket counter
-    unsigned long long tickets = 0;       // what the counter holds once every launch queued so far has started its work-groups
+    unsigned long long* slots = nullptr;
+    unsigned long long tickets = 0;       // what the ticket counter holds once every launch queued so far has started its work-groups
     unsigned long long era = 0;           // launch counter >> 24 when the words were last cleared
+    unsigned long long launches = 0;      // chunked launches so far (which counter word is next)
     int n = 0;
     hipEvent_t done = nullptr;
     hipStream_t last = nullptr;
@@ -2727,30 +3426,37 @@ struct FusedDev {
 };
 static FusedDev g_fused[16];
 static unsigned long long g_fused_epoch = 0;
-static int32_t fused_launch_begin(hipStream_t s, int wgs, unsigned long long** slots, unsigned long long* epoch, unsigned long long** ticket,
-                                  unsigned long long* ticket_base) {
+struct FusedWords {
+    unsigned long long *slots, *ticket, *lost, *counter, *counter_zero;
+    unsigned long long epoch, ticket_base;
+};
+// n_words: epoch words the launch needs; wgs: tickets it will draw (pip_tile_fused_kernel; 0 for the chunked kernel)
+static int32_t fused_launch_begin(hipStream_t s, int64_t n_words, int wgs, FusedWords* out) {
     int dev = 0;
     GPK_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 16) return fail(GPK_ERR_DEVICE, "spatial_join: device %d out of range", dev);
+    if (n_words > (int64_t)0x7FFFFFF0ll) return fail(GPK_ERR_INVALID_ARGUMENT, "spatial_join: %lld epoch words", (long long)n_words);
     g_fused_mu.lock();  // released by fused_launch_end: launch order = event order
     FusedDev& f = g_fused[dev];
     auto bail = [&](hipError_t e) {
         g_fused_mu.unlock();
         return fail(GPK_ERR_DEVICE, "spatial_join: %s", hipGetErrorString(e));
     };
-    if (f.n < wgs) {
+    if ((int64_t)f.n < n_words) {
         if (f.slots) {
             (void)hipDeviceSynchronize();
             (void)hipFree(f.slots);
             f.slots = nullptr;
         }
-        const int want = wgs < 1024 ? 1024 : wgs;
-        hipError_t e = device_malloc((void**)&f.slots, sizeof(unsigned long long) * (size_t)(want + 1));
+        const int want = n_words < 4096 ? 4096 : (int)n_words;
+        const size_t bytes = sizeof(unsigned long long) * (size_t)(want + 2 + FUSED_COUNTERS);
+        hipError_t e = device_malloc((void**)&f.slots, bytes);
         if (e != hipSuccess) return bail(e);
-        e = hipMemset(f.slots, 0, sizeof(unsigned long long) * (size_t)(want + 1));
+        e = hipMemset(f.slots, 0, bytes);
         if (e != hipSuccess) return bail(e);
         f.n = want;
         f.tickets = 0;
+        f.launches = 0;
         f.era = g_fused_epoch >> (64 - FUSED_TOTAL_BITS);
     }
     if (!f.done) {
@@ -2769,17 +3475,22 @@ static int32_t fused_launch_begin(hipStream_t s, int wgs, unsigned long long** s
     ++g_fused_epoch;
     if ((g_fused_epoch & ((1ull << (64 - FUSED_TOTAL_BITS)) - 1ull)) == 0ull) ++g_fused_epoch;  // (a tag of 0 is what a fresh word holds)
     // the tag is 24 bits of the launch counter: when it has wrapped since this device's words were last cleared, a word written 16.7 M
-    // launches ago by a larger grid could carry the new launch's tag — clear them (stream-ordered, behind every earlier launch)
+    // launches ago by a larger launch could carry the new launch's tag — clear them (stream-ordered, behind every earlier launch)
     if ((g_fused_epoch >> (64 - FUSED_TOTAL_BITS)) != f.era) {
-        const hipError_t e = hipMemsetAsync(f.slots, 0, sizeof(unsigned long long) * (size_t)f.n, s);
+        const hipError_t e = hipMemsetAsync(f.slots, 0, sizeof(unsigned long long) * (size_t)(f.n + 1), s);  // (+ the `lost` word)
         if (e != hipSuccess) return bail(e);
         f.era = g_fused_epoch >> (64 - FUSED_TOTAL_BITS);
     }
-    *epoch = g_fused_epoch & ((1ull << (64 - FUSED_TOTAL_BITS)) - 1ull);
-    *slots = f.slots;
-    *ticket = f.slots + f.n;
-    *ticket_base = f.tickets;
+    out->epoch = g_fused_epoch & ((1ull << (64 - FUSED_TOTAL_BITS)) - 1ull);
+    out->slots = f.slots;
+    out->lost = f.slots + f.n;
+    out->ticket = f.slots + f.n + 1;
+    out->ticket_base = f.tickets;
     f.tickets += (unsigned long long)wgs;
+    unsigned long long* const counters = f.slots + f.n + 2;
+    out->counter = counters + (f.launches % FUSED_COUNTERS);
+    out->counter_zero = counters + ((f.launches + FUSED_COUNTERS / 2) % FUSED_COUNTERS);
+    if (wgs == 0) ++f.launches;
     return GPK_OK;
 }
 static void fused_launch_end(hipStream_t s, bool launched) {
@@ -2788,7 +3499,7 @@ static void fused_launch_end(hipStream_t s, bool launched) {
     if (dev >= 0 && dev < 16) {
         g_fused[dev].last = s;
         g_fused[dev].any = true;
-        if (!launched) g_fused[dev].n = 0;  // the ticket counter and the host's idea of it may differ now: fresh words for the next launch
+        if (!launched) g_fused[dev].n = 0;  // the counters and the host's idea of them may differ now: fresh words for the next launch
     }
     g_fused_mu.unlock();
 }
@@ -2847,9 +3558,27 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         if (fused_wgs > want) fused_wgs = want;
         if (fused_wgs < 1) fused_wgs = 1;
     }
-    const bool lds_hits = fused && !no_lds_hits && right->d.n_geoms <= 65535 && right_index->pip.R >= 32 &&
+    // round 5: the chunked form (hits of two tiles per wave in LDS, pairs written while the next chunk is decided) serves every column
+    // whose right side has 16-bit geometry ids — no limit on the left column's length.  GPK_FUSED_FORM=wave: the round-4 forms (A/B runs)
+    static const bool no_chunked = [] {
+        const char* e = getenv("GPK_FUSED_FORM");
+        return e && !strcmp(e, "wave");
+    }();
+    const int64_t n_chunks = (n_blocks + ROUTE_BLOCK / 64 - 1) / (ROUTE_BLOCK / 64);
+    const int64_t chunk_wgs = n_chunks < (int64_t)cu_count() ? (n_chunks < 1 ? 1 : n_chunks) : (int64_t)cu_count();
+    // Which form (all bit-identical): `pool` — tiles drawn inside the work-group, hits in a work-group pool — when a work-group's range
+    // is at most POOL_TILES tiles (10.49 M rows on 256 CUs); `chunked` beyond that; GPK_FUSED_FORM=wave | chunked | pool forces one (A/B
+    // runs; wave = the round-4 LDS-hits form), GPK_FUSED_LDS=0 the staging form
+    static const char* const form = getenv("GPK_FUSED_FORM");
+    const bool lh_ok = fused && !no_lds_hits && right->d.n_geoms <= 65535 && right_index->pip.R >= 32;
+    const bool fits = (n_blocks + fused_wgs - 1) / fused_wgs <= (int64_t)POOL_TILES;
+    const bool want_wave = form && !strcmp(form, "wave"), want_chunked = form && !strcmp(form, "chunked");
+    (void)no_chunked;
+    const bool chunked = lh_ok && n_chunks >= 1 && (want_chunked || (!fits && !want_wave));
+    const bool pool = lh_ok && !chunked && fits && !want_wave;
+    const bool lds_hits = lh_ok && !chunked && !pool &&
                           (n_blocks + fused_wgs * (ROUTE_BLOCK / 64) - 1) / (fused_wgs * (ROUTE_BLOCK / 64)) <= FUSED_LH_TILES;
-    const size_t stage_bytes = fused && want_pairs && !lds_hits ? sizeof(uint2) * (size_t)n_blocks * (size_t)tile_points : 0;
+    const size_t stage_bytes = fused && want_pairs && !lds_hits && !chunked && !pool ? sizeof(uint2) * (size_t)n_blocks * (size_t)tile_points : 0;
     size_t need = align256(fused ? 64 : counts_bytes + 64) /*code*/ + align256(sizeof(unsigned long long) * (size_t)(n_blocks + n_super + 3)) +
                   align256(sizeof(uint32_t) * (size_t)multi_cap) + align256(sizeof(ChainCold)) + align256(stage_bytes) + 1024;
     if (host_out && out_counts) need += align256(counts_bytes);
@@ -2938,6 +3667,35 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         hot.inv_fh_s = pv.inv_fh * (double)PIP_SUB;
         hot.sub_max = (double)(((uint32_t)PIP_SUB << hot.logR) - 1u);
     }
+    if (fused && chunked) {  // one launch: work-groups take chunks of W tiles; a chunk's pairs are written while the next is decided
+        ChunkTail tail;
+        memset(&tail, 0, sizeof tail);
+        tail.pairs = (uint2*)pairs_dev;
+        tail.capacity = pair_capacity;
+        tail.grand = grand;
+        tail.grand_host = total_out;
+        tail.left_base = left_row_base;
+        tail.n_chunks = (uint32_t)n_chunks;
+        FusedWords fw;
+        int32_t frc = fused_launch_begin(s, n_chunks, 0, &fw);
+        if (frc != GPK_OK) return frc;
+        tail.slots = fw.slots;
+        tail.epoch = fw.epoch;
+        tail.counter = fw.counter;
+        tail.counter_zero = fw.counter_zero;
+        tail.lost = fw.lost;
+        const int64_t wgs = chunk_wgs;
+        frc = [&]() -> int32_t {
+            GPK_LAUNCH("gpk_pip_tile", pip_tile_chunked_kernel, dim3((unsigned)wgs), dim3(ROUTE_BLOCK), 0, s, hot, tail);
+            return GPK_OK;
+        }();
+        fused_launch_end(s, frc == GPK_OK);
+        if (frc != GPK_OK) return frc;
+        *counts_dev_out = counts_dev;
+        *pairs_dev_out = pairs_dev;
+        *grand_out = grand;
+        return GPK_OK;
+    }
     if (fused) {  // one launch: persistent work-groups (one per CU), contiguous tiles per wave, pairs written by the same kernel
         const int64_t wgs = fused_wgs;
         FusedTail tail;
@@ -2947,10 +3705,18 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         tail.grand = grand;
         tail.grand_host = total_out;
         tail.left_base = left_row_base;
-        int32_t frc = fused_launch_begin(s, (int)wgs, &tail.slots, &tail.epoch, &tail.ticket, &tail.ticket_base);
+        FusedWords fw;
+        int32_t frc = fused_launch_begin(s, wgs, (int)wgs, &fw);
         if (frc != GPK_OK) return frc;
+        tail.slots = fw.slots;
+        tail.epoch = fw.epoch;
+        tail.ticket = fw.ticket;
+        tail.ticket_base = fw.ticket_base;
+        tail.lost = fw.lost;
         frc = [&]() -> int32_t {
-            if (lds_hits)
+            if (pool)
+                GPK_LAUNCH("gpk_pip_tile", pip_tile_pool_kernel, dim3((unsigned)wgs), dim3(ROUTE_BLOCK), 0, s, hot, tail);
+            else if (lds_hits)
                 GPK_LAUNCH("gpk_pip_tile", pip_tile_fused_kernel<true>, dim3((unsigned)wgs), dim3(ROUTE_BLOCK), 0, s, hot, tail);
             else
                 GPK_LAUNCH("gpk_pip_tile", pip_tile_fused_kernel<false>, dim3((unsigned)wgs), dim3(ROUTE_BLOCK), 0, s, hot, tail);

@@ -1093,6 +1093,25 @@ __global__ void route_build_kernel(const uint32_t* __restrict__ cell, int64_t n_
     route[w] = rw;
 }
 
+// RouteWord::pad = the 16-bit rank of rec0 among its raster row's records (rec0 - the rec0 of the row's first word that has records): the
+// persistent point-join kernels keep 16-bit ranks + one base per row in LDS, and with the rank in the word their image load is one
+// pass of independent 16-byte reads (the row's base = rec0 - pad of any of its words with records).  One thread per raster row.
+__global__ void route_rank_kernel(RouteWord* __restrict__ route, int R) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= R) return;
+    const int per_row = R / 32;
+    RouteWord* rw = route + (int64_t)row * per_row;
+    uint32_t base = 0u;
+    bool have = false;
+    for (int j = 0; j < per_row; ++j) {
+        if (rw[j].bmask && !have) {
+            base = rw[j].rec0;
+            have = true;
+        }
+        rw[j].pad = rw[j].bmask ? rw[j].rec0 - base : 0u;
+    }
+}
+
 // one-part records: the flagged cells as a work list (cell, part), record pos[c] — the build then launches one wave per
 // RECORD instead of one per raster cell (two thirds of the cells of the C2 raster, nineteen in twenty of a 2048 x 2048 one,
 // carry no record)
@@ -1584,6 +1603,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
             GPK_HIP(cached_malloc((void**)&route, sizeof(RouteWord) * (size_t)n_words));
             keep(route);
             GPK_LAUNCH("gpk_pipidx_route", route_build_kernel, blocks_for(n_words), dim3(256), 0, s, (const uint32_t*)cell, n_words, route);
+            if (R >= 32) GPK_LAUNCH("gpk_pipidx_route_rank", route_rank_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, s, route, R);
             pv.route = route;
             ix->nbytes += (int64_t)(sizeof(RouteWord) * (size_t)n_words);
         }
@@ -1640,6 +1660,7 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
                 GPK_HIP(cached_malloc((void**)&route, sizeof(RouteWord) * (size_t)n_words));
                 keep(route);
                 GPK_LAUNCH("gpk_pipidx_route", route_build_kernel, blocks_for(n_words), dim3(256), 0, s, (const uint32_t*)cell, n_words, route);
+            if (R >= 32) GPK_LAUNCH("gpk_pipidx_route_rank", route_rank_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, s, route, R);
                 pv.route = route;
                 ix->nbytes += (int64_t)(sizeof(RouteWord) * (size_t)n_words);
             }
