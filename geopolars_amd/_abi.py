@@ -41,6 +41,7 @@ INDEX_BBOX_GRID = 1
 INDEX_PIP = 2
 INDEX_PIP_LIGHT = 4
 INDEX_PIP_FULL = 8
+QUERY_CONTAINED, QUERY_INTERSECTING = 0, 1  # gpk_index_query_envelope modes
 PREDICATES = {"intersects": PRED_INTERSECTS, "contains": PRED_CONTAINS, "within": PRED_WITHIN}
 
 
@@ -116,6 +117,7 @@ _PROTOS = {
     "gpk_index_free": (C.c_int32, [_VP]),
     "gpk_index_nbytes": (C.c_int32, [_VP, C.POINTER(C.c_int64)]),
     "gpk_index_describe": (C.c_int32, [_VP, C.POINTER(C.c_int64)]),
+    "gpk_index_query_envelope": (C.c_int32, [_VP, _VP, C.c_int64, C.c_int32, _VP, _VP, C.c_int64, C.POINTER(C.c_int64), C.c_int32, _VP]),
     "gpk_spatial_join": (
         C.c_int32,
         [_VP, _VP, _VP, C.c_int32, C.c_uint32, _VP, _VP, C.c_int64, C.POINTER(C.c_int64), C.c_int32, _VP],

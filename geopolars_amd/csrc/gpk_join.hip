@@ -3254,10 +3254,30 @@ static inline dim3 grid_for(int64_t n, int block) {
 }
 
 // polygonal x polygonal: candidates (count, scan, fill) -> pair-parallel exact refine -> hits (count, scan, emit)
-enum { REFINE_POLYGONAL = 0, REFINE_LINEAL_POINT = 1, REFINE_CONTAINS = 2 };
+enum { REFINE_POLYGONAL = 0, REFINE_LINEAL_POINT = 1, REFINE_CONTAINS = 2, REFINE_ENVELOPE_INTERSECTS = 3, REFINE_ENVELOPE_CONTAINED = 4 };
+// gpk_index_query_envelope's refine (rstar's locate_in_envelope_intersecting / locate_in_envelope, spatial_index.rs:385-387,424-426): a
+// candidate's box already meets the query box (closed intervals: for_each_bbox_candidate); `contained` additionally asks that it lies
+// inside it, bounds included (rstar AABB::contains_envelope)
+__global__ __launch_bounds__(256) void query_boxes_kernel(const double4* __restrict__ in, int64_t n, double4* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double4 b = in[i];
+    const bool nan = !(b.x == b.x && b.y == b.y && b.z == b.z && b.w == b.w);
+    out[i] = nan ? make_double4(NAN, NAN, NAN, NAN) : make_double4(fmin(b.x, b.z), fmin(b.y, b.w), fmax(b.x, b.z), fmax(b.y, b.w));
+}
+__global__ __launch_bounds__(256) void envelope_refine_kernel(const uint32_t* __restrict__ cand_l, const uint32_t* __restrict__ cand_r, int64_t n,
+                                                               const double4* __restrict__ lbbox, const double4* __restrict__ rbbox, int contained,
+                                                               uint8_t* __restrict__ hit) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double4 lb = lbbox[cand_l[i]], rb = rbbox[cand_r[i]];
+    bool ok = rb.x == rb.x && lb.x == lb.x;
+    if (contained) ok = ok && rb.x >= lb.x && rb.z <= lb.z && rb.y >= lb.y && rb.w <= lb.w;
+    hit[i] = ok ? 1 : 0;
+}
 static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, const gpk_index* right_index, uint32_t left_row_base,
                          uint32_t* out_counts, uint32_t* out_pairs, int64_t pair_capacity, int64_t* n_pairs, int32_t out_space,
-                         hipStream_t s, int refine = REFINE_POLYGONAL) {
+                         hipStream_t s, int refine = REFINE_POLYGONAL, const double4* given_lbbox = nullptr) {
     const int64_t n = left->d.n_geoms;
     const bool host_out = out_space != GPK_MEM_DEVICE;
     const bool want_pairs = pair_capacity > 0;
@@ -3269,10 +3289,15 @@ static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, co
         return rc;
     };
     // left boxes and the candidate buffers live in the thread's auxiliary arenas (no hipMalloc / hipFree per call)
-    GPK_TRY(workspace_aux(0).begin(sizeof(double4) * (size_t)n + 256));
-    double4* lbbox = (double4*)workspace_aux(0).take(sizeof(double4) * (size_t)n);
-    int32_t rc = gpk_bounds(left, (double*)lbbox, GPK_MEM_DEVICE, (void*)s);
-    if (rc != GPK_OK) return done(rc);
+    // (given_lbbox: gpk_index_query_envelope hands its query boxes over — in device memory — in the left boxes' place)
+    double4* lbbox = const_cast<double4*>(given_lbbox);
+    int32_t rc = GPK_OK;
+    if (!given_lbbox) {
+        GPK_TRY(workspace_aux(0).begin(sizeof(double4) * (size_t)n + 256));
+        lbbox = (double4*)workspace_aux(0).take(sizeof(double4) * (size_t)n);
+        rc = gpk_bounds(left, (double*)lbbox, GPK_MEM_DEVICE, (void*)s);
+        if (rc != GPK_OK) return done(rc);
+    }
     const int64_t nb = (n + 255) / 256;
     const size_t pairs_bytes = sizeof(uint32_t) * 2 * (size_t)pair_capacity;
     const size_t i32n = align256(sizeof(int32_t) * (size_t)(n + 1));
@@ -3359,7 +3384,11 @@ static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, co
             int64_t blocks = ((int64_t)n_cand + (256 / JOIN_GS) - 1) / (256 / JOIN_GS);
             const int64_t cap = (int64_t)cu_count() * 64;
             if (blocks > cap) blocks = cap;
-            if (refine == REFINE_LINEAL_POINT)
+            if (refine == REFINE_ENVELOPE_INTERSECTS || refine == REFINE_ENVELOPE_CONTAINED)
+                GPK_LAUNCH("gpk_envelope_refine", envelope_refine_kernel, dim3((unsigned)(((int64_t)n_cand + 255) / 256)), dim3(256), 0, s,
+                           (const uint32_t*)cand_l, (const uint32_t*)cand_r, (int64_t)n_cand, (const double4*)lbbox, right_index->v.bbox,
+                           refine == REFINE_ENVELOPE_CONTAINED ? 1 : 0, hit);
+            else if (refine == REFINE_LINEAL_POINT)
                 GPK_LAUNCH("gpk_lineal_point_refine", lineal_point_refine_kernel, dim3((unsigned)(((int64_t)n_cand + 255) / 256)), dim3(256), 0, s,
                            left->d, right->d, (const uint32_t*)cand_l, (const uint32_t*)cand_r, (int64_t)n_cand, hit);
             else if (refine == REFINE_CONTAINS)
@@ -3904,6 +3933,41 @@ int32_t gpk_join_trace(unsigned long long* out, int64_t n_words) {  // diagnosis
     return GPK_OK;
 }
 #endif
+
+int32_t gpk_index_query_envelope(const gpk_index* idx, const double* boxes4, int64_t n_boxes, int32_t mode, uint32_t* out_counts,
+                                 uint32_t* out_pairs, int64_t pair_capacity, int64_t* n_pairs, int32_t space, void* stream) {
+    if (!idx || !n_pairs || (n_boxes > 0 && !boxes4)) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (mode != GPK_QUERY_CONTAINED && mode != GPK_QUERY_INTERSECTING) return fail(GPK_ERR_INVALID_ARGUMENT, "unknown envelope query mode %d", mode);
+    if (n_boxes < 0 || pair_capacity < 0 || (pair_capacity > 0 && !out_pairs)) return fail(GPK_ERR_INVALID_ARGUMENT, "bad sizes");
+    if (n_boxes > (int64_t)0x7FFFFFF0ll) return fail(GPK_ERR_INVALID_ARGUMENT, "more than 2^31 query boxes");
+    *n_pairs = 0;
+    GPK_TRY(require_device());
+    if (n_boxes == 0) return GPK_OK;
+    hipStream_t s = (hipStream_t)stream;
+    // the queries take the left rows' place in the box join, the index's own array the right rows' (the index holds the leaves: no
+    // geometry is read); null and empty rows of the indexed array have NaN boxes and are in no directory cell
+    gpk_geoarray left, right;
+    memset(&left, 0, sizeof left);
+    memset(&right, 0, sizeof right);
+    left.d.type = GPK_GEOM_POINT;
+    left.d.n_geoms = n_boxes;
+    left.device = right.device = idx->device;
+    right.d.type = idx->geom_type;
+    right.d.n_geoms = idx->n_geoms;
+    // the queries in the library's own memory, corners ordered the way `AABB::from_corners` orders them (lower = the component-wise
+    // minimum of the two corners, upper = the maximum)
+    GPK_TRY(workspace_aux(0).begin(2 * (sizeof(double4) * (size_t)n_boxes + 256)));
+    double4* boxes_dev = (double4*)workspace_aux(0).take(sizeof(double4) * (size_t)n_boxes);
+    const double4* src = reinterpret_cast<const double4*>(boxes4);
+    if (space != GPK_MEM_DEVICE) {
+        double4* up = (double4*)workspace_aux(0).take(sizeof(double4) * (size_t)n_boxes);
+        GPK_HIP(hipMemcpyAsync(up, boxes4, sizeof(double4) * (size_t)n_boxes, hipMemcpyHostToDevice, s));
+        src = up;
+    }
+    GPK_LAUNCH("gpk_query_boxes", query_boxes_kernel, dim3((unsigned)((n_boxes + 255) / 256)), dim3(256), 0, s, src, n_boxes, boxes_dev);
+    return bbox_join(&left, &right, idx, 0u, out_counts, out_pairs, pair_capacity, n_pairs, space, s,
+                     mode == GPK_QUERY_CONTAINED ? REFINE_ENVELOPE_CONTAINED : REFINE_ENVELOPE_INTERSECTS, boxes_dev);
+}
 
 int32_t gpk_index_free(gpk_index* idx) {
     if (!idx) return GPK_OK;

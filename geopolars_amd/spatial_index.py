@@ -67,6 +67,33 @@ class SpatialIndex:
         _abi.check(_abi.lib().gpk_index_describe(self._h, out))
         return {"R": int(out[0]), "lean": bool(out[1]), "chains": bool(out[2]), "route": bool(out[3]), "list_heavy": bool(out[4])}
 
+    def query_envelopes(self, boxes, mode: str = "contained", stream: int = 0) -> tuple[np.ndarray, np.ndarray]:
+        """gpk_index_query_envelope for a batch of query boxes ((n, 4): minx, miny, maxx, maxy): the (query, geometry index) pairs
+        sorted by (query, index) and the per-query counts.  mode: "contained" (rstar locate_in_envelope) | "intersecting"
+        (locate_in_envelope_intersecting); closed intervals (spatial_index.rs:383-393,422-429)."""
+        lib = _abi.lib()
+        b = np.ascontiguousarray(np.asarray(boxes, dtype=np.float64).reshape(-1, 4))
+        n = len(b)
+        m = {"contained": _abi.QUERY_CONTAINED, "intersecting": _abi.QUERY_INTERSECTING}[mode]
+        counts = np.zeros(n, dtype=np.uint32)
+        n_pairs = C.c_int64(0)
+        _abi.check(lib.gpk_index_query_envelope(self._h, b.ctypes.data, n, m, counts.ctypes.data, None, 0, C.byref(n_pairs), MEM_HOST, stream))
+        pairs = np.zeros((int(n_pairs.value), 2), dtype=np.uint32)
+        if len(pairs):
+            _abi.check(lib.gpk_index_query_envelope(self._h, b.ctypes.data, n, m, counts.ctypes.data, pairs.ctypes.data, len(pairs), C.byref(n_pairs), MEM_HOST, stream))
+        return pairs, counts
+
+    def locate_in_envelope(self, lower, upper) -> np.ndarray:
+        """`r_tree.locate_in_envelope(&AABB::from_corners(lower, upper))` (spatial_index.rs:383-387): the indexes of the geometries
+        whose bounding box lies inside the closed query box, ascending."""
+        pairs, _ = self.query_envelopes([[lower[0], lower[1], upper[0], upper[1]]], "contained")
+        return pairs[:, 1].astype(np.int64)
+
+    def locate_in_envelope_intersecting(self, lower, upper) -> np.ndarray:
+        """rstar `locate_in_envelope_intersecting`: the geometries whose bounding box meets the closed query box."""
+        pairs, _ = self.query_envelopes([[lower[0], lower[1], upper[0], upper[1]]], "intersecting")
+        return pairs[:, 1].astype(np.int64)
+
     def free(self) -> None:
         if self._h:
             _abi.lib().gpk_index_free(self._h)

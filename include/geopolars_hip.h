@@ -299,6 +299,21 @@ int32_t gpk_index_build(const gpk_geoarray* a, void* stream, gpk_index** out);
 int32_t gpk_index_build_ex(const gpk_geoarray* a, int32_t parts, const double* bbox4_dev, void* stream,
                            gpk_index** out);
 int32_t gpk_index_free(gpk_index* idx);
+/* A query on the index by itself — what the reference's own index tests do (spatial_index.rs:383-393,422-429):
+ * `r_tree.locate_in_envelope(&AABB::from_corners(lo, hi))` = every leaf (one per indexed geometry: its bounding box) CONTAINED in the
+ * query box, `locate_in_envelope_intersecting` = every leaf that meets it; both with closed intervals (a leaf touching the query box's
+ * border is contained / intersecting — rstar AABB::contains_envelope / intersects).  Batched: n_boxes query boxes
+ *   boxes4[4 * n_boxes]      two corners (x0, y0, x1, y1) per query, in `space`; ordered as AABB::from_corners orders them (component-wise
+ *                            min / max); a box with a NaN matches nothing
+ *   out_counts[n_boxes]      u32 leaves per query (may be NULL)
+ *   out_pairs[2 * capacity]  u32 (query, geometry index) interleaved, sorted by (query, index) (NULL + capacity 0: count only)
+ *   *n_pairs                 total, always set (GPK_ERR_CAPACITY when > capacity and pairs were asked for)
+ * Null and empty geometries have no leaf.  No geometry is read: the answer comes from the index's boxes and grid directory. */
+#define GPK_QUERY_CONTAINED    0 /* rstar RTree::locate_in_envelope */
+#define GPK_QUERY_INTERSECTING 1 /* rstar RTree::locate_in_envelope_intersecting */
+int32_t gpk_index_query_envelope(const gpk_index* idx, const double* boxes4, int64_t n_boxes, int32_t mode,
+                                 uint32_t* out_counts, uint32_t* out_pairs, int64_t pair_capacity, int64_t* n_pairs,
+                                 int32_t space, void* stream);
 int32_t gpk_index_nbytes(const gpk_index* idx, int64_t* out_bytes);
 /* What the index holds (tests and bench.py report it; nothing in a join depends on the caller knowing):
  *   out = {raster side R (0: no point-in-polygon tables), one-part-per-cell ("lean") 0/1, local chains 0/1 (`test` sub-cells

@@ -119,6 +119,27 @@ def bounds(a: GeoArrowArray) -> np.ndarray:
     return out
 
 
+def envelope_query(a: GeoArrowArray, boxes, mode: str = "contained"):
+    """rstar 0.11 `RTree::locate_in_envelope` / `locate_in_envelope_intersecting` over the leaves the reference inserts — one per
+    geometry, its bounding box (spatial_index.rs:320-334, the reference's own use: :383-393,422-429) — restated by brute force:
+    `AABB::contains_envelope` (lower <= lower' and upper' <= upper) and `AABB::intersects` (closed intervals).  Null and empty
+    geometries have no leaf.  Returns (pairs (query, index) sorted, counts per query)."""
+    b = bounds(a)
+    ok = a.is_valid() & ~np.isnan(b[:, 0])
+    q = np.asarray(boxes, dtype=np.float64).reshape(-1, 4)
+    pairs, counts = [], np.zeros(len(q), dtype=np.uint32)
+    for i, (x0, y0, x1, y1) in enumerate(q):
+        x0, x1, y0, y1 = min(x0, x1), max(x0, x1), min(y0, y1), max(y0, y1)  # AABB::from_corners orders the corners (NaN stays NaN-ish: no match)
+        if mode == "contained":
+            m = ok & (b[:, 0] >= x0) & (b[:, 1] >= y0) & (b[:, 2] <= x1) & (b[:, 3] <= y1)
+        else:
+            m = ok & (b[:, 0] <= x1) & (b[:, 2] >= x0) & (b[:, 1] <= y1) & (b[:, 3] >= y0)
+        idx = np.nonzero(m)[0]
+        counts[i] = len(idx)
+        pairs.append(np.column_stack([np.full(len(idx), i, dtype=np.uint32), idx.astype(np.uint32)]))
+    return (np.concatenate(pairs) if pairs else np.zeros((0, 2), dtype=np.uint32)), counts
+
+
 def euclidean_length(a: GeoArrowArray) -> np.ndarray:
     out = np.empty(len(a), dtype=np.float64)
     d = a.desc()
