@@ -70,7 +70,44 @@ class GeoArrowDesc(C.Structure):
         ("n_parts", C.c_int64),
         ("n_rings", C.c_int64),
         ("validity", C.c_void_p),
+        ("x", C.c_void_p),  # separated coordinates (xy NULL): Struct<x, y> GeoArrow arrays
+        ("y", C.c_void_p),
     ]
+
+
+class ArrowSchema(C.Structure):
+    """Arrow C Data Interface (what `pyarrow.Array._export_to_c` fills: py-geopolars/src/ffi.rs:12-32)"""
+
+
+ArrowSchema._fields_ = [
+    ("format", C.c_char_p),
+    ("name", C.c_char_p),
+    ("metadata", C.c_void_p),
+    ("flags", C.c_int64),
+    ("n_children", C.c_int64),
+    ("children", C.POINTER(C.POINTER(ArrowSchema))),
+    ("dictionary", C.POINTER(ArrowSchema)),
+    ("release", C.CFUNCTYPE(None, C.POINTER(ArrowSchema))),
+    ("private_data", C.c_void_p),
+]
+
+
+class ArrowArray(C.Structure):
+    pass
+
+
+ArrowArray._fields_ = [
+    ("length", C.c_int64),
+    ("null_count", C.c_int64),
+    ("offset", C.c_int64),
+    ("n_buffers", C.c_int64),
+    ("n_children", C.c_int64),
+    ("buffers", C.POINTER(C.c_void_p)),
+    ("children", C.POINTER(C.POINTER(ArrowArray))),
+    ("dictionary", C.POINTER(ArrowArray)),
+    ("release", C.CFUNCTYPE(None, C.POINTER(ArrowArray))),
+    ("private_data", C.c_void_p),
+]
 
 
 # every symbol the header declares: name -> (restype, argtypes)
@@ -81,6 +118,7 @@ _PROTOS = {
     "gpk_device_count": (C.c_int32, [C.POINTER(C.c_int32)]),
     "gpk_device_info": (C.c_int32, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int32)]),
     "gpk_geoarray_upload": (C.c_int32, [C.POINTER(GeoArrowDesc), _VP, C.POINTER(_VP)]),
+    "gpk_geoarray_from_arrow": (C.c_int32, [_VP, _VP, C.c_int32, _VP, C.POINTER(_VP), C.POINTER(C.c_int32)]),
     "gpk_geoarray_free": (C.c_int32, [_VP]),
     "gpk_geoarray_nbytes": (C.c_int32, [_VP, C.POINTER(C.c_int64)]),
     "gpk_wkb_decode": (C.c_int32, [_VP, _VP, C.c_int64, _VP, C.POINTER(C.c_int64), _VP, _VP, _VP, _VP]),

@@ -30,6 +30,7 @@ SOURCES = [
     "gpk_rowwise.hip",
     "gpk_hull.hip",
     "gpk_wkb.cpp",
+    "gpk_arrow.cpp",
     "gpk_wkb_device.hip",
     "gpk_wkb_encode.hip",
     "gpk_take.hip",

@@ -354,7 +354,8 @@ static int32_t validate_desc(const gpk_geoarrow_desc* d) {
         return fail(GPK_ERR_INVALID_ARGUMENT, "negative length");
     if (d->n_coords > INT32_MAX || d->n_geoms > INT32_MAX)
         return fail(GPK_ERR_INVALID_OFFSETS, "arrays beyond i32 offsets are not supported (split the chunk)");
-    if (d->n_coords > 0 && !d->xy) return fail(GPK_ERR_INVALID_ARGUMENT, "xy is NULL");
+    if (d->n_coords > 0 && !d->xy && !(d->x && d->y)) return fail(GPK_ERR_INVALID_ARGUMENT, "xy is NULL (and x / y are not both given)");
+    if (d->xy && (d->x || d->y)) return fail(GPK_ERR_INVALID_ARGUMENT, "coordinates given twice: xy and x / y");
     switch (d->geom_type) {
     case GPK_GEOM_POINT:
         if (d->n_coords != d->n_geoms)
@@ -390,6 +391,12 @@ static int32_t check_offsets(const int32_t* off, int64_t n, int64_t child_len, c
         return fail(GPK_ERR_INVALID_OFFSETS, "%s[last] = %d but child length is %lld", what, off[n],
                     (long long)child_len);
     return GPK_OK;
+}
+
+// Struct<x, y> coordinates -> the interleaved form the kernels read: two coalesced 8-byte streams in, one 16-byte stream out
+__global__ __launch_bounds__(256) void interleave_xy_kernel(const double* __restrict__ x, const double* __restrict__ y, int64_t n, double2* __restrict__ xy) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) xy[i] = make_double2(x[i], y[i]);
 }
 
 int32_t gpk_geoarray_upload(const gpk_geoarrow_desc* d, void* stream, gpk_geoarray** out) {
@@ -444,7 +451,38 @@ int32_t gpk_geoarray_upload(const gpk_geoarrow_desc* d, void* stream, gpk_geoarr
          (const void**)&a->d.ring_off},
         {d->validity, (size_t)((d->n_geoms + 7) / 8), (const void**)&a->d.validity},
     };
+    if (!d->xy && d->x && d->y && d->n_coords > 0) {
+        // separated coordinates: interleaved on the device into a buffer the handle owns.  Host arrays travel as they are (two
+        // copies into a scratch block that goes back to the block cache) — the host never builds the interleaved array.
+        const size_t half = sizeof(double) * (size_t)d->n_coords;
+        void *xy_dev = nullptr, *tmp = nullptr;
+        hipError_t e = cached_malloc(&xy_dev, 2 * half);
+        const double *xs = d->x, *ys = d->y;
+        if (e == hipSuccess && d->mem_space != GPK_MEM_DEVICE) {
+            e = cached_malloc(&tmp, 2 * half);
+            if (e == hipSuccess) e = hipMemcpyAsync(tmp, d->x, half, hipMemcpyHostToDevice, s);
+            if (e == hipSuccess) e = hipMemcpyAsync((char*)tmp + half, d->y, half, hipMemcpyHostToDevice, s);
+            xs = (const double*)tmp;
+            ys = (const double*)((char*)tmp + half);
+        }
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(interleave_xy_kernel, dim3((unsigned)((d->n_coords + 255) / 256)), dim3(256), 0, s, xs, ys, d->n_coords, (double2*)xy_dev);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess && tmp) e = hipStreamSynchronize(s);  // (the scratch block is handed back below)
+        if (tmp) cached_free(tmp);
+        if (e != hipSuccess) {
+            if (xy_dev) cached_free(xy_dev);
+            gpk_geoarray_free(a);
+            return fail(e == hipErrorOutOfMemory ? GPK_ERR_OOM : GPK_ERR_DEVICE, "upload: %s", hipGetErrorString(e));
+        }
+        a->owned[0] = xy_dev;
+        a->d.xy = (const double2*)xy_dev;
+        a->nbytes += (int64_t)(2 * half);
+        bufs[0].src = nullptr;  // (done)
+    }
     for (int i = 0; i < 5; ++i) {
+        if (i == 0 && a->owned[0]) continue;
         *bufs[i].dst = nullptr;
         if (!bufs[i].src || bufs[i].bytes == 0) continue;
         a->nbytes += (int64_t)bufs[i].bytes;

@@ -272,9 +272,18 @@ struct Writer {
         u32(type);
         u32(count);
     }
-    void coords(const double* xy, int64_t c0, int64_t c1) {
-        memcpy(p, xy + 2 * c0, sizeof(double) * 2 * (size_t)(c1 - c0));
-        p += 16 * (c1 - c0);
+    // (interleaved coordinates, or the descriptor's separated x / y arrays)
+    void coords(const gpk_geoarrow_desc* d, int64_t c0, int64_t c1) {
+        if (d->xy) {
+            memcpy(p, d->xy + 2 * c0, sizeof(double) * 2 * (size_t)(c1 - c0));
+            p += 16 * (c1 - c0);
+            return;
+        }
+        for (int64_t c = c0; c < c1; ++c) {
+            memcpy(p, d->x + c, 8);
+            memcpy(p + 8, d->y + c, 8);
+            p += 16;
+        }
     }
 };
 inline bool row_valid(const uint8_t* v, int64_t i) { return !v || ((v[i >> 3] >> (i & 7)) & 1); }
@@ -309,7 +318,7 @@ extern "C" int32_t gpk_wkb_encode(const gpk_geoarrow_desc* d, int32_t* out_offse
         return fail(GPK_ERR_MISMATCHED_GEOMETRY, "unknown geometry type %d", t);
     if (d->n_geoms > 0 && ((t != GPK_GEOM_POINT && !d->geom_offsets) ||
                            ((t == GPK_GEOM_POLYGON || t == GPK_GEOM_MULTILINESTRING || t == GPK_GEOM_MULTIPOLYGON) && !d->ring_offsets) ||
-                           (t == GPK_GEOM_MULTIPOLYGON && !d->part_offsets) || (d->n_coords > 0 && !d->xy)))
+                           (t == GPK_GEOM_MULTIPOLYGON && !d->part_offsets) || (d->n_coords > 0 && !d->xy && !(d->x && d->y))))
         return fail(GPK_ERR_INVALID_OFFSETS, "missing offsets / coordinates for geometry type %d", t);
     int64_t total = 0;
     if (out_offsets) out_offsets[0] = 0;
@@ -328,7 +337,7 @@ extern "C" int32_t gpk_wkb_encode(const gpk_geoarrow_desc* d, int32_t* out_offse
         w.header(3u, (uint32_t)(r1 - r0));
         for (int32_t r = r0; r < r1; ++r) {
             w.u32((uint32_t)(ro[r + 1] - ro[r]));
-            w.coords(d->xy, ro[r], ro[r + 1]);
+            w.coords(d, ro[r], ro[r + 1]);
         }
     };
     for (int64_t g = 0; g < d->n_geoms; ++g) {
@@ -337,18 +346,18 @@ extern "C" int32_t gpk_wkb_encode(const gpk_geoarrow_desc* d, int32_t* out_offse
         case GPK_GEOM_POINT:
             w.u8(1);
             w.u32(1u);
-            w.coords(d->xy, g, g + 1);
+            w.coords(d, g, g + 1);
             break;
         case GPK_GEOM_LINESTRING:
             w.header(2u, (uint32_t)(go[g + 1] - go[g]));
-            w.coords(d->xy, go[g], go[g + 1]);
+            w.coords(d, go[g], go[g + 1]);
             break;
         case GPK_GEOM_MULTIPOINT:
             w.header(4u, (uint32_t)(go[g + 1] - go[g]));
             for (int32_t i = go[g]; i < go[g + 1]; ++i) {
                 w.u8(1);
                 w.u32(1u);
-                w.coords(d->xy, i, i + 1);
+                w.coords(d, i, i + 1);
             }
             break;
         case GPK_GEOM_POLYGON: polygon(go[g], go[g + 1]); break;
@@ -356,7 +365,7 @@ extern "C" int32_t gpk_wkb_encode(const gpk_geoarrow_desc* d, int32_t* out_offse
             w.header(5u, (uint32_t)(go[g + 1] - go[g]));
             for (int32_t l = go[g]; l < go[g + 1]; ++l) {
                 w.header(2u, (uint32_t)(ro[l + 1] - ro[l]));
-                w.coords(d->xy, ro[l], ro[l + 1]);
+                w.coords(d, ro[l], ro[l + 1]);
             }
             break;
         default:

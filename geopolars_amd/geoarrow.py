@@ -311,13 +311,21 @@ class DeviceGeoArray:
         geom_type: int, xy, geom_offsets=None, part_offsets=None, ring_offsets=None, validity=None, stream: int = 0
     ) -> "DeviceGeoArray":
         """Zero-copy view over torch CUDA tensors (xy: (n,2) float64; offsets int32).  The tensors are
-        kept alive by the returned object — the borrowed-buffer contract of the C ABI."""
+        kept alive by the returned object — the borrowed-buffer contract of the C ABI.  `xy` may also be a PAIR (x, y) of float64
+        tensors — Struct<x, y> coordinates: they are interleaved on the device into a buffer the handle owns."""
         d = GeoArrowDesc()
         d.geom_type = geom_type
         d.mem_space = _abi.MEM_DEVICE
-        d.n_coords = xy.shape[0]
-        d.xy = xy.data_ptr()
-        tensors = [xy]
+        if isinstance(xy, (tuple, list)):
+            xs, ys = xy
+            d.n_coords = xs.shape[0]
+            d.x, d.y = xs.data_ptr(), ys.data_ptr()
+            tensors = [xs, ys]
+            xy = xs
+        else:
+            d.n_coords = xy.shape[0]
+            d.xy = xy.data_ptr()
+            tensors = [xy]
         for name, t in (("geom_offsets", geom_offsets), ("part_offsets", part_offsets), ("ring_offsets", ring_offsets), ("validity", validity)):
             if t is not None:
                 setattr(d, name, t.data_ptr())
@@ -348,6 +356,34 @@ class DeviceGeoArray:
         _abi.check(_abi.lib().gpk_geoarray_download(self.handle, sizes, None, None, None, None, stream))
         self.n_coords = int(sizes[0])
         self._validity = None if validity is None else np.ascontiguousarray(validity, dtype=np.uint8)
+        return self
+
+    @staticmethod
+    def from_arrow(column, geom_type: int = -1, stream: int = 0) -> "DeviceGeoArray":
+        """A pyarrow geometry column -> device-resident GeoArrow through the Arrow C Data Interface (gpk_geoarray_from_arrow), the
+        way the reference moves every Series across its FFI boundary (py-geopolars/src/ffi.rs:12-32: `_export_to_c` into two
+        structs; chunked columns are rechunked first, :56).  WKB binary / large binary columns, and native GeoArrow nestings over
+        Struct<x, y> (internals/geoseries.py:86-113) or FixedSizeList<f64, 2> coordinates; slices are fine.  `geom_type`:
+        GEOM_MULTIPOINT / GEOM_MULTILINESTRING to read one / two list levels as those types (default LINESTRING / POLYGON)."""
+        import pyarrow as pa
+
+        if isinstance(column, pa.ChunkedArray):
+            column = column.combine_chunks() if column.num_chunks != 1 else column.chunk(0)
+        c_array, c_schema = _abi.ArrowArray(), _abi.ArrowSchema()
+        column._export_to_c(C.addressof(c_array), C.addressof(c_schema))
+        out = C.c_void_p()
+        gt = C.c_int32(-1)
+        try:
+            _abi.check(_abi.lib().gpk_geoarray_from_arrow(C.addressof(c_array), C.addressof(c_schema), geom_type, stream, C.byref(out), C.byref(gt)))
+        finally:  # the importer's duty (the library only borrowed the structs)
+            if c_array.release:
+                c_array.release(C.byref(c_array))
+            if c_schema.release:
+                c_schema.release(C.byref(c_schema))
+        self = DeviceGeoArray(out.value, int(gt.value), len(column), -1)
+        sizes = (C.c_int64 * 4)()
+        _abi.check(_abi.lib().gpk_geoarray_download(self.handle, sizes, None, None, None, None, stream))
+        self.n_coords = int(sizes[0])
         return self
 
     def to_wkb(self, stream: int = 0) -> tuple[np.ndarray, np.ndarray]:

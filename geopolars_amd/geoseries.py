@@ -66,6 +66,14 @@ class GeoSeries:
         return GeoSeries(None, device=DeviceGeoArray.from_wkb(values, offsets, validity))
 
     @staticmethod
+    def from_arrow(column, geom_type: int = -1) -> "GeoSeries":
+        """`geopolars.from_arrow` (py-geopolars/src/ffi.rs:93-109 calls it on the way back; the Series it wraps crosses into Rust
+        through the Arrow C Data Interface, :12-32): a pyarrow geometry column — WKB binary, or native GeoArrow with Struct<x, y>
+        (internals/geoseries.py:86-113) or FixedSizeList<f64, 2> coordinates — handed to the library as the two exported structs
+        (gpk_geoarray_from_arrow); the column lands in HBM without a host-side rewrite."""
+        return GeoSeries(None, device=DeviceGeoArray.from_arrow(column, geom_type))
+
+    @staticmethod
     def from_points(xy) -> "GeoSeries":
         return GeoSeries(GeoArrowArray.from_points(xy))
 

@@ -73,8 +73,12 @@ extern "C" {
  *   POLYGON / MULTILINESTRING     geom_offsets[n+1] -> rings ; ring_offsets[n_rings+1] -> coords
  *   MULTIPOLYGON                  geom_offsets[n+1] -> parts ; part_offsets[n_parts+1] -> rings ;
  *                                 ring_offsets[n_rings+1] -> coords
- * coords are interleaved xy (FixedSizeList<f64,2>); rings are stored closed (first == last).
- * Unused offset pointers are NULL.  All buffers of one descriptor live in `mem_space`.
+ * coords are interleaved xy (FixedSizeList<f64,2>) — or SEPARATED: `xy` NULL and `x`, `y` two arrays of n_coords doubles, the
+ * Struct<x: f64, y: f64> coordinate arrays the reference's Python layer builds with `pyarrow.StructArray.from_arrays([x, y])`
+ * (py-geopolars/python/geopolars/internals/geoseries.py:86-113).  Kernels read interleaved coordinates (one 16-byte request per
+ * vertex); a separated descriptor is interleaved ON THE DEVICE while it is uploaded — one pass, no host-side copy — so the
+ * handle owns its coordinates even when the descriptor's buffers are device memory (offsets and validity are still borrowed).
+ * Rings are stored closed (first == last).  Unused offset pointers are NULL.  All buffers of one descriptor live in `mem_space`.
  */
 typedef struct gpk_geoarrow_desc {
     int32_t        geom_type;     /* GPK_GEOM_* */
@@ -88,6 +92,8 @@ typedef struct gpk_geoarrow_desc {
     int64_t        n_parts;       /* MULTIPOLYGON only */
     int64_t        n_rings;       /* POLYGON / MULTILINESTRING / MULTIPOLYGON */
     const uint8_t* validity;      /* Arrow bitmap, NULL = all valid */
+    const double*  x;             /* separated coordinates (xy == NULL): n_coords doubles each, else NULL */
+    const double*  y;
 } gpk_geoarrow_desc;
 
 typedef struct gpk_geoarray gpk_geoarray; /* device-resident SoA copy (or borrowed view) */
@@ -140,6 +146,45 @@ int32_t gpk_wkb_encode(const gpk_geoarrow_desc* desc, int32_t* out_offsets, uint
                        int64_t capacity, int64_t* n_bytes);
 int32_t gpk_geoarray_to_wkb(const gpk_geoarray* a, int32_t* out_offsets, uint8_t* out_values,
                             int64_t capacity, int64_t* n_bytes, int32_t out_space, void* stream);
+/* The reference's FFI seam — the Arrow C Data Interface (py-geopolars/src/ffi.rs:12-32: a pyarrow array exported with `_export_to_c`,
+ * rechunked to ONE array first, :56) — as an entry point: `array` / `schema` are the two exported structs of a geometry column in
+ * host memory, BORROWED for the call (the caller releases them as it would after any import).  Accepted columns
+ *   Binary / LargeBinary ("z" / "Z")                     WKB rows: decoded on the GPU like gpk_geoarray_from_wkb
+ *   [List<]* Struct<x: f64, y: f64>                       native GeoArrow with SEPARATED coordinates, as the reference's Python layer
+ *                                                         builds them (internals/geoseries.py:86-113); 0 - 3 list levels, "+l" or "+L"
+ *   [List<]* FixedSizeList<f64, 2>                        native GeoArrow, interleaved
+ * Sliced arrays (offset != 0 at any level), 64-bit list offsets (narrowed after a range check) and validity bitmaps with a bit
+ * offset are handled.  One and two list levels are two geometry types each: `geom_type_hint` (GPK_GEOM_*, or -1) or the schema's
+ * ARROW:extension:name (geoarrow.multipoint / geoarrow.multilinestring) picks MULTIPOINT / MULTILINESTRING, else LINESTRING / POLYGON.
+ * *out_geom_type (may be NULL) = the handle's type.  Anything else: GPK_ERR_MISMATCHED_GEOMETRY. */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+struct ArrowSchema {
+    const char* format;
+    const char* name;
+    const char* metadata;
+    int64_t flags;
+    int64_t n_children;
+    struct ArrowSchema** children;
+    struct ArrowSchema* dictionary;
+    void (*release)(struct ArrowSchema*);
+    void* private_data;
+};
+struct ArrowArray {
+    int64_t length;
+    int64_t null_count;
+    int64_t offset;
+    int64_t n_buffers;
+    int64_t n_children;
+    const void** buffers;
+    struct ArrowArray** children;
+    struct ArrowArray* dictionary;
+    void (*release)(struct ArrowArray*);
+    void* private_data;
+};
+#endif
+int32_t gpk_geoarray_from_arrow(const struct ArrowArray* array, const struct ArrowSchema* schema, int32_t geom_type_hint,
+                                void* stream, gpk_geoarray** out, int32_t* out_geom_type);
 /* Device -> host copy of a handle's GeoArrow buffers.  sizes[4] = {n_coords, n_parts, n_rings, n_geoms} is always
  * filled; NULL buffers are skipped (call once with NULLs to size the buffers). */
 int32_t gpk_geoarray_download(const gpk_geoarray* a, int64_t sizes[4], double* xy, int32_t* geom_offsets,

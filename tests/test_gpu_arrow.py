@@ -1,0 +1,179 @@
+"""GPU tests of the boundary the reference actually has: the Arrow C Data Interface (py-geopolars/src/ffi.rs:12-32 — a pyarrow array
+exported with `_export_to_c` into an ArrowArray / ArrowSchema pair) and the coordinate layout its Python layer builds — Struct<x, y>
+fields from `pyarrow.StructArray.from_arrays([coords[:, 0], coords[:, 1]], ["x", "y"])` under 0 - 2 `ListArray` levels
+(py-geopolars/python/geopolars/internals/geoseries.py:86-113).  gpk_geoarray_from_arrow must land every such column in HBM so that
+the operators answer exactly as for the same geometry uploaded as interleaved GeoArrow buffers (compared through download(): bit
+equality of coordinates and offsets, and through area / bounds / a join)."""
+import ctypes as C
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+from geopolars_amd import _abi, synth
+from geopolars_amd.geoarrow import DeviceGeoArray, GeoArrowArray
+from geopolars_amd.geoseries import GeoSeries
+from geopolars_amd.spatial_index import SpatialIndex, join_pairs
+
+pytestmark = pytest.mark.gpu
+
+
+def _struct_coords(xy):
+    return pa.StructArray.from_arrays([pa.array(xy[:, 0]), pa.array(xy[:, 1])], ["x", "y"])
+
+
+def _nested(host: GeoArrowArray, coords, large=False):
+    """the reference's construction (internals/geoseries.py:86-113), for every nesting"""
+    levels = {
+        _abi.GEOM_POINT: [],
+        _abi.GEOM_LINESTRING: [host.geom_offsets],
+        _abi.GEOM_MULTIPOINT: [host.geom_offsets],
+        _abi.GEOM_POLYGON: [host.ring_offsets, host.geom_offsets],
+        _abi.GEOM_MULTILINESTRING: [host.ring_offsets, host.geom_offsets],
+        _abi.GEOM_MULTIPOLYGON: [host.ring_offsets, host.part_offsets, host.geom_offsets],
+    }[host.geom_type]
+    arr = coords
+    for off in levels:
+        if large:
+            arr = pa.LargeListArray.from_arrays(pa.array(off.astype(np.int64), type=pa.int64()), arr)
+        else:
+            arr = pa.ListArray.from_arrays(pa.array(off, type=pa.int32()), arr)
+    return arr
+
+
+def _same(dev: DeviceGeoArray, host: GeoArrowArray):
+    got = dev.download()
+    assert got.geom_type == host.geom_type and len(got) == len(host)
+    assert np.array_equal(got.xy, host.xy)
+    for name in ("geom_offsets", "part_offsets", "ring_offsets"):
+        a, b = getattr(got, name), getattr(host, name)
+        assert (a is None) == (b is None), name
+        if a is not None:
+            assert np.array_equal(a, b), name
+
+
+CASES = {
+    "points": lambda: synth.uniform_points(5000, seed=2),
+    "linestrings": lambda: synth.random_linestrings(700, seed=3, max_log2=5.0),
+    "polygons": lambda: synth.star_polygons(400, 24),
+    "multipolygons": lambda: synth.powerlaw_multipolygons(300, seed=5, cap=200),
+}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+@pytest.mark.parametrize("coords", ["struct", "interleaved"])
+@pytest.mark.parametrize("large", [False, True])
+def test_native_geoarrow_columns_through_the_c_data_interface(gpk, oracle, case, coords, large):
+    host = CASES[case]()
+    c = _struct_coords(host.xy) if coords == "struct" else pa.FixedSizeListArray.from_arrays(pa.array(host.xy.reshape(-1)), 2)
+    col = _nested(host, c, large)
+    dev = DeviceGeoArray.from_arrow(col)
+    assert dev.geom_type == host.geom_type
+    _same(dev, host)
+    s = GeoSeries(None, device=dev)
+    if host.geom_type != _abi.GEOM_POINT:
+        assert np.array_equal(s.bounds(), oracle.bounds(host))
+    if host.geom_type in (_abi.GEOM_POLYGON, _abi.GEOM_MULTIPOLYGON):
+        np.testing.assert_allclose(s.area(), oracle.area(host), rtol=1e-9, atol=0)
+
+
+def test_slices_of_every_level_and_chunked_columns(gpk, oracle):
+    host = synth.star_polygons(300, 16)
+    col = _nested(host, _struct_coords(host.xy))
+    for lo, n in ((0, 300), (17, 100), (299, 1), (120, 0)):
+        sl = col.slice(lo, n)
+        want = host.take(np.arange(lo, lo + n))
+        _same(DeviceGeoArray.from_arrow(sl), want)
+    # a column in three chunks is rechunked first (ffi.rs:56)
+    chunked = pa.chunked_array([col.slice(0, 100), col.slice(100, 150), col.slice(250, 50)])
+    _same(DeviceGeoArray.from_arrow(chunked), host)
+    # sliced COORDINATE children (a struct array whose fields carry their own offsets)
+    pts = synth.uniform_points(1000, seed=9)
+    st = _struct_coords(pts.xy).slice(100, 500)
+    _same(DeviceGeoArray.from_arrow(st), pts.take(np.arange(100, 600)))
+    fl = pa.FixedSizeListArray.from_arrays(pa.array(pts.xy.reshape(-1)), 2).slice(3, 77)
+    _same(DeviceGeoArray.from_arrow(fl), pts.take(np.arange(3, 80)))
+
+
+def test_wkb_columns_binary_and_large_binary_with_nulls(gpk, oracle):
+    host = synth.star_polygons(200, 12)
+    values, offsets = host.to_wkb()
+    rows = [bytes(values[offsets[i] : offsets[i + 1]]) for i in range(len(host))]
+    rows[5] = None
+    rows[77] = None
+    for typ in (pa.binary(), pa.large_binary()):
+        col = pa.array(rows, type=typ)
+        dev = DeviceGeoArray.from_arrow(col)
+        assert dev.geom_type == _abi.GEOM_POLYGON and dev.n_geoms == 200
+        got = dev.download()
+        valid = got.is_valid()
+        assert not valid[5] and not valid[77] and valid.sum() == 198
+        area = GeoSeries(None, device=dev).area()
+        want = oracle.area(host)
+        ok = np.ones(200, dtype=bool)
+        ok[[5, 77]] = False
+        np.testing.assert_allclose(area[ok], want[ok], rtol=1e-9, atol=0)
+        # a slice whose validity bitmap starts in the middle of a byte
+        sl = DeviceGeoArray.from_arrow(col.slice(3, 100))
+        v = sl.download().is_valid()
+        assert not v[2] and not v[74] and v.sum() == 98
+
+
+def test_multi_types_by_hint_and_by_extension_name(gpk):
+    rng = np.random.default_rng(4)
+    xy = rng.uniform(0, 100, (60, 2))
+    off = np.array([0, 10, 10, 25, 60], dtype=np.int32)
+    col = pa.ListArray.from_arrays(pa.array(off), _struct_coords(xy))
+    assert DeviceGeoArray.from_arrow(col).geom_type == _abi.GEOM_LINESTRING
+    assert DeviceGeoArray.from_arrow(col, geom_type=_abi.GEOM_MULTIPOINT).geom_type == _abi.GEOM_MULTIPOINT
+    # the schema's ARROW:extension:name travels in the ArrowSchema's metadata
+    field = pa.field("geometry", col.type, metadata={"ARROW:extension:name": "geoarrow.multipoint"})
+    lib = _abi.lib()
+    c_array, c_schema = _abi.ArrowArray(), _abi.ArrowSchema()
+    col._export_to_c(C.addressof(c_array))
+    field._export_to_c(C.addressof(c_schema))
+    out, gt = C.c_void_p(), C.c_int32(-1)
+    try:
+        _abi.check(lib.gpk_geoarray_from_arrow(C.addressof(c_array), C.addressof(c_schema), -1, None, C.byref(out), C.byref(gt)))
+    finally:
+        c_array.release(C.byref(c_array))
+        c_schema.release(C.byref(c_schema))
+    assert gt.value == _abi.GEOM_MULTIPOINT
+    lib.gpk_geoarray_free(out)
+    # what is not a geometry column says so
+    for bad in (pa.array([1.0, 2.0]), pa.array(["a", "b"]), pa.ListArray.from_arrays(pa.array(off), pa.array(rng.uniform(size=60)))):
+        with pytest.raises(_abi.GeopolarsHipError) as e:
+            DeviceGeoArray.from_arrow(bad)
+        assert e.value.code == _abi.GPK_ERR_MISMATCHED_GEOMETRY
+    with pytest.raises(_abi.GeopolarsHipError):
+        DeviceGeoArray.from_arrow(col, geom_type=_abi.GEOM_POLYGON)
+
+
+def test_separated_device_buffers_and_a_join_over_struct_coordinates(gpk, oracle):
+    """points handed over as TWO device arrays (x, y): interleaved during the upload, then the headline join"""
+    import torch
+
+    pts = synth.uniform_points(200_000, seed=12)
+    polys = synth.star_polygons(1000, 64)
+    dev = torch.device("cuda", 0)
+    x, y = torch.from_numpy(np.ascontiguousarray(pts.xy[:, 0])).to(dev), torch.from_numpy(np.ascontiguousarray(pts.xy[:, 1])).to(dev)
+    dpts = DeviceGeoArray.from_device_buffers(_abi.GEOM_POINT, (x, y))
+    _same(dpts, pts)
+    right = GeoSeries.from_arrow(_nested(polys, _struct_coords(polys.xy)))
+    ep, ec, _ = oracle.spatial_join(pts, polys, "intersects", mode=0)
+    gp, gc = join_pairs(GeoSeries(None, device=dpts), right, "intersects", r_index=SpatialIndex(right))
+    assert np.array_equal(gc, ec) and np.array_equal(gp, ep)
+    # host x / y arrays through the descriptor, and the host WKB encoder reading them
+    d = pts.desc()
+    xs, ys = np.ascontiguousarray(pts.xy[:, 0]), np.ascontiguousarray(pts.xy[:, 1])
+    d.xy, d.x, d.y = None, xs.ctypes.data, ys.ctypes.data
+    out = C.c_void_p()
+    _abi.check(_abi.lib().gpk_geoarray_upload(C.byref(d), None, C.byref(out)))
+    _same(DeviceGeoArray(out.value, _abi.GEOM_POINT, len(pts), len(pts)), pts)
+    nb = C.c_int64(0)
+    off = np.zeros(len(pts) + 1, dtype=np.int32)
+    _abi.check(_abi.lib().gpk_wkb_encode(C.byref(d), off.ctypes.data, None, 0, C.byref(nb)))
+    vals = np.zeros(nb.value, dtype=np.uint8)
+    _abi.check(_abi.lib().gpk_wkb_encode(C.byref(d), off.ctypes.data, vals.ctypes.data, len(vals), C.byref(nb)))
+    v2, o2 = pts.to_wkb()
+    assert np.array_equal(vals, v2) and np.array_equal(off, o2)
