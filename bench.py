@@ -7,7 +7,9 @@
 Default = the headline, `configs[1]` ("C2"): predicate evals/s of the 10M-point x 1k-polygon (64-vertex)
 point-in-polygon join.  The other configurations print one line each in the same format:
 
-  c2  10M random points contains() against 1k 64-vertex polygons            gpk_spatial_join_async   weak scaling
+  c2  10M random points contains() against 1k 64-vertex polygons            gpk_spatial_join_async   STRONG scaling (the 10M-point
+                                                                                                     problem is fixed: BASELINE's "1/2/4/8 GPU";
+                                                                                                     the weak form rides along in config)
   c3  10M points euclidean distance to 100k linestrings (4-256 segments)    gpk_distance_rowwise     weak scaling
   c4  1M x 1M polygon intersects() spatial join, left side row-sharded      gpk_spatial_join         strong scaling
   c5  6.25M points (one rank's share of 50M) within() 5M power-law          gpk_spatial_join_async   weak scaling
@@ -323,52 +325,104 @@ def run_c2(ctx: Ctx) -> None:
         polys_host = broadcast_geoarray(polys_host, 0, device=dev)  # RCCL, once, outside the timed region
     polys = DeviceGeoArray.upload(polys_host, stream=stream)
     index = SpatialIndex.from_device(polys, stream=stream)
-    # `rotate` distinct input / output sets: each step reads points it has not seen for rotate-1 steps and writes outputs
-    # nobody has read (3 x (160 + 40 + 80) MB + the library's 40 MB code scratch >> the 256 MiB Infinity Cache)
+    # STRONG scaling is the headline (BASELINE.json: "10M pts x 1k polys PIP, 1/2/4/8 GPU" — the 10M-point problem is fixed): rank r owns
+    # rows [r n / W, (r + 1) n / W) of the SAME 10M points and emits pairs with left_row_base = its first row; the weak-scaled form
+    # (10M points per GPU) is measured in the same run and reported beside it (config.weak_scaling).  At N = 1 they are one measurement.
+    W = ctx.world
+    lo, hi = (ctx.rank * n) // W, ((ctx.rank + 1) * n) // W
+    if args.as_shard:  # test hook: this single process plays shard r of w of the strong-scaled problem (the row split, the pairs' row base and
+        r_, w_ = (int(v) for v in args.as_shard.split("/"))  # the parity check of a shard run on a one-GPU box; the line is not a measurement)
+        lo, hi = (r_ * n) // w_, ((r_ + 1) * n) // w_
     R = max(1, args.rotate)
-    sets = []
-    t_h2d = None
-    for r in range(R):
-        pts_host = synth.uniform_points(n, seed=synth.SEED + 1 + ctx.rank + 1000 * r)  # each rank: its own shard of the left series
-        if r == 0 and ctx.rank == 0:
-            pinned = torch.from_numpy(pts_host.xy).pin_memory()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            xy = pinned.to(dev, non_blocking=True)
-            torch.cuda.synchronize()
-            t_h2d = time.perf_counter() - t0  # the PCIe leg a host-buffer boundary would add per step (never part of `value`)
-            del pinned
-        else:
-            xy = torch.from_numpy(pts_host.xy).to(dev)
-        sets.append(
-            {
-                "host": pts_host,
-                "pts": DeviceGeoArray.from_device_buffers(_abi.GEOM_POINT, xy, stream=stream),
-                "counts": torch.empty(n, dtype=torch.int32, device=dev),
-                "pairs": torch.empty((n, 2), dtype=torch.int32, device=dev),  # capacity: one hit per point (disjoint polygons)
-                "total": torch.zeros(1, dtype=torch.int64, device=dev),
-            }
-        )
-    torch.cuda.synchronize()
+
+    def build_sets(rows_lo: int, rows_hi: int, seed_rank: int, time_h2d: bool):
+        """`rotate` distinct input / output sets: each step reads points it has not seen for rotate-1 steps and writes outputs nobody
+        has read (3 x (160 + 40 + 80) MB + the library's scratch >> the 256 MiB Infinity Cache)"""
+        out, t_h2d = [], None
+        k = rows_hi - rows_lo
+        for r in range(R):
+            pts_all = synth.uniform_points(n, seed=synth.SEED + 1 + seed_rank + 1000 * r)
+            pts_host = pts_all if (rows_lo, rows_hi) == (0, n) else pts_all.take(np.arange(rows_lo, rows_hi))
+            if time_h2d and r == 0 and ctx.rank == 0:
+                pinned = torch.from_numpy(pts_host.xy).pin_memory()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                xy = pinned.to(dev, non_blocking=True)
+                torch.cuda.synchronize()
+                t_h2d = time.perf_counter() - t0  # the PCIe leg a host-buffer boundary would add per step (never part of `value`)
+                del pinned
+            else:
+                xy = torch.from_numpy(pts_host.xy).to(dev)
+            out.append(
+                {
+                    "host": pts_host,
+                    "pts": DeviceGeoArray.from_device_buffers(_abi.GEOM_POINT, xy, stream=stream),
+                    "counts": torch.empty(k, dtype=torch.int32, device=dev),
+                    "pairs": torch.empty((max(k, 1), 2), dtype=torch.int32, device=dev),  # capacity: one hit per point (disjoint polygons)
+                    "total": torch.zeros(1, dtype=torch.int64, device=dev),
+                    "base": rows_lo,
+                }
+            )
+        torch.cuda.synchronize()
+        return out, t_h2d
+
+    sets, t_h2d = build_sets(lo, hi, 0, True)  # (strong: every rank slices the SAME columns — seed independent of the rank)
     sync_steps = args.sync_steps or args.index_per_step
     last = {"set": 0}
+    cur = {"sets": sets}
 
     def step(i: int) -> None:
-        """One full pass: 10M points -> counts + sorted (l, r) pairs + total, all written to HBM.  Default: the
+        """One full pass: this rank's points -> counts + sorted (l, r) pairs + total, all written to HBM.  Default: the
         stream-ordered entry point (steps queue up on the HIP stream; the timed region ends with a synchronise, so
         every step has completed); --sync-steps: the blocking entry point, one host round trip per step."""
-        s = sets[i % R]
+        s = cur["sets"][i % R]
         last["set"] = i % R
         if sync_steps:
-            idx = SpatialIndex.from_device(polys, stream=stream) if args.index_per_step else index
-            join_pairs_device(s["pts"], polys, idx, "intersects", s["counts"], s["pairs"], left_row_base=0, stream=stream)
+            idx = SpatialIndex.from_device(polys, stream=stream, light=True) if args.index_per_step else index
+            join_pairs_device(s["pts"], polys, idx, "intersects", s["counts"], s["pairs"], left_row_base=s["base"], stream=stream)
+            if args.index_per_step:
+                idx.free()
         else:
-            join_pairs_enqueue(s["pts"], polys, index, "intersects", s["counts"], s["pairs"], s["total"], left_row_base=0, stream=stream)
+            join_pairs_enqueue(s["pts"], polys, index, "intersects", s["counts"], s["pairs"], s["total"], left_row_base=s["base"], stream=stream)
 
     # (a step of the fused join is the one launch `gpk_pip_tile`; with GPK_TILE_KERNEL=route — the round-3 pair — the writer shows up)
     elapsed, k_tile, n_tile, warm = ctx.timed(step, "gpk_pip_tile", args.steps, args.warmup, profile=not args.no_profile,
                                               one_launch_steps=lambda w: "gpk_pip_write" not in w and not sync_steps)
     fused = "gpk_pip_write" not in warm
+    rank_seconds_main = list(getattr(ctx, "rank_seconds", []))
+    weak = None
+    if W > 1 and not args.no_weak:  # the weak-scaled form beside the headline: 10M points PER GPU (rank-dependent seeds)
+        del sets
+        torch.cuda.empty_cache()
+        cur["sets"], _ = build_sets(0, n, ctx.rank + 1, False)
+        w_elapsed, w_tile, _, _ = ctx.timed(step, "gpk_pip_tile", args.steps, args.warmup, profile=not args.no_profile,
+                                            one_launch_steps=lambda w: "gpk_pip_write" not in w and not sync_steps)
+        weak = {"value": float(W) * n * m * args.steps / w_elapsed, "unit": "evals/s", "ms_per_step": w_elapsed / args.steps * 1e3, "points_per_gpu": n,
+                "gpk_pip_tile_ms": w_tile, "ms_per_step_per_rank": [t / args.steps * 1e3 for t in getattr(ctx, "rank_seconds", [])]}
+        cur["sets"], _ = build_sets(lo, hi, 0, False)
+        ctx.rank_seconds = rank_seconds_main
+    sets = cur["sets"]
+    # the reference's DEFAULT call shape — SpatialJoinArgs::default() has r_index: None (spatial_index.rs:24-35,60-71): the index is
+    # built inside every call — measured beside the prepared-index step on the N = 1 line (blocking entry point, index built and freed
+    # per step; a second, shorter timed region)
+    default_shape = None
+    if W == 1 and not args.index_per_step and not args.no_default_shape:
+        def step_default(i: int) -> None:
+            s_ = sets[i % R]
+            idx = SpatialIndex.from_device(polys, stream=stream, light=True)
+            join_pairs_device(s_["pts"], polys, idx, "intersects", s_["counts"], s_["pairs"], left_row_base=0, stream=stream)
+            idx.free()
+        for i in range(3):
+            step_default(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        k_def = max(5, args.steps // 2)
+        for i in range(k_def):
+            step_default(i)
+        torch.cuda.synchronize()
+        d_ms = (time.perf_counter() - t0) / k_def * 1e3
+        default_shape = {"ms_per_step": d_ms, "evals_per_s": n * m / (d_ms * 1e-3), "steps": k_def,
+                         "what": "gpk_spatial_join with r_index = None's work done per call: index built (GPK_INDEX_PIP_LIGHT), join, index freed; blocking entry point"}
     # what the exact phase did, measured on one extra untimed step (a few atomics per tile: never inside the timed region)
     st = (C.c_int64 * 4)()
     if not args.no_join_stats:
@@ -379,18 +433,19 @@ def run_c2(ctx: Ctx) -> None:
         lib.gpk_join_stats_enable(0)
     torch.cuda.synchronize()
     s_last = sets[last["set"]]
-    h = join_pairs_device(s_last["pts"], polys, index, "intersects", s_last["counts"], s_last["pairs"], left_row_base=0, stream=stream)
+    h = join_pairs_device(s_last["pts"], polys, index, "intersects", s_last["counts"], s_last["pairs"], left_row_base=s_last["base"], stream=stream)
     if ctx.rank != 0:
         ctx.finish()
         return
 
-    evals = float(ctx.world) * n * m * args.steps
+    n_local = hi - lo
+    evals = float(n) * m * args.steps  # the whole job: the fixed 10M-point problem, whatever the number of ranks
     ms_per_step = elapsed / args.steps * 1e3
     v_total = polys_host.n_coords
     # algorithmic bytes (each distinct byte once): points in, polygon coords + offsets in, hit counts out,
     # and the 8H pair bytes — all of it belongs to the ONE launch of the fused join; with the round-3 pair of kernels the pair
     # bytes belong to gpk_pip_write and the dominant launch owns the rest
-    bytes_join = 16 * n + 16 * v_total + 2 * 4 * (m + 1) + 4 * n + 8 * h
+    bytes_join = 16 * n_local + 16 * v_total + 2 * 4 * (m + 1) + 4 * n_local + 8 * h  # (of THIS rank's launch: rank 0's kernel is the one timed)
     bytes_tile = bytes_join if fused else bytes_join - 8 * h
     achieved = bytes_tile / (k_tile * 1e-3) / 1e9 if k_tile > 0 else 0.0
     traffic, valu_busy, traffic_note = None, None, None
@@ -405,8 +460,10 @@ def run_c2(ctx: Ctx) -> None:
     queued, edges = int(st[0]), int(st[1])
     step_s = ms_per_step * 1e-3
     config = {
-        "workload": f"C2: {n} uniform points contains() against {m} {args.verts}-vertex star polygons, per GPU",
-        "points_per_gpu": n,
+        "workload": f"C2: {n} uniform points contains() against {m} {args.verts}-vertex star polygons" + (f", the points row-sharded over {W} GPUs ({n_local} rows on rank 0)" if W > 1 else ""),
+        "points_total": n,
+        "points_per_gpu": n_local,
+        "rows_of_this_rank": [lo, hi],
         "polygons": m,
         "vertices_per_polygon": args.verts,
         "hits_per_step": h,
@@ -416,7 +473,9 @@ def run_c2(ctx: Ctx) -> None:
         "index_tables": index.describe(),
         "index": "rebuilt per step" if args.index_per_step else "prebuilt r_index (spatial_index.rs:20-21)",
         "call": "gpk_spatial_join (blocking)" if sync_steps else "gpk_spatial_join_async (stream-ordered; the timed region ends synchronised)",
-        "parallelism": f"row-sharded x{ctx.world}, right side replicated",
+        "parallelism": f"left rows sharded x{ctx.world} (strong scaling: the {n}-point problem is fixed), right side replicated, no data-path collective",
+        "weak_scaling": weak,
+        "default_call_shape_r_index_none": default_shape,
         "input_rotation": f"{R} distinct 10M-point inputs and output sets ({R * (16 * n + 4 * n + 8 * n) / 2**20:.0f} MiB): inputs come from HBM, not from the 256 MiB Infinity Cache",
         "join_bytes_per_step": bytes_join,
         "join_GBps_end_to_end": bytes_join / step_s / 1e9,
@@ -446,16 +505,17 @@ def run_c2(ctx: Ctx) -> None:
         "algorithmic_bytes": bytes_tile,
         "source_hash": source_hash(),
     }
-    out = base_line(ctx, "predicate evals/sec (10M pts x 1k polys point-in-polygon)", evals / elapsed, "evals/s", ms_per_step, "weak", config, roofline)
-    out["parity"] = parity_point_join(s_last["host"], polys_host, "intersects", s_last["counts"], s_last["pairs"], h, args.parity_rows)
+    out = base_line(ctx, "predicate evals/sec (10M pts x 1k polys point-in-polygon)", evals / elapsed, "evals/s", ms_per_step, "strong", config, roofline)
+    out["parity"] = parity_point_join(s_last["host"], polys_host, "intersects", s_last["counts"], s_last["pairs"], h, args.parity_rows, base=s_last["base"])
     if ctx.world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_join(s_last["host"], polys_host, "intersects", s_last["counts"], args.cpu_seconds)
     ctx.finish()  # (RCCL may print its banner while the group goes down: the JSON line stays the last line of stdout)
     emit_line(out)
 
 
-def parity_point_join(pts_host, right_host, predicate: str, gpu_counts, gpu_pairs, h: int, rows: int) -> dict:
-    """GPU counts + (l, r) pairs of a RANDOM sample of left rows vs the CPU oracle on exactly those rows: bit-exact or no number."""
+def parity_point_join(pts_host, right_host, predicate: str, gpu_counts, gpu_pairs, h: int, rows: int, base: int = 0) -> dict:
+    """GPU counts + (l, r) pairs of a RANDOM sample of left rows vs the CPU oracle on exactly those rows: bit-exact or no number.
+    `base`: the left_row_base the join ran with (a rank's shard of the left rows: its pairs carry global row numbers)."""
     from oracle import pyoracle
 
     pyoracle.build()
@@ -464,6 +524,9 @@ def parity_point_join(pts_host, right_host, predicate: str, gpu_counts, gpu_pair
     ep, ec, _ = pyoracle.spatial_join(pts_host.take(idx), right_host, predicate, mode=1, n_threads=0)
     gc = gpu_counts.cpu().numpy().astype(np.uint32)
     gp = gpu_pairs[:h].cpu().numpy().astype(np.uint32)
+    if base:
+        gp = gp.copy()
+        gp[:, 0] -= np.uint32(base)
     got = pairs_of_rows(gp, idx.astype(np.uint32))
     if not np.array_equal(gc[idx], ec) or not np.array_equal(got, ep) or int(gc.sum()) != h:
         raise SystemExit("bench.py: GPU join differs from the CPU oracle on the parity sample — no speed reported")
@@ -1053,15 +1116,13 @@ def run_c5(ctx: Ctx) -> None:
             # scattered cache lines out of a multi-gigabyte index.  Its stated roofline is therefore the rate of scattered 64-byte
             # lines (TCC_EA0_RDREQ = FETCH_SIZE / 64 B, from the committed counter record) against what the memory system delivers
             # for INDEPENDENT scattered lines at this footprint (tools/micro/random_lines.hip: 50 G lines/s = 3.2 TB/s at 3 GB).
+            # Round 5: `frac` is stated against the guide's 8 TB/s like every other line (algorithmic bytes / launch time); the
+            # scattered-line view — what the memory system delivers for INDEPENDENT scattered 64-byte lines at this footprint
+            # (tools/micro/random_lines.hip: 50 G lines/s = 3.2 TB/s at 3 GB) — is a secondary field.
             lines = rec["fetch_bytes_raw"] / 64.0
-            roofline["algorithmic_bytes_streaming_model"] = {"bytes": nbytes, "achieved_GBps": achieved, "frac_of_8TBps": achieved / HBM_PEAK_GBS,
-                                                            "note": "kept for reference: more than the kernel reads (counted fetch traffic is below it)"}
-            roofline["achieved"] = lines * 64.0 / k_s / 1e9
-            roofline["peak"] = RANDOM_LINE_PEAK_GBS
-            roofline["frac"] = roofline["achieved"] / RANDOM_LINE_PEAK_GBS
-            roofline["scattered_lines_per_launch"] = lines
-            roofline["scattered_lines_per_s"] = lines / k_s
-            roofline["note"] = "bound = HBM as a source of scattered 64-byte lines: achieved = counted lines x 64 B / launch time; peak = 50 G independent random lines/s x 64 B (tools/micro/random_lines.hip at a 3 GB footprint)"
+            roofline["scattered_lines"] = {"lines_per_launch": lines, "lines_per_s": lines / k_s, "achieved_GBps": lines * 64.0 / k_s / 1e9, "peak_GBps": RANDOM_LINE_PEAK_GBS,
+                                           "frac": lines * 64.0 / k_s / 1e9 / RANDOM_LINE_PEAK_GBS,
+                                           "note": "counted TCC_EA0_RDREQ lines x 64 B / launch time against 50 G independent random lines/s x 64 B"}
     line = base_line(ctx, "predicate evals/sec (points within power-law multipolygons, + area)", float(W) * n * right_host.n_geoms * args.steps / elapsed, "evals/s", ms_per_step, "weak", config, roofline)
     line["parity"] = parity_point_join(pts_host, right_host, "within", counts, pairs, h, args.parity_rows)
     line["parity"]["area"] = parity_area(shard_host, area)
@@ -1127,7 +1188,10 @@ def main() -> None:
     ap.add_argument("--no-profile", action="store_true", help="tuning only: no HIP events around the kernels (the roofline leg reads zero)")
     ap.add_argument("--no-join-stats", action="store_true", help="c2: skip the extra untimed step that counts the exact phase's work (its atomics make that one launch ~7x longer: kernel-trace averages of a profiler run stay clean without it)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the exchange even at world size 1 (path test)")
-    ap.add_argument("--comm", choices=["torch", "abi"], default="torch", help="c4: the right-side exchange through torch.distributed (geopolars_amd.dist) or through the library's own RCCL entry points (gpk_allgatherv_*)")
+    ap.add_argument("--as-shard", default="", metavar="R/W", help="c2, test hook: run shard R of W of the strong-scaled problem in this one process")
+    ap.add_argument("--no-weak", action="store_true", help="c2 at N > 1: skip the weak-scaled measurement (10M points per GPU) reported beside the strong-scaled headline")
+    ap.add_argument("--no-default-shape", action="store_true", help="c2 at N = 1: skip the r_index = None measurement (index built inside every call)")
+    ap.add_argument("--comm", choices=["torch", "abi"], default="abi", help="c4: the right-side exchange through torch.distributed (geopolars_amd.dist) or through the library's own RCCL entry points (gpk_allgatherv_*)")
     ap.add_argument("--spawn", action="store_true", help="launch the rank(s) under torch.distributed.run even for --gpus 1 (what --gpus N > 1 does by itself when there is no launcher)")
     args = ap.parse_args()
     if args.steps is None:

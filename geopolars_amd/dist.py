@@ -122,15 +122,28 @@ _LEVELS = ("geom_offsets", "part_offsets", "ring_offsets")
 
 
 def _pad_gather(t: torch.Tensor, lens: list[int], group) -> list[torch.Tensor]:
-    """One fixed-size all-gather of a variable-length buffer: pad to the longest shard, gather, trim.  `lens` are the
-    first-dimension lengths of every rank's shard (from the header), so no length exchange happens here."""
+    """All-gatherv of a variable-length buffer WITHOUT padding (round 5; it used to pad every shard to the longest one and run one
+    fixed-size all-gather): one allocation of the exact total, every rank's piece broadcast straight to its final place — the
+    grouped-broadcast form of the library's own collective (csrc/gpk_comm.hip) — so the bytes on the links are the bytes of the
+    column whatever the shards' sizes.  `lens` are the first-dimension lengths of every rank's shard (from the header): no length
+    exchange happens here.  Returns the per-rank views of the gathered buffer (contiguous, in rank order)."""
     world = len(lens)
-    m = max(max(lens), 1)
-    pad = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    pad[: t.shape[0]] = t
-    out = torch.empty((world * m,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, pad, group=group)
-    return [out[k * m : k * m + lens[k]] for k in range(world)]
+    rank = dist.get_rank(group)
+    out = torch.empty((sum(lens),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    views, at = [], 0
+    for k in range(world):
+        views.append(out[at : at + lens[k]])
+        at += lens[k]
+    if lens[rank]:
+        views[rank].copy_(t[: lens[rank]])
+    work = []
+    for k in range(world):
+        if lens[k]:
+            src = dist.get_global_rank(group, k) if group is not None else k
+            work.append(dist.broadcast(views[k], src, group=group, async_op=True))
+    for w in work:
+        w.wait()
+    return views
 
 
 def all_gatherv_buffers(local: GeoBuffers, group=None, stats: Optional[dict] = None) -> GeoBuffers:
@@ -197,11 +210,12 @@ def all_gatherv_geoarray(local: GeoArrowArray, device: Optional[torch.device] = 
     return all_gatherv_buffers(GeoBuffers.from_host(local, device), group).to_host()
 
 
-def broadcast_buffers(local: Optional[GeoBuffers], src: int = 0, device: Optional[torch.device] = None, group=None) -> GeoBuffers:
+def broadcast_buffers(local: Optional[GeoBuffers], src: int = 0, device: Optional[torch.device] = None, group=None) -> GeoBuffers:  # (device: required)
     """Replicate a small right side (C2's 1k polygons) from `src` to every rank, device to device: a header, then each buffer with
     one broadcast.  `local` is read on `src` only (its tensors already live on `device`); the result stays on `device` — what
     `to_device_geoarray()` borrows (no host round trip: round 3's replicate went through numpy on every rank)."""
-    device = device or (local.xy.device if local is not None else torch.device("cpu"))
+    if device is None:  # (every rank must name the same kind of device: the source's tensors' device is unknown elsewhere)
+        raise ValueError("broadcast_buffers: pass `device` on every rank (the source's tensors live on it)")
     rank = dist.get_rank(group)
     hdr = torch.zeros(8, dtype=torch.int64, device=device)
     if rank == src:
@@ -275,7 +289,7 @@ def join_partition_right(xy_local: torch.Tensor, right_shard, right_row_base: in
     t2 = time.perf_counter()
     n = int(xy_all.shape[0])
     pts = DeviceGeoArray.from_device_buffers(_abi.GEOM_POINT, xy_all, stream=stream)
-    counts = torch.empty(n, dtype=torch.int32, device=dev)
+    counts = torch.zeros(n, dtype=torch.int32, device=dev)
     cap = int(pair_capacity) if pair_capacity is not None else max(n, 1024)
     pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
     import ctypes as C
@@ -288,22 +302,29 @@ def join_partition_right(xy_local: torch.Tensor, right_shard, right_row_base: in
                                          C.byref(n_pairs), MEM_DEVICE, stream)
         return rc, int(n_pairs.value)
 
-    rc, h = run(pairs)
-    if rc == _abi.GPK_ERR_CAPACITY and h > cap:  # (the ABI reports the exact total: once more with room for it)
-        pairs = torch.empty((h, 2), dtype=torch.int32, device=dev)
+    retry_ms = 0.0
+    try:
         rc, h = run(pairs)
-    _abi.check(rc)
-    pairs = pairs[:h]
-    if right_row_base:
-        pairs[:, 1] += int(right_row_base)
-    torch.cuda.synchronize(dev)
-    t3 = time.perf_counter()
-    index.free()
+        if rc == _abi.GPK_ERR_CAPACITY and h > cap:  # (the ABI reports the exact total: once more with room for it — timed on its own)
+            torch.cuda.synchronize(dev)
+            tr = time.perf_counter()
+            pairs = torch.empty((h, 2), dtype=torch.int32, device=dev)
+            rc, h = run(pairs)
+            torch.cuda.synchronize(dev)
+            retry_ms = (time.perf_counter() - tr) * 1e3
+        _abi.check(rc)
+        pairs = pairs[:h]
+        if right_row_base:
+            pairs[:, 1] += int(right_row_base)
+        torch.cuda.synchronize(dev)
+        t3 = time.perf_counter()
+    finally:
+        index.free()  # (also when the join raised: the shard's index holds device memory)
     total = counts.clone()
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
     return {"pairs": pairs, "counts": counts, "counts_total": total, "left_lens": lens,
-            "ms": {"gather": (t1 - t0) * 1e3, "index": (t2 - t1) * 1e3, "join": (t3 - t2) * 1e3}}
+            "ms": {"gather": (t1 - t0) * 1e3, "index": (t2 - t1) * 1e3, "join": (t3 - t2) * 1e3 - retry_ms, "capacity_retry": retry_ms}}
 
 
 class Comm:

@@ -137,6 +137,20 @@ def test_bench_n_rank_path_at_world_1(gpk, config, extra):
         assert line["config"]["right_side_exchange"]["bytes"] > 0
 
 
+@pytest.mark.parametrize("shard", ["0/8", "5/8", "7/8", "2/3"])
+def test_bench_c2_strong_scaled_shards(gpk, shard):
+    """the headline at N > 1 is STRONG scaled — rank r owns rows [r n / W, (r + 1) n / W) of the fixed 10M points and its pairs carry
+    that base; --as-shard r/W runs one rank's share in this process (one GPU here), parity-gated like any line"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--as-shard", shard, "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-default-shape", "--parity-rows", "50000"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    k, w = (int(v) for v in shard.split("/"))
+    lo, hi = k * 10_000_000 // w, (k + 1) * 10_000_000 // w
+    assert line["scaling"] == "strong" and line["config"]["rows_of_this_rank"] == [lo, hi] and line["config"]["points_per_gpu"] == hi - lo
+    assert line["parity"]["bit_exact"] and line["parity"]["pairs_checked"] > 10_000
+
+
 def test_bench_launches_its_own_ranks(gpk):
     """`python bench.py --gpus N` with no launcher re-runs itself under torch.distributed.run (exercised here at N = 1 with
     --spawn: the same code path, RCCL initialised by the spawned rank); the line carries every rank's own step time"""
@@ -233,7 +247,7 @@ def test_right_partitioned_one_shot_join_equals_the_whole_join(gpk, oracle, k):
         assert len(p) == 0 or (p[:, 1].min() >= lo and p[:, 1].max() < hi)
         got_pairs.append(p)
         got_counts += res["counts"].cpu().numpy().astype(np.int64)
-        assert set(res["ms"]) == {"gather", "index", "join"}
+        assert set(res["ms"]) == {"gather", "index", "join", "capacity_retry"} and res["ms"]["capacity_retry"] > 0.0  # (the retry is timed on its own)
     allp = np.concatenate(got_pairs)
     allp = allp[np.lexsort((allp[:, 1], allp[:, 0]))]
     assert np.array_equal(allp, ep)
