@@ -2631,6 +2631,9 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_chunked_kernel(ChainHot 
 // tiles before t.  Rare rows are settled BEFORE the tile's hits are ranked (chain_tile, POOL), so their hits are ordinary hits; a tile
 // with a row in several geometries, or one that finds the pool full, is decided again at emission.  Same eligibility as the LDS-hits
 // form (16-bit geometry ids, at most POOL_TILES tiles per work-group); longer columns take pip_tile_chunked_kernel.
+#ifndef GPK_POOL_EMIT_COMPACT
+#define GPK_POOL_EMIT_COMPACT 1
+#endif
 #ifndef GPK_POOL_STRIDED
 #define GPK_POOL_STRIDED 1
 #endif
@@ -2826,6 +2829,36 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_pool_kernel(ChainHot h, 
         const uint32_t outb = have ? s_texcl[et_j] + gex : 0u, idsb = start_j + gex;
         const uint32_t rowb = (uint32_t)(((int64_t)T0 + et_j) * TILE) + kj * 64u + t.left_base;
         const uint32_t mlo = (uint32_t)mv, mhi = (uint32_t)(mv >> 32);
+        FUSED_STAMP(13);
+#if GPK_POOL_EMIT_COMPACT
+        // A COMPACT loop: with 16 waves on a CU this code is bound by the instructions it issues (35 per point row measured 7 us for the
+        // 40 rows of a wave: v_readlane, 64-bit address arithmetic and a capacity test per row), so: what a row needs from its lane
+        // travels as ONE packed word (pairs before the row within the work-group | where its ids start), the row number is scalar
+        // arithmetic, the pairs are addressed as a 32-bit index from the work-group's place (a uniform pointer), and the capacity test
+        // is made once for the work-group (a pair buffer that ends inside this work-group's pairs takes the guarded loop).
+        static_assert(POOL_TILES * TILE < 65536 && POOL_IDS < 65536, "two 16-bit fields");
+        const uint32_t packed = (outb & 0xFFFFu) | (idsb << 16);
+        unsigned long long* const out64 = reinterpret_cast<unsigned long long*>(t.pairs) + base_off;  // (wave-uniform)
+        const bool all_fit = (int64_t)(base_off + wg_tot) <= t.capacity;
+        const uint32_t room = all_fit ? 0xFFFFFFFFu : (t.capacity > (int64_t)base_off ? (uint32_t)(t.capacity - (int64_t)base_off) : 0u);
+        const uint32_t row_wave = (uint32_t)(((int64_t)T0 + wave) * TILE) + t.left_base + (uint32_t)lane;
+#pragma unroll 1
+        for (uint32_t j = 0; j < n_mine * (uint32_t)P; j += 2u) {
+            // (rows j and j + 1 belong to the same tile: P is even)
+            const uint32_t row_s = row_wave + (j >> 3) * (uint32_t)(W * TILE) + (j & 7u) * 64u;
+            const unsigned long long m0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mhi, (int)j) << 32) | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mlo, (int)j);
+            const unsigned long long m1 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mhi, (int)j + 1) << 32) | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mlo, (int)j + 1);
+            const uint32_t pk0 = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)j), pk1 = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)j + 1);
+            const uint32_t r0 = lanes_below(m0), r1 = lanes_below(m1);
+            const bool a0 = ((m0 >> lane) & 1ull) != 0ull, a1 = ((m1 >> lane) & 1ull) != 0ull;
+            uint32_t id0 = 0u, id1 = 0u;
+            if (a0) id0 = (uint32_t)s_pool[(pk0 >> 16) + r0];
+            if (a1) id1 = (uint32_t)s_pool[(pk1 >> 16) + r1];
+            const uint32_t x0 = (pk0 & 0xFFFFu) + r0, x1 = (pk1 & 0xFFFFu) + r1;
+            if (a0 && x0 < room) __builtin_nontemporal_store(((unsigned long long)id0 << 32) | (unsigned long long)row_s, out64 + x0);
+            if (a1 && x1 < room) __builtin_nontemporal_store(((unsigned long long)id1 << 32) | (unsigned long long)(row_s + 64u), out64 + x1);
+        }
+#else
         for (uint32_t j0 = 0; j0 < n_mine * (uint32_t)P; j0 += 8u) {
             uint32_t idv[8], rank[8], act = 0u;
             static_for<8>([&](auto U) {
@@ -2836,7 +2869,7 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_pool_kernel(ChainHot h, 
                 idv[u] = 0u;
                 if ((m >> lane) & 1ull) {
                     act |= 1u << u;
-                    idv[u] = (uint32_t)s_pool[(uint32_t)__builtin_amdgcn_readlane((int)idsb, j) + rank[u]];
+                    idv[u] = GPK_FUSED_ABLATE == 4 ? rank[u] : (uint32_t)s_pool[(uint32_t)__builtin_amdgcn_readlane((int)idsb, j) + rank[u]];  // (4, tuning builds: no id gather)
                 }
             });
             asm volatile("" : "+v"(idv[0]), "+v"(idv[1]), "+v"(idv[2]), "+v"(idv[3]), "+v"(idv[4]), "+v"(idv[5]), "+v"(idv[6]), "+v"(idv[7]));
@@ -2847,7 +2880,9 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_pool_kernel(ChainHot h, 
                     const unsigned long long at = base_off + (unsigned long long)((uint32_t)__builtin_amdgcn_readlane((int)outb, j) + rank[u]);
                     if ((int64_t)at < t.capacity) {
                         const unsigned long long v = ((unsigned long long)idv[u] << 32) | (unsigned long long)((uint32_t)__builtin_amdgcn_readlane((int)rowb, j) + (uint32_t)lane);
-                        if (GPK_LH_NT)
+                        if (GPK_FUSED_ABLATE == 3)  // (tuning builds only: everything but the store)
+                            asm volatile("" ::"v"(v), "v"(at));
+                        else if (GPK_LH_NT)
                             __builtin_nontemporal_store(v, reinterpret_cast<unsigned long long*>(t.pairs + at));
                         else
                             *reinterpret_cast<unsigned long long*>(t.pairs + at) = v;
@@ -2855,7 +2890,9 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_pool_kernel(ChainHot h, 
                 }
             });
         }
+#endif
     }
+    FUSED_STAMP(14);
     // the tiles that are decided again, storing at their final offsets (a row in several geometries; the pool was full)
     for (uint32_t et = (uint32_t)wave; et < nt; et += (uint32_t)W) {
         if (s_tstart[et] != 0xFFFFFFFFu) continue;

@@ -38,7 +38,7 @@ for rep in range(2):
     us = lambda x: (x - t0) / 100.0
     print(f"rep {rep}: traced waves {len(a)}; kernel span (first entry -> last stamp) {us(a.max()):.1f} us")
     names = {0: "entry", 1: "image built", 2: "first tile starts", 3: "tile 0 done", 4: "tile 1 done", 5: "tile 2 done", 6: "tile 3 done", 7: "tile 4 done", 9: "tiles done",
-             10: "wg barrier", 11: "place known", 12: "emission issued", 13: "stores drained"}
+             10: "wg barrier", 11: "place known", 13: "emit preamble", 14: "emit loop done", 12: "emission issued"}
     for i, nm in names.items():
         col = a[:, i]
         col = col[col > 0]
