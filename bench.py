@@ -421,8 +421,20 @@ def run_c2(ctx: Ctx) -> None:
             step_default(i)
         torch.cuda.synchronize()
         d_ms = (time.perf_counter() - t0) / k_def * 1e3
+        # ... and the call itself with right_index = NULL, repeated against the same right-side handle: the library keeps the index it
+        # built on the handle (handles are immutable), so every call after the first finds it
+        join_pairs_device(sets[0]["pts"], polys, None, "intersects", sets[0]["counts"], sets[0]["pairs"], left_row_base=0, stream=stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(k_def):
+            s_ = sets[i % R]
+            join_pairs_device(s_["pts"], polys, None, "intersects", s_["counts"], s_["pairs"], left_row_base=0, stream=stream)
+        torch.cuda.synchronize()
+        m_ms = (time.perf_counter() - t0) / k_def * 1e3
         default_shape = {"ms_per_step": d_ms, "evals_per_s": n * m / (d_ms * 1e-3), "steps": k_def,
-                         "what": "gpk_spatial_join with r_index = None's work done per call: index built (GPK_INDEX_PIP_LIGHT), join, index freed; blocking entry point"}
+                         "what": "gpk_spatial_join with r_index = None's work done per call: index built (GPK_INDEX_PIP_LIGHT), join, index freed; blocking entry point",
+                         "repeated_against_the_same_right_handle": {"ms_per_step": m_ms, "evals_per_s": n * m / (m_ms * 1e-3),
+                                                                    "what": "gpk_spatial_join(right_index = NULL) called again and again with the same right-side handle: the index built by the first call stays on the handle (blocking entry point: one host round trip per call)"}}
     # what the exact phase did, measured on one extra untimed step (a few atomics per tile: never inside the timed region)
     st = (C.c_int64 * 4)()
     if not args.no_join_stats:

@@ -68,6 +68,12 @@ struct gpk_geoarray {
     void* owned[5];  // hipMalloc'ed copies (xy, geom_off, part_off, ring_off, validity) or nullptr
     int64_t nbytes;
     gpk_seq_classes* classes;  // lazily built (under a lock), freed with the handle
+    // gpk_spatial_join called WITHOUT an index (the reference's default: SpatialJoinArgs::default() has r_index: None and builds an R-tree
+    // inside every call, spatial_index.rs:24-35,60-71) keeps the index it builds on the right-side handle — handles are immutable after
+    // upload, so the index of a handle never goes stale — and the next such call finds it.  [0]: boxes + grid directory, [1]: + the
+    // point-in-polygon tables (GPK_INDEX_PIP_LIGHT).  Built under a lock, freed with the handle; only indexes of at most
+    // GPK_AUTO_INDEX_MAX_MB (default 256) are kept; GPK_AUTO_INDEX=0 turns the memo off.
+    struct gpk_index* auto_index[2];
 };
 
 namespace gpk {

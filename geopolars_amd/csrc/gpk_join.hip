@@ -4215,8 +4215,30 @@ int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right, co
     gpk_index* tmp_index = nullptr;
     if (!right_index) {  // built on the fly, like spatial_index.rs:60-71 — only the tables this arm reads
         // (an index that serves ONE join skips the per-entry records of list cells: they cost more to build than one join saves)
-        GPK_TRY(gpk_index_build_ex(right, GPK_INDEX_BBOX_GRID | (pip ? GPK_INDEX_PIP | GPK_INDEX_PIP_LIGHT : 0), nullptr, stream, &tmp_index));
-        right_index = tmp_index;
+        // The built index stays on the right-side handle (gpk_geoarray::auto_index): the reference's default call shape repeated
+        // against the same series — a dataframe joined batch after batch against one geometry column — pays for the build once.
+        static const bool memo_on = [] {
+            const char* e = getenv("GPK_AUTO_INDEX");
+            return !(e && *e == '0');
+        }();
+        static const int64_t memo_max = [] {
+            const char* e = getenv("GPK_AUTO_INDEX_MAX_MB");
+            return (int64_t)(e && *e ? atoll(e) : 256) << 20;
+        }();
+        static std::mutex memo_mu;
+        const int slot = pip ? 1 : 0;
+        gpk_geoarray* rw = const_cast<gpk_geoarray*>(right);
+        std::lock_guard<std::mutex> lk(memo_mu);
+        if (memo_on && rw->auto_index[slot]) {
+            right_index = rw->auto_index[slot];
+        } else {
+            GPK_TRY(gpk_index_build_ex(right, GPK_INDEX_BBOX_GRID | (pip ? GPK_INDEX_PIP | GPK_INDEX_PIP_LIGHT : 0), nullptr, stream, &tmp_index));
+            right_index = tmp_index;
+            if (memo_on && tmp_index->nbytes <= memo_max) {
+                rw->auto_index[slot] = tmp_index;
+                tmp_index = nullptr;  // (owned by the handle from here on)
+            }
+        }
     } else if (right_index->n_geoms != right->d.n_geoms || right_index->n_coords != right->d.n_coords || right_index->n_rings != right->d.n_rings) {
         // (an index whose slabs name coordinates by index reads THIS array's coordinates: rows alone do not identify the column)
         return fail(GPK_ERR_INVALID_ARGUMENT, "right_index was built over a different array");

@@ -522,6 +522,11 @@ int32_t gpk_geoarray_free(gpk_geoarray* a) {
     }
     for (int i = 0; i < 5; ++i)
         if (a->owned[i]) cached_free(a->owned[i]);
+    for (int k = 0; k < 2; ++k)
+        if (a->auto_index[k]) {
+            gpk_index_free(a->auto_index[k]);
+            a->auto_index[k] = nullptr;
+        }
     if (a->classes) {
         if (a->classes->lists) (void)hipFree(a->classes->lists);
         if (a->classes->chunk_begin) (void)hipFree(a->classes->chunk_begin);

@@ -372,7 +372,10 @@ int32_t gpk_index_describe(const gpk_index* idx, int64_t out[8]);
  *   out_counts[n_left]   u32 hits per left row (may be NULL)
  *   out_pairs[2*cap]     u32 (l, r) interleaved (may be NULL when cap == 0: count-only mode)
  *   *n_pairs             total hits (always set; GPK_ERR_CAPACITY if > cap and pairs requested)
- * `right_index` may be NULL (built on the fly like spatial_index.rs:60-71).
+ * `right_index` may be NULL (built on the fly like spatial_index.rs:60-71).  The index such a call builds STAYS on the right-side
+ * handle (handles are immutable after upload, so it cannot go stale) and is freed with it: the reference's default call shape —
+ * SpatialJoinArgs::default() has r_index: None, spatial_index.rs:24-35 — repeated against the same series pays for one build.
+ * Only indexes of at most GPK_AUTO_INDEX_MAX_MB (environment, default 256) are kept; GPK_AUTO_INDEX=0 builds and frees per call.
  * Geometry dispatch = the match of spatial_index.rs:89-137: point <-> polygon / multipolygon on either side
  * (`poly.contains(point)` whatever the predicate), polygonal x polygonal `intersects`, polygon / multipolygon x POLYGON
  * `contains` (:99-101,107-111; upstream's DE-9IM relate restated as "right is not empty and a subset of left"),

@@ -378,3 +378,22 @@ def test_parts_with_thousands_of_vertices_inside_one_raster_cell(gpk, oracle, wi
     gp, gc = join_pairs(GeoSeries(left), rs, "intersects", r_index=SpatialIndex(rs))
     assert np.array_equal(gc, ec) and np.array_equal(gp, ep)
     assert ec[200_000 : 200_000 + len(near)].sum() > 10_000  # the dense points do land inside the many-vertex parts
+
+
+def test_the_index_a_join_builds_for_itself_stays_on_the_right_handle(gpk, oracle):
+    """the reference's default call shape — SpatialJoinArgs::default() has r_index: None (spatial_index.rs:24-35,60-71) — repeated
+    against one right side: the first call builds the index, later calls find it on the (immutable) handle; a different left side
+    and a different arm (polygon x polygon: boxes + directory only) are served too; freeing the handle frees what it holds"""
+    polys = synth.star_polygons(500, 32)
+    right = GeoSeries(polys)
+    for seed in (1, 2, 3):
+        pts = synth.uniform_points(40_000 + seed, seed=seed)
+        ep, ec, _ = oracle.spatial_join(pts, polys, "intersects", mode=0)
+        gp, gc = join_pairs(GeoSeries(pts), right, "intersects", r_index=None)
+        assert np.array_equal(gc, ec) and np.array_equal(gp, ep)
+    other = synth.clustered_polygons(2000, seed=5)
+    ep, ec, _ = oracle.spatial_join(other, polys, "intersects", mode=0)
+    for _ in range(2):
+        gp, gc = join_pairs(GeoSeries(other), right, "intersects", r_index=None)
+        assert np.array_equal(gc, ec) and np.array_equal(gp, ep)
+    right.device().free()
