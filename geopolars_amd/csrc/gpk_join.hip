@@ -2635,7 +2635,7 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_chunked_kernel(ChainHot 
 #define GPK_POOL_EMIT_COMPACT 1
 #endif
 #ifndef GPK_POOL_STRIDED
-#define GPK_POOL_STRIDED 1
+#define GPK_POOL_STRIDED 0  // 1: draw d -> tile (d % W) * stride + d / W (the tiles in flight `stride` apart): measured 1.5 - 2 us SLOWER on C2 (94.2 -> 96.4)
 #endif
 constexpr int POOL_TILES = FUSED_LH_TILES * (ROUTE_BLOCK / 64);   // tile records per work-group
 constexpr int POOL_IDS = 17408;                                   // 16-bit hit slots per work-group (34 KB)
@@ -2715,7 +2715,8 @@ __global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_pool_kernel(ChainHot h, 
         if (t >= nf_draws) break;
 #if GPK_POOL_STRIDED
         // draw d -> tile (d % W) * stride + d / W: the W tiles in flight in a work-group lie `stride` tiles apart, as the runs of
-        // pip_tile_fused_kernel's waves do (W neighbouring tiles at a time measured 3 - 4 us slower per tile: they share memory channels)
+        // pip_tile_fused_kernel's waves do (tried when the first version of this kernel ran 3 - 4 us slower per tile than the wave form;
+        // the cause was the atomic optimizer's lane loop, not the tiles' addresses: off by default)
         t = (t % (uint32_t)W) * nf_stride + t / (uint32_t)W;
         if (t >= nf) continue;
 #endif

@@ -1,13 +1,18 @@
-"""GPU parity of the one-launch point join (gpk_join.hip: pip_tile_fused_kernel — tiles decided, hits ranked and the sorted (l, r)
-pair list written by the same persistent work-groups; two forms: hits kept in LDS until their place is known — geometry ids of 16 bits,
-at most five tiles per wave — or parked in staging slots, GPK_FUSED_LDS=0 / longer columns) through the C ABI vs the CPU oracle, bit-exact on counts, pairs and totals
-(`Contains<Point>`, spatial_index.rs:91-96; sorted pairs = the two index vectors of spatial_index.rs:145-159).
+"""GPU parity of the one-launch point join (gpk_join.hip) through the C ABI vs the CPU oracle, bit-exact on counts, pairs and totals
+(`Contains<Point>`, spatial_index.rs:91-96; sorted pairs = the two index vectors of spatial_index.rs:145-159).  Tiles decided, hits
+ranked and the sorted (l, r) pair list written by the same persistent work-groups, in one of four forms that must all answer alike:
+  pool     (round 5, the default up to 10.49 M rows on 256 CUs) a work-group's waves draw tiles from an LDS counter, hits in one pool of
+           16-bit geometry ids per work-group, rare rows settled before the tile's hits are ranked — pip_tile_pool_kernel;
+  chunked  (round 5, longer columns) chunks of 16 tiles from an agent-scope counter, a chunk's pairs written while the next is decided,
+           two tiles of hits per wave in LDS whatever the column's length — pip_tile_chunked_kernel;
+  wave     (round 4, GPK_FUSED_FORM=wave) a contiguous run of tiles per wave, its hits in the wave's own LDS list — pip_tile_fused_kernel<true>;
+  staging  (GPK_FUSED_LDS=0, or more than 65,535 geometries) hits parked in the pair slots of the wave's own rows.
+GPK_FUSED_FORM / GPK_FUSED_LDS are read once per process: the forms other than the default run in their own interpreter.
 
-What only this kernel has, and what is aimed at here: a wave's hits parked in the pair slots of its own rows and moved to their
-place once the work-groups before it have published their totals; rare rows (list cells, sub-cells without a chain entry,
-uncertifiable orientations) that open a gap for their hits among those already parked; rows in SEVERAL geometries that outgrow a
-wave's slots (the wave decides its tiles again, storing at final offsets); left_row_base; a pair buffer smaller than the total;
-count-only calls; launches from two streams (they share the epoch words); columns shorter than one tile per wave."""
+What only these kernels have, and what is aimed at here: hits that wait in LDS until the work-groups before have published their totals;
+rare rows (list cells, half cells without a chain, uncertifiable orientations); rows in SEVERAL geometries (the tile is decided again,
+storing at final offsets); left_row_base; a pair buffer smaller than the total; count-only calls; launches from two streams (they
+share the epoch words); columns shorter than one tile per wave, and longer than any LDS list."""
 import ctypes as C
 
 import numpy as np
@@ -166,8 +171,8 @@ def test_the_round_three_pair_of_kernels_still_answers_the_same(gpk, oracle):
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr[-3000:]
 
 
-def test_a_column_too_long_for_the_lds_form_takes_the_staging_form(gpk, oracle):
-    """more than 5 tiles per wave (> 10.7 M points on 256 CUs): the hits are parked in staging slots instead of LDS"""
+def test_a_column_too_long_for_a_work_groups_pool_takes_the_chunked_form(gpk, oracle):
+    """more than 80 tiles per work-group (> 10.49 M points on 256 CUs): chunks of 16 tiles from a counter, 1343 chunks = 6 generations"""
     polys = synth.star_polygons(1000, 64)
     pts = synth.uniform_points(11_000_003, seed=77)
     ep, ec, _ = oracle.spatial_join(pts, polys, "intersects", mode=1)
@@ -204,4 +209,47 @@ def test_the_staging_form_on_the_same_inputs(gpk, oracle):
         "print('ok', int(ec.sum()), int(ec.max()))\n"
     )
     r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, GPK_FUSED_LDS="0"))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr[-3000:]
+
+
+_FORM_PROG = (
+    "import numpy as np, sys\n"
+    "sys.path.insert(0, 'tests')\n"
+    "from geopolars_amd import synth\n"
+    "from geopolars_amd.geoarrow import GeoArrowArray\n"
+    "from geopolars_amd.geoseries import GeoSeries\n"
+    "from geopolars_amd.spatial_index import SpatialIndex, join_pairs\n"
+    "from oracle import pyoracle\n"
+    "import test_gpu_fused as T\n"
+    "pyoracle.build()\n"
+    "rng = np.random.default_rng(3)\n"
+    "cases = []\n"
+    "polys = T._stacked(900, 37)\n"
+    "pts = np.concatenate([synth.uniform_points(60_001, seed=4).xy, np.column_stack([rng.uniform(499.0, 505.0, 3000), rng.uniform(959.0, 965.0, 3000)])])\n"
+    "rng.shuffle(pts)\n"
+    "cases.append((GeoArrowArray.from_points(pts), polys))\n"
+    "stars = synth.star_polygons(1000, 64)\n"
+    "for n in (0, 1, 511, 513, 8191, 8193, 700_001):\n"
+    "    cases.append((synth.uniform_points(n, seed=n % 89 + 2), stars))\n"
+    "xy = rng.uniform(0, 1000, (150_001, 2)); xy[rng.integers(0, len(xy), 700)] = np.nan\n"
+    "cases.append((GeoArrowArray.from_points(xy, validity=np.packbits(rng.uniform(size=len(xy)) > 0.15, bitorder='little')), stars))\n"
+    "for pts, polys in cases:\n"
+    "    right = GeoSeries(polys); index = SpatialIndex(right)\n"
+    "    ep, ec, _ = pyoracle.spatial_join(pts, polys, 'intersects', mode=0)\n"
+    "    for base in (0, 123456):\n"
+    "        gp, gc = join_pairs(GeoSeries(pts), right, 'intersects', r_index=index, left_row_base=base)\n"
+    "        e = ep.copy(); e[:, 0] += base\n"
+    "        assert np.array_equal(gc, ec) and np.array_equal(gp, e), (len(pts), base)\n"
+    "print('ok', len(cases))\n"
+)
+
+
+@pytest.mark.parametrize("form", ["wave", "chunked", "pool"])
+def test_every_form_of_the_fused_join_on_the_same_inputs(gpk, oracle, form):
+    """GPK_FUSED_FORM=wave | chunked | pool (read once per process) forces one form for every eligible join: rows in several geometries,
+    left_row_base, ragged tails, null and empty rows, columns around the tile / chunk boundaries — in its own interpreter"""
+    import os, subprocess, sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _FORM_PROG], capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, GPK_FUSED_FORM=form))
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr[-3000:]

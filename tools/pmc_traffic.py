@@ -52,7 +52,7 @@ def main():
     import bench  # source_hash()
 
     KERNEL = "pip_tile"
-    rec = {"kernel": "gpk_pip_tile", "source_hash": bench.source_hash(), "command": "python bench.py --steps 10 --warmup 2 --no-cpu-baseline (cold inputs: 3 rotating 10M-point sets)"}
+    rec = {"kernel": "gpk_pip_tile", "source_hash": bench.source_hash(), "command": "python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-join-stats --no-default-shape (cold inputs: 3 rotating 10M-point sets)"}
     vals = {}
     for d in glob.glob(os.path.join(root, "pmc_*")):
         if os.path.isdir(d):

@@ -7,7 +7,7 @@
 # 4. tools/pmc_traffic.py folds all of it into one JSON that names the source hash it was measured at.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; TAG=$1; OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT
-CMD="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-join-stats --parity-rows 20000"
+CMD="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-join-stats --no-default-shape --parity-rows 20000"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES"; do
   d=$(echo $set | tr ' ' '_' | cut -c1-40)
