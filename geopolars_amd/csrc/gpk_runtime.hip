@@ -399,6 +399,11 @@ __global__ __launch_bounds__(256) void interleave_xy_kernel(const double* __rest
     if (i < n) xy[i] = make_double2(x[i], y[i]);
 }
 
+__global__ __launch_bounds__(256) void rebase_offsets_kernel(const int32_t* __restrict__ in, int64_t n, int32_t first, int32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] - first;
+}
+
 int32_t gpk_geoarray_upload(const gpk_geoarrow_desc* d, void* stream, gpk_geoarray** out) {
     if (!out) return fail(GPK_ERR_INVALID_ARGUMENT, "out is NULL");
     *out = nullptr;
@@ -503,6 +508,51 @@ int32_t gpk_geoarray_upload(const gpk_geoarrow_desc* d, void* stream, gpk_geoarr
         *bufs[i].dst = p;
     }
     if (d->mem_space == GPK_MEM_HOST) GPK_HIP(hipStreamSynchronize(s));  // host buffers are only borrowed for the call
+    if (d->mem_space == GPK_MEM_DEVICE && t != GPK_GEOM_POINT) {
+        // A device view whose offsets do not start at 0 — a sliced Arrow list array hands over its offsets unrebased next to the SLICE of
+        // the child buffer they index — is normalised here: every kernel of the library indexes children from 0 (ring_of_coord, the
+        // chain tables, the unary passes), and only concat / all-gatherv knew how to subtract a first offset.  One small read-back per
+        // upload of a device view; a level that starts at 0 stays borrowed, one that does not gets an owned, rebased copy.
+        struct Lv {
+            const int32_t** p;
+            int64_t n;
+            int slot;
+        } lv[3] = {{&a->d.geom_off, d->n_geoms + 1, 1}, {&a->d.part_off, n_parts + 1, 2}, {&a->d.ring_off, n_rings + 1, 3}};
+        int32_t first[3] = {0, 0, 0};
+        bool any = false;
+        for (int i = 0; i < 3; ++i)
+            if (*lv[i].p && lv[i].n > 0) {
+                const hipError_t e = hipMemcpyAsync(&first[i], *lv[i].p, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+                if (e != hipSuccess) {
+                    gpk_geoarray_free(a);
+                    return fail(GPK_ERR_DEVICE, "upload: %s", hipGetErrorString(e));
+                }
+                any = true;
+            }
+        if (any) {
+            const hipError_t e = hipStreamSynchronize(s);
+            if (e != hipSuccess) {
+                gpk_geoarray_free(a);
+                return fail(GPK_ERR_DEVICE, "upload: %s", hipGetErrorString(e));
+            }
+        }
+        for (int i = 0; i < 3; ++i) {
+            if (first[i] == 0 || !*lv[i].p) continue;
+            void* p = nullptr;
+            hipError_t e = cached_malloc(&p, sizeof(int32_t) * (size_t)lv[i].n);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(rebase_offsets_kernel, dim3((unsigned)((lv[i].n + 255) / 256)), dim3(256), 0, s, *lv[i].p, lv[i].n, first[i], (int32_t*)p);
+                e = hipGetLastError();
+            }
+            if (e != hipSuccess) {
+                if (p) cached_free(p);
+                gpk_geoarray_free(a);
+                return fail(e == hipErrorOutOfMemory ? GPK_ERR_OOM : GPK_ERR_DEVICE, "upload: %s", hipGetErrorString(e));
+            }
+            a->owned[lv[i].slot] = p;
+            *lv[i].p = (const int32_t*)p;
+        }
+    }
     *out = a;
     return GPK_OK;
 }

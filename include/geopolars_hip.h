@@ -112,7 +112,9 @@ int32_t gpk_device_info(char* name_buf, size_t cap, int32_t* out_cus);
 int32_t gpk_device_cache_release(void);
 
 /* ---- "copied once to HBM as SoA" ---------------------------------------------------------- */
-/* replaces the per-op row decode of util.rs:27-37 (iter_geom) */
+/* replaces the per-op row decode of util.rs:27-37 (iter_geom).  A DEVICE view whose offsets do not start at 0 (a sliced Arrow list
+ * array: unrebased offsets next to the slice of the child buffer they index) is accepted: the level gets an owned, rebased copy, so
+ * every entry point sees children indexed from 0 (one 4-byte read-back per offsets level and upload of a device view). */
 int32_t gpk_geoarray_upload(const gpk_geoarrow_desc* desc, void* stream, gpk_geoarray** out);
 int32_t gpk_geoarray_free(gpk_geoarray* a);
 /* HBM bytes held by the handle (owned + borrowed), for roofline accounting */
