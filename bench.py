@@ -391,7 +391,7 @@ def run_c2(ctx: Ctx) -> None:
     fused = "gpk_pip_write" not in warm
     rank_seconds_main = list(getattr(ctx, "rank_seconds", []))
     weak = None
-    if W > 1 and not args.no_weak:  # the weak-scaled form beside the headline: 10M points PER GPU (rank-dependent seeds)
+    if (W > 1 or args.force_weak) and not args.no_weak:  # the weak-scaled form beside the headline: 10M points PER GPU (rank-dependent seeds)
         del sets
         torch.cuda.empty_cache()
         cur["sets"], _ = build_sets(0, n, ctx.rank + 1, False)
@@ -1201,6 +1201,7 @@ def main() -> None:
     ap.add_argument("--no-join-stats", action="store_true", help="c2: skip the extra untimed step that counts the exact phase's work (its atomics make that one launch ~7x longer: kernel-trace averages of a profiler run stay clean without it)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the exchange even at world size 1 (path test)")
     ap.add_argument("--as-shard", default="", metavar="R/W", help="c2, test hook: run shard R of W of the strong-scaled problem in this one process")
+    ap.add_argument("--force-weak", action="store_true", help="c2, test hook: run the weak-scaled measurement at N = 1 too (the code path of N > 1 on a one-GPU box)")
     ap.add_argument("--no-weak", action="store_true", help="c2 at N > 1: skip the weak-scaled measurement (10M points per GPU) reported beside the strong-scaled headline")
     ap.add_argument("--no-default-shape", action="store_true", help="c2 at N = 1: skip the r_index = None measurement (index built inside every call)")
     ap.add_argument("--comm", choices=["torch", "abi"], default="abi", help="c4: the right-side exchange through torch.distributed (geopolars_amd.dist) or through the library's own RCCL entry points (gpk_allgatherv_*)")

@@ -142,6 +142,8 @@ def test_bench_c2_strong_scaled_shards(gpk, shard):
     """the headline at N > 1 is STRONG scaled — rank r owns rows [r n / W, (r + 1) n / W) of the fixed 10M points and its pairs carry
     that base; --as-shard r/W runs one rank's share in this process (one GPU here), parity-gated like any line"""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--as-shard", shard, "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-default-shape", "--parity-rows", "50000"]
+    if shard == "5/8":  # (one case also walks the weak-scaled leg that runs beside the headline at N > 1)
+        cmd.append("--force-weak")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
@@ -149,6 +151,9 @@ def test_bench_c2_strong_scaled_shards(gpk, shard):
     lo, hi = k * 10_000_000 // w, (k + 1) * 10_000_000 // w
     assert line["scaling"] == "strong" and line["config"]["rows_of_this_rank"] == [lo, hi] and line["config"]["points_per_gpu"] == hi - lo
     assert line["parity"]["bit_exact"] and line["parity"]["pairs_checked"] > 10_000
+    if shard == "5/8":
+        weak = line["config"]["weak_scaling"]
+        assert weak["points_per_gpu"] == 10_000_000 and weak["value"] > 0 and weak["ms_per_step"] > line["ms_per_step"]
 
 
 def test_bench_launches_its_own_ranks(gpk):
