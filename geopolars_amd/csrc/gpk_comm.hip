@@ -124,6 +124,10 @@ __global__ void bytes_to_bitmap_kernel(const uint8_t* __restrict__ bytes, int64_
 struct gpk_comm {
     ncclComm_t comm;
     int32_t rank, world, device;
+    // device scratch of the collectives' small words (header rows of every rank + this rank's own row; the agreement words), reserved
+    // when the communicator is created: nothing is allocated between the first collective of an exchange and its last, so a rank
+    // cannot fail locally — and leave its peers blocked inside a collective — for want of scratch
+    int64_t* scratch;
 };
 
 namespace gpk {
@@ -146,13 +150,23 @@ struct Shards {
     const DevGeo& mine_or(int k) const { return me < 0 ? local[k]->d : local[0]->d; }
     bool holds(int k) const { return me < 0 || k == me; }
 };
-constexpr int HDR = 9;  // n_geoms, n_parts, n_rings, n_coords, has_validity, type, first geom / part / ring offset
-__global__ void first_offsets_kernel(const int32_t* __restrict__ geom_off, const int32_t* __restrict__ part_off, const int32_t* __restrict__ ring_off,
-                                     int64_t* __restrict__ hdr) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    hdr[6] = geom_off ? geom_off[0] : 0;
-    hdr[7] = part_off ? part_off[0] : 0;
-    hdr[8] = ring_off ? ring_off[0] : 0;
+constexpr int HDR = 10;  // n_geoms, n_parts, n_rings, n_coords, has_validity, type, first geom / part / ring offset, the owning rank's local status
+// the first offsets of up to COMM_MAX_WORLD shards, read on the device: thread k fills row k's entries 6 .. 8 (the rows' other entries
+// were copied in from the host; a shard without rows has no first offsets)
+struct ShardOffsets {
+    const int32_t* geom_off[COMM_MAX_WORLD];
+    const int32_t* part_off[COMM_MAX_WORLD];
+    const int32_t* ring_off[COMM_MAX_WORLD];
+    int32_t n;
+};
+__global__ void first_offsets_kernel(ShardOffsets so, int64_t* __restrict__ hdr) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= so.n) return;
+    int64_t* h = hdr + (size_t)HDR * k;
+    if (h[0] <= 0) return;
+    h[6] = so.geom_off[k] ? so.geom_off[k][0] : 0;
+    h[7] = so.part_off[k] ? so.part_off[k][0] : 0;
+    h[8] = so.ring_off[k] ? so.ring_off[k][0] : 0;
 }
 static void header_of(const DevGeo& d, int64_t* h) {
     const bool has_part = d.type == GPK_GEOM_MULTIPOLYGON,
@@ -163,30 +177,51 @@ static void header_of(const DevGeo& d, int64_t* h) {
     h[3] = d.n_coords;
     h[4] = d.validity ? 1 : 0;
     h[5] = d.type;
-    h[6] = h[7] = h[8] = 0;
+    h[6] = h[7] = h[8] = h[9] = 0;
 }
-// hdr[HDR * W] on the host: every shard's sizes and first offsets (the only host read of the exchange)
-static int32_t gather_header(const Shards& S, std::vector<int64_t>& hdr, hipStream_t s) {
+// hdr[HDR * W] on the host: every shard's sizes and first offsets (the only host read of the exchange).  Entry 9 of a row is the
+// owning rank's LOCAL STATUS (GPK_OK unless something failed before the exchange): it travels inside the all-gather every rank takes
+// part in, so a rank that failed locally still makes the collective call and every rank learns of it (*peer_rc) instead of blocking.
+// One host -> device copy and one kernel for all the rows this process stages (a chunked column's K rows used to pay K syncs).
+static int32_t gather_header(const Shards& S, std::vector<int64_t>& hdr, hipStream_t s, int32_t local_rc, int32_t* peer_rc) {
     const int W = S.W;
+    *peer_rc = GPK_OK;
     hdr.assign((size_t)HDR * W, 0);
-    GPK_TRY(workspace_aux(0).begin(sizeof(int64_t) * (size_t)(HDR * (W + 1)) + 512));
-    int64_t* hdr_dev = (int64_t*)workspace_aux(0).take(sizeof(int64_t) * (size_t)(HDR * (W + 1)));
-    auto stage = [&](const DevGeo& d, int64_t* at) -> int32_t {  // one shard's header row, its first offsets read on the device
-        int64_t h[HDR];
-        header_of(d, h);
-        GPK_HIP(hipMemcpyAsync(at, h, sizeof h, hipMemcpyHostToDevice, s));
-        if (d.n_geoms > 0) hipLaunchKernelGGL(first_offsets_kernel, dim3(1), dim3(64), 0, s, d.geom_off, d.part_off, d.ring_off, at);
-        GPK_HIP(hipStreamSynchronize(s));  // (h is a local)
-        return GPK_OK;
-    };
-    if (S.me < 0) {
-        for (int k = 0; k < W; ++k) GPK_TRY(stage(S.local[k]->d, hdr_dev + (size_t)HDR * k));
+    int64_t* hdr_dev = nullptr;
+    if (S.me >= 0) {
+        hdr_dev = S.c->scratch;  // (reserved with the communicator: HDR * (W + 1) words)
     } else {
-        GPK_TRY(stage(S.local[0]->d, hdr_dev + (size_t)HDR * W));
-        GPK_NCCL(S.r, S.r->AllGather(hdr_dev + (size_t)HDR * W, hdr_dev, HDR, ncclInt64, S.c->comm, s));
+        GPK_TRY(workspace_aux(0).begin(sizeof(int64_t) * (size_t)(HDR * (W + 1)) + 512));
+        hdr_dev = (int64_t*)workspace_aux(0).take(sizeof(int64_t) * (size_t)(HDR * (W + 1)));
     }
-    GPK_HIP(hipMemcpyAsync(hdr.data(), hdr_dev, sizeof(int64_t) * (size_t)(HDR * W), hipMemcpyDeviceToHost, s));
-    GPK_HIP(hipStreamSynchronize(s));
+    const int n_rows = S.me < 0 ? W : 1;
+    std::vector<int64_t> rows((size_t)HDR * n_rows, 0);
+    ShardOffsets so;
+    memset(&so, 0, sizeof so);
+    so.n = n_rows;
+    for (int k = 0; k < n_rows; ++k) {
+        const DevGeo& d = S.local[k]->d;
+        header_of(d, rows.data() + (size_t)HDR * k);
+        rows[(size_t)HDR * k + 9] = S.me < 0 ? GPK_OK : local_rc;
+        so.geom_off[k] = d.geom_off;
+        so.part_off[k] = d.part_off;
+        so.ring_off[k] = d.ring_off;
+    }
+    int64_t* stage_at = S.me < 0 ? hdr_dev : hdr_dev + (size_t)HDR * W;
+    hipError_t e = hipMemcpyAsync(stage_at, rows.data(), sizeof(int64_t) * rows.size(), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && local_rc == GPK_OK) {
+        hipLaunchKernelGGL(first_offsets_kernel, dim3(1), dim3(COMM_MAX_WORLD), 0, s, so, stage_at);
+        e = hipGetLastError();
+    }
+    if (S.me >= 0) {  // (always: also after a local failure — the row then says so)
+        const ncclResult_t n = S.r->AllGather(stage_at, hdr_dev, HDR, ncclInt64, S.c->comm, s);
+        if (n != ncclSuccess) return fail(GPK_ERR_DEVICE, "ncclAllGather failed: %s", S.r->GetErrorString(n));
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(hdr.data(), hdr_dev, sizeof(int64_t) * (size_t)(HDR * W), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);  // (`rows` is a local: the copy out of it is done by now)
+    if (e != hipSuccess) return fail(GPK_ERR_DEVICE, "allgatherv: %s", hipGetErrorString(e));
+    for (int k = 0; k < W; ++k)
+        if (hdr[(size_t)HDR * k + 9] != GPK_OK && *peer_rc == GPK_OK) *peer_rc = (int32_t)hdr[(size_t)HDR * k + 9];
     return GPK_OK;
 }
 // piece k of one buffer (counts[k] elements of `elem` bytes, read at src(k)) -> out + begin[k] * elem.  Every rank issues the same
@@ -214,8 +249,7 @@ static int32_t move_pieces(const Shards& S, SrcOf src, const int64_t* counts, co
 // the others waiting inside the broadcasts that follow
 static int32_t agree(const Shards& S, int32_t my_rc, hipStream_t s) {
     if (S.me < 0) return my_rc;
-    int64_t* w = (int64_t*)workspace_aux(0).take(sizeof(int64_t) * (size_t)(S.W + 1));
-    if (!w) return my_rc != GPK_OK ? my_rc : fail(GPK_ERR_OOM, "allgatherv: scratch");
+    int64_t* w = S.c->scratch + (size_t)HDR * (S.W + 1);  // (reserved with the communicator: W + 1 words behind the header rows)
     const int64_t mine = my_rc;
     std::vector<int64_t> all((size_t)S.W);
     GPK_HIP(hipMemcpyAsync(w + S.W, &mine, sizeof mine, hipMemcpyHostToDevice, s));
@@ -236,7 +270,9 @@ static int32_t assemble_column(const Shards& S, hipStream_t s, gpk_geoarray** ou
     const bool has_geom = type != GPK_GEOM_POINT, has_part = type == GPK_GEOM_MULTIPOLYGON,
                has_ring = type == GPK_GEOM_POLYGON || type == GPK_GEOM_MULTILINESTRING || type == GPK_GEOM_MULTIPOLYGON;
     std::vector<int64_t> hdr;
-    GPK_TRY(gather_header(S, hdr, s));
+    int32_t peer_rc = GPK_OK;
+    GPK_TRY(gather_header(S, hdr, s, GPK_OK, &peer_rc));
+    if (peer_rc != GPK_OK) return fail(peer_rc, "allgatherv: a rank reported status %d before the exchange", peer_rc);
     bool any_valid = false;
     int64_t tot[4] = {0, 0, 0, 0};
     for (int k = 0; k < W; ++k) {
@@ -415,6 +451,13 @@ int32_t gpk_comm_init(int32_t rank, int32_t world, const uint8_t id[128], gpk_co
         delete c;
         return fail(GPK_ERR_DEVICE, "ncclCommInitRank failed: %s", r->GetErrorString(n));
     }
+    c->scratch = nullptr;
+    const hipError_t he = hipMalloc((void**)&c->scratch, sizeof(int64_t) * (size_t)((HDR + 1) * (world + 1)));
+    if (he != hipSuccess) {
+        (void)r->CommDestroy(c->comm);
+        delete c;
+        return fail(GPK_ERR_OOM, "comm: scratch: %s", hipGetErrorString(he));
+    }
     *out = c;
     return GPK_OK;
 }
@@ -423,6 +466,7 @@ int32_t gpk_comm_free(gpk_comm* c) {
     if (!c) return GPK_OK;
     const Rccl* r;
     if (rccl(&r) == GPK_OK) (void)r->CommDestroy(c->comm);
+    if (c->scratch) (void)hipFree(c->scratch);
     delete c;
     return GPK_OK;
 }
