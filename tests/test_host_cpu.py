@@ -370,3 +370,48 @@ def test_bench_gpus_n_without_a_launcher_spawns_n_ranks():
 
     if not torch.cuda.is_available():
         assert r.returncode != 0 and r.stderr.count("no GPU visible") == 2
+
+
+def test_arrow_c_data_import_walks_the_structs_before_it_needs_a_device():
+    """gpk_geoarray_from_arrow (the reference's FFI seam, py-geopolars/src/ffi.rs:12-32) is host code up to the upload: what is not a
+    geometry column is refused by its FORMAT (no device involved), what is one gets as far as the device and — here, without one —
+    says GPK_ERR_DEVICE; separated x / y coordinates reach the host WKB encoder through the same descriptor"""
+    import ctypes as C
+
+    import pyarrow as pa
+
+    from geopolars_amd.geoarrow import DeviceGeoArray
+
+    from geopolars_amd import synth as _s
+
+    host = _s.star_polygons(6, 8)
+    st = pa.StructArray.from_arrays([pa.array(host.xy[:, 0]), pa.array(host.xy[:, 1])], ["x", "y"])
+    col = pa.ListArray.from_arrays(pa.array(host.geom_offsets), pa.ListArray.from_arrays(pa.array(host.ring_offsets), st))
+    on_gpu = _abi.device_count() > 0
+    for bad in (pa.array([1.0, 2.0]), pa.array(["a"]), pa.ListArray.from_arrays(pa.array([0, 2], type=pa.int32()), pa.array([1.0, 2.0]))):
+        with pytest.raises(_abi.GeopolarsHipError) as e:
+            DeviceGeoArray.from_arrow(bad)
+        assert e.value.code == _abi.GPK_ERR_MISMATCHED_GEOMETRY
+    with pytest.raises(_abi.GeopolarsHipError) as e:
+        DeviceGeoArray.from_arrow(col, geom_type=_abi.GEOM_POINT)  # two list levels cannot be points
+    assert e.value.code == _abi.GPK_ERR_MISMATCHED_GEOMETRY
+    if not on_gpu:
+        for ok in (col, col.slice(1, 3), pa.array([b"\x01"], type=pa.large_binary())):
+            with pytest.raises(_abi.GeopolarsHipError) as e:
+                DeviceGeoArray.from_arrow(ok)
+            assert e.value.code == _abi.GPK_ERR_DEVICE
+    # the host encoder reads separated coordinates
+    d = host.desc()
+    xs, ys = np.ascontiguousarray(host.xy[:, 0]), np.ascontiguousarray(host.xy[:, 1])
+    d.xy, d.x, d.y = None, xs.ctypes.data, ys.ctypes.data
+    nb = C.c_int64(0)
+    off = np.zeros(len(host) + 1, dtype=np.int32)
+    _abi.check(_abi.lib().gpk_wkb_encode(C.byref(d), off.ctypes.data, None, 0, C.byref(nb)))
+    vals = np.zeros(nb.value, dtype=np.uint8)
+    _abi.check(_abi.lib().gpk_wkb_encode(C.byref(d), off.ctypes.data, vals.ctypes.data, len(vals), C.byref(nb)))
+    v2, o2 = host.to_wkb()
+    assert np.array_equal(vals, v2) and np.array_equal(off, o2)
+    # coordinates given twice are refused
+    d.xy = host.xy.ctypes.data
+    out = C.c_void_p()
+    assert _abi.lib().gpk_geoarray_upload(C.byref(d), None, C.byref(out)) in (_abi.GPK_ERR_INVALID_ARGUMENT, _abi.GPK_ERR_DEVICE)
