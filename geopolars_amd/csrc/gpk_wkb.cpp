@@ -17,6 +17,10 @@ struct Reader {
     bool ok = true;
     bool le = true;
 
+    int extra = 0;  // Z / M ordinates per coordinate of the geometry being read (dropped: GeoSeries is 2D, as geozero's to_geo is)
+    void skip_extra() {
+        for (int i = 0; i < extra; ++i) (void)f64();
+    }
     uint8_t u8() {
         if (p + 1 > end) {
             ok = false;
@@ -85,10 +89,17 @@ int read_header(Reader& r) {
     uint32_t t = r.u32();
     if (!r.ok) return 0;
     if (t & 0x20000000u) (void)r.u32();  // EWKB SRID
-    if (t & 0xC0000000u) return 0;        // EWKB Z / M
+    // Z / M ordinates are read past: EWKB flags 0x80000000 (Z) / 0x40000000 (M); ISO type codes 1000 + t (Z), 2000 + t (M), 3000 + t (ZM)
+    int extra = ((t & 0x80000000u) ? 1 : 0) + ((t & 0x40000000u) ? 1 : 0);
     t &= 0x0FFFFFFFu;
-    if (t >= 1000) return 0;  // ISO Z / M / ZM
-    if (t < 1 || t > 6) return 0;
+    if (t >= 1000) {
+        const uint32_t dim = t / 1000;
+        if (dim > 3 || extra) return 0;
+        extra = dim == 3 ? 2 : 1;
+        t %= 1000;
+    }
+    if (t < 1 || t > 6) return 0;  // (7 = GeometryCollection: no GeoArrow nesting holds it)
+    r.extra = extra;
     return (int)t;
 }
 
@@ -108,6 +119,7 @@ Family family_of(int t) {
 void read_coords(Reader& r, uint32_t n, Sink& s) {
     for (uint32_t i = 0; i < n && r.ok; ++i) {
         const double x = r.f64(), y = r.f64();
+        r.skip_extra();
         if (r.ok) s.coord(x, y);
     }
 }
@@ -187,6 +199,7 @@ extern "C" int32_t gpk_wkb_decode(const uint8_t* values, const int32_t* offsets,
             switch (t) {
             case 1: {
                 const double x = r.f64(), y = r.f64();
+                r.skip_extra();
                 if (out_type == GPK_GEOM_POINT)
                     s.coord(x, y);
                 else if (!(std::isnan(x) && std::isnan(y)))
@@ -216,6 +229,7 @@ extern "C" int32_t gpk_wkb_decode(const uint8_t* values, const int32_t* offsets,
                     }
                     if (ct == 1) {
                         const double x = r.f64(), y = r.f64();
+                        r.skip_extra();
                         if (!(std::isnan(x) && std::isnan(y))) s.coord(x, y);
                     } else if (ct == 2) {
                         const uint32_t n = r.u32();

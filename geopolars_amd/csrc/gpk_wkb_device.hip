@@ -7,6 +7,8 @@
 //   fill  : one lane per row re-parses and writes coordinates and offsets.
 // Handles little-endian ISO WKB and EWKB with SRID, 2D, types 1-6 with the same promotion rules as the host
 // decoder (gpk_wkb.cpp); anything else (big-endian, Z/M, mixed families, truncation) is reported, never guessed.
+#include <vector>
+
 #include "gpk_device.h"
 #include "gpk_scan.h"
 
@@ -533,8 +535,41 @@ extern "C" int32_t gpk_geoarray_from_wkb(const uint8_t* wkb_values, const int32_
     W_HIP(hipStreamSynchronize(s));
     const uint32_t hflags = (uint32_t)((volatile unsigned long long*)totals_host)[3];
     const uint32_t longest_row = (uint32_t)(((volatile unsigned long long*)totals_host)[3] >> 32);
-    if (hflags & 0x80000000u)
-        return done(fail(GPK_ERR_MISMATCHED_GEOMETRY, "gpk_geoarray_from_wkb: malformed, big-endian or Z/M WKB in the column (use gpk_wkb_decode on the host)"));
+    if (hflags & 0x80000000u) {
+        // The column holds rows this decoder does not read — big-endian records, Z / M ordinates (EWKB flags or ISO 1000-codes) — or
+        // malformed ones.  A HOST column is parsed by the host decoder instead (gpk_wkb_decode reads both byte orders and drops Z / M, as
+        // geozero's to_geo does for the reference, util.rs:27-37) and uploaded: the caller gets its handle either way, the exotic
+        // encodings just do not get the GPU's parse rate.  A DEVICE column is reported: its bytes are not the host's to read.
+        if (mem_space != GPK_MEM_HOST)
+            return done(fail(GPK_ERR_MISMATCHED_GEOMETRY, "gpk_geoarray_from_wkb: malformed, big-endian or Z/M WKB in a device column (decode it with gpk_wkb_decode on the host)"));
+        int64_t counts[5] = {0, 0, 0, 0, 0};
+        W_TRY(gpk_wkb_decode(wkb_values, wkb_offsets, n_rows, validity, counts, nullptr, nullptr, nullptr, nullptr));
+        const int ht = (int)counts[0];
+        std::vector<double> hxy((size_t)(2 * counts[4] + 2));
+        std::vector<int32_t> hg((size_t)(n_rows + 1)), hp((size_t)(counts[2] + 1)), hr((size_t)(counts[3] + 1));
+        W_TRY(gpk_wkb_decode(wkb_values, wkb_offsets, n_rows, validity, counts, hxy.data(), hg.data(), hp.data(), hr.data()));
+        gpk_geoarrow_desc hd;
+        memset(&hd, 0, sizeof hd);
+        hd.geom_type = ht;
+        hd.mem_space = GPK_MEM_HOST;
+        hd.n_geoms = n_rows;
+        hd.n_coords = counts[4];
+        hd.xy = hxy.data();
+        hd.validity = validity;
+        const bool h_ring = ht == GPK_GEOM_MULTILINESTRING || ht == GPK_GEOM_POLYGON || ht == GPK_GEOM_MULTIPOLYGON;
+        if (ht != GPK_GEOM_POINT) hd.geom_offsets = hg.data();
+        if (ht == GPK_GEOM_MULTIPOLYGON) {
+            hd.part_offsets = hp.data();
+            hd.n_parts = counts[2];
+        }
+        if (h_ring) {
+            hd.ring_offsets = hr.data();
+            hd.n_rings = counts[3];
+        }
+        W_TRY(gpk_geoarray_upload(&hd, stream, out));
+        if (out_geom_type) *out_geom_type = ht;
+        return done(GPK_OK);
+    }
     const bool fp = hflags & ((1u << 1) | (1u << 4)), fl = hflags & ((1u << 2) | (1u << 5)), fg = hflags & ((1u << 3) | (1u << 6));
     if ((int)fp + (int)fl + (int)fg > 1)
         return done(fail(GPK_ERR_MISMATCHED_GEOMETRY, "gpk_geoarray_from_wkb: mixed geometry families in one column"));

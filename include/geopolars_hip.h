@@ -120,7 +120,7 @@ int32_t gpk_geoarray_free(gpk_geoarray* a);
 /* HBM bytes held by the handle (owned + borrowed), for roofline accounting */
 int32_t gpk_geoarray_nbytes(const gpk_geoarray* a, int64_t* out_bytes);
 
-/* WKB BinaryArray<i32> (util.rs:27-37 input format) -> GeoArrow buffers, host side.
+/* WKB BinaryArray<i32> (util.rs:27-37 input format) -> GeoArrow buffers, host side (both byte orders; Z / M ordinates are read past).
  * Pass 1 (out == NULL): validates and fills `counts` = {geom_type, n_geoms, n_parts, n_rings, n_coords}.
  * Pass 2: fills caller-allocated buffers of exactly those sizes.  Mixed Polygon/MultiPolygon input is
  * promoted to MULTIPOLYGON, mixed LineString/MultiLineString to MULTILINESTRING. */
@@ -130,8 +130,11 @@ int32_t gpk_wkb_decode(const uint8_t* wkb_values, const int32_t* wkb_offsets, in
 
 /* The same decode on the GPU: the raw WKB column (values + offsets, in `mem_space`) is copied to HBM once and
  * decoded there into a device-resident handle (scan -> prefix sums -> fill); the GeoArrow SoA never exists on
- * the host.  Little-endian ISO WKB / EWKB+SRID, 2D, types 1-6, same promotion rules as gpk_wkb_decode;
- * big-endian or Z/M input is reported (GPK_ERR_MISMATCHED_GEOMETRY) so the caller can use the host decoder. */
+ * the host.  Little-endian ISO WKB / EWKB+SRID, 2D, types 1-6, same promotion rules as gpk_wkb_decode.  A HOST column that also
+ * holds big-endian records or Z / M ordinates (EWKB flags, ISO 1000-codes) is parsed by the host decoder instead — both byte orders,
+ * Z / M dropped like geozero's to_geo drops them for the reference — and uploaded: same handle, without the GPU's parse rate; in a
+ * DEVICE column such rows are reported (GPK_ERR_MISMATCHED_GEOMETRY).  Type 7 (GeometryCollection, geoseries.rs:60-73) has no GeoArrow
+ * nesting and is reported either way. */
 int32_t gpk_geoarray_from_wkb(const uint8_t* wkb_values, const int32_t* wkb_offsets, int64_t n_rows,
                               const uint8_t* validity, int32_t mem_space, void* stream,
                               gpk_geoarray** out, int32_t* out_geom_type);

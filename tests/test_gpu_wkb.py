@@ -77,17 +77,52 @@ def test_nulls_multipoints_and_operators_on_a_device_decoded_series(gpk, oracle)
 
 
 def test_unsupported_input_is_reported(gpk):
+    """what the GPU decoder does not read — big-endian records, Z / M ordinates — reaches HBM through the host decoder when the column
+    is in host memory (round 5; geozero's to_geo, which the reference decodes with, reads both and drops Z / M); a DEVICE column with
+    such rows, mixed families, GeometryCollections and truncated rows are reported"""
+    import torch
+
     be = struct.pack(">BIdd", 0, 1, 1.0, 2.0)
-    with pytest.raises(_abi.MismatchedGeometry):
-        DeviceGeoArray.from_wkb(np.frombuffer(be, np.uint8), np.array([0, len(be)], np.int32))
-    z = struct.pack("<BIddd", 1, 1001, 0, 0, 0)
-    with pytest.raises(_abi.MismatchedGeometry):
-        DeviceGeoArray.from_wkb(np.frombuffer(z, np.uint8), np.array([0, len(z)], np.int32))
+    z = struct.pack("<BIddd", 1, 1001, 3.0, 4.0, 99.0)
+    zm = struct.pack("<BIdddd", 1, 1 | 0xC0000000, 5.0, 6.0, 7.0, 8.0)
+    le = struct.pack("<BIdd", 1, 1, 9.0, 10.0)
+    rows = [le, be, z, zm, le]
+    off = np.cumsum([0] + [len(r) for r in rows]).astype(np.int32)
+    vals = np.frombuffer(b"".join(rows), np.uint8)
+    got = DeviceGeoArray.from_wkb(vals, off)
+    assert got.geom_type == _abi.GEOM_POINT and got.download().xy.tolist() == [[9.0, 10.0], [1.0, 2.0], [3.0, 4.0], [5.0, 6.0], [9.0, 10.0]]
+    # a polygon column where a few rows are big-endian / carry Z: the same handle as the all-little-endian 2D column
+    host = synth.star_polygons(300, 9)
+    v2, o2 = host.to_wkb()
+    recs = [bytes(v2[o2[i] : o2[i + 1]]) for i in range(len(host))]
+
+    def with_z(rec, big):
+        n = struct.unpack("<I", rec[9:13])[0]
+        xy = np.frombuffer(rec[13:], "<f8").reshape(n, 2)
+        e = ">" if big else "<"
+        body = b"".join(struct.pack(e + "ddd", x, y, 42.0) for x, y in xy)
+        return struct.pack(e + "BII", 0 if big else 1, 1003, 1) + struct.pack(e + "I", n) + body
+
+    for i in (3, 77, 150, 299):
+        recs[i] = with_z(recs[i], big=i % 2 == 1)
+    off = np.cumsum([0] + [len(r) for r in recs]).astype(np.int32)
+    got = DeviceGeoArray.from_wkb(np.frombuffer(b"".join(recs), np.uint8), off).download()
+    assert got.geom_type == _abi.GEOM_POLYGON and np.array_equal(got.xy, host.xy) and np.array_equal(got.ring_offsets, host.ring_offsets)
+    # the same rows in DEVICE memory are reported (gpk_geoarray_from_wkb with mem_space DEVICE)
+    import ctypes as C
+
+    dv = torch.from_numpy(np.frombuffer(be, np.uint8).copy()).cuda()
+    do = torch.tensor([0, len(be)], dtype=torch.int32).cuda()
+    out, gt = C.c_void_p(), C.c_int32(-1)
+    assert _abi.lib().gpk_geoarray_from_wkb(dv.data_ptr(), do.data_ptr(), 1, None, _abi.MEM_DEVICE, None, C.byref(out), C.byref(gt)) == _abi.GPK_ERR_MISMATCHED_GEOMETRY
     pt = struct.pack("<BIdd", 1, 1, 1.0, 2.0)
     ls = struct.pack("<BII", 1, 2, 1) + struct.pack("<dd", 0, 0)
     with pytest.raises(_abi.MismatchedGeometry):
         DeviceGeoArray.from_wkb(np.frombuffer(pt + ls, np.uint8), np.array([0, len(pt), len(pt) + len(ls)], np.int32))
+    gc = struct.pack("<BII", 1, 7, 0)
     with pytest.raises(_abi.MismatchedGeometry):
+        DeviceGeoArray.from_wkb(np.frombuffer(gc, np.uint8), np.array([0, len(gc)], np.int32))
+    with pytest.raises(_abi.GeopolarsHipError):
         DeviceGeoArray.from_wkb(np.frombuffer(pt[:-3], np.uint8), np.array([0, len(pt) - 3], np.int32))
     empty = DeviceGeoArray.from_wkb(np.zeros(0, np.uint8), np.zeros(1, np.int32))
     assert empty.n_geoms == 0
@@ -236,10 +271,13 @@ def test_a_ring_longer_than_its_row_is_reported(gpk):
     bad = bytearray(good)
     bad[9:13] = struct.pack("<I", 5)  # claims five coordinates, the row holds four
     values, offsets = _column([good, bytes(bad), good])
-    with pytest.raises(_abi.MismatchedGeometry):
+    # (round 5: a host column the GPU scan flags is handed to the host decoder, which names the row: INVALID_OFFSETS, "truncated or malformed")
+    with pytest.raises(_abi.GeopolarsHipError) as e:
         DeviceGeoArray.from_wkb(values, offsets)
+    assert e.value.code in (_abi.GPK_ERR_MISMATCHED_GEOMETRY, _abi.GPK_ERR_INVALID_OFFSETS) and "row 1" in str(e.value)
     huge = bytearray(good)
     huge[9:13] = struct.pack("<I", 0xFFFFFFF0)  # 16 n overflows 32 bits
     values, offsets = _column([bytes(huge)])
-    with pytest.raises(_abi.MismatchedGeometry):
+    with pytest.raises(_abi.GeopolarsHipError) as e:
         DeviceGeoArray.from_wkb(values, offsets)
+    assert e.value.code in (_abi.GPK_ERR_MISMATCHED_GEOMETRY, _abi.GPK_ERR_INVALID_OFFSETS)

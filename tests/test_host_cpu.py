@@ -108,10 +108,27 @@ def test_wkb_decoder_big_endian_ewkb_and_errors():
     a = GeoArrowArray.from_wkb(vals, np.array([0, len(poly), len(poly) + len(mpoly)], np.int32))
     assert a.geom_type == _abi.GEOM_MULTIPOLYGON
     assert a.geom_offsets.tolist() == [0, 1, 3] and a.part_offsets.tolist() == [0, 1, 2, 3] and a.ring_offsets.tolist() == [0, 4, 8, 12]
-    # Z geometry is rejected, as are mixed families and truncated buffers
-    z = struct.pack("<BIddd", 1, 1001, 0, 0, 0)
+    # Z / M ordinates are read past (geozero's to_geo, which the reference decodes rows with, yields 2D geometries): ISO 1000-codes,
+    # EWKB flag bits, either byte order, nested in multi-geometries
+    z_iso = struct.pack("<BIddd", 1, 1001, 7.0, 8.0, 99.0)
+    m_iso = struct.pack(">BIddd", 0, 2001, 1.0, 2.0, 55.0)
+    zm_iso = struct.pack("<BIdddd", 1, 3001, 3.0, 4.0, 9.0, 9.5)
+    z_ewkb = struct.pack("<BIIddd", 1, 1 | 0x80000000 | 0x20000000, 4326, 5.0, 6.0, -1.0)
+    zm_ewkb = struct.pack("<BIdddd", 1, 1 | 0xC0000000, 10.0, 11.0, 1.0, 2.0)
+    rows = [z_iso, m_iso, zm_iso, z_ewkb, zm_ewkb]
+    off = np.cumsum([0] + [len(r) for r in rows]).astype(np.int32)
+    a = GeoArrowArray.from_wkb(np.frombuffer(b"".join(rows), np.uint8), off)
+    assert a.geom_type == _abi.GEOM_POINT and a.xy.tolist() == [[7.0, 8.0], [1.0, 2.0], [3.0, 4.0], [5.0, 6.0], [10.0, 11.0]]
+    ring_z = struct.pack("<I", 4) + b"".join(struct.pack("<ddd", *c) for c in [(0, 0, 5), (1, 0, 5), (0, 1, 5), (0, 0, 5)])
+    poly_z = struct.pack("<BII", 1, 1003, 1) + ring_z
+    mpoly_z = struct.pack("<BII", 1, 1006, 2) + poly_z + poly_z
+    a = GeoArrowArray.from_wkb(np.frombuffer(poly_z + mpoly_z, np.uint8), np.array([0, len(poly_z), len(poly_z) + len(mpoly_z)], np.int32))
+    assert a.geom_type == _abi.GEOM_MULTIPOLYGON and a.ring_offsets.tolist() == [0, 4, 8, 12]
+    assert a.xy[:4].tolist() == [[0, 0], [1, 0], [0, 1], [0, 0]] and np.array_equal(a.xy[:4], a.xy[8:12])
+    # a GeometryCollection (type 7) has no GeoArrow nesting: rejected, as are mixed families and truncated buffers
+    gc = struct.pack("<BII", 1, 7, 0)
     with pytest.raises(_abi.MismatchedGeometry):
-        GeoArrowArray.from_wkb(np.frombuffer(z, np.uint8), np.array([0, len(z)], np.int32))
+        GeoArrowArray.from_wkb(np.frombuffer(gc, np.uint8), np.array([0, len(gc)], np.int32))
     with pytest.raises(_abi.MismatchedGeometry):
         v = np.frombuffer(pt_be + poly, np.uint8)
         GeoArrowArray.from_wkb(v, np.array([0, len(pt_be), len(pt_be) + len(poly)], np.int32))
