@@ -250,17 +250,19 @@ def take_column(column, idx: np.ndarray):
 
 
 def spatial_join(lhs, rhs, options: Optional[SpatialJoinArgs] = None):
-    """spatial_join(lhs, rhs, SpatialJoinArgs) over pyarrow Tables with a WKB `geometry` column
-    (spatial_index.rs:44-45).  Returns a pyarrow Table shaped like the reference's result:
-    suffixed left columns, then suffixed right columns (spatial_index.rs:165-199)."""
+    """spatial_join(lhs, rhs, SpatialJoinArgs) over pyarrow Tables with a `geometry` column (spatial_index.rs:44-45) — WKB binary as the
+    reference holds it, or a native GeoArrow nesting.  Returns a pyarrow Table shaped like the reference's result: suffixed left columns,
+    then suffixed right columns (spatial_index.rs:165-199).  The geometry columns cross into the library the way every Series crosses
+    the reference's FFI — as Arrow C Data Interface structs (py-geopolars/src/ffi.rs:12-32; gpk_geoarray_from_arrow): WKB is decoded
+    on the GPU, nothing is rewritten on the host."""
     import pyarrow as pa
 
     options = options or SpatialJoinArgs()
     if options.join_type not in ("inner", "left"):
         # spatial_index.rs:200-202 rejects every other JoinType
         raise _abi.GeopolarsHipError(_abi.GPK_ERR_INVALID_ARGUMENT, "Failed to generate the spatial index for the left dataframe")
-    lgeo = GeoSeries.from_wkb(lhs.column("geometry"))
-    rgeo = GeoSeries.from_wkb(rhs.column("geometry"))
+    lgeo = GeoSeries.from_arrow(lhs.column("geometry"))
+    rgeo = GeoSeries.from_arrow(rhs.column("geometry"))
     r_index = options.r_index or SpatialIndex(rgeo)
     pairs, counts = join_pairs(lgeo, rgeo, options.predicate, r_index)
     li, ri = join_indices(counts, pairs, options.join_type)  # i64 row indices, r = -1 for unmatched left rows
