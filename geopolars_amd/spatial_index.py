@@ -266,11 +266,24 @@ def spatial_join(lhs, rhs, options: Optional[SpatialJoinArgs] = None):
     r_index = options.r_index or SpatialIndex(rgeo)
     pairs, counts = join_pairs(lgeo, rgeo, options.predicate, r_index)
     li, ri = join_indices(counts, pairs, options.join_type)  # i64 row indices, r = -1 for unmatched left rows
+    def as_wkb(column, geo: GeoSeries):
+        """a native GeoArrow geometry column leaves the join the way the reference's geometry columns are held — WKB binary
+        (from_geom_vec, util.rs:11-24) — encoded on the GPU from the series the join already uploaded"""
+        if pa.types.is_binary(column.type) or pa.types.is_large_binary(column.type):
+            return column
+        values, offsets = geo.to_wkb()
+        out = pa.Array.from_buffers(pa.binary(), len(geo), [None, pa.py_buffer(offsets.tobytes()), pa.py_buffer(values.tobytes())])
+        if column.null_count:
+            import pyarrow.compute as pc
+
+            out = pc.if_else(pc.is_valid(column.combine_chunks() if isinstance(column, pa.ChunkedArray) else column), out, pa.scalar(None, pa.binary()))
+        return out
+
     cols, names = [], []
     for name in lhs.column_names:
-        cols.append(take_column(lhs.column(name), li))
+        cols.append(take_column(as_wkb(lhs.column(name), lgeo) if name == "geometry" else lhs.column(name), li))
         names.append(name + (options.l_suffix or ""))
     for name in rhs.column_names:
-        cols.append(take_column(rhs.column(name), ri))
+        cols.append(take_column(as_wkb(rhs.column(name), rgeo) if name == "geometry" else rhs.column(name), ri))
         names.append(name + (options.r_suffix or ""))
     return pa.table(cols, names=names)

@@ -177,3 +177,27 @@ def test_separated_device_buffers_and_a_join_over_struct_coordinates(gpk, oracle
     _abi.check(_abi.lib().gpk_wkb_encode(C.byref(d), off.ctypes.data, vals.ctypes.data, len(vals), C.byref(nb)))
     v2, o2 = pts.to_wkb()
     assert np.array_equal(vals, v2) and np.array_equal(off, o2)
+
+
+def test_spatial_join_over_tables_whose_geometry_columns_are_native_geoarrow(gpk, oracle):
+    """the dataframe-shaped call (spatial_index.rs:37-204 over pyarrow tables): geometry columns as the reference's Python layer builds
+    them — Struct<x, y> under list levels (internals/geoseries.py:86-113) — or as WKB binary give the same joined table"""
+    from geopolars_amd.spatial_index import SpatialJoinArgs, spatial_join
+
+    polys = synth.star_polygons(300, 16)
+    pts = synth.uniform_points(20_000, seed=7)
+    lt_native = pa.table({"id": pa.array(np.arange(len(pts))), "geometry": _struct_coords(pts.xy)})
+    rt_native = pa.table({"name": pa.array([f"p{i}" for i in range(len(polys))]), "geometry": _nested(polys, _struct_coords(polys.xy))})
+    lt_wkb = pa.table({"id": lt_native.column("id"), "geometry": pts.to_arrow_wkb()})
+    rt_wkb = pa.table({"name": rt_native.column("name"), "geometry": polys.to_arrow_wkb()})
+    for how in ("inner", "left"):
+        a = spatial_join(lt_native, rt_native, SpatialJoinArgs(join_type=how))
+        b = spatial_join(lt_wkb, rt_wkb, SpatialJoinArgs(join_type=how))
+        assert a.column_names == b.column_names and a.num_rows == b.num_rows
+        assert a.column("id_left").equals(b.column("id_left")) and a.column("name_right").equals(b.column("name_right"))
+        # (a native geometry column leaves the join as WKB, like the reference's: the same bytes as the WKB tables' columns)
+        assert a.column("geometry_left").equals(b.column("geometry_left")) and a.column("geometry_right").equals(b.column("geometry_right"))
+    ep, ec, _ = oracle.spatial_join(pts, polys, "intersects", mode=0)
+    inner = spatial_join(lt_native, rt_native)
+    assert inner.num_rows == len(ep)
+    assert np.array_equal(inner.column("id_left").to_numpy(), ep[:, 0]) and inner.column("name_right").to_pylist() == [f"p{j}" for j in ep[:, 1]]
