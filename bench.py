@@ -385,7 +385,7 @@ def run_c2(ctx: Ctx) -> None:
         else:
             join_pairs_enqueue(s["pts"], polys, index, "intersects", s["counts"], s["pairs"], s["total"], left_row_base=s["base"], stream=stream)
 
-    # (a step of the fused join is the one launch `gpk_pip_tile`; with GPK_TILE_KERNEL=route — the round-3 pair — the writer shows up)
+    # (a step of the fused join is the one launch `gpk_pip_tile`; with GPK_TILE_KERNEL=chain — chain tile kernel + writer — the writer shows up)
     elapsed, k_tile, n_tile, warm = ctx.timed(step, "gpk_pip_tile", args.steps, args.warmup, profile=not args.no_profile,
                                               one_launch_steps=lambda w: "gpk_pip_write" not in w and not sync_steps)
     fused = "gpk_pip_write" not in warm
@@ -479,9 +479,9 @@ def run_c2(ctx: Ctx) -> None:
         "polygons": m,
         "vertices_per_polygon": args.verts,
         "hits_per_step": h,
-        "algorithm": "ONE launch per join (persistent work-groups): two-level exact raster routing (level 1 from an LDS image, level 2 = one 16-byte half-cell record) -> `test` sub-cells decided from the half cell's local chain (base winding + about two ring edges read from the right side's extended coordinates, exact orientation filter; uncertifiable rows go through the generic exact walk) -> a wave's hits parked in its rows' pair slots, work-group totals chained through epoch-tagged words, sorted (l,r) pairs + counts written by the same launch; N x M logical pairs counted, raster-rejected pairs included"
+        "algorithm": "ONE launch per join (pip_flow_kernel, persistent work-groups): two-level exact raster routing (level 1 from an LDS image, level 2 = one 16-byte half-cell record) -> a row with a polygon to be in is a hit at once (4-byte entry in the tile's slots of a global pool, count 1); `test` points wait on the wave's LDS list and are decided in dense passes from the half cell's local chain (base winding + about two ring edges, exact orientation filter; uncertifiable rows go through the generic exact walk), a failed test kills its entry -> work-group totals chained through epoch-tagged words, sorted (l,r) pairs written from the pool 64 entries at a time by the same launch; N x M logical pairs counted, raster-rejected pairs included"
         if fused
-        else "round-3 pair of kernels (GPK_TILE_KERNEL=route): routed tile kernel + writer",
+        else "chain tile kernel + writer (GPK_TILE_KERNEL=chain)",
         "index_tables": index.describe(),
         "index": "rebuilt per step" if args.index_per_step else "prebuilt r_index (spatial_index.rs:20-21)",
         "call": "gpk_spatial_join (blocking)" if sync_steps else "gpk_spatial_join_async (stream-ordered; the timed region ends synchronised)",

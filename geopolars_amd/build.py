@@ -26,6 +26,7 @@ SOURCES = [
     "gpk_runtime.hip",
     "gpk_unary.hip",
     "gpk_join.hip",
+    "gpk_pipflow.hip",
     "gpk_pipindex.hip",
     "gpk_rowwise.hip",
     "gpk_hull.hip",

@@ -28,6 +28,7 @@
 #include "gpk_contains.h"
 #include "gpk_lineal.h"
 #include "gpk_scan.h"
+#include "gpk_pipshared.h"
 
 namespace gpk {
 
@@ -186,12 +187,6 @@ constexpr int PIP_WPT = GPK_WR_WPT;            // writer: consecutive points per
 constexpr int PIP_WTILE = WR_BLOCK * PIP_WPT;  // writer: points per work-group (a multiple of PIP_TILE)
 constexpr int WR_CAP = PIP_WTILE;              // writer: pairs of one tile compacted in LDS (16 KB) before the coalesced copy-out
 static_assert(PIP_WTILE % PIP_TILE == 0, "a writer tile is a whole number of pip_tile tiles");
-// per-point result code handed from pip_tile to pip_write: a geometry id (exactly one hit), CODE_NONE, or
-// CODE_MULTI (several hits: the writer re-enumerates them with the generic walk)
-constexpr uint32_t CODE_NONE = 0xFFFFFFFFu, CODE_MULTI = 0xFFFFFFFEu;
-// a code with the top bit set (and not one of the two above) is 0x80000000 | offset into the multi-hit pool:
-// pool[offset] = m, then the m geometry ids (ascending) of a point that lies in several geometries
-constexpr uint32_t CODE_POOL = 0x80000000u;
 constexpr int PIP_KHIT = 2;  // part hits remembered per point in LDS; rows with more take the generic walk
 
 // Visits every right-side row whose closed bbox contains the point, in ascending id order.
@@ -1146,98 +1141,38 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_LEAN_MINWAVES) void pip_tile_lean_ke
     }
 }
 
-// ---- pip_tile_chain / pip_tile_route: the lean tile step with `test` sub-cells decided from their local chains -----------------
-// (gpk_index::pip_lean with PipView::sub_aux: chain tables, gpk_index.h.)  One WAVE owns a tile of 64 * P points and never meets
-// another wave: no work-group queue, no barrier.  A point's way through the tables, one dependent memory round trip per step:
+// ---- pip_tile_chain: the lean tile step with `test` sub-cells decided from their local chains ----------------------------------------
+// (gpk_index::pip_lean with chain tables, gpk_index.h.)  One WAVE owns a tile of 64 * P points and never meets another wave: no
+// work-group queue, no barrier.  A point's way through the tables, one dependent memory round trip per step:
 //   1. the point itself (coalesced 16-byte loads, non-temporal: read once);
-//   2. its raster cell: empty -> done; strictly inside a part -> the level-1 word names it; an edge crosses the cell -> the half-cell
-//      record of the point's sub-cell (ONE 16-byte request: 32 labels, the part, where the half's chain entries start);
-//   3. the label: outside / inside -> done; `test` -> the sub-cell's chain entry (the rank of the label among the half's `test`
-//      labels locates it): a head word (edge count, base winding) + one 64-byte line with the chain's vertices;
-//   4. base + the contributions of the chain's one or two edges (1.26 on the C2 right side); count + code + tile total.
+//   2. its raster cell's level-1 word: empty -> done; strictly inside a part -> the word names it; an edge crosses the cell -> the
+//      half-cell record of the point's sub-cell (ONE 16-byte request: 32 labels, the part, the half's chain word);
+//   3. the label: outside / inside -> done; `test` -> the half cell's chain (gpk_index.h: GPK_HALF_CHAINS);
+//   4. base + the contributions of the chain's edges; count + code + tile total (pip_write turns the codes into pairs).
 // Step 3 / 4 concern one point in twenty, scattered over the lanes: the wave packs those points into a list in its own slice of
 // LDS (no other wave sees it: wave-level ordering is enough) and lanes 0 .. T - 1 take one each — one round trip and one pass of
 // the orientation code for all of the tile's `test` points, in dense lanes.
-//   pip_tile_chain   level 1 from memory (any raster size);
-//   pip_tile_route   level 1 from an LDS image (PipView::route, R <= PIP_ROUTE_RMAX) kept by persistent work-groups: an empty cell
-//                    costs no request at all, a record's index comes straight from the LDS word (one round trip less), and
-//                    only interiors read their level-1 word.
-// What bounds them (measured): the L2's request rate — every divergent gather is one request whatever its size —
-// and the vector ALU (each point costs ~100 instructions); hence one request per table level and no per-lane loops.
+// This kernel serves chain indexes WITHOUT an LDS routing image (rasters beyond PIP_ROUTE_RMAX) and whatever gpk_pipflow.hip's
+// one-launch join does not take (GPK_TILE_KERNEL=chain: A/B runs); with the image, pip_flow_kernel is the join.  The round-3 .. 5 forms
+// that sat between the two (level 1 from the image in persistent work-groups, hits in per-wave LDS lists / staging slots / chunks /
+// a work-group pool) were retired in round 6: DESIGN.md 4.1 keeps their measurements.
 //
-// The kernels' arguments hold only what the hot path reads (the full views — two DevGeo, IndexView, PipView: 100 dwords — do
-// not fit the scalar register file next to the kernel's own state; the compiler then parks them in vector-register lanes and
-// pays a v_readlane per use).  What needs those views is rare — a point of a list cell, a `test` point whose sub-cell has no
-// chain entry, a point whose orientation against a chain edge Shewchuk's stage-A bound cannot certify: a handful per launch
-// on real data — and is settled at the end of the tile by the whole wave with the generic (always exact) walk, its arguments
-// read from device memory (ChainCold) at that point.  The kernels contain no call and no scratch memory: the expansion
-// arithmetic of the exact orientation is unrolled into registers that are free there (dev::orient2d_exact_unrolled).
+// The kernel's arguments hold only what the hot path reads (ChainHot, gpk_pipshared.h); what needs the full views — a point of a
+// list cell, a `test` point whose half cell has no chain, a point whose orientation against a chain edge Shewchuk's stage-A bound
+// cannot certify: a handful per launch on real data — is settled at the end of the tile by the whole wave with the generic (always
+// exact) walk, its arguments read from device memory (ChainCold) at that point.
 #ifndef GPK_CHAIN_PPT
 #define GPK_CHAIN_PPT 4
 #endif
-#define GPK_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-// a loop over 0 .. N - 1 whose index is a compile-time constant in the body: per-point state lives in small arrays, and only constant
-// indices from the start keep the compiler from turning such an array into one wide register tuple (or leaving it in scratch memory)
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (N > 0) {
-        static_for<N - 1>(f);
-        f(std::integral_constant<int, N - 1>{});
-    }
-}
 #ifndef GPK_CHAIN_NT
-#define GPK_CHAIN_NT 1  // non-temporal point loads: a point is read exactly once by these kernels
+#define GPK_CHAIN_NT 1  // non-temporal point loads: a point is read exactly once by this kernel
 #endif
 #ifndef GPK_CHAIN_ABLATE
 #define GPK_CHAIN_ABLATE 0  // tuning builds only (answers wrong on purpose): 1 = `test` points count as outside
 #endif
-#ifndef GPK_FUSED_PREFETCH
-#define GPK_FUSED_PREFETCH 0  // the next tile's points requested during the exact step (fused kernel): measured 4 % SLOWER (108 vs 104 us)
-#endif
-#ifndef GPK_ROUTE_BLOCK
-#define GPK_ROUTE_BLOCK 1024
-#endif
-#ifndef GPK_ROUTE_PPT
-#define GPK_ROUTE_PPT 8
-#endif
-#ifndef GPK_FUSED_PPT
-#define GPK_FUSED_PPT 8
-#endif
-constexpr int CHAIN_PPT = GPK_CHAIN_PPT, ROUTE_PPT = GPK_ROUTE_PPT, ROUTE_BLOCK = GPK_ROUTE_BLOCK, FUSED_PPT = GPK_FUSED_PPT;
-static_assert(PIP_WTILE % (64 * CHAIN_PPT) == 0 && PIP_WTILE % (64 * ROUTE_PPT) == 0, "a writer tile is a whole number of chain tiles");
+constexpr int CHAIN_PPT = GPK_CHAIN_PPT;
+static_assert(PIP_WTILE % (64 * CHAIN_PPT) == 0, "a writer tile is a whole number of chain tiles");
 
-struct ChainHot {
-    const double2* pts_xy;
-    const uint8_t* pts_validity;
-    int64_t n_points, n_tiles;
-    const uint8_t* polys_validity;
-    int32_t R, logR;  // the raster side is a power of two
-    double rx0, ry0, inv_fw, inv_fh;
-    const uint32_t* cell;
-    const HalfCell* half;
-    const ChainAux* sub_aux;
-    const uint32_t* chain_head;
-    const double2* chain_ext;
-    const double2* chain_xy;  // GPK_HALF_CHAINS: the vertices the records' chain words index
-    const uint32_t* part_geom;
-    const RouteWord* route;
-    uint32_t* counts;
-    uint32_t* code;
-    unsigned long long* block_tot;
-    unsigned long long* super_tot;
-    unsigned long long* stats;
-    const struct ChainCold* cold;  // what the generic walk of a rare row reads (written by join_prep_kernel)
-    uint2* stage;                  // pip_tile_fused_kernel: one pair slot per left row, a wave's hits at the start of its rows' slots
-    int32_t n_full_tiles, pad;     // pip_tile_fused_kernel: tiles 0 .. n_full_tiles - 1 need no guards (whole tiles of a column without a validity bitmap)
-    double inv_fw_s, inv_fh_s, sub_max;  // pip_tile_fused_kernel: inv_fw * PIP_SUB, inv_fh * PIP_SUB (exact: a power of two), (PIP_SUB << logR) - 1
-};
-// the arguments of the rare arm, in device memory: loaded where they are used — as kernel arguments they would be held in scalar
-// registers across the hot loop (and spilled)
-struct ChainCold {
-    DevGeo polys;
-    IndexView ix;
-    GridParams grid;
-};
 // one small launch in place of the memset of a join's totals: zeroes them and writes the rare arm's arguments
 __global__ __launch_bounds__(256) void join_prep_kernel(unsigned long long* __restrict__ zero, int64_t n_zero, ChainCold* __restrict__ cold_out, DevGeo polys,
                                                         IndexView ix) {
@@ -1248,98 +1183,6 @@ __global__ __launch_bounds__(256) void join_prep_kernel(unsigned long long* __re
         cold_out->grid = *ix.grid;
     }
 }
-// The generic (always exact) walk for ONE point, by a whole wave: directory candidates in ascending id order, each candidate's
-// rings with the lanes striding over the edges (a row costs a handful of dependent loads, not one per edge), the exact
-// orientation kernel inlined.  Returns the hit count; *first = the first hit.  Same answers as generic_point.
-// INLINE_EXACT: the expansion arithmetic of the exact orientation unrolled into registers (no call, no scratch memory: what the
-// persistent route kernel wants, which owns 128 registers per lane anyway) or reached by a call (the chain kernel: 84 registers
-// instead of 113, i.e. one more wave per SIMD, for a 208-byte stack).
-// emit != nullptr: hit number t of the row (ascending geometry id) is stored as (l, id) in emit[t] while t < emit_room
-template <bool INLINE_EXACT>
-__device__ __forceinline__ uint32_t chain_generic_row(const ChainCold* __restrict__ cold, double px, double py, int lane, uint32_t* first,
-                                                      uint2* emit = nullptr, uint32_t emit_room = 0u, uint32_t l = 0u) {
-    const DevGeo polys = cold->polys;
-    const IndexView ix = cold->ix;
-    const GridParams g = cold->grid;
-    uint32_t cnt = 0;
-    *first = CODE_NONE;
-    if (!(px == px && py == py)) return 0u;
-    const int cx = dev::cell_of(px, g.x0, g.inv_w, g.gx), cy = dev::cell_of(py, g.y0, g.inv_h, g.gy);
-    const int cc = cy * g.gx + cx;
-    for (int q = ix.cell_off[cc]; q < ix.cell_off[cc + 1]; ++q) {
-        const int j = ix.items[q];
-        const double4 bb = ix.bbox[j];
-        if (!(px >= bb.x && px <= bb.z && py >= bb.y && py <= bb.w) || !dev::valid_row(polys.validity, j)) continue;
-        int p0, p1;
-        dev::geom_parts(polys, j, p0, p1);
-        bool hit = false;
-        for (int part = p0; part < p1 && !hit; ++part) {  // Contains<Point>: strictly inside some member polygon
-            int r0, r1;
-            dev::part_rings(polys, part, r0, r1);
-            int pos = dev::POS_INSIDE;  // position w.r.t. the polygon: exterior first, then the holes
-            for (int r = r0; r < r1 && pos == dev::POS_INSIDE; ++r) {
-                const int c0 = polys.ring_off[r], n = polys.ring_off[r + 1] - c0;
-                int wn = 0, on = 0;
-                if (n == 1) {
-                    const double2 s0 = polys.xy[c0];
-                    on = (px == s0.x && py == s0.y) ? 1 : 0;
-                }
-                for (int i = lane; i + 1 < n; i += 64) {
-                    const double2 s0 = polys.xy[c0 + i], s1 = polys.xy[c0 + i + 1];
-                    on |= (int)(INLINE_EXACT ? dev::ring_edge_inline(s0.x, s0.y, s1.x, s1.y, px, py, wn) : dev::ring_edge(s0.x, s0.y, s1.x, s1.y, px, py, wn));
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    wn += __shfl_xor(wn, o, 64);
-                    on |= __shfl_xor(on, o, 64);
-                }
-                const int rp = n == 0 ? dev::POS_OUTSIDE : (on ? dev::POS_BOUNDARY : (wn != 0 ? dev::POS_INSIDE : dev::POS_OUTSIDE));
-                if (r == r0)
-                    pos = rp;  // Outside / OnBoundary of the exterior ends it
-                else if (rp == dev::POS_BOUNDARY)
-                    pos = dev::POS_BOUNDARY;
-                else if (rp == dev::POS_INSIDE)
-                    pos = dev::POS_OUTSIDE;  // inside a hole
-            }
-            hit = r1 > r0 && pos == dev::POS_INSIDE;
-        }
-        if (hit) {
-            if (cnt == 0) *first = (uint32_t)j;
-            if (emit != nullptr && lane == 0 && cnt < emit_room) emit[cnt] = make_uint2(l, (uint32_t)j);
-            ++cnt;
-        }
-    }
-    return cnt;
-}
-
-// set bits of a wave mask below this lane (v_mbcnt: no lane-mask register pair to keep)
-__device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-// What the fused kernel's tile loop reads once per tile (or hardly ever) is read from the kernel-argument segment where it is used
-// — a scalar load that hits the scalar cache — instead of living in scalar registers across the loop, which has none to spare: every
-// spilled scalar costs v_writelane / v_readlane pairs, and past 64 of them a second vector register.  (The pointer is made opaque:
-// named directly the compiler loads every argument at the top of the kernel.)
-template <typename T>
-__device__ __forceinline__ T kernel_arg_at(uint32_t offset) {
-    const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(ka));
-    return *(const T __attribute__((address_space(4)))*)(ka + offset);
-}
-#define HOT_ARG(field) (FUSED ? kernel_arg_at<decltype(ChainHot::field)>((uint32_t)offsetof(ChainHot, field)) : h.field)
-// The same walk as a CALL (pip_tile_fused_kernel): the fused tile loop keeps the next tile's points in registers across the rare arm;
-// inlined, the walk's register needs are the loop's (everything live across it is spilled, on every path); called, only the call
-// site saves what it must.
-__device__ __noinline__ uint32_t chain_generic_row_call(const ChainCold* cold, double px, double py, int lane, uint2* emit, uint32_t emit_room, uint32_t l) {
-    uint32_t first;
-    return chain_generic_row<false>(cold, px, py, lane, &first, emit, emit_room, l);
-}
-// (count in the low half, the first hit's geometry in the high half)
-__device__ __noinline__ unsigned long long chain_generic_row_first_call(const ChainCold* cold, double px, double py, int lane) {
-    uint32_t first;
-    const uint32_t cnt = chain_generic_row<false>(cold, px, py, lane, &first);
-    return ((unsigned long long)first << 32) | cnt;
-}
 // one `test` point of a tile, in the wave's LDS list (24 bytes; reading the point again from memory instead was measured: the
 // tile's lines are streamed with the non-temporal hint and are gone from the L2 — 20 us more per launch)
 struct ChainItem {
@@ -1349,151 +1192,65 @@ struct ChainItem {
 };
 // list slots per wave = one pass of the exact step: a quarter of the tile's points.  A tile with more `test` points than that (the
 // raster is far too coarse for such a right side) hands the surplus to the generic walk like any other deferred row.
-template <int P, bool LH = false>
-constexpr int chain_items() { return LH ? 12 * P : 16 * P; }  // (LH: the kernel that also keeps its hits in LDS)
-
-// The P points a lane holds, as 2 * P separately named doubles: a `double[P]` that lives across loop iterations (the fused kernel
-// requests a tile's points one tile ahead) is promoted to ONE 2 * P-register vector value — every use then drags the whole tuple
-// through the register allocator, and through scratch memory when it does not fit.  Nested structs are split into their fields.
 template <int P>
-struct PointRegs {
-    double x, y;
-    PointRegs<P - 1> rest;
-};
-template <>
-struct PointRegs<0> {};
-template <int K, int P>
-__device__ __forceinline__ double& point_x(PointRegs<P>& r) {
-    if constexpr (K == 0)
-        return r.x;
-    else
-        return point_x<K - 1>(r.rest);
-}
-template <int K, int P>
-__device__ __forceinline__ double& point_y(PointRegs<P>& r) {
-    if constexpr (K == 0)
-        return r.y;
-    else
-        return point_y<K - 1>(r.rest);
-}
-// a tile's points into registers (NaN for rows past the end and null rows).  FULL: see chain_tile
-template <int P, bool FULL, bool FUSED>
-__device__ __forceinline__ void chain_load_points(const ChainHot& h, int64_t tile, int lane, PointRegs<P>& pr) {
-    constexpr int CHAIN_TILE = 64 * P;
+constexpr int chain_items() { return 16 * P; }
+
+// FULL: the tile holds 64 * P points and the left column has no validity bitmap (wave-uniform, true for all tiles but the last
+// of a plain column): no per-point guards on loads and stores
+template <int P, bool FULL>
+__device__ __forceinline__ void chain_tile(const ChainHot& h, ChainItem* s_items, int64_t tile, int lane) {
+    constexpr int S = PIP_SUB, CHAIN_TILE = 64 * P, ITEMS = chain_items<P>();
+    constexpr bool FUSED = false;  // (the exact step below is shared text with the round-4 / 5 kernels: no argument-segment reads here)
     const int64_t base = tile * CHAIN_TILE;
-    const int64_t n_points = FULL ? 0 : (HOT_ARG(n_points));
-    const uint32_t rem = FULL ? (uint32_t)CHAIN_TILE : (uint32_t)(n_points - base < (int64_t)CHAIN_TILE ? n_points - base : (int64_t)CHAIN_TILE);
-    const double2* __restrict__ tile_xy = (HOT_ARG(pts_xy)) + base;
+    const uint32_t rem = FULL ? (uint32_t)CHAIN_TILE : (uint32_t)(h.n_points - base < (int64_t)CHAIN_TILE ? h.n_points - base : (int64_t)CHAIN_TILE);
+    const int logR = h.logR;
+    // 1. the points (NaN for rows past the end and null rows)
+    const double2* __restrict__ tile_xy = h.pts_xy + base;
+    double px[P], py[P];
     static_for<P>([&](auto K) {
         constexpr int k = decltype(K)::value;
         double2 v = make_double2(NAN, NAN);
-        if (FULL || ((uint32_t)(k * 64 + lane) < rem && dev::valid_row(HOT_ARG(pts_validity), base + k * 64 + lane)))
+        if (FULL || ((uint32_t)(k * 64 + lane) < rem && dev::valid_row(h.pts_validity, base + k * 64 + lane)))
             v = GPK_CHAIN_NT ? dev::load_stream(tile_xy + (k * 64 + lane)) : tile_xy[k * 64 + lane];
-        point_x<k>(pr) = v.x;
-        point_y<k>(pr) = v.y;
+        px[k] = v.x;
+        py[k] = v.y;
     });
-}
-template <int P, bool FUSED>
-__device__ __forceinline__ void chain_load_points_any(const ChainHot& h, int64_t tile, int lane, PointRegs<P>& pr) {
-    const bool full = FUSED ? tile < (int64_t)h.n_full_tiles : (h.pts_validity == nullptr && (tile + 1) * (int64_t)(64 * P) <= h.n_points);
-    if (full)  // (wave-uniform)
-        chain_load_points<P, true, FUSED>(h, tile, lane, pr);
-    else
-        chain_load_points<P, false, FUSED>(h, tile, lane, pr);
-}
-// FULL: the tile holds 64 * P points and the left column has no validity bitmap (wave-uniform, true for all tiles but the last
-// of a plain column): no per-point guards on loads and stores
-// FUSED (pip_tile_fused_kernel): no result codes and tile totals — the tile's hits go, in row order, to out[run ...] (slots below
-// out_cap only) as (l_add + row, geometry) and `run` moves on by their number; the rare rows are settled BEFORE the others are
-// ranked (their hit counts shift the ranks) and store their hits themselves
-// LH (pip_tile_fused_kernel<true>): the hits stay in LDS — lh.ids[run ...] 16-bit geometry ids in row order, lh.masks[k] the hit mask
-// of the tile's point row k — until the work-group knows where its pairs go; the routing image carries 16-bit record ranks
-// relative to a per-row base (s_rec0 = the uint16 ranks, lh.rowbase the bases).
-struct LdsHits {
-    uint16_t* ids;              // the wave's hit list (capacity `cap`)
-    unsigned long long* masks;  // this TILE's P masks
-    const uint32_t* rowbase;    // record rank of the first record of every raster row
-    uint32_t* over;             // set when the wave cannot keep its hits here (capacity, a row in several geometries): it decides its tiles again
-    uint32_t cap;
-    // POOL (pip_tile_pool_kernel): the work-group's hit pool — a tile's hits take `ids[start ...]` (start drawn from *pool_top once the tile
-    // knows how many it has; capacity `cap`), the tile's record = its P masks (`masks`), *tile_start (~0: the tile is decided again at
-    // emission — pool full, or a row in several geometries) and *tile_tot (pairs the tile contributes)
-    uint32_t* pool_top;
-    uint32_t* tile_start;
-    uint32_t* tile_tot;
-};
-template <int P, bool ROUTE, bool FULL, bool FUSED = false, bool LH = false, bool IMG16 = LH, bool POOL = false>
-__device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mask, const uint32_t* s_rec0, ChainItem* s_items, int64_t tile, int lane,
-                                           uint2* out, uint32_t out_cap, uint32_t* run_io, PointRegs<P>& pr, int64_t next_tile, const LdsHits lh = LdsHits{}) {
-    constexpr int S = PIP_SUB, CHAIN_TILE = 64 * P, ITEMS = chain_items<P, IMG16>();  // (IMG16: the kernel that keeps its hits in LDS, either pass)
-    const int64_t base = tile * CHAIN_TILE;
-    const int64_t n_points = FULL ? 0 : (HOT_ARG(n_points));
-    const uint32_t rem = FULL ? (uint32_t)CHAIN_TILE : (uint32_t)(n_points - base < (int64_t)CHAIN_TILE ? n_points - base : (int64_t)CHAIN_TILE);
-    const int logR = h.logR;
-    // 1. the points (PREFETCH: the caller's registers hold them already — requested during the previous tile's exact step — and
-    // receive the next tile's below)
-    constexpr bool PREFETCH = FUSED && GPK_FUSED_PREFETCH;
-    const double2* __restrict__ tile_xy = (HOT_ARG(pts_xy)) + base;
-    // (only guard-free tiles are requested ahead: next_tile < 0 on entry means "this tile's points are not here yet")
-    if (!PREFETCH || !FULL) chain_load_points<P, FULL, FUSED>(h, tile, lane, pr);
     // (GPK_SCHED_FENCE: nothing is moved across — left to itself the scheduler interleaves the steps of different points until it
     // runs out of registers, then spills; the source order below IS the intended schedule: requests of a step back to back, their
     // uses in the next step)
     GPK_SCHED_FENCE();
-    // 2. level 1 (ROUTE: from the LDS image where that answers), then the half-cell records
-    uint32_t sidx4[(P + 3) / 4], w[P], gw[P];  // sub-cell within the cell (label index, x fastest; byte k % 4 of word k / 4: eight registers
-                                    // less than one each); record index known from LDS (recmask); level-1
-                                    // word requested (its own register: a register with a request pending for SOME lanes cannot be
-                                    // read by the others without waiting for it)
-    uint32_t recmask = 0u;          // bit k: point k's cell carries a one-part record and w[k] is its index (ROUTE only)
-    // (the scaled reciprocals and the last sub-cell arrive as kernel arguments: computed in the kernel they are vector-unit results —
-    // six vector registers of loop-invariant values)
-    const double sub_max = FUSED ? h.sub_max : (double)(((uint32_t)S << logR) - 1u);
-    const double inv_w_s = FUSED ? h.inv_fw_s : h.inv_fw * S, inv_h_s = FUSED ? h.inv_fh_s : h.inv_fh * S;
-    const uint32_t* __restrict__ const cell_words = HOT_ARG(cell);
+    // 2. level 1, then the half-cell records
+    uint32_t sidx4[(P + 3) / 4], w[P], gw[P];  // sub-cell within the cell (label index, x fastest; byte k % 4 of word k / 4); record index; level-1 word
+    uint32_t recmask = 0u;                     // bit k: point k's cell carries a one-part record and w[k] is its index
+    const double sub_max = (double)(((uint32_t)S << logR) - 1u);
+    const double inv_w_s = h.inv_fw * S, inv_h_s = h.inv_fh * S;
+    const uint32_t* __restrict__ const cell_words = h.cell;
     static_for<(P + 3) / 4>([&](auto J) { sidx4[decltype(J)::value] = 0u; });
 #define SIDX(k) ((sidx4[(k) / 4] >> (8 * ((k) % 4))) & 0xFFu)
+#define HOT_ARG(field) (h.field)
     static_for<P>([&](auto K) {
         constexpr int k = decltype(K)::value;
         // dev::cell_of at sub-cell resolution (negative / NaN products clamp to 0, large ones to the last sub-cell)
-        const double pxk = point_x<k>(pr), pyk = point_y<k>(pr);
+        const double pxk = px[k], pyk = py[k];
         const uint32_t sx = (uint32_t)fmin(fmax((pxk - h.rx0) * inv_w_s, 0.0), sub_max);
         const uint32_t sy = (uint32_t)fmin(fmax((pyk - h.ry0) * inv_h_s, 0.0), sub_max);
         const bool real = pxk == pxk && pyk == pyk;
         const uint32_t cx = sx / S, cy = sy / S;
         sidx4[k / 4] |= ((sy % S) * S + (sx % S)) << (8 * (k % 4));
         w[k] = gw[k] = 0u;
-        bool want = false;
-        if (ROUTE) {
-            const uint32_t at = (cy << (logR - 5)) + (cx >> 5), bit = cx & 31u;
-            const uint2 m = s_mask[at];  // RouteWord: bmask, gmask
-            if (real && ((m.x >> bit) & 1u)) {
-                if constexpr (IMG16)
-                    w[k] = lh.rowbase[cy] + (uint32_t)reinterpret_cast<const uint16_t*>(s_rec0)[at] + (uint32_t)__popc(m.x & ((1u << bit) - 1u));
-                else
-                    w[k] = s_rec0[at] + (uint32_t)__popc(m.x & ((1u << bit) - 1u));
-                recmask |= 1u << k;
-            } else {
-                want = real && ((m.y >> bit) & 1u);
-            }
-        } else {
-            want = real;
-        }
-        if (want) gw[k] = cell_words[(cy << logR) + cx];
+        if (real) gw[k] = cell_words[(cy << logR) + cx];
         GPK_SCHED_FENCE();
     });
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const HalfCell* __restrict__ const half_recs = HOT_ARG(half);
+    const HalfCell* __restrict__ const half_recs = h.half;
     u32x4 rec[P];  // HalfCell: lw[0], lw[1], part, aux_base  (kept as the 16-byte tuple the request fills: copies out of it would sit
                    // in the requesting branch and wait for the request on the spot — P round trips one after the other)
     static_for<P>([&](auto K) {
         constexpr int k = decltype(K)::value;
         rec[k] = u32x4{0u, 0u, 0u, 0u};
-        if (!ROUTE) {  // the record's index is in the word just read: this wait is the chain kernel's extra round trip
-            if ((gw[k] >> 30) == CELL_TAG_SUB && !(gw[k] & SUB2_BIT)) {
-                w[k] = gw[k] & 0x3FFFFFFFu;
-                recmask |= 1u << k;
-            }
+        if ((gw[k] >> 30) == CELL_TAG_SUB && !(gw[k] & SUB2_BIT)) {  // (the record's index is in the word just read)
+            w[k] = gw[k] & 0x3FFFFFFFu;
+            recmask |= 1u << k;
         }
         if ((recmask >> k) & 1u) rec[k] = *reinterpret_cast<const u32x4*>(half_recs + 2u * w[k] + (SIDX(k) >> 5));
     });
@@ -1544,8 +1301,8 @@ __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mas
                     slots[k / 4] |= at << (8 * (k % 4));
                     tmask |= 1u << k;
                     ChainItem* it = s_items + at;
-                    it->px = point_x<k>(pr);
-                    it->py = point_y<k>(pr);
+                    it->px = px[k];
+                    it->py = py[k];
                     it->aux_at = aux_at;
                 } else {
                     dmask |= 1u << k;  // the list is full
@@ -1555,13 +1312,9 @@ __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mas
         GPK_SCHED_FENCE();
     });
 #undef SIDX
-    if constexpr (PREFETCH) {  // the next tile's points: their round trip runs next to the exact step's (px, py are dead from here)
-        if (next_tile >= 0) chain_load_points<P, true, FUSED>(h, next_tile, lane, pr);  // (wave-uniform; the caller names guard-free tiles only)
-        GPK_SCHED_FENCE();
-    }
-    uint32_t* const counts_all = HOT_ARG(counts);
+    uint32_t* const counts_all = h.counts;
     uint32_t* __restrict__ tile_counts = counts_all ? counts_all + base : nullptr;
-    uint32_t* __restrict__ tile_code = FUSED ? nullptr : h.code + base;
+    uint32_t* __restrict__ tile_code = h.code + base;
     // 4. the exact step: one listed point per lane and pass
     n_items = n_items < (uint32_t)ITEMS ? n_items : (uint32_t)ITEMS;
     unsigned long long edges_walked = 0;
@@ -1669,225 +1422,9 @@ __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mas
             n_rare += (uint32_t)__popcll(m);
         });
     }
-    if (!FUSED && h.stats && n_items) {  // measurement runs only (gpk_join_stats_enable): uniform branch on the pointer
+    if (h.stats && n_items) {  // measurement runs only (gpk_join_stats_enable): uniform branch on the pointer
         if (lane == 0) atomicAdd(&h.stats[0], (unsigned long long)n_items);
         if (edges_walked) atomicAdd(&h.stats[1], edges_walked);
-    }
-    if constexpr (FUSED) {
-#ifdef GPK_TILE_TRACE
-        unsigned long long* const stats = nullptr;  // (the trace build stamps the wall clock into that buffer: no counting)
-#else
-        unsigned long long* const stats = HOT_ARG(stats);
-#endif
-        if (stats && n_items) {
-            if (lane == 0) atomicAdd(&stats[0], (unsigned long long)n_items);
-            if (edges_walked) atomicAdd(&stats[1], edges_walked);
-        }
-        const uint32_t run = *run_io;
-        const uint32_t* const part_geom = HOT_ARG(part_geom);
-        const uint8_t* const polys_validity = HOT_ARG(polys_validity);
-        if constexpr (POOL) {
-            // the rare rows FIRST: the generic walk's verdict turns a row with at most one hit into an ordinary row (its lane takes the
-            // geometry), so the ranking below sees every hit of the tile; a row in several geometries cannot be told by a bit per row —
-            // the tile is decided again at emission, storing at its final offsets
-            uint32_t geom_known = 0u, multi_hits = 0u;  // bit k: res[k] is a geometry id already; hits of the multi-geometry rows
-            if (n_rare) {  // (wave-uniform)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                for (uint32_t i = 0; i < n_rare; ++i) {
-                    const uint32_t li = s_rare[i], rk = li >> 6, rj = li & 63u;
-                    const double2 q = tile_xy[li];
-                    const unsigned long long cf = chain_generic_row_first_call(HOT_ARG(cold), q.x, q.y, lane);
-                    const uint32_t cnt = (uint32_t)cf, first = (uint32_t)(cf >> 32);
-                    if (cnt <= 1u) {
-                        static_for<P>([&](auto K) {
-                            constexpr int k = decltype(K)::value;
-                            if ((uint32_t)k == rk && (uint32_t)lane == rj) {
-                                res[k] = cnt ? first : CODE_NONE;
-                                dmask &= ~(1u << k);
-                                geom_known |= 1u << k;
-                            }
-                        });
-                    } else {
-                        multi_hits += cnt;
-                        if (lane == 0 && tile_counts) tile_counts[li] = cnt;
-                    }
-                }
-                if (stats && lane == 0) atomicAdd(&stats[2], (unsigned long long)n_rare);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next tile overwrites the rare list)
-                __builtin_amdgcn_wave_barrier();
-            }
-            // part -> geometry, count, the row's mask into the tile's record
-            uint32_t hitbits = 0u, hits = 0u;  // (hits: wave-uniform)
-            static_for<P>([&](auto K) {
-                constexpr int k = decltype(K)::value;
-                const uint32_t li = (uint32_t)(k * 64 + lane);
-                uint32_t r = res[k];
-                if (r != CODE_NONE && !((geom_known >> k) & 1u)) {
-                    const uint32_t geom = part_geom ? part_geom[r] : r;
-                    r = dev::valid_row(polys_validity, geom) ? geom : CODE_NONE;
-                }
-                res[k] = r;
-                const bool mine = (FULL || li < rem) && !((dmask >> k) & 1u);
-                const bool hit = mine && r != CODE_NONE;
-                const unsigned long long m = __ballot(hit);
-                if (mine && tile_counts) dev::store_stream(tile_counts + li, hit ? 1u : 0u);
-                if (hit) hitbits |= 1u << k;
-                if (lane == 0) lh.masks[k] = m;
-                hits += (uint32_t)__popcll(m);
-            });
-            // the tile's place in the pool, then the ids at their ranks
-            // (all 64 lanes add `hits`: *pool_top runs in units of 64 — see the tile draw in pip_tile_pool_kernel)
-            uint32_t start = __hip_atomic_fetch_add(lh.pool_top, hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            start = __builtin_amdgcn_readfirstlane(start) >> 6;
-            const bool again = multi_hits != 0u || start + hits > lh.cap;
-            if (!again) {
-                uint32_t pos = start;
-                static_for<P>([&](auto K) {
-                    constexpr int k = decltype(K)::value;
-                    const bool hit = ((hitbits >> k) & 1u) != 0u;
-                    const unsigned long long m = __ballot(hit);
-                    if (hit) lh.ids[pos + lanes_below(m)] = (uint16_t)res[k];
-                    pos += (uint32_t)__popcll(m);
-                });
-            }
-            if (lane == 0) {
-                *lh.tile_start = again ? 0xFFFFFFFFu : start;
-                *lh.tile_tot = hits + multi_hits;
-            }
-            return;
-        }
-        if constexpr (LH) {
-            // the ordinary rows: part -> geometry, count, the hit's 16-bit geometry id at its rank in the wave's LDS list, the row's mask
-            uint32_t hits = 0;  // wave-uniform
-            static_for<P>([&](auto K) {
-                constexpr int k = decltype(K)::value;
-                const uint32_t li = (uint32_t)(k * 64 + lane);
-                uint32_t r = res[k];
-                if (r != CODE_NONE) {
-                    const uint32_t geom = part_geom ? part_geom[r] : r;
-                    r = dev::valid_row(polys_validity, geom) ? geom : CODE_NONE;
-                }
-                const bool mine = (FULL || li < rem) && !((dmask >> k) & 1u);
-                const bool hit = mine && r != CODE_NONE;
-                const unsigned long long m = __ballot(hit);
-                if (mine && tile_counts) dev::store_stream(tile_counts + li, hit ? 1u : 0u);
-                if (hit) {
-                    const uint32_t at = run + hits + lanes_below(m);
-                    if (at < lh.cap) lh.ids[at] = (uint16_t)r;
-                }
-                if (lane == 0) lh.masks[k] = m;
-                hits += (uint32_t)__popcll(m);
-            });
-            // the rare rows, in row order: a row with ONE hit takes its place in the list (the tail moves up by one, its bit joins the row's
-            // mask); a row in several geometries cannot be told by a bit — the wave gives up the list and decides its tiles again
-            if (n_rare) {  // (wave-uniform)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                for (uint32_t i = 0; i < n_rare; ++i) {
-                    const uint32_t li = s_rare[i], rk = li >> 6, rj = li & 63u;
-                    uint32_t before = (uint32_t)__popcll(lh.masks[rk] & ((1ull << rj) - 1ull));  // (earlier rare rows' bits are in the masks by now)
-                    for (uint32_t kk = 0; kk < rk; ++kk) before += (uint32_t)__popcll(lh.masks[kk]);
-                    const uint32_t at = run + before, end = run + hits;
-                    const double2 q = tile_xy[li];
-                    const unsigned long long cf = chain_generic_row_first_call(HOT_ARG(cold), q.x, q.y, lane);
-                    const uint32_t cnt = (uint32_t)cf, first = (uint32_t)(cf >> 32);
-                    if (cnt == 1u) {
-                        for (uint32_t hi = end; hi > at; hi = hi - at > 64u ? hi - 64u : at) {  // [at, end) up by one, from the top
-                            const uint32_t lo = hi - at > 64u ? hi - 64u : at, src = lo + (uint32_t)lane;
-                            uint16_t v = 0;
-                            if (src < hi && src < lh.cap) v = lh.ids[src];
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                            if (src < hi && src + 1u < lh.cap) lh.ids[src + 1u] = v;
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        }
-                        if (lane == 0) {
-                            if (at < lh.cap) lh.ids[at] = (uint16_t)first;
-                            lh.masks[rk] |= 1ull << rj;
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    } else if (cnt > 1u && lane == 0) {
-                        *lh.over = 1u;
-                    }
-                    if (lane == 0 && tile_counts) tile_counts[li] = cnt;
-                    hits += cnt;
-                }
-                if (stats && lane == 0) atomicAdd(&stats[2], (unsigned long long)n_rare);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next tile overwrites the rare list)
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (run + hits > lh.cap && lane == 0) *lh.over = 1u;
-            *run_io = run + hits;
-            return;
-        }
-        unsigned long long* s_mh = reinterpret_cast<unsigned long long*>(s_rare + 64 * P);  // the point rows' hit masks, for the rare arm
-        static_assert(sizeof(ChainItem) * ITEMS >= sizeof(uint32_t) * 64 * P + sizeof(unsigned long long) * P, "the list also holds the rows' hit masks");
-        // the ordinary rows: part -> geometry (null geometries dropped), count, the hit at its rank among them
-        uint32_t hits = 0;  // wave-uniform
-        static_for<P>([&](auto K) {
-            constexpr int k = decltype(K)::value;
-            const uint32_t li = (uint32_t)(k * 64 + lane);
-            uint32_t r = res[k];
-            if (r != CODE_NONE) {
-                const uint32_t geom = part_geom ? part_geom[r] : r;
-                r = dev::valid_row(polys_validity, geom) ? geom : CODE_NONE;
-            }
-            const bool mine = (FULL || li < rem) && !((dmask >> k) & 1u);  // (a rare row's count and hits are written by its walk)
-            const bool hit = mine && r != CODE_NONE;
-            const unsigned long long m = __ballot(hit);
-            if (mine && tile_counts) dev::store_stream(tile_counts + li, hit ? 1u : 0u);
-            if (hit && out) {
-                const uint32_t at = run + hits + lanes_below(m);
-                if (at < out_cap) out[at] = make_uint2((uint32_t)(base + li), r);
-            }
-            if (n_rare && lane == 0) s_mh[k] = m;
-            hits += (uint32_t)__popcll(m);
-        });
-        // the rare rows, in row order, when nothing of the tile's state is live any more: the generic walk counts the row's hits; a
-        // row that has some opens a gap for them among the hits stored so far (the run's tail moves up) and walks again, storing
-        if (n_rare) {  // (wave-uniform)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            uint32_t cum = 0;  // hits of the rare rows so far
-            for (uint32_t i = 0; i < n_rare; ++i) {
-                const uint32_t li = s_rare[i], rk = li >> 6, rj = li & 63u;
-                uint32_t before = (uint32_t)__popcll(s_mh[rk] & ((1ull << rj) - 1ull));
-                for (uint32_t kk = 0; kk < rk; ++kk) before += (uint32_t)__popcll(s_mh[kk]);
-                const uint32_t at = run + before + cum, end = run + hits + cum;
-                const double2 q = tile_xy[li];
-                uint32_t cnt = 0;
-                for (int phase = 0; phase < 2; ++phase) {
-                    cnt = chain_generic_row_call(HOT_ARG(cold), q.x, q.y, lane, phase ? out + at : nullptr, at < out_cap ? out_cap - at : 0u, (uint32_t)(base + li));
-                    if (phase == 1 || cnt == 0u || !out) break;
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the hits stored so far have arrived)
-                    for (uint32_t hi = end; hi > at; hi = hi - at > 64u ? hi - 64u : at) {  // [at, end) up by cnt, from the top
-                        const uint32_t lo = hi - at > 64u ? hi - 64u : at, src = lo + (uint32_t)lane;
-                        uint2 v = make_uint2(0u, 0u);
-                        if (src < hi && src < out_cap) v = out[src];
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (every lane has its entry before any lane stores)
-                        if (src < hi && src + cnt < out_cap && src + cnt >= src) out[src + cnt] = v;
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                if (lane == 0 && tile_counts) tile_counts[li] = cnt;
-                cum += cnt;
-            }
-            hits += cum;
-            if (stats && lane == 0) atomicAdd(&stats[2], (unsigned long long)n_rare);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the next tile overwrites the list)
-            __builtin_amdgcn_wave_barrier();
-        }
-        *run_io = run + hits;
-        return;
     }
     // part -> geometry (null geometries dropped), count + code, the tile's total
     unsigned long long hits = 0;  // wave-uniform
@@ -1917,7 +1454,7 @@ __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mas
             const uint32_t li = s_rare[i];
             const double2 q = tile_xy[li];
             uint32_t first;
-            const uint32_t cnt = chain_generic_row<ROUTE>(h.cold, q.x, q.y, lane, &first);
+            const uint32_t cnt = chain_generic_row<false>(h.cold, q.x, q.y, lane, &first);
             if (lane == 0) {
                 if (tile_counts) tile_counts[li] = cnt;
                 tile_code[li] = cnt == 0 ? CODE_NONE : (cnt == 1 ? first : CODE_MULTI);
@@ -1933,989 +1470,16 @@ __device__ __forceinline__ void chain_tile(const ChainHot& h, const uint2* s_mas
         if (hits) atomicAdd(&h.super_tot[tile >> PIP_SUPER_SHIFT], hits);  // integer adds: order-independent
     }
 }
-template <int P, bool ROUTE, bool FUSED = false>
-__device__ __forceinline__ void chain_tile_any(const ChainHot& h, const uint2* s_mask, const uint32_t* s_rec0, ChainItem* s_items, int64_t tile, int lane,
-                                               uint2* out, uint32_t out_cap, uint32_t* run_io, PointRegs<P>& pr, int64_t next_tile) {
-    const bool full = FUSED ? tile < (int64_t)h.n_full_tiles : (h.pts_validity == nullptr && (tile + 1) * (int64_t)(64 * P) <= h.n_points);
-    if (full)  // (wave-uniform)
-        chain_tile<P, ROUTE, true, FUSED>(h, s_mask, s_rec0, s_items, tile, lane, out, out_cap, run_io, pr, next_tile);
-    else
-        chain_tile<P, ROUTE, false, FUSED>(h, s_mask, s_rec0, s_items, tile, lane, out, out_cap, run_io, pr, next_tile);
-}
-template <int P, bool ROUTE>
-__device__ __forceinline__ void chain_tile_any(const ChainHot& h, const uint2* s_mask, const uint32_t* s_rec0, ChainItem* s_items, int64_t tile, int lane) {
-    PointRegs<P> pr;
-    chain_tile_any<P, ROUTE, false>(h, s_mask, s_rec0, s_items, tile, lane, nullptr, 0u, nullptr, pr, (int64_t)-1);
-}
-
+#undef HOT_ARG
 __global__ __launch_bounds__(PIP_BLOCK) void pip_tile_chain_kernel(ChainHot h) {
     __shared__ ChainItem s_items[PIP_BLOCK / 64][chain_items<CHAIN_PPT>()];
     const int64_t tile = (int64_t)blockIdx.x * (PIP_BLOCK / 64) + (threadIdx.x >> 6);
     if (tile >= h.n_tiles) return;  // (whole waves)
-    chain_tile_any<CHAIN_PPT, false>(h, nullptr, nullptr, s_items[threadIdx.x >> 6], tile, threadIdx.x & 63);
-}
-
-// persistent work-groups (one per CU: the routing image takes most of its LDS), a wave walks tiles wave, wave + W, ...
-__global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_route_kernel(ChainHot h) {
-    constexpr int WORDS = PIP_ROUTE_RMAX * PIP_ROUTE_RMAX / 32;
-    __shared__ uint2 s_mask[WORDS];     // RouteWord::bmask, gmask
-    __shared__ uint32_t s_rec0[WORDS];  // RouteWord::rec0
-    __shared__ ChainItem s_items[ROUTE_BLOCK / 64][chain_items<ROUTE_PPT>()];
-    {
-        const int words = h.R * h.R / 32;
-        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(h.route);
-        for (int i = threadIdx.x; i < words; i += ROUTE_BLOCK) {
-            const uint4 rw = src[i];
-            s_mask[i] = make_uint2(rw.x, rw.y);
-            s_rec0[i] = rw.z;
-        }
-    }
     const int lane = threadIdx.x & 63;
-    const int64_t stride = (int64_t)gridDim.x * (ROUTE_BLOCK / 64);
-    __syncthreads();
-    for (int64_t tile = (int64_t)blockIdx.x * (ROUTE_BLOCK / 64) + (threadIdx.x >> 6); tile < h.n_tiles; tile += stride)
-        chain_tile_any<ROUTE_PPT, true>(h, s_mask, s_rec0, s_items[threadIdx.x >> 6], tile, lane);
-}
-
-// The whole join in ONE launch (round 4): persistent work-groups as above, but a wave owns a CONTIGUOUS run of tiles and keeps its
-// hits — already in (l, r) order — in the pair slots of its own rows (ChainHot::stage: scratch, one slot per left row, read back by
-// the wave that wrote it: same CU, same L2).  When its tiles are done a work-group publishes its hit total; the totals of the
-// work-groups before it (one 64-bit word each, tagged with the launch's epoch so that nothing has to be zeroed: agent-scope
-// atomics, the only words that cross XCDs) give its offset in the pair list, and every wave copies its run there.  No result
-// codes, no tile totals, no writer launch: the step's traffic is points in, counts out, hits out + once through the staging slots.
-// A work-group only ever waits for work-groups with SMALLER indices, which the dispatcher places first; concurrent launches from
-// different streams are kept apart by the host (they share the epoch words).  A wave whose hits outgrow its rows' slots (rows in
-// several geometries) decides its tiles a second time, storing straight to the final offsets it then knows.
-#ifndef GPK_FUSED_ABLATE
-#define GPK_FUSED_ABLATE 0
-#endif
-#ifndef GPK_LH_EMIT_OLD
-#define GPK_LH_EMIT_OLD 0  // 1: the round-4 emission loop (A/B runs)
-#endif
-// The hits of `n_rows` point rows (64 points each, n_rows a multiple of 8, at most 64), out of LDS — masks[j] = the hit mask of row j,
-// ids[] = the hits' 16-bit geometry ids in row order — to pairs[my_off ...] as (first_row + 64 j + lane, id).  Lane j reads mask j:
-// ONE LDS round trip for all masks and one wave scan give every row's rank base; the loop then reads masks and bases out of registers
-// (v_readlane) and has eight id gathers in flight before the first store.  (Row by row with the mask read from LDS in every
-// iteration the loop was a chain of 2 n_rows dependent LDS round trips: 6 of the 10.7 us the emission cost in round 4.)
-__device__ __forceinline__ void emit_hit_rows(const unsigned long long* masks, const uint16_t* ids, int n_rows, uint32_t first_row, unsigned long long my_off,
-                                              uint2* pairs, int64_t capacity, int lane, bool nontemporal) {
-    const unsigned long long mv = lane < n_rows ? masks[lane] : 0ull;
-    const uint32_t cnt = (uint32_t)__popcll(mv);
-    uint32_t incl = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-    }
-    const uint32_t excl = incl - cnt, mlo = (uint32_t)mv, mhi = (uint32_t)(mv >> 32);
-    for (int j0 = 0; j0 < n_rows; j0 += 8) {
-        uint32_t idv[8], rank[8], act = 0u;
-        static_for<8>([&](auto U) {
-            constexpr int u = decltype(U)::value;
-            const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mhi, j0 + u) << 32) | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mlo, j0 + u);
-            rank[u] = (uint32_t)__builtin_amdgcn_readlane((int)excl, j0 + u) + lanes_below(m);
-            idv[u] = 0u;
-            if ((m >> lane) & 1ull) {
-                act |= 1u << u;
-                idv[u] = (uint32_t)ids[rank[u]];
-            }
-        });
-        asm volatile("" : "+v"(idv[0]), "+v"(idv[1]), "+v"(idv[2]), "+v"(idv[3]), "+v"(idv[4]), "+v"(idv[5]), "+v"(idv[6]), "+v"(idv[7]));
-        static_for<8>([&](auto U) {
-            constexpr int u = decltype(U)::value;
-            if ((act >> u) & 1u) {
-                const unsigned long long at = my_off + rank[u];
-                if ((int64_t)at < capacity) {
-                    const unsigned long long v = ((unsigned long long)idv[u] << 32) | (unsigned long long)(first_row + (uint32_t)((j0 + u) * 64 + lane));
-                    if (GPK_FUSED_ABLATE == 3)  // (tuning builds only: everything but the store)
-                        asm volatile("" ::"v"(v), "v"(at));
-                    else if (nontemporal)
-                        __builtin_nontemporal_store(v, reinterpret_cast<unsigned long long*>(pairs + at));
-                    else
-                        *reinterpret_cast<unsigned long long*>(pairs + at) = v;
-                }
-            }
-        });
-    }
-}
-struct FusedTail {
-    uint2* pairs;            // may be nullptr: counts and total only
-    int64_t capacity;        // pair slots of `pairs`
-    unsigned long long* slots;   // one word per work-group: epoch << FUSED_TOTAL_BITS | hit total
-    unsigned long long epoch;
-    unsigned long long* grand;
-    unsigned long long* grand_host;
-    uint32_t left_base, pad;
-    unsigned long long* ticket;      // work-groups number themselves in the order they START: ticket - ticket_base
-    unsigned long long ticket_base;  // (the counter only ever grows: the host knows where a launch's numbers begin)
-    unsigned long long* lost;        // a work-group that gave up waiting stores the launch's epoch here; the work-group that writes the total
-                                     // reads it AFTER its own waits (which cover every word anybody waited for): FUSED_LOST is sticky
-};
-#ifndef GPK_FUSED_STAGGER
-#define GPK_FUSED_STAGGER 0
-#endif
-#ifndef GPK_FUSED_COPY_UNROLL
-#define GPK_FUSED_COPY_UNROLL 8
-#endif
-constexpr int FUSED_TOTAL_BITS = 40;
-constexpr uint32_t FUSED_SPIN_LIMIT = 1u << 22;
-constexpr unsigned long long FUSED_LOST = ~0ull;  // in the total's place: the launch gave up waiting (gpk_spatial_join reports GPK_ERR_DEVICE)
-// LH = true (round 4, second form): the wave's hits never leave the CU before they are final — 16-bit geometry ids in an LDS list, one
-// 64-bit hit mask per point row — so there are no staging stores, no staging reads, and the copy phase is a stream of stores out of
-// LDS.  Eligible when geometry ids fit 16 bits and a wave owns at most FUSED_LH_TILES tiles (the host checks); the routing image
-// shrinks to make room (16-bit record ranks relative to a per-row base, 96 list slots per wave).  A wave whose hits do not fit its
-// list, or that meets a row in several geometries, decides its tiles again, storing at the final offsets (as the staging form does).
-#ifndef GPK_LH_EMIT_RANK
-#define GPK_LH_EMIT_RANK 0
-#endif
-#ifndef GPK_LH_NT
-#define GPK_LH_NT 1
-#endif
-constexpr int FUSED_LH_TILES = 5;
-constexpr int FUSED_LH_IDS = 1120;  // 16-bit hit slots per wave: 2240 + 320 bytes of masks = 2560 bytes per wave, 40 KB per work-group
-// GPK_TILE_TRACE (diagnosis builds only; tools/fused_trace.py): lane 0 of waves 0, 5, 10, 15 of every work-group stamps the wall clock
-// (100 MHz) at the kernel's stage boundaries: 16 words per traced wave at stats[8 + ((blockIdx.x * 4 + wave / 5) * 16 + i)]
-#ifdef GPK_TILE_TRACE
-#define FUSED_STAMP(i)                                                                                                         \
-    do {                                                                                                                       \
-        unsigned long long* _st = kernel_arg_at<unsigned long long*>((uint32_t)offsetof(ChainHot, stats));                   \
-        if (_st && lane == 0 && wave % 5 == 0 && blockIdx.x < 900u) _st[8 + (blockIdx.x * 4 + wave / 5) * 16 + (i)] = wall_clock64(); \
-    } while (0)
-#else
-#define FUSED_STAMP(i) do {} while (0)
-#endif
-template <bool LH>
-__global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_fused_kernel(ChainHot h, FusedTail tail_in_the_argument_segment) {
-    constexpr int WORDS = PIP_ROUTE_RMAX * PIP_ROUTE_RMAX / 32, W = ROUTE_BLOCK / 64, TILE = 64 * FUSED_PPT, P = FUSED_PPT;
-#ifdef GPK_TILE_TRACE
-    {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        FUSED_STAMP(0);
-    }
-#endif
-    __shared__ uint2 s_mask[WORDS];                                 // RouteWord::bmask, gmask
-    __shared__ uint32_t s_rec0[LH ? WORDS / 2 : WORDS];             // RouteWord::rec0 (LH: as uint16 ranks within the raster row)
-    __shared__ uint32_t s_rowbase[LH ? PIP_ROUTE_RMAX : 1];         // LH: record rank of the row's first record
-    __shared__ ChainItem s_items[W][chain_items<P, LH>()];
-    __shared__ uint16_t s_ids[LH ? W : 1][LH ? FUSED_LH_IDS : 1];
-    __shared__ unsigned long long s_hmask[LH ? W : 1][LH ? FUSED_LH_TILES * P : 1];
-    __shared__ uint32_t s_over[W];
-    __shared__ unsigned long long s_wtot[W];
-    __shared__ unsigned long long s_part[W];
-    __shared__ uint32_t s_wg;
-    // (the work-group's ticket is asked for before the image is read and used after: its round trip is the image's)
-    typedef const FusedTail __attribute__((address_space(4))) * TailPtr0;
-    const TailPtr0 tail_at_entry = (TailPtr0)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(ChainHot));
-    unsigned long long my_ticket = 0ull;
-    if (threadIdx.x == 0) my_ticket = __hip_atomic_fetch_add(tail_at_entry->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    {
-        const int words = h.R * h.R / 32;
-        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(h.route);
-        if constexpr (LH) {
-            // (RouteWord::pad = rec0's rank within its raster row: one pass of independent reads; a row's base = rec0 - pad of any of
-            // its words that has records — the lanes that find one all store the same value)
-            const int per_row = h.R / 32;  // (R >= 32: the host checks)
-            uint16_t* rec16 = reinterpret_cast<uint16_t*>(s_rec0);
-            for (int i = threadIdx.x; i < words; i += ROUTE_BLOCK) {
-                const uint4 rw = src[i];
-                s_mask[i] = make_uint2(rw.x, rw.y);
-                rec16[i] = (uint16_t)rw.w;
-                if (rw.x) s_rowbase[i / per_row] = rw.z - rw.w;
-            }
-        } else {
-            for (int i = threadIdx.x; i < words; i += ROUTE_BLOCK) {
-                const uint4 rw = src[i];
-                s_mask[i] = make_uint2(rw.x, rw.y);
-                s_rec0[i] = rw.z;
-            }
-        }
-    }
-    // (the wave's number as a SCALAR: what follows from it — its tile range, where its hits go, how many it has — then lives in scalar
-    // registers; derived from threadIdx.x the compiler takes it all for per-lane values, seven vector registers the tile loop does not have)
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    FUSED_STAMP(1);
-    // this work-group's number: the order in which the work-groups of the launch started, not blockIdx — a work-group waits (below) for
-    // the totals of those numbered before it, and those are then known to be running or done whatever order the dispatcher chose
-    if (threadIdx.x == 0) s_wg = (uint32_t)(my_ticket - tail_at_entry->ticket_base);
-    if (lane == 0) s_over[wave] = 0u;
-    __syncthreads();
-    const uint32_t wg = __builtin_amdgcn_readfirstlane(s_wg);
-    int tile0, tile1;
-    {
-        const int64_t gwave = (int64_t)wg * W + wave, n_waves = (int64_t)gridDim.x * W;
-        tile0 = (int)(gwave * h.n_tiles / n_waves);
-        tile1 = (int)((gwave + 1) * h.n_tiles / n_waves);
-    }
-    uint2* out = (!LH && h.stage) ? h.stage + (int64_t)tile0 * TILE : nullptr;
-    uint32_t out_cap = (uint32_t)(tile1 - tile0) * (uint32_t)TILE, run = 0u;
-#if GPK_FUSED_STAGGER  // tuning builds: the waves of a work-group start their first tile GPK_FUSED_STAGGER * 64 clocks apart
-    for (int i = 0; i < wave; ++i) __builtin_amdgcn_s_sleep(GPK_FUSED_STAGGER);
-#endif
-    // guard-free tiles first, then the guarded ones (the column's last tile; every tile of a column with a validity bitmap): two plain
-    // loops — one loop that picks the variant per tile keeps the values that travel round its back edge in scratch memory
-    const int tile_f = tile1 < h.n_full_tiles ? tile1 : (tile0 > h.n_full_tiles ? tile0 : h.n_full_tiles);
-    {
-        PointRegs<P> pr;
-        if constexpr (LH) {
-            LdsHits lh{s_ids[wave], s_hmask[wave], s_rowbase, &s_over[wave], (uint32_t)FUSED_LH_IDS};
-            FUSED_STAMP(2);
-            for (int tile = tile0; tile < tile_f; ++tile) {
-                lh.masks = s_hmask[wave] + (tile - tile0) * P;
-                chain_tile<P, true, true, true, true>(h, s_mask, s_rec0, s_items[wave], (int64_t)tile, lane, nullptr, 0u, &run, pr, (int64_t)-1, lh);
-                FUSED_STAMP(3 + (tile - tile0));
-            }
-            for (int tile = tile_f; tile < tile1; ++tile) {
-                lh.masks = s_hmask[wave] + (tile - tile0) * P;
-                chain_tile<P, true, false, true, true>(h, s_mask, s_rec0, s_items[wave], (int64_t)tile, lane, nullptr, 0u, &run, pr, (int64_t)-1, lh);
-            }
-        } else {
-            if (GPK_FUSED_PREFETCH && tile0 < tile_f) chain_load_points<P, true, true>(h, (int64_t)tile0, lane, pr);
-            for (int tile = tile0; tile < tile_f; ++tile)
-                chain_tile<P, true, true, true>(h, s_mask, s_rec0, s_items[wave], (int64_t)tile, lane, out, out_cap, &run, pr,
-                                                tile + 1 < tile_f ? (int64_t)(tile + 1) : (int64_t)-1);
-            for (int tile = tile_f; tile < tile1; ++tile)
-                chain_tile<P, true, false, true>(h, s_mask, s_rec0, s_items[wave], (int64_t)tile, lane, out, out_cap, &run, pr, (int64_t)-1);
-        }
-    }
-#if GPK_FUSED_ABLATE == 2  // tuning builds only: the tile phase alone (no totals, no pair list)
-    return;
-#endif
-    // (the tail of the kernel arguments is read HERE, from the argument segment: named directly the compiler loads it at the top
-    // of the kernel and carries its fourteen scalar registers through the tile loop, which has none to spare)
-    typedef const FusedTail __attribute__((address_space(4))) * TailPtr;
-    static_assert(sizeof(ChainHot) % 8 == 0, "FusedTail follows ChainHot in the argument segment");
-    const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(ka));
-    const TailPtr tp = (TailPtr)(ka + sizeof(ChainHot));
-    FusedTail t;
-    t.pairs = tp->pairs;
-    t.capacity = tp->capacity;
-    t.slots = tp->slots;
-    t.epoch = tp->epoch;
-    t.grand = tp->grand;
-    t.grand_host = tp->grand_host;
-    t.left_base = tp->left_base;
-    t.ticket = nullptr;
-    t.ticket_base = 0;
-    // this work-group's total, published; the totals before it
-    FUSED_STAMP(9);
-    if (lane == 0) s_wtot[wave] = (unsigned long long)run;
-    __syncthreads();
-    FUSED_STAMP(10);
-    unsigned long long wg_tot = 0, mine_off = 0;
-#pragma unroll
-    for (int w = 0; w < W; ++w) {
-        const unsigned long long v = s_wtot[w];
-        wg_tot += v;
-        if (w < wave) mine_off += v;
-    }
-    if (threadIdx.x == 0) __hip_atomic_store(&t.slots[wg], (t.epoch << FUSED_TOTAL_BITS) | wg_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned long long acc = 0;
-    bool gave_up = false;
-    for (unsigned b = threadIdx.x; b < wg; b += ROUTE_BLOCK) {
-        unsigned long long v;
-        uint32_t spins = 0;
-        while (((v = __hip_atomic_load(&t.slots[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> FUSED_TOTAL_BITS) != t.epoch) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > FUSED_SPIN_LIMIT) {  // (seconds: a work-group before this one never ran — report, never hang the device)
-                gave_up = true;
-                break;
-            }
-        }
-        acc += v & ((1ull << FUSED_TOTAL_BITS) - 1ull);
-    }
-    const bool lost = __syncthreads_or(gave_up);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if (lane == 0) s_part[wave] = acc;
-    __syncthreads();
-    unsigned long long base_off = 0;
-#pragma unroll
-    for (int w = 0; w < W; ++w) base_off += s_part[w];
-    if ((wg == gridDim.x - 1 || lost) && threadIdx.x == 0) {
-        // (a work-group that gave up says so in the launch's `lost` word before anything else; the last work-group waited for every
-        // word any other waited for, so it reads `lost` after the store of whoever gave up: the total cannot hide a lost work-group)
-        unsigned long long* const lostp = tp->lost;
-        if (lost) __hip_atomic_store(lostp, t.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool any_lost = lost || __hip_atomic_load(lostp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == t.epoch;
-        if (wg == gridDim.x - 1 || lost) {
-            *t.grand = any_lost ? FUSED_LOST : base_off + wg_tot;
-            if (t.grand_host) *t.grand_host = any_lost ? FUSED_LOST : base_off + wg_tot;
-        }
-    }
-    FUSED_STAMP(11);
-    if (!t.pairs || lost || GPK_FUSED_ABLATE == 1) return;  // (ablation 1, tuning builds only: no copy)
-    const unsigned long long my_off = base_off + mine_off;
-    bool redo;
-    if constexpr (LH) {
-        redo = s_over[wave] != 0u;  // (set by this wave's own lane 0: wave-uniform)
-        if (!redo && !GPK_LH_EMIT_RANK && !GPK_LH_EMIT_OLD) {
-            static_assert(FUSED_LH_TILES * P <= 64, "one mask per lane");
-            emit_hit_rows(s_hmask[wave], s_ids[wave], (tile1 - tile0) * P, (uint32_t)((int64_t)tile0 * TILE) + t.left_base, my_off, t.pairs, t.capacity, lane, GPK_LH_NT != 0);
-        } else if (!redo && !GPK_LH_EMIT_RANK) {  // the hits, out of LDS, to their place in the pair list: a row's rank = the hits before it
-            uint32_t pos = 0;
-            for (int tile = tile0; tile < tile1; ++tile) {
-#pragma unroll
-                for (int k = 0; k < P; ++k) {
-                    const unsigned long long m = s_hmask[wave][(tile - tile0) * P + k];
-                    const uint32_t rank = pos + lanes_below(m);
-                    if ((m >> lane) & 1ull) {
-                        const unsigned long long at = my_off + rank;
-                        const uint32_t row = (uint32_t)((int64_t)tile * TILE + k * 64 + lane) + t.left_base;
-                        if ((int64_t)at < t.capacity) {
-                            const unsigned long long v = ((unsigned long long)s_ids[wave][rank] << 32) | (unsigned long long)row;
-                            if (GPK_FUSED_ABLATE == 3)  // (tuning builds only: everything but the store)
-                                asm volatile("" ::"v"(v), "v"(at));
-                            else if (GPK_LH_NT)
-                                __builtin_nontemporal_store(v, reinterpret_cast<unsigned long long*>(t.pairs + at));
-                            else
-                                *reinterpret_cast<unsigned long long*>(t.pairs + at) = v;
-                        }
-                    }
-                    pos += (uint32_t)__popcll(m);
-                }
-            }
-        } else if (!redo) {
-            // the hits, out of LDS, to their place in the pair list.  First every hit row writes its number (within the wave's rows) at
-            // its rank — into the list slots, which are free now —, then the lanes walk the RANKS: a wave stores 512 contiguous bytes per
-            // instruction (stored row by row, an instruction covered ~180 bytes of two lines: 10.7 us for the 28 MB)
-            uint16_t* rows16 = reinterpret_cast<uint16_t*>(s_items[wave]);
-            static_assert(sizeof(ChainItem) * chain_items<P, true>() >= sizeof(uint16_t) * FUSED_LH_IDS, "the list slots hold a row number per hit");
-            static_assert(FUSED_LH_TILES * TILE <= 65536, "a row's number within the wave's rows fits 16 bits");
-            uint32_t pos = 0;
-            for (int tile = tile0; tile < tile1; ++tile) {
-#pragma unroll
-                for (int k = 0; k < P; ++k) {
-                    const unsigned long long m = s_hmask[wave][(tile - tile0) * P + k];
-                    if ((m >> lane) & 1ull) rows16[pos + lanes_below(m)] = (uint16_t)((tile - tile0) * TILE + k * 64 + lane);
-                    pos += (uint32_t)__popcll(m);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const uint32_t row_base = (uint32_t)((int64_t)tile0 * TILE) + t.left_base;
-            for (uint32_t r = (uint32_t)lane; r < run; r += 64u) {
-                const unsigned long long at = my_off + r;
-                if ((int64_t)at < t.capacity) {
-                    const unsigned long long v = ((unsigned long long)s_ids[wave][r] << 32) | (unsigned long long)(row_base + rows16[r]);
-                    if (GPK_LH_NT)
-                        __builtin_nontemporal_store(v, reinterpret_cast<unsigned long long*>(t.pairs + at));
-                    else
-                        *reinterpret_cast<unsigned long long*>(t.pairs + at) = v;
-                }
-            }
-        }
-    } else {
-        redo = run > out_cap;
-        if (!redo) {  // the run, moved to its place in the pair list
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const uint2* __restrict__ src = out;
-            constexpr int CU = GPK_FUSED_COPY_UNROLL;  // entries a lane has in flight: the loop is a chain of round trips otherwise
-            for (uint32_t i0 = 0; i0 < run; i0 += 64u * CU) {
-                uint2 v[CU];
-#pragma unroll
-                for (int u = 0; u < CU; ++u) {
-                    const uint32_t i = i0 + (uint32_t)(u * 64 + lane);
-                    v[u] = i < run ? src[i] : make_uint2(0u, 0u);
-                }
-#pragma unroll
-                for (int u = 0; u < CU; ++u) {
-                    const uint32_t i = i0 + (uint32_t)(u * 64 + lane);
-                    if (i < run && (int64_t)(my_off + i) < t.capacity)
-                        __builtin_nontemporal_store(((unsigned long long)v[u].y << 32) | (unsigned long long)(v[u].x + t.left_base),
-                                                    reinterpret_cast<unsigned long long*>(t.pairs + my_off + i));
-                }
-            }
-        }
-    }
-    FUSED_STAMP(12);
-#ifdef GPK_TILE_TRACE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    FUSED_STAMP(13);
-#endif
-    if (!redo) return;
-    // the wave could not park its hits (rows in several geometries; more hits than slots): it decides its tiles again, storing at the
-    // final offsets, and adds the left rows' base afterwards
-    {
-        const int64_t room = t.capacity - (int64_t)my_off;
-        out = t.pairs + my_off;
-        out_cap = room <= 0 ? 0u : (room > (int64_t)0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)room);
-        const uint32_t left_base = t.left_base;
-        run = 0u;
-        PointRegs<P> pr;
-        LdsHits lh{};
-        lh.rowbase = s_rowbase;
-        for (int tile = tile0; tile < tile_f; ++tile)
-            chain_tile<P, true, true, true, false, LH>(h, s_mask, s_rec0, s_items[wave], (int64_t)tile, lane, out, out_cap, &run, pr, (int64_t)-1, lh);
-        for (int tile = tile_f; tile < tile1; ++tile)
-            chain_tile<P, true, false, true, false, LH>(h, s_mask, s_rec0, s_items[wave], (int64_t)tile, lane, out, out_cap, &run, pr, (int64_t)-1, lh);
-        if (left_base) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            for (uint32_t i = (uint32_t)lane; i < run && i < out_cap; i += 64u) out[i].x += left_base;
-        }
-    }
-}
-
-// ---- round 5: the same join with its pair list written WHILE tiles are still being decided --------------------------------------
-// pip_tile_fused_kernel emits every pair after the slowest work-group's last tile: 28 MB of stores drained with nothing else in
-// flight (10.7 us of a 97 us launch on C2), and its hits wait in LDS for the whole of a wave's run, which ties the kernel to columns of
-// at most FUSED_LH_TILES tiles per wave.  Here the unit of ordering is a CHUNK — W consecutive tiles, one per wave of a work-group:
-//   * work-groups take chunks from one agent-scope counter in the order they ask (a chunk's pairs follow those of every chunk numbered
-//     before it, and every such chunk has been TAKEN by a running work-group: whatever the dispatcher does, nobody waits for a
-//     work-group that has not started);
-//   * when the last of its waves has decided its tile, a work-group publishes the chunk's hit total (epoch-tagged word, as before);
-//   * a wave emits the hits of its tile of chunk k after it has decided its tile of chunk k + 1: by then the totals of the chunks
-//     before chunk k are (nearly always) there, so the stores of one chunk travel next to the loads of the next, and only the last
-//     chunk of every work-group is emitted with nothing behind it;
-//   * the place of chunk c = the pairs of all GENERATIONS (256 chunks) before its own — carried in LDS from chunk to chunk, one
-//     256-word read per generation — + the totals of its own generation's chunks before it: at most 511 words per chunk and
-//     work-group, read by whichever wave needs the place first.
-// LDS holds two tiles' hits per wave whatever the column's length.  Eligible: geometry ids of 16 bits, a routing image (R >= 32).
-struct ChunkTail {
-    uint2* pairs;            // may be nullptr: counts and total only
-    int64_t capacity;        // pair slots of `pairs`
-    unsigned long long* slots;   // one word per chunk: epoch << FUSED_TOTAL_BITS | hits of the chunk
-    unsigned long long epoch;
-    unsigned long long* grand;
-    unsigned long long* grand_host;
-    uint32_t left_base, n_chunks;
-    unsigned long long* counter;      // chunk tickets of THIS launch (zero when it starts)
-    unsigned long long* counter_zero; // the counter of a later launch: zeroed by the work-group that takes chunk 0
-    unsigned long long* lost;         // a work-group that gave up waiting stores the launch's epoch here: the total becomes FUSED_LOST
-};
-constexpr int CHUNK_GEN_SHIFT = 8, CHUNK_GEN = 1 << CHUNK_GEN_SHIFT;
-constexpr unsigned long long CHUNK_WAIT_TICKS = 200000000ull;  // two seconds of the 100 MHz wall clock: a chunk's owner never ran
-#ifndef GPK_CHUNK_ABLATE
-#define GPK_CHUNK_ABLATE 0  // tuning builds only: 1 = no emission (totals and places only)
-#endif
-// the total of chunk `at` (spinning on the epoch tag; wall-clock bounded: *lost)
-__device__ __forceinline__ unsigned long long chunk_total_wait(const unsigned long long* slots, uint32_t at, unsigned long long epoch, bool* lost) {
-    unsigned long long v = __hip_atomic_load(&slots[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((v >> FUSED_TOTAL_BITS) != epoch) {
-        const unsigned long long t0 = wall_clock64();
-        uint32_t spins = 0;
-        while (((v = __hip_atomic_load(&slots[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> FUSED_TOTAL_BITS) != epoch) {
-            __builtin_amdgcn_s_sleep(8);
-            if ((++spins & 1023u) == 0u && wall_clock64() - t0 > CHUNK_WAIT_TICKS) {
-                *lost = true;
-                return 0ull;
-            }
-        }
-    }
-    return v & ((1ull << FUSED_TOTAL_BITS) - 1ull);
-}
-__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ uint32_t lds_tag(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-#define LDS_ORDER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")  // (this wave's LDS writes so far are done before what follows)
-__global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_chunked_kernel(ChainHot h, ChunkTail tail_in_the_argument_segment) {
-    constexpr int WORDS = PIP_ROUTE_RMAX * PIP_ROUTE_RMAX / 32, W = ROUTE_BLOCK / 64, TILE = 64 * FUSED_PPT, P = FUSED_PPT;
-    __shared__ uint2 s_mask[WORDS];                  // RouteWord::bmask, gmask
-    __shared__ uint32_t s_rec0[WORDS / 2];           // RouteWord::rec0 as uint16 ranks within the raster row
-    __shared__ uint32_t s_rowbase[PIP_ROUTE_RMAX];   // record rank of the row's first record
-    __shared__ ChainItem s_items[W][chain_items<P, true>()];
-    __shared__ uint16_t s_ids[W][2][TILE];           // a wave's hits of its tiles of chunks k and k + 1 (one slot per row: no overflow)
-    __shared__ unsigned long long s_hmask[W][2][P];
-    __shared__ uint32_t s_over[W][2];
-    // rings over the work-group's local chunk number k (k & 3: its waves are never more than two chunks apart — a wave starts chunk
-    // k + 2 after emitting chunk k, whose place needs every wave's total of chunk k)
-    __shared__ uint32_t s_wtot[4][W], s_arrive[4], s_arrived_tag[4];  // (s_arrived_tag: k + 1 once every wave's total of round k is in s_wtot)
-    __shared__ uint32_t s_chunk[4], s_chunk_tag[4], s_chunk_claim[4];  // tags: k + 1
-    __shared__ unsigned long long s_place[4];
-    __shared__ uint32_t s_place_tag[4], s_place_claim[4];
-    __shared__ uint32_t s_kgen, s_lost;              // s_kcum = the pairs of the generations before s_kgen
-    __shared__ unsigned long long s_kcum;
-    {
-        const int words = h.R * h.R / 32;
-        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(h.route);
-        const int per_row = h.R / 32;  // (R >= 32: the host checks)
-        // (thread 0: this work-group's first chunk, asked for now, posted when the row bases are in)
-        typedef const ChunkTail __attribute__((address_space(4))) * TailPtr0;
-        const TailPtr0 tp0 = (TailPtr0)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(ChainHot));
-        uint32_t first_c = 0u;
-        if (threadIdx.x == 0) first_c = __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(tp0->counter), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (threadIdx.x < 4) {
-            s_arrive[threadIdx.x] = 0u;
-            s_chunk_tag[threadIdx.x] = s_chunk_claim[threadIdx.x] = s_arrived_tag[threadIdx.x] = 0u;
-            s_place_tag[threadIdx.x] = s_place_claim[threadIdx.x] = 0u;
-        }
-        if (threadIdx.x == 0) {
-            s_kgen = 0u;
-            s_lost = 0u;
-            s_kcum = 0ull;
-            if (first_c == 0u) __hip_atomic_store(tp0->counter_zero, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_chunk[0] = first_c < tp0->n_chunks ? first_c : 0xFFFFFFFFu;
-            s_chunk_claim[0] = 1u;
-            s_chunk_tag[0] = 1u;
-        }
-        uint16_t* rec16 = reinterpret_cast<uint16_t*>(s_rec0);
-        for (int i = threadIdx.x; i < words; i += ROUTE_BLOCK) {  // (one pass: see pip_tile_fused_kernel)
-            const uint4 rw = src[i];
-            s_mask[i] = make_uint2(rw.x, rw.y);
-            rec16[i] = (uint16_t)rw.w;
-            if (rw.x) s_rowbase[i / per_row] = rw.z - rw.w;
-        }
-    }
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    __syncthreads();
-#if GPK_CHUNK_ABLATE == 2  // tuning builds only: launch + routing image
-    return;
-#endif
-    typedef const ChunkTail __attribute__((address_space(4))) * TailPtr;
-    static_assert(sizeof(ChainHot) % 8 == 0, "ChunkTail follows ChainHot in the argument segment");
-    // (the tail is read from the argument segment where it is used: see pip_tile_fused_kernel)
-    auto tail = [&]() -> TailPtr {
-        const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(ka));
-        return (TailPtr)(ka + sizeof(ChainHot));
-    };
-    for (uint32_t k = 0;; ++k) {
-        const uint32_t slot = k & 3u, buf = k & 1u;
-        // ---- the chunk of round k: asked for a round ahead (chunk 0 at the top of the kernel, chunk k + 1 by the first wave that starts
-        // round k: the counter's round trip runs next to a tile), so this wait is over before it starts unless that wave is the slowest
-        while (lds_tag(&s_chunk_tag[slot]) != k + 1u) __builtin_amdgcn_s_sleep(2);
-        asm volatile("" ::: "memory");
-        const uint32_t c = __builtin_amdgcn_readfirstlane(s_chunk[slot]);
-        const bool valid = c != 0xFFFFFFFFu;
-        if (valid) {
-            const int64_t tile = (int64_t)c * W + wave;
-            uint32_t run = 0u;
-            if (lane == 0) s_over[wave][buf] = 0u;
-            // the first wave to start round k asks for the chunk of round k + 1 (not waited for here)
-            const uint32_t nslot = (k + 1u) & 3u;
-            uint32_t first = 0u, next_c = 0xFFFFFFFFu;
-            if (lane == 0) first = __hip_atomic_fetch_max(&s_chunk_claim[nslot], k + 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < k + 2u ? 1u : 0u;
-            first = __builtin_amdgcn_readfirstlane(first);
-            if (first && lane == 0 && !lds_tag(&s_lost))
-                next_c = __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(tail()->counter), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (tile < h.n_tiles) {
-                PointRegs<P> pr;
-                LdsHits lh{s_ids[wave][buf], s_hmask[wave][buf], s_rowbase, &s_over[wave][buf], (uint32_t)TILE};
-                if (tile < (int64_t)h.n_full_tiles)
-                    chain_tile<P, true, true, true, true>(h, s_mask, s_rec0, s_items[wave], tile, lane, nullptr, 0u, &run, pr, (int64_t)-1, lh);
-                else
-                    chain_tile<P, true, false, true, true>(h, s_mask, s_rec0, s_items[wave], tile, lane, nullptr, 0u, &run, pr, (int64_t)-1, lh);
-            }
-            if (first && lane == 0) {
-                s_chunk[nslot] = next_c < tail()->n_chunks ? next_c : 0xFFFFFFFFu;
-                LDS_ORDER();
-                __hip_atomic_store(&s_chunk_tag[nslot], k + 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            // the wave's total; the last wave to arrive publishes the chunk's
-            if (lane == 0) {
-                s_wtot[slot][wave] = run;
-                LDS_ORDER();
-                const uint32_t before = __hip_atomic_fetch_add(&s_arrive[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (before == (uint32_t)(W - 1)) {
-                    unsigned long long tot = 0;
-#pragma unroll
-                    for (int w = 0; w < W; ++w) tot += (unsigned long long)s_wtot[slot][w];
-                    __hip_atomic_store(&s_arrive[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_store(&s_arrived_tag[slot], k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    const TailPtr tp = tail();
-                    __hip_atomic_store(&tp->slots[c], (tp->epoch << FUSED_TOTAL_BITS) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-        // ---- the hits of round k - 1, to their place in the pair list
-        if (k > 0u) {
-            const uint32_t q = k - 1u, qslot = q & 3u, qbuf = q & 1u;
-            const uint32_t cq = __builtin_amdgcn_readfirstlane(s_chunk[qslot]);  // (valid: the loop left otherwise)
-            const TailPtr tp = tail();
-            uint2* const pairs = tp->pairs;
-            const uint32_t n_chunks = tp->n_chunks;
-            const bool is_last = cq + 1u == n_chunks;
-            if (pairs != nullptr || is_last) {  // (count-only calls: only the last chunk's place — the total — is asked for)
-                if (lds_tag(&s_place_tag[qslot]) != q + 1u) {
-                    uint32_t old = 0u;
-                    if (lane == 0) old = __hip_atomic_fetch_max(&s_place_claim[qslot], q + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    old = __builtin_amdgcn_readfirstlane(old);
-                    if (old < q + 1u) {
-                        // the generations before the chunk's (carried from the work-group's previous chunk), then its own generation's
-                        // chunks before it
-                        const unsigned long long* slots = tp->slots;
-                        const unsigned long long epoch = tp->epoch;
-                        const uint32_t gen = cq >> CHUNK_GEN_SHIFT;
-                        uint32_t kgen = s_kgen;
-                        unsigned long long kcum = s_kcum;
-                        bool lost = false;
-                        while (kgen < gen && !lost) {
-                            unsigned long long part = 0;
-#pragma unroll
-                            for (int j = 0; j < CHUNK_GEN / 64; ++j) part += chunk_total_wait(slots, (kgen << CHUNK_GEN_SHIFT) + (uint32_t)(j * 64 + lane), epoch, &lost);
-                            lost = __any(lost);
-                            kcum += wave_sum_u64(part);
-                            ++kgen;
-                        }
-                        unsigned long long part = 0;
-                        if (!lost)
-                            for (uint32_t i = (uint32_t)lane; i < (cq & (uint32_t)(CHUNK_GEN - 1)); i += 64u)
-                                part += chunk_total_wait(slots, (gen << CHUNK_GEN_SHIFT) + i, epoch, &lost);
-                        lost = __any(lost);
-                        const unsigned long long place = kcum + wave_sum_u64(part);
-                        if (lane == 0) {
-                            if (lost) {
-                                __hip_atomic_store(tp->lost, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                __hip_atomic_store(&s_lost, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            }
-                            s_kgen = kgen;
-                            s_kcum = kcum;
-                            s_place[qslot] = lost ? FUSED_LOST : place;
-                            LDS_ORDER();
-                            __hip_atomic_store(&s_place_tag[qslot], q + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                    }
-                    while (lds_tag(&s_place_tag[qslot]) != q + 1u) __builtin_amdgcn_s_sleep(2);
-                }
-                // (the other waves' totals of round q: a wave a whole round behind the others is waited for here)
-                while (lds_tag(&s_arrived_tag[qslot]) != q + 1u) __builtin_amdgcn_s_sleep(2);
-                asm volatile("" ::: "memory");
-                const unsigned long long place = s_place[qslot];
-                uint32_t mine_off = 0u, wg_tot = 0u;
-#pragma unroll
-                for (int w = 0; w < W; ++w) {
-                    const uint32_t v = s_wtot[qslot][w];
-                    wg_tot += v;
-                    if (w < wave) mine_off += v;
-                }
-                if (is_last && wave == 0 && lane == 0) {  // the launch's total: the last chunk's place + its hits — unless some work-group gave up
-                    const bool any_lost = place == FUSED_LOST || __hip_atomic_load(tp->lost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tp->epoch;
-                    const unsigned long long total = any_lost ? FUSED_LOST : place + (unsigned long long)wg_tot;
-                    *tp->grand = total;
-                    if (tp->grand_host) *tp->grand_host = total;
-                }
-                const int64_t tile = (int64_t)cq * W + wave;
-                if (pairs != nullptr && place != FUSED_LOST && tile < h.n_tiles && GPK_CHUNK_ABLATE != 1) {
-                    const unsigned long long my_off = place + (unsigned long long)mine_off;
-                    const int64_t capacity = tp->capacity;
-                    const uint32_t left_base = tp->left_base;
-                    if (s_over[wave][qbuf] == 0u) {  // (set by this wave's own lane 0: wave-uniform)
-                        emit_hit_rows(s_hmask[wave][qbuf], s_ids[wave][qbuf], P, (uint32_t)(tile * TILE) + left_base, my_off, pairs, capacity, lane, GPK_LH_NT != 0);
-                    } else {
-                        // a row of the tile lies in several geometries (a bit per row cannot say that): the wave decides the tile again,
-                        // storing at the final offsets, and adds the left rows' base afterwards
-                        const int64_t room = capacity - (int64_t)my_off;
-                        uint2* const out = pairs + my_off;
-                        const uint32_t out_cap = room <= 0 ? 0u : (room > (int64_t)0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)room);
-                        uint32_t run = 0u;
-                        PointRegs<P> pr;
-                        LdsHits lh{};
-                        lh.rowbase = s_rowbase;
-                        if (tile < (int64_t)h.n_full_tiles)
-                            chain_tile<P, true, true, true, false, true>(h, s_mask, s_rec0, s_items[wave], tile, lane, out, out_cap, &run, pr, (int64_t)-1, lh);
-                        else
-                            chain_tile<P, true, false, true, false, true>(h, s_mask, s_rec0, s_items[wave], tile, lane, out, out_cap, &run, pr, (int64_t)-1, lh);
-                        if (left_base) {
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            for (uint32_t i = (uint32_t)lane; i < run && i < out_cap; i += 64u) out[i].x += left_base;
-                        }
-                    }
-                }
-            }
-        }
-        if (!valid) break;
-    }
-}
-
-// ---- round 5: tiles handed out INSIDE the work-group ---------------------------------------------------------------------------------
-// pip_tile_fused_kernel<true> gives every wave a contiguous run of tiles; its timeline (tools/fused_trace.py, C2) shows what that costs:
-// a wave owns four or five tiles (4.77 on average) and waves run at different speeds, so the median wave is done at 72 us, the
-// median work-group's LAST wave at 80, and every work-group waits for its last wave.  Here a work-group still owns a contiguous range
-// of tiles (its pairs are contiguous in the pair list), but its waves draw tiles from an LDS counter one at a time; hits go to ONE pool
-// of 16-bit geometry ids per work-group (a tile takes its place in it with a single LDS atomic once it knows its hit count), a tile's
-// record = its masks + where its ids start, and after the work-group's barrier tile t's pairs go to place + the totals of the range's
-// tiles before t.  Rare rows are settled BEFORE the tile's hits are ranked (chain_tile, POOL), so their hits are ordinary hits; a tile
-// with a row in several geometries, or one that finds the pool full, is decided again at emission.  Same eligibility as the LDS-hits
-// form (16-bit geometry ids, at most POOL_TILES tiles per work-group); longer columns take pip_tile_chunked_kernel.
-#ifndef GPK_POOL_EMIT_COMPACT
-#define GPK_POOL_EMIT_COMPACT 1
-#endif
-#ifndef GPK_POOL_STRIDED
-#define GPK_POOL_STRIDED 0  // 1: draw d -> tile (d % W) * stride + d / W (the tiles in flight `stride` apart): measured 1.5 - 2 us SLOWER on C2 (94.2 -> 96.4)
-#endif
-constexpr int POOL_TILES = FUSED_LH_TILES * (ROUTE_BLOCK / 64);   // tile records per work-group
-constexpr int POOL_IDS = 17408;                                   // 16-bit hit slots per work-group (34 KB)
-__global__ __launch_bounds__(ROUTE_BLOCK) void pip_tile_pool_kernel(ChainHot h, FusedTail tail_in_the_argument_segment) {
-    constexpr int WORDS = PIP_ROUTE_RMAX * PIP_ROUTE_RMAX / 32, W = ROUTE_BLOCK / 64, TILE = 64 * FUSED_PPT, P = FUSED_PPT;
-    __shared__ uint2 s_mask[WORDS];                  // RouteWord::bmask, gmask
-    __shared__ uint32_t s_rec0[WORDS / 2];           // RouteWord::pad: uint16 record ranks within the raster row
-    __shared__ uint32_t s_rowbase[PIP_ROUTE_RMAX];   // record rank of the row's first record
-    __shared__ ChainItem s_items[W][chain_items<P, true>()];
-    __shared__ uint16_t s_pool[POOL_IDS];
-    __shared__ unsigned long long s_tmask[POOL_TILES][P];
-    __shared__ uint32_t s_tstart[POOL_TILES], s_ttot[POOL_TILES], s_texcl[POOL_TILES];
-    __shared__ uint32_t s_next, s_next2, s_pool_top, s_wg, s_wgtot, s_gave_up;
-    __shared__ unsigned long long s_part[W];
-    typedef const FusedTail __attribute__((address_space(4))) * TailPtr;
-    static_assert(sizeof(ChainHot) % 8 == 0, "FusedTail follows ChainHot in the argument segment");
-    auto tail = [&]() -> TailPtr {  // (read where it is used: see pip_tile_fused_kernel)
-        const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(ka));
-        return (TailPtr)(ka + sizeof(ChainHot));
-    };
-#ifdef GPK_TILE_TRACE
-    {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        FUSED_STAMP(0);
-    }
-#endif
-    // (the work-group's ticket is asked for before the image is read and used after: its round trip is the image's)
-    unsigned long long my_ticket = 0ull;
-    if (threadIdx.x == 0) my_ticket = __hip_atomic_fetch_add(tail()->ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    {
-        const int words = h.R * h.R / 32, per_row = h.R / 32;  // (R >= 32: the host checks)
-        const uint4* __restrict__ src = reinterpret_cast<const uint4*>(h.route);
-        uint16_t* rec16 = reinterpret_cast<uint16_t*>(s_rec0);
-        for (int i = threadIdx.x; i < words; i += ROUTE_BLOCK) {  // (one pass: see pip_tile_fused_kernel)
-            const uint4 rw = src[i];
-            s_mask[i] = make_uint2(rw.x, rw.y);
-            rec16[i] = (uint16_t)rw.w;
-            if (rw.x) s_rowbase[i / per_row] = rw.z - rw.w;
-        }
-    }
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    FUSED_STAMP(1);
-    if (threadIdx.x == 0) {
-        s_wg = (uint32_t)(my_ticket - tail()->ticket_base);
-        s_next = 0u;
-        s_next2 = 0u;
-        s_pool_top = 0u;
-        s_gave_up = 0u;
-    }
-    __syncthreads();
-    const uint32_t wg = __builtin_amdgcn_readfirstlane(s_wg);
-    const int T0 = (int)((int64_t)wg * h.n_tiles / (int64_t)gridDim.x), T1 = (int)((int64_t)(wg + 1u) * h.n_tiles / (int64_t)gridDim.x);
-    const uint32_t nt = (uint32_t)(T1 - T0);  // (<= POOL_TILES: the host checks)
-    // ---- the tiles, one at a time from the work-group's counters: the guard-free tiles of the range first (a prefix of it: whole tiles
-    // of a column without a validity bitmap), then the guarded ones — two plain loops, each around ONE instance of the tile code (a loop
-    // that picks the variant per tile keeps what travels round its back edge in scratch memory: + 13 us on C2)
-    FUSED_STAMP(2);
-#ifdef GPK_TILE_TRACE
-    int n_mine = 0;
-#endif
-    const uint32_t nf = (int64_t)T1 <= (int64_t)h.n_full_tiles ? nt : ((int64_t)T0 >= (int64_t)h.n_full_tiles ? 0u : (uint32_t)(h.n_full_tiles - T0));
-#if GPK_POOL_STRIDED
-    const uint32_t nf_stride = (nf + (uint32_t)W - 1u) / (uint32_t)W, nf_draws = nf_stride * (uint32_t)W;
-#else
-    const uint32_t nf_draws = nf;
-#endif
-    for (;;) {
-        // (EVERY lane adds 1 — the counter runs in units of 64 — and the wave barrier keeps the iterations apart.  Under `if (lane == 0)`
-        // the compiler threaded lane 0 from the tile record's store at the end of one iteration straight into the draw of the next, and
-        // the loop it built around the readfirstlane never ended; with per-lane values (lane 0 adds 1, the others 0) its atomic optimizer
-        // walks the 64 lanes one by one: + 1000 scalar and + 400 vector instructions per tile for the two atomics of a tile.  A uniform
-        // value costs one v_mbcnt and ONE LDS atomic.)
-        __builtin_amdgcn_wave_barrier();
-        uint32_t t = __hip_atomic_fetch_add(&s_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        t = __builtin_amdgcn_readfirstlane(t) >> 6;
-        if (t >= nf_draws) break;
-#if GPK_POOL_STRIDED
-        // draw d -> tile (d % W) * stride + d / W: the W tiles in flight in a work-group lie `stride` tiles apart, as the runs of
-        // pip_tile_fused_kernel's waves do (tried when the first version of this kernel ran 3 - 4 us slower per tile than the wave form;
-        // the cause was the atomic optimizer's lane loop, not the tiles' addresses: off by default)
-        t = (t % (uint32_t)W) * nf_stride + t / (uint32_t)W;
-        if (t >= nf) continue;
-#endif
-        PointRegs<P> pr;
-        LdsHits lh{s_pool, s_tmask[t], s_rowbase, nullptr, (uint32_t)POOL_IDS, &s_pool_top, &s_tstart[t], &s_ttot[t]};
-        uint32_t unused_run = 0u;
-        chain_tile<P, true, true, true, false, true, true>(h, s_mask, s_rec0, s_items[wave], (int64_t)T0 + t, lane, nullptr, 0u, &unused_run, pr, (int64_t)-1, lh);
-#ifdef GPK_TILE_TRACE
-        if (n_mine < 6) FUSED_STAMP(3 + n_mine);
-        ++n_mine;
-#endif
-    }
-    for (;;) {
-        __builtin_amdgcn_wave_barrier();
-        uint32_t t = __hip_atomic_fetch_add(&s_next2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        t = (__builtin_amdgcn_readfirstlane(t) >> 6) + nf;
-        if (t >= nt) break;
-        PointRegs<P> pr;
-        LdsHits lh{s_pool, s_tmask[t], s_rowbase, nullptr, (uint32_t)POOL_IDS, &s_pool_top, &s_tstart[t], &s_ttot[t]};
-        uint32_t unused_run = 0u;
-        chain_tile<P, true, false, true, false, true, true>(h, s_mask, s_rec0, s_items[wave], (int64_t)T0 + t, lane, nullptr, 0u, &unused_run, pr, (int64_t)-1, lh);
-    }
-    FUSED_STAMP(9);
-#if GPK_FUSED_ABLATE == 2  // tuning builds only: the tile phase alone
-    return;
-#endif
-    __syncthreads();
-    FUSED_STAMP(10);
-    // ---- the tiles' places within the work-group's pairs (wave 0: one scan over at most 128 totals), the work-group's total
-    static_assert(POOL_TILES <= 128, "two totals per lane");
-    if (wave == 0) {
-        const uint32_t v0 = (uint32_t)lane < nt ? s_ttot[lane] : 0u, v1 = (uint32_t)(lane + 64) < nt ? s_ttot[lane + 64] : 0u;
-        uint32_t i0 = v0, i1 = v1;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t a = __shfl_up(i0, o, 64), b = __shfl_up(i1, o, 64);
-            if (lane >= o) {
-                i0 += a;
-                i1 += b;
-            }
-        }
-        const uint32_t sum0 = __shfl(i0, 63, 64), sum1 = __shfl(i1, 63, 64);
-        if ((uint32_t)lane < nt) s_texcl[lane] = i0 - v0;
-        if ((uint32_t)(lane + 64) < nt) s_texcl[lane + 64] = sum0 + i1 - v1;
-        if (lane == 0) s_wgtot = sum0 + sum1;
-    }
-    __syncthreads();
-    const unsigned long long wg_tot = (unsigned long long)s_wgtot;
-    const TailPtr tp = tail();
-    FusedTail t;
-    t.pairs = tp->pairs;
-    t.capacity = tp->capacity;
-    t.slots = tp->slots;
-    t.epoch = tp->epoch;
-    t.left_base = tp->left_base;
-    if (threadIdx.x == 0) __hip_atomic_store(&t.slots[wg], (t.epoch << FUSED_TOTAL_BITS) | wg_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned long long acc = 0;
-    bool gave_up = false;
-    for (unsigned b = threadIdx.x; b < wg; b += ROUTE_BLOCK) {
-        unsigned long long v;
-        uint32_t spins = 0;
-        while (((v = __hip_atomic_load(&t.slots[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> FUSED_TOTAL_BITS) != t.epoch) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > FUSED_SPIN_LIMIT) {  // (seconds: a work-group before this one never ran — report, never hang the device)
-                gave_up = true;
-                break;
-            }
-        }
-        acc += v & ((1ull << FUSED_TOTAL_BITS) - 1ull);
-    }
-    if (gave_up) __hip_atomic_store(&s_gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __syncthreads();
-    const bool lost = s_gave_up != 0u;
-
-    acc = wave_sum_u64(acc);
-    if (lane == 0) s_part[wave] = acc;
-    __syncthreads();
-    unsigned long long base_off = 0;
-#pragma unroll
-    for (int w = 0; w < W; ++w) base_off += s_part[w];
-    if ((wg == gridDim.x - 1 || lost) && threadIdx.x == 0) {  // (see pip_tile_fused_kernel: FUSED_LOST is sticky)
-        unsigned long long* const lostp = tp->lost;
-        if (lost) __hip_atomic_store(lostp, t.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool any_lost = lost || __hip_atomic_load(lostp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == t.epoch;
-        unsigned long long* const grand = tp->grand;
-        unsigned long long* const grand_host = tp->grand_host;
-        *grand = any_lost ? FUSED_LOST : base_off + wg_tot;
-        if (grand_host) *grand_host = any_lost ? FUSED_LOST : base_off + wg_tot;
-    }
-    FUSED_STAMP(11);
-    if (!t.pairs || lost || GPK_FUSED_ABLATE == 1) return;  // (ablation 1, tuning builds only: no emission)
-    // ---- emission: the tiles of the range dealt round the waves (wave w: tiles w, w + W, ...: at most POOL_TILES / W of them).  One
-    // pass for all of a wave's tiles: lane j holds point row j % P of the wave's tile j / P — its mask, where its ids start in the pool,
-    // where its pairs go (one LDS round trip + one wave scan for everything) — and the loop reads rows out of registers, eight id
-    // gathers in flight before the first store (tile by tile this was 7 us of a 94 us launch)
-    static_assert(POOL_TILES / W * P <= 64, "one (tile, row) per lane");
-    {
-        const uint32_t n_mine = nt > (uint32_t)wave ? (nt - (uint32_t)wave + (uint32_t)W - 1u) / (uint32_t)W : 0u;
-        const uint32_t tj = (uint32_t)lane / (uint32_t)P, kj = (uint32_t)lane % (uint32_t)P, et_j = (uint32_t)wave + tj * (uint32_t)W;
-        const bool have = tj < n_mine;
-        const uint32_t start_j = have ? s_tstart[et_j] : 0xFFFFFFFFu;
-        const unsigned long long mv = have && start_j != 0xFFFFFFFFu ? s_tmask[et_j][kj] : 0ull;
-        const uint32_t cnt = (uint32_t)__popcll(mv);
-        uint32_t incl = cnt;
-#pragma unroll
-        for (int o = 1; o < P; o <<= 1) {  // (inclusive scan within the P lanes of a tile)
-            const uint32_t v = __shfl_up(incl, o, P);
-            if ((int)kj >= o) incl += v;
-        }
-        const uint32_t gex = incl - cnt;
-        const uint32_t outb = have ? s_texcl[et_j] + gex : 0u, idsb = start_j + gex;
-        const uint32_t rowb = (uint32_t)(((int64_t)T0 + et_j) * TILE) + kj * 64u + t.left_base;
-        const uint32_t mlo = (uint32_t)mv, mhi = (uint32_t)(mv >> 32);
-        FUSED_STAMP(13);
-#if GPK_POOL_EMIT_COMPACT
-        // A COMPACT loop: with 16 waves on a CU this code is bound by the instructions it issues (35 per point row measured 7 us for the
-        // 40 rows of a wave: v_readlane, 64-bit address arithmetic and a capacity test per row), so: what a row needs from its lane
-        // travels as ONE packed word (pairs before the row within the work-group | where its ids start), the row number is scalar
-        // arithmetic, the pairs are addressed as a 32-bit index from the work-group's place (a uniform pointer), and the capacity test
-        // is made once for the work-group (a pair buffer that ends inside this work-group's pairs takes the guarded loop).
-        static_assert(POOL_TILES * TILE < 65536 && POOL_IDS < 65536, "two 16-bit fields");
-        const uint32_t packed = (outb & 0xFFFFu) | (idsb << 16);
-        unsigned long long* const out64 = reinterpret_cast<unsigned long long*>(t.pairs) + base_off;  // (wave-uniform)
-        const bool all_fit = (int64_t)(base_off + wg_tot) <= t.capacity;
-        const uint32_t room = all_fit ? 0xFFFFFFFFu : (t.capacity > (int64_t)base_off ? (uint32_t)(t.capacity - (int64_t)base_off) : 0u);
-        const uint32_t row_wave = (uint32_t)(((int64_t)T0 + wave) * TILE) + t.left_base + (uint32_t)lane;
-#pragma unroll 1
-        for (uint32_t j = 0; j < n_mine * (uint32_t)P; j += 2u) {
-            // (rows j and j + 1 belong to the same tile: P is even)
-            const uint32_t row_s = row_wave + (j >> 3) * (uint32_t)(W * TILE) + (j & 7u) * 64u;
-            const unsigned long long m0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mhi, (int)j) << 32) | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mlo, (int)j);
-            const unsigned long long m1 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mhi, (int)j + 1) << 32) | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mlo, (int)j + 1);
-            const uint32_t pk0 = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)j), pk1 = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)j + 1);
-            const uint32_t r0 = lanes_below(m0), r1 = lanes_below(m1);
-            const bool a0 = ((m0 >> lane) & 1ull) != 0ull, a1 = ((m1 >> lane) & 1ull) != 0ull;
-            uint32_t id0 = 0u, id1 = 0u;
-            if (a0) id0 = (uint32_t)s_pool[(pk0 >> 16) + r0];
-            if (a1) id1 = (uint32_t)s_pool[(pk1 >> 16) + r1];
-            const uint32_t x0 = (pk0 & 0xFFFFu) + r0, x1 = (pk1 & 0xFFFFu) + r1;
-            if (a0 && x0 < room) __builtin_nontemporal_store(((unsigned long long)id0 << 32) | (unsigned long long)row_s, out64 + x0);
-            if (a1 && x1 < room) __builtin_nontemporal_store(((unsigned long long)id1 << 32) | (unsigned long long)(row_s + 64u), out64 + x1);
-        }
-#else
-        for (uint32_t j0 = 0; j0 < n_mine * (uint32_t)P; j0 += 8u) {
-            uint32_t idv[8], rank[8], act = 0u;
-            static_for<8>([&](auto U) {
-                constexpr int u = decltype(U)::value;
-                const int j = (int)j0 + u;
-                const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mhi, j) << 32) | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mlo, j);
-                rank[u] = lanes_below(m);
-                idv[u] = 0u;
-                if ((m >> lane) & 1ull) {
-                    act |= 1u << u;
-                    idv[u] = GPK_FUSED_ABLATE == 4 ? rank[u] : (uint32_t)s_pool[(uint32_t)__builtin_amdgcn_readlane((int)idsb, j) + rank[u]];  // (4, tuning builds: no id gather)
-                }
-            });
-            asm volatile("" : "+v"(idv[0]), "+v"(idv[1]), "+v"(idv[2]), "+v"(idv[3]), "+v"(idv[4]), "+v"(idv[5]), "+v"(idv[6]), "+v"(idv[7]));
-            static_for<8>([&](auto U) {
-                constexpr int u = decltype(U)::value;
-                const int j = (int)j0 + u;
-                if ((act >> u) & 1u) {
-                    const unsigned long long at = base_off + (unsigned long long)((uint32_t)__builtin_amdgcn_readlane((int)outb, j) + rank[u]);
-                    if ((int64_t)at < t.capacity) {
-                        const unsigned long long v = ((unsigned long long)idv[u] << 32) | (unsigned long long)((uint32_t)__builtin_amdgcn_readlane((int)rowb, j) + (uint32_t)lane);
-                        if (GPK_FUSED_ABLATE == 3)  // (tuning builds only: everything but the store)
-                            asm volatile("" ::"v"(v), "v"(at));
-                        else if (GPK_LH_NT)
-                            __builtin_nontemporal_store(v, reinterpret_cast<unsigned long long*>(t.pairs + at));
-                        else
-                            *reinterpret_cast<unsigned long long*>(t.pairs + at) = v;
-                    }
-                }
-            });
-        }
-#endif
-    }
-    FUSED_STAMP(14);
-    // the tiles that are decided again, storing at their final offsets (a row in several geometries; the pool was full)
-    for (uint32_t et = (uint32_t)wave; et < nt; et += (uint32_t)W) {
-        if (s_tstart[et] != 0xFFFFFFFFu) continue;
-        const unsigned long long my_off = base_off + (unsigned long long)s_texcl[et];
-        const int64_t tile = (int64_t)T0 + et;
-        const int64_t room = t.capacity - (int64_t)my_off;
-        uint2* const out = t.pairs + my_off;
-        const uint32_t out_cap = room <= 0 ? 0u : (room > (int64_t)0xFFFFFFFFll ? 0xFFFFFFFFu : (uint32_t)room);
-        uint32_t run = 0u;
-        PointRegs<P> pr;
-        LdsHits lh{};
-        lh.rowbase = s_rowbase;
-        if (tile < (int64_t)h.n_full_tiles)
-            chain_tile<P, true, true, true, false, true>(h, s_mask, s_rec0, s_items[wave], tile, lane, out, out_cap, &run, pr, (int64_t)-1, lh);
-        else
-            chain_tile<P, true, false, true, false, true>(h, s_mask, s_rec0, s_items[wave], tile, lane, out, out_cap, &run, pr, (int64_t)-1, lh);
-        if (t.left_base) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            for (uint32_t i = (uint32_t)lane; i < run && i < out_cap; i += 64u) out[i].x += t.left_base;
-        }
-    }
-    FUSED_STAMP(12);
+    if (h.pts_validity == nullptr && (tile + 1) * (int64_t)(64 * CHAIN_PPT) <= h.n_points)  // (wave-uniform)
+        chain_tile<CHAIN_PPT, true>(h, s_items[threadIdx.x >> 6], tile, lane);
+    else
+        chain_tile<CHAIN_PPT, false>(h, s_items[threadIdx.x >> 6], tile, lane);
 }
 
 // pip_write: turns the per-point codes into the sorted (l, r) pair list.  Reads 4 bytes per point, writes 8
@@ -3017,11 +1581,7 @@ __global__ __launch_bounds__(WR_BLOCK) void pip_write_kernel(DevGeo pts, DevGeo 
 }
 
 // ---- join statistics (bench.py's edge_tests/s; off unless enabled) ---------------------------------------------------
-#ifdef GPK_TILE_TRACE
-constexpr size_t JOIN_STATS_WORDS = 8 + 8 * 8000;  // + the stage stamps of up to 8000 sampled tiles
-#else
-constexpr size_t JOIN_STATS_WORDS = 4;
-#endif
+constexpr size_t JOIN_STATS_WORDS = 8 + 8 * 8000;  // + the stage stamps a GPK_TILE_TRACE build of gpk_pipflow.hip leaves (512 KB, only when statistics are on)
 static unsigned long long* g_join_stats = nullptr;  // device: {queued (point, part) pairs, slab edges walked by the exact phase, 0, 0}
 static bool g_join_stats_on = false;
 static unsigned long long* join_stats_buffer() { return g_join_stats_on ? g_join_stats : nullptr; }
@@ -3476,16 +2036,13 @@ static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, co
 // The epoch words of the fused point joins: one buffer per device (zeroed when created; a launch's tag is never 0), a process-wide
 // launch counter, and an event that keeps launches from DIFFERENT streams apart — they share the words, and two such launches
 // running side by side could each hold compute units the other's lower-numbered work-groups still wait for.
-// Layout: n total words | the `lost` word of pip_tile_chunked_kernel | the ticket counter of pip_tile_fused_kernel | FUSED_COUNTERS
-// chunk counters — launch number i counts in word i % FUSED_COUNTERS and zeroes word (i + FUSED_COUNTERS / 2) % FUSED_COUNTERS for
-// the launch that will use it (launches on one device run one after the other): no counter is ever zeroed from the host.
+// Layout: n total words (one per work-group) | the `lost` word | the ticket counter (it only ever grows: the host knows where a
+// launch's numbers begin).
 static std::mutex g_fused_mu;
-constexpr int FUSED_COUNTERS = 64;
 struct FusedDev {
     unsigned long long* slots = nullptr;
     unsigned long long tickets = 0;       // what the ticket counter holds once every launch queued so far has started its work-groups
     unsigned long long era = 0;           // launch counter >> 24 when the words were last cleared
-    unsigned long long launches = 0;      // chunked launches so far (which counter word is next)
     int n = 0;
     hipEvent_t done = nullptr;
     hipStream_t last = nullptr;
@@ -3494,10 +2051,10 @@ struct FusedDev {
 static FusedDev g_fused[16];
 static unsigned long long g_fused_epoch = 0;
 struct FusedWords {
-    unsigned long long *slots, *ticket, *lost, *counter, *counter_zero;
+    unsigned long long *slots, *ticket, *lost;
     unsigned long long epoch, ticket_base;
 };
-// n_words: epoch words the launch needs; wgs: tickets it will draw (pip_tile_fused_kernel; 0 for the chunked kernel)
+// n_words: epoch words the launch needs; wgs: tickets it will draw
 static int32_t fused_launch_begin(hipStream_t s, int64_t n_words, int wgs, FusedWords* out) {
     int dev = 0;
     GPK_HIP(hipGetDevice(&dev));
@@ -3516,14 +2073,13 @@ static int32_t fused_launch_begin(hipStream_t s, int64_t n_words, int wgs, Fused
             f.slots = nullptr;
         }
         const int want = n_words < 4096 ? 4096 : (int)n_words;
-        const size_t bytes = sizeof(unsigned long long) * (size_t)(want + 2 + FUSED_COUNTERS);
+        const size_t bytes = sizeof(unsigned long long) * (size_t)(want + 2);
         hipError_t e = device_malloc((void**)&f.slots, bytes);
         if (e != hipSuccess) return bail(e);
         e = hipMemset(f.slots, 0, bytes);
         if (e != hipSuccess) return bail(e);
         f.n = want;
         f.tickets = 0;
-        f.launches = 0;
         f.era = g_fused_epoch >> (64 - FUSED_TOTAL_BITS);
     }
     if (!f.done) {
@@ -3554,10 +2110,6 @@ static int32_t fused_launch_begin(hipStream_t s, int64_t n_words, int wgs, Fused
     out->ticket = f.slots + f.n + 1;
     out->ticket_base = f.tickets;
     f.tickets += (unsigned long long)wgs;
-    unsigned long long* const counters = f.slots + f.n + 2;
-    out->counter = counters + (f.launches % FUSED_COUNTERS);
-    out->counter_zero = counters + ((f.launches + FUSED_COUNTERS / 2) % FUSED_COUNTERS);
-    if (wgs == 0) ++f.launches;
     return GPK_OK;
 }
 static void fused_launch_end(hipStream_t s, bool launched) {
@@ -3584,10 +2136,10 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         return e && *e && *e != '0';
     }();
     const bool lean = right_index->pip.R > 0 && right_index->pip_lean && !no_lean;
-    // an index with chains (ChainAux, gpk_index.h) is served by the chain kernels only: its records carry chain positions where
-    // the queue kernel expects slab ranges.  GPK_NO_ROUTE=1: A/B runs without the LDS routing image.
-    // GPK_TILE_KERNEL=chain: A/B runs of the chain kernel on an index that has the LDS routing image
-    static const bool no_route = [] {
+    // an index with chains (gpk_index.h) is served by the chain kernel or — with an LDS routing image — by the one-launch join of
+    // gpk_pipflow.hip: its records carry chain words where the queue kernels expect slab ranges.
+    // GPK_TILE_KERNEL=chain: A/B runs of the chain kernel + writer on an index that has the image
+    static const bool no_flow = [] {
         const char* e = getenv("GPK_TILE_KERNEL");
         return e && !strcmp(e, "chain");
     }();
@@ -3596,15 +2148,14 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
     PipView pvj = right_index->pip;
     pvj.slab_xy = right->d.xy;
     const bool chain = right_index->pip.R > 0 && (GPK_HALF_CHAINS ? right_index->pip.chain_xy != nullptr : right_index->pip.sub_aux != nullptr);
-    const bool route = chain && !no_route && right_index->pip.route != nullptr && right_index->pip.R <= PIP_ROUTE_RMAX;
-    // GPK_TILE_KERNEL=route: A/B runs of the round-3 pair (routed tile kernel + writer) instead of the fused launch
-    static const bool no_fused = [] {
-        const char* e = getenv("GPK_TILE_KERNEL");
-        return e && !strcmp(e, "route");
-    }();
-    const bool fused = route && !no_fused && n < (int64_t)0xFFFFFFFFll;
     const bool one_per_lane = !chain && !lean && right_index->pip.R > 0 && right_index->pip_list_heavy;  // (pip_tile_kernel<., ., 1>)
-    const int tile_points = chain ? 64 * (fused ? FUSED_PPT : (route ? ROUTE_PPT : CHAIN_PPT)) : (lean ? LEAN_TILE : (one_per_lane ? PIP_BLOCK : PIP_TILE));
+    // `flow` (gpk_pipflow.hip, round 6): ONE launch — optimistic hits in a global pool, dense exact passes, dense emission, tiles of
+    // 64 .. 512 rows by the column's length — for every chain index with a routing image, up to 4 M geometries and 201 M left rows
+    const int flow_p = GPK_HALF_CHAINS && chain && !no_flow && right_index->pip.route != nullptr && right_index->pip.R <= PIP_ROUTE_RMAX
+                           ? pip_flow_points_per_lane(n, right->d.n_geoms, right_index->pip.R, cu_count())
+                           : 0;
+    const bool flow = flow_p > 0;
+    const int tile_points = flow ? 64 * flow_p : (chain ? 64 * CHAIN_PPT : (lean ? LEAN_TILE : (one_per_lane ? PIP_BLOCK : PIP_TILE)));
     const int64_t n_blocks = (n + tile_points - 1) / tile_points;
     const bool want_pairs = pair_capacity > 0;
     const size_t counts_bytes = sizeof(uint32_t) * (size_t)n;
@@ -3613,39 +2164,14 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
     const int64_t n_wblocks = (n + PIP_WTILE - 1) / PIP_WTILE;
     // words in the multi-hit pool (a chain launch has no multi-hit rows in it: a rare row with several hits is CODE_MULTI)
     const uint32_t multi_cap = chain ? 1024u : (uint32_t)(n < (int64_t)0x18000000 ? 2 * n + 1024 : (int64_t)0x30000000);
-    // the fused kernel's second form keeps the hits in LDS (no staging slots): geometry ids must fit 16 bits and a wave own at most
-    // FUSED_LH_TILES tiles.  GPK_FUSED_LDS=0: the staging form (A/B runs)
-    static const bool no_lds_hits = [] {
-        const char* e = getenv("GPK_FUSED_LDS");
-        return e && *e == '0';
-    }();
-    int64_t fused_wgs = (int64_t)cu_count();
+    int64_t flow_wgs = (int64_t)cu_count();  // persistent work-groups, one per CU (the routing image takes most of a CU's LDS)
     {
-        const int64_t want = (n_blocks + ROUTE_BLOCK / 64 - 1) / (ROUTE_BLOCK / 64);
-        if (fused_wgs > want) fused_wgs = want;
-        if (fused_wgs < 1) fused_wgs = 1;
+        const int64_t want = (n_blocks + 15) / 16;  // (16 waves a work-group, a tile a wave)
+        if (flow_wgs > want) flow_wgs = want;
+        if (flow_wgs < 1) flow_wgs = 1;
     }
-    // round 5: the chunked form (hits of two tiles per wave in LDS, pairs written while the next chunk is decided) serves every column
-    // whose right side has 16-bit geometry ids — no limit on the left column's length.  GPK_FUSED_FORM=wave: the round-4 forms (A/B runs)
-    static const bool no_chunked = [] {
-        const char* e = getenv("GPK_FUSED_FORM");
-        return e && !strcmp(e, "wave");
-    }();
-    const int64_t n_chunks = (n_blocks + ROUTE_BLOCK / 64 - 1) / (ROUTE_BLOCK / 64);
-    const int64_t chunk_wgs = n_chunks < (int64_t)cu_count() ? (n_chunks < 1 ? 1 : n_chunks) : (int64_t)cu_count();
-    // Which form (all bit-identical): `pool` — tiles drawn inside the work-group, hits in a work-group pool — when a work-group's range
-    // is at most POOL_TILES tiles (10.49 M rows on 256 CUs); `chunked` beyond that; GPK_FUSED_FORM=wave | chunked | pool forces one (A/B
-    // runs; wave = the round-4 LDS-hits form), GPK_FUSED_LDS=0 the staging form
-    static const char* const form = getenv("GPK_FUSED_FORM");
-    const bool lh_ok = fused && !no_lds_hits && right->d.n_geoms <= 65535 && right_index->pip.R >= 32;
-    const bool fits = (n_blocks + fused_wgs - 1) / fused_wgs <= (int64_t)POOL_TILES;
-    const bool want_wave = form && !strcmp(form, "wave"), want_chunked = form && !strcmp(form, "chunked");
-    (void)no_chunked;
-    const bool chunked = lh_ok && n_chunks >= 1 && (want_chunked || (!fits && !want_wave));
-    const bool pool = lh_ok && !chunked && fits && !want_wave;
-    const bool lds_hits = lh_ok && !chunked && !pool &&
-                          (n_blocks + fused_wgs * (ROUTE_BLOCK / 64) - 1) / (fused_wgs * (ROUTE_BLOCK / 64)) <= FUSED_LH_TILES;
-    const size_t stage_bytes = fused && want_pairs && !lds_hits && !chunked && !pool ? sizeof(uint2) * (size_t)n_blocks * (size_t)tile_points : 0;
+    const bool fused = flow;  // (no result codes, no tile totals, no writer launch)
+    const size_t stage_bytes = flow ? pip_flow_pool_bytes(n) : 0;
     size_t need = align256(fused ? 64 : counts_bytes + 64) /*code*/ + align256(sizeof(unsigned long long) * (size_t)(n_blocks + n_super + 3)) +
                   align256(sizeof(uint32_t) * (size_t)multi_cap) + align256(sizeof(ChainCold)) + align256(stage_bytes) + 1024;
     if (host_out && out_counts) need += align256(counts_bytes);
@@ -3728,43 +2254,15 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         hot.super_tot = stot;
         hot.stats = stats;
         hot.cold = cold;
-        hot.stage = stage;
-        hot.n_full_tiles = left->d.validity ? 0 : (int32_t)(n / tile_points);
+        hot.stage = nullptr;
+        hot.pool = reinterpret_cast<uint32_t*>(stage);
+        hot.n_full_tiles = left->d.validity ? 0 : (int32_t)(n / tile_points);  // (tiles that need no guards: whole tiles of a column without a validity bitmap)
         hot.inv_fw_s = pv.inv_fw * (double)PIP_SUB;
         hot.inv_fh_s = pv.inv_fh * (double)PIP_SUB;
         hot.sub_max = (double)(((uint32_t)PIP_SUB << hot.logR) - 1u);
     }
-    if (fused && chunked) {  // one launch: work-groups take chunks of W tiles; a chunk's pairs are written while the next is decided
-        ChunkTail tail;
-        memset(&tail, 0, sizeof tail);
-        tail.pairs = (uint2*)pairs_dev;
-        tail.capacity = pair_capacity;
-        tail.grand = grand;
-        tail.grand_host = total_out;
-        tail.left_base = left_row_base;
-        tail.n_chunks = (uint32_t)n_chunks;
-        FusedWords fw;
-        int32_t frc = fused_launch_begin(s, n_chunks, 0, &fw);
-        if (frc != GPK_OK) return frc;
-        tail.slots = fw.slots;
-        tail.epoch = fw.epoch;
-        tail.counter = fw.counter;
-        tail.counter_zero = fw.counter_zero;
-        tail.lost = fw.lost;
-        const int64_t wgs = chunk_wgs;
-        frc = [&]() -> int32_t {
-            GPK_LAUNCH("gpk_pip_tile", pip_tile_chunked_kernel, dim3((unsigned)wgs), dim3(ROUTE_BLOCK), 0, s, hot, tail);
-            return GPK_OK;
-        }();
-        fused_launch_end(s, frc == GPK_OK);
-        if (frc != GPK_OK) return frc;
-        *counts_dev_out = counts_dev;
-        *pairs_dev_out = pairs_dev;
-        *grand_out = grand;
-        return GPK_OK;
-    }
-    if (fused) {  // one launch: persistent work-groups (one per CU), contiguous tiles per wave, pairs written by the same kernel
-        const int64_t wgs = fused_wgs;
+    if (flow) {  // one launch: persistent work-groups (one per CU) draw tiles, rank optimistic hits, and write the pairs themselves
+        const int64_t wgs = flow_wgs;
         FusedTail tail;
         memset(&tail, 0, sizeof tail);
         tail.pairs = (uint2*)pairs_dev;
@@ -3780,15 +2278,7 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         tail.ticket = fw.ticket;
         tail.ticket_base = fw.ticket_base;
         tail.lost = fw.lost;
-        frc = [&]() -> int32_t {
-            if (pool)
-                GPK_LAUNCH("gpk_pip_tile", pip_tile_pool_kernel, dim3((unsigned)wgs), dim3(ROUTE_BLOCK), 0, s, hot, tail);
-            else if (lds_hits)
-                GPK_LAUNCH("gpk_pip_tile", pip_tile_fused_kernel<true>, dim3((unsigned)wgs), dim3(ROUTE_BLOCK), 0, s, hot, tail);
-            else
-                GPK_LAUNCH("gpk_pip_tile", pip_tile_fused_kernel<false>, dim3((unsigned)wgs), dim3(ROUTE_BLOCK), 0, s, hot, tail);
-            return GPK_OK;
-        }();
+        frc = launch_pip_flow(hot, tail, (int)wgs, flow_p, s);
         fused_launch_end(s, frc == GPK_OK);
         if (frc != GPK_OK) return frc;
         *counts_dev_out = counts_dev;
@@ -3796,13 +2286,7 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         *grand_out = grand;
         return GPK_OK;
     }
-    if (chain && route) {  // persistent work-groups, one per CU
-        const int tiles_per_wg = ROUTE_BLOCK / 64;
-        int64_t wgs = (int64_t)cu_count();
-        const int64_t want = (n_blocks + tiles_per_wg - 1) / tiles_per_wg;
-        if (wgs > want) wgs = want;
-        J_LAUNCH("gpk_pip_tile", pip_tile_route_kernel, dim3((unsigned)wgs), dim3(ROUTE_BLOCK), 0, s, hot);
-    } else if (chain)
+    if (chain)
         J_LAUNCH("gpk_pip_tile", pip_tile_chain_kernel, dim3((unsigned)((n_blocks + PIP_BLOCK / 64 - 1) / (PIP_BLOCK / 64))), dim3(PIP_BLOCK), 0, s, hot);
     else if (lean)
         J_LAUNCH("gpk_pip_tile", pip_tile_lean_kernel, dim3((unsigned)n_blocks), dim3(PIP_BLOCK), 0, s, left->d, right->d, right_index->v, pvj,
@@ -3962,15 +2446,13 @@ int32_t gpk_join_stats(int64_t out[4], int32_t reset) {
     return GPK_OK;
 }
 
-#ifdef GPK_TILE_TRACE
-int32_t gpk_join_trace(unsigned long long* out, int64_t n_words) {  // diagnosis builds only: the raw stage stamps
+int32_t gpk_join_trace(unsigned long long* out, int64_t n_words) {  // the raw stage stamps of a GPK_TILE_TRACE build of gpk_pipflow.hip (zeros otherwise)
     if (!g_join_stats || !out) return GPK_ERR_INVALID_ARGUMENT;
     GPK_HIP(hipDeviceSynchronize());
     GPK_HIP(hipMemcpy(out, g_join_stats + 8, sizeof(unsigned long long) * (size_t)(n_words < (int64_t)(JOIN_STATS_WORDS - 8) ? n_words : (int64_t)(JOIN_STATS_WORDS - 8)), hipMemcpyDeviceToHost));
     GPK_HIP(hipMemset(g_join_stats, 0, JOIN_STATS_WORDS * sizeof(unsigned long long)));
     return GPK_OK;
 }
-#endif
 
 int32_t gpk_index_query_envelope(const gpk_index* idx, const double* boxes4, int64_t n_boxes, int32_t mode, uint32_t* out_counts,
                                  uint32_t* out_pairs, int64_t pair_capacity, int64_t* n_pairs, int32_t space, void* stream) {

@@ -1,4 +1,4 @@
-"""GPU parity of the chain tile kernels (gpk_join.hip: pip_tile_chain_kernel, pip_tile_route_kernel — rare rows settled inside them)
+"""GPU parity of the chain kernels (gpk_join.hip: pip_tile_chain_kernel + writer; gpk_pipflow.hip: pip_flow_kernel, the one-launch join — rare rows settled inside them)
 through the C ABI vs the CPU oracle, bit-exact on counts and sorted (l, r) pairs (`Contains<Point>`, spatial_index.rs:91-96).
 
 Right sides here are DISJOINT polygons — what makes an index "lean" and gives it local chains — shaped to reach every arm:
@@ -152,7 +152,7 @@ def test_two_boundary_runs_in_one_subcell(gpk, oracle):
     slit = np.array([[50.0 * i + 25.0, 50.0 * j + 5.0 + t] for i in range(20) for j in range(20) for t in (3.0, 7.3, 12.9, 24.0, 29.9995, 30.0005)])
     pts = np.concatenate([around(slit, 0.004, 30, 6), synth.uniform_points(20_000, seed=10).xy])
     d, exact, deferred, _ = check(oracle, GeoArrowArray.from_points(pts), polys, want={"lean": True, "chains": True})
-    assert deferred > 500
+    assert exact + deferred > 500  # (decided by half-cell chains, or by the walk: where the arc is too long, and where a tile lists more rows than its wave's list holds)
 
 
 def test_parts_with_holes(gpk, oracle):
@@ -211,9 +211,9 @@ def test_million_rows_against_the_oracle_counts(gpk, oracle):
     check(oracle, pts, polys, "contains", want={"R": 512, "chains": True, "route": True})
 
 
-@pytest.mark.parametrize("kernel", ["chain", "route"])
+@pytest.mark.parametrize("kernel", ["chain", "flow"])
 def test_every_tile_kernel_on_the_same_index(gpk, oracle, kernel):
-    """GPK_TILE_KERNEL is read once per process: each of the two kernels gets its own interpreter, same inputs, same oracle answers"""
+    """GPK_TILE_KERNEL is read once per process (chain: tile kernel + writer instead of the one-launch join): each kernel gets its own interpreter, same inputs, same oracle answers"""
     import os, subprocess, sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

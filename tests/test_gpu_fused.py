@@ -1,18 +1,19 @@
-"""GPU parity of the one-launch point join (gpk_join.hip) through the C ABI vs the CPU oracle, bit-exact on counts, pairs and totals
-(`Contains<Point>`, spatial_index.rs:91-96; sorted pairs = the two index vectors of spatial_index.rs:145-159).  Tiles decided, hits
-ranked and the sorted (l, r) pair list written by the same persistent work-groups, in one of four forms that must all answer alike:
-  pool     (round 5, the default up to 10.49 M rows on 256 CUs) a work-group's waves draw tiles from an LDS counter, hits in one pool of
-           16-bit geometry ids per work-group, rare rows settled before the tile's hits are ranked — pip_tile_pool_kernel;
-  chunked  (round 5, longer columns) chunks of 16 tiles from an agent-scope counter, a chunk's pairs written while the next is decided,
-           two tiles of hits per wave in LDS whatever the column's length — pip_tile_chunked_kernel;
-  wave     (round 4, GPK_FUSED_FORM=wave) a contiguous run of tiles per wave, its hits in the wave's own LDS list — pip_tile_fused_kernel<true>;
-  staging  (GPK_FUSED_LDS=0, or more than 65,535 geometries) hits parked in the pair slots of the wave's own rows.
-GPK_FUSED_FORM / GPK_FUSED_LDS are read once per process: the forms other than the default run in their own interpreter.
+"""GPU parity of the one-launch point join (gpk_pipflow.hip: pip_flow_kernel) through the C ABI vs the CPU oracle, bit-exact on counts,
+pairs and totals (`Contains<Point>`, spatial_index.rs:91-96; sorted pairs = the two index vectors of spatial_index.rs:145-159).  Tiles
+decided, hits ranked and the sorted (l, r) pair list written by the same persistent work-groups:
+  * a row with a polygon to be in is a hit at once — a 4-byte entry in its tile's slots of a global pool, count 1 — and `test` points wait
+    on their wave's LDS list for a dense pass of the exact step; a failed test kills the entry, the count, and one of the tile's total;
+  * tiles of 64 * P rows, P = 8 for long columns, 4 / 2 / 1 for short ones (GPK_FLOW_P forces one, read once per process: the forced
+    sizes run in their own interpreter);
+  * GPK_TILE_KERNEL=chain: the chain tile kernel + writer in the one-launch join's place (the same answers, its own interpreter).
+The hit forms of rounds 4 and 5 (per-wave LDS lists, staging slots, chunks, the work-group pool) were retired in round 6.
 
-What only these kernels have, and what is aimed at here: hits that wait in LDS until the work-groups before have published their totals;
-rare rows (list cells, half cells without a chain, uncertifiable orientations); rows in SEVERAL geometries (the tile is decided again,
-storing at final offsets); left_row_base; a pair buffer smaller than the total; count-only calls; launches from two streams (they
-share the epoch words); columns shorter than one tile per wave, and longer than any LDS list."""
+What only this kernel has, and what is aimed at here: entries that wait in the pool until the work-groups before have published their
+totals; rows the tables cannot settle (list cells, half cells without a chain, uncertifiable orientations: walked by the whole wave
+from the list); rows in SEVERAL geometries (one entry that carries the count, expanded at emission); tiles that list more rows than a
+wave's list holds (entries left pending, settled at the end of the tile); more than 65,535 pairs before an ordinary tile of a
+work-group; left_row_base; a pair buffer smaller than the total; count-only calls; launches from two streams (they share the epoch
+words); columns shorter than one tile per wave, and longer than a round of emission."""
 import ctypes as C
 
 import numpy as np
@@ -148,8 +149,8 @@ def test_launches_from_two_streams_and_back_to_back(gpk, oracle):
         assert np.array_equal(pr[: len(ep)].cpu().numpy().view(np.uint32), ep)
 
 
-def test_the_round_three_pair_of_kernels_still_answers_the_same(gpk, oracle):
-    """GPK_TILE_KERNEL=route (read once per process): routed tile kernel + writer on the same inputs in its own interpreter"""
+def test_the_chain_kernel_and_writer_still_answer_the_same(gpk, oracle):
+    """GPK_TILE_KERNEL=chain (read once per process): chain tile kernel + writer on the same inputs in its own interpreter"""
     import os, subprocess, sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -167,49 +168,17 @@ def test_the_round_three_pair_of_kernels_still_answers_the_same(gpk, oracle):
         "assert np.array_equal(gc, ec) and np.array_equal(gp, ep)\n"
         "print('ok', int(ec.sum()))\n"
     )
-    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, GPK_TILE_KERNEL="route"))
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, GPK_TILE_KERNEL="chain"))
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr[-3000:]
 
 
-def test_a_column_too_long_for_a_work_groups_pool_takes_the_chunked_form(gpk, oracle):
-    """more than 80 tiles per work-group (> 10.49 M points on 256 CUs): chunks of 16 tiles from a counter, 1343 chunks = 6 generations"""
+def test_a_column_of_eleven_million_rows(gpk, oracle):
+    """84 tiles per work-group: the round-5 pool form ended at 80 (10.49 M rows on 256 CUs)"""
     polys = synth.star_polygons(1000, 64)
     pts = synth.uniform_points(11_000_003, seed=77)
     ep, ec, _ = oracle.spatial_join(pts, polys, "intersects", mode=1)
     gp, gc = join_pairs(GeoSeries(pts), GeoSeries(polys), "intersects", r_index=SpatialIndex(GeoSeries(polys)))
     assert np.array_equal(gc, ec) and np.array_equal(gp, ep)
-
-
-def test_the_staging_form_on_the_same_inputs(gpk, oracle):
-    """GPK_FUSED_LDS=0 (read once per process): rows in several geometries, left_row_base, ragged tails — in its own interpreter"""
-    import os, subprocess, sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    prog = (
-        "import numpy as np, sys\n"
-        "sys.path.insert(0, 'tests')\n"
-        "from geopolars_amd import synth\n"
-        "from geopolars_amd.geoarrow import GeoArrowArray\n"
-        "from geopolars_amd.geoseries import GeoSeries\n"
-        "from geopolars_amd.spatial_index import SpatialIndex, join_pairs\n"
-        "from oracle import pyoracle\n"
-        "import test_gpu_fused as T\n"
-        "pyoracle.build()\n"
-        "polys = T._stacked(900, 37)\n"
-        "rng = np.random.default_rng(3)\n"
-        "pts = np.concatenate([synth.uniform_points(60_001, seed=4).xy, np.column_stack([rng.uniform(499.0, 505.0, 3000), rng.uniform(959.0, 965.0, 3000)])])\n"
-        "rng.shuffle(pts)\n"
-        "pts = GeoArrowArray.from_points(pts)\n"
-        "right = GeoSeries(polys); index = SpatialIndex(right)\n"
-        "ep, ec, _ = pyoracle.spatial_join(pts, polys, 'intersects', mode=0)\n"
-        "for base in (0, 123456):\n"
-        "    gp, gc = join_pairs(GeoSeries(pts), right, 'intersects', r_index=index, left_row_base=base)\n"
-        "    e = ep.copy(); e[:, 0] += base\n"
-        "    assert np.array_equal(gc, ec) and np.array_equal(gp, e)\n"
-        "print('ok', int(ec.sum()), int(ec.max()))\n"
-    )
-    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, GPK_FUSED_LDS="0"))
-    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr[-3000:]
 
 
 _FORM_PROG = (
@@ -244,12 +213,69 @@ _FORM_PROG = (
 )
 
 
-@pytest.mark.parametrize("form", ["wave", "chunked", "pool"])
-def test_every_form_of_the_fused_join_on_the_same_inputs(gpk, oracle, form):
-    """GPK_FUSED_FORM=wave | chunked | pool (read once per process) forces one form for every eligible join: rows in several geometries,
-    left_row_base, ragged tails, null and empty rows, columns around the tile / chunk boundaries — in its own interpreter"""
+@pytest.mark.parametrize("env", [{"GPK_FLOW_P": "8"}, {"GPK_FLOW_P": "4"}, {"GPK_FLOW_P": "2"}, {"GPK_FLOW_P": "1"}, {"GPK_TILE_KERNEL": "chain"}])
+def test_every_tile_size_of_the_join_on_the_same_inputs(gpk, oracle, env):
+    """GPK_FLOW_P=8 | 4 | 2 | 1 (read once per process) forces one tile size for every eligible join — by default short columns take the
+    small tiles —, GPK_TILE_KERNEL=chain the chain kernel + writer: rows in several geometries, left_row_base, ragged tails, null and
+    empty rows, columns around the tile boundaries — in its own interpreter"""
     import os, subprocess, sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", _FORM_PROG], capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, GPK_FUSED_FORM=form))
+    r = subprocess.run([sys.executable, "-c", _FORM_PROG], capture_output=True, text=True, timeout=900, cwd=root, env=dict(os.environ, **env))
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr[-3000:]
+
+
+def test_tiles_that_list_more_rows_than_a_waves_list_holds(gpk, oracle):
+    """points packed along the polygons' edges: a 512-row tile lists hundreds of `test` points, its wave's list holds 128 — the surplus
+    stays pending in the pool and is settled by the generic walk at the end of the tile (GPK_FLOW_P=8: in its own interpreter)"""
+    import os, subprocess, sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = (
+        "import numpy as np, ctypes as C\n"
+        "from geopolars_amd import synth, _abi\n"
+        "from geopolars_amd.geoarrow import GeoArrowArray\n"
+        "from geopolars_amd.geoseries import GeoSeries\n"
+        "from geopolars_amd.spatial_index import SpatialIndex, join_pairs\n"
+        "from oracle import pyoracle\n"
+        "pyoracle.build()\n"
+        "polys = synth.star_polygons(400, 24)\n"
+        "rng = np.random.default_rng(12)\n"
+        "v = polys.xy; ro = polys.ring_offsets\n"
+        "a, b = v[:-1], v[1:]; same = np.ones(len(a), dtype=bool); same[ro[1:-1] - 1] = False\n"
+        "t = rng.uniform(0, 1, (same.sum(), 12, 1))\n"
+        "on = (a[same][:, None, :] * (1 - t) + b[same][:, None, :] * t).reshape(-1, 2) + rng.normal(0, 0.02, (same.sum() * 12, 2))\n"
+        "xy = np.concatenate([on, synth.uniform_points(40_000, seed=5).xy]); rng.shuffle(xy[: len(on) // 2])\n"
+        "pts = GeoArrowArray.from_points(xy)\n"
+        "right = GeoSeries(polys); index = SpatialIndex(right)\n"
+        "assert index.describe()['route']\n"
+        "lib = _abi.lib(); st = (C.c_int64 * 4)(); lib.gpk_join_stats_enable(1); lib.gpk_join_stats(st, 1)\n"
+        "ep, ec, _ = pyoracle.spatial_join(pts, polys, 'intersects', mode=0)\n"
+        "for base in (0, 999):\n"
+        "    gp, gc = join_pairs(GeoSeries(pts), right, 'intersects', r_index=index, left_row_base=base)\n"
+        "    e = ep.copy(); e[:, 0] += base\n"
+        "    assert np.array_equal(gc, ec) and np.array_equal(gp, e)\n"
+        "lib.gpk_join_stats(st, 1)\n"
+        "assert st[2] > 1000, list(st)  # rows settled by the walk: the pending ones\n"
+        "print('ok', int(ec.sum()), list(st))\n"
+    )
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, GPK_FLOW_P="8"))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr[-3000:]
+
+
+def test_more_than_65535_pairs_before_an_ordinary_tile_of_a_work_group(gpk, oracle):
+    """spatially sorted points: a long run inside a zone of 8 stacked squares (rows in 8 geometries each: far more than 65,535 pairs within
+    one work-group's range), ordinary tiles after it.  (The round-5 pool form packed a row's pair offset within its work-group into 16
+    bits: ADVICE r5.)"""
+    polys = _stacked(900, 8, at=(500.0, 960.0), side=6.0, verts=24)
+    rng = np.random.default_rng(21)
+    zone = np.column_stack([rng.uniform(500.2, 505.8, 30_000), rng.uniform(960.2, 965.8, 30_000)])
+    rest = synth.uniform_points(1_500_000, seed=22).xy
+    rest = rest[np.lexsort((rest[:, 0], np.floor(rest[:, 1] / 8.0)))]  # rows of 8 units, x ascending within: neighbours stay neighbours
+    cut = 700_000
+    xy = np.concatenate([rest[:cut], zone, rest[cut:]])
+    ep, ec, _ = oracle.spatial_join(GeoArrowArray.from_points(xy), polys, "intersects", mode=1)
+    right = GeoSeries(polys)
+    gp, gc = join_pairs(GeoSeries(GeoArrowArray.from_points(xy)), right, "intersects", r_index=SpatialIndex(right))
+    assert int(ec[cut : cut + len(zone)].sum()) == 8 * len(zone) > 3 * 65536
+    assert np.array_equal(gc, ec) and np.array_equal(gp, ep)

@@ -17,6 +17,7 @@ ap.add_argument("--verts", type=int, default=64)
 ap.add_argument("--points", type=int, default=10_000_000)
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--tag", default="")
+ap.add_argument("--frac", type=float, default=1.0, help="points uniform over this fraction of the domain's side (locality experiment: the index lines touched shrink with its square)")
 a = ap.parse_args()
 lib = _abi.lib()
 dev = torch.device("cuda", 0)
@@ -26,7 +27,7 @@ polys = DeviceGeoArray.upload(synth.star_polygons(a.polys, a.verts), stream=stre
 index = SpatialIndex.from_device(polys, stream=stream)
 sets = []
 for r in range(3):
-    xy = torch.from_numpy(synth.uniform_points(n, seed=77 + r).xy).to(dev)
+    xy = torch.from_numpy(synth.uniform_points(n, seed=77 + r, domain=synth.DOMAIN * a.frac).xy).to(dev)
     sets.append((DeviceGeoArray.from_device_buffers(_abi.GEOM_POINT, xy, stream=stream), torch.empty(n, dtype=torch.int32, device=dev),
                  torch.empty((n, 2), dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)))
 def step(i):
