@@ -248,6 +248,90 @@ class Ctx:
             self.dist.destroy_process_group()
 
 
+def open_comm_guarded(ctx: "Ctx", seconds: float):
+    """The library's own communicator (gpk_comm_init + one tiny gpk_allgatherv_rows_f64: the first collective is where a broken
+    fabric shows) opened with a BOUNDED wait, and an agreement of all ranks over the torch group on whether everybody got it.
+    -> (Comm or None, note): None = every rank falls back to geopolars_amd.dist's torch.distributed exchange (the one the gloo
+    world-2 tests cover); a rank still stuck inside RCCL's initialisation is left behind on its own thread."""
+    import threading
+
+    from geopolars_amd.dist import Comm
+
+    torch = ctx.torch
+    box = {}
+
+    def work():
+        try:
+            c = Comm.from_torch(ctx.dev)
+            probe = torch.full((1, 1), float(ctx.rank), dtype=torch.float64, device=ctx.dev)
+            got = c.all_gather_rows(probe)
+            torch.cuda.synchronize()
+            if got.shape[0] != ctx.world or [float(v) for v in got.flatten().tolist()] != [float(r) for r in range(ctx.world)]:
+                raise RuntimeError(f"gpk_allgatherv_rows_f64 probe returned {got.flatten().tolist()}")
+            box["comm"] = c
+        except BaseException as e:  # noqa: BLE001 (reported, and the run goes on without the communicator)
+            box["err"] = f"{type(e).__name__}: {e}"
+
+    if os.environ.get("GPK_BENCH_FAIL_COMM"):  # test hook: behave as if the library's communicator never came up
+        box["err"] = "GPK_BENCH_FAIL_COMM set"
+    else:
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        th.join(seconds)
+        if th.is_alive():
+            box["err"] = f"gpk_comm_init / the first collective did not return within {seconds:.0f} s"
+    ok = torch.tensor([1 if "comm" in box else 0], dtype=torch.int32, device=ctx.dev)
+    ctx.dist.all_reduce(ok, op=ctx.dist.ReduceOp.MIN)
+    if int(ok.item()) == 1:
+        return box["comm"], ""
+    note = box.get("err", "another rank could not open the library's communicator")
+    print(f"bench.py rank {ctx.rank}: C-ABI exchange unavailable ({note}): falling back to torch.distributed", file=sys.stderr)
+    return None, note
+
+
+def _marker_dir() -> str:
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), f"gpk_bench_{os.environ.get('MASTER_PORT', 'single')}_{os.environ.get('TORCHELASTIC_RUN_ID', os.getppid())}")
+
+
+def error_line(args, message: str) -> dict:
+    """what rank 0 prints when the run did not finish: the contract's keys with no value, and why"""
+    return {"metric": {"c2": "predicate evals/sec (10M pts x 1k polys point-in-polygon)", "c3": "point-to-linestring distance evaluations/sec",
+                       "c4": "polygon x polygon intersects() join pairs/sec", "c5": "within()+area() rows/sec"}.get(args.config, args.config),
+            "value": None, "unit": None, "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+            "higher_is_better": True, "scaling": None, "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": args.config}, "error": message}
+
+
+def start_watchdog(args, rank: int, seconds: float) -> None:
+    """A daemon thread per rank: when the run outlives `seconds`, or ANOTHER rank leaves an error marker (it died: the survivors would wait
+    in a collective for ever), rank 0 prints the JSON line with `error` and every rank exits — the caller always gets a line."""
+    import threading
+
+    d = _marker_dir()
+    os.makedirs(d, exist_ok=True)
+    t_end = time.monotonic() + seconds
+
+    def watch():
+        while True:
+            time.sleep(1.0)
+            why = None
+            if time.monotonic() > t_end:
+                why = f"watchdog: the run did not finish within {seconds:.0f} s"
+            else:
+                try:
+                    for fn in os.listdir(d):
+                        if fn.endswith(".err") and fn != f"rank{rank}.err":
+                            why = f"{fn[:-4]} failed: " + open(os.path.join(d, fn)).read()[:400]
+                            break
+                except OSError:
+                    pass
+            if why:
+                if rank == 0:
+                    emit_line(error_line(args, why))
+                os._exit(4)
+
+    threading.Thread(target=watch, daemon=True).start()
+
+
 def emit_line(line: dict) -> None:
     """Rank 0's ONE JSON line, on a line of its own: RCCL writes its warnings to the C stdout buffer, which is flushed in
     4 KiB pieces that end mid-line — so the C buffer is flushed first and the JSON starts after a newline."""
@@ -789,7 +873,8 @@ def run_c4(ctx: Ctx) -> None:
         shard_arr = right_shard.to_device_geoarray(stream)
         box = torch.empty((rhi - rlo, 4), dtype=torch.float64, device=dev)
         _abi.check(lib.gpk_bounds(shard_arr.handle, box.data_ptr(), _abi.MEM_DEVICE, stream))
-        comm = Comm.from_torch(dev) if args.comm == "abi" else None  # (the unique id travels over the torch group: any side channel would do)
+        # (the unique id travels over the torch group: any side channel would do; bounded wait + agreed fallback: open_comm_guarded)
+        comm, comm_note = open_comm_guarded(ctx, args.comm_timeout) if args.comm == "abi" else (None, "")
         ctx.barrier()
         t0 = time.perf_counter()
         stats = {}
@@ -803,7 +888,7 @@ def run_c4(ctx: Ctx) -> None:
             right = right_buf.to_device_geoarray(stream)
         ctx.barrier()
         exchange = {"ms": ctx.max_over_ranks(time.perf_counter() - t0) * 1e3, "bytes": stats["gathered_bytes"] + leaves.numel() * 8,
-                    "through": "C ABI (gpk_allgatherv_*)" if comm is not None else "torch.distributed (geopolars_amd.dist)"}
+                    "through": "C ABI (gpk_allgatherv_*)" if comm is not None else "torch.distributed (geopolars_amd.dist)" + (f" — fallback: {comm_note}" if comm_note else "")}
     else:
         right, leaves = right_shard.to_device_geoarray(stream), None
     left = dev_array(torch, left_host, dev, stream)
@@ -1205,6 +1290,8 @@ def main() -> None:
     ap.add_argument("--no-weak", action="store_true", help="c2 at N > 1: skip the weak-scaled measurement (10M points per GPU) reported beside the strong-scaled headline")
     ap.add_argument("--no-default-shape", action="store_true", help="c2 at N = 1: skip the r_index = None measurement (index built inside every call)")
     ap.add_argument("--comm", choices=["torch", "abi"], default="abi", help="c4: the right-side exchange through torch.distributed (geopolars_amd.dist) or through the library's own RCCL entry points (gpk_allgatherv_*)")
+    ap.add_argument("--comm-timeout", type=float, default=120.0, help="c4: seconds to wait for the library's communicator (gpk_comm_init + a probe collective) before every rank falls back to --comm torch")
+    ap.add_argument("--watchdog", type=float, default=3000.0, help="seconds after which rank 0 prints the JSON line with an `error` field and every rank exits (also when another rank has died)")
     ap.add_argument("--spawn", action="store_true", help="launch the rank(s) under torch.distributed.run even for --gpus 1 (what --gpus N > 1 does by itself when there is no launcher)")
     args = ap.parse_args()
     if args.steps is None:
@@ -1213,8 +1300,30 @@ def main() -> None:
         args.points = {"c2": 10_000_000, "c3": 10_000_000, "c4": 0, "c5": 6_250_000}[args.config]
     if (args.gpus > 1 or args.spawn) and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
-    ctx = Ctx(args)
-    {"c2": run_c2, "c3": run_c3, "c4": run_c4, "c5": run_c5}[args.config](ctx)
+    rank = int(os.environ.get("RANK", "0"))
+    start_watchdog(args, rank, args.watchdog)
+    try:
+        if os.environ.get("GPK_BENCH_RAISE"):  # test hooks (tests/test_host_cpu.py): a rank that dies / a run that never ends
+            raise RuntimeError(os.environ["GPK_BENCH_RAISE"])
+        if os.environ.get("GPK_BENCH_HANG"):
+            time.sleep(1e6)
+        ctx = Ctx(args)
+        {"c2": run_c2, "c3": run_c3, "c4": run_c4, "c5": run_c5}[args.config](ctx)
+    except SystemExit:
+        raise
+    except BaseException as e:  # noqa: BLE001 — whatever happened, rank 0 prints ONE JSON line that says so
+        import traceback
+
+        traceback.print_exc()
+        msg = f"rank {rank}: {type(e).__name__}: {e}"
+        try:
+            with open(os.path.join(_marker_dir(), f"rank{rank}.err"), "w") as f:
+                f.write(msg)
+        except OSError:
+            pass
+        if rank == 0:
+            emit_line(error_line(args, msg))
+        os._exit(5)  # (not sys.exit: a rank stuck inside a collective on another thread must not keep the process alive)
 
 
 if __name__ == "__main__":

@@ -30,6 +30,7 @@ GEOM_POLYGON = 3
 GEOM_MULTIPOINT = 4
 GEOM_MULTILINESTRING = 5
 GEOM_MULTIPOLYGON = 6
+ARROW_WKB, ARROW_INTERLEAVED, ARROW_STRUCT = 0, 1, 2  # gpk_geoarray_to_arrow layouts
 
 MEM_HOST = 0
 MEM_DEVICE = 1
@@ -119,6 +120,7 @@ _PROTOS = {
     "gpk_device_info": (C.c_int32, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int32)]),
     "gpk_geoarray_upload": (C.c_int32, [C.POINTER(GeoArrowDesc), _VP, C.POINTER(_VP)]),
     "gpk_geoarray_from_arrow": (C.c_int32, [_VP, _VP, C.c_int32, _VP, C.POINTER(_VP), C.POINTER(C.c_int32)]),
+    "gpk_geoarray_to_arrow": (C.c_int32, [_VP, C.c_int32, _VP, _VP, _VP]),
     "gpk_geoarray_free": (C.c_int32, [_VP]),
     "gpk_geoarray_nbytes": (C.c_int32, [_VP, C.POINTER(C.c_int64)]),
     "gpk_wkb_decode": (C.c_int32, [_VP, _VP, C.c_int64, _VP, C.POINTER(C.c_int64), _VP, _VP, _VP, _VP]),
@@ -169,6 +171,9 @@ _PROTOS = {
     "gpk_comm_unique_id": (C.c_int32, [C.POINTER(C.c_uint8)]),
     "gpk_comm_init": (C.c_int32, [C.c_int32, C.c_int32, C.POINTER(C.c_uint8), C.POINTER(_VP)]),
     "gpk_comm_free": (C.c_int32, [_VP]),
+    "gpk_comm_mock_world": (C.c_int32, [C.c_int32, C.POINTER(_VP)]),
+    "gpk_comm_init_mock": (C.c_int32, [C.c_int32, _VP, C.POINTER(_VP)]),
+    "gpk_comm_mock_world_free": (C.c_int32, [_VP]),
     "gpk_comm_info": (C.c_int32, [_VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gpk_allgatherv_geoarray": (C.c_int32, [_VP, _VP, _VP, C.POINTER(_VP), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "gpk_geoarray_concat": (C.c_int32, [C.POINTER(_VP), C.c_int32, _VP, C.POINTER(_VP), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -12,6 +12,7 @@
 // the copy the process already has when there is one (a PyTorch process brings its own librccl.so).
 #include <dlfcn.h>
 
+#include <condition_variable>
 #include <mutex>
 #include <vector>
 
@@ -123,6 +124,7 @@ __global__ void bytes_to_bitmap_kernel(const uint8_t* __restrict__ bytes, int64_
 
 struct gpk_comm {
     ncclComm_t comm;
+    const gpk::Rccl* table;  // the transport: RCCL's entry points (rccl()), or the in-process one of gpk_comm_init_mock
     int32_t rank, world, device;
     // device scratch of the collectives' small words (header rows of every rank + this rank's own row; the agreement words), reserved
     // when the communicator is created: nothing is allocated between the first collective of an exchange and its last, so a rank
@@ -131,6 +133,75 @@ struct gpk_comm {
 };
 
 namespace gpk {
+
+// ---- an in-process transport (tests): `world` THREADS of one process on one device stand in for the ranks -------------------------
+// The collectives keep RCCL's signatures, so gpk_allgatherv_* run unchanged over it — header all-gather, the agreement, the grouped
+// broadcasts, placement, rebase and validity repack — with W ranks that really are apart in time (each on its own thread and stream).
+// Every call is a rendezvous: the rank makes what it queued visible (a stream sync), posts its pointer, all ranks meet, each copies what
+// it is owed (device to device), all ranks meet again.
+struct MockWorld {
+    int W = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    unsigned long long gen = 0;
+    const void* ptr[64];
+    void meet() {
+        std::unique_lock<std::mutex> lk(mu);
+        const unsigned long long g = gen;
+        if (++arrived == W) {
+            arrived = 0;
+            ++gen;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return gen != g; });
+        }
+    }
+};
+struct MockRank {
+    MockWorld* w;
+    int rank;
+};
+static size_t mock_size(ncclDataType_t t) { return t == ncclInt64 || t == ncclUint64 || t == ncclFloat64 ? 8 : (t == ncclInt32 || t == ncclUint32 || t == ncclFloat32 ? 4 : (t == ncclFloat16 ? 2 : 1)); }
+static ncclResult_t mock_all_gather(const void* send, void* recv, size_t count, ncclDataType_t t, ncclComm_t comm, hipStream_t s) {
+    MockRank* m = reinterpret_cast<MockRank*>(comm);
+    const size_t bytes = count * mock_size(t);
+    bool ok = hipStreamSynchronize(s) == hipSuccess;
+    m->w->ptr[m->rank] = send;
+    m->w->meet();
+    for (int k = 0; k < m->w->W; ++k) ok = ok && hipMemcpy((char*)recv + (size_t)k * bytes, m->w->ptr[k], bytes, hipMemcpyDeviceToDevice) == hipSuccess;
+    m->w->meet();
+    return ok ? ncclSuccess : (ncclResult_t)1;
+}
+static ncclResult_t mock_broadcast(const void* send, void* recv, size_t count, ncclDataType_t t, int root, ncclComm_t comm, hipStream_t s) {
+    MockRank* m = reinterpret_cast<MockRank*>(comm);
+    bool ok = hipStreamSynchronize(s) == hipSuccess;
+    if (m->rank == root) m->w->ptr[root] = send;
+    m->w->meet();
+    if (recv != m->w->ptr[root]) ok = ok && hipMemcpy(recv, m->w->ptr[root], count * mock_size(t), hipMemcpyDeviceToDevice) == hipSuccess;
+    m->w->meet();
+    return ok ? ncclSuccess : (ncclResult_t)1;
+}
+static ncclResult_t mock_group() { return ncclSuccess; }
+static ncclResult_t mock_destroy(ncclComm_t comm) {
+    delete reinterpret_cast<MockRank*>(comm);
+    return ncclSuccess;
+}
+static const char* mock_error(ncclResult_t) { return "in-process transport: a device copy failed"; }
+static const Rccl* mock_table() {
+    static const Rccl t = [] {
+        Rccl r;
+        r.lib = (void*)1;
+        r.CommDestroy = mock_destroy;
+        r.AllGather = mock_all_gather;
+        r.Broadcast = mock_broadcast;
+        r.GroupStart = mock_group;
+        r.GroupEnd = mock_group;
+        r.GetErrorString = mock_error;
+        return r;
+    }();
+    return &t;
+}
 
 // ---- who holds the shards of a column, and how a piece gets to its place --------------------------------------------------
 // The exchange has two halves.  MOVE: the lengths of every shard become known everywhere and shard k's bytes of each buffer land
@@ -446,6 +517,7 @@ int32_t gpk_comm_init(int32_t rank, int32_t world, const uint8_t id[128], gpk_co
     c->rank = rank;
     c->world = world;
     (void)hipGetDevice(&c->device);
+    c->table = r;
     const ncclResult_t n = r->CommInitRank(&c->comm, world, uid, rank);
     if (n != ncclSuccess) {
         delete c;
@@ -462,10 +534,43 @@ int32_t gpk_comm_init(int32_t rank, int32_t world, const uint8_t id[128], gpk_co
     return GPK_OK;
 }
 
+int32_t gpk_comm_mock_world(int32_t world, void** out_world) {
+    if (!out_world || world < 1 || world > COMM_MAX_WORLD) return fail(GPK_ERR_INVALID_ARGUMENT, "mock world of %d ranks", world);
+    MockWorld* w = new MockWorld;
+    w->W = world;
+    *out_world = w;
+    return GPK_OK;
+}
+int32_t gpk_comm_mock_world_free(void* world) {
+    delete static_cast<MockWorld*>(world);
+    return GPK_OK;
+}
+int32_t gpk_comm_init_mock(int32_t rank, void* world, gpk_comm** out) {
+    if (!world || !out) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
+    MockWorld* w = static_cast<MockWorld*>(world);
+    *out = nullptr;
+    if (rank < 0 || rank >= w->W) return fail(GPK_ERR_INVALID_ARGUMENT, "comm: rank %d of %d", rank, w->W);
+    GPK_TRY(require_device());
+    gpk_comm* c = new gpk_comm;
+    c->rank = rank;
+    c->world = w->W;
+    c->table = mock_table();
+    c->comm = reinterpret_cast<ncclComm_t>(new MockRank{w, rank});
+    (void)hipGetDevice(&c->device);
+    c->scratch = nullptr;
+    const hipError_t he = hipMalloc((void**)&c->scratch, sizeof(int64_t) * (size_t)((HDR + 1) * (w->W + 1)));
+    if (he != hipSuccess) {
+        (void)mock_destroy(c->comm);
+        delete c;
+        return fail(GPK_ERR_OOM, "comm: scratch: %s", hipGetErrorString(he));
+    }
+    *out = c;
+    return GPK_OK;
+}
+
 int32_t gpk_comm_free(gpk_comm* c) {
     if (!c) return GPK_OK;
-    const Rccl* r;
-    if (rccl(&r) == GPK_OK) (void)r->CommDestroy(c->comm);
+    if (c->table) (void)c->table->CommDestroy(c->comm);
     if (c->scratch) (void)hipFree(c->scratch);
     delete c;
     return GPK_OK;
@@ -483,8 +588,7 @@ int32_t gpk_comm_info(const gpk_comm* c, int32_t* out_rank, int32_t* out_world) 
 int32_t gpk_allgatherv_rows_f64(gpk_comm* c, const double* local_dev, int64_t n_local, int32_t width, double* out_dev, int64_t out_capacity_rows,
                                 int64_t* out_total_rows, int64_t* out_counts, void* stream) {
     if (!c || !out_total_rows || n_local < 0 || width < 1 || (n_local > 0 && !local_dev)) return fail(GPK_ERR_INVALID_ARGUMENT, "bad argument");
-    const Rccl* r;
-    GPK_TRY(rccl(&r));
+    const Rccl* r = c->table;
     hipStream_t s = (hipStream_t)stream;
     GPK_TRY(workspace_aux(0).begin(sizeof(int64_t) * (size_t)(c->world + 1) + 512));
     int64_t* hdr_dev = (int64_t*)workspace_aux(0).take(sizeof(int64_t) * (size_t)(c->world + 1));
@@ -515,8 +619,7 @@ int32_t gpk_allgatherv_rows_f64(gpk_comm* c, const double* local_dev, int64_t n_
 int32_t gpk_allgatherv_geoarray(gpk_comm* c, const gpk_geoarray* shard, void* stream, gpk_geoarray** out, int64_t* out_row_base, int64_t* out_bytes) {
     if (!c || !shard || !out) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
     *out = nullptr;
-    const Rccl* r;
-    GPK_TRY(rccl(&r));
+    const Rccl* r = c->table;
     Shards S;
     S.W = c->world;
     S.me = c->rank;

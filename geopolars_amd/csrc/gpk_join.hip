@@ -2711,13 +2711,19 @@ int32_t gpk_spatial_join(const gpk_geoarray* left, const gpk_geoarray* right, co
         static std::mutex memo_mu;
         const int slot = pip ? 1 : 0;
         gpk_geoarray* rw = const_cast<gpk_geoarray*>(right);
+        // (only a handle that owns every buffer it reads: a borrowed device view can be rewritten by its owner between two calls, and
+        // an index kept over it would answer for the old bytes)
+        const void* const reads[5] = {right->d.xy, right->d.geom_off, right->d.part_off, right->d.ring_off, right->d.validity};
+        bool owns_all = true;
+        for (int i = 0; i < 5; ++i) owns_all = owns_all && (reads[i] == nullptr || right->owned[i] != nullptr);
+        const bool memo = memo_on && owns_all;
         std::lock_guard<std::mutex> lk(memo_mu);
-        if (memo_on && rw->auto_index[slot]) {
+        if (memo && rw->auto_index[slot]) {
             right_index = rw->auto_index[slot];
         } else {
             GPK_TRY(gpk_index_build_ex(right, GPK_INDEX_BBOX_GRID | (pip ? GPK_INDEX_PIP | GPK_INDEX_PIP_LIGHT : 0), nullptr, stream, &tmp_index));
             right_index = tmp_index;
-            if (memo_on && tmp_index->nbytes <= memo_max) {
+            if (memo && tmp_index->nbytes <= memo_max) {
                 rw->auto_index[slot] = tmp_index;
                 tmp_index = nullptr;  // (owned by the handle from here on)
             }

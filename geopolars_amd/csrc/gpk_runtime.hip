@@ -604,7 +604,13 @@ int32_t gpk_geoarray_len(const gpk_geoarray* a, int64_t* out_n) {
 
 int32_t gpk_geoarray_nbytes(const gpk_geoarray* a, int64_t* out_bytes) {
     if (!a || !out_bytes) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
-    *out_bytes = a->nbytes;
+    int64_t total = a->nbytes;
+    for (int k = 0; k < 2; ++k)  // (+ the indexes joins without an index have left on the handle)
+        if (a->auto_index[k]) {
+            int64_t ib = 0;
+            if (gpk_index_nbytes(a->auto_index[k], &ib) == GPK_OK) total += ib;
+        }
+    *out_bytes = total;
     return GPK_OK;
 }
 

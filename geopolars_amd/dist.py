@@ -343,6 +343,19 @@ class Comm:
         self._h, self.rank, self.world = h, rank, world
 
     @staticmethod
+    def mock(rank: int, world_handle, world: int) -> "Comm":
+        """a communicator of the in-process test transport (gpk_comm_mock_world / gpk_comm_init_mock): threads for ranks, no RCCL"""
+        import ctypes as C
+
+        from . import _abi
+
+        self = Comm.__new__(Comm)
+        h = C.c_void_p()
+        _abi.check(_abi.lib().gpk_comm_init_mock(rank, world_handle, C.byref(h)))
+        self._h, self.rank, self.world = h, rank, world
+        return self
+
+    @staticmethod
     def unique_id() -> bytes:
         import ctypes as C
 

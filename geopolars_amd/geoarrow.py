@@ -386,6 +386,18 @@ class DeviceGeoArray:
         self.n_coords = int(sizes[0])
         return self
 
+    def to_arrow(self, layout: str = "struct", stream: int = 0):
+        """-> a pyarrow array imported from the two C Data Interface structs gpk_geoarray_to_arrow fills (callee-owned buffers, released by
+        pyarrow through the structs' release callbacks): how a result leaves the reference (`to_py_array`, py-geopolars/src/ffi.rs:35-52).
+        layout: "wkb" (Binary of ISO WKB, encoded on the GPU), "struct" (GeoArrow over Struct<x, y>: what the reference's Python layer
+        builds) or "interleaved" (FixedSizeList<f64, 2>)."""
+        import pyarrow as pa
+
+        code = {"wkb": _abi.ARROW_WKB, "interleaved": _abi.ARROW_INTERLEAVED, "struct": _abi.ARROW_STRUCT}[layout]
+        c_array, c_schema = _abi.ArrowArray(), _abi.ArrowSchema()
+        _abi.check(_abi.lib().gpk_geoarray_to_arrow(self.handle, code, stream, C.addressof(c_array), C.addressof(c_schema)))
+        return pa.Array._import_from_c(C.addressof(c_array), C.addressof(c_schema))  # (moves the structs: pyarrow calls release)
+
     def to_wkb(self, stream: int = 0) -> tuple[np.ndarray, np.ndarray]:
         """-> (values uint8, offsets int32): the WKB column, ENCODED ON THE GPU from the device-resident buffers
         (gpk_geoarray_to_wkb); only the finished bytes cross PCIe."""

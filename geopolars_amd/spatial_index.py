@@ -116,6 +116,11 @@ class SpatialJoinArgs:
     r_suffix: Optional[str] = "_right"
     l_index: Optional[SpatialIndex] = None  # accepted for signature parity; only the right index is used
     r_index: Optional[SpatialIndex] = None
+    # not in the reference (its geometry columns are WKB, which names its type per row): the geometry type of a NATIVE GeoArrow column
+    # whose nesting alone does not tell it — one list level is a LineString or a MultiPoint, two a Polygon or a MultiLineString — and
+    # which carries no ARROW:extension:name (geoarrow.*).  spatial_join refuses such a column without a hint rather than guess.
+    l_geom_type: int = -1
+    r_geom_type: int = -1
 
 
 def join_pairs(
@@ -249,6 +254,30 @@ def take_column(column, idx: np.ndarray):
     return pa.Array.from_buffers(t, n_idx, [pa.py_buffer(out_valid.tobytes()), pa.py_buffer(out.tobytes())])
 
 
+def _geometry_type_of(table, hint: int, hint_name: str) -> int:
+    """the geom_type to import a table's geometry column with: the caller's hint, else -1 (WKB names its types; a GeoArrow extension
+    name does; three list levels and bare coordinates can only be one type) — or an error for one / two list levels without either"""
+    import pyarrow as pa
+
+    if hint >= 0:
+        return hint
+    t = table.schema.field("geometry").type
+    ext = (table.schema.field("geometry").metadata or {}).get(b"ARROW:extension:name")
+    if isinstance(t, pa.BaseExtensionType):
+        ext, t = t.extension_name.encode(), t.storage_type
+    depth = 0
+    while pa.types.is_list(t) or pa.types.is_large_list(t):
+        depth, t = depth + 1, t.value_type
+    if depth in (1, 2) and not ext:
+        kinds = "LineString or MultiPoint" if depth == 1 else "Polygon or MultiLineString"
+        raise _abi.GeopolarsHipError(
+            _abi.GPK_ERR_INVALID_ARGUMENT,
+            f"spatial_join: a GeoArrow geometry column of {depth} list level(s) without an ARROW:extension:name is a {kinds} column: "
+            f"name the type in SpatialJoinArgs.{hint_name}",
+        )
+    return -1
+
+
 def spatial_join(lhs, rhs, options: Optional[SpatialJoinArgs] = None):
     """spatial_join(lhs, rhs, SpatialJoinArgs) over pyarrow Tables with a `geometry` column (spatial_index.rs:44-45) — WKB binary as the
     reference holds it, or a native GeoArrow nesting.  Returns a pyarrow Table shaped like the reference's result: suffixed left columns,
@@ -261,8 +290,8 @@ def spatial_join(lhs, rhs, options: Optional[SpatialJoinArgs] = None):
     if options.join_type not in ("inner", "left"):
         # spatial_index.rs:200-202 rejects every other JoinType
         raise _abi.GeopolarsHipError(_abi.GPK_ERR_INVALID_ARGUMENT, "Failed to generate the spatial index for the left dataframe")
-    lgeo = GeoSeries.from_arrow(lhs.column("geometry"))
-    rgeo = GeoSeries.from_arrow(rhs.column("geometry"))
+    lgeo = GeoSeries.from_arrow(lhs.column("geometry"), _geometry_type_of(lhs, options.l_geom_type, "l_geom_type"))
+    rgeo = GeoSeries.from_arrow(rhs.column("geometry"), _geometry_type_of(rhs, options.r_geom_type, "r_geom_type"))
     r_index = options.r_index or SpatialIndex(rgeo)
     pairs, counts = join_pairs(lgeo, rgeo, options.predicate, r_index)
     li, ri = join_indices(counts, pairs, options.join_type)  # i64 row indices, r = -1 for unmatched left rows
@@ -271,13 +300,7 @@ def spatial_join(lhs, rhs, options: Optional[SpatialJoinArgs] = None):
         (from_geom_vec, util.rs:11-24) — encoded on the GPU from the series the join already uploaded"""
         if pa.types.is_binary(column.type) or pa.types.is_large_binary(column.type):
             return column
-        values, offsets = geo.to_wkb()
-        out = pa.Array.from_buffers(pa.binary(), len(geo), [None, pa.py_buffer(offsets.tobytes()), pa.py_buffer(values.tobytes())])
-        if column.null_count:
-            import pyarrow.compute as pc
-
-            out = pc.if_else(pc.is_valid(column.combine_chunks() if isinstance(column, pa.ChunkedArray) else column), out, pa.scalar(None, pa.binary()))
-        return out
+        return geo.device().to_arrow("wkb")  # (gpk_geoarray_to_arrow: the library's buffers, validity included, released by pyarrow)
 
     cols, names = [], []
     for name in lhs.column_names:

@@ -190,6 +190,22 @@ struct ArrowArray {
 #endif
 int32_t gpk_geoarray_from_arrow(const struct ArrowArray* array, const struct ArrowSchema* schema, int32_t geom_type_hint,
                                 void* stream, gpk_geoarray** out, int32_t* out_geom_type);
+/* ... and the way back (py-geopolars/src/ffi.rs:35-52: `to_py_array` hands every result to Python as an ArrowArray / ArrowSchema pair
+ * that the importer releases): the handle's column in HOST memory behind the two caller-provided structs, every buffer owned by the
+ * library until the importer calls the structs' `release` callbacks (which free the buffers, the children and the private data; a
+ * struct whose release is NULL has been released).  `layout`:
+ *   GPK_ARROW_WKB          Binary ("z", i32 offsets) of ISO WKB, encoded on the GPU (gpk_geoarray_to_wkb) — how the reference holds
+ *                          geometry columns (util.rs:11-24); ARROW:extension:name geoarrow.wkb
+ *   GPK_ARROW_STRUCT       native GeoArrow, 0 - 3 "+l" levels by geometry type over Struct<x: f64, y: f64> — what the reference's Python
+ *                          layer builds (internals/geoseries.py:86-113)
+ *   GPK_ARROW_INTERLEAVED  the same nesting over FixedSizeList<f64, 2>
+ * Native layouts carry ARROW:extension:name geoarrow.point / linestring / polygon / multipoint / multilinestring / multipolygon, so
+ * that gpk_geoarray_from_arrow(to_arrow(x)) == x for every type.  Null rows keep their (empty) slots; the outermost array carries the
+ * validity bitmap and null_count. */
+#define GPK_ARROW_WKB 0
+#define GPK_ARROW_INTERLEAVED 1
+#define GPK_ARROW_STRUCT 2
+int32_t gpk_geoarray_to_arrow(const gpk_geoarray* a, int32_t layout, void* stream, struct ArrowArray* out_array, struct ArrowSchema* out_schema);
 /* Device -> host copy of a handle's GeoArrow buffers.  sizes[4] = {n_coords, n_parts, n_rings, n_geoms} is always
  * filled; NULL buffers are skipped (call once with NULLs to size the buffers). */
 int32_t gpk_geoarray_download(const gpk_geoarray* a, int64_t sizes[4], double* xy, int32_t* geom_offsets,
@@ -378,9 +394,12 @@ int32_t gpk_index_describe(const gpk_index* idx, int64_t out[8]);
  *   out_pairs[2*cap]     u32 (l, r) interleaved (may be NULL when cap == 0: count-only mode)
  *   *n_pairs             total hits (always set; GPK_ERR_CAPACITY if > cap and pairs requested)
  * `right_index` may be NULL (built on the fly like spatial_index.rs:60-71).  The index such a call builds STAYS on the right-side
- * handle (handles are immutable after upload, so it cannot go stale) and is freed with it: the reference's default call shape —
+ * handle WHEN THE HANDLE OWNS ITS BUFFERS (host uploads, gpk_geoarray_from_wkb / _from_arrow, results of this library: nobody can
+ * change those bytes, so the index cannot go stale) and is freed with it: the reference's default call shape —
  * SpatialJoinArgs::default() has r_index: None, spatial_index.rs:24-35 — repeated against the same series pays for one build.
- * Only indexes of at most GPK_AUTO_INDEX_MAX_MB (environment, default 256) are kept; GPK_AUTO_INDEX=0 builds and frees per call.
+ * A handle that BORROWS device buffers (GPK_MEM_DEVICE descriptors: the caller may rewrite them between calls) gets a fresh index
+ * in every such call.  Only indexes of at most GPK_AUTO_INDEX_MAX_MB (environment, default 256) are kept; GPK_AUTO_INDEX=0 builds and
+ * frees per call; gpk_geoarray_nbytes includes the kept indexes.
  * Geometry dispatch = the match of spatial_index.rs:89-137: point <-> polygon / multipolygon on either side
  * (`poly.contains(point)` whatever the predicate), polygonal x polygonal `intersects`, polygon / multipolygon x POLYGON
  * `contains` (:99-101,107-111; upstream's DE-9IM relate restated as "right is not empty and a subset of left"),
@@ -463,6 +482,13 @@ int32_t gpk_comm_unique_id(uint8_t out_id[128]);
 int32_t gpk_comm_init(int32_t rank, int32_t world, const uint8_t id[128], gpk_comm** out);
 int32_t gpk_comm_free(gpk_comm* comm);
 int32_t gpk_comm_info(const gpk_comm* comm, int32_t* out_rank, int32_t* out_world);
+/* An IN-PROCESS transport for tests of the exchange (no RCCL): `world` threads of one process on one device stand in for the ranks.
+ * gpk_comm_mock_world makes the meeting place, every thread opens its communicator on it with gpk_comm_init_mock and calls
+ * gpk_allgatherv_* as ranks would — every line of the exchange but RCCL's own runs, with ranks that are apart in time.  Free the
+ * communicators first, then the world. */
+int32_t gpk_comm_mock_world(int32_t world, void** out_world);
+int32_t gpk_comm_init_mock(int32_t rank, void* world, gpk_comm** out);
+int32_t gpk_comm_mock_world_free(void* world);
 int32_t gpk_allgatherv_geoarray(gpk_comm* comm, const gpk_geoarray* shard, void* stream, gpk_geoarray** out,
                                 int64_t* out_row_base, int64_t* out_bytes);
 int32_t gpk_allgatherv_rows_f64(gpk_comm* comm, const double* local_dev, int64_t n_local, int32_t width, double* out_dev,

@@ -27,12 +27,30 @@ int main(void) {
     rc = gpk_device_count(&n_dev);
     printf("devices: rc=%d n=%d\n", (int)rc, (int)n_dev);
     rc = gpk_geoarray_upload(&d, NULL, &h);
-    if (rc == GPK_OK) { /* a GPU is present: exercise one operator and release the handle */
+    if (rc == GPK_OK) { /* a GPU is present: one operator, then the column out and in again through the C Data Interface structs */
         double area = -1.0;
+        struct ArrowArray arr;
+        struct ArrowSchema sch;
+        gpk_geoarray* back = NULL;
+        int32_t gt = -1;
         rc = gpk_area(h, &area, GPK_MEM_HOST, NULL);
         printf("area: rc=%d value=%g\n", (int)rc, area);
+        if (rc != GPK_OK || area != 0.5) return 11;
+        memset(&arr, 0, sizeof arr);
+        memset(&sch, 0, sizeof sch);
+        rc = gpk_geoarray_to_arrow(h, GPK_ARROW_STRUCT, NULL, &arr, &sch);
+        if (rc != GPK_OK || arr.length != 1 || arr.n_children != 1 || !arr.release || !sch.release || strcmp(sch.format, "+l") != 0) return 15;
+        rc = gpk_geoarray_from_arrow(&arr, &sch, -1, NULL, &back, &gt); /* (borrowed: still ours to release) */
+        if (rc != GPK_OK || gt != GPK_GEOM_POLYGON) return 16;
+        area = -1.0;
+        rc = gpk_area(back, &area, GPK_MEM_HOST, NULL);
+        printf("area after the round trip: rc=%d value=%g\n", (int)rc, area);
+        arr.release(&arr);
+        sch.release(&sch);
+        if (arr.release || sch.release) return 17; /* a released struct says so */
+        gpk_geoarray_free(back);
         gpk_geoarray_free(h);
-        return (rc == GPK_OK && area == 0.5) ? 0 : 11;
+        return (rc == GPK_OK && area == 0.5) ? 0 : 18;
     }
     gpk_last_error(msg, sizeof msg);
     printf("no device: rc=%d message=\"%s\"\n", (int)rc, msg);

@@ -137,6 +137,20 @@ def test_bench_n_rank_path_at_world_1(gpk, config, extra):
         assert line["config"]["right_side_exchange"]["bytes"] > 0
 
 
+def test_bench_falls_back_to_the_torch_exchange_when_the_librarys_communicator_does_not_come_up(gpk):
+    """--comm abi is the default exchange of C4; if gpk_comm_init / the probe collective fail or do not return within --comm-timeout on ANY
+    rank, every rank agrees (over the torch group) to run geopolars_amd.dist's exchange instead and the line says which one ran"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), GPK_BENCH_FAIL_COMM="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "c4", "--force-dist", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--parity-rows", "20000",
+           "--polygons", "150000"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    ex = line["config"]["right_side_exchange"]
+    assert ex["through"].startswith("torch.distributed") and "fallback" in ex["through"] and ex["bytes"] > 0 and line["parity"]["bit_exact"]
+    assert "falling back to torch.distributed" in r.stderr
+
+
 @pytest.mark.parametrize("shard", ["0/8", "5/8", "7/8", "2/3"])
 def test_bench_c2_strong_scaled_shards(gpk, shard):
     """the headline at N > 1 is STRONG scaled — rank r owns rows [r n / W, (r + 1) n / W) of the fixed 10M points and its pairs carry
@@ -226,6 +240,94 @@ def test_c_abi_communicator_at_world_1(gpk, oracle):
     assert np.array_equal(counts.cpu().numpy().astype(np.uint32), exp_counts)
     assert np.array_equal(pairs[:h].cpu().numpy().astype(np.uint32), exp_pairs)
     comm.free()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_c_abi_all_gatherv_between_ranks_that_are_apart_in_time(gpk, world):
+    """gpk_allgatherv_geoarray / gpk_allgatherv_rows_f64 with MORE THAN ONE RANK: `world` threads of this process, each with its own
+    communicator on the library's in-process transport (gpk_comm_init_mock: RCCL's signatures, rendezvous + device copies) and its own
+    HIP stream, run the exchange as ranks do — header all-gather, agreement, grouped broadcasts, placement (shard k > 0 drops its leading
+    offset), rebase by the children before, validity repack across byte boundaries — for every nesting, shards of odd and zero length,
+    nulls on some ranks only, and views whose offsets do not start at 0; every rank must end with the whole column"""
+    import ctypes as C
+    import threading
+
+    import torch
+
+    from geopolars_amd.dist import Comm, slice_rows
+    from geopolars_amd.geoarrow import DeviceGeoArray
+
+    lib = _abi.lib()
+    wh = C.c_void_p()
+    _abi.check(lib.gpk_comm_mock_world(world, C.byref(wh)))
+    rng = np.random.default_rng(40 + world)
+    pts = synth.uniform_points(10_007, seed=3)
+    cases = {
+        "points": pts,
+        "points, nulls": GeoArrowArray.from_points(pts.xy, validity=np.packbits(rng.uniform(size=len(pts)) > 0.3, bitorder="little")),
+        "linestrings": synth.random_linestrings(1_203, seed=9, max_log2=5.0),
+        "polygons": synth.clustered_polygons(3_001, seed=7),
+        "multipolygons": synth.powerlaw_multipolygons(997, seed=8, cap=300),
+    }
+    errors, results = [], {}
+
+    def rank_main(r: int):
+        try:
+            stream = torch.cuda.Stream()
+            comm = Comm.mock(r, wh, world)
+            for name, host in cases.items():
+                n = len(host)
+                cuts = sorted(set([0, n] + list(np.sort(rng_cuts[name]))))  # (the same cuts on every rank)
+                cuts = (cuts + [n] * (world + 1))[: world + 1]
+                cuts[-1] = n
+                lo, hi = cuts[r], cuts[r + 1]
+                piece = slice_rows(host, lo, hi)
+                if name == "points, nulls" and r % 2 == 1:  # nulls on some ranks only: the others' rows are all valid
+                    piece = GeoArrowArray.from_points(piece.xy)
+                shard = DeviceGeoArray.upload(piece, stream=stream.cuda_stream)
+                full, base, nbytes = comm.all_gatherv(shard, stream=stream.cuda_stream)
+                torch.cuda.synchronize()
+                results[(name, r)] = (full.download(), base, lo)
+                box = torch.full((hi - lo, 4), float(r), dtype=torch.float64, device="cuda")
+                leaves = comm.all_gather_rows(box, stream=stream.cuda_stream)
+                results[(name + " leaves", r)] = leaves.cpu().numpy()
+                full.free()
+                shard.free()
+            comm.free()
+        except BaseException as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+
+    rng_cuts = {name: rng.integers(0, len(h) + 1, world - 1) for name, h in cases.items()}
+    if world == 3:  # one empty shard, one of a single row
+        for name, h in cases.items():
+            rng_cuts[name] = np.array([1, 1])
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not any(t.is_alive() for t in threads), "a rank is stuck inside the exchange"
+    assert not errors, errors
+    for name, host in cases.items():
+        for r in range(world):
+            got, base, lo = results[(name, r)]
+            assert base == lo and got.geom_type == host.geom_type and len(got) == len(host), (name, r)
+            assert np.array_equal(got.xy, host.xy), (name, r)
+            for f in ("geom_offsets", "part_offsets", "ring_offsets"):
+                a, b = getattr(got, f), getattr(host, f)
+                assert (a is None) == (b is None) and (a is None or np.array_equal(a, b)), (name, r, f)
+            if name == "points, nulls":
+                cuts = sorted(set([0, len(host)] + list(np.sort(rng_cuts[name]))))
+                cuts = (cuts + [len(host)] * (world + 1))[: world + 1]
+                cuts[-1] = len(host)
+                want = host.is_valid().copy()
+                for k in range(world):
+                    if k % 2 == 1:
+                        want[cuts[k] : cuts[k + 1]] = True
+                assert np.array_equal(got.is_valid(), want), (name, r)
+            leaves = results[(name + " leaves", r)]
+            assert leaves.shape == (len(host), 4) and np.all(np.diff(leaves[:, 0]) >= 0) and set(np.unique(leaves)) <= set(float(k) for k in range(world))
+    _abi.check(lib.gpk_comm_mock_world_free(wh))
 
 
 @pytest.mark.parametrize("k", [2, 4, 8])

@@ -273,8 +273,8 @@ def test_wkb_encoder_matches_independent_writer_and_handles_nulls():
     assert lib.gpk_wkb_encode(C.byref(d), None, small.ctypes.data, 10, C.byref(nb)) == _abi.GPK_ERR_CAPACITY and nb.value == len(v)
 
 
-def test_plain_c_client_links_and_fails_loudly_without_a_device(tmp_path):
-    """include/geopolars_hip.h compiled as strict C99 by gcc, linked against the library, run as a process"""
+def build_and_run_c_client(tmp_path):
+    """include/geopolars_hip.h compiled as strict C99 by gcc, linked against the library, run as a process -> the finished process"""
     import subprocess
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -286,6 +286,12 @@ def test_plain_c_client_links_and_fails_loudly_without_a_device(tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    return r
+
+
+def test_plain_c_client_links_and_fails_loudly_without_a_device(tmp_path):
+    r = build_and_run_c_client(tmp_path)
+    assert "no device" in r.stdout or "area" in r.stdout
 
 
 def test_off_path_operators_say_so():
@@ -432,3 +438,33 @@ def test_arrow_c_data_import_walks_the_structs_before_it_needs_a_device():
     d.xy = host.xy.ctypes.data
     out = C.c_void_p()
     assert _abi.lib().gpk_geoarray_upload(C.byref(d), None, C.byref(out)) in (_abi.GPK_ERR_INVALID_ARGUMENT, _abi.GPK_ERR_DEVICE)
+
+
+def test_bench_always_prints_a_line_when_a_rank_dies_or_the_run_hangs(tmp_path):
+    """rank 0 prints ONE JSON line whatever happens: an exception in the rank (the line carries `error`), a run that outlives the
+    watchdog, another rank's death (its marker file wakes the survivors' watchdogs, which would otherwise wait in a collective)"""
+    import json, subprocess, sys as _sys, time as _time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    bench = [_sys.executable, os.path.join(root, "bench.py"), "--config", "c4", "--steps", "1", "--warmup", "1"]
+
+    def line_of(r):
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
+
+    r = subprocess.run(bench, capture_output=True, text=True, timeout=120, env=dict(base, GPK_BENCH_RAISE="boom", TMPDIR=str(tmp_path)))
+    assert r.returncode == 5
+    line = line_of(r)
+    assert "boom" in line["error"] and line["value"] is None and line["n_gpus"] == 1 and "intersects" in line["metric"]
+    r = subprocess.run(bench + ["--watchdog", "2"], capture_output=True, text=True, timeout=120, env=dict(base, GPK_BENCH_HANG="1", TMPDIR=str(tmp_path)))
+    assert r.returncode == 4 and "watchdog" in line_of(r)["error"]
+    # rank 1 of 2 dies; rank 0 (hanging, as it would inside a collective) learns of it and prints the line
+    env2 = dict(base, WORLD_SIZE="2", MASTER_PORT="29999", TORCHELASTIC_RUN_ID="t", TMPDIR=str(tmp_path))
+    p0 = subprocess.Popen(bench, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(env2, RANK="0", GPK_BENCH_HANG="1"))
+    _time.sleep(1.0)
+    r1 = subprocess.run(bench, capture_output=True, text=True, timeout=120, env=dict(env2, RANK="1", GPK_BENCH_RAISE="rank one is gone"))
+    assert r1.returncode == 5 and '"metric"' not in r1.stdout  # (only rank 0 prints)
+    out, _ = p0.communicate(timeout=60)
+    assert p0.returncode == 4
+    line = json.loads([l for l in out.splitlines() if l.startswith('{"metric"')][-1])
+    assert "rank1 failed" in line["error"] and "rank one is gone" in line["error"] and line["n_gpus"] == 2
