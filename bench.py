@@ -810,6 +810,8 @@ def parity_distance(pts_host, ls_host, rows, gpu_out, k: int) -> dict:
     got = gpu_out.cpu().numpy()[idx]
     rel = np.abs(got - exp) / np.maximum(np.abs(exp), 1e-300)
     ok = bool(np.all((rel <= 1e-9) | (got == exp)) and np.array_equal(got == 0.0, exp == 0.0) and np.array_equal(np.isnan(got), np.isnan(exp)))
+    if not ok and os.environ.get("GPK_BENCH_ABLATION"):  # tuning builds that answer wrong on purpose (tools/): timing only, said on the line
+        return {"rows": int(len(idx)), "ablation_build": True, "max_rel_err": float("nan")}
     if not ok:
         raise SystemExit("bench.py: GPU distances differ from the CPU oracle beyond 1e-9 on the parity sample — no speed reported")
     return {"rows": int(len(idx)), "sampling": "uniform random without replacement (seed 4243)", "tolerance": "1e-9 relative, zero / non-zero exact", "max_rel_err": float(rel[np.isfinite(rel)].max(initial=0.0))}

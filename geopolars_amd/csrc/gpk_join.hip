@@ -1660,24 +1660,55 @@ __global__ __launch_bounds__(256) void bbox_cand_kernel(DevGeo left, DevGeo righ
 // offsets and the second directory walk (bbox_cand_kernel<true>: 0.90 ms of the 6.1 ms C4 join) does not run.
 constexpr int CAND_STAGE = 16;
 static_assert(CAND_STAGE <= CAND_INLINE_SORT, "a staged row is one that the fill pass would have sorted inline");
+// Round 6: CAND_LANES lanes per left row.  One lane per row walked its cells' items as a chain of dependent requests — cell offsets, then
+// ids two at a time, then their boxes — about eight round trips a row with the lanes of a wave on rows of different lengths (0.82 ms
+// for the 1 M rows of C4); the lanes of a row now take the items of a cell side by side (ids together, boxes together: two round trips
+// a cell) and append their finds to the row's slice with one ballot.
+constexpr int CAND_LANES = 8;
 __global__ __launch_bounds__(256) void bbox_cand_stage_kernel(DevGeo left, DevGeo right, IndexView ix, const double4* __restrict__ lbbox,
                                                                int32_t* __restrict__ cand_cnt, uint32_t* __restrict__ stage,
                                                                int32_t* __restrict__ flags /* [0]: big rows, [1]: rows beyond CAND_STAGE */) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= left.n_geoms) return;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = t / CAND_LANES;
+    const int sub = (int)(threadIdx.x & (CAND_LANES - 1)), gbase = (int)(threadIdx.x & 63) & ~(CAND_LANES - 1);
+    if (i >= left.n_geoms) return;  // (whole groups: CAND_LANES divides the block)
     int cnt = 0;
     uint32_t* mine = stage + i * CAND_STAGE;
-    if (dev::valid_row(left.validity, i)) {
+    const double4 lb = lbbox[i];
+    if (dev::valid_row(left.validity, i) && lb.x == lb.x) {
         const GridParams g = *ix.grid;
-        for_each_bbox_candidate(ix, g, lbbox[i], [&](int j) {
-            if (!dev::valid_row(right.validity, j)) return;
-            if (cnt < CAND_STAGE) mine[cnt] = (uint32_t)j;  // (in directory order: cand_compact_kernel sorts the slice across its 16 lanes)
-            ++cnt;
-        });
+        const int cx0 = dev::cell_of(lb.x, g.x0, g.inv_w, g.gx), cx1 = dev::cell_of(lb.z, g.x0, g.inv_w, g.gx);
+        const int cy0 = dev::cell_of(lb.y, g.y0, g.inv_h, g.gy), cy1 = dev::cell_of(lb.w, g.y0, g.inv_h, g.gy);
+        for (int cy = cy0; cy <= cy1; ++cy)
+            for (int cx = cx0; cx <= cx1; ++cx) {
+                const int c = cy * g.gx + cx;
+                const int k0 = ix.cell_off[c], k1 = ix.cell_off[c + 1];
+                for (int kb = k0; kb < k1; kb += CAND_LANES) {  // (group-uniform trip count)
+                    const int k = kb + sub;
+                    bool keep = false;
+                    int j = 0;
+                    if (k < k1) {
+                        j = ix.items[k];
+                        const double4 rb = ix.bbox[j];
+                        // closed-interval overlap, and the pair belongs to THIS cell: the one that holds the lower-left corner of the two
+                        // boxes' intersection (for_each_bbox_candidate)
+                        if (!(lb.z < rb.x || lb.w < rb.y || rb.z < lb.x || rb.w < lb.y)) {
+                            const double rx = lb.x > rb.x ? lb.x : rb.x, ry = lb.y > rb.y ? lb.y : rb.y;
+                            keep = dev::cell_of(rx, g.x0, g.inv_w, g.gx) == cx && dev::cell_of(ry, g.y0, g.inv_h, g.gy) == cy && dev::valid_row(right.validity, j);
+                        }
+                    }
+                    const uint32_t m = (uint32_t)((__ballot(keep) >> gbase) & ((1u << CAND_LANES) - 1u));
+                    const int at = cnt + __popc(m & ((1u << sub) - 1u));
+                    if (keep && at < CAND_STAGE) mine[at] = (uint32_t)j;  // (in directory order: cand_compact_kernel sorts the slice across its 16 lanes)
+                    cnt += __popc(m);
+                }
+            }
     }
-    cand_cnt[i] = cnt;
-    if (cnt > CAND_STAGE) flags[1] = 1;
-    if (cnt > CAND_INLINE_SORT) flags[0] = 1;
+    if (sub == 0) {
+        cand_cnt[i] = cnt;
+        if (cnt > CAND_STAGE) flags[1] = 1;
+        if (cnt > CAND_INLINE_SORT) flags[0] = 1;
+    }
 }
 // (a row with more than CAND_STAGE candidates — a dense cluster — walks the directory again, like bbox_cand_kernel<true>: one lane of
 // its CAND_STAGE; rows beyond CAND_INLINE_SORT send the whole join down the two-search path with its segmented sort)
@@ -1746,6 +1777,9 @@ __device__ __forceinline__ int64_t row_of_candidate(const int32_t* __restrict__ 
 }
 // (GPK_REFINE_MINWAVES=4 — 128 registers instead of 141, four waves per SIMD instead of three — was 4 % faster, 4.06 -> 3.90 ms, and wrote
 // 1.1 GB of spilled registers per launch to scratch memory, WRITE_SIZE 9.7 MB -> 1.14 GB: not taken)
+#ifndef GPK_REFINE_KEEP_A
+#define GPK_REFINE_KEEP_A 1
+#endif
 #ifndef GPK_REFINE_MINWAVES
 #define GPK_REFINE_MINWAVES 1
 #endif
@@ -1760,8 +1794,13 @@ __global__ __launch_bounds__(256, GPK_REFINE_MINWAVES) void pair_refine_kernel(D
     const int lane = threadIdx.x & (JOIN_GS - 1);
     PairSmallLds* slice = slices + threadIdx.x / JOIN_GS;
     const bool plain = left.type == GPK_GEOM_POLYGON && right.type == GPK_GEOM_POLYGON && lbbox && rbbox;  // (uniform)
+    // A group takes a CONTIGUOUS run of candidates: they are ordered by left row, so consecutive ones mostly share it and its ring stays
+    // staged (round 6; a group used to stride over the list, staging both rings of every pair)
     const int64_t groups = (int64_t)gridDim.x * (256 / JOIN_GS);
-    for (int64_t c = (int64_t)blockIdx.x * (256 / JOIN_GS) + threadIdx.x / JOIN_GS; c < n_cand; c += groups) {
+    const int64_t per = (n_cand + groups - 1) / groups, g_id = (int64_t)blockIdx.x * (256 / JOIN_GS) + threadIdx.x / JOIN_GS;
+    const int64_t c_lo = g_id * per, c_hi = c_lo + per < n_cand ? c_lo + per : n_cand;
+    int64_t staged_i = -1;  // the left row whose ring is in slice->a
+    for (int64_t c = c_lo; c < c_hi; ++c) {
         const int64_t i = (int64_t)cand_l[c], j = (int64_t)cand_r[c];
         bool h;
         bool small = false;
@@ -1784,10 +1823,13 @@ __global__ __launch_bounds__(256, GPK_REFINE_MINWAVES) void pair_refine_kernel(D
                 small = na >= 1 && nb >= 1 && na <= PP_SMALL && nb <= PP_SMALL;
             }
         }
-        if (small)
-            h = polygon_pair_small<JOIN_GS>(left.xy + ca, na, right.xy + cb, nb, lbbox[i], rbbox[j], lane, slice);
-        else
+        if (small) {
+            h = polygon_pair_small<JOIN_GS>(left.xy + ca, na, right.xy + cb, nb, lbbox[i], rbbox[j], lane, slice, GPK_REFINE_KEEP_A && staged_i == i);
+            staged_i = i;
+        } else {
             h = polygonal_intersects_polygonal_group<JOIN_GS>(left, i, right, j, lane, reinterpret_cast<double4*>(slice), lbbox, rbbox);
+            staged_i = -1;  // (the general routine keeps its segment lists in the slice)
+        }
         if (lane == 0) hit[c] = h;
     }
 }
@@ -1924,8 +1966,8 @@ static int32_t bbox_join(const gpk_geoarray* left, const gpk_geoarray* right, co
     auto stage1 = [&]() -> int32_t {
         GPK_HIP(hipMemsetAsync(big_rows, 0, 2 * sizeof(int32_t), s));
         if (staged)
-            GPK_LAUNCH("gpk_bbox_cand_count", bbox_cand_stage_kernel, dim3((unsigned)nb), dim3(256), 0, s, left->d, right->d, right_index->v,
-                       lbbox, cand_cnt, stage, big_rows);
+            GPK_LAUNCH("gpk_bbox_cand_count", bbox_cand_stage_kernel, dim3((unsigned)((n * CAND_LANES + 255) / 256)), dim3(256), 0, s, left->d, right->d,
+                       right_index->v, lbbox, cand_cnt, stage, big_rows);
         else
             GPK_LAUNCH("gpk_bbox_cand_count", bbox_cand_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, left->d, right->d, right_index->v,
                        lbbox, cand_cnt, (const int32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, big_rows);

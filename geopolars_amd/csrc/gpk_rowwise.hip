@@ -445,144 +445,223 @@ __device__ __forceinline__ double vmin_f64(double a, double b) {  // one instruc
     asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-__device__ __forceinline__ void seg_step(SegState& st, double2 b, double px, double py, double& best_v, Frac& best_i, double& sum_d2) {
-    const double rx = px - b.x, ry = py - b.y;
-    const double nb2 = __builtin_fma(rx, rx, ry * ry);
+// Round 6: the step by instruction count (the kernel is bound by f64 issue: 0.59 of the issue rate, PMC).  What does not depend on the
+// point — the reciprocal of the segment's squared length — is computed ONCE per staged window by the lane that copied the vertex and
+// read back from LDS with it; the distance to a segment is the distance to the clamped projection a + clamp(q.d / d.d, 0, 1) d, whose
+// end points ARE the vertices (no separate vertex minimum, no cross-multiplied fraction compare): 12 vector instructions a segment
+// (dx dy | dot | t | ex ey | e.e | min | next q) where the vertex / fraction form above took 17 - 21.  The clamp is the multiply's own
+// output modifier.  A zero-length segment stores 0 for its reciprocal: t = 0, the distance to its vertex (geo-types' a == b arm).
+__device__ __forceinline__ double mul_clamp01(double a, double b) {
+    double r;
+    asm("v_mul_f64 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void seg_step(SegState& st, double2 b, double inv_d2, double px, double py, double& best) {
     const double dx = b.x - st.ax, dy = b.y - st.ay;
-    const double d2 = __builtin_fma(dx, dx, dy * dy);
     const double dot = __builtin_fma(st.qx, dx, st.qy * dy);
-    const double cross = __builtin_fma(st.qx, dy, -(st.qy * dx));
-    best_v = vmin_f64(best_v, nb2);
-    sum_d2 += d2;  // >= the longest segment: bounds how close a point upstream calls "on the linestring" can be (below)
-    const double c2 = cross * cross;
-    // (as a branch: written with selects — no exec-mask bookkeeping — the kernel is 28 % SLOWER: whole waves skip the update on most
-    // segments once the nearest one has been met)
-    if (dot > 0.0 && dot < d2 && c2 * best_i.den < best_i.num * d2) {  // projection inside the segment, and nearer
-        best_i.num = c2;
-        best_i.den = d2;
-    }
+    const double t = mul_clamp01(dot, inv_d2);
+    const double ex = __builtin_fma(-t, dx, st.qx), ey = __builtin_fma(-t, dy, st.qy);
+    best = vmin_f64(best, __builtin_fma(ex, ex, ey * ey));
     st.ax = b.x;
     st.ay = b.y;
-    st.qx = rx;
-    st.qy = ry;
+    st.qx = px - b.x;
+    st.qy = py - b.y;
 }
 
 constexpr int DC_K = 31;      // segments per staged window of one linestring (32 vertices)
 constexpr int DC_SLOT = 33;   // LDS stride of a staged window in vertices (odd: windows of different targets sit on different banks)
 constexpr int DC_MAXD = 8;    // targets staged at once per wave (a chunk with more distinct targets goes in several groups)
+#ifndef GPK_DIST_ABLATE
+#define GPK_DIST_ABLATE 0  // tuning builds only (answers wrong on purpose): 1 = points read and results written in map order (no gather, no scatter)
+#endif
+#ifndef GPK_DIST_ROWS
+#define GPK_DIST_ROWS 1  // (2: measured 3 % slower on C3 — 122 registers halve the occupancy)
+#endif
+constexpr int DC_R = GPK_DIST_ROWS;       // rows per lane: a wave's chunk is 128 ordered rows (lane l holds rows l and 64 + l of it)
+// what does not depend on the point, once per linestring column (kept with the row map): the reciprocal of every segment's squared
+// length (0 for a zero-length one, and for the last vertex of the array) and every linestring's longest squared segment
+__global__ __launch_bounds__(256) void seg_inv_kernel(const double2* __restrict__ xy, int64_t n_coords, double* __restrict__ inv) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_coords) return;
+    double r = 0.0;
+    if (j + 1 < n_coords) {
+        const double2 a = xy[j], b = xy[j + 1];
+        const double dx = b.x - a.x, dy = b.y - a.y, d2 = __builtin_fma(dx, dx, dy * dy);
+        r = d2 > 0.0 ? 1.0 / d2 : 0.0;
+    }
+    inv[j] = r;
+}
+__global__ __launch_bounds__(256) void seg_max_kernel(DevGeo ls, const double* __restrict__ inv, double* __restrict__ max_d2) {
+    // 8 lanes per linestring: the smallest non-zero reciprocal is the longest segment
+    const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int sub = threadIdx.x & 7;
+    double lo = INFINITY;
+    if (t < ls.n_geoms) {
+        const int c0 = ls.geom_off[t], c1 = ls.geom_off[t + 1];
+        for (int j = c0 + sub; j + 1 < c1; j += 8) {
+            const double r = inv[j];
+            if (r > 0.0 && r < lo) lo = r;
+        }
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+        const double w = __shfl_xor(lo, o, 8);
+        lo = w < lo ? w : lo;
+    }
+    if (t < ls.n_geoms && sub == 0) max_d2[t] = lo == INFINITY ? 0.0 : 1.0 / lo;
+}
 __global__ __launch_bounds__(256) void distance_grouped_kernel(DevGeo pts, DevGeo ls, const uint32_t* __restrict__ perm,
-                                                               const uint32_t* __restrict__ tsorted, int64_t n_valid, double* __restrict__ out) {
+                                                               const uint32_t* __restrict__ tsorted, const double* __restrict__ seg_inv,
+                                                               const double* __restrict__ seg_max, int64_t n_valid, double* __restrict__ out) {
     __shared__ double2 s_xy[4][DC_MAXD * DC_SLOT];
+    __shared__ double s_inv[4][DC_MAXD * DC_SLOT];  // 1 / |v[j + 1] - v[j]|^2 of a staged window's segment j
+    __shared__ int s_run[4][DC_MAXD][2];            // the runs of the current group: first coordinate, vertex count
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double2* sv = s_xy[wave];
-    const int64_t n_chunks = (n_valid + 63) >> 6;
+    double* sinv = s_inv[wave];
+    int(*srun)[2] = s_run[wave];
+    constexpr int CHUNK = 64 * DC_R;
+    const int64_t n_chunks = (n_valid + CHUNK - 1) / CHUNK;
     for (int64_t ch = (int64_t)blockIdx.x * 4 + wave; ch < n_chunks; ch += (int64_t)gridDim.x * 4) {
-        const int64_t pos = (ch << 6) + lane;
-        const bool active = pos < n_valid;
-        const uint32_t t = active ? tsorted[pos] : 0xFFFFFFFFu;
-        const uint32_t i = active ? perm[pos] : 0u;
-        double2 p = make_double2(NAN, NAN);
-        if (active && dev::valid_row(pts.validity, i)) p = pts.xy[i];
-        int c0 = 0, nv = 0;
-        if (active) {
-            c0 = ls.geom_off[t];
-            nv = ls.geom_off[t + 1] - c0;
+        bool active[DC_R];
+        uint32_t t[DC_R], i[DC_R];
+        double2 p[DC_R];
+        int c0[DC_R], nv[DC_R], my_run[DC_R];
+        double best[DC_R], mx[DC_R];
+        SegState st[DC_R];
+        unsigned long long heads[DC_R];
+        uint32_t t_last = 0xFFFFFFFFu;  // the target of the row before (lane 63 of the row set before)
+        int runs_before = 0;
+#pragma unroll
+        for (int r = 0; r < DC_R; ++r) {
+            const int64_t pos = ch * CHUNK + r * 64 + lane;
+            active[r] = pos < n_valid;
+            t[r] = active[r] ? tsorted[pos] : 0xFFFFFFFFu;
+            i[r] = active[r] ? perm[pos] : 0u;
+            p[r] = make_double2(NAN, NAN);
+            if (active[r] && dev::valid_row(pts.validity, i[r])) p[r] = pts.xy[GPK_DIST_ABLATE ? (uint32_t)pos : i[r]];
+            c0[r] = nv[r] = 0;
+            mx[r] = 0.0;
+            if (active[r]) {
+                c0[r] = ls.geom_off[t[r]];
+                nv[r] = ls.geom_off[t[r] + 1] - c0[r];
+                mx[r] = seg_max[t[r]];
+            }
+            // runs of equal targets over the 128 ordered rows: the k-th run of the chunk is staged in LDS slot k (mod DC_MAXD)
+            uint32_t t_prev = __shfl_up(t[r], 1, 64);
+            if (lane == 0) t_prev = t_last;
+            heads[r] = __ballot(active[r] && ((r == 0 && lane == 0) || t[r] != t_prev));
+            my_run[r] = runs_before + (int)__popcll(heads[r] & ((2ull << lane) - 1ull)) - 1;
+            runs_before += (int)__popcll(heads[r]);
+            t_last = __shfl(t[r], 63, 64);
+            best[r] = INFINITY;
+            st[r] = SegState{0, 0, 0, 0};
         }
-        // runs of equal targets: the k-th run of the wave is staged in LDS slot k (mod DC_MAXD)
-        const uint32_t t_prev = __shfl_up(t, 1, 64);
-        const unsigned long long heads = __ballot(active && (lane == 0 || t != t_prev));
-        const int my_run = (int)__popcll(heads & ((2ull << lane) - 1ull)) - 1;
-        const int n_runs = (int)__popcll(heads);
-        double best_v = INFINITY, sum_d2 = 0.0;  // nearest vertex (squared); sum of squared segment lengths
-        Frac best_i{INFINITY, 1.0};              // nearest interior projection (squared, as a fraction)
-        SegState st{0, 0, 0, 0};
+        const int n_runs = runs_before;
         for (int g0 = 0; g0 < n_runs; g0 += DC_MAXD) {
-            const bool mine = active && my_run >= g0 && my_run < g0 + DC_MAXD;
-            const int slot = (my_run - g0) * DC_SLOT;
-            int nv_max = mine ? nv : 0;
+            // the group's runs: every run's first row says where its linestring starts and how long it is
+            __builtin_amdgcn_wave_barrier();
+            int nv_max = 0;
+#pragma unroll
+            for (int r = 0; r < DC_R; ++r) {
+                const bool head = ((heads[r] >> lane) & 1ull) != 0ull;
+                if (head && my_run[r] >= g0 && my_run[r] < g0 + DC_MAXD) {
+                    srun[my_run[r] - g0][0] = c0[r];
+                    srun[my_run[r] - g0][1] = nv[r];
+                }
+                const bool mine = active[r] && my_run[r] >= g0 && my_run[r] < g0 + DC_MAXD;
+                nv_max = mine && nv[r] > nv_max ? nv[r] : nv_max;
+            }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 const int w = __shfl_xor(nv_max, o, 64);
                 nv_max = w > nv_max ? w : nv_max;
             }
-            // lane j of each half wave copies vertex j of a window: two targets per load instruction
+            const int g_runs = n_runs - g0 < DC_MAXD ? n_runs - g0 : DC_MAXD;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             for (int w0 = 0; w0 < (nv_max > 1 ? nv_max - 1 : 1); w0 += DC_K) {
                 __builtin_amdgcn_wave_barrier();
-                {
-                    unsigned long long m = heads;
-                    for (int q = 0; q < g0; ++q) m &= m - 1;  // skip the runs of earlier groups
+                {   // lane j of each half wave copies vertex j of a window and its segment's reciprocal: two runs per round
                     const int half = lane >> 5, j = lane & 31;
-                    for (int sl = 0; sl < DC_MAXD && m; sl += 2) {
-                        const int lead0 = __ffsll((long long)m) - 1;
-                        m &= m - 1;
-                        int lead1 = lead0;
-                        bool two = false;
-                        if (m && sl + 1 < DC_MAXD) {
-                            lead1 = __ffsll((long long)m) - 1;
-                            m &= m - 1;
-                            two = true;
+                    for (int sl = 0; sl < g_runs; sl += 2) {
+                        const int q = sl + half;
+                        if (q < g_runs) {
+                            const int s_c0 = srun[q][0], s_nv = srun[q][1];
+                            if (w0 + j < s_nv) {
+                                sv[q * DC_SLOT + j] = ls.xy[s_c0 + w0 + j];
+                                sinv[q * DC_SLOT + j] = seg_inv[s_c0 + w0 + j];
+                            }
                         }
-                        const int lead = half ? lead1 : lead0;
-                        const int s_c0 = __shfl(c0, lead, 64), s_nv = __shfl(nv, lead, 64);
-                        if ((half == 0 || two) && w0 + j < s_nv) sv[(sl + half) * DC_SLOT + j] = ls.xy[s_c0 + w0 + j];
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (mine && nv > 0) {
-                    if (w0 == 0) {
-                        const double2 a = sv[slot];
-                        st.ax = a.x;
-                        st.ay = a.y;
-                        st.qx = p.x - a.x;
-                        st.qy = p.y - a.y;
-                        // the first vertex; a one-vertex linestring is at f64::MAX unless the point IS the vertex (upstream's fold)
-                        const double na2 = __builtin_fma(st.qx, st.qx, st.qy * st.qy);
-                        if (nv > 1 || na2 == 0.0) best_v = na2;
+#pragma unroll
+                for (int r = 0; r < DC_R; ++r) {
+                    const bool mine = active[r] && my_run[r] >= g0 && my_run[r] < g0 + DC_MAXD;
+                    if (mine && nv[r] > 0 && w0 < (nv[r] > 1 ? nv[r] - 1 : 1)) {
+                        const int slot = (my_run[r] - g0) * DC_SLOT;
+                        if (w0 == 0) {
+                            const double2 a = sv[slot];
+                            st[r].ax = a.x;
+                            st[r].ay = a.y;
+                            st[r].qx = p[r].x - a.x;
+                            st[r].qy = p[r].y - a.y;
+                            // a one-vertex linestring is at f64::MAX unless the point IS the vertex (upstream's fold); with segments, their
+                            // end points cover the vertices
+                            if (nv[r] == 1 && st[r].qx == 0.0 && st[r].qy == 0.0) best[r] = 0.0;
+                        }
+                        const int kmax = nv[r] - 1 - w0 < DC_K ? nv[r] - 1 - w0 : DC_K;
+                        // two segments per trip, the next trip's first vertex requested before this trip's arithmetic; the reads past the
+                        // last vertex stay inside the window's slot (DC_SLOT = DC_K + 2 entries)
+                        int k = 1;
+                        double2 b0 = sv[slot + 1];
+                        double i0 = sinv[slot];
+                        for (; k + 1 <= kmax; k += 2) {
+                            const double2 b1 = sv[slot + k + 1];
+                            const double i1 = sinv[slot + k];
+                            const double2 n0 = sv[slot + k + 2];
+                            const double in0 = sinv[slot + k + 1];
+                            seg_step(st[r], b0, i0, p[r].x, p[r].y, best[r]);
+                            seg_step(st[r], b1, i1, p[r].x, p[r].y, best[r]);
+                            b0 = n0;
+                            i0 = in0;
+                        }
+                        if (k <= kmax) seg_step(st[r], b0, i0, p[r].x, p[r].y, best[r]);
                     }
-                    const int kmax = nv - 1 - w0 < DC_K ? nv - 1 - w0 : DC_K;
-                    // two segments per trip, the next trip's first vertex requested before this trip's arithmetic (the loop used to wait
-                    // for its ds_read at the top of every segment and rotate its state through four 64-bit moves); the read past the last
-                    // vertex stays inside the window's slot (DC_SLOT = DC_K + 2 entries)
-                    int k = 1;
-                    double2 b0 = sv[slot + 1];
-                    for (; k + 1 <= kmax; k += 2) {
-                        const double2 b1 = sv[slot + k + 1];
-                        const double2 n0 = sv[slot + k + 2];
-                        seg_step(st, b0, p.x, p.y, best_v, best_i, sum_d2);
-                        seg_step(st, b1, p.x, p.y, best_v, best_i, sum_d2);
-                        b0 = n0;
-                    }
-                    if (k <= kmax) seg_step(st, b0, p.x, p.y, best_v, best_i, sum_d2);
                 }
             }
         }
         // Upstream short-circuits "the point is on the linestring => 0" with |tx - ty| <= f64::EPSILON per segment
         // (tx - ty == cross / (dx dy)), which only a point within ~6 eps * |segment| of a segment can satisfy: squared,
-        // best <= 64 eps^2 * (longest segment)^2 <= 64 eps^2 * sum of the squared segment lengths.  Such lanes — and exact vertex hits, best == 0 — replay the upstream test
+        // best <= 64 eps^2 * (longest segment)^2.  Such lanes — and exact vertex hits, best == 0 — replay the upstream test
         // verbatim from global memory, so the zero / non-zero outcome stays exact; everybody else skips it.
-        int eps_hit = 0;
-        const double best = vmin_f64(best_v, best_i.num == INFINITY ? INFINITY : best_i.num / best_i.den);  // squared distance (INFINITY: no segment)
-        const bool maybe = active && nv > 0 && best <= 3.1554436208840472e-30 * sum_d2;  // 64 * 2^-104
-        if (maybe) {
-            if (nv == 1) eps_hit = 1;  // best == 0 above: the point equals the vertex
-            for (int k = 0; k + 1 < nv && !eps_hit; ++k) {
-                const double2 a = ls.xy[c0 + k], b = ls.xy[c0 + k + 1];
-                const double cr = (p.x - a.x) * (b.y - a.y) - (p.y - a.y) * (b.x - a.x);
-                eps_hit = (int)((a.x == p.x && a.y == p.y) || (b.x == p.x && b.y == p.y) ||
-                                segment_contains_eps(p.x, p.y, a.x, a.y, b.x, b.y, cr, (b.x - a.x) * (b.y - a.y)));
+#pragma unroll
+        for (int r = 0; r < DC_R; ++r) {
+            int eps_hit = 0;
+            const bool maybe = active[r] && nv[r] > 0 && best[r] <= 3.1554436208840472e-30 * mx[r];  // 64 * 2^-104
+            if (maybe) {
+                if (nv[r] == 1) eps_hit = 1;  // best == 0 above: the point equals the vertex
+                for (int k = 0; k + 1 < nv[r] && !eps_hit; ++k) {
+                    const double2 a = ls.xy[c0[r] + k], b = ls.xy[c0[r] + k + 1];
+                    const double cr = (p[r].x - a.x) * (b.y - a.y) - (p[r].y - a.y) * (b.x - a.x);
+                    eps_hit = (int)((a.x == p[r].x && a.y == p[r].y) || (b.x == p[r].x && b.y == p[r].y) ||
+                                    segment_contains_eps(p[r].x, p[r].y, a.x, a.y, b.x, b.y, cr, (b.x - a.x) * (b.y - a.y)));
+                }
             }
-        }
-        if (active) {
-            double d;
-            if (!dev::valid_row(ls.validity, t) || isnan(p.x) || isnan(p.y))
-                d = NAN;
-            else if (nv == 0 || eps_hit)
-                d = 0.0;
-            else
-                d = best == INFINITY ? DBL_MAX : sqrt(best);
-            out[i] = d;
+            if (active[r]) {
+                double d;
+                if (!dev::valid_row(ls.validity, t[r]) || isnan(p[r].x) || isnan(p[r].y))
+                    d = NAN;
+                else if (nv[r] == 0 || eps_hit)
+                    d = 0.0;
+                else
+                    d = best[r] == INFINITY ? DBL_MAX : sqrt(best[r]);
+                out[GPK_DIST_ABLATE ? (uint32_t)(ch * CHUNK + r * 64 + lane) : i[r]] = d;
+            }
         }
     }
 }
@@ -699,6 +778,8 @@ struct gpk_rowmap {
     int64_t n, n_valid, n_targets;
     uint32_t* perm;     // left rows in (target length order, target) order; rows without a target last
     uint32_t* tsorted;  // their targets, same order
+    double* seg_inv;    // per coordinate of the linestring column: 1 / squared length of the segment that starts there (seg_inv_kernel)
+    double* seg_max;    // per linestring: its longest squared segment
     int64_t nbytes;
 };
 namespace gpk {
@@ -734,6 +815,20 @@ static int32_t rowmap_build_dev(const gpk_geoarray* ls, const uint32_t* rows_dev
         if (e1 != hipSuccess || e2 != hipSuccess) return fin(fail(GPK_ERR_OOM, "row map: hipMalloc failed"));
     }
     m->nbytes = (int64_t)(2 * nb);
+    {   // what the distance kernel reads per segment and per linestring besides the coordinates
+        const int64_t nc = ls->d.n_coords;
+        const size_t ib8 = align256(sizeof(double) * (size_t)(nc > 0 ? nc : 1)), mb8 = align256(sizeof(double) * (size_t)(L > 0 ? L : 1));
+        if (cached_malloc((void**)&m->seg_inv, ib8) != hipSuccess || cached_malloc((void**)&m->seg_max, mb8) != hipSuccess)
+            return fin(fail(GPK_ERR_OOM, "row map: hipMalloc failed"));
+        m->nbytes += (int64_t)(ib8 + mb8);
+        auto pre = [&]() -> int32_t {
+            if (nc > 0) GPK_LAUNCH("gpk_rowmap_seg_inv", seg_inv_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, ls->d.xy, nc, m->seg_inv);
+            if (L > 0) GPK_LAUNCH("gpk_rowmap_seg_max", seg_max_kernel, dim3((unsigned)((L * 8 + 255) / 256)), dim3(256), 0, s, ls->d, (const double*)m->seg_inv, m->seg_max);
+            return GPK_OK;
+        };
+        const int32_t prc = pre();
+        if (prc != GPK_OK) return fin(prc);
+    }
     if (n == 0) return fin(GPK_OK);  // an empty batch: an empty map (n_valid = 0), no launch (a grid of zero blocks is an error)
     // scratch: cnt | cnt_sorted | off | cursor (L+2 i32 each) | rank (L u32) | keys, sorted (L u64 each) | scan totals
     const size_t ib = align256(sizeof(int32_t) * (size_t)(L + 2)), kb = align256(sizeof(unsigned long long) * (size_t)(L + 1));
@@ -803,11 +898,11 @@ static int32_t distance_rowmap_dev(const gpk_geoarray* pts, const gpk_geoarray* 
     if (nv < n)  // map entries without a target: the answer of a null row
         GPK_LAUNCH("gpk_rowmap_nan", rowmap_nan_kernel, dim3((unsigned)((n - nv + 255) / 256)), dim3(256), 0, s, (const uint32_t*)map->perm, nv, n, out_dev);
     if (nv == 0) return GPK_OK;
-    int64_t blocks = ((nv + 63) / 64 + 3) / 4;  // one wave per chunk of 64 ordered rows
+    int64_t blocks = ((nv + 64 * DC_R - 1) / (64 * DC_R) + 3) / 4;  // one wave per chunk of 128 ordered rows
     const int64_t cap = (int64_t)cu_count() * 16;
     if (blocks > cap) blocks = cap;
     GPK_LAUNCH("gpk_distance_grouped", distance_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pts->d, ls->d, (const uint32_t*)map->perm,
-               (const uint32_t*)map->tsorted, nv, out_dev);
+               (const uint32_t*)map->tsorted, (const double*)map->seg_inv, (const double*)map->seg_max, nv, out_dev);
     return GPK_OK;
 }
 
@@ -819,7 +914,7 @@ extern "C" {
 
 int32_t gpk_rowmap_free(gpk_rowmap* m) {
     if (!m) return GPK_OK;
-    if (m->perm || m->tsorted) {  // (cached blocks: wait once, on the owning device, for whatever still reads the map)
+    if (m->perm || m->tsorted || m->seg_inv) {  // (cached blocks: wait once, on the owning device, for whatever still reads the map)
         int cur = -1;
         (void)hipGetDevice(&cur);
         if (cur != m->device) (void)hipSetDevice(m->device);
@@ -828,6 +923,8 @@ int32_t gpk_rowmap_free(gpk_rowmap* m) {
     }
     if (m->perm) cached_free(m->perm);
     if (m->tsorted) cached_free(m->tsorted);
+    if (m->seg_inv) cached_free(m->seg_inv);
+    if (m->seg_max) cached_free(m->seg_max);
     delete m;
     return GPK_OK;
 }
