@@ -563,7 +563,7 @@ def run_c2(ctx: Ctx) -> None:
         "polygons": m,
         "vertices_per_polygon": args.verts,
         "hits_per_step": h,
-        "algorithm": "ONE launch per join (pip_flow_kernel, persistent work-groups): two-level exact raster routing (level 1 from an LDS image, level 2 = one 16-byte half-cell record) -> a row with a polygon to be in is a hit at once (4-byte entry in the tile's slots of a global pool, count 1); `test` points wait on the wave's LDS list and are decided in dense passes from the half cell's local chain (base winding + about two ring edges, exact orientation filter; uncertifiable rows go through the generic exact walk), a failed test kills its entry -> work-group totals chained through epoch-tagged words, sorted (l,r) pairs written from the pool 64 entries at a time by the same launch; N x M logical pairs counted, raster-rejected pairs included"
+        "algorithm": "ONE launch per join (pip_tile_flow_kernel, persistent work-groups): two-level exact raster routing (level 1 from an LDS image, level 2 = one 16-byte half-cell record) -> a row with a polygon to be in is a hit at once (4-byte entry in the tile's slots of a global pool, count 1); `test` points wait on the wave's LDS list and are decided in dense passes from the half cell's local chain (base winding + about two ring edges, exact orientation filter; uncertifiable rows go through the generic exact walk), a failed test kills its entry -> work-group totals chained through epoch-tagged words, sorted (l,r) pairs written from the pool 64 entries at a time by the same launch; N x M logical pairs counted, raster-rejected pairs included"
         if fused
         else "chain tile kernel + writer (GPK_TILE_KERNEL=chain)",
         "index_tables": index.describe(),

@@ -1153,7 +1153,7 @@ __global__ __launch_bounds__(PIP_BLOCK, GPK_LEAN_MINWAVES) void pip_tile_lean_ke
 // LDS (no other wave sees it: wave-level ordering is enough) and lanes 0 .. T - 1 take one each — one round trip and one pass of
 // the orientation code for all of the tile's `test` points, in dense lanes.
 // This kernel serves chain indexes WITHOUT an LDS routing image (rasters beyond PIP_ROUTE_RMAX) and whatever gpk_pipflow.hip's
-// one-launch join does not take (GPK_TILE_KERNEL=chain: A/B runs); with the image, pip_flow_kernel is the join.  The round-3 .. 5 forms
+// one-launch join does not take (GPK_TILE_KERNEL=chain: A/B runs); with the image, pip_tile_flow_kernel is the join.  The round-3 .. 5 forms
 // that sat between the two (level 1 from the image in persistent work-groups, hits in per-wave LDS lists / staging slots / chunks /
 // a work-group pool) were retired in round 6: DESIGN.md 4.1 keeps their measurements.
 //

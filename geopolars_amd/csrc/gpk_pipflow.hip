@@ -74,7 +74,7 @@ struct FlowItem {
 static_assert(sizeof(FlowItem) == 24, "list slot");
 
 #ifdef GPK_TILE_TRACE
-// diagnosis builds (tools/fused_trace.py): lane 0 of waves 0, 5, 10, 15 of every work-group stamps the 100 MHz wall clock at the
+// diagnosis builds (tools/flow_trace.py): lane 0 of waves 0, 5, 10, 15 of every work-group stamps the 100 MHz wall clock at the
 // stage boundaries: 16 words per traced wave at stats[8 + ((blockIdx.x * 4 + wave / 5) * 16 + i)]
 #define FLOW_STAMP(i)                                                                                                    \
     do {                                                                                                                 \
@@ -496,7 +496,7 @@ __device__ __forceinline__ void flow_emit_chunk(const ChainHot& h, uint32_t e, u
 }
 
 template <bool SIMPLE, int P>
-__global__ __launch_bounds__(FLOW_BLOCK) void pip_flow_kernel(ChainHot h, FusedTail tail) {
+__global__ __launch_bounds__(FLOW_BLOCK) void pip_tile_flow_kernel(ChainHot h, FusedTail tail) {
     constexpr int WORDS = PIP_ROUTE_RMAX * PIP_ROUTE_RMAX / 32, W = FLOW_W, TS = P == 8 ? 9 : (P == 4 ? 8 : (P == 2 ? 7 : 6));
     __shared__ uint2 s_mask[WORDS];     // RouteWord::bmask, gmask
     __shared__ uint32_t s_rec0[WORDS];  // RouteWord::rec0
@@ -720,9 +720,9 @@ size_t pip_flow_pool_bytes(int64_t n_left_rows) { return sizeof(uint32_t) * (siz
 template <int P>
 static int32_t launch_pip_flow_p(const ChainHot& hot, const FusedTail& tail, int wgs, hipStream_t s) {
     if (hot.part_geom == nullptr && hot.polys_validity == nullptr)
-        GPK_LAUNCH("gpk_pip_tile", (pip_flow_kernel<true, P>), dim3((unsigned)wgs), dim3(FLOW_BLOCK), 0, s, hot, tail);
+        GPK_LAUNCH("gpk_pip_tile", (pip_tile_flow_kernel<true, P>), dim3((unsigned)wgs), dim3(FLOW_BLOCK), 0, s, hot, tail);
     else
-        GPK_LAUNCH("gpk_pip_tile", (pip_flow_kernel<false, P>), dim3((unsigned)wgs), dim3(FLOW_BLOCK), 0, s, hot, tail);
+        GPK_LAUNCH("gpk_pip_tile", (pip_tile_flow_kernel<false, P>), dim3((unsigned)wgs), dim3(FLOW_BLOCK), 0, s, hot, tail);
     return GPK_OK;
 }
 int32_t launch_pip_flow(const ChainHot& hot, const FusedTail& tail, int wgs, int points_per_lane, hipStream_t s) {

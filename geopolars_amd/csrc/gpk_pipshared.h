@@ -53,7 +53,7 @@ struct ChainHot {
     uint2* stage;                  // pip_tile_fused_kernel: one pair slot per left row, a wave's hits at the start of its rows' slots
     int32_t n_full_tiles, pad;     // pip_tile_fused_kernel: tiles 0 .. n_full_tiles - 1 need no guards (whole tiles of a column without a validity bitmap)
     double inv_fw_s, inv_fh_s, sub_max;  // pip_tile_fused_kernel: inv_fw * PIP_SUB, inv_fh * PIP_SUB (exact: a power of two), (PIP_SUB << logR) - 1
-    uint32_t* pool;                // pip_flow_kernel: one 4-byte hit slot per left row (a tile's hits at the start of its 512 slots)
+    uint32_t* pool;                // pip_tile_flow_kernel: one 4-byte hit slot per left row (a tile's hits at the start of its 512 slots)
 };
 // the arguments of the rare arm, in device memory: loaded where they are used — as kernel arguments they would be held in scalar
 // registers across the hot loop (and spilled)
@@ -180,7 +180,7 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     return v;
 }
 
-// gpk_pipflow.hip: the one-launch join (pip_flow_kernel).  pip_flow_points_per_lane: 0 when the join cannot take it, else the tile size
+// gpk_pipflow.hip: the one-launch join (pip_tile_flow_kernel).  pip_flow_points_per_lane: 0 when the join cannot take it, else the tile size
 // (64 * points per lane) that ChainHot::n_tiles / n_full_tiles must be counted in; launch_pip_flow: the caller holds the launch lock of
 // fused_launch_begin and has filled the epoch words of `tail`.
 int pip_flow_points_per_lane(int64_t n_left_rows, int64_t n_right_geoms, int32_t R, int wgs);

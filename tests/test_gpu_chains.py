@@ -1,4 +1,4 @@
-"""GPU parity of the chain kernels (gpk_join.hip: pip_tile_chain_kernel + writer; gpk_pipflow.hip: pip_flow_kernel, the one-launch join — rare rows settled inside them)
+"""GPU parity of the chain kernels (gpk_join.hip: pip_tile_chain_kernel + writer; gpk_pipflow.hip: pip_tile_flow_kernel, the one-launch join — rare rows settled inside them)
 through the C ABI vs the CPU oracle, bit-exact on counts and sorted (l, r) pairs (`Contains<Point>`, spatial_index.rs:91-96).
 
 Right sides here are DISJOINT polygons — what makes an index "lean" and gives it local chains — shaped to reach every arm:

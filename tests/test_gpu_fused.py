@@ -1,4 +1,4 @@
-"""GPU parity of the one-launch point join (gpk_pipflow.hip: pip_flow_kernel) through the C ABI vs the CPU oracle, bit-exact on counts,
+"""GPU parity of the one-launch point join (gpk_pipflow.hip: pip_tile_flow_kernel) through the C ABI vs the CPU oracle, bit-exact on counts,
 pairs and totals (`Contains<Point>`, spatial_index.rs:91-96; sorted pairs = the two index vectors of spatial_index.rs:145-159).  Tiles
 decided, hits ranked and the sorted (l, r) pair list written by the same persistent work-groups:
   * a row with a polygon to be in is a hit at once — a 4-byte entry in its tile's slots of a global pool, count 1 — and `test` points wait

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnosis: the timeline of pip_flow_kernel (gpk_pipflow.hip) from a GPK_TILE_TRACE build.
+"""Diagnosis: the timeline of pip_tile_flow_kernel (gpk_pipflow.hip) from a GPK_TILE_TRACE build.
     GPK_LIB_PATH=geopolars_amd/variants/trace1.so python tools/flow_trace.py [n]     stage stamps (us after the first wave's entry)
     GPK_LIB_PATH=geopolars_amd/variants/trace2.so python tools/flow_trace.py [n]     + a wave's tile time summed by phase
 Stamps (100 MHz wall clock): 0 entry, 1 image built, 2 first tile starts, 3 .. 8 after tile i (trace1) / phase sums (trace2),
