@@ -41,6 +41,10 @@ for src, dst in (
     (f"{tag}_ops.jsonl",) * 2,
     (f"{tag}_ops_kernel_stats.csv",) * 2,
     (f"{tag}_reference_benches.jsonl",) * 2,
+    (f"{tag}_sizes.txt",) * 2,
+    (f"{tag}_timeline_trace1.txt", f"{tag}_timeline_flow.txt"),
+    (f"{tag}_timeline_trace2.txt", f"{tag}_timeline_flow_phases.txt"),
+    (f"{tag}_c2_pmc_counters.txt",) * 2,
     (f"prof_{tag}/{tag}_pmc_traffic.json", f"{tag}_pmc_traffic.json"),
     (f"prof_{tag}_cfg/{tag}_pmc_traffic_configs.json", f"{tag}_pmc_traffic_configs.json"),
 ):

@@ -16,3 +16,9 @@ for c in c3 c4 c5; do
 done
 bash tools/prof_stats.sh ${TAG}_ops python $R/tools/bench_ops.py; grep -h '"op"' $O/${TAG}_ops.log > $O/${TAG}_ops.jsonl
 python tools/bench_reference_benches.py > $O/${TAG}_reference_benches.jsonl 2>/dev/null
+# round 6: the headline kernel over column lengths (a shard of the strong-scaled problem) and its launch timeline (a GPK_TILE_TRACE build)
+for n in 10000000 5000000 2500000 1250000 625000; do timeout 100 python tools/tile_time.py --points $n --tag "rows $n" 2>&1 | tail -1; done > $O/${TAG}_sizes.txt 2>&1; cat $O/${TAG}_sizes.txt
+for v in trace1 trace2; do
+  [ -e $R/geopolars_amd/variants/$v.so ] && GPK_LIB_PATH=$R/geopolars_amd/variants/$v.so timeout 100 python tools/flow_trace.py 2>&1 | tail -16 > $O/${TAG}_timeline_$v.txt
+done
+bash tools/pmc_mem.sh ${TAG} > /dev/null 2>&1; cp $O/pmcm_${TAG}.txt $O/${TAG}_c2_pmc_counters.txt 2>/dev/null
