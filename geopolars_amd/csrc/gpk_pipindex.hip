@@ -1490,11 +1490,12 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
             // no ring with refined rows: nearly every record takes the fast path — its own instance (twice the waves per SIMD), then one
             // for the stragglers (parts with holes); a column WITH refined rings (C5: 15 % of the records) keeps the single launch,
             // where a second pass over all records to find the others costs more than the occupancy gives (measured: +1 ms / -10 %)
-            if (n_refined == 0) {
-                GPK_LAUNCH("gpk_pipidx_sub_build", (sub_build_kernel<1, true, 1>), blocks_for((int64_t)n_sub * PIP_SUB * PIP_SUB), dim3(256), 0, s, d, pv, g,
+            static const bool force_split = getenv("GPK_SUB_SPLIT") != nullptr;  // A/B runs: the two instances also for columns with refined rings
+            if (n_refined == 0 || force_split) {
+                GPK_LAUNCH("gpk_pipidx_sub_build_fast", (sub_build_kernel<1, true, 1>), blocks_for((int64_t)n_sub * PIP_SUB * PIP_SUB), dim3(256), 0, s, d, pv, g,
                            (const int32_t*)nullptr, (const int32_t*)nullptr, n_cells, (const uint32_t*)cell, (const uint32_t*)list, sub, (SubCell2*)nullptr,
                            (const int32_t*)swork_cell, (const uint32_t*)swork_part, (int64_t)n_sub);
-                GPK_LAUNCH("gpk_pipidx_sub_build", (sub_build_kernel<1, true, 2>), blocks_for((int64_t)n_sub * PIP_SUB * PIP_SUB), dim3(256), 0, s, d, pv, g,
+                GPK_LAUNCH("gpk_pipidx_sub_build_rest", (sub_build_kernel<1, true, 2>), blocks_for((int64_t)n_sub * PIP_SUB * PIP_SUB), dim3(256), 0, s, d, pv, g,
                            (const int32_t*)nullptr, (const int32_t*)nullptr, n_cells, (const uint32_t*)cell, (const uint32_t*)list, sub, (SubCell2*)nullptr,
                            (const int32_t*)swork_cell, (const uint32_t*)swork_part, (int64_t)n_sub);
             } else {

@@ -102,43 +102,80 @@ static __global__ __launch_bounds__(1024) void scan_block_totals_kernel(unsigned
     }
 }
 
+// (round 6: eight values a thread — 2048 a work-group, two 16-byte loads each when the arrays are 16-byte aligned — instead of one: an
+// index build over a 4096 x 4096 raster runs ~30 scans of up to 16.7 M values, and at 256 values a work-group each was 65 k work-groups
+// twice over plus a 65 k-entry single-block scan of their totals: 147 us a scan, 4.4 ms of a 34 ms build)
+constexpr int SCAN_PER = 8, SCAN_BLOCK = 256 * SCAN_PER;
+__device__ __forceinline__ void scan_load8(const int32_t* __restrict__ in, int64_t n, int64_t i0, bool vec, int32_t (&v)[SCAN_PER]) {
+    if (vec && i0 + SCAN_PER <= n) {
+        const int4 a = *reinterpret_cast<const int4*>(in + i0), b = *reinterpret_cast<const int4*>(in + i0 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; ++k) v[k] = i0 + k < n ? in[i0 + k] : 0;
+    }
+}
 static __global__ __launch_bounds__(256) void scan_i32_partial_kernel(const int32_t* __restrict__ in, int64_t n,
-                                                               unsigned long long* __restrict__ block_tot) {
+                                                               unsigned long long* __restrict__ block_tot, int vec) {
     __shared__ unsigned long long lds[5];
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    unsigned long long v = i < n ? (unsigned long long)in[i] : 0ull, tot;
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * SCAN_PER;
+    int32_t x[SCAN_PER];
+    scan_load8(in, n, i0, vec != 0, x);
+    unsigned long long v = 0, tot;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) v += (unsigned long long)x[k];
     (void)dev::block_exclusive_scan<unsigned long long, 256>(v, lds, &tot);
     if (threadIdx.x == 0) block_tot[blockIdx.x] = tot;
 }
 static __global__ __launch_bounds__(256) void scan_i32_final_kernel(const int32_t* __restrict__ in, int64_t n,
                                                              const unsigned long long* __restrict__ block_off,
-                                                             int32_t* __restrict__ out, int32_t* __restrict__ out2) {
+                                                             int32_t* __restrict__ out, int32_t* __restrict__ out2, int vec) {
     __shared__ unsigned long long lds[5];
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    unsigned long long v = i < n ? (unsigned long long)in[i] : 0ull, tot;
-    const unsigned long long ex = dev::block_exclusive_scan<unsigned long long, 256>(v, lds, &tot);
-    const unsigned long long o = block_off[blockIdx.x] + ex;
-    if (i < n) {
-        out[i] = (int32_t)o;
-        if (out2) out2[i] = (int32_t)o;
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * SCAN_PER;
+    int32_t x[SCAN_PER];
+    scan_load8(in, n, i0, vec != 0, x);
+    unsigned long long v = 0, tot;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) v += (unsigned long long)x[k];
+    unsigned long long o = block_off[blockIdx.x] + dev::block_exclusive_scan<unsigned long long, 256>(v, lds, &tot);
+    int32_t y[SCAN_PER];
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) {
+        y[k] = (int32_t)o;
+        o += (unsigned long long)x[k];
     }
-    if (i == n - 1) {
-        out[n] = (int32_t)(o + v);
+    // (in-place scans: every value of this thread was read above, and no other thread reads them)
+    if (vec && i0 + SCAN_PER <= n) {
+        *reinterpret_cast<int4*>(out + i0) = make_int4(y[0], y[1], y[2], y[3]);
+        *reinterpret_cast<int4*>(out + i0 + 4) = make_int4(y[4], y[5], y[6], y[7]);
+        if (out2) {
+            *reinterpret_cast<int4*>(out2 + i0) = make_int4(y[0], y[1], y[2], y[3]);
+            *reinterpret_cast<int4*>(out2 + i0 + 4) = make_int4(y[4], y[5], y[6], y[7]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < SCAN_PER; ++k)
+            if (i0 + k < n) {
+                out[i0 + k] = y[k];
+                if (out2) out2[i0 + k] = y[k];
+            }
     }
+    if (i0 <= n - 1 && n - 1 < i0 + SCAN_PER) out[n] = (int32_t)o;  // (o = the prefix past this thread's last value: the values past n are 0)
 }
 
 
 // Exclusive scan of n int32 counts into out[0..n] (out[n] = total); out2 (optional) receives a second
-// copy of out[0..n-1] (fill cursors).  block_tot needs (n+255)/256 + 1 entries; the grand total is
-// left in block_tot[(n+255)/256].
+// copy of out[0..n-1] (fill cursors).  block_tot needs (n+255)/256 + 1 entries (callers size it so; (n + 2047) / 2048 + 1 are used);
+// the grand total is left in block_tot[(n+255)/256] — the place callers read it from — as well.
 static inline int32_t exclusive_scan_i32(const int32_t* in, int64_t n, int32_t* out, int32_t* out2,
                                          unsigned long long* block_tot, hipStream_t s) {
-    const int64_t nb = (n + 255) / 256;
     if (n <= 0) return GPK_OK;
-    GPK_LAUNCH("gpk_scan_partial", scan_i32_partial_kernel, dim3((unsigned)nb), dim3(256), 0, s, in, n, block_tot);
-    GPK_LAUNCH("gpk_scan_totals", scan_block_totals_kernel, dim3(1), dim3(1024), 0, s, block_tot, nb, block_tot + nb,
+    const int64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK, nb_old = (n + 255) / 256;
+    const int vec = ((uintptr_t)in % 16 == 0 && (uintptr_t)out % 16 == 0 && (!out2 || (uintptr_t)out2 % 16 == 0)) ? 1 : 0;
+    GPK_LAUNCH("gpk_scan_partial", scan_i32_partial_kernel, dim3((unsigned)nb), dim3(256), 0, s, in, n, block_tot, vec);
+    GPK_LAUNCH("gpk_scan_totals", scan_block_totals_kernel, dim3(1), dim3(1024), 0, s, block_tot, nb, block_tot + nb_old,
                (unsigned long long*)nullptr);
-    GPK_LAUNCH("gpk_scan_final", scan_i32_final_kernel, dim3((unsigned)nb), dim3(256), 0, s, in, n, block_tot, out, out2);
+    GPK_LAUNCH("gpk_scan_final", scan_i32_final_kernel, dim3((unsigned)nb), dim3(256), 0, s, in, n, block_tot, out, out2, vec);
     return GPK_OK;
 }
 

@@ -18,7 +18,7 @@ for rep in range(3):
 lib.gpk_profile_reset(); lib.gpk_profile_filter(b""); lib.gpk_profile_enable(1)
 t0 = time.perf_counter(); ix = SpatialIndex.from_device(d, stream=stream); torch.cuda.synchronize(); wall = (time.perf_counter() - t0) * 1e3
 lib.gpk_profile_enable(0)
-names = ["gpk_seq_bbox","gpk_bounds_combine","gpk_stats_to_bbox","gpk_index_extent","gpk_index_count","gpk_index_fill","gpk_index_sort","gpk_scan","gpk_one_ring_each","gpk_seq_classify","gpk_seq_long"] + ["gpk_pipidx_" + x for x in ("part_geom","ring_part","ring_rows","slab_count","slab_fill","part_info","mark_count","mark_fill","unique_flags","unique_compact","cell_count","cell_fill","sub_flag","sub_build","sub2_build","sub_commit","lrec_count","lrec_assign","lrec_build")]
+names = ["gpk_seq_bbox","gpk_bounds_combine","gpk_stats_to_bbox","gpk_index_extent","gpk_index_count","gpk_index_fill","gpk_index_sort","gpk_scan","gpk_one_ring_each","gpk_seq_classify","gpk_seq_long"] + ["gpk_pipidx_" + x for x in ("part_geom","ring_part","ring_rows","slab_count","slab_fill","part_info","mark_count","mark_fill","unique_flags","unique_compact","cell_count","cell_fill","sub_flag","sub_head","sub_work","sub_build","sub_build_fast","sub_build_rest","sub2_build","sub_commit","lrec_count","lrec_assign","lrec_build")]
 tot = 0
 for nm in names:
     ms, cnt = C.c_double(0), C.c_int64(0); lib.gpk_profile_query(nm.encode(), C.byref(ms), C.byref(cnt))
