@@ -95,6 +95,47 @@ def squares(cx, cy, half):
 
 # ---- point x polygon -------------------------------------------------------------------------------------------------
 @regime
+def random_disjoint_right_sides_against_adversarial_point_mixes():
+    """the one-launch point join (gpk_pipflow.hip) on forty random draws: disjoint star polygons of random count / vertex count / scale
+    (lean right sides with chains and an LDS routing image), point columns mixing uniform points, points packed along edges, points ON
+    vertices and edge midpoints, NaN rows, duplicates — lengths round the tile-size thresholds, a random left_row_base"""
+    rng = np.random.default_rng(606)
+    total = 0
+    for it in range(40):
+        n_polys = int(rng.choice([1, 3, 17, 120, 900, 2500]))
+        n_verts = int(rng.choice([3, 4, 7, 24, 64, 200]))
+        polys = synth.star_polygons(n_polys, n_verts, seed=1000 + it, domain=float(rng.choice([1.0, 1000.0, 3.0e6])))
+        v = polys.xy
+        n_uni = int(rng.choice([0, 1, 63, 64, 65, 4097, 70_000, 300_000]))
+        lo, hi = v.min(axis=0), v.max(axis=0)
+        parts = [rng.uniform(lo - 0.05 * (hi - lo), hi + 0.05 * (hi - lo), (n_uni, 2))]
+        k = int(rng.integers(0, 4000))
+        if k:
+            i = rng.integers(0, len(v) - 1, k)
+            t = rng.uniform(0, 1, (k, 1))
+            along = v[i] * (1 - t) + v[i + 1] * t  # (pairs that straddle two rings are just more points)
+            parts += [along + rng.normal(0, 1e-7 * float(hi[0] - lo[0] + 1e-30), (k, 2)), v[i], (v[i] + v[i + 1]) / 2.0]
+        xy = np.concatenate(parts)
+        if len(xy):
+            xy[rng.integers(0, len(xy), max(1, len(xy) // 500))] = np.nan
+            dup = rng.integers(0, len(xy), len(xy) // 50)
+            xy = np.concatenate([xy, xy[dup]])
+            rng.shuffle(xy)
+        pts = GeoArrowArray.from_points(xy)
+        exp_pairs, exp_counts, _ = oracle.spatial_join(pts, polys, "intersects", mode=1)
+        total += len(exp_pairs)
+        if DRY:
+            continue
+        base = int(rng.choice([0, 5, 1 << 20]))
+        got_pairs, got_counts = join_pairs(GeoSeries(pts), GeoSeries(polys), "intersects", left_row_base=base)
+        e = exp_pairs.copy()
+        e[:, 0] += base
+        assert np.array_equal(got_counts, exp_counts), (it, n_polys, n_verts, len(xy))
+        assert np.array_equal(got_pairs, e), (it, n_polys, n_verts, len(xy))
+    return total
+
+
+@regime
 def many_tiny_polygons_few_points():
     rng = np.random.default_rng(1)
     c = rng.uniform(0, 1000, (300_000, 2))
