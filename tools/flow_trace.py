@@ -49,6 +49,16 @@ for rep in range(2):
         if len(col):
             v = us(col)
             print(f"  {names[i]:18s} n {len(col):5d}  min {v.min():6.1f}  p10 {np.percentile(v, 10):6.1f}  median {np.median(v):6.1f}  p90 {np.percentile(v, 90):6.1f}  max {v.max():6.1f}")
+    if not phases and len(a) >= 1024:  # where the late work-groups sit: barrier time by XCD (blockIdx % 8: the dispatcher deals work-groups round the XCDs)
+        full = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 16).astype(np.int64)[: 256 * 4].reshape(256, 4, 16)
+        bar = (full[:, :, 10].max(axis=1) - t0) / 100.0
+        done = (full[:, :, 9].max(axis=1) - t0) / 100.0
+        ent = (full[:, :, 0].min(axis=1) - t0) / 100.0
+        print("  work-group barrier by XCD (blockIdx % 8): " + "  ".join(f"{x}: {np.median(bar[x::8]):.1f} / {bar[x::8].max():.1f}" for x in range(8)))
+        print("  work-group entry by XCD:                  " + "  ".join(f"{x}: {np.median(ent[x::8]):.1f}" for x in range(8)))
+        order = np.argsort(bar)
+        print("  the 12 latest work-groups (blockIdx: barrier us): " + ", ".join(f"{int(b)}: {bar[b]:.1f}" for b in order[-12:]))
+        print("  barrier by blockIdx quartile: " + "  ".join(f"{np.median(bar[q * 64:(q + 1) * 64]):.1f}" for q in range(4)))
     if phases:
         for i, nm in enumerate(["list walked", "points arrived", "routed + records arrived", "ranked + stored", "drawn", "final flush"]):
             v = a[:, 3 + i] / 100.0
