@@ -25,6 +25,7 @@ ARCH = "gfx950"
 SOURCES = [
     "gpk_runtime.hip",
     "gpk_unary.hip",
+    "gpk_ringstream.hip",
     "gpk_join.hip",
     "gpk_pipflow.hip",
     "gpk_pipindex.hip",

@@ -61,6 +61,10 @@ struct gpk_seq_classes {
     int32_t* chunk_begin;
     int64_t n_chunks;
     bool one_to_one;  // sequence s is exactly geometry s (LINESTRING column; POLYGON column of single-ring polygons)
+    // polygonal columns: the strip table of the one-pass reductions (gpk_ringstream.hip): first ring / first geometry of every strip of
+    // RS_STRIP coordinates (one allocation, ring entries then geometry entries); strips_ok: the column is eligible for that form
+    int32_t* strip_first;
+    bool strips_ok;
 };
 struct gpk_geoarray {
     gpk::DevGeo d;

@@ -1,0 +1,27 @@
+// gpk_ringstream.h — the one-pass form of area / signed_area / euclidean_length / bounds over polygonal columns (gpk_ringstream.hip)
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "gpk_common.h"
+
+namespace gpk {
+
+enum : int { RS_AREA = 0, RS_SIGNED_AREA = 1, RS_LENGTH = 2, RS_BOUNDS = 3 };
+constexpr int RS_BLOCK = 512;                    // coordinates a wave works on at a time: 8 consecutive ones a lane
+constexpr int RS_BLOCKS = 2;                     // blocks of a strip
+constexpr int RS_STRIP = RS_BLOCK * RS_BLOCKS;   // coordinates of a strip: one wave's job
+constexpr int RS_CAP = RS_STRIP / 4;             // rings that may begin in one strip (rings of 4 coordinates — triangles — are at the cap)
+constexpr int RS_WAVES = 4;                      // waves of a work-group (they share nothing but the launch)
+
+int64_t ring_stream_strips(int64_t n_coords);
+// fills ring_first / geom_first (ring_stream_strips() + 1 entries each) and ORs into *flags_dev what makes the column ineligible
+// (0 afterwards: eligible)
+int32_t ring_stream_build_table(const DevGeo& a, int32_t* ring_first, int32_t* geom_first, int32_t* flags_dev, hipStream_t s);
+// ring_vals: rs values per ring (4 doubles for RS_BOUNDS, 1 otherwise); strip_part: twice that per strip
+int32_t ring_stream_launch(int op, const DevGeo& a, const int32_t* ring_first, const int32_t* geom_first, double* ring_vals, double* strip_part, double* out,
+                           hipStream_t s);
+
+}  // namespace gpk

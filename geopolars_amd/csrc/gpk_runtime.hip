@@ -580,6 +580,7 @@ int32_t gpk_geoarray_free(gpk_geoarray* a) {
     if (a->classes) {
         if (a->classes->lists) (void)hipFree(a->classes->lists);
         if (a->classes->chunk_begin) (void)hipFree(a->classes->chunk_begin);
+        if (a->classes->strip_first) (void)hipFree(a->classes->strip_first);
         delete a->classes;
     }
     delete a;

@@ -16,6 +16,7 @@
 
 #include "gpk_device.h"
 #include "gpk_index.h"
+#include "gpk_ringstream.h"
 #include "gpk_scan.h"
 
 namespace gpk {
@@ -1046,6 +1047,7 @@ static int32_t seq_classes_of(const gpk_geoarray* a, hipStream_t s, const gpk_se
     auto bail = [&](int32_t rc) {
         if (c->lists) (void)hipFree(c->lists);
         if (c->chunk_begin) (void)hipFree(c->chunk_begin);
+        if (c->strip_first) (void)hipFree(c->strip_first);
         delete c;
         return rc;
     };
@@ -1118,6 +1120,26 @@ static int32_t seq_classes_of(const gpk_geoarray* a, hipStream_t s, const gpk_se
             if (chunks) (void)hipFree(chunks);
             if (btot) (void)hipFree(btot);
         }
+        static const bool stream_on = [] {
+            const char* e = getenv("GPK_RING_STREAM");  // A/B runs and the tests of the two-stage form: 0 keeps every column on it
+            return !(e && e[0] == '0');
+        }();
+        if (rc == GPK_OK && stream_on && is_polygonal(a->d.type) && a->d.n_coords < (int64_t)0x7FFFFFFF - RS_STRIP) {
+            // the strip table of the one-pass form (gpk_ringstream.hip) and whether the column is eligible for it
+            auto run4 = [&]() -> int32_t {
+                const int64_t n_strips = ring_stream_strips(a->d.n_coords);
+                GPK_HIP(device_malloc((void**)&c->strip_first, sizeof(int32_t) * (size_t)(2 * (n_strips + 1) + 1)));
+                int32_t* flags = c->strip_first + 2 * (n_strips + 1);
+                GPK_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t), s));
+                GPK_TRY(ring_stream_build_table(a->d, c->strip_first, c->strip_first + n_strips + 1, flags, s));
+                int32_t h_flags = -1;
+                GPK_HIP(hipMemcpyAsync(&h_flags, flags, sizeof h_flags, hipMemcpyDeviceToHost, s));
+                GPK_HIP(hipStreamSynchronize(s));
+                c->strips_ok = h_flags == 0;
+                return GPK_OK;
+            };
+            rc = run4();
+        }
         if (rc != GPK_OK) return bail(rc);
     }
     const_cast<gpk_geoarray*>(a)->classes = c;
@@ -1178,6 +1200,8 @@ struct UnaryCtx {
     void* out2_dev = nullptr;
     int64_t n_seq = 0;
     int32_t* flag = nullptr;  // one device word for the operator (centroid: "some ring has zero area")
+    const gpk_seq_classes* classes = nullptr;
+    double* strip_part = nullptr;  // the one-pass form's sums across strip boundaries (gpk_ringstream.hip), when the column is eligible
 };
 static int32_t unary_begin(const gpk_geoarray* a, size_t out_bytes, size_t out2_bytes, void* out,
                            void* out2, int32_t out_space, UnaryCtx* c) {
@@ -1193,10 +1217,14 @@ static int32_t unary_begin(const gpk_geoarray* a, size_t out_bytes, size_t out2_
         const gpk_seq_classes* cl;
         GPK_TRY(seq_classes_of(a, (hipStream_t) nullptr, &cl));
         part_bytes = sizeof(double) * 12 * (size_t)cl->n_chunks;
+        c->classes = cl;
     }
-    GPK_TRY(workspace().begin(align256(stats_bytes) + align256(part_bytes) + (stage ? align256(out_bytes) + align256(out2_bytes) : 0) + 1024));
+    const size_t strip_bytes = c->classes && c->classes->strips_ok ? sizeof(double) * 8 * (size_t)ring_stream_strips(a->d.n_coords) : 0;
+    GPK_TRY(workspace().begin(align256(stats_bytes) + align256(part_bytes) + align256(strip_bytes) +
+                              (stage ? align256(out_bytes) + align256(out2_bytes) : 0) + 1024));
     c->stats = (double*)workspace().take(stats_bytes ? stats_bytes : 8);
     c->long_part = part_bytes ? (double*)workspace().take(part_bytes) : nullptr;
+    c->strip_part = strip_bytes ? (double*)workspace().take(strip_bytes) : nullptr;
     c->out_dev = stage ? workspace().take(out_bytes ? out_bytes : 8) : out;
     c->out2_dev = out2 ? (stage ? workspace().take(out2_bytes ? out2_bytes : 8) : out2) : nullptr;
     c->flag = (int32_t*)workspace().take(64);
@@ -1235,6 +1263,24 @@ using namespace gpk;
 
 extern "C" {
 
+// polygonal columns eligible for the one-pass form (gpk_ringstream.hip): the whole operator in one streaming launch + the strip-boundary fix
+static bool ring_stream_ok(const gpk_geoarray* a, const UnaryCtx& c) {
+    return is_polygonal(a->d.type) && c.classes && c.classes->strips_ok && c.strip_part;
+}
+// bounds (four running values a coordinate, four LDS updates a flush) is measured slower in the one-pass form on every test column
+// (2M x 64: 0.73 against 0.44 ms; power-law: 0.23 against 0.19): it stays on the two-stage form unless GPK_RING_STREAM_BOUNDS=1 (A/B runs)
+static bool ring_stream_bounds_on() {
+    static const bool on = [] {
+        const char* e = getenv("GPK_RING_STREAM_BOUNDS");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+static int32_t ring_stream_run(int op, const gpk_geoarray* a, const UnaryCtx& c, hipStream_t s) {
+    const int64_t n_strips = ring_stream_strips(a->d.n_coords);
+    return ring_stream_launch(op, a->d, c.classes->strip_first, c.classes->strip_first + n_strips + 1, c.stats, c.strip_part, (double*)c.out_dev, s);
+}
+
 static int32_t area_impl(const gpk_geoarray* a, double* out, int32_t out_space, void* stream, bool is_signed) {
     UnaryCtx c;
     hipStream_t s = (hipStream_t)stream;
@@ -1244,6 +1290,8 @@ static int32_t area_impl(const gpk_geoarray* a, double* out, int32_t out_space, 
     if (n == 0) return GPK_OK;
     if (a->d.type == GPK_GEOM_POINT) {
         GPK_LAUNCH("gpk_point_unary", point_unary_kernel, grid_for(n), dim3(256), 0, s, a->d, 0, (double*)c.out_dev, (uint8_t*)nullptr);
+    } else if (ring_stream_ok(a, c)) {
+        GPK_TRY(ring_stream_run(is_signed ? RS_SIGNED_AREA : RS_AREA, a, c, s));
     } else {
         const gpk_seq_classes* cl = nullptr;
         if (is_polygonal(a->d.type)) GPK_TRY(seq_classes_of(a, s, &cl));
@@ -1280,6 +1328,8 @@ int32_t gpk_euclidean_length(const gpk_geoarray* a, double* out, int32_t out_spa
     if (n == 0) return GPK_OK;
     if (a->d.type == GPK_GEOM_POINT) {
         GPK_LAUNCH("gpk_point_unary", point_unary_kernel, grid_for(n), dim3(256), 0, s, a->d, 0, (double*)c.out_dev, (uint8_t*)nullptr);
+    } else if (ring_stream_ok(a, c)) {
+        GPK_TRY(ring_stream_run(RS_LENGTH, a, c, s));
     } else {
         const gpk_seq_classes* cl = nullptr;
         if (a->d.type != GPK_GEOM_MULTIPOINT) GPK_TRY(seq_classes_of(a, s, &cl));
@@ -1302,6 +1352,8 @@ int32_t gpk_bounds(const gpk_geoarray* a, double* out4, int32_t out_space, void*
     if (n == 0) return GPK_OK;
     if (a->d.type == GPK_GEOM_POINT) {
         GPK_LAUNCH("gpk_point_unary", point_unary_kernel, grid_for(n), dim3(256), 0, s, a->d, 2, (double*)c.out_dev, (uint8_t*)nullptr);
+    } else if (ring_stream_ok(a, c) && ring_stream_bounds_on()) {
+        GPK_TRY(ring_stream_run(RS_BOUNDS, a, c, s));
     } else {
         const gpk_seq_classes* cl;
         GPK_TRY(seq_classes_of(a, s, &cl));

@@ -45,7 +45,7 @@ def timed_impl(lib, fn, reps=10):
     out = {}
     # per-kernel breakdown
     # per-kernel breakdown: ms per call of the operator (a name may cover several launches)
-    for name in (b"gpk_ring_area", b"gpk_seq_bbox", b"gpk_ring_centroid", b"gpk_seq_long_combine", b"gpk_area_combine", b"gpk_bounds_combine", b"gpk_centroid_combine", b"gpk_affine", b"gpk_distance", b"gpk_length_combine", b"gpk_seq_length", b"gpk_hull", b"gpk_wkb"):
+    for name in (b"gpk_ring_area", b"gpk_seq_bbox", b"gpk_ring_centroid", b"gpk_seq_long_combine", b"gpk_area_combine", b"gpk_bounds_combine", b"gpk_centroid_combine", b"gpk_affine", b"gpk_distance", b"gpk_length_combine", b"gpk_seq_length", b"gpk_hull", b"gpk_wkb", b"gpk_ring_stream_area", b"gpk_ring_stream_length", b"gpk_ring_stream_bounds", b"gpk_ring_stream_fix"):
         m, c = C.c_double(0), C.c_int64(0)
         lib.gpk_profile_query(name, C.byref(m), C.byref(c))
         if c.value:
