@@ -64,6 +64,7 @@ struct gpk_seq_classes {
     // polygonal columns: the strip table of the one-pass reductions (gpk_ringstream.hip): first ring / first geometry of every strip of
     // RS_STRIP coordinates (one allocation, ring entries then geometry entries); strips_ok: the column is eligible for that form
     int32_t* strip_first;
+    void *strip_cross, *strip_desc;  // the ring records of the geometries that cross strip boundaries
     bool strips_ok;
 };
 struct gpk_geoarray {

@@ -20,8 +20,10 @@ int64_t ring_stream_strips(int64_t n_coords);
 // fills ring_first / geom_first (ring_stream_strips() + 1 entries each) and ORs into *flags_dev what makes the column ineligible
 // (0 afterwards: eligible)
 int32_t ring_stream_build_table(const DevGeo& a, int32_t* ring_first, int32_t* geom_first, int32_t* flags_dev, hipStream_t s);
+// the ring records of the geometries that cross strip boundaries (two device allocations the caller keeps with the handle and hipFree's)
+int32_t ring_stream_build_cross(const DevGeo& a, const int32_t* ring_first, const int32_t* geom_first, hipStream_t s, void** cross_out, void** desc_out);
 // ring_vals: rs values per ring (4 doubles for RS_BOUNDS, 1 otherwise); strip_part: twice that per strip
-int32_t ring_stream_launch(int op, const DevGeo& a, const int32_t* ring_first, const int32_t* geom_first, double* ring_vals, double* strip_part, double* out,
-                           hipStream_t s);
+int32_t ring_stream_launch(int op, const DevGeo& a, const int32_t* ring_first, const int32_t* geom_first, const void* cross, const void* desc, double* ring_vals,
+                           double* strip_part, double* out, hipStream_t s);
 
 }  // namespace gpk

@@ -28,6 +28,7 @@
 // any strip (rings of 4 coordinates — triangles — are exactly at the cap).  Everything else takes the two-stage form.
 #include "gpk_device.h"
 #include "gpk_ringstream.h"
+#include "gpk_scan.h"
 
 namespace gpk {
 
@@ -373,43 +374,137 @@ __global__ __launch_bounds__(64 * RS_WAVES) void ring_stream_kernel(DevGeo a, co
     }
 }
 
-// one thread per strip: the geometry that began in the strip and did not end in it
+// the geometry that began in the strip and did not end in it (false: none)
+__device__ __forceinline__ bool rs_crossing_geometry(const DevGeo& a, const int32_t* __restrict__ ring_first, const int32_t* __restrict__ geom_first,
+                                                     int64_t strip, int64_t& g, int& r_begin, int& r_end) {
+    g = (int64_t)geom_first[strip + 1] - 1;
+    if (g < (int64_t)geom_first[strip]) return false;  // no geometry begins in this strip
+    rs_geom_rings(a, g, r_begin, r_end);
+    const int64_t strip_end = (strip + 1) * RS_STRIP < a.n_coords ? (strip + 1) * RS_STRIP : a.n_coords;
+    const int s_next = ring_first[strip + 1];
+    const int s_end = (int64_t)a.ring_off[s_next] == strip_end ? s_next : s_next - 1;
+    return r_end > s_end;  // (else it ended here: the strip's wave writes its row)
+}
+// What the second launch needs of such a geometry is laid down ONCE per column (gpk_seq_classes): per strip a header {geometry, where its
+// ring records begin, how many}, per ring a record {ring, its first and past-the-end coordinate, "first ring of its polygon"}.  Found from
+// the offsets, that is a chain of eight dependent reads (strip table -> geometry offsets -> part offsets -> ring offsets -> values): 25 us
+// for a launch that moves a few hundred KB.  From the records it is three: header -> ring records -> ring values.
+struct RsCross {
+    int32_t g, desc_off, n_desc, pad;
+};
+struct RsDesc {
+    int32_t r, c0, c1, part_first;
+};
+__global__ void ring_cross_count_kernel(DevGeo a, const int32_t* __restrict__ ring_first, const int32_t* __restrict__ geom_first, int64_t n_strips,
+                                        int32_t* __restrict__ counts) {
+    const int64_t strip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (strip >= n_strips) return;
+    int64_t g;
+    int r_begin, r_end;
+    counts[strip] = rs_crossing_geometry(a, ring_first, geom_first, strip, g, r_begin, r_end) ? r_end - r_begin : 0;
+}
+__global__ void ring_cross_fill_kernel(DevGeo a, const int32_t* __restrict__ ring_first, const int32_t* __restrict__ geom_first, int64_t n_strips,
+                                       const int32_t* __restrict__ desc_off, RsCross* __restrict__ cross, RsDesc* __restrict__ desc) {
+    const int64_t strip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (strip >= n_strips) return;
+    int64_t g;
+    int r_begin, r_end;
+    if (!rs_crossing_geometry(a, ring_first, geom_first, strip, g, r_begin, r_end)) {
+        cross[strip] = RsCross{-1, 0, 0, 0};
+        return;
+    }
+    cross[strip] = RsCross{(int32_t)g, desc_off[strip], r_end - r_begin, 0};
+    RsDesc* d = desc + desc_off[strip];
+    int p0, p1;
+    dev::geom_parts(a, g, p0, p1);
+    for (int p = p0; p < p1; ++p) {
+        int r0, r1;
+        dev::part_rings(a, p, r0, r1);
+        for (int r = r0; r < r1; ++r) *d++ = RsDesc{r, a.ring_off[r], a.ring_off[r + 1], r == r0 ? 1 : 0};
+    }
+}
+
+// one thread per strip: the geometry that began in the strip and did not end in it, folded from its ring records with the rules of rs_geometry
 template <int OP>
-__global__ __launch_bounds__(256) void ring_stream_fix_kernel(DevGeo a, const int32_t* __restrict__ ring_first, const int32_t* __restrict__ geom_first,
-                                                              int64_t n_strips, const double* __restrict__ ring_vals, const double* __restrict__ strip_part,
+__global__ __launch_bounds__(256) void ring_stream_fix_kernel(DevGeo a, const RsCross* __restrict__ cross, const RsDesc* __restrict__ desc, int64_t n_strips,
+                                                              const double* __restrict__ ring_vals, const double* __restrict__ strip_part,
                                                               double* __restrict__ out) {
     constexpr int K = rs_k<OP>();
     const int64_t strip = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (strip >= n_strips) return;
-    const int64_t g = (int64_t)geom_first[strip + 1] - 1;
-    if (g < (int64_t)geom_first[strip]) return;  // no geometry begins in this strip
-    int r_begin, r_end;
-    rs_geom_rings(a, g, r_begin, r_end);
-    const int64_t n_coords = a.n_coords;
-    const int64_t strip_end = (strip + 1) * RS_STRIP < n_coords ? (strip + 1) * RS_STRIP : n_coords;
-    const int s_next = ring_first[strip + 1];
-    const int s_end = (int64_t)a.ring_off[s_next] == strip_end ? s_next : s_next - 1;
-    if (r_end <= s_end) return;  // it ended here: the strip's wave wrote its row
-    auto val = [&](int r) {
-        const int c0 = a.ring_off[r], c1 = a.ring_off[r + 1];
-        const int64_t sa = c0 / RS_STRIP, sb = (c1 - 1) / RS_STRIP;
+    const int4 hv = reinterpret_cast<const int4*>(cross)[strip];
+    const int64_t g = hv.x;
+    if (g < 0) return;
+    const bool valid = dev::valid_row(a.validity, g);
+    auto val = [&](const int4 d) {  // (r, c0, c1, part_first)
+        const int64_t sa = d.y / RS_STRIP, sb = (d.z - 1) / RS_STRIP;
         RsVal<OP> v;
         if (sa == sb) {  // complete in one strip: that strip's wave left its value
 #pragma unroll
-            for (int k = 0; k < K; ++k) v.v[k] = ring_vals[(int64_t)r * K + k];
+            for (int k = 0; k < K; ++k) v.v[k] = ring_vals[(int64_t)d.x * K + k];
             return v;
         }
+        const double2 first = a.xy[d.y], last = a.xy[d.z - 1];  // (requested before the sums: one more round trip otherwise)
 #pragma unroll
         for (int k = 0; k < K; ++k) v.v[k] = strip_part[(sa * 2 + 1) * K + k];
-        for (int64_t t = sa + 1; t <= sb; ++t) {
-            RsVal<OP> p;
+        for (int64_t t = sa + 1; t <= sb; t += 8) {  // (a ring of 100 000 coordinates: a hundred strips — eight reads in flight, folded in strip order)
+            RsVal<OP> p[8];
 #pragma unroll
-            for (int k = 0; k < K; ++k) p.v[k] = strip_part[(t * 2) * K + k];
-            v = rs_combine<OP>(v, p);
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int k = 0; k < K; ++k) p[u].v[k] = t + u <= sb ? strip_part[((t + u) * 2) * K + k] : rs_identity<OP>().v[k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (t + u <= sb) v = rs_combine<OP>(v, p[u]);
         }
-        return rs_ring_value<OP>(v, a.xy[c0], a.xy[c1 - 1]);
+        return rs_ring_value<OP>(v, first, last);
     };
-    rs_geometry<OP>(a, g, val, out);
+    const int4* dd = reinterpret_cast<const int4*>(desc) + hv.y;
+    if constexpr (OP == RS_BOUNDS) {
+        RsVal<OP> b = rs_identity<OP>();
+        bool have = false;
+        if (valid)
+            for (int i = 0; i < hv.z; ++i) {
+                const int4 d = dd[i];
+                if (!d.w) continue;  // Polygon::bounding_rect scans the exterior only
+                have = true;
+                const RsVal<OP> e = val(d);
+                b.v[0] = fmin(b.v[0], e.v[0]);
+                b.v[1] = fmin(b.v[1], e.v[1]);
+                b.v[2] = fmax(b.v[2], e.v[2]);
+                b.v[3] = fmax(b.v[3], e.v[3]);
+            }
+        reinterpret_cast<double4*>(out)[g] = have ? make_double4(b.v[0], b.v[1], b.v[2], b.v[3]) : make_double4(NAN, NAN, NAN, NAN);
+    } else {
+        if (!valid) {
+            out[g] = NAN;
+            return;
+        }
+        double v = 0.0, area = 0.0;
+        bool open_part = false, neg = false;
+        auto close_part = [&]() {
+            const double sa = neg ? -area : area;
+            v += OP == RS_SIGNED_AREA ? sa : fabs(sa);
+        };
+        for (int i = 0; i < hv.z; ++i) {
+            const int4 d = dd[i];
+            if constexpr (OP == RS_LENGTH) {
+                if (d.w) v += val(d).v[0];  // exterior rings only
+            } else {
+                const double h = val(d).v[0] / 2.0;
+                if (d.w) {
+                    if (open_part) close_part();
+                    open_part = true;
+                    neg = h < 0.0;
+                    area = fabs(h);
+                } else {
+                    area -= fabs(h);
+                }
+            }
+        }
+        if (OP != RS_LENGTH && open_part) close_part();
+        out[g] = v;
+    }
 }
 
 // ---- the strip table of a column (once per handle) ----
@@ -470,24 +565,61 @@ int32_t ring_stream_build_table(const DevGeo& a, int32_t* ring_first, int32_t* g
     return GPK_OK;
 }
 
-template <int OP>
-static int32_t ring_stream_launch_op(const DevGeo& a, const int32_t* ring_first, const int32_t* geom_first, double* ring_vals, double* strip_part, double* out,
-                                     hipStream_t s, const char* name) {
+// the ring records of the strip-crossing geometries (device allocations the caller keeps with the handle)
+int32_t ring_stream_build_cross(const DevGeo& a, const int32_t* ring_first, const int32_t* geom_first, hipStream_t s, void** cross_out, void** desc_out) {
     const int64_t n_strips = ring_stream_strips(a.n_coords);
-    GPK_LAUNCH(name, ring_stream_kernel<OP>, dim3((unsigned)((n_strips + RS_WAVES - 1) / RS_WAVES)), dim3(64 * RS_WAVES), 0, s, a, ring_first, geom_first, n_strips,
-               ring_vals, strip_part, out);
-    GPK_LAUNCH("gpk_ring_stream_fix", ring_stream_fix_kernel<OP>, dim3((unsigned)((n_strips + 255) / 256)), dim3(256), 0, s, a, ring_first, geom_first, n_strips,
-               (const double*)ring_vals, (const double*)strip_part, out);
+    int32_t *counts = nullptr, *offs = nullptr;
+    unsigned long long* btot = nullptr;
+    RsCross* cross = nullptr;
+    RsDesc* desc = nullptr;
+    auto run = [&]() -> int32_t {
+        GPK_HIP(device_malloc((void**)&counts, sizeof(int32_t) * (size_t)(n_strips + 1)));
+        GPK_HIP(device_malloc((void**)&offs, sizeof(int32_t) * (size_t)(n_strips + 1)));
+        GPK_HIP(device_malloc((void**)&btot, sizeof(unsigned long long) * (size_t)((n_strips + 255) / 256 + 2)));
+        GPK_HIP(device_malloc((void**)&cross, sizeof(RsCross) * (size_t)n_strips));
+        const dim3 grid((unsigned)((n_strips + 255) / 256));
+        GPK_LAUNCH("gpk_ring_cross_count", ring_cross_count_kernel, grid, dim3(256), 0, s, a, ring_first, geom_first, n_strips, counts);
+        GPK_TRY(exclusive_scan_i32(counts, n_strips, offs, nullptr, btot, s));
+        int32_t total = 0;
+        GPK_HIP(hipMemcpyAsync(&total, offs + n_strips, sizeof total, hipMemcpyDeviceToHost, s));
+        GPK_HIP(hipStreamSynchronize(s));
+        GPK_HIP(device_malloc((void**)&desc, sizeof(RsDesc) * (size_t)(total > 0 ? total : 1)));
+        GPK_LAUNCH("gpk_ring_cross_fill", ring_cross_fill_kernel, grid, dim3(256), 0, s, a, ring_first, geom_first, n_strips, (const int32_t*)offs, cross, desc);
+        GPK_HIP(hipStreamSynchronize(s));
+        return GPK_OK;
+    };
+    const int32_t rc = run();
+    if (counts) (void)hipFree(counts);
+    if (offs) (void)hipFree(offs);
+    if (btot) (void)hipFree(btot);
+    if (rc != GPK_OK) {
+        if (cross) (void)hipFree(cross);
+        if (desc) (void)hipFree(desc);
+        return rc;
+    }
+    *cross_out = cross;
+    *desc_out = desc;
     return GPK_OK;
 }
 
-int32_t ring_stream_launch(int op, const DevGeo& a, const int32_t* ring_first, const int32_t* geom_first, double* ring_vals, double* strip_part, double* out,
-                           hipStream_t s) {
+template <int OP>
+static int32_t ring_stream_launch_op(const DevGeo& a, const int32_t* ring_first, const int32_t* geom_first, const void* cross, const void* desc,
+                                     double* ring_vals, double* strip_part, double* out, hipStream_t s, const char* name) {
+    const int64_t n_strips = ring_stream_strips(a.n_coords);
+    GPK_LAUNCH(name, ring_stream_kernel<OP>, dim3((unsigned)((n_strips + RS_WAVES - 1) / RS_WAVES)), dim3(64 * RS_WAVES), 0, s, a, ring_first, geom_first, n_strips,
+               ring_vals, strip_part, out);
+    GPK_LAUNCH("gpk_ring_stream_fix", ring_stream_fix_kernel<OP>, dim3((unsigned)((n_strips + 255) / 256)), dim3(256), 0, s, a, (const RsCross*)cross,
+               (const RsDesc*)desc, n_strips, (const double*)ring_vals, (const double*)strip_part, out);
+    return GPK_OK;
+}
+
+int32_t ring_stream_launch(int op, const DevGeo& a, const int32_t* ring_first, const int32_t* geom_first, const void* cross, const void* desc,
+                           double* ring_vals, double* strip_part, double* out, hipStream_t s) {
     switch (op) {
-    case RS_AREA: return ring_stream_launch_op<RS_AREA>(a, ring_first, geom_first, ring_vals, strip_part, out, s, "gpk_ring_stream_area");
-    case RS_SIGNED_AREA: return ring_stream_launch_op<RS_SIGNED_AREA>(a, ring_first, geom_first, ring_vals, strip_part, out, s, "gpk_ring_stream_area");
-    case RS_LENGTH: return ring_stream_launch_op<RS_LENGTH>(a, ring_first, geom_first, ring_vals, strip_part, out, s, "gpk_ring_stream_length");
-    case RS_BOUNDS: return ring_stream_launch_op<RS_BOUNDS>(a, ring_first, geom_first, ring_vals, strip_part, out, s, "gpk_ring_stream_bounds");
+    case RS_AREA: return ring_stream_launch_op<RS_AREA>(a, ring_first, geom_first, cross, desc, ring_vals, strip_part, out, s, "gpk_ring_stream_area");
+    case RS_SIGNED_AREA: return ring_stream_launch_op<RS_SIGNED_AREA>(a, ring_first, geom_first, cross, desc, ring_vals, strip_part, out, s, "gpk_ring_stream_area");
+    case RS_LENGTH: return ring_stream_launch_op<RS_LENGTH>(a, ring_first, geom_first, cross, desc, ring_vals, strip_part, out, s, "gpk_ring_stream_length");
+    case RS_BOUNDS: return ring_stream_launch_op<RS_BOUNDS>(a, ring_first, geom_first, cross, desc, ring_vals, strip_part, out, s, "gpk_ring_stream_bounds");
     default: return fail(GPK_ERR_INVALID_ARGUMENT, "ring_stream_launch: op %d", op);
     }
 }

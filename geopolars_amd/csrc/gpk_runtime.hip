@@ -581,6 +581,8 @@ int32_t gpk_geoarray_free(gpk_geoarray* a) {
         if (a->classes->lists) (void)hipFree(a->classes->lists);
         if (a->classes->chunk_begin) (void)hipFree(a->classes->chunk_begin);
         if (a->classes->strip_first) (void)hipFree(a->classes->strip_first);
+        if (a->classes->strip_cross) (void)hipFree(a->classes->strip_cross);
+        if (a->classes->strip_desc) (void)hipFree(a->classes->strip_desc);
         delete a->classes;
     }
     delete a;

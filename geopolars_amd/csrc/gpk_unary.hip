@@ -1048,6 +1048,8 @@ static int32_t seq_classes_of(const gpk_geoarray* a, hipStream_t s, const gpk_se
         if (c->lists) (void)hipFree(c->lists);
         if (c->chunk_begin) (void)hipFree(c->chunk_begin);
         if (c->strip_first) (void)hipFree(c->strip_first);
+        if (c->strip_cross) (void)hipFree(c->strip_cross);
+        if (c->strip_desc) (void)hipFree(c->strip_desc);
         delete c;
         return rc;
     };
@@ -1120,11 +1122,16 @@ static int32_t seq_classes_of(const gpk_geoarray* a, hipStream_t s, const gpk_se
             if (chunks) (void)hipFree(chunks);
             if (btot) (void)hipFree(btot);
         }
-        static const bool stream_on = [] {
-            const char* e = getenv("GPK_RING_STREAM");  // A/B runs and the tests of the two-stage form: 0 keeps every column on it
-            return !(e && e[0] == '0');
+        // Which polygonal columns take the one-pass form (gpk_ringstream.hip): those it is measured faster on — ragged columns (no single size
+        // class) and columns of rings of at most 16 coordinates; a column whose rings all sit in one of the larger classes (2M x 65 coordinates:
+        // 0.44 against 0.38 ms) keeps the two-stage form.  GPK_RING_STREAM=0: no column takes it; =1: every eligible one (tests, A/B runs).
+        static const int stream_mode = [] {
+            const char* e = getenv("GPK_RING_STREAM");
+            return e ? (e[0] == '0' ? 0 : 1) : 2;
         }();
-        if (rc == GPK_OK && stream_on && is_polygonal(a->d.type) && a->d.n_coords < (int64_t)0x7FFFFFFF - RS_STRIP) {
+        const bool uniform_large = (c->count[1] == n_seq || c->count[2] == n_seq || c->count[3] == n_seq) && n_seq > 0;
+        if (rc == GPK_OK && stream_mode != 0 && !(stream_mode == 2 && uniform_large) && is_polygonal(a->d.type) &&
+            a->d.n_coords < (int64_t)0x7FFFFFFF - RS_STRIP) {
             // the strip table of the one-pass form (gpk_ringstream.hip) and whether the column is eligible for it
             auto run4 = [&]() -> int32_t {
                 const int64_t n_strips = ring_stream_strips(a->d.n_coords);
@@ -1136,6 +1143,7 @@ static int32_t seq_classes_of(const gpk_geoarray* a, hipStream_t s, const gpk_se
                 GPK_HIP(hipMemcpyAsync(&h_flags, flags, sizeof h_flags, hipMemcpyDeviceToHost, s));
                 GPK_HIP(hipStreamSynchronize(s));
                 c->strips_ok = h_flags == 0;
+                if (c->strips_ok) GPK_TRY(ring_stream_build_cross(a->d, c->strip_first, c->strip_first + n_strips + 1, s, &c->strip_cross, &c->strip_desc));
                 return GPK_OK;
             };
             rc = run4();
@@ -1278,7 +1286,8 @@ static bool ring_stream_bounds_on() {
 }
 static int32_t ring_stream_run(int op, const gpk_geoarray* a, const UnaryCtx& c, hipStream_t s) {
     const int64_t n_strips = ring_stream_strips(a->d.n_coords);
-    return ring_stream_launch(op, a->d, c.classes->strip_first, c.classes->strip_first + n_strips + 1, c.stats, c.strip_part, (double*)c.out_dev, s);
+    return ring_stream_launch(op, a->d, c.classes->strip_first, c.classes->strip_first + n_strips + 1, c.classes->strip_cross, c.classes->strip_desc, c.stats,
+                              c.strip_part, (double*)c.out_dev, s);
 }
 
 static int32_t area_impl(const gpk_geoarray* a, double* out, int32_t out_space, void* stream, bool is_signed) {

@@ -1,0 +1,105 @@
+"""The one-pass form of area / signed_area / euclidean_length (csrc/gpk_ringstream.hip: strips of 1024 coordinates a wave, ring values
+in an LDS table, geometries folded at the end of the strip, strip-crossing geometries from per-column ring records) against the oracle
+and against the two-stage form of csrc/gpk_unary.hip, on columns built to stress what is new in it:
+
+  * rings and geometries cut by strip boundaries at every offset (ring lengths coprime to 1024, a sweep of leading paddings);
+  * rings longer than a strip, than many strips (partial sums of whole strips), geometries of many rings across several strips;
+  * rings that begin and end inside one lane's 8 coordinates (triangles), the cap of rings per strip, columns that are NOT eligible
+    (a zero-length ring) and must take the two-stage form;
+  * open rings (area 0 by area.rs), collinear rings (area exactly 0), null rows, empty polygons, multipolygons with holes;
+  * bit-reproducibility run to run (the sums' order is fixed by the column's layout).
+
+GPK_RING_STREAM (read once per process) selects the form: each form runs in its own interpreter.  Tolerance: 1e-9 relative (north
+star), exact where the oracle's value is exactly 0."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+_PROG = r"""
+import numpy as np, sys, os
+sys.path.insert(0, os.getcwd())
+from geopolars_amd import synth
+from geopolars_amd.geoarrow import GeoArrowArray
+from geopolars_amd.geoseries import GeoSeries
+from oracle import pyoracle as oracle
+oracle.build(); oracle.lib()
+
+def ring(n, r, cx, cy, phase=0.0, cw=False):
+    t = phase + 2 * np.pi * np.arange(n) / n
+    if cw: t = -t
+    rr = r * (1.0 + 0.3 * np.sin(5 * t))
+    return [(cx + rr[i] * np.cos(t[i]), cy + rr[i] * np.sin(t[i])) for i in range(n)]
+
+def check(name, a, exact_zero_rows=()):
+    s = GeoSeries(a)
+    for op, got, exp in (("area", s.area(), oracle.area(a)), ("signed_area", s.signed_area(), oracle.area(a, signed=True)),
+                         ("length", s.euclidean_length(), oracle.euclidean_length(a))):
+        got, exp = np.asarray(got), np.asarray(exp)
+        assert got.shape == exp.shape, (name, op)
+        assert np.array_equal(np.isnan(got), np.isnan(exp)), (name, op, "null rows")
+        m = ~np.isnan(exp)
+        bad = np.abs(got[m] - exp[m]) > 1e-9 * np.maximum(np.abs(exp[m]), 1e-300)
+        assert not bad.any(), (name, op, np.nonzero(bad)[0][:5], got[m][bad][:5], exp[m][bad][:5])
+        again = np.asarray(getattr(s, op if op != "length" else "euclidean_length")())
+        assert np.array_equal(again, got, equal_nan=True), (name, op, "not reproducible")
+    assert np.array_equal(s.bounds(), oracle.bounds(a), equal_nan=True), (name, "bounds")
+
+rng = np.random.default_rng(7)
+cases = {}
+# 1. every alignment of rings against strips: ring lengths coprime to 1024, a few hundred rings each
+for n in (3, 4, 7, 9, 63, 65, 127, 511, 1023, 1025, 2049, 5000):
+    k = max(3, 20000 // n)
+    cases["rings_%d" % n] = GeoArrowArray.from_polygons([[ring(n, 5.0 + (i % 7), 30.0 * i, 11.0)] for i in range(k)])
+# 2. a sweep of paddings: the same polygons after 0 .. 9 leading triangles (every phase of a boundary within a lane)
+body = [[ring(37, 4.0, 10.0 * i, 3.0)] for i in range(300)]
+for pad in range(10):
+    cases["pad_%d" % pad] = GeoArrowArray.from_polygons([[ring(3, 1.0, -5.0 * j, -9.0)] for j in range(pad)] + body)
+# 3. giants: rings of many strips, with holes that are giants too, between small neighbours
+cases["giants"] = GeoArrowArray.from_polygons(
+    [[ring(11, 2.0, 0, 0)], [ring(100001, 500.0, 2000.0, 0.0), ring(30011, 100.0, 2000.0, 0.0, 0.3, cw=True)], [ring(5, 1.0, 9, 9)],
+     [ring(3000, 40.0, -900.0, 0.0), ring(1500, 10.0, -900.0, 0.0, cw=True), ring(700, 5.0, -880.0, 5.0, cw=True)], [ring(8, 1.0, 1, 1)]])
+# 4. multipolygons: power-law ring sizes (the benchmark's shape), and geometries of MANY rings across several strips
+cases["powerlaw"] = synth.powerlaw_multipolygons(20000)
+mp = []
+for g in range(40):
+    parts = []
+    for p in range(1 + (g * 7) % 23):
+        rings_ = [ring(4 + (g + p) % 90, 3.0, 50.0 * g + 8.0 * p, 0.0)]
+        for h in range((g + p) % 4):
+            rings_.append(ring(3 + (h + p) % 40, 0.5, 50.0 * g + 8.0 * p, 0.0, cw=True))
+        parts.append(rings_)
+    mp.append(parts)
+cases["many_rings"] = GeoArrowArray.from_multipolygons(mp)
+# 5. degenerate rings: open (area 0), collinear (area exactly 0), repeated points, two-coordinate rings; empty polygons; nulls
+line = [(float(i), 3.0 * i) for i in range(2600)]
+r9 = ring(9, 2.0, 5, 5)
+deg = [[[(0, 0), (4, 0), (4, 4), (0, 4.5)]], [line + line[-2::-1]], [[(1, 1), (1, 1), (1, 1), (1, 1)]], [], [r9 + r9[:1]], [[(0, 0), (1, 1), (0, 0)]], [[(2, 2), (3, 3)]]]
+a = GeoArrowArray.from_polygons(deg * 30, close=False)  # (the first ring stays open: area 0 by area.rs)
+cases["degenerate"] = a
+v = np.ones(a.n_geoms, dtype=bool)
+v[::5] = False
+cases["nulls"] = GeoArrowArray(a.geom_type, a.xy, geom_offsets=a.geom_offsets, ring_offsets=a.ring_offsets, validity=v)
+for name, arr in cases.items():
+    check(name, arr)
+# 6. a column that is not eligible (a zero-length ring): the two-stage form answers, whatever GPK_RING_STREAM says
+ro = np.array([0, 4, 4, 9], dtype=np.int32)
+xy = np.array([(0, 0), (2, 0), (2, 2), (0, 0), (5, 5), (7, 5), (7, 7), (5, 7), (5, 5)], dtype=np.float64)
+check("zero_length_ring", GeoArrowArray(cases["giants"].geom_type, xy, geom_offsets=np.array([0, 2, 3], dtype=np.int32), ring_offsets=ro))
+print("RINGSTREAM_OK", len(cases) + 1)
+"""
+
+
+@pytest.mark.parametrize("mode", ["1", "0", None])
+def test_one_pass_and_two_stage_forms_agree_with_the_oracle(mode):
+    """mode 1: every eligible column through the one-pass form; 0: none; None: the product's choice by column shape"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("GPK_RING_STREAM", None)
+    if mode is not None:
+        env["GPK_RING_STREAM"] = mode
+    r = subprocess.run([sys.executable, "-c", _PROG], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0 and "RINGSTREAM_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
