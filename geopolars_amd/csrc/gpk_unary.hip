@@ -656,9 +656,12 @@ __global__ void bounds_combine_kernel(DevGeo a, const double* __restrict__ stats
             for (int p = p0; p < p1; ++p) {
                 int r0, r1;
                 dev::part_rings(a, p, r0, r1);
-                if (r1 <= r0 || a.ring_off[r0 + 1] == a.ring_off[r0]) continue;
-                have = true;
+                if (r1 <= r0) continue;
                 const double4 b = bbox_records(stats, n_seq)[r0];
+                // (an empty exterior ring has no box: its record is the reductions' identity — as is that of a ring of NaN coordinates, which
+                // does count; only such a record sends the thread to the ring's offsets, two more dependent reads a polygon otherwise)
+                if (!(b.x <= b.z) && a.ring_off[r0 + 1] == a.ring_off[r0]) continue;
+                have = true;
                 mnx = fmin(mnx, b.x);
                 mny = fmin(mny, b.y);
                 mxx = fmax(mxx, b.z);
@@ -669,9 +672,9 @@ __global__ void bounds_combine_kernel(DevGeo a, const double* __restrict__ stats
             geom_seq_range(a, g, s0, s1);
             const int32_t* so = a.type == GPK_GEOM_MULTILINESTRING ? a.ring_off : a.geom_off;
             for (int s = s0; s < s1; ++s) {
-                if (so[s + 1] == so[s]) continue;
-                have = true;
                 const double4 b = bbox_records(stats, n_seq)[s];
+                if (!(b.x <= b.z) && so[s + 1] == so[s]) continue;
+                have = true;
                 mnx = fmin(mnx, b.x);
                 mny = fmin(mny, b.y);
                 mxx = fmax(mxx, b.z);
