@@ -138,7 +138,16 @@ class Ctx:
             if self.rank == 0:
                 print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}: the line reports n_gpus = {self.world}", file=sys.stderr)
         if not torch.cuda.is_available():
-            print("bench.py: no GPU visible — libgeopolars_hip has no CPU fallback", file=sys.stderr)
+            print("bench.py: no GPU visible — libgeopolars_hip has no CPU fallback", file=sys.stderr, flush=True)
+            if self.world > 1:
+                # (the launcher ends the other ranks when the first one exits: every rank says why before that — each leaves a marker and
+                # waits, up to 30 s, until all have)
+                d = _marker_dir()
+                os.makedirs(d, exist_ok=True)
+                open(os.path.join(d, f"nogpu.{self.rank}"), "w").close()
+                t0 = time.time()
+                while time.time() - t0 < 30.0 and sum(1 for f in os.listdir(d) if f.startswith("nogpu.")) < self.world:
+                    time.sleep(0.05)
             sys.exit(3)
         torch.cuda.set_device(self.local_rank)
         self.dev = torch.device("cuda", self.local_rank)

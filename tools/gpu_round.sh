@@ -15,6 +15,8 @@ for c in c3 c4 c5; do
   bash tools/prof_stats.sh ${TAG}_$c python $R/bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --parity-rows 20000
 done
 bash tools/prof_stats.sh ${TAG}_ops python $R/tools/bench_ops.py; grep -h '"op"' $O/${TAG}_ops.log > $O/${TAG}_ops.jsonl
+# (round 6) the reductions the one-pass form took over, with every column kept on the two-stage form: the same box, back to back
+GPK_RING_STREAM=0 timeout 300 python tools/bench_ops.py --ops area,euclidean_length 2>/dev/null | grep -h '"op"' > $O/${TAG}_ops_twostage.jsonl
 python tools/bench_reference_benches.py > $O/${TAG}_reference_benches.jsonl 2>/dev/null
 # round 6: the headline kernel over column lengths (a shard of the strong-scaled problem) and its launch timeline (a GPK_TILE_TRACE build)
 for n in 10000000 5000000 2500000 1250000 625000; do timeout 100 python tools/tile_time.py --points $n --tag "rows $n" 2>&1 | tail -1; done > $O/${TAG}_sizes.txt 2>&1; cat $O/${TAG}_sizes.txt
