@@ -459,40 +459,49 @@ __global__ __launch_bounds__(256) void ring_stream_fix_kernel(DevGeo a, const Rs
         }
         return rs_ring_value<OP>(v, first, last);
     };
+    // The ring records eight at a time: the records, then the eight rings' values (as if each were complete in one strip: an address that is
+    // always valid), are each ONE round trip for the batch; only a ring that crosses a strip boundary (one or two a geometry) then takes its
+    // own.  Record by record the fold of a multipolygon of six rings was twelve dependent round trips.
     const int4* dd = reinterpret_cast<const int4*>(desc) + hv.y;
-    if constexpr (OP == RS_BOUNDS) {
-        RsVal<OP> b = rs_identity<OP>();
-        bool have = false;
-        if (valid)
-            for (int i = 0; i < hv.z; ++i) {
-                const int4 d = dd[i];
-                if (!d.w) continue;  // Polygon::bounding_rect scans the exterior only
+    RsVal<OP> b = rs_identity<OP>();
+    bool have = false;
+    double v = 0.0, area = 0.0;
+    bool open_part = false, neg = false;
+    auto close_part = [&]() {
+        const double sa = neg ? -area : area;
+        v += OP == RS_SIGNED_AREA ? sa : fabs(sa);
+    };
+    if (OP != RS_BOUNDS && !valid) {
+        out[g] = NAN;
+        return;
+    }
+    const int n_desc = (OP == RS_BOUNDS && !valid) ? 0 : hv.z;
+    for (int i0 = 0; i0 < n_desc; i0 += 8) {
+        int4 d[8];
+        RsVal<OP> rv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) d[u] = dd[i0 + u < n_desc ? i0 + u : n_desc - 1];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int k = 0; k < K; ++k) rv[u].v[k] = ring_vals[(int64_t)d[u].x * K + k];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + u >= n_desc) break;
+            const bool crossing = d[u].y / RS_STRIP != (d[u].z - 1) / RS_STRIP;
+            if constexpr (OP == RS_BOUNDS) {
+                if (!d[u].w) continue;  // Polygon::bounding_rect scans the exterior only
                 have = true;
-                const RsVal<OP> e = val(d);
+                const RsVal<OP> e = crossing ? val(d[u]) : rv[u];
                 b.v[0] = fmin(b.v[0], e.v[0]);
                 b.v[1] = fmin(b.v[1], e.v[1]);
                 b.v[2] = fmax(b.v[2], e.v[2]);
                 b.v[3] = fmax(b.v[3], e.v[3]);
-            }
-        reinterpret_cast<double4*>(out)[g] = have ? make_double4(b.v[0], b.v[1], b.v[2], b.v[3]) : make_double4(NAN, NAN, NAN, NAN);
-    } else {
-        if (!valid) {
-            out[g] = NAN;
-            return;
-        }
-        double v = 0.0, area = 0.0;
-        bool open_part = false, neg = false;
-        auto close_part = [&]() {
-            const double sa = neg ? -area : area;
-            v += OP == RS_SIGNED_AREA ? sa : fabs(sa);
-        };
-        for (int i = 0; i < hv.z; ++i) {
-            const int4 d = dd[i];
-            if constexpr (OP == RS_LENGTH) {
-                if (d.w) v += val(d).v[0];  // exterior rings only
+            } else if constexpr (OP == RS_LENGTH) {
+                if (d[u].w) v += (crossing ? val(d[u]) : rv[u]).v[0];  // exterior rings only
             } else {
-                const double h = val(d).v[0] / 2.0;
-                if (d.w) {
+                const double h = (crossing ? val(d[u]) : rv[u]).v[0] / 2.0;
+                if (d[u].w) {
                     if (open_part) close_part();
                     open_part = true;
                     neg = h < 0.0;
@@ -502,6 +511,10 @@ __global__ __launch_bounds__(256) void ring_stream_fix_kernel(DevGeo a, const Rs
                 }
             }
         }
+    }
+    if constexpr (OP == RS_BOUNDS) {
+        reinterpret_cast<double4*>(out)[g] = have ? make_double4(b.v[0], b.v[1], b.v[2], b.v[3]) : make_double4(NAN, NAN, NAN, NAN);
+    } else {
         if (OP != RS_LENGTH && open_part) close_part();
         out[g] = v;
     }
