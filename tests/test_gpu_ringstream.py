@@ -7,6 +7,8 @@ and against the two-stage form of csrc/gpk_unary.hip, on columns built to stress
   * rings that begin and end inside one lane's 8 coordinates (triangles), the cap of rings per strip, columns that are NOT eligible
     (a zero-length ring) and must take the two-stage form;
   * open rings (area 0 by area.rs), collinear rings (area exactly 0), null rows, empty polygons, multipolygons with holes;
+  * 24 seeded random columns (ring lengths log-uniform in 3 .. 5000, 1 in 20 left open, 1 - 4 polygons a geometry with up to 3 holes,
+    empty geometries, null rows; POLYGON and MULTIPOLYGON);
   * bit-reproducibility run to run (the sums' order is fixed by the column's layout).
 
 GPK_RING_STREAM (read once per process) selects the form: each form runs in its own interpreter.  Tolerance: 1e-9 relative (north
@@ -82,7 +84,32 @@ a = GeoArrowArray.from_polygons(deg * 30, close=False)  # (the first ring stays 
 cases["degenerate"] = a
 v = np.ones(a.n_geoms, dtype=bool)
 v[::5] = False
-cases["nulls"] = GeoArrowArray(a.geom_type, a.xy, geom_offsets=a.geom_offsets, ring_offsets=a.ring_offsets, validity=v)
+cases["nulls"] = GeoArrowArray(a.geom_type, a.xy, geom_offsets=a.geom_offsets, ring_offsets=a.ring_offsets, validity=np.packbits(v, bitorder="little"))
+# 7. seeded random columns: ring lengths log-uniform in 3 .. 5000 (closed or, 1 in 20, left open), 1 - 4 polygons a geometry with 0 - 3 holes,
+#    empty geometries, nulls; POLYGON and MULTIPOLYGON
+for seed in range(24):
+    r_ = np.random.default_rng(1000 + seed)
+    n_geoms = int(r_.integers(5, 400))
+    big = seed % 3 == 0
+    geoms = []
+    for g in range(n_geoms):
+        parts = []
+        for p in range(0 if r_.random() < 0.05 else int(r_.integers(1, 5))):
+            rings_ = []
+            for h in range(int(r_.integers(1, 5))):
+                n = int(np.exp(r_.uniform(np.log(3), np.log(5000 if big else 60))))
+                pts = ring(n, float(r_.uniform(0.5, 50.0)), float(r_.uniform(-1e4, 1e4)), float(r_.uniform(-1e4, 1e4)), cw=h > 0)
+                rings_.append(pts + ([] if r_.random() < 0.05 else pts[:1]))
+            parts.append(rings_)
+        geoms.append(parts)
+    if seed % 2 == 0:
+        arr = GeoArrowArray.from_multipolygons(geoms, close=False)
+    else:
+        arr = GeoArrowArray.from_polygons([pp[0] if pp else [] for pp in geoms], close=False)
+    if seed % 4 == 1:
+        vv = np.packbits(r_.random(arr.n_geoms) > 0.2, bitorder="little")
+        arr = GeoArrowArray(arr.geom_type, arr.xy, geom_offsets=arr.geom_offsets, part_offsets=arr.part_offsets, ring_offsets=arr.ring_offsets, validity=vv)
+    cases["random_%d" % seed] = arr
 for name, arr in cases.items():
     check(name, arr)
 # 6. a column that is not eligible (a zero-length ring): the two-stage form answers, whatever GPK_RING_STREAM says
