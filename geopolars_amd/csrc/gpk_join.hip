@@ -2283,6 +2283,7 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         hot.inv_fw = pv.inv_fw;
         hot.inv_fh = pv.inv_fh;
         hot.cell = pv.cell;
+        hot.cell16 = getenv("GPK_NO_CELL16") ? nullptr : pv.cell16;
         hot.half = reinterpret_cast<const HalfCell*>(pv.sub);  // (an index with chains keeps its one-part records in half-cell form)
         hot.sub_aux = pv.sub_aux;
         hot.chain_head = pv.chain_head;
