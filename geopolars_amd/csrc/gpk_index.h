@@ -139,8 +139,6 @@ struct PipView {
     const double2* chain_ext;        // vertices 4 .. of the chains longer than three edges
     const double2* chain_xy;         // GPK_HALF_CHAINS: extended ring coordinates the half-cell chains index (then sub_aux / chain_head / chain_ext are null)
     const RouteWord* route;          // LDS image of the level-1 routing (chains + R <= PIP_ROUTE_RMAX); else nullptr
-    const uint16_t* cell16;          // (with `route`) the level-1 words in 16 bits: 0 = empty, part + 1 = strictly inside that part, 0xFFFF = read `cell`
-                                     // — half the bytes of the table the interior third of the points reads (pip_tile_flow_kernel)
     const SubCell* lrec;             // level-2 records of the BOUNDARY entries of list cells: when set, such an entry is
                                      // `record index << 1 | 1` (the record names the part), else `part << 1 | 1`
     const uint32_t* part_geom;       // nullptr for POLYGON arrays (part == geometry)

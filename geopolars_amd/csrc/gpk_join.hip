@@ -2283,9 +2283,6 @@ static int32_t pip_join_enqueue(const gpk_geoarray* left, const gpk_geoarray* ri
         hot.inv_fw = pv.inv_fw;
         hot.inv_fh = pv.inv_fh;
         hot.cell = pv.cell;
-        // (the 16-bit level-1 words pay when the launch runs long enough for the L2s' contents to matter — 10 M rows: 91.2 against 93.2 us — and
-        // cost a short launch 1.2 - 1.5 us — 1.25 M rows: 25.4 against 24.2, 5 M: 53.4 against 51.8; one box, three alternating runs each)
-        hot.cell16 = (getenv("GPK_NO_CELL16") || n < 8000000) ? nullptr : pv.cell16;
         hot.half = reinterpret_cast<const HalfCell*>(pv.sub);  // (an index with chains keeps its one-part records in half-cell form)
         hot.sub_aux = pv.sub_aux;
         hot.chain_head = pv.chain_head;

@@ -358,15 +358,7 @@ __device__ __forceinline__ void flow_tile(const ChainHot& h, const uint2* s_mask
             const uint32_t w = r0s[k] + (uint32_t)__popc(__builtin_amdgcn_ubfe(ms[k].x, 0u, bit));
             rec[k] = *reinterpret_cast<const u32x4*>(h.half + (2u * w + ((sy >> 2) & 1u)));
         }
-        if (want) {
-            const uint32_t ci = ((sy >> 3) << logR) + (sx >> 3);
-            if (h.cell16) {  // (wave-uniform) 0 / part + 1 / 0xFFFF: read the full word (list cells, whatever a lean index should not hold)
-                const uint32_t v = h.cell16[ci];
-                gw[k] = v == 0xFFFFu ? h.cell[ci] : (v ? 0x40000000u | ((v - 1u) << 1) : 0u);
-            } else {
-                gw[k] = h.cell[ci];
-            }
-        }
+        if (want) gw[k] = h.cell[((sy >> 3) << logR) + (sx >> 3)];
     });
     GPK_SCHED_FENCE();
 #else

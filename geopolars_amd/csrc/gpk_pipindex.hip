@@ -1093,17 +1093,6 @@ __global__ void route_build_kernel(const uint32_t* __restrict__ cell, int64_t n_
     route[w] = rw;
 }
 
-// the level-1 words in 16 bits (PipView::cell16)
-__global__ void cell16_kernel(const uint32_t* __restrict__ cell, int64_t n_cells, uint16_t* __restrict__ cell16) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_cells) return;
-    const uint32_t g = cell[i];
-    uint32_t v = 0xFFFFu;
-    if (g == 0u) v = 0u;
-    if ((g & 0xC0000001u) == 0x40000000u && ((g >> 1) & 0x1FFFFFFFu) < 0xFFFEu) v = ((g >> 1) & 0x1FFFFFFFu) + 1u;  // CELL_TAG_SINGLE, strictly inside
-    cell16[i] = (uint16_t)v;
-}
-
 // RouteWord::pad = the 16-bit rank of rec0 among its raster row's records (rec0 - the rec0 of the row's first word that has records): the
 // persistent point-join kernels keep 16-bit ranks + one base per row in LDS, and with the rank in the word their image load is one
 // pass of independent 16-byte reads (the row's base = rec0 - pad of any of its words with records).  One thread per raster row.
@@ -1618,12 +1607,6 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
             if (R >= 32) GPK_LAUNCH("gpk_pipidx_route_rank", route_rank_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, s, route, R);
             pv.route = route;
             ix->nbytes += (int64_t)(sizeof(RouteWord) * (size_t)n_words);
-            uint16_t* cell16 = nullptr;
-            GPK_HIP(cached_malloc((void**)&cell16, sizeof(uint16_t) * (size_t)n_cells));
-            keep(cell16);
-            GPK_LAUNCH("gpk_pipidx_cell16", cell16_kernel, blocks_for(n_cells), dim3(256), 0, s, (const uint32_t*)cell, n_cells, cell16);
-            pv.cell16 = cell16;
-            ix->nbytes += (int64_t)(sizeof(uint16_t) * (size_t)n_cells);
         }
         GPK_HIP(hipStreamSynchronize(s));  // (the temporaries go back to the arena when this function returns)
         if (getenv("GPK_DEBUG_INDEX")) fprintf(stderr, "[gpk] half-cell chains: %d records, %lld extended coordinates%s\n", n_sub, (long long)n_ext, pv.route ? ", routing image" : "");

@@ -54,7 +54,6 @@ struct ChainHot {
     int32_t n_full_tiles, pad;     // pip_tile_fused_kernel: tiles 0 .. n_full_tiles - 1 need no guards (whole tiles of a column without a validity bitmap)
     double inv_fw_s, inv_fh_s, sub_max;  // pip_tile_fused_kernel: inv_fw * PIP_SUB, inv_fh * PIP_SUB (exact: a power of two), (PIP_SUB << logR) - 1
     uint32_t* pool;                // pip_tile_flow_kernel: one 4-byte hit slot per left row (a tile's hits at the start of its 512 slots)
-    const uint16_t* cell16;        // pip_tile_flow_kernel: PipView::cell16 (the level-1 words in 16 bits), or nullptr
 };
 // the arguments of the rare arm, in device memory: loaded where they are used — as kernel arguments they would be held in scalar
 // registers across the hot loop (and spilled)
