@@ -10,8 +10,15 @@
 namespace gpk {
 
 enum : int { RS_AREA = 0, RS_SIGNED_AREA = 1, RS_LENGTH = 2, RS_BOUNDS = 3 };
-constexpr int RS_BLOCK = 512;                    // coordinates a wave works on at a time: 8 consecutive ones a lane
-constexpr int RS_BLOCKS = 2;                     // blocks of a strip
+#ifndef GPK_RS_CPL
+#define GPK_RS_CPL 4
+#endif
+// consecutive coordinates a lane takes of a block.  4: 102 / 85 registers (area / length) and 30 KB of LDS a work-group — 16 / 20 waves a CU —
+// against 156 / 135 and 46 KB — 12 waves — at 8; 19 % more instructions a coordinate and 4 - 9 % less time (the launch is bound by the
+// dependent round trips at a strip's ends: more waves hide more of them); 2: as 4 for length, slower for area
+constexpr int RS_CPL = GPK_RS_CPL;
+constexpr int RS_BLOCK = 64 * RS_CPL;             // coordinates a wave works on at a time
+constexpr int RS_BLOCKS = 1024 / RS_BLOCK;        // blocks of a strip
 constexpr int RS_STRIP = RS_BLOCK * RS_BLOCKS;   // coordinates of a strip: one wave's job
 constexpr int RS_CAP = RS_STRIP / 4;             // rings that may begin in one strip (rings of 4 coordinates — triangles — are at the cap)
 constexpr int RS_WAVES = 4;                      // waves of a work-group (they share nothing but the launch)

@@ -7,10 +7,10 @@
 // handful of coordinates, a few of 100 000) the groups read short, scattered runs, the classes interleave in memory, and the second
 // launch re-reads a table the first one wrote: 0.34 - 0.41 of 8 TB/s where a column of equal rings reaches 0.66.  Here the unit of work
 // is a STRIP of RS_STRIP consecutive coordinates, whatever rings they belong to:
-//   * a wave takes one strip; a lane takes 8 CONSECUTIVE coordinates of a 512-coordinate block (loaded coalesced, 16 bytes a lane and
+//   * a wave takes one strip; a lane takes RS_CPL = 4 CONSECUTIVE coordinates of a 256-coordinate block (loaded coalesced, 16 bytes a lane and
 //     1 KB a wave per instruction, the next block requested before this one is worked on, and turned through a padded LDS buffer);
 //   * where rings begin is a bit mask of the strip built from the ring offsets (the column's strip table — first ring / first geometry
-//     of every strip, built once per handle — says which offsets); a lane walks its 8 coordinates with the mask's 9 bits in a register:
+//     of every strip, built once per handle — says which offsets); a lane walks its coordinates with the mask's bits for them (+ the next lane's first) in a register:
 //     rings that begin and end inside the lane are finished there, the ring that crosses lanes is finished by a SEGMENTED SCAN over
 //     the lanes' open partial sums, the ring that crosses blocks rides in wave-uniform registers;
 //   * ring values land in an LDS table indexed by the ring's number within the strip; at the end of the strip a lane per GEOMETRY that
@@ -168,8 +168,10 @@ __device__ __forceinline__ double rs_lane_value(double v, int src_lane) {  // (s
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane), __builtin_amdgcn_readlane(__double2loint(v), src_lane));
 }
 
-constexpr int RS_XY_SLOTS = RS_BLOCK + RS_BLOCK / 8 + 2;  // coordinate k of a block sits at slot k + k / 8: a lane's 9 reads are 144 bytes apart (no bank
-                                                          // conflicts); slot 9 l + 8 — between lane l's coordinates and lane l + 1's — is lane l's scratch
+constexpr int CPL = RS_CPL;  // consecutive coordinates a lane takes of a block
+constexpr uint32_t CMASK = (1u << CPL) - 1u;
+constexpr int RS_XY_SLOTS = RS_BLOCK + RS_BLOCK / CPL + 2;  // coordinate k of a block sits at slot k + k / CPL: a lane's CPL + 1 reads are 16 (CPL + 1) bytes apart (no bank
+                                                          // conflicts for CPL = 4 or 8); slot (CPL + 1) l + CPL — between lane l's coordinates and lane l + 1's — is lane l's scratch
 constexpr int RS_MASK_WORDS = RS_STRIP / 32 + 2;
 constexpr int RS_OPEN_WORDS = (RS_CAP + 2 + 31) / 32;
 
@@ -215,11 +217,11 @@ __global__ __launch_bounds__(64 * RS_WAVES) void ring_stream_kernel(DevGeo a, co
     const int g_lo = rs_uniform(geom_first[strip]), g_hi = rs_uniform(geom_first[strip + 1]);    // geometries [g_lo, g_hi) begin in it
 
     // the block's coordinates, requested a block ahead: coordinate r * 64 + lane in round r (1 KB a wave per instruction)
-    double2 pre[8], pre_x = make_double2(0.0, 0.0);
+    double2 pre[CPL], pre_x = make_double2(0.0, 0.0);
     auto request = [&](int b) {
         const int64_t b0 = base + (int64_t)b * RS_BLOCK;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
+        for (int r = 0; r < CPL; ++r) {
             const int64_t i = b0 + r * 64 + lane;
             pre[r] = i < n_coords ? xy[i] : make_double2(0.0, 0.0);
         }
@@ -257,24 +259,24 @@ __global__ __launch_bounds__(64 * RS_WAVES) void ring_stream_kernel(DevGeo a, co
         const int64_t b0 = base + (int64_t)b * RS_BLOCK;
         if (b0 >= n_coords) break;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
+        for (int r = 0; r < CPL; ++r) {
             const int k = r * 64 + lane;
-            s_xy[k + (k >> 3)] = pre[r];
+            s_xy[k + k / CPL] = pre[r];
         }
-        if (lane == 0) s_xy[RS_BLOCK + RS_BLOCK / 8] = pre_x;
+        if (lane == 0) s_xy[RS_BLOCK + RS_BLOCK / CPL] = pre_x;
         if (b + 1 < RS_BLOCKS) request(b + 1);
         rs_wave_fence();
-        const int pos0 = b * RS_BLOCK + 8 * lane;  // my first coordinate within the strip
+        const int pos0 = b * RS_BLOCK + CPL * lane;  // my first coordinate within the strip
         const uint32_t m_lo = s_mask[pos0 >> 5], m_hi = s_mask[(pos0 >> 5) + 1];
-        const uint32_t hb = (uint32_t)(((((unsigned long long)m_hi) << 32) | m_lo) >> (pos0 & 31)) & 0x1FFu;  // bit j: a ring begins at my coordinate j (j = 8: at the next lane's first)
+        const uint32_t hb = (uint32_t)(((((unsigned long long)m_hi) << 32) | m_lo) >> (pos0 & 31)) & ((2u << CPL) - 1u);  // bit j: a ring begins at my coordinate j (j = 8: at the next lane's first)
         int lid = (int)(s_wpre[pos0 >> 5] + __popc(m_lo & ((1u << (pos0 & 31)) - 1u)));  // rings begun before my first coordinate: its ring's number in the strip (0: the ring that entered the strip)
-        double2 c[9];
+        double2 c[CPL + 1];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) c[j] = s_xy[9 * lane + j];
-        c[8] = s_xy[9 * lane + 9];  // (the next lane's first coordinate; lane 63: the coordinate after the block)
-        const uint32_t heads8 = hb & 0xFFu, tails8 = (hb >> 1) & 0xFFu;
-        const int64_t left = n_coords - (b0 + 8 * lane);
-        const uint32_t live8 = left >= 8 ? 0xFFu : (left <= 0 ? 0u : (1u << (int)left) - 1u);
+        for (int j = 0; j < CPL; ++j) c[j] = s_xy[(CPL + 1) * lane + j];
+        c[CPL] = s_xy[(CPL + 1) * lane + CPL + 1];  // (the next lane's first coordinate; lane 63: the coordinate after the block)
+        const uint32_t heads8 = hb & CMASK, tails8 = (hb >> 1) & CMASK;
+        const int64_t left = n_coords - (b0 + CPL * lane);
+        const uint32_t live8 = left >= CPL ? CMASK : (left <= 0 ? 0u : (1u << (int)left) - 1u);
         const uint32_t drop8 = tails8 | ~live8;  // no edge leaves a ring's last coordinate (or the column)
         // the first coordinate of the ring my first coordinate belongs to: the last ring begun in a lane before mine, else the block's carry
         double2 first = first_carry;
@@ -284,13 +286,13 @@ __global__ __launch_bounds__(64 * RS_WAVES) void ring_stream_kernel(DevGeo a, co
             if (heads8) {
                 double2 h = c[0];
 #pragma unroll
-                for (int j = 1; j < 8; ++j)
+                for (int j = 1; j < CPL; ++j)
                     if ((heads8 >> j) & 1u) h = c[j];
-                s_xy[9 * lane + 8] = h;  // (my scratch slot)
+                s_xy[(CPL + 1) * lane + CPL] = h;  // (my scratch slot)
             }
             rs_wave_fence();
-            if (head_lanes & below) first = s_xy[9 * (63 - __clzll(head_lanes & below)) + 8];
-            if (head_lanes) first_carry = s_xy[9 * (63 - __clzll(head_lanes)) + 8];
+            if (head_lanes & below) first = s_xy[(CPL + 1) * (63 - __clzll(head_lanes & below)) + CPL];
+            if (head_lanes) first_carry = s_xy[(CPL + 1) * (63 - __clzll(head_lanes)) + CPL];
         }
         // my 8 coordinates in order.  The area terms are geo's (twice_signed_ring_area shifts every coordinate by the ring's first one): the same
         // products bit for bit, only the order of the sum differs — a ring whose terms are all exactly 0 (collinear) has area exactly 0.
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) void ring_stream_kernel(DevGeo a, co
             e = make_double2(c[0].x - first.x, c[0].y - first.y);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < CPL; ++j) {
             if ((hb >> j) & 1u) ++lid;
             const double2 ring_first_j = first;
             if constexpr (OP == RS_BOUNDS) {
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) void ring_stream_kernel(DevGeo a, co
                 acc = rs_identity<OP>();
             }
         }
-        if (!((tails8 >> 7) & 1u) && ((live8 >> 7) & 1u)) flush();  // the run still open at my last coordinate: its ring goes on in the next lane
+        if (!((tails8 >> (CPL - 1)) & 1u) && ((live8 >> (CPL - 1)) & 1u)) flush();  // the run still open at my last coordinate: its ring goes on in the next lane
         rs_wave_fence();  // (the next block overwrites s_xy)
     }
     rs_wave_fence();
