@@ -307,7 +307,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) void ring_stream_kernel(DevGeo a, co
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
             if ((hb >> j) & 1u) ++lid;
-            const double2 ring_first_j = first;
+            bool closed_j = true;  // (area: my coordinate j is its ring's first coordinate again — e, its offset from it, is exactly 0)
             if constexpr (OP == RS_BOUNDS) {
                 if ((live8 >> j) & 1u) {
                     acc.v[0] = c[j].x < acc.v[0] ? c[j].x : acc.v[0];
@@ -319,6 +319,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) void ring_stream_kernel(DevGeo a, co
                 const double l = hypot(c[j + 1].x - c[j].x, c[j + 1].y - c[j].y);
                 acc.v[0] += ((drop8 >> j) & 1u) ? 0.0 : l;
             } else {
+                closed_j = e.x == 0.0 && e.y == 0.0;
                 if ((hb >> (j + 1)) & 1u) first = c[j + 1];
                 const double2 en = make_double2(c[j + 1].x - first.x, c[j + 1].y - first.y);
                 const double cr = e.x * en.y - e.y * en.x;
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(64 * RS_WAVES) void ring_stream_kernel(DevGeo a, co
             }
             if ((tails8 >> j) & 1u) {
                 flush();
-                if (AREA && !(ring_first_j.x == c[j].x && ring_first_j.y == c[j].y)) atomicOr(&s_open[lid >> 5], 1u << (lid & 31));  // not closed: its area is 0 (area.rs)
+                if (AREA && !closed_j) atomicOr(&s_open[lid >> 5], 1u << (lid & 31));  // not closed: its area is 0 (area.rs)
                 acc = rs_identity<OP>();
             }
         }
