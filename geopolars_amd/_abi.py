@@ -122,6 +122,7 @@ _PROTOS = {
     "gpk_geoarray_from_arrow": (C.c_int32, [_VP, _VP, C.c_int32, _VP, C.POINTER(_VP), C.POINTER(C.c_int32)]),
     "gpk_geoarray_to_arrow": (C.c_int32, [_VP, C.c_int32, _VP, _VP, _VP]),
     "gpk_geoarray_free": (C.c_int32, [_VP]),
+    "gpk_geoarray_invalidate": (C.c_int32, [_VP]),
     "gpk_geoarray_nbytes": (C.c_int32, [_VP, C.POINTER(C.c_int64)]),
     "gpk_wkb_decode": (C.c_int32, [_VP, _VP, C.c_int64, _VP, C.POINTER(C.c_int64), _VP, _VP, _VP, _VP]),
     "gpk_geoarray_from_wkb": (C.c_int32, [_VP, _VP, C.c_int64, _VP, C.c_int32, _VP, C.POINTER(_VP), C.POINTER(C.c_int32)]),

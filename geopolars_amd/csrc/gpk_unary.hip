@@ -1293,6 +1293,24 @@ static int32_t ring_stream_run(int op, const gpk_geoarray* a, const UnaryCtx& c,
                               c.strip_part, (double*)c.out_dev, s);
 }
 
+// see the header: a caller that REWRITES the offsets of a handle over borrowed device buffers drops what the handle has derived from them
+int32_t gpk_geoarray_invalidate(gpk_geoarray* a) {
+    if (!a) return fail(GPK_ERR_INVALID_ARGUMENT, "NULL argument");
+    GPK_TRY(require_device());
+    GPK_HIP(hipDeviceSynchronize());  // (launches in flight may still read the tables)
+    std::lock_guard<std::mutex> lk(g_classes_mu);
+    if (a->classes) {
+        if (a->classes->lists) (void)hipFree(a->classes->lists);
+        if (a->classes->chunk_begin) (void)hipFree(a->classes->chunk_begin);
+        if (a->classes->strip_first) (void)hipFree(a->classes->strip_first);
+        if (a->classes->strip_cross) (void)hipFree(a->classes->strip_cross);
+        if (a->classes->strip_desc) (void)hipFree(a->classes->strip_desc);
+        delete a->classes;
+        a->classes = nullptr;
+    }
+    return GPK_OK;
+}
+
 static int32_t area_impl(const gpk_geoarray* a, double* out, int32_t out_space, void* stream, bool is_signed) {
     UnaryCtx c;
     hipStream_t s = (hipStream_t)stream;

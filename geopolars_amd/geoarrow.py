@@ -448,6 +448,11 @@ class DeviceGeoArray:
         _abi.check(_abi.lib().gpk_geoarray_nbytes(self.handle, C.byref(n)))
         return int(n.value)
 
+    def invalidate(self) -> None:
+        """gpk_geoarray_invalidate: the owner of BORROWED device buffers has rewritten their offsets in place — drop what the handle
+        derived from them (size classes, strip tables); coordinates may be rewritten without this"""
+        _abi.check(_abi.lib().gpk_geoarray_invalidate(self.handle))
+
     def free(self) -> None:
         if self._h:
             _abi.lib().gpk_geoarray_free(self._h)

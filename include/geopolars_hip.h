@@ -117,6 +117,13 @@ int32_t gpk_device_cache_release(void);
  * every entry point sees children indexed from 0 (one 4-byte read-back per offsets level and upload of a device view). */
 int32_t gpk_geoarray_upload(const gpk_geoarrow_desc* desc, void* stream, gpk_geoarray** out);
 int32_t gpk_geoarray_free(gpk_geoarray* a);
+/* A handle derives tables from its OFFSETS on first use and keeps them (the size classes of the streaming reductions, the strip table and
+ * ring records of their one-pass form: csrc/gpk_unary.hip, csrc/gpk_ringstream.hip) — handles are immutable (above).  A handle over
+ * BORROWED device buffers (GPK_MEM_DEVICE descriptors) is only as immutable as its owner keeps those buffers: rewriting COORDINATES in
+ * place is harmless to the tables, rewriting OFFSETS is not — call this (or make a new handle: no copy either way) before the next
+ * call on the handle.  Waits for the device.  (The index gpk_spatial_join keeps on a handle is kept only on handles that own their
+ * buffers: nothing to drop there.) */
+int32_t gpk_geoarray_invalidate(gpk_geoarray* a);
 /* HBM bytes held by the handle (owned + borrowed), for roofline accounting */
 int32_t gpk_geoarray_nbytes(const gpk_geoarray* a, int64_t* out_bytes);
 

@@ -130,3 +130,54 @@ def test_one_pass_and_two_stage_forms_agree_with_the_oracle(mode):
         env["GPK_RING_STREAM"] = mode
     r = subprocess.run([sys.executable, "-c", _PROG], capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert r.returncode == 0 and "RINGSTREAM_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_a_borrowed_view_whose_offsets_are_rewritten_is_invalidated(gpk, oracle):
+    """The strip table and the ring records of the one-pass form are derived from a handle's OFFSETS once (include/geopolars_hip.h,
+    gpk_geoarray_invalidate): a handle over borrowed device tensors answers for the new layout after its owner rewrote the offsets in
+    place and said so; rewriting coordinates needs nothing."""
+    import numpy as np
+    import torch
+
+    from geopolars_amd import synth
+    from geopolars_amd.geoarrow import DeviceGeoArray, GeoArrowArray
+
+    a = synth.powerlaw_multipolygons(3000)
+    dev = torch.device("cuda", 0)
+    xy = torch.from_numpy(np.ascontiguousarray(a.xy)).to(dev)
+    go = torch.from_numpy(a.geom_offsets).to(dev)
+    po = torch.from_numpy(a.part_offsets).to(dev)
+    ro = torch.from_numpy(a.ring_offsets).to(dev)
+    h = DeviceGeoArray.from_device_buffers(a.geom_type, xy, go, po, ro, stream=torch.cuda.current_stream().cuda_stream)
+
+    def area_of(handle, n):
+        out = torch.empty(n, dtype=torch.float64, device=dev)
+        from geopolars_amd import _abi
+
+        _abi.check(_abi.lib().gpk_area(handle.handle, out.data_ptr(), _abi.MEM_DEVICE, torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+
+    def close(got, exp):
+        m = ~np.isnan(exp)
+        assert np.array_equal(np.isnan(got), np.isnan(exp))
+        assert not (np.abs(got[m] - exp[m]) > 1e-9 * np.maximum(np.abs(exp[m]), 1e-300)).any()
+
+    close(area_of(h, a.n_geoms), oracle.area(a))
+    # coordinates rewritten in place (a translation keeps every ring closed): no invalidation needed
+    xy += 3.0
+    moved = GeoArrowArray(a.geom_type, a.xy + 3.0, geom_offsets=a.geom_offsets, part_offsets=a.part_offsets, ring_offsets=a.ring_offsets)
+    close(area_of(h, a.n_geoms), oracle.area(moved))
+    # the same coordinates cut into OTHER geometries: every polygon becomes a geometry of its own (geometry offsets 0 .. n_parts), in place
+    n_parts = len(a.part_offsets) - 1
+    assert n_parts + 1 >= a.n_geoms + 1
+    go2 = torch.arange(0, a.n_geoms + 1, dtype=torch.int32, device=dev)  # geometry g = polygon g alone; the polygons beyond a.n_geoms are dropped with their offsets
+    go.copy_(go2)
+    h.invalidate()
+    relaid = GeoArrowArray(a.geom_type, a.xy + 3.0, geom_offsets=np.arange(0, a.n_geoms + 1, dtype=np.int32), part_offsets=a.part_offsets[: a.n_geoms + 1],
+                           ring_offsets=a.ring_offsets[: a.part_offsets[a.n_geoms] + 1])
+    relaid = GeoArrowArray(relaid.geom_type, relaid.xy[: relaid.ring_offsets[-1]], geom_offsets=relaid.geom_offsets, part_offsets=relaid.part_offsets, ring_offsets=relaid.ring_offsets)
+    # (the handle still spans the old buffers: rings and coordinates beyond the last geometry are no longer any geometry's — the one-pass
+    # form's eligibility check sees offsets that do not cover the coordinates and the two-stage form answers)
+    close(area_of(h, a.n_geoms), oracle.area(relaid))
+    h.free()
