@@ -113,6 +113,12 @@ Workspace& workspace();
 // second and third per-thread arenas for calls whose scratch is sized in stages (the polygon x polygon join learns its
 // candidate count only after a first pass, and gpk_bounds inside it uses workspace() itself)
 Workspace& workspace_aux(int which);
+
+// Small read-backs (a count that sizes the next table): the copy lands in PINNED host memory — into a pageable variable this runtime stages
+// it, + 8 us a copy on top of the 11 us a stream sync costs (tools/micro/readback_probe.hip) — and reaches the caller's variable in
+// sync_small, which MUST be the sync that follows (per calling thread; at most 16 copies of at most 64 bytes between two syncs).
+hipError_t d2h_small(void* host_dst, const void* dev_src, size_t bytes, hipStream_t s);
+hipError_t sync_small(hipStream_t s);
 // one more arena per (calling thread, stream): scratch of stream-ordered calls that must survive until the stream gets there
 Workspace& workspace_for_stream(hipStream_t s);
 

@@ -2669,9 +2669,9 @@ int32_t gpk_index_build_ex(const gpk_geoarray* a, int32_t parts, const double* b
         IX_LAUNCH("gpk_index_count", grid_register_kernel<false>, grid_for(n, 256), dim3(256), 0, s, bbox, n, grid, cell_cnt, (int32_t*)nullptr);
     IX_TRY(exclusive_scan_i32(cell_cnt, n_cells, cell_off, cursor, btot, s));
     unsigned long long total = 0;
-    IX_HIP(hipMemcpyAsync(&total, btot + n_blocks, sizeof total, hipMemcpyDeviceToHost, s));
-    IX_HIP(hipMemcpyAsync(&ix->host_grid, grid, sizeof(GridParams), hipMemcpyDeviceToHost, s));
-    IX_HIP(hipStreamSynchronize(s));
+    IX_HIP(d2h_small(&total, btot + n_blocks, sizeof total, s));
+    IX_HIP(d2h_small(&ix->host_grid, grid, sizeof(GridParams), s));
+    IX_HIP(sync_small(s));
     if (total > (unsigned long long)INT32_MAX)
         return cleanup(fail(GPK_ERR_INVALID_OFFSETS, "spatial index directory overflows i32 (%llu entries)", total));
     int32_t* items = nullptr;

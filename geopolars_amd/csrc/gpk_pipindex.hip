@@ -1300,9 +1300,9 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
         GPK_LAUNCH("gpk_pipidx_ring_rows", ring_rows_kernel, blocks_for(n_rings), dim3(256), 0, s, ring_bbox, n_rings, d.ring_off, gs, max_shift,
                    row0, nrows, n_refined_dev);
         GPK_TRY(exclusive_scan_i32(nrows, n_rings, slab_base, nullptr, btot, s));
-        GPK_HIP(hipMemcpyAsync(&n_slabs, slab_base + n_rings, sizeof n_slabs, hipMemcpyDeviceToHost, s));
-        GPK_HIP(hipMemcpyAsync(&n_refined, n_refined_dev, sizeof n_refined, hipMemcpyDeviceToHost, s));
-        GPK_HIP(hipStreamSynchronize(s));
+        GPK_HIP(d2h_small(&n_slabs, slab_base + n_rings, sizeof n_slabs, s));
+        GPK_HIP(d2h_small(&n_refined, n_refined_dev, sizeof n_refined, s));
+        GPK_HIP(sync_small(s));
         if ((int64_t)n_slabs > max_scan) {  // few-vertex rings spanning many slab rows: more slabs than coordinates
             max_scan = n_slabs;
             GPK_TRY(t.alloc(&btot, (size_t)((max_scan + 255) / 256 + 4)));
@@ -1320,8 +1320,8 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
         n_edges = 0;
         if (n_slabs > 0) {
             GPK_TRY(exclusive_scan_i32(slab_cnt, n_slabs, slab_off, cursor, btot, s));
-            GPK_HIP(hipMemcpyAsync(&n_edges, slab_off + n_slabs, sizeof n_edges, hipMemcpyDeviceToHost, s));
-            GPK_HIP(hipStreamSynchronize(s));
+            GPK_HIP(d2h_small(&n_edges, slab_off + n_slabs, sizeof n_edges, s));
+            GPK_HIP(sync_small(s));
         }
         if (max_shift == 0 || (int64_t)n_edges <= 8 * d.n_coords + (1 << 20)) break;
     }
@@ -1377,8 +1377,8 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
                (unsigned long long*)nullptr);
     GPK_TRY(exclusive_scan_i32(mark_cnt, d.n_coords, mark_off, nullptr, btot, s));
     unsigned long long n_marks_raw = 0;  // the scan keeps its grand total in 64 bits
-    GPK_HIP(hipMemcpyAsync(&n_marks_raw, btot + (d.n_coords + 255) / 256, sizeof n_marks_raw, hipMemcpyDeviceToHost, s));
-    GPK_HIP(hipStreamSynchronize(s));
+    GPK_HIP(d2h_small(&n_marks_raw, btot + (d.n_coords + 255) / 256, sizeof n_marks_raw, s));
+    GPK_HIP(sync_small(s));
     if (n_marks_raw >= (1ull << 31))
         return GPK_OK;  // pathological (huge edges over a fine raster): leave the accelerator off
     stamp("mark count + scan");
@@ -1413,8 +1413,8 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
                    (int64_t)n_marks_raw, pos, marks, mark_start);
         GPK_TRY(exclusive_scan_i32(mark_start, n_cells, mark_start, nullptr, btot, s));
         int32_t nu = 0;
-        GPK_HIP(hipMemcpyAsync(&nu, pos + n_marks_raw, sizeof nu, hipMemcpyDeviceToHost, s));
-        GPK_HIP(hipStreamSynchronize(s));
+        GPK_HIP(d2h_small(&nu, pos + n_marks_raw, sizeof nu, s));
+        GPK_HIP(sync_small(s));
         n_marks = nu;
     }
 
@@ -1432,8 +1432,8 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
                need, (const int32_t*)nullptr, cell, (uint32_t*)nullptr, cell_scratch, (const double4*)ring_bbox);
     GPK_TRY(exclusive_scan_i32(need, n_cells, list_off, nullptr, btot, s));
     int32_t list_len = 0;
-    GPK_HIP(hipMemcpyAsync(&list_len, list_off + n_cells, sizeof list_len, hipMemcpyDeviceToHost, s));
-    GPK_HIP(hipStreamSynchronize(s));
+    GPK_HIP(d2h_small(&list_len, list_off + n_cells, sizeof list_len, s));
+    GPK_HIP(sync_small(s));
     if ((unsigned)list_len >= (1u << 30)) return GPK_OK;
     uint32_t* list = nullptr;
     GPK_HIP(cached_malloc((void**)&list, sizeof(uint32_t) * (size_t)(list_len ? list_len : 1)));
@@ -1464,9 +1464,9 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
         GPK_LAUNCH("gpk_pipidx_sub_flag", sub_flag_kernel, blocks_for(n_cells), dim3(256), 0, s, cell, (const uint32_t*)list, n_cells, sflag, sflag2);
         GPK_TRY(exclusive_scan_i32(sflag, n_cells, spos, nullptr, btot, s));
         GPK_TRY(exclusive_scan_i32(sflag2, n_cells, spos2, nullptr, btot, s));
-        GPK_HIP(hipMemcpyAsync(&n_sub, spos + n_cells, sizeof n_sub, hipMemcpyDeviceToHost, s));
-        GPK_HIP(hipMemcpyAsync(&n_sub2, spos2 + n_cells, sizeof n_sub2, hipMemcpyDeviceToHost, s));
-        GPK_HIP(hipStreamSynchronize(s));
+        GPK_HIP(d2h_small(&n_sub, spos + n_cells, sizeof n_sub, s));
+        GPK_HIP(d2h_small(&n_sub2, spos2 + n_cells, sizeof n_sub2, s));
+        GPK_HIP(sync_small(s));
         if ((unsigned)n_sub >= SUB2_BIT || (unsigned)n_sub2 >= SUB2_BIT) {  // would not fit the cell word: no level 2
             n_sub = n_sub2 = 0;
             sub_overflow = true;
@@ -1530,8 +1530,8 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
         GPK_LAUNCH("gpk_pipidx_lrec_count", lrec_count_kernel, blocks_for(n_cells), dim3(256), 0, s, (const uint32_t*)cell, (const uint32_t*)list, n_cells,
                    lcnt);
         GPK_TRY(exclusive_scan_i32(lcnt, n_cells, lpos, nullptr, btot, s));
-        GPK_HIP(hipMemcpyAsync(&n_lrec, lpos + n_cells, sizeof n_lrec, hipMemcpyDeviceToHost, s));
-        GPK_HIP(hipStreamSynchronize(s));
+        GPK_HIP(d2h_small(&n_lrec, lpos + n_cells, sizeof n_lrec, s));
+        GPK_HIP(sync_small(s));
         if (getenv("GPK_DEBUG_INDEX")) fprintf(stderr, "[gpk] level 2: %d boundary entries in list cells (list length %d)\n", n_lrec, list_len);
         if (n_lrec > 0 && (int64_t)n_lrec < (int64_t)1 << 28) {  // 2^28 records = 8 GB: beyond that the lists stay plain
             int32_t* work_cell;
@@ -1619,8 +1619,8 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
         GPK_LAUNCH("gpk_pipidx_chain_count", chain_count_kernel, blocks_for(n_sub), dim3(256), 0, s, (const SubCell*)sub, (int64_t)n_sub, ccnt);
         GPK_TRY(exclusive_scan_i32(ccnt, n_sub, cbase_tmp, nullptr, btot, s));
         int32_t n_aux = 0;
-        GPK_HIP(hipMemcpyAsync(&n_aux, cbase_tmp + n_sub, sizeof n_aux, hipMemcpyDeviceToHost, s));
-        GPK_HIP(hipStreamSynchronize(s));
+        GPK_HIP(d2h_small(&n_aux, cbase_tmp + n_sub, sizeof n_aux, s));
+        GPK_HIP(sync_small(s));
         if (n_aux > 0) {
             ChainAux* aux = nullptr;
             GPK_HIP(cached_malloc((void**)&aux, sizeof(ChainAux) * (size_t)n_aux));
@@ -1640,8 +1640,8 @@ int32_t build_pip_index(const gpk_geoarray* a, gpk_index* ix, hipStream_t s, int
                        (const int32_t*)cbase_tmp, aux, chead, first_at, ext_need);
             GPK_TRY(exclusive_scan_i32(ext_need, n_aux, ext_off, nullptr, btot3, s));
             int32_t n_ext = 0;
-            GPK_HIP(hipMemcpyAsync(&n_ext, ext_off + n_aux, sizeof n_ext, hipMemcpyDeviceToHost, s));
-            GPK_HIP(hipStreamSynchronize(s));
+            GPK_HIP(d2h_small(&n_ext, ext_off + n_aux, sizeof n_ext, s));
+            GPK_HIP(sync_small(s));
             double2* ext = nullptr;
             GPK_HIP(cached_malloc((void**)&ext, sizeof(double2) * (size_t)(n_ext > 0 ? n_ext : 1)));
             keep(ext);

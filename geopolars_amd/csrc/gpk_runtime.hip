@@ -216,6 +216,36 @@ Workspace& workspace_for_stream(hipStream_t s) {
     arenas.emplace_back(s, new Workspace);
     return *arenas.back().second;
 }
+namespace {
+struct SmallReadBacks {
+    unsigned char* pinned = nullptr;  // 16 slots of 64 bytes
+    struct Pending {
+        void* dst;
+        size_t bytes;
+    } pending[16];
+    int n = 0;
+};
+SmallReadBacks& small_readbacks() {
+    static thread_local SmallReadBacks r;
+    return r;
+}
+}  // namespace
+hipError_t d2h_small(void* host_dst, const void* dev_src, size_t bytes, hipStream_t s) {
+    SmallReadBacks& r = small_readbacks();
+    if (!r.pinned && hipHostMalloc((void**)&r.pinned, 16 * 64, hipHostMallocDefault) != hipSuccess) r.pinned = nullptr;
+    if (!r.pinned || bytes > 64 || r.n >= 16) return hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, s);  // (the plain way)
+    r.pending[r.n] = {host_dst, bytes};
+    return hipMemcpyAsync(r.pinned + 64 * r.n++, dev_src, bytes, hipMemcpyDeviceToHost, s);
+}
+hipError_t sync_small(hipStream_t s) {
+    SmallReadBacks& r = small_readbacks();
+    const hipError_t e = hipStreamSynchronize(s);
+    if (e == hipSuccess)
+        for (int i = 0; i < r.n; ++i) memcpy(r.pending[i].dst, r.pinned + 64 * i, r.pending[i].bytes);
+    r.n = 0;
+    return e;
+}
+
 Workspace& workspace_aux(int which) {
     static thread_local Workspace aux[2];
     return aux[which & 1];
