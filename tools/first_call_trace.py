@@ -14,13 +14,18 @@ for i in range(3):
     SpatialIndex.from_device(polys, light=True).free()
 torch.cuda.synchronize()
 sys.stderr.write("==== build\n")
-t0 = time.perf_counter()
 n = 1 if os.environ.get("GPK_DEBUG_SYNC") else 50
+tb = tf = 0.0
 for i in range(n):
+    t0 = time.perf_counter()
     idx = SpatialIndex.from_device(polys, light=True)
+    t1 = time.perf_counter()
     idx.free()
+    t2 = time.perf_counter()
+    tb += t1 - t0
+    tf += t2 - t1
 torch.cuda.synchronize()
-print("build + free: %%.3f ms" %% ((time.perf_counter() - t0) / n * 1e3))
+print("build %%.3f ms + free %%.3f ms" %% (tb / n * 1e3, tf / n * 1e3))
 ''' % root
 r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, env=dict(os.environ, GPK_DEBUG_SYNC="1"))
 names = [l.split("launch ")[1] for l in r.stderr.split("==== build")[-1].splitlines() if "launch " in l]
