@@ -19,11 +19,13 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
 }
+void drop_small_readbacks();  // (below: read-backs queued by d2h_small and never waited for — an error return in between — must not be delivered later)
 int32_t fail(int32_t code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
+    drop_small_readbacks();
     return code;
 }
 
@@ -230,6 +232,7 @@ SmallReadBacks& small_readbacks() {
     return r;
 }
 }  // namespace
+void drop_small_readbacks() { small_readbacks().n = 0; }
 hipError_t d2h_small(void* host_dst, const void* dev_src, size_t bytes, hipStream_t s) {
     SmallReadBacks& r = small_readbacks();
     if (!r.pinned && hipHostMalloc((void**)&r.pinned, 16 * 64, hipHostMallocDefault) != hipSuccess) r.pinned = nullptr;
